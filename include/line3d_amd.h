@@ -1,0 +1,148 @@
+/*
+ * line3d_amd.h -- C ABI of the MI355X-native Line3D matching / affinity hot path.
+ *
+ * Drop-in boundary: these entry points are what a Line3D build binds instead of the three
+ * functions of the reference's device seam (cudawrapper.h:49-75) -- plain pointers and sizes,
+ * no C++ containers, no torch types.  INTEGRATION.md shows the ~80-line cudawrapper
+ * replacement that forwards the reference's DataArray/std::list arguments to these calls so
+ * that line3D.cc / segments.h link unchanged.
+ *
+ * Conventions: every function returns L3D_OK (0) or an error code; l3d_last_error(ctx) gives
+ * the message (the reference prints CUDA errors and carries on, dataArray.h:153-156; here they
+ * are reported).  All matrices are row-major float32 unless stated.  Output arrays marked
+ * "callee-allocated" are released with l3d_free().  A context owns one GPU, one HIP stream and
+ * grow-only device arenas; it is single-caller like the reference (global texture references,
+ * cudawrapper.cu:5-10) but several contexts may coexist.
+ */
+#ifndef LINE3D_AMD_H
+#define LINE3D_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L3D_OK 0
+#define L3D_ERR_INVALID 1
+#define L3D_ERR_HIP 2
+#define L3D_ERR_NOMEM 3
+#define L3D_ERR_NODEVICE 4
+
+/* cudawrapper.h:35,43-46 / commons.h:42-66 */
+#define L3D_RDD_MAX_ITER 10
+#define L3D_DEF_COLLINEARITY_S 2.0f
+
+typedef struct l3d_ctx l3d_ctx;
+
+/* L3DMatchingPair, sparsematrix.h:37-65 (active_ is always true on this path and is dropped) */
+typedef struct l3d_match {
+    uint32_t segID1;   /* segment in the source view */
+    uint32_t camID2;   /* neighbour: LOCAL index on input, GLOBAL view id on output (cudawrapper.cu:1103) */
+    uint32_t segID2;   /* segment in the neighbour */
+    float depths[4];   /* src p1, src p2, tgt q1, tgt q2 (cudawrapper.cu:594-601) */
+    float confidence;
+} l3d_match;
+
+/* CLEdge, clustering.h:57-61 */
+typedef struct l3d_edge {
+    int32_t i, j;
+    float w;
+} l3d_edge;
+
+/* L3DSegment3D (commons.h:69-78) + the three per-view scalars similarity_coll3D reads
+ * (view.cc:353-377): one hypothesis handed to l3d_similarity_coll3D_batch */
+typedef struct l3d_hypothesis {
+    double P1[3], P2[3], dir[3];
+    float depth_p1, depth_p2;
+    float k_lower, k_upper, median_depth;
+    uint32_t pad;
+} l3d_hypothesis;
+
+int l3d_ctx_create(int device, l3d_ctx** ctx);
+void l3d_ctx_destroy(l3d_ctx* ctx);
+const char* l3d_last_error(const l3d_ctx* ctx);
+void l3d_free(void* p);
+
+/* Replaces compute_collinearity (cudawrapper.h:49-51, K_collinearity cudawrapper.cu:476-535)
+ * together with the host scan of the dense S x S relation in the L3DSegments constructor
+ * (segments.h:73-98): returns the non-zero upper-triangle entries (i < j, ascending (i,j)),
+ * i.e. exactly what the constructor inserts into segment2collinearities_ (both directions).
+ * segments: n_segments x 4 (p1x,p1y,p2x,p2y).  Outputs callee-allocated. */
+int l3d_compute_collinearity(l3d_ctx* ctx, const float* segments, int n_segments, float collin_s,
+                             int32_t** out_i, int32_t** out_j, float** out_w, int* out_n);
+
+/* Replaces compute_pairwise_matches (cudawrapper.h:54-70, cudawrapper.cu:858-1128):
+ * K_pairwise_matches for every neighbour in to_be_matched, selection of pairs with four
+ * positive depths, (segment, camera, target) ordering, K_verify_matches over the union with the
+ * already existing (reverse) matches, best-hypothesis median depth, and the conf > 1 filter.
+ *
+ *   src_segs      S_src x 4            source view segments            (tex_segments)
+ *   RtKinv_src    3 x 3, C_src 3       source camera                   (line3D.cc:787-803)
+ *   tgt_segs      sum(S_n) x 4         all neighbours' segments        (tex_segments_f4, line3D.cc:770-784)
+ *   offsets       N x (start,count)    into tgt_segs                   (line3D.cc:779)
+ *   F, RtKinv     N x 3 x 3; centers N x 3; P N x 3 x 4              (line3D.cc:739-763)
+ *   to_be_matched n_tbm local neighbour indices                        (line3D.cc:732-736)
+ *   in_matches    existing matches, camID2 = LOCAL index               (view.cc:200-224)
+ *   local2global  N global view ids                                    (line3D.cc:729)
+ *   seg_begin/seg_end  source-segment range to process ([0,S_src) for the whole view); the
+ *                 verification of a source segment only reads candidates of that segment, so a
+ *                 range is exact -- this is what the multi-GPU sharding uses.
+ * Outputs: *out_matches (callee-allocated, sorted (segID1, local camera, segID2), camID2 GLOBAL,
+ * confidence already divided by 2, cudawrapper.cu:1089-1110), *out_n, *median_depth
+ * (cudawrapper.cu:1066-1076; untouched when nothing is verified), and, if non-NULL,
+ * *out_best_depths (callee-allocated 2*(*out_n_best) floats: the depth pairs entering the median,
+ * in segment order) so that sharded callers can merge medians exactly.
+ * With n_tbm == 0 the reference returns immediately (cudawrapper.cu:877-878): the output is the
+ * input list unchanged (LOCAL camera ids, confidence 0) and *median_depth is left alone. */
+int l3d_compute_pairwise_matches(l3d_ctx* ctx,
+                                 const float* src_segs, int S_src, const float* RtKinv_src, const float* C_src,
+                                 const float* tgt_segs, const int32_t* offsets, int N,
+                                 const float* F, const float* RtKinv, const float* centers, const float* P,
+                                 const int32_t* to_be_matched, int n_tbm,
+                                 const l3d_match* in_matches, int n_in, const uint32_t* local2global,
+                                 float uncertainty_k_upper, float uncertainty_k_lower,
+                                 float sigma_p, float sigma_a, float spatial_k,
+                                 int seg_begin, int seg_end,
+                                 l3d_match** out_matches, int* out_n, float* median_depth,
+                                 float** out_best_depths, int* out_n_best);
+
+/* Replaces replicator_dynamics_diffusion (cudawrapper.h:73-74, cudawrapper.cu:1131-1191) plus the
+ * SparseMatrix construction of performDiffusion (line3D.cc:1258, sparsematrix.cc:63-191):
+ * A = the affinity edge list in list order, n = number of nodes; out (caller-allocated, nnz
+ * entries) = the entries of the returned matrix (row-sorted) as (i,j,w).  The reference's
+ * positional lock-step product (cudawrapper.cu:786-800) is reproduced, not "fixed". */
+int l3d_replicator_dynamics_diffusion(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n, int iters, l3d_edge* out);
+
+/* Batched Line3D::similarity_coll3D (line3D.cc:1600-1681) for the affinity fill
+ * (clusterSegments2D, line3D.cc:968-1221): sim[k] = similarity(hyp[pairs[2k]], hyp[pairs[2k+1]]). */
+int l3d_similarity_coll3D_batch(l3d_ctx* ctx, const l3d_hypothesis* hyp, int n_hyp,
+                                const int32_t* pairs, int n_pairs, float sigma_a, float* sim);
+
+/* ---- residency: keep a view's segments in HBM across calls ------------------------------------
+ * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
+ * caller may instead register segment arrays once; l3d_compute_pairwise_matches recognises
+ * host pointers that were registered (same pointer, same size) and skips the upload. */
+int l3d_register_segments(l3d_ctx* ctx, const float* segments, int n_segments);
+int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
+ * l3d_profile_get returns the launch count and summed duration for one kernel name
+ * ("pair_mask", "pair_fill", "verify", ...; l3d_profile_names lists them, ';'-separated). */
+int l3d_profile_enable(l3d_ctx* ctx, int on);
+int l3d_profile_reset(l3d_ctx* ctx);
+int l3d_profile_get(l3d_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);
+const char* l3d_profile_names(void);
+/* counters of the last l3d_compute_pairwise_matches call:
+ * [0] stage-1 pairs evaluated, [1] raw candidates (incl. existing), [2] verify inner iterations
+ * (sum over segments of m^2), [3] kept matches */
+int l3d_last_stats(l3d_ctx* ctx, double stats[4]);
+
+/* contract math exported for tests (device evaluation of c_expf / c_acosf / c_acos) */
+int l3d_test_contract_math(l3d_ctx* ctx, const float* x, int n, float* out_expf, float* out_acosf, double* out_acos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINE3D_AMD_H */

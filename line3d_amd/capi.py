@@ -1,0 +1,172 @@
+"""ctypes binding of the C ABI (include/line3d_amd.h).  Plumbing only: every compute call lands in the
+HIP library; if the library or a GPU is missing the constructor raises (no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libline3d_amd.so")
+
+MATCH_DTYPE = np.dtype([("segID1", "<u4"), ("camID2", "<u4"), ("segID2", "<u4"),
+                        ("depths", "<f4", (4,)), ("confidence", "<f4")])
+EDGE_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("w", "<f4")])
+HYP_DTYPE = np.dtype([("P1", "<f8", (3,)), ("P2", "<f8", (3,)), ("dir", "<f8", (3,)),
+                      ("depth_p1", "<f4"), ("depth_p2", "<f4"),
+                      ("k_lower", "<f4"), ("k_upper", "<f4"), ("median_depth", "<f4"), ("pad", "<u4")])
+assert MATCH_DTYPE.itemsize == 32 and EDGE_DTYPE.itemsize == 12 and HYP_DTYPE.itemsize == 96
+
+_lib = None
+
+
+def load_library():
+    """dlopen libline3d_amd.so (built in-tree by __graft_entry__.build() / make -C line3d_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.l3d_last_error.restype = C.c_char_p
+        lib.l3d_last_error.argtypes = [C.c_void_p]
+        lib.l3d_profile_names.restype = C.c_char_p
+        lib.l3d_free.argtypes = [C.c_void_p]
+        lib.l3d_ctx_destroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class L3DError(RuntimeError):
+    pass
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One GPU, one stream, grow-only device arenas (l3d_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.l3d_ctx_create(C.c_int(device), C.byref(h))
+        if rc != 0:
+            raise L3DError("l3d_ctx_create failed (code %d): no usable MI355X / HIP device -- this package has no CPU fallback" % rc)
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.l3d_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise L3DError("line3d_amd error %d: %s" % (rc, self.lib.l3d_last_error(self.h).decode()))
+
+    # -- measurement --------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.l3d_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._chk(self.lib.l3d_profile_reset(self.h))
+
+    def profile_get(self, name: str):
+        n = C.c_int64(0)
+        ms = C.c_double(0)
+        self._chk(self.lib.l3d_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def profile_all(self):
+        return {k: self.profile_get(k) for k in self.lib.l3d_profile_names().decode().split(";")}
+
+    def last_stats(self):
+        s = (C.c_double * 4)()
+        self._chk(self.lib.l3d_last_stats(self.h, s))
+        return list(s)
+
+    def register_segments(self, segs: np.ndarray):
+        assert segs.dtype == np.float32 and segs.flags.c_contiguous
+        self._keep.append(segs)
+        self._chk(self.lib.l3d_register_segments(self.h, _p(segs), C.c_int(len(segs))))
+
+    # -- the three seam functions ---------------------------------------------------------------
+    def compute_collinearity(self, segs, collin_s=2.0):
+        segs = np.ascontiguousarray(segs, dtype=np.float32)
+        oi, oj, ow = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+        n = C.c_int(0)
+        self._chk(self.lib.l3d_compute_collinearity(self.h, _p(segs), C.c_int(len(segs)), C.c_float(collin_s),
+                                                    C.byref(oi), C.byref(oj), C.byref(ow), C.byref(n)))
+        k = n.value
+        i = np.ctypeslib.as_array(oi, (k,)).copy() if k else np.zeros(0, np.int32)
+        j = np.ctypeslib.as_array(oj, (k,)).copy() if k else np.zeros(0, np.int32)
+        w = np.ctypeslib.as_array(ow, (k,)).copy() if k else np.zeros(0, np.float32)
+        for p in (oi, oj, ow):
+            self.lib.l3d_free(p)
+        return i, j, w
+
+    def compute_pairwise_matches(self, src_segs, RtKinv_src, C_src, tgt_segs, offsets, F, RtKinv, centers, P,
+                                 to_be_matched, in_matches, local2global, k_upper, k_lower, sigma_p, sigma_a,
+                                 spatial_k, median_depth=1.0, seg_range=None, want_best=False):
+        def f32(a):
+            return a if (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous) else np.ascontiguousarray(a, dtype=np.float32)
+        src_segs, tgt_segs = f32(src_segs), f32(tgt_segs)
+        RtKinv_src, C_src, F, RtKinv, centers, P = f32(RtKinv_src), f32(C_src), f32(F), f32(RtKinv), f32(centers), f32(P)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        tbm = np.ascontiguousarray(to_be_matched, dtype=np.int32)
+        inm = np.ascontiguousarray(in_matches, dtype=MATCH_DTYPE)
+        l2g = np.ascontiguousarray(local2global, dtype=np.uint32)
+        S = len(src_segs)
+        s0, s1 = (0, S) if seg_range is None else seg_range
+        out = C.c_void_p()
+        n_out = C.c_int(0)
+        med = C.c_float(median_depth)
+        bd = C.POINTER(C.c_float)()
+        nb = C.c_int(0)
+        self._chk(self.lib.l3d_compute_pairwise_matches(
+            self.h, _p(src_segs), C.c_int(S), _p(RtKinv_src), _p(C_src), _p(tgt_segs), _p(offsets), C.c_int(len(offsets)),
+            _p(F), _p(RtKinv), _p(centers), _p(P), _p(tbm), C.c_int(len(tbm)), _p(inm), C.c_int(len(inm)), _p(l2g),
+            C.c_float(k_upper), C.c_float(k_lower), C.c_float(sigma_p), C.c_float(sigma_a), C.c_float(spatial_k),
+            C.c_int(s0), C.c_int(s1), C.byref(out), C.byref(n_out), C.byref(med), C.byref(bd), C.byref(nb)))
+        n = n_out.value
+        res = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            C.memmove(res.ctypes.data, out, n * 32)
+        self.lib.l3d_free(out)
+        best = np.ctypeslib.as_array(bd, (nb.value * 2,)).copy() if nb.value else np.zeros(0, np.float32)
+        if bd:
+            self.lib.l3d_free(bd)
+        if want_best:
+            return res, med.value, best
+        return res, med.value
+
+    def replicator_dynamics_diffusion(self, edges, n, iters=10):
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        out = np.zeros(len(edges), dtype=EDGE_DTYPE)
+        self._chk(self.lib.l3d_replicator_dynamics_diffusion(self.h, _p(edges), C.c_int(len(edges)), C.c_int(n),
+                                                             C.c_int(iters), _p(out)))
+        return out
+
+    def similarity_coll3D_batch(self, hyp, pairs, sigma_a):
+        hyp = np.ascontiguousarray(hyp, dtype=HYP_DTYPE)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        sim = np.zeros(len(pairs), dtype=np.float32)
+        self._chk(self.lib.l3d_similarity_coll3D_batch(self.h, _p(hyp), C.c_int(len(hyp)), _p(pairs), C.c_int(len(pairs)),
+                                                       C.c_float(sigma_a), _p(sim)))
+        return sim
+
+    def test_contract_math(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        e = np.zeros(len(x), np.float32)
+        ac = np.zeros(len(x), np.float32)
+        acd = np.zeros(len(x), np.float64)
+        self._chk(self.lib.l3d_test_contract_math(self.h, _p(x), C.c_int(len(x)), _p(e), _p(ac), _p(acd)))
+        return e, ac, acd

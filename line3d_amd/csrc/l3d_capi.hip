@@ -1,0 +1,562 @@
+// l3d_capi.hip -- the C ABI (include/line3d_amd.h): context, device arenas, launch sequencing.
+// Host orchestration of the reference seam functions (cudawrapper.cu:833-1191) re-designed for a
+// device-resident flow: no dense S x S buffer, no per-neighbour download, no host list sort --
+// candidates are produced on the device already in (segment, camera, target) order.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/line3d_amd.h"
+#include "l3d_kernels.hpp"
+
+using namespace l3d;
+
+static_assert(sizeof(l3d_match) == sizeof(Match), "l3d_match layout");
+static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
+static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;      // grow-only arena with slack
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+
+}  // namespace
+
+struct l3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // arenas of the matching path
+    DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
+    DevBuf kept_cnt, kept_start, best, kept;
+    // other paths
+    DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
+    std::unordered_map<const void*, std::pair<void*, size_t>> resident;
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    double stats[4] = { 0, 0, 0, 0 };
+};
+
+namespace {
+
+int fail(l3d_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+hipEvent_t get_event(l3d_ctx* c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    l3d_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(l3d_ctx* c_, const char* n) : c(c_), name(n)
+    {
+        if (c->prof_on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->prof_on) { (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
+    }
+};
+
+void prof_resolve(l3d_ctx* c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches += 1; }
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// host pointer -> device pointer, uploading unless the array is registered as resident
+template <class T>
+int to_device(l3d_ctx* c, DevBuf& buf, const void* host, size_t bytes, const T** out)
+{
+    auto it = c->resident.find(host);
+    if (it != c->resident.end() && it->second.second == bytes) { *out = reinterpret_cast<const T*>(it->second.first); return L3D_OK; }
+    HIPCHK(c, buf.reserve(bytes ? bytes : 16));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    *out = buf.as<T>();
+    return L3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3d_ctx_create(int device, l3d_ctx** out)
+{
+    if (!out) return L3D_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return L3D_ERR_NODEVICE;   // fail loudly: no CPU fallback
+    if (device < 0 || device >= n) return L3D_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return L3D_ERR_HIP;
+    l3d_ctx* c = new l3d_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
+    *out = c;
+    return L3D_OK;
+}
+
+void l3d_ctx_destroy(l3d_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_resolve(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept,
+                       &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
+    for (auto* b : bufs) b->release();
+    for (auto& kv : c->resident) (void)hipFree(kv.second.first);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* l3d_last_error(const l3d_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void l3d_free(void* p) { free(p); }
+
+int l3d_register_segments(l3d_ctx* c, const float* segments, int n_segments)
+{
+    if (!c || !segments || n_segments < 0) return fail(c, L3D_ERR_INVALID, "l3d_register_segments: bad argument");
+    (void)hipSetDevice(c->device);
+    l3d_unregister_segments(c, segments);
+    const size_t bytes = (size_t)n_segments * 16;
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, bytes ? bytes : 16));
+    if (bytes) HIPCHK(c, hipMemcpy(d, segments, bytes, hipMemcpyHostToDevice));
+    c->resident[segments] = { d, bytes };
+    return L3D_OK;
+}
+
+int l3d_unregister_segments(l3d_ctx* c, const float* segments)
+{
+    if (!c) return L3D_ERR_INVALID;
+    auto it = c->resident.find(segments);
+    if (it != c->resident.end()) { (void)hipFree(it->second.first); c->resident.erase(it); }
+    return L3D_OK;
+}
+
+int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
+int l3d_profile_reset(l3d_ctx* c)
+{
+    if (!c) return L3D_ERR_INVALID;
+    prof_resolve(c);
+    c->prof.clear();
+    return L3D_OK;
+}
+int l3d_profile_get(l3d_ctx* c, const char* kernel, int64_t* launches, double* total_ms)
+{
+    if (!c || !kernel) return L3D_ERR_INVALID;
+    prof_resolve(c);
+    auto it = c->prof.find(kernel);
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    return L3D_OK;
+}
+const char* l3d_profile_names(void) { return kProfNames; }
+int l3d_last_stats(l3d_ctx* c, double stats[4])
+{
+    if (!c || !stats) return L3D_ERR_INVALID;
+    memcpy(stats, c->stats, sizeof(c->stats));
+    return L3D_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int l3d_compute_pairwise_matches(l3d_ctx* c,
+                                 const float* src_segs, int S_src, const float* RtKinv_src, const float* C_src,
+                                 const float* tgt_segs, const int32_t* offsets, int N,
+                                 const float* F, const float* RtKinv, const float* centers, const float* P,
+                                 const int32_t* to_be_matched, int n_tbm,
+                                 const l3d_match* in_matches, int n_in, const uint32_t* local2global,
+                                 float k_upper, float k_lower, float sigma_p, float sigma_a, float spatial_k,
+                                 int seg_begin, int seg_end,
+                                 l3d_match** out_matches, int* out_n, float* median_depth,
+                                 float** out_best_depths, int* out_n_best)
+{
+    (void)k_upper; (void)k_lower;   // only printed by the reference (cudawrapper.cu:1074-1082)
+    if (!c) return L3D_ERR_INVALID;
+    if (!out_matches || !out_n || !median_depth) return fail(c, L3D_ERR_INVALID, "null output pointer");
+    *out_matches = nullptr; *out_n = 0;
+    if (out_best_depths) *out_best_depths = nullptr;
+    if (out_n_best) *out_n_best = 0;
+    memset(c->stats, 0, sizeof(c->stats));
+    if (S_src < 0 || N < 0 || n_tbm < 0 || n_in < 0 || n_tbm > N) return fail(c, L3D_ERR_INVALID, "negative or inconsistent size");
+    if (n_in > 0 && !in_matches) return fail(c, L3D_ERR_INVALID, "in_matches is null");
+
+    // cudawrapper.cu:877-878: nothing to match -> the list comes back untouched
+    if (n_tbm == 0) {
+        l3d_match* o = (l3d_match*)malloc(sizeof(l3d_match) * (size_t)(n_in > 0 ? n_in : 1));
+        if (!o) return fail(c, L3D_ERR_NOMEM, "malloc");
+        if (n_in) memcpy(o, in_matches, sizeof(l3d_match) * (size_t)n_in);
+        *out_matches = o; *out_n = n_in;
+        return L3D_OK;
+    }
+    if (!src_segs || !RtKinv_src || !C_src || !tgt_segs || !offsets || !F || !RtKinv || !centers || !P || !to_be_matched || !local2global)
+        return fail(c, L3D_ERR_INVALID, "null input pointer");
+    if (seg_begin < 0) seg_begin = 0;
+    if (seg_end > S_src) seg_end = S_src;
+    if (seg_end < seg_begin) seg_end = seg_begin;
+
+    int total_tgt = 0, maxW = 0;
+    for (int i = 0; i < N; ++i) {
+        if (offsets[2 * i] < 0 || offsets[2 * i + 1] < 0) return fail(c, L3D_ERR_INVALID, "negative offset");
+        total_tgt = std::max(total_tgt, offsets[2 * i] + offsets[2 * i + 1]);
+    }
+    double pairs = 0;
+    for (int j = 0; j < n_tbm; ++j) {
+        if (to_be_matched[j] < 0 || to_be_matched[j] >= N) return fail(c, L3D_ERR_INVALID, "to_be_matched out of range");
+        maxW = std::max(maxW, offsets[2 * to_be_matched[j] + 1]);
+        pairs += (double)(seg_end - seg_begin) * offsets[2 * to_be_matched[j] + 1];
+    }
+    const int W64 = 4 * ((maxW + 255) / 256);
+    if (W64 > kMaxW64) return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments");
+    c->stats[0] = pairs;
+
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    // ---- existing matches: localized by the caller; keep those of the processed range, order them
+    // (segment, camera, target) and rank them inside their (segment, camera) run
+    std::vector<ExistRec> ex;
+    ex.reserve((size_t)n_in);
+    for (int i = 0; i < n_in; ++i) {
+        const l3d_match& m = in_matches[i];
+        if ((int)m.segID1 < seg_begin || (int)m.segID1 >= seg_end) continue;
+        if ((int)m.camID2 >= N) return fail(c, L3D_ERR_INVALID, "in_matches camera index out of range");
+        ExistRec r;
+        r.seg = (int)m.segID1; r.cam = (int)m.camID2; r.tgt = m.segID2; r.rank = 0;
+        memcpy(r.d, m.depths, 16);
+        ex.push_back(r);
+    }
+    std::stable_sort(ex.begin(), ex.end(), [](const ExistRec& a, const ExistRec& b) {
+        if (a.seg != b.seg) return a.seg < b.seg;
+        if (a.cam != b.cam) return a.cam < b.cam;
+        return a.tgt < b.tgt;
+    });
+    for (size_t i = 1; i < ex.size(); ++i)
+        if (ex[i].seg == ex[i - 1].seg && ex[i].cam == ex[i - 1].cam) ex[i].rank = ex[i - 1].rank + 1;
+    const int n_ex = (int)ex.size();
+
+    // ---- uploads
+    const float4 *d_src = nullptr, *d_tgt = nullptr;
+    int rc;
+    if ((rc = to_device(c, c->src_segs, src_segs, (size_t)S_src * 16, &d_src))) return rc;
+    if ((rc = to_device(c, c->tgt_segs, tgt_segs, (size_t)total_tgt * 16, &d_tgt))) return rc;
+    // one staging block for the small tables: offsets | F | RtKinv | centers | P | RtKinv_src | C_src
+    const size_t o_off = 0, o_F = o_off + (size_t)N * 8, o_R = o_F + (size_t)N * 36, o_C = o_R + (size_t)N * 36,
+                 o_P = o_C + (size_t)N * 12, o_Rs = o_P + (size_t)N * 48, o_Cs = o_Rs + 36, t_bytes = o_Cs + 12;
+    std::vector<unsigned char> tab(t_bytes);
+    memcpy(&tab[o_off], offsets, (size_t)N * 8);
+    memcpy(&tab[o_F], F, (size_t)N * 36);
+    memcpy(&tab[o_R], RtKinv, (size_t)N * 36);
+    memcpy(&tab[o_C], centers, (size_t)N * 12);
+    memcpy(&tab[o_P], P, (size_t)N * 48);
+    memcpy(&tab[o_Rs], RtKinv_src, 36);
+    memcpy(&tab[o_Cs], C_src, 12);
+    HIPCHK(c, c->tables.reserve(t_bytes));
+    HIPCHK(c, hipMemcpyAsync(c->tables.p, tab.data(), t_bytes, hipMemcpyHostToDevice, st));
+    const unsigned char* tb = c->tables.as<unsigned char>();
+    HIPCHK(c, c->tbm.reserve((size_t)n_tbm * 4));
+    HIPCHK(c, hipMemcpyAsync(c->tbm.p, to_be_matched, (size_t)n_tbm * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, c->l2g.reserve((size_t)N * 4));
+    HIPCHK(c, hipMemcpyAsync(c->l2g.p, local2global, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, c->exist.reserve((size_t)n_ex * sizeof(ExistRec) + 16));
+    if (n_ex) HIPCHK(c, hipMemcpyAsync(c->exist.p, ex.data(), (size_t)n_ex * sizeof(ExistRec), hipMemcpyHostToDevice, st));
+
+    const size_t nrow = (size_t)S_src * N;
+    HIPCHK(c, c->mask.reserve((size_t)n_tbm * S_src * W64 * 8));
+    HIPCHK(c, c->rowcnt.reserve(nrow * 4));
+    HIPCHK(c, c->row_start.reserve((nrow + 1) * 4));
+    HIPCHK(c, c->kept_cnt.reserve((size_t)S_src * 4 + 4));
+    HIPCHK(c, c->kept_start.reserve((size_t)S_src * 4 + 8));
+    HIPCHK(c, c->best.reserve((size_t)S_src * 8 + 8));
+    HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, nrow * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S_src * 4, st));
+
+    PairArgs pa;
+    pa.src_segs = d_src; pa.tgt_segs = d_tgt;
+    pa.offsets = reinterpret_cast<const int2*>(tb + o_off);
+    pa.F = reinterpret_cast<const float*>(tb + o_F);
+    pa.RtKinv = reinterpret_cast<const float*>(tb + o_R);
+    pa.centers = reinterpret_cast<const float*>(tb + o_C);
+    pa.RtKinv_src = reinterpret_cast<const float*>(tb + o_Rs);
+    pa.C_src = reinterpret_cast<const float*>(tb + o_Cs);
+    pa.tbm = c->tbm.as<int>();
+    pa.mask = c->mask.as<unsigned long long>();
+    pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end;
+
+    if (seg_end > seg_begin) {
+        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, maxW, st); }
+        { ProfScope p(c, "row_count"); launch_row_count(pa, c->rowcnt.as<int>(), st); }
+    }
+    { ProfScope p(c, "exist"); launch_exist_hist(c->exist.as<ExistRec>(), n_ex, N, c->rowcnt.as<int>(), st); }
+    { ProfScope p(c, "scan"); launch_scan(c->rowcnt.as<int>(), c->row_start.as<int>(), (int)nrow, st); }
+    int R = 0;
+    HIPCHK(c, hipMemcpyAsync(&R, c->row_start.as<int>() + nrow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    c->stats[1] = R;
+    if (R == 0) {            // cudawrapper.cu:955-956: matches stays empty, median_depth untouched
+        *out_matches = (l3d_match*)malloc(sizeof(l3d_match));
+        return L3D_OK;
+    }
+
+    HIPCHK(c, c->cand_meta.reserve((size_t)R * 8));
+    HIPCHK(c, c->cand_depths.reserve((size_t)R * 16));
+    HIPCHK(c, c->cand_conf.reserve((size_t)R * 4));
+    HIPCHK(c, c->kept.reserve((size_t)R * sizeof(Match)));
+
+    if (seg_end > seg_begin) {
+        ProfScope p(c, "pair_fill");
+        launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+    }
+    { ProfScope p(c, "exist"); launch_exist_place(c->exist.as<ExistRec>(), n_ex, N, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+
+    VerifyArgs va;
+    va.src_segs = d_src; va.tgt_segs = d_tgt; va.offsets = pa.offsets;
+    va.P = reinterpret_cast<const float*>(tb + o_P);
+    va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
+    va.row_start = c->row_start.as<int>();
+    va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
+    va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
+    va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
+    { ProfScope p(c, "verify"); launch_verify(va, st); }
+    { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
+    { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
+    { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), c->l2g.as<unsigned>(), c->kept.as<Match>(), st); }
+
+    int n_kept = 0;
+    std::vector<float> best((size_t)(seg_end - seg_begin) * 2);
+    std::vector<int> rs_host;
+    HIPCHK(c, hipMemcpyAsync(&n_kept, c->kept_start.as<int>() + S_src, 4, hipMemcpyDeviceToHost, st));
+    if (!best.empty())
+        HIPCHK(c, hipMemcpyAsync(best.data(), c->best.as<float2>() + seg_begin, best.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    l3d_match* o = (l3d_match*)malloc(sizeof(l3d_match) * (size_t)(n_kept > 0 ? n_kept : 1));
+    if (!o) return fail(c, L3D_ERR_NOMEM, "malloc");
+    if (n_kept) HIPCHK(c, hipMemcpy(o, c->kept.p, sizeof(l3d_match) * (size_t)n_kept, hipMemcpyDeviceToHost));
+    *out_matches = o; *out_n = n_kept;
+    c->stats[3] = n_kept;
+
+    // median of the best hypotheses' depths, cudawrapper.cu:1066-1076
+    std::vector<float> depths;
+    depths.reserve(best.size());
+    for (size_t i = 0; i + 1 < best.size(); i += 2)
+        if (best[i] != -1.0f) { depths.push_back(best[i]); depths.push_back(best[i + 1]); }
+    if (out_best_depths && out_n_best) {
+        float* bd = (float*)malloc(sizeof(float) * (depths.size() ? depths.size() : 1));
+        if (!bd) return fail(c, L3D_ERR_NOMEM, "malloc");
+        if (!depths.empty()) memcpy(bd, depths.data(), depths.size() * 4);
+        *out_best_depths = bd; *out_n_best = (int)(depths.size() / 2);
+    }
+    *median_depth = -1.0f;
+    if (!depths.empty()) {
+        std::sort(depths.begin(), depths.end());
+        *median_depth = depths[depths.size() / 2];
+    }
+    return L3D_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float collin_s,
+                             int32_t** out_i, int32_t** out_j, float** out_w, int* out_n)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!out_i || !out_j || !out_w || !out_n || S < 0 || (S > 0 && !segments)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *out_i = nullptr; *out_j = nullptr; *out_w = nullptr; *out_n = 0;
+    if (S < 2) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int W64 = 4 * ((S + 255) / 256);
+    const float4* d_segs = nullptr;
+    int rc;
+    if ((rc = to_device(c, c->g0, segments, (size_t)S * 16, &d_segs))) return rc;
+    HIPCHK(c, c->g1.reserve((size_t)S * W64 * 8));
+    HIPCHK(c, c->g2.reserve((size_t)S * 4));
+    HIPCHK(c, c->g3.reserve((size_t)(S + 1) * 4));
+    HIPCHK(c, hipMemsetAsync(c->g1.p, 0, (size_t)S * W64 * 8, st));
+    HIPCHK(c, hipMemsetAsync(c->g2.p, 0, (size_t)S * 4, st));
+    const float sigma_sqr = collin_s * collin_s;   // cudawrapper.cu:850
+    { ProfScope p(c, "collinearity"); launch_collinearity(d_segs, S, sigma_sqr, c->g1.as<unsigned long long>(), W64, c->g2.as<int>(), st); }
+    { ProfScope p(c, "scan"); launch_scan(c->g2.as<int>(), c->g3.as<int>(), S, st); }
+    int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, c->g3.as<int>() + S, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    if (n == 0) return L3D_OK;
+    HIPCHK(c, c->g4.reserve((size_t)n * 4));
+    HIPCHK(c, c->g5.reserve((size_t)n * 4));
+    HIPCHK(c, c->g6.reserve((size_t)n * 4));
+    { ProfScope p(c, "collinearity_fill");
+      launch_collinearity_fill(d_segs, S, sigma_sqr, c->g1.as<unsigned long long>(), W64, c->g3.as<int>(), c->g4.as<int>(), c->g5.as<int>(), c->g6.as<float>(), st); }
+    int32_t* oi = (int32_t*)malloc((size_t)n * 4);
+    int32_t* oj = (int32_t*)malloc((size_t)n * 4);
+    float* ow = (float*)malloc((size_t)n * 4);
+    if (!oi || !oj || !ow) { free(oi); free(oj); free(ow); return fail(c, L3D_ERR_NOMEM, "malloc"); }
+    HIPCHK(c, hipMemcpyAsync(oi, c->g4.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(oj, c->g5.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(ow, c->g6.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *out_i = oi; *out_j = oj; *out_w = ow; *out_n = n;
+    return L3D_OK;
+}
+
+}  // extern "C"
+
+namespace {
+struct HostSparse { std::vector<float4> entries; std::vector<int> start; };
+// sparsematrix.cc:99-131 for an already sorted list
+HostSparse build_sparse(const std::vector<l3d_edge>& sorted, int n, bool by_row)
+{
+    HostSparse s;
+    s.entries.resize(sorted.size());
+    s.start.assign((size_t)n, -1);
+    int cur = -1;
+    for (size_t pos = 0; pos < sorted.size(); ++pos) {
+        s.entries[pos] = make_float4((float)sorted[pos].i, (float)sorted[pos].j, sorted[pos].w, 0.0f);
+        const int rc = by_row ? sorted[pos].i : sorted[pos].j;
+        if (rc != cur) { s.start[(size_t)rc] = (int)pos; cur = rc; }
+    }
+    return s;
+}
+}  // namespace
+
+extern "C" {
+
+int l3d_replicator_dynamics_diffusion(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int iters, l3d_edge* out)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && (!A || !out))) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (nnz == 0 || n == 0) return L3D_OK;      // sparsematrix.cc:77-78: empty matrix, nothing to do
+    for (int k = 0; k < nnz; ++k)
+        if (A[k].i < 0 || A[k].i >= n || A[k].j < 0 || A[k].j >= n) return fail(c, L3D_ERR_INVALID, "edge index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    // W: column-sorted (line3D.cc:1258 -> sparsematrix.cc:81-86, stable list sort by (j,i))
+    std::vector<l3d_edge> e(A, A + nnz);
+    std::stable_sort(e.begin(), e.end(), [](const l3d_edge& a, const l3d_edge& b) { return a.j < b.j || (a.j == b.j && a.i < b.i); });
+    HostSparse W = build_sparse(e, n, false);
+    // P: the column-sorted entries re-sorted by row (cudawrapper.cu:1145 -> sparsematrix.cc:157-167)
+    std::stable_sort(e.begin(), e.end(), [](const l3d_edge& a, const l3d_edge& b) { return a.i < b.i || (a.i == b.i && a.j < b.j); });
+    HostSparse Pm = build_sparse(e, n, true);
+
+    const size_t eb = (size_t)nnz * 16, sb = (size_t)n * 4;
+    HIPCHK(c, c->g0.reserve(eb)); HIPCHK(c, c->g1.reserve(eb)); HIPCHK(c, c->g2.reserve(eb));
+    HIPCHK(c, c->g3.reserve(sb)); HIPCHK(c, c->g4.reserve(sb)); HIPCHK(c, c->g5.reserve(sb));
+    float4 *dW = c->g0.as<float4>(), *dP = c->g1.as<float4>(), *dPp = c->g2.as<float4>();
+    int *dWc = c->g3.as<int>(), *dPr = c->g4.as<int>(), *dPpr = c->g5.as<int>();
+    HIPCHK(c, hipMemcpyAsync(dW, W.entries.data(), eb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dP, Pm.entries.data(), eb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dPp, Pm.entries.data(), eb, hipMemcpyHostToDevice, st));   // P' = copy of P (1148)
+    HIPCHK(c, hipMemcpyAsync(dWc, W.start.data(), sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dPr, Pm.start.data(), sb, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dPpr, Pm.start.data(), sb, hipMemcpyHostToDevice, st));
+    { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
+    for (int it = 0; it < iters; ++it) {
+        { ProfScope p(c, "diffusion_step"); launch_diffusion_step(dP, dW, dPr, dWc, dPp, dPpr, nnz, st); }
+        std::swap(dP, dPp);
+        std::swap(dPr, dPpr);
+        if (it < iters - 1) { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
+    }
+    std::vector<float4> res((size_t)nnz);
+    HIPCHK(c, hipMemcpyAsync(res.data(), dP, eb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    for (int k = 0; k < nnz; ++k) { out[k].i = (int)res[k].x; out[k].j = (int)res[k].y; out[k].w = res[k].z; }
+    return L3D_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int l3d_similarity_coll3D_batch(l3d_ctx* c, const l3d_hypothesis* hyp, int n_hyp, const int32_t* pairs, int n_pairs,
+                                float sigma_a, float* sim)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (n_hyp < 0 || n_pairs < 0 || (n_pairs > 0 && (!hyp || !pairs || !sim))) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (n_pairs == 0) return L3D_OK;
+    for (int k = 0; k < 2 * n_pairs; ++k)
+        if (pairs[k] < 0 || pairs[k] >= n_hyp) return fail(c, L3D_ERR_INVALID, "pair index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->g0.reserve((size_t)n_hyp * sizeof(Hypothesis)));
+    HIPCHK(c, c->g1.reserve((size_t)n_pairs * 8));
+    HIPCHK(c, c->g2.reserve((size_t)n_pairs * 4));
+    HIPCHK(c, hipMemcpyAsync(c->g0.p, hyp, (size_t)n_hyp * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->g1.p, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    const float two_log = 2.0f * logf(0.01f);      // view.cc:376
+    { ProfScope p(c, "similarity"); launch_similarity(c->g0.as<Hypothesis>(), c->g1.as<int2>(), n_pairs, sigma_a, two_log, c->g2.as<float>(), st); }
+    HIPCHK(c, hipMemcpyAsync(sim, c->g2.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return L3D_OK;
+}
+
+int l3d_test_contract_math(l3d_ctx* c, const float* x, int n, float* e, float* ac, double* acd)
+{
+    if (!c || n < 0 || (n > 0 && (!x || !e || !ac || !acd))) return L3D_ERR_INVALID;
+    if (n == 0) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->g0.reserve((size_t)n * 4)); HIPCHK(c, c->g1.reserve((size_t)n * 4));
+    HIPCHK(c, c->g2.reserve((size_t)n * 4)); HIPCHK(c, c->g3.reserve((size_t)n * 8));
+    HIPCHK(c, hipMemcpyAsync(c->g0.p, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    launch_test_math(c->g0.as<float>(), n, c->g1.as<float>(), c->g2.as<float>(), c->g3.as<double>(), st);
+    HIPCHK(c, hipMemcpyAsync(e, c->g1.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(ac, c->g2.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(acd, c->g3.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return L3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,640 @@
+// l3d_kernels.hip -- HIP kernels for gfx950 (CDNA4, wave64) of the Line3D matching path.
+// No MFMA: there is no dense contraction on this path; the kernels are
+// FP32-VALU bound, inputs are tiny and L2/LDS resident.
+//
+//   k_pair_mask      stage 1a: epipolar/overlap test + triangulation, one bit per (src,tgt) pair
+//   k_row_count      stage 1b: per (src segment, camera) candidate counts from the bit rows
+//   k_exist_hist     counts of the already existing (reverse) matches
+//   k_scan           exclusive scan (single workgroup)
+//   k_pair_fill      stage 1c: depth records for the set bits, written in (seg,cam,tgt) order
+//   k_exist_place    existing matches into their candidate slots
+//   k_verify         stage 2: multi-view support score of every candidate (K_verify_matches)
+//   k_seg_post       per segment: best hypothesis depths, number of kept matches
+//   k_kept_write     ordered compaction of the kept matches
+//   k_collinearity   per-view 2-D collinearity relation (upper triangle, bit + value)
+//   k_rownorm / k_diffusion_step   replicator dynamics diffusion
+//   k_similarity     batched similarity_coll3D for the affinity fill
+#include "l3d_geometry.hpp"
+#include "l3d_kernels.hpp"
+
+namespace l3d {
+
+// =================================================================================================
+// Stage 1a.  grid = (tgt tiles of 256, src blocks of kSrcPerBlock, n_tbm); block = 256.
+// Lane <-> target segment (its invariants live in registers), the block walks kSrcPerBlock source
+// segments whose invariants are staged in LDS and read as broadcasts.  One wave ballot = one
+// 64-bit word of the (camera, src) bit row.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
+{
+    __shared__ SrcPairInv s_src[kSrcPerBlock];
+    __shared__ float s_cam[9 + 9 + 3];   // F, RtKinv_tgt, C_tgt of this camera
+
+    const int j = blockIdx.z;
+    const int cam = a.tbm[j];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int x = blockIdx.x * 256 + tid;
+    const int width = a.offsets[cam].y;
+    const int toff = a.offsets[cam].x;
+    const int y0 = a.seg_begin + blockIdx.y * kSrcPerBlock;
+
+    if (blockIdx.x * 256 >= width) return;   // whole tile beyond this camera's segments (uniform)
+
+    if (tid < 9) s_cam[tid] = a.F[cam * 9 + tid];
+    else if (tid < 18) s_cam[tid] = a.RtKinv[cam * 9 + (tid - 9)];
+    else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
+    __syncthreads();
+    if (tid < kSrcPerBlock && y0 + tid < a.seg_end) s_src[tid] = make_src_inv(a.src_segs[y0 + tid], s_cam);
+
+    const bool valid = x < width;
+    const float4 tseg = valid ? a.tgt_segs[toff + x] : make_float4(0.f, 0.f, 1.f, 1.f);
+    const TgtPairInv t = make_tgt_inv(tseg, s_cam);
+    const f3 C_tgt = mk3(s_cam[18], s_cam[19], s_cam[20]);
+    const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    __syncthreads();
+
+    const int ny = min(kSrcPerBlock, a.seg_end - y0);
+    for (int k = 0; k < ny; ++k) {
+        const SrcPairInv& s = s_src[k];
+        bool ok = false;
+        if (valid) {
+            f3 l2_p1, l2_p2, l1_q1, l1_q2;
+            if (pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2)) {
+                const float4 d = pair_depths(s, t, l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, s_cam + 9, C_src, C_tgt);
+                ok = d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f;   // cudawrapper.cu:931
+            }
+        }
+        const unsigned long long bits = __ballot(ok);
+        if (lane == 0) a.mask[((size_t)j * a.S_src + (y0 + k)) * a.W64 + blockIdx.x * 4 + wave] = bits;
+    }
+}
+
+// Stage 1b.  One wave per (src segment, tbm camera) row.
+__global__ __launch_bounds__(256) void k_row_count(PairArgs a, int* __restrict__ rowcnt)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nrows = (a.seg_end - a.seg_begin) * a.n_tbm;
+    if (row >= nrows) return;
+    const int j = row % a.n_tbm;
+    const int y = a.seg_begin + row / a.n_tbm;
+    const int cam = a.tbm[j];
+    const int nw = (a.offsets[cam].y + 63) >> 6;
+    const unsigned long long* m = a.mask + ((size_t)j * a.S_src + y) * a.W64;
+    int c = 0;
+    for (int w = lane; w < nw; w += 64) c += __popcll(m[w]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if (lane == 0) rowcnt[y * a.N + cam] = c;
+}
+
+__global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int* __restrict__ rowcnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&rowcnt[ex[i].seg * N + ex[i].cam], 1);
+}
+
+// Exclusive scan of n ints by ONE workgroup of 1024 threads; out has n+1 entries.
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n)
+{
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int b = tid * chunk, e = min(n, b + chunk);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += in[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? s_part[tid - 1] : 0;
+    for (int i = b; i < e; ++i) { out[i] = run; run += in[i]; }
+    if (tid == 1023) out[n] = s_part[1023];
+}
+
+// r-th (0-based) set bit of a 64-bit word
+__device__ __forceinline__ int select_bit(unsigned long long m, int r)
+{
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long lo = m & ((1ull << w) - 1ull);
+        const int c = __popcll(lo);
+        if (r >= c) { r -= c; m >>= w; pos += w; } else { m = lo; }
+    }
+    return pos;
+}
+
+// Stage 1c.  One wave per (src segment, tbm camera) row: the row's set bits are enumerated in
+// ascending target order, 64 at a time with all lanes busy, and the depth record of each is written
+// to slot row_start + rank -> candidates come out sorted (seg, cam, tgt) with no sort pass.
+__global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __restrict__ row_start,
+                                                   uint2* __restrict__ cand_meta, float4* __restrict__ cand_depths)
+{
+    __shared__ unsigned long long s_words[4][kMaxW64];
+    __shared__ int s_pref[4][kMaxW64 + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const int nrows = (a.seg_end - a.seg_begin) * a.n_tbm;
+    if (row >= nrows) return;
+    const int j = row % a.n_tbm;
+    const int y = a.seg_begin + row / a.n_tbm;
+    const int cam = a.tbm[j];
+    const int nw = (a.offsets[cam].y + 63) >> 6;
+    const int toff = a.offsets[cam].x;
+    const unsigned long long* m = a.mask + ((size_t)j * a.S_src + y) * a.W64;
+
+    // words + exclusive prefix of popcounts (nw <= kMaxW64; chunks of 64 words)
+    int base = 0;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        const unsigned long long word = w < nw ? m[w] : 0ull;
+        int c = __popcll(word);
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (w < nw) { s_words[wave][w] = word; s_pref[wave][w] = base + incl - c; }
+        base += __shfl(incl, 63);
+    }
+    const int total = base;
+    if (lane == 0) s_pref[wave][nw] = total;
+    if (total == 0) return;
+
+    const SrcPairInv s = make_src_inv(a.src_segs[y], a.F + cam * 9);
+    const f3 C_tgt = mk3(a.centers[cam * 3], a.centers[cam * 3 + 1], a.centers[cam * 3 + 2]);
+    const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    const int slot0 = row_start[y * a.N + cam];
+
+    for (int k = lane; k < total; k += 64) {
+        int lo = 0, hi = nw;               // largest w with pref[w] <= k
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[wave][mid] <= k) lo = mid; else hi = mid; }
+        const int x = lo * 64 + select_bit(s_words[wave][lo], k - s_pref[wave][lo]);
+        const TgtPairInv t = make_tgt_inv(a.tgt_segs[toff + x], a.F + cam * 9);
+        f3 l2_p1, l2_p2, l1_q1, l1_q2;
+        pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
+        const float4 d = pair_depths(s, t, l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
+        cand_meta[slot0 + k] = make_uint2((unsigned)x, (unsigned)cam);
+        cand_depths[slot0 + k] = d;
+    }
+}
+
+__global__ void k_exist_place(const ExistRec* __restrict__ ex, int n, int N, const int* __restrict__ row_start,
+                              uint2* __restrict__ cand_meta, float4* __restrict__ cand_depths)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ExistRec r = ex[i];
+    const int slot = row_start[r.seg * N + r.cam] + r.rank;
+    cand_meta[slot] = make_uint2(r.tgt, r.cam);
+    cand_depths[slot] = make_float4(r.d[0], r.d[1], r.d[2], r.d[3]);
+}
+
+// =================================================================================================
+// Stage 2.  One workgroup per source segment.  Every candidate record is both a hypothesis (its own
+// 3-D segment X1,X2) and a witness for the other hypotheses of the same source segment.
+// Candidate tiles are staged in LDS together with everything that depends on the candidate only
+// (3-D endpoints, unit direction, normalised target line); the per-(hypothesis, camera) projections
+// are refreshed when the (wave-uniform) witness camera changes.
+// =================================================================================================
+struct Witness {            // 20 floats
+    float X1[3], X2[3], v[3];
+    float l2[3], den2;      // target line and sqrt(l.x^2+l.y^2)
+    float q[4];
+    int cam;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void k_verify(VerifyArgs a)
+{
+    __shared__ Witness s_w[kVerifyTile];
+    __shared__ float s_ray[6];
+
+    const int y = a.seg_begin + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    if (m == 0) return;
+
+    const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    if (tid == 0) {
+        const float4 s = a.src_segs[y];
+        const f3 r1 = normalize(mat3_apply(a.RtKinv_src, mk3(s.x, s.y, 1.0f)));
+        const f3 r2 = normalize(mat3_apply(a.RtKinv_src, mk3(s.z, s.w, 1.0f)));
+        s_ray[0] = r1.x; s_ray[1] = r1.y; s_ray[2] = r1.z;
+        s_ray[3] = r2.x; s_ray[4] = r2.y; s_ray[5] = r2.z;
+    }
+    __syncthreads();
+    const f3 ray1 = mk3(s_ray[0], s_ray[1], s_ray[2]);
+    const f3 ray2 = mk3(s_ray[3], s_ray[4], s_ray[5]);
+
+    const float two_sig_d = 2.0f * (a.sigma_p * a.sigma_p);
+    const float two_sig_a = 2.0f * (a.sigma_a * a.sigma_a);
+
+    for (int h0 = 0; h0 < m; h0 += 256) {
+        const int h = h0 + tid;
+        const bool hv = h < m;
+        // hypothesis registers
+        f3 X1 = mk3(0, 0, 0), X2 = mk3(0, 0, 0), v1 = mk3(0, 0, 0);
+        float T1 = -1.0f, T2 = -1.0f;
+        int cam_h = -1;
+        if (hv) {
+            const float4 d = a.cand_depths[start + h];
+            cam_h = (int)a.cand_meta[start + h].y;
+            X1 = C + d.x * ray1;                 // D_unproject_point_src, cudawrapper.cu:338-344
+            X2 = C + d.y * ray2;
+            v1 = normalize(X1 - X2);
+            if (a.spatial_k > 0.0f) {
+                T1 = sq_threshold(a.spatial_k * length(C - X1));
+                T2 = sq_threshold(a.spatial_k * length(C - X2));
+            }
+        }
+        float conf_sum = 0.0f, cur_max = 0.0f;
+        int cur_cam = -1;                       // wave-uniform
+        f3 pr1 = mk3(0, 0, 0), pr2 = mk3(0, 0, 0), line1 = mk3(0, 0, 0);
+        float den1 = 1.0f;
+        bool pvalid = false;
+
+        for (int c0 = 0; c0 < m; c0 += kVerifyTile) {
+            __syncthreads();
+            // stage witnesses c0 .. c0+tile
+            for (int i = tid; i < kVerifyTile && c0 + i < m; i += 256) {
+                const uint2 meta = a.cand_meta[start + c0 + i];
+                const float4 d = a.cand_depths[start + c0 + i];
+                const f3 Q1 = C + d.x * ray1;
+                const f3 Q2 = C + d.y * ray2;
+                const f3 v2 = normalize(Q1 - Q2);
+                const float4 tq = a.tgt_segs[a.offsets[meta.y].x + meta.x];
+                const f3 q1 = mk3(tq.x, tq.y, 1.0f), q2 = mk3(tq.z, tq.w, 1.0f);
+                const f3 l2 = cross(q1, q2);
+                Witness w;
+                w.X1[0] = Q1.x; w.X1[1] = Q1.y; w.X1[2] = Q1.z;
+                w.X2[0] = Q2.x; w.X2[1] = Q2.y; w.X2[2] = Q2.z;
+                w.v[0] = v2.x; w.v[1] = v2.y; w.v[2] = v2.z;
+                w.l2[0] = l2.x; w.l2[1] = l2.y; w.l2[2] = l2.z;
+                w.den2 = line_norm2d(l2);
+                w.q[0] = tq.x; w.q[1] = tq.y; w.q[2] = tq.z; w.q[3] = tq.w;
+                w.cam = (int)meta.y;
+                w.pad = 0;
+                s_w[i] = w;
+            }
+            __syncthreads();
+            const int nt = min(kVerifyTile, m - c0);
+            for (int i = 0; i < nt; ++i) {
+                const Witness& w = s_w[i];
+                const int cam2 = w.cam;                       // uniform
+                if (cam2 != cur_cam) {                         // cudawrapper.cu:677-687
+                    conf_sum += cur_max;
+                    cur_max = 0.0f;
+                    cur_cam = cam2;
+                    bool va, vb;
+                    pr1 = project(a.P + cam2 * 12, X1, va);   // :690-693
+                    pr2 = project(a.P + cam2 * 12, X2, vb);
+                    pvalid = va && vb;
+                    line1 = cross(pr1, pr2);
+                    den1 = line_norm2d(line1);
+                }
+                if (!hv || cam2 == cam_h || !pvalid) continue;   // :658,:674 (own slot has cam2 == cam_h)
+                // 3-D gate, :388-401
+                if (a.spatial_k > 0.0f) {
+                    const f3 e1 = X1 - mk3(w.X1[0], w.X1[1], w.X1[2]);
+                    const f3 e2 = X2 - mk3(w.X2[0], w.X2[1], w.X2[2]);
+                    if (dot(e1, e1) > T1 || dot(e2, e2) > T2) continue;
+                }
+                // 2-D distance, :404-417 (x/d is monotone for d>0: max of quotients = quotient of max)
+                const f3 l2 = mk3(w.l2[0], w.l2[1], w.l2[2]);
+                const f3 q1 = mk3(w.q[0], w.q[1], 1.0f), q2 = mk3(w.q[2], w.q[3], 1.0f);
+                const float d1 = __builtin_fmaxf(__builtin_fabsf(line_numer(l2, pr1) / w.den2),
+                                                 __builtin_fabsf(line_numer(l2, pr2) / w.den2));
+                const float d2 = __builtin_fmaxf(__builtin_fabsf(line_numer(line1, q1) / den1),
+                                                 __builtin_fabsf(line_numer(line1, q2) / den1));
+                const float dist = __builtin_fmaxf(d1, d2);
+                // angle, :118-130 (double arithmetic: CUDART_PI is a double literal)
+                const float cs = __builtin_fmaxf(__builtin_fminf(dot(v1, mk3(w.v[0], w.v[1], w.v[2])), 1.0f), -1.0f);
+                float angle = (float)((double)c_acosf(cs) / 3.1415926535897931e+0 * (double)180.0f);
+                if (angle > 90.0f) angle = 180.0f - angle;
+                const float cd = c_expf(-dist * dist / two_sig_d);
+                const float conf = __builtin_fminf(cd, c_expf(-angle * angle / two_sig_a));
+                if (conf > 0.5f && conf > cur_max) cur_max = conf;   // :699-704
+            }
+        }
+        conf_sum += cur_max;                                    // :709
+        if (hv) a.cand_conf[start + h] = conf_sum;
+        __syncthreads();
+    }
+}
+
+// Per segment (one wave each): first strict maximum of the confidences -> best depths for the
+// median (cudawrapper.cu:1037-1062) and the number of kept matches (conf > 1, :1096).
+__global__ __launch_bounds__(256) void k_seg_post(VerifyArgs a, int* __restrict__ kept_cnt, float2* __restrict__ best_depths)
+{
+    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= a.seg_end) return;
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    float best = 0.0f;
+    int best_i = 0x7fffffff;
+    int kept = 0;
+    for (int i = lane; i < m; i += 64) {
+        const float c = a.cand_conf[start + i];
+        kept += c > 1.0f;
+        if (c > best) { best = c; best_i = i; }      // strided ascending: first index of this lane's max
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        kept += __shfl_down(kept, o);
+        const float ob = __shfl_down(best, o);
+        const int oi = __shfl_down(best_i, o);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+        kept_cnt[y] = kept;
+        float2 bd = make_float2(-1.0f, -1.0f);         // marker: not part of the median list
+        if (best > 0.5f) {                             // conf_t/2.0f
+            const float4 d = a.cand_depths[start + best_i];
+            bd = make_float2(d.x, d.y);
+        }
+        best_depths[y] = bd;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kept_write(VerifyArgs a, const int* __restrict__ kept_start,
+                                                    const unsigned* __restrict__ local2global, Match* __restrict__ out)
+{
+    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= a.seg_end) return;
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    int o = kept_start[y];
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        const float c = i < m ? a.cand_conf[start + i] : 0.0f;
+        const bool k = c > 1.0f;
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
+            const uint2 meta = a.cand_meta[start + i];
+            const float4 d = a.cand_depths[start + i];
+            Match r;
+            r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
+            r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
+            r.confidence = c / 2.0f;                 // confidence_norm, cudawrapper.cu:1089,1098
+            out[pos] = r;
+        }
+        o += __popcll(b);
+    }
+}
+
+// =================================================================================================
+// Collinearity (K_collinearity, cudawrapper.cu:476-535).  One thread per (x<y) pair inside 64x... tiles;
+// output: dense upper-triangle bit rows + a compact value written in a second pass on the host side
+// from the few set bits.  Here: row y, lanes sweep x<y; ballot -> bit words; values recomputed on fill.
+// =================================================================================================
+__device__ __forceinline__ float collin_pair(float4 sx, float4 sy, float sigma_sqr)
+{
+    const f3 p1 = mk3(sx.x, sx.y, 1.0f), p2 = mk3(sx.z, sx.w, 1.0f);
+    const f3 q1 = mk3(sy.x, sy.y, 1.0f), q2 = mk3(sy.z, sy.w, 1.0f);
+    const f3 line1 = cross(p1, p2), line2 = cross(q1, q2);
+    const float d1 = __builtin_fmaxf(dist_p2l(line2, p1), dist_p2l(line2, p2));
+    const float d2 = __builtin_fmaxf(dist_p2l(line1, q1), dist_p2l(line1, q2));
+    const float d = __builtin_fmaxf(d1, d2);
+    const float aff = c_expf(-d * d / (2.0f * sigma_sqr));
+    if (!(aff > kCollinAffT)) return 0.0f;
+    const float pos1 = (q1.x - p1.x) * (q2.x - p1.x) + (q1.y - p1.y) * (q2.y - p1.y);
+    const float pos2 = (q1.x - p2.x) * (q2.x - p2.x) + (q1.y - p2.y) * (q2.y - p2.y);
+    const float pos3 = (p1.x - q1.x) * (p2.x - q1.x) + (p1.y - q1.y) * (p2.y - q1.y);
+    const float pos4 = (p1.x - q2.x) * (p2.x - q2.x) + (p1.y - q2.y) * (p2.y - q2.y);
+    if (pos1 > -kEpsG && pos2 > -kEpsG && pos3 > -kEpsG && pos4 > -kEpsG) return aff;
+    return 0.0f;
+}
+
+// grid = (ceil(S/256), S): row = smaller index i, lanes = larger index j (> i).  mask[i][word].
+__global__ __launch_bounds__(256) void k_collinearity(const float4* __restrict__ segs, int S, float sigma_sqr,
+                                                      unsigned long long* __restrict__ mask, int W64, int* __restrict__ rowcnt)
+{
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 + 255 <= i) return;               // whole tile at or below the diagonal
+    bool ok = false;
+    if (j < S && j > i) ok = collin_pair(segs[i], segs[j], sigma_sqr) > 0.0f;   // x=i < y=j
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) {
+        mask[(size_t)i * W64 + blockIdx.x * 4 + (threadIdx.x >> 6)] = b;
+        if (b) atomicAdd(&rowcnt[i], __popcll(b));
+    }
+}
+
+// one wave per row i: write (i, j, w) for the set bits in ascending j
+__global__ __launch_bounds__(256) void k_collinearity_fill(const float4* __restrict__ segs, int S, float sigma_sqr,
+                                                           const unsigned long long* __restrict__ mask, int W64,
+                                                           const int* __restrict__ row_start,
+                                                           int* __restrict__ out_i, int* __restrict__ out_j, float* __restrict__ out_w)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= S) return;
+    int o = row_start[i];
+    const int nw = (S + 63) >> 6;
+    for (int w = (i >> 6); w < nw; ++w) {
+        const unsigned long long b = mask[(size_t)i * W64 + w];
+        if (!b) continue;
+        if ((b >> lane) & 1ull) {
+            const int j = w * 64 + lane;
+            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
+            out_i[pos] = i; out_j[pos] = j;
+            out_w[pos] = collin_pair(segs[i], segs[j], sigma_sqr);
+        }
+        o += __popcll(b);
+    }
+}
+
+// =================================================================================================
+// Replicator dynamics diffusion.  Entries are float4 (row, col, val, 0) like the reference's
+// SparseMatrix (sparsematrix.cc:99-131); start[] = first entry of a row/col or -1.
+// =================================================================================================
+// K_sparseMat_row_normalization (cudawrapper.cu:717-762): one wave per row, serial-order sum kept
+// (the sum order is part of the result): lane 0 accumulates in entry order, all lanes divide.
+__global__ __launch_bounds__(256) void k_rownorm(float4* __restrict__ data, const int* __restrict__ start, int num_rows, int nnz)
+{
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= num_rows) return;
+    const int s = start[y];
+    if (s < 0) return;
+    int e = s;
+    float sum = 0.0f;
+    // row length: rows are contiguous runs of entries with .x == y
+    if (lane == 0) {
+        while (e < nnz && (int)data[e].x == y) { sum += data[e].z; ++e; }
+        if (sum < kEpsG) sum = kEpsG;
+    }
+    e = __shfl(e, 0);
+    sum = __shfl(sum, 0);
+    for (int i = s + lane; i < e; i += 64) data[i].z = data[i].z / sum;
+}
+
+// K_sparseMat_diffusion_step (cudawrapper.cu:765-829): one thread per entry; positional lock-step
+// product of row r of P with column c of W; result stored at (r,c) of P'.
+__global__ void k_diffusion_step(const float4* __restrict__ P, const float4* __restrict__ W,
+                                 const int* __restrict__ P_rows, const int* __restrict__ W_cols,
+                                 float4* __restrict__ Pp, const int* __restrict__ Pp_rows, int nnz)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nnz) return;
+    const float4 data = P[y];
+    const int r = (int)data.y;
+    const int c = (int)data.x;
+    float mul = 0.0f;
+    int sp = P_rows[r], sw = W_cols[c];
+    if (sp >= 0 && sw >= 0) {
+        while (sp < nnz && sw < nnz) {
+            const float4 d1 = P[sp];
+            const float4 d2 = W[sw];
+            if ((int)d1.x != r || (int)d2.y != c) break;
+            mul += (d1.z * d2.z);
+            ++sp; ++sw;
+        }
+    }
+    mul *= data.z;
+    if (mul < kEpsG) mul = kEpsG;
+    int s = Pp_rows[r];
+    while (s >= 0 && s < nnz) {
+        const float4 dat = Pp[s];
+        if ((int)dat.x != r) break;
+        if ((int)dat.y == c) { Pp[s].z = mul; break; }
+        ++s;
+    }
+}
+
+// =================================================================================================
+// similarity_coll3D (line3D.cc:1600-1681): double geometry, float Gaussians.
+// =================================================================================================
+__device__ __forceinline__ float p2l_3D(const double* P1, const double* dir, const double* X)   // :1684-1691
+{
+    const double v0 = X[0] - P1[0], v1 = X[1] - P1[1], v2 = X[2] - P1[2];
+    const double s = v0 * dir[0] + v1 * dir[1] + v2 * dir[2];
+    const double d0 = (P1[0] + dir[0] * s) - X[0];
+    const double d1 = (P1[1] + dir[1] * s) - X[1];
+    const double d2 = (P1[2] + dir[2] * s) - X[2];
+    return (float)__builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+}
+__device__ __forceinline__ float lower_unc(const Hypothesis& h, float depth)   // view.cc:353-359
+{
+    return depth < h.median_depth ? h.k_lower * depth : h.k_lower * h.median_depth;
+}
+__device__ __forceinline__ float upper_unc(const Hypothesis& h, float depth)
+{
+    return depth < h.median_depth ? h.k_upper * depth : h.k_upper * h.median_depth;
+}
+__device__ __forceinline__ float gauss_term(const Hypothesis& h, float depth, float d, float two_log)
+{
+    const float lo = lower_unc(h, depth);
+    if (d < lo) return 1.0f;
+    const float up = upper_unc(h, depth);
+    const float sig = -(up - lo) * (up - lo) / two_log;         // view.cc:371-377
+    return c_expf(-(d - lo) * (d - lo) / (2.0f * sig));
+}
+
+__global__ void k_similarity(const Hypothesis* __restrict__ hyp, const int2* __restrict__ pairs, int n,
+                             float sigma_a, float two_log, float* __restrict__ sim)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Hypothesis& a = hyp[pairs[k].x];
+    const Hypothesis& b = hyp[pairs[k].y];
+    const float d1 = p2l_3D(b.P1, b.dir, a.P1);
+    const float d2 = p2l_3D(b.P1, b.dir, a.P2);
+    const float w12 = __builtin_fminf(gauss_term(a, a.depth_p1, d1, two_log), gauss_term(a, a.depth_p2, d2, two_log));
+    const float d3 = p2l_3D(a.P1, a.dir, b.P1);
+    const float d4 = p2l_3D(a.P1, a.dir, b.P2);
+    const float w34 = __builtin_fminf(gauss_term(b, b.depth_p1, d3, two_log), gauss_term(b, b.depth_p2, d4, two_log));
+    const float w_d = __builtin_fminf(w12, w34);
+    const double dd = a.dir[0] * b.dir[0] + a.dir[1] * b.dir[1] + a.dir[2] * b.dir[2];
+    float angle = (float)(c_acos(__builtin_fmax(__builtin_fmin(dd, 1.0), -1.0)) / 3.14159265358979323846 * (double)180.0f);
+    if (angle > 90.0f) angle = 180.0f - angle;
+    const float w_a = c_expf(-angle * angle / (2.0f * sigma_a * sigma_a));
+    const float s = __builtin_fminf(w_d, w_a);
+    sim[k] = s <= 0.01f ? 0.0f : s;
+}
+
+__global__ void k_test_math(const float* __restrict__ x, int n, float* __restrict__ e, float* __restrict__ ac, double* __restrict__ acd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    e[i] = c_expf(x[i]);
+    const float cl = __builtin_fmaxf(__builtin_fminf(x[i], 1.0f), -1.0f);
+    ac[i] = c_acosf(cl);
+    acd[i] = c_acos((double)cl);
+}
+
+// ---- launchers (host) ---------------------------------------------------------------------------
+void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st)
+{
+    dim3 grid((maxW + 255) / 256, (a.seg_end - a.seg_begin + kSrcPerBlock - 1) / kSrcPerBlock, a.n_tbm);
+    hipLaunchKernelGGL(k_pair_mask, grid, dim3(256), 0, st, a);
+}
+void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st)
+{
+    const int nrows = (a.seg_end - a.seg_begin) * a.n_tbm;
+    hipLaunchKernelGGL(k_row_count, dim3((nrows + 3) / 4), dim3(256), 0, st, a, rowcnt);
+}
+void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_exist_hist, dim3((n + 255) / 256), dim3(256), 0, st, ex, n, N, rowcnt);
+}
+void launch_scan(const int* in, int* out, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
+{
+    const int nrows = (a.seg_end - a.seg_begin) * a.n_tbm;
+    hipLaunchKernelGGL(k_pair_fill, dim3((nrows + 3) / 4), dim3(256), 0, st, a, row_start, meta, depths);
+}
+void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_exist_place, dim3((n + 255) / 256), dim3(256), 0, st, ex, n, N, row_start, meta, depths);
+}
+void launch_verify(const VerifyArgs& a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_verify, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a);
+}
+void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_seg_post, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_cnt, best);
+}
+void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kept_write, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, out);
+}
+void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_collinearity, dim3((S + 255) / 256, S), dim3(256), 0, st, segs, S, sigma_sqr, mask, W64, rowcnt);
+}
+void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
+                              const int* row_start, int* oi, int* oj, float* ow, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_collinearity_fill, dim3((S + 3) / 4), dim3(256), 0, st, segs, S, sigma_sqr, mask, W64, row_start, oi, oj, ow);
+}
+void launch_rownorm(float4* data, const int* start, int n, int nnz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rownorm, dim3((n + 3) / 4), dim3(256), 0, st, data, start, n, nnz);
+}
+void launch_diffusion_step(const float4* P, const float4* W, const int* P_rows, const int* W_cols, float4* Pp,
+                           const int* Pp_rows, int nnz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_diffusion_step, dim3((nnz + 255) / 256), dim3(256), 0, st, P, W, P_rows, W_cols, Pp, Pp_rows, nnz);
+}
+void launch_similarity(const Hypothesis* hyp, const int2* pairs, int n, float sigma_a, float two_log, float* sim, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_similarity, dim3((n + 255) / 256), dim3(256), 0, st, hyp, pairs, n, sigma_a, two_log, sim);
+}
+void launch_test_math(const float* x, int n, float* e, float* ac, double* acd, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_test_math, dim3((n + 255) / 256), dim3(256), 0, st, x, n, e, ac, acd);
+}
+
+}  // namespace l3d

@@ -1,0 +1,81 @@
+// l3d_kernels.hpp -- argument blocks and launchers shared by l3d_kernels.hip and l3d_capi.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace l3d {
+
+constexpr int kSrcPerBlock = 32;    // source segments walked by one k_pair_mask workgroup
+constexpr int kMaxW64 = 256;        // bit-row words per camera: up to 16384 segments per view
+constexpr int kVerifyTile = 256;    // witnesses staged in LDS per step of k_verify
+
+struct Match {                      // == l3d_match (include/line3d_amd.h)
+    uint32_t segID1, camID2, segID2;
+    float depths[4];
+    float confidence;
+};
+
+struct ExistRec {                   // an existing (reverse) match, localized and ranked by the host
+    int seg, cam;                   // source segment, LOCAL camera
+    uint32_t tgt;
+    int rank;                       // index inside its (seg,cam) run, ascending tgt
+    float d[4];
+};
+
+struct Hypothesis {                 // == l3d_hypothesis
+    double P1[3], P2[3], dir[3];
+    float depth_p1, depth_p2;
+    float k_lower, k_upper, median_depth;
+    uint32_t pad;
+};
+
+struct PairArgs {
+    const float4* src_segs;         // S_src
+    const float4* tgt_segs;         // concatenated neighbours
+    const int2* offsets;            // N x (start,count)
+    const float* F;                 // N x 9
+    const float* RtKinv;            // N x 9
+    const float* centers;           // N x 3
+    const float* RtKinv_src;        // 9
+    const float* C_src;             // 3
+    const int* tbm;                 // n_tbm local camera ids
+    unsigned long long* mask;       // [n_tbm][S_src][W64]
+    int S_src, N, n_tbm, W64;
+    int seg_begin, seg_end;
+};
+
+struct VerifyArgs {
+    const float4* src_segs;
+    const float4* tgt_segs;
+    const int2* offsets;
+    const float* P;                 // N x 12
+    const float* RtKinv_src;
+    const float* C_src;
+    const int* row_start;           // [S_src*N + 1]
+    const uint2* cand_meta;         // (tgt, cam)
+    const float4* cand_depths;
+    float* cand_conf;
+    int N, seg_begin, seg_end;
+    float sigma_p, sigma_a, spatial_k;
+};
+
+void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
+void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
+void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
+void launch_scan(const int* in, int* out, int n, hipStream_t st);
+void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
+void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
+void launch_verify(const VerifyArgs& a, hipStream_t st);
+void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);
+void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);
+void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
+void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
+                              const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);
+void launch_rownorm(float4* data, const int* start, int n, int nnz, hipStream_t st);
+void launch_diffusion_step(const float4* P, const float4* W, const int* P_rows, const int* W_cols, float4* Pp,
+                           const int* Pp_rows, int nnz, hipStream_t st);
+void launch_similarity(const Hypothesis* hyp, const int2* pairs, int n, float sigma_a, float two_log, float* sim, hipStream_t st);
+void launch_test_math(const float* x, int n, float* e, float* ac, double* acd, hipStream_t st);
+
+}  // namespace l3d

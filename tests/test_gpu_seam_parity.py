@@ -1,0 +1,138 @@
+"""GPU parity of the three seam functions (+ similarity batch) against the CPU oracle, through the C ABI.
+Bar: bit-exact (match ids, depths, confidences, median; collinearity weights; diffusion values)."""
+import numpy as np
+import pytest
+
+import l3d_oracle_pipeline as op
+
+pytestmark = pytest.mark.gpu
+
+
+def test_contract_math_bit_exact(gpu_ctx, oracle_lib):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([-rng.random(20000) * 3.0, -rng.random(2000) * 90.0, rng.random(20000) * 2 - 1,
+                        [0.0, -0.0, 1.0, -1.0, 0.5, -0.5, -87.5, -86.9]]).astype(np.float32)
+    e, ac, acd = gpu_ctx.test_contract_math(x)
+    xc = np.clip(x, -1, 1)
+    e_o = np.array([oracle_lib.l3do_test_expf(float(v)) for v in x], dtype=np.float32)
+    ac_o = np.array([oracle_lib.l3do_test_acosf(float(v)) for v in xc], dtype=np.float32)
+    acd_o = np.array([oracle_lib.l3do_test_acos(float(v)) for v in xc], dtype=np.float64)
+    assert np.array_equal(e.view(np.uint32), e_o.view(np.uint32))
+    assert np.array_equal(ac.view(np.uint32), ac_o.view(np.uint32))
+    assert np.array_equal(acd.view(np.uint64), acd_o.view(np.uint64))
+
+
+def test_collinearity_matches_oracle(gpu_ctx, oracle_lib, small_scene):
+    for v in small_scene.views[:3]:
+        segs = v["segments"]
+        rel = op.collinearity(oracle_lib, segs, 2.0)
+        ii, jj = np.nonzero(np.triu(rel > 0, 1))
+        gi, gj, gw = gpu_ctx.compute_collinearity(segs, 2.0)
+        assert np.array_equal(gi, ii.astype(np.int32)) and np.array_equal(gj, jj.astype(np.int32))
+        assert np.array_equal(gw.view(np.uint32), rel[jj, ii].view(np.uint32))
+
+
+def test_collinearity_structured(gpu_ctx, oracle_lib):
+    # collinear but non-overlapping pieces of the same lines, plus overlapping and crossing ones
+    segs = []
+    for k in range(40):
+        x0, y0, dx, dy = 50.0 + 13 * k, 30.0 + 7 * k, np.cos(0.1 * k), np.sin(0.1 * k)
+        for a, b in ((0, 40), (55, 90), (30, 60), (120, 200)):
+            segs.append([x0 + a * dx, y0 + a * dy, x0 + b * dx, y0 + b * dy])
+    segs = np.array(segs, dtype=np.float32)
+    rel = op.collinearity(oracle_lib, segs, 2.0)
+    ii, jj = np.nonzero(np.triu(rel > 0, 1))
+    assert len(ii) > 40
+    gi, gj, gw = gpu_ctx.compute_collinearity(segs, 2.0)
+    assert np.array_equal(gi, ii.astype(np.int32)) and np.array_equal(gj, jj.astype(np.int32))
+    assert np.array_equal(gw.view(np.uint32), rel[jj, ii].view(np.uint32))
+
+
+def _run_view(ctx, tr, seg_range=None):
+    mv = tr["marshal"]
+    return ctx.compute_pairwise_matches(mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"],
+                                        mv["F"], mv["RtKinv"], mv["centers"], mv["P"], mv["tbm"], tr["in_matches"],
+                                        mv["l2g"], mv["k_upper"], mv["k_lower"], 3.5, 10.0, mv["spatial_k"],
+                                        median_depth=1.0, seg_range=seg_range, want_best=True)
+
+
+def test_pairwise_matches_bit_exact_per_view(gpu_ctx, small_oracle):
+    total = 0
+    for v in sorted(small_oracle.trace):
+        tr = small_oracle.trace[v]
+        got, med, _ = _run_view(gpu_ctx, tr)
+        exp = tr["matches"]
+        assert len(got) == len(exp), "view %d: %d vs %d kept" % (v, len(got), len(exp))
+        assert got.tobytes() == exp.tobytes(), "view %d differs" % v
+        assert np.float32(med) == np.float32(tr["median"])
+        total += len(got)
+    assert total > 1000
+
+
+def test_pairwise_matches_segment_ranges_concatenate(gpu_ctx, small_oracle):
+    """Sharding by source-segment range is exact: the ranges' outputs concatenate to the full output
+    and the merged best-depth lists give the same median."""
+    tr = small_oracle.trace[4]
+    full, med, best = _run_view(gpu_ctx, tr)
+    S = len(tr["marshal"]["src_segs"])
+    parts, bests = [], []
+    for s0, s1 in ((0, 97), (97, 200), (200, S)):
+        m, _, b = _run_view(gpu_ctx, tr, (s0, s1))
+        parts.append(m)
+        bests.append(b)
+    cat = np.concatenate(parts)
+    assert cat.tobytes() == full.tobytes()
+    allb = np.sort(np.concatenate(bests))
+    assert np.array_equal(np.sort(best), allb)
+    assert np.float32(allb[len(allb) // 2]) == np.float32(med)
+
+
+def test_pairwise_matches_edge_cases(gpu_ctx, small_oracle):
+    tr = small_oracle.trace[9]            # last view: nothing to match -> list returned untouched
+    assert len(tr["marshal"]["tbm"]) == 0
+    got, med, _ = _run_view(gpu_ctx, tr)
+    assert got.tobytes() == tr["in_matches"].tobytes() and med == 1.0
+    # empty source range
+    tr = small_oracle.trace[2]
+    got, med, best = _run_view(gpu_ctx, tr, (5, 5))
+    assert len(got) == 0 and len(best) == 0
+
+
+def test_rdd_matches_oracle(gpu_ctx, oracle_lib, small_oracle):
+    A = small_oracle.affinity
+    n = len(small_oracle.local2global)
+    exp = op.rdd(oracle_lib, A, n, 10)
+    got = gpu_ctx.replicator_dynamics_diffusion(A, n, 10)
+    assert got.tobytes() == exp.tobytes()
+    # toy matrix with ragged rows (positional product quirk is exercised when row/col lengths differ)
+    rng = np.random.default_rng(5)
+    e = []
+    for i in range(30):
+        for j in rng.choice(30, size=rng.integers(1, 6), replace=False):
+            e.append((i, int(j), rng.random()))
+    e = np.array(e, dtype=op.EDGE_DTYPE)
+    rows = set(e["i"].tolist())
+    e = np.concatenate([e, np.array([(k, k, 0.5) for k in range(30) if k not in rows], dtype=op.EDGE_DTYPE)])
+    assert gpu_ctx.replicator_dynamics_diffusion(e, 30, 3).tobytes() == op.rdd(oracle_lib, e, 30, 3).tobytes()
+
+
+def test_similarity_batch_matches_oracle(gpu_ctx, small_oracle):
+    from line3d_amd import capi
+    o = small_oracle
+    keys = sorted(o.best_match)
+    hyp = np.zeros(len(keys), dtype=capi.HYP_DTYPE)
+    for k, key in enumerate(keys):
+        b = o.best_match[key]
+        v = o.views[b["cam"]]
+        hyp[k]["P1"], hyp[k]["P2"], hyp[k]["dir"] = b["seg3D"][0:3], b["seg3D"][3:6], b["seg3D"][6:9]
+        hyp[k]["depth_p1"], hyp[k]["depth_p2"] = b["depths"]
+        hyp[k]["k_lower"], hyp[k]["k_upper"], hyp[k]["median_depth"] = v.k_lower, v.k_upper, v.median_depth
+    rng = np.random.default_rng(11)
+    pairs = rng.integers(0, len(keys), size=(4000, 2)).astype(np.int32)
+    idx = {key: k for k, key in enumerate(keys)}
+    real = [(idx[s], idx[t]) for s in keys[:400] for t in o.potential.get(s, {}) if t in idx]
+    pairs = np.concatenate([pairs, np.array(real, dtype=np.int32)])
+    got = gpu_ctx.similarity_coll3D_batch(hyp, pairs, 10.0)
+    exp = np.array([o._similarity(o.best_match[keys[a]], o.best_match[keys[b]]) for a, b in pairs], dtype=np.float32)
+    assert (exp > 0).sum() > 100
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
