@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- Line3D matching hot path (matchViews: stage 1 pair test + stage 2 verification + filter +
+host bookkeeping) on synthetic helix scenes.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full matchViews pass over the scene.  Workload: BASELINE.json configs[1] per GPU --
+64*N views x 2000 segments, 12 neighbours (N=1: config 2 itself; N=8: config 3) -> weak scaling.
+For N>1 every rank holds the whole (replicated) host state, computes a 1/N source-segment range of each
+view on its GPU and the per-view kept lists are all-gathered over RCCL before the (replicated) commit.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views-per-gpu", type=int, default=64)
+    ap.add_argument("--segments", type=int, default=2000)
+    ap.add_argument("--neighbors", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=20260)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-segments", type=int, default=96)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, n_neighbors, sample_segments):
+    """The oracle (scalar C restatement of the reference formulation, 1 thread) on a bounded sample of the same
+    workload: view 0 of the scene, the first `sample_segments` source segments against all its neighbours,
+    stage 1 + sort + stage 2 + filter.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import l3d_oracle_pipeline as op
+    o = op.OracleLine3D(matching_neighbors=n_neighbors, use_collinearity=False)
+    for v in scene.views[: n_neighbors + 1]:
+        sims = {k: s for k, s in v["sims"].items() if k <= n_neighbors}
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], sims)
+    o.computation = True
+    o.matched, o.potential = {}, {}
+    o.find_visual_neighbors()
+    o.transform_geometry()
+    vid = scene.views[0]["id"]
+    for n in o.visual_neighbors[vid]:
+        o._fundamental(vid, n)
+    mv = o.marshal_view(vid)
+    t0 = time.time()
+    m, med, stats = op.compute_pairwise_matches(
+        o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
+        mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"],
+        3.5, 10.0, mv["spatial_k"], seg_range=(0, sample_segments), want_stats=True)
+    dt = time.time() - t0
+    return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port",
+                sample="view 0 of the bench scene, first %d of %d source segments x %d neighbours: %d pairs, %d raw candidates, "
+                       "%.3g verify inner iterations, %.1f s on 1 thread (oracle/l3d_oracle.c, reference formulation)"
+                       % (sample_segments, len(mv["src_segs"]), len(mv["tbm"]), int(stats[3]), int(stats[0]), stats[2], dt),
+                seconds=dt, verify_iterations_per_s=stats[2] / dt)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+    if args.gpus != n_gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from line3d_amd import distributed as l3dist
+
+    V = args.views_per_gpu * n_gpus
+    scene = make_scene(V, args.segments, args.neighbors, seed=args.seed)
+    l3d = Line3D("", matchingNeighbors=args.neighbors, device=local_rank)
+    t0 = time.time()
+    load_scene(l3d, scene)               # uploads segments, per-view collinearity (HIP)
+    l3d.prepare()                        # neighbours, scene normalisation; inputs become HBM-resident
+    t_setup = time.time() - t0
+    ctx = l3d.context()
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        if world > 1:
+            l3dist.match_views_sharded(l3d, rank, world, dist)
+        else:
+            l3d.match_views()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    st = l3d.stats()
+    prof = {} if args.no_profile else ctx.profile_all()
+    ctx.profile_enable(False)
+
+    # whole-job pairs per step: every rank evaluates its 1/N share of every view's pairs
+    pairs_local = st["pairs"]
+    pairs_total = pairs_local
+    raw_local = st["raw"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([pairs_local, raw_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        pairs_total, raw_total = float(t[0].item()), float(t[1].item())
+    else:
+        raw_total = raw_local
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = pairs_total * args.steps / dt
+        # dominant kernel = the one with the largest summed duration on this rank
+        roof = None
+        if prof:
+            name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
+            # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): per view, R candidates
+            R_per_launch = raw_local / max(1, len(scene.views))
+            pairs_per_launch = pairs_local / max(1, len(scene.views))
+            alg = {
+                "verify": 44.0 * R_per_launch,           # meta 8 + depths 16 + target segment 16 read, confidence 4 written
+                "pair_mask": pairs_per_launch / 8.0 + 16.0 * 2 * args.segments * args.neighbors / 2,  # bit rows + segments
+                "pair_fill": (24.0 + 8.0) * R_per_launch,
+            }.get(name, 0.0)
+            avg_ms = ms / max(1, launches)
+            achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+                        traffic=None, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
+                        note="path is FP32-VALU bound, not HBM bound (SURVEY.md 8d); see kernels_ms for the split",
+                        kernels_ms={k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]})
+        out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="BASELINE configs[%d]: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
+                                        % (1 if n_gpus == 1 else 2, V, args.segments, args.neighbors),
+                               views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
+                               parallelism="replicas of host state, source-segment ranges sharded x%d, RCCL all-gather of kept lists" % n_gpus
+                               if n_gpus > 1 else "single GPU"),
+                   views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
+                   kept_per_step=st["kept"], setup_s=t_setup,
+                   host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))
+        if roof:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments)
+        print(json.dumps(out))
+    l3d.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,57 @@ int l3d_last_stats(l3d_ctx* ctx, double stats[4]);
 /* contract math exported for tests (device evaluation of c_expf / c_acosf / c_acos) */
 int l3d_test_contract_math(l3d_ctx* ctx, const float* x, int n, float* out_expf, float* out_acosf, double* out_acos);
 
+/* =================================================================================================
+ * Host pipeline behind the reference's public operator interface, class L3D::Line3D
+ * (line3D.h:61-101): the same calls, argument meaning and error behaviour, with plain arrays in
+ * place of cv::Mat / Eigen / std::list.  include/line3D_amd.hpp wraps these in a C++ class named
+ * L3D::Line3D.  Images are replaced by their detected segments (the LSD front end is out of
+ * scope): `segments` is what detectLineSegments would have produced (line3D.cc:1789-1871).
+ * K, R (3x3 row-major) and t are doubles like the reference's Eigen arguments.
+ * ================================================================================================= */
+typedef struct l3d_line3d l3d_line3d;
+
+/* Line3D::Line3D (line3D.cc:6-48); defaults commons.h:42-61.  Owns one l3d_ctx on `device`. */
+int l3d_line3d_create(int device, int matching_neighbors, float uncertainty_t_upper_2D, float uncertainty_t_lower_2D,
+                      float sigma_p, float sigma_a, float min_baseline, int use_collinearity, int verbose,
+                      l3d_line3d** out);
+void l3d_line3d_destroy(l3d_line3d* h);
+const char* l3d_line3d_last_error(const l3d_line3d* h);
+l3d_ctx* l3d_line3d_context(l3d_line3d* h);
+int l3d_line3d_reset(l3d_line3d* h);                                             /* line3D.cc:62-92 */
+int l3d_line3d_num_cameras(const l3d_line3d* h);                                 /* line3D.h:98 */
+/* Line3D::addImage (line3D.cc:95-217) and addImage_fixed_sim (line3D.cc:220-342) */
+int l3d_line3d_add_image(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height,
+                         const float* segments, int n_segments, const double* K, const double* R, const double* t,
+                         const uint32_t* worldpoint_ids, int n_worldpoints);
+int l3d_line3d_add_image_fixed_sim(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height,
+                                   const float* segments, int n_segments, const double* K, const double* R, const double* t,
+                                   const uint32_t* sim_ids, const float* sims, int n_sims);
+/* Line3D::compute3Dmodel (line3D.cc:345-374) = prepare + match_views + finish */
+int l3d_line3d_compute3Dmodel(l3d_line3d* h, int perform_diffusion);
+int l3d_line3d_prepare(l3d_line3d* h);          /* findVisualNeighbors + transformGeometry; inputs become HBM-resident */
+int l3d_line3d_match_views(l3d_line3d* h);      /* Line3D::matchViews, line3D.cc:620-648 (re-runnable) */
+int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion);   /* optimizeLocalMatches + clusterSegments2D */
+/* step-wise matchViews for view sharding: begin; for each view in match_order: compute a source-segment
+ * range, (all-gather), commit the merged kept list; end. */
+int l3d_line3d_match_begin(l3d_line3d* h, int* n_order);
+int l3d_line3d_match_order(l3d_line3d* h, uint32_t* view_ids, int* n_segments);
+int l3d_line3d_view_num_to_be_matched(l3d_line3d* h, uint32_t view_id);
+int l3d_line3d_match_view_compute(l3d_line3d* h, uint32_t view_id, int seg_begin, int seg_end,
+                                  l3d_match** out, int* n_out, float* median, float** best_depths, int* n_best);
+int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_match* matches, int n,
+                                 const float* best_depths, int n_best, float median);
+int l3d_line3d_match_end(l3d_line3d* h);
+/* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */
+int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d);
+int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, double* seg3d, uint32_t* seg2d);
+int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4]);
+/* inspection */
+int l3d_line3d_keep_view_matches(l3d_line3d* h, int on);
+int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median);
+int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes);
+int l3d_line3d_stats(const l3d_line3d* h, double* stats12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1075 @@
+// line3d_host.cpp -- host side of the hot path above the C ABI: the L3D::Line3D pipeline
+// (line3D.cc, view.cc) re-built on flat arrays.  It mirrors the reference's operator interface
+// (addImage / addImage_fixed_sim / compute3Dmodel / getResult) and its order-dependent semantics
+// (toBeMatched, reverse-match propagation, only-best overwrite, first-touch node numbering), and
+// calls the HIP path exclusively through include/line3d_amd.h.  Cited line numbers refer to the
+// reference files under /root/reference.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/line3d_amd.h"
+#include "l3d_linalg.hpp"
+
+using namespace l3d::la;
+
+namespace {
+
+typedef uint64_t Key;   // (camID << 32) | segID : orders like L3DSegment2D::operator< (commons.h:92-94)
+inline Key mk(uint32_t cam, uint32_t seg) { return ((Key)cam << 32) | seg; }
+inline uint32_t kcam(Key k) { return (uint32_t)(k >> 32); }
+inline uint32_t kseg(Key k) { return (uint32_t)k; }
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct View {                                   // L3DView, view.h:40-153
+    uint32_t id = 0;
+    int index = 0;                              // dense index in ascending id order (set in prepare)
+    M3 K, R, Kinv, Rt, RtKinv;
+    V3 t, C;
+    double P[12];
+    unsigned width = 0, height = 0;
+    double pp[2];
+    float unc_upper_px = 0, unc_lower_px = 0, k_upper = 0, k_lower = 0, median_depth = 1.0f;
+    std::vector<float> segs;                    // S x 4
+    std::vector<int> coll_start;                // CSR of segment2collinearities_ (segments.h:84-97)
+    std::vector<int> coll_other;
+    std::vector<float> coll_w;
+    bool store_exists = false;                  // the "_raw.bin" match file
+    std::vector<l3d_match> store;
+    std::vector<float> nb_segs;                 // concatenated neighbour segments (resident on the GPU)
+    int S() const { return (int)(segs.size() / 4); }
+
+    void derive()                               // view.cc:24-34 / :243-257
+    {
+        Kinv = inverse(K);
+        Rt = transpose(R);
+        RtKinv = mul(Rt, Kinv);
+        C = mul(Rt, V3{ -1.0 * t.x, -1.0 * t.y, -1.0 * t.z });
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                const double col[3] = { c < 3 ? R(0, c) : t.x, c < 3 ? R(1, c) : t.y, c < 3 ? R(2, c) : t.z };
+                for (int k = 0; k < 3; ++k) s += K(r, k) * col[k];
+                P[r * 4 + c] = s;
+            }
+        k_upper = (float)specific_k(unc_upper_px);     // defineSpatialUncertainty, view.cc:90-121
+        k_lower = (float)specific_k(unc_lower_px);
+    }
+    double specific_k(double dist_px) const        // view.cc:124-147
+    {
+        V3 n = mul(RtKinv, V3{ pp[0], pp[1], 1.0 });
+        n = n / norm(n);
+        const V3 Pl = C + n;
+        V3 d = mul(RtKinv, V3{ pp[0] + dist_px, pp[1], 1.0 });
+        d = d / norm(d);
+        const double tt = (dot(Pl, n) - dot(n, C)) / dot(n, d);
+        const V3 Q = C + tt * d;
+        return norm(Pl - Q);
+    }
+    void transform(const double* Qinv, double scale)   // view.cc:227-261
+    {
+        t = t * scale;
+        double Rt34[12], out[12];
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rt34[r * 4 + c] = R(r, c); }
+        Rt34[3] = t.x; Rt34[7] = t.y; Rt34[11] = t.z;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Rt34[r * 4 + k] * Qinv[k * 4 + c];
+                out[r * 4 + c] = s;
+            }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = out[r * 4 + c];
+        t = { out[3], out[7], out[11] };
+        derive();
+    }
+};
+
+struct Hyp {                                    // L3DCorrespondenceRRW + L3DSegment3D, commons.h:69-160
+    Key src;
+    float score;
+    V3 P1, P2, dir;
+    float depth_p1, depth_p2;
+};
+
+struct FinalLine {
+    std::vector<Key> segs2D;
+    std::vector<std::pair<V3, V3>> segs3D;
+};
+
+}  // namespace
+
+struct l3d_line3d {
+    l3d_ctx* ctx = nullptr;
+    std::string err;
+    bool verbose = false;
+    // parameters, line3D.cc:6-31
+    int matching_neighbors = 10;
+    float unc_upper = 5.0f, unc_lower = 1.0f, sigma_p = 3.5f, sigma_a = 10.0f, min_baseline = 0.25f;
+    bool use_collinearity = true;
+    bool computation = false;
+    bool prepared = false;
+
+    std::map<uint32_t, View> views;
+    std::vector<View*> vlist;                                  // ascending id
+    std::map<uint32_t, std::map<uint32_t, float>> view_similarities;
+    std::map<uint32_t, unsigned> num_wps;
+    std::map<uint32_t, std::map<uint32_t, unsigned>> common_wps;
+    std::unordered_map<uint32_t, std::vector<uint32_t>> worldpoints2views;   // ascending by construction? no: sorted on use
+    std::map<uint32_t, std::vector<uint32_t>> visual_neighbors; // ascending ids
+    std::map<uint64_t, M3> fundamentals;                       // (a<<32|b)
+    std::set<uint64_t> matched;                                // (a<<32|b): matched_[a][b]
+
+    // geometry transformation
+    double transf_scale_inv = 1.0;
+    M3 transf_Rinv = identity3();
+    V3 transf_tneg;
+
+    // matching products
+    std::vector<uint32_t> order;                               // views with >=1 neighbour, ascending
+    std::vector<std::vector<std::pair<uint32_t, Key>>> pot;    // per view index: (seg, other key), potential_correspondences_
+    std::vector<std::pair<Key, Key>> pot_foreign;              // keys whose camera is not a view (early-return quirk)
+    std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
+    bool keep_view_matches = false;
+
+    // final hypotheses
+    std::vector<Hyp> hyps;                                     // best_match_ in key order
+    std::vector<std::vector<int>> best_idx;                    // per view index: seg -> hyp index or -1
+    std::vector<l3d_edge> A;
+    std::vector<Key> local2global;
+    std::vector<FinalLine> result;
+
+    // statistics
+    double stat_pairs = 0, stat_raw = 0, stat_kept = 0;
+    double t_match = 0, t_gpu_call = 0, t_commit = 0, t_finalize = 0, t_affinity = 0, t_cluster = 0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    View* find_view(uint32_t id) { auto it = views.find(id); return it == views.end() ? nullptr : &it->second; }
+    bool vn_has(uint32_t a, uint32_t b) const
+    {
+        auto it = visual_neighbors.find(a);
+        return it != visual_neighbors.end() && std::binary_search(it->second.begin(), it->second.end(), b);
+    }
+};
+
+namespace {
+
+typedef l3d_line3d L;
+
+// ------------------------------------------------------------------------------------------------
+int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
+              const double* K, const double* R, const double* t)
+{
+    View v;
+    v.id = id;
+    memcpy(v.K.m, K, 72);
+    memcpy(v.R.m, R, 72);
+    v.t = { t[0], t[1], t[2] };
+    v.width = width; v.height = height;
+    v.pp[0] = (double)((float)width / 2.0f);        // view.cc:20-21
+    v.pp[1] = (double)((float)height / 2.0f);
+    v.unc_upper_px = h->unc_upper; v.unc_lower_px = h->unc_lower;
+    v.segs.assign(segs, segs + (size_t)n * 4);
+    v.coll_start.assign((size_t)n + 1, 0);
+    if (h->use_collinearity && n > 1) {             // L3DSegments ctor, segments.h:73-101
+        int32_t *ci = nullptr, *cj = nullptr; float* cw = nullptr; int cn = 0;
+        int rc = l3d_compute_collinearity(h->ctx, v.segs.data(), n, L3D_DEF_COLLINEARITY_S, &ci, &cj, &cw, &cn);
+        if (rc) return h->fail(rc, std::string("collinearity: ") + l3d_last_error(h->ctx));
+        std::vector<int> cnt((size_t)n, 0);
+        for (int k = 0; k < cn; ++k) { cnt[ci[k]]++; cnt[cj[k]]++; }
+        for (int s = 0; s < n; ++s) v.coll_start[s + 1] = v.coll_start[s] + cnt[s];
+        v.coll_other.resize((size_t)v.coll_start[n]);
+        v.coll_w.resize((size_t)v.coll_start[n]);
+        std::vector<int> cur(v.coll_start.begin(), v.coll_start.end() - 1);
+        // triplets come sorted by (i,j), i<j: for a segment s its partners j>s arrive ascending, and its
+        // partners i<s arrive ascending (ascending i) and before them in index order -> fill lower part first
+        for (int k = 0; k < cn; ++k) { const int s = cj[k]; v.coll_other[cur[s]] = ci[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
+        for (int k = 0; k < cn; ++k) { const int s = ci[k]; v.coll_other[cur[s]] = cj[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
+        l3d_free(ci); l3d_free(cj); l3d_free(cw);
+    }
+    v.derive();
+    h->views[id] = std::move(v);
+    return L3D_OK;
+}
+
+// Line3D::processWorldpointList, line3D.cc:1874-1935
+void process_worldpoints(L* h, uint32_t viewID, const uint32_t* wps, int n)
+{
+    h->num_wps[viewID] = 0;
+    for (int i = 0; i < n; ++i) {
+        std::vector<uint32_t>& w2v = h->worldpoints2views[wps[i]];
+        std::sort(w2v.begin(), w2v.end());
+        if (w2v.size() == 2) {
+            const uint32_t v1 = w2v[0], v2 = w2v[1];
+            h->common_wps[v1][v2] += 1;
+            h->common_wps[v2][v1] += 1;
+            ++h->num_wps[v1];
+            ++h->num_wps[v2];
+        }
+        if (w2v.size() >= 2) {
+            for (uint32_t v : w2v) {
+                h->common_wps[v][viewID] += 1;
+                h->common_wps[viewID][v] += 1;
+            }
+            ++h->num_wps[viewID];
+        }
+        if (std::find(w2v.begin(), w2v.end(), viewID) == w2v.end()) w2v.push_back(viewID);
+    }
+}
+
+// Line3D::findVisualNeighbors, line3D.cc:476-549
+void find_visual_neighbors(L* h)
+{
+    h->visual_neighbors.clear();
+    for (auto& it : h->common_wps) {
+        if (h->view_similarities.count(it.first)) continue;
+        for (auto& n : it.second) {
+            const float sim = 2.0f * float(n.second) / float(h->num_wps[it.first] + h->num_wps[n.first]);
+            if (sim > 1e-12) h->view_similarities[it.first][n.first] = sim;
+        }
+    }
+    struct VN { uint32_t cam; float sim; };
+    for (auto& sit : h->view_similarities) {
+        View* self = h->find_view(sit.first);
+        std::vector<VN> vn;
+        if (self) {
+            for (auto& n : sit.second) {
+                View* o = h->find_view(n.first);
+                if (!o || !((float)norm(self->C - o->C) > h->min_baseline)) continue;
+                bool ok = true;
+                for (const VN& e : vn)
+                    if ((float)norm(h->find_view(e.cam)->C - o->C) <= h->min_baseline) { ok = false; break; }
+                if (ok) vn.push_back({ n.first, n.second });
+            }
+        }
+        std::stable_sort(vn.begin(), vn.end(), [](const VN& a, const VN& b) { return a.sim > b.sim; });
+        if (h->matching_neighbors > 0 && (int)vn.size() > h->matching_neighbors) vn.resize((size_t)h->matching_neighbors);
+        std::vector<uint32_t>& out = h->visual_neighbors[sit.first];
+        for (const VN& e : vn) out.push_back(e.cam);
+        std::sort(out.begin(), out.end());
+    }
+}
+
+// Line3D::transformGeometry + findSimilarityTransform + euclideanTransformation + applyTransformation,
+// line3D.cc:552-617, 1694-1779
+int transform_geometry(L* h)
+{
+    h->fundamentals.clear();
+    const double size = (double)h->views.size();
+    std::vector<V3> in_pts;
+    V3 m;
+    for (auto& kv : h->views) { m = m + kv.second.C; in_pts.push_back(kv.second.C); }
+    m = m / size;
+    double q = 0.0;
+    for (auto& p : in_pts) q += norm(p - m);
+    q /= size;
+    q = (double)sqrtf(2.0f) / q;
+    std::vector<V3> out_pts;
+    V3 cog_out;
+    for (auto& p : in_pts) {
+        const V3 t3 = { q * p.x + (-q * m.x), q * p.y + (-q * m.y), q * p.z + (-q * m.z) };
+        cog_out = cog_out + t3;
+        out_pts.push_back(t3);
+    }
+    cog_out = cog_out / size;
+    const size_t n = in_pts.size();
+    double scales_sum = 0.0;
+    for (size_t i = 0; i < n; ++i) scales_sum += norm(out_pts[i] - cog_out) / norm(in_pts[i] - m);
+    const double scale = scales_sum / double(n);
+    const V3 cog_in = m * scale;
+    M3 H;
+    for (size_t i = 0; i < n; ++i) {
+        const V3 a = in_pts[i] * scale - cog_in, b = out_pts[i] - cog_out;
+        const double bv[3] = { b.x, b.y, b.z }, av[3] = { a.x, a.y, a.z };
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H(r, c) += bv[r] * av[c];
+    }
+    M3 U, V; double s[3];
+    l3d::la::svd3(H, U, s, V);
+    M3 Vt = transpose(V);
+    M3 Rm = mul(U, Vt);
+    if (det(Rm) < 0) { for (int c = 0; c < 3; ++c) Vt(2, c) *= -1; Rm = mul(U, Vt); }
+    V3 tt = cog_out - mul(Rm, cog_in);
+    tt = tt / scale;
+    double Q[16] = { Rm(0, 0), Rm(0, 1), Rm(0, 2), tt.x * scale, Rm(1, 0), Rm(1, 1), Rm(1, 2), tt.y * scale,
+                     Rm(2, 0), Rm(2, 1), Rm(2, 2), tt.z * scale, 0, 0, 0, 1 };
+    double Qinv[16];
+    if (!inverse4(Q, Qinv)) return h->fail(L3D_ERR_INVALID, "transformGeometry: singular similarity transform");
+    h->transf_scale_inv = 1.0 / scale;
+    h->transf_Rinv = transpose(Rm);
+    h->transf_tneg = tt * -1.0;
+    for (auto& kv : h->views) kv.second.transform(Qinv, scale);
+    return L3D_OK;
+}
+
+V3 inverse_transform(const L* h, V3 P) { return mul(h->transf_Rinv, P * h->transf_scale_inv + h->transf_tneg); }   // :1782-1786
+
+// Line3D::fundamental, line3D.cc:1968-1993 (+ cache both ways, :1949-1965)
+const M3& fundamental(L* h, uint32_t a, uint32_t b)
+{
+    const uint64_t key = ((uint64_t)a << 32) | b;
+    auto it = h->fundamentals.find(key);
+    if (it != h->fundamentals.end()) return it->second;
+    const View& v1 = h->views[a];
+    const View& v2 = h->views[b];
+    const M3 R = mul(v2.R, transpose(v1.R));
+    const V3 t = v2.t - mul(R, v1.t);
+    M3 T;
+    T(0, 0) = 0.0;  T(0, 1) = -t.z; T(0, 2) = t.y;
+    T(1, 0) = t.z;  T(1, 1) = 0.0;  T(1, 2) = -t.x;
+    T(2, 0) = -t.y; T(2, 1) = t.x;  T(2, 2) = 0.0;
+    const M3 E = mul(T, R);
+    const M3 F = mul(mul(inverse(transpose(v2.K)), E), inverse(v1.K));
+    h->fundamentals[((uint64_t)b << 32) | a] = transpose(F);
+    return h->fundamentals[key] = F;
+}
+
+// The float tables of performMatching, line3D.cc:716-803
+struct Marshal {
+    std::vector<float> F, RtKinv, P, centers;
+    std::vector<int32_t> offsets, tbm;
+    std::vector<uint32_t> l2g;
+    float RtKinv_src[9], C_src[3];
+    float spatial_k;
+};
+
+void marshal_view(L* h, View& v, Marshal& m)
+{
+    const std::vector<uint32_t>& nbs = h->visual_neighbors[v.id];
+    const size_t N = nbs.size();
+    m.F.resize(N * 9); m.RtKinv.resize(N * 9); m.P.resize(N * 12); m.centers.resize(N * 3);
+    m.offsets.resize(N * 2); m.l2g.resize(N); m.tbm.clear();
+    int total = 0;
+    for (size_t loc = 0; loc < N; ++loc) {
+        const uint32_t nb = nbs[loc];
+        const View& o = h->views[nb];
+        m.l2g[loc] = nb;
+        if (!h->matched.count(((uint64_t)v.id << 32) | nb)) m.tbm.push_back((int32_t)loc);
+        const M3& F = fundamental(h, v.id, nb);
+        for (int k = 0; k < 9; ++k) { m.F[loc * 9 + k] = (float)F.m[k]; m.RtKinv[loc * 9 + k] = (float)o.RtKinv.m[k]; }
+        for (int k = 0; k < 12; ++k) m.P[loc * 12 + k] = (float)o.P[k];
+        m.centers[loc * 3 + 0] = (float)o.C.x; m.centers[loc * 3 + 1] = (float)o.C.y; m.centers[loc * 3 + 2] = (float)o.C.z;
+        m.offsets[loc * 2] = total; m.offsets[loc * 2 + 1] = o.S();
+        total += o.S();
+    }
+    for (int k = 0; k < 9; ++k) m.RtKinv_src[k] = (float)v.RtKinv.m[k];
+    m.C_src[0] = (float)v.C.x; m.C_src[1] = (float)v.C.y; m.C_src[2] = (float)v.C.z;
+    m.spatial_k = (float)v.specific_k((double)(2.0f * h->sigma_p));     // line3D.cc:820
+}
+
+// loadAndLocalizeExistingMatches, view.cc:200-224
+void localized_existing(L* h, View& v, std::vector<l3d_match>& out)
+{
+    out.clear();
+    if (!v.store_exists) return;
+    const std::vector<uint32_t>& nbs = h->visual_neighbors[v.id];
+    for (const l3d_match& mm : v.store) {
+        auto it = std::lower_bound(nbs.begin(), nbs.end(), mm.camID2);
+        if (it != nbs.end() && *it == mm.camID2) {
+            l3d_match x = mm;
+            x.camID2 = (uint32_t)(it - nbs.begin());
+            out.push_back(x);
+        }
+    }
+}
+
+// L3DView::addMatches(matches, remove_old, only_best), view.cc:162-197
+void add_matches(View& v, const l3d_match* m, size_t n, bool remove_old, bool only_best)
+{
+    std::vector<l3d_match> tmp;
+    if (only_best) {
+        // per segID1 (ascending): first match with the highest confidence in list order (stable sort, front)
+        std::map<uint32_t, size_t> best;
+        for (size_t i = 0; i < n; ++i) {
+            auto it = best.find(m[i].segID1);
+            if (it == best.end()) best[m[i].segID1] = i;
+            else if (m[i].confidence > m[it->second].confidence) it->second = i;
+        }
+        for (auto& kv : best) tmp.push_back(m[kv.second]);
+        m = tmp.data(); n = tmp.size();
+    }
+    if (v.store_exists && !remove_old) v.store.insert(v.store.end(), m, m + n);
+    else v.store.assign(m, m + n);
+    v.store_exists = true;
+}
+
+// The host bookkeeping of performMatching after compute_pairwise_matches, line3D.cc:834-884
+void commit_view(L* h, View& v, const l3d_match* matches, int n, float median_depth)
+{
+    const double t0 = now_s();
+    v.median_depth = median_depth;                                       // :835
+    std::map<uint32_t, std::vector<l3d_match>> other;
+    std::vector<std::pair<uint32_t, Key>>& mine = h->pot[(size_t)v.index];
+    for (int i = 0; i < n; ++i) {                                        // :838-866
+        const l3d_match& mp = matches[i];
+        const uint32_t cam = mp.camID2;
+        if (h->vn_has(cam, v.id) && !h->matched.count(((uint64_t)cam << 32) | v.id)) {
+            l3d_match r;
+            r.segID1 = mp.segID2; r.camID2 = v.id; r.segID2 = mp.segID1; r.confidence = 0.0f;
+            r.depths[0] = mp.depths[2]; r.depths[1] = mp.depths[3]; r.depths[2] = mp.depths[0]; r.depths[3] = mp.depths[1];
+            other[cam].push_back(r);
+        }
+        mine.emplace_back(mp.segID1, mk(cam, mp.segID2));
+        View* o = h->find_view(cam);
+        if (o) h->pot[(size_t)o->index].emplace_back(mp.segID2, mk(v.id, mp.segID1));
+        else h->pot_foreign.emplace_back(mk(cam, mp.segID2), mk(v.id, mp.segID1));
+    }
+    for (auto& kv : other) add_matches(h->views[kv.first], kv.second.data(), kv.second.size(), false, false);   // :868-872
+    for (uint32_t nb : h->visual_neighbors[v.id]) {                      // :875-881
+        h->matched.insert(((uint64_t)v.id << 32) | nb);
+        if (h->vn_has(nb, v.id)) h->matched.insert(((uint64_t)nb << 32) | v.id);
+    }
+    add_matches(v, matches, (size_t)n, true, true);                      // :884
+    if (h->keep_view_matches) h->view_matches[v.id].assign(matches, matches + n);
+    h->stat_kept += n;
+    h->t_commit += now_s() - t0;
+}
+
+int compute_view(L* h, View& v, int s0, int s1, l3d_match** out, int* n_out, float* median, float** best, int* n_best)
+{
+    Marshal m;
+    marshal_view(h, v, m);
+    std::vector<l3d_match> existing;
+    localized_existing(h, v, existing);
+    if (s1 < 0) s1 = v.S();
+    *median = 1.0f;                                                      // line3D.cc:811
+    const double t0 = now_s();
+    int rc = l3d_compute_pairwise_matches(h->ctx, v.segs.data(), v.S(), m.RtKinv_src, m.C_src,
+                                          v.nb_segs.data(), m.offsets.data(), (int)m.l2g.size(),
+                                          m.F.data(), m.RtKinv.data(), m.centers.data(), m.P.data(),
+                                          m.tbm.data(), (int)m.tbm.size(), existing.data(), (int)existing.size(), m.l2g.data(),
+                                          v.k_upper, v.k_lower, h->sigma_p, h->sigma_a, m.spatial_k, s0, s1,
+                                          out, n_out, median, best, n_best);
+    h->t_gpu_call += now_s() - t0;
+    if (rc) return h->fail(rc, std::string("compute_pairwise_matches: ") + l3d_last_error(h->ctx));
+    double st[4];
+    l3d_last_stats(h->ctx, st);
+    h->stat_pairs += st[0];
+    h->stat_raw += st[1];
+    return L3D_OK;
+}
+
+// potential_correspondences_ becomes a sorted, de-duplicated adjacency per view (it is a std::map of
+// std::maps in the reference: set semantics, ascending iteration)
+void finalize_matching(L* h)
+{
+    const double t0 = now_s();
+    for (auto& p : h->pot) {
+        std::sort(p.begin(), p.end());
+        p.erase(std::unique(p.begin(), p.end()), p.end());
+    }
+    std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
+    h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
+    h->t_finalize += now_s() - t0;
+}
+
+int prepare(L* h)
+{
+    if (h->views.size() < 4) return h->fail(L3D_ERR_INVALID, "not enough images! can't compute 3D model...");   // line3D.cc:347-351
+    h->computation = true;
+    find_visual_neighbors(h);
+    int rc = transform_geometry(h);
+    if (rc) return rc;
+    h->vlist.clear();
+    int idx = 0;
+    for (auto& kv : h->views) { kv.second.index = idx++; h->vlist.push_back(&kv.second); }
+    // residency: every view's neighbour tile (concatenated neighbour segments) and its own segments stay
+    // in HBM for the whole run (the reference re-uploads them per view, line3D.cc:793-800)
+    for (View* v : h->vlist) {
+        v->nb_segs.clear();
+        auto it = h->visual_neighbors.find(v->id);
+        if (it != h->visual_neighbors.end())
+            for (uint32_t nb : it->second) { const View& o = h->views[nb]; v->nb_segs.insert(v->nb_segs.end(), o.segs.begin(), o.segs.end()); }
+        if (v->nb_segs.empty()) v->nb_segs.resize(4, 0.0f);
+        rc = l3d_register_segments(h->ctx, v->segs.data(), v->S());
+        if (!rc) rc = l3d_register_segments(h->ctx, v->nb_segs.data(), (int)(v->nb_segs.size() / 4));
+        if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
+    }
+    h->prepared = true;
+    return L3D_OK;
+}
+
+// reset of everything matchViews produces (line3D.cc:355-358 + the views' match files)
+void match_begin(L* h)
+{
+    h->matched.clear();
+    h->pot.assign(h->vlist.size(), {});
+    h->pot_foreign.clear();
+    h->view_matches.clear();
+    h->order.clear();
+    for (View* v : h->vlist) { v->store.clear(); v->store_exists = false; v->median_depth = 1.0f; }
+    for (auto& kv : h->visual_neighbors)
+        if (!kv.second.empty() && h->views.count(kv.first)) h->order.push_back(kv.first);    // line3D.cc:626-632
+    h->stat_pairs = h->stat_raw = h->stat_kept = 0;
+    h->t_match = h->t_gpu_call = h->t_commit = h->t_finalize = 0;
+}
+
+// Line3D::matchViews, line3D.cc:620-648
+int match_views(L* h)
+{
+    const double t0 = now_s();
+    match_begin(h);
+    for (uint32_t id : h->order) {
+        View& v = h->views[id];
+        l3d_match* m = nullptr; int n = 0; float med = 1.0f;
+        int rc = compute_view(h, v, 0, -1, &m, &n, &med, nullptr, nullptr);
+        if (rc) return rc;
+        commit_view(h, v, m, n, med);
+        l3d_free(m);
+    }
+    finalize_matching(h);
+    h->t_match = now_s() - t0;
+    return L3D_OK;
+}
+
+// L3DView::unprojectSegment, view.cc:302-342
+void unproject_segment(const View& v, uint32_t id, float d1, float d2, Hyp& o)
+{
+    const float* s = &v.segs[(size_t)id * 4];
+    V3 r1 = mul(v.RtKinv, V3{ s[0], s[1], 1.0 });
+    r1 = r1 / norm(r1);
+    V3 r2 = mul(v.RtKinv, V3{ s[2], s[3], 1.0 });
+    r2 = r2 / norm(r2);
+    o.P1 = v.C + r1 * (double)d1;
+    o.P2 = v.C + r2 * (double)d2;
+    o.dir = o.P2 - o.P1;
+    o.dir = o.dir / norm(o.dir);
+    o.depth_p1 = d1; o.depth_p2 = d2;
+}
+
+// Line3D::greedySelection, line3D.cc:899-965: the stored list holds one (best) match per segment
+void greedy_selection(L* h)
+{
+    h->hyps.clear();
+    h->best_idx.assign(h->vlist.size(), {});
+    for (View* v : h->vlist) {
+        std::vector<int>& bi = h->best_idx[(size_t)v->index];
+        bi.assign((size_t)v->S(), -1);
+        if (!v->store_exists) continue;
+        // group by segment (ascending), first of the highest confidence
+        std::map<uint32_t, size_t> best;
+        for (size_t i = 0; i < v->store.size(); ++i) {
+            auto it = best.find(v->store[i].segID1);
+            if (it == best.end()) best[v->store[i].segID1] = i;
+            else if (v->store[i].confidence > v->store[it->second].confidence) it->second = i;
+        }
+        for (auto& kv : best) {
+            const l3d_match& mp = v->store[kv.second];
+            if (kv.first >= (uint32_t)v->S()) continue;
+            Hyp hy;
+            hy.src = mk(v->id, kv.first);
+            hy.score = fminf(mp.confidence, 1.0f);
+            unproject_segment(*v, kv.first, mp.depths[0], mp.depths[1], hy);
+            bi[kv.first] = (int)h->hyps.size();
+            h->hyps.push_back(hy);
+        }
+    }
+}
+
+int best_of(const L* h, Key k)
+{
+    auto it = h->views.find(kcam(k));
+    if (it == h->views.end()) return -1;
+    const std::vector<int>& bi = h->best_idx[(size_t)it->second.index];
+    return kseg(k) < bi.size() ? bi[kseg(k)] : -1;
+}
+
+// Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115 (stays on the host)
+void perform_clustering(const std::vector<l3d_edge>& edges_in, int numNodes, float c, std::vector<int>& labels)
+{
+    std::vector<l3d_edge> e(edges_in);
+    std::stable_sort(e.begin(), e.end(), [](const l3d_edge& a, const l3d_edge& b) { return a.w < b.w; });
+    std::vector<int> rank((size_t)numNodes, 0), cid((size_t)numNodes), size((size_t)numNodes, 1);
+    std::vector<float> thr((size_t)numNodes, c);
+    for (int i = 0; i < numNodes; ++i) cid[i] = i;
+    auto find = [&](int node) { int y = node; while (y != cid[y]) y = cid[y]; cid[node] = y; return y; };
+    for (const l3d_edge& ed : e) {
+        int a = find(ed.i), b = find(ed.j);
+        if (a != b && ed.w <= thr[a] && ed.w <= thr[b]) {
+            if (rank[a] > rank[b]) { cid[b] = a; size[a] += size[b]; }
+            else { cid[a] = b; size[b] += size[a]; if (rank[a] == rank[b]) rank[b]++; }
+            a = find(a);
+            thr[a] = ed.w + c / (float)size[a];
+        }
+    }
+    labels.resize((size_t)numNodes);
+    for (int k = 0; k < numNodes; ++k) labels[k] = find(k);
+}
+
+// Line3D::performDiffusion, line3D.cc:1255-1303
+int perform_diffusion(L* h, std::vector<l3d_edge>& A, int n)
+{
+    std::vector<l3d_edge> W(A.size());
+    int rc = l3d_replicator_dynamics_diffusion(h->ctx, A.data(), (int)A.size(), n, L3D_RDD_MAX_ITER, W.data());
+    if (rc) return h->fail(rc, std::string("rdd: ") + l3d_last_error(h->ctx));
+    std::map<std::pair<int, int>, float> entries;
+    for (const l3d_edge& e : W) {
+        const float w12 = e.w;
+        float w21 = w12;
+        auto it = entries.find({ e.j, e.i });
+        if (it != entries.end()) w21 = it->second;
+        const float w = fminf(w12, w21);
+        entries[{ e.i, e.j }] = w;
+        entries[{ e.j, e.i }] = w;
+    }
+    A.clear();
+    for (auto& kv : entries) A.push_back({ kv.first.first, kv.first.second, kv.second });
+    return L3D_OK;
+}
+
+// getLineEquation3D + projectToLine, line3D.cc:1392-1597
+void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std::vector<std::pair<V3, V3>>& aligned)
+{
+    aligned.clear();
+    if (t3.empty()) return;
+    const double n = (double)t3.size() * 2.0;
+    V3 Pc;
+    for (auto& e : t3) { Pc = Pc + e.second.first; Pc = Pc + e.second.second; }
+    Pc = Pc / n;
+    M3 Sc;
+    auto acc = [&](V3 p) {
+        const V3 d = p - Pc;
+        const double dv[3] = { d.x, d.y, d.z };
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sc(r, c) += dv[r] * dv[c];
+    };
+    for (auto& e : t3) { acc(e.second.first); acc(e.second.second); }
+    double w[3]; M3 V;
+    l3d::la::eig_sym3(Sc, w, V);
+    int mx = 0;
+    for (int k = 1; k < 3; ++k) if (w[k] > w[mx]) mx = k;
+    V3 dir = { V(0, mx), V(1, mx), V(2, mx) };
+    dir = dir / norm(dir);
+    // sign convention (Eigen's is unpinned): the largest |component| is positive
+    {
+        const double a[3] = { std::fabs(dir.x), std::fabs(dir.y), std::fabs(dir.z) };
+        int k = 0; if (a[1] > a[k]) k = 1; if (a[2] > a[k]) k = 2;
+        const double c = k == 0 ? dir.x : (k == 1 ? dir.y : dir.z);
+        if (c < 0) dir = dir * -1.0;
+    }
+    struct SP { V3 P; unsigned seg3D, cam; float dist; };
+    std::vector<SP> sortable;
+    V3 min_point;
+    double min_length = 0.0, max_length = 0.0;
+    const double dn2 = norm(dir) * norm(dir);
+    unsigned segID = 0;
+    for (auto& e : t3) {
+        const V3 P1 = e.second.first, P2 = e.second.second;
+        const V3 proj1 = Pc + (dot(dir, P1 - Pc) / dn2) * dir;
+        const V3 proj2 = Pc + (dot(dir, P2 - Pc) / dn2) * dir;
+        const double loc1 = dot(dir, Pc - proj1);
+        if (loc1 <= min_length) { min_length = loc1; min_point = proj1; }
+        if (loc1 >= max_length) max_length = loc1;
+        const double loc2 = dot(dir, Pc - proj2);
+        if (loc2 <= min_length) { min_length = loc2; min_point = proj2; }
+        if (loc2 >= max_length) max_length = loc2;
+        sortable.push_back({ P1, segID, kcam(e.first), 0.0f });
+        sortable.push_back({ P2, segID, kcam(e.first), 0.0f });
+        ++segID;
+    }
+    for (SP& s : sortable) s.dist = (float)norm(s.P - min_point);
+    std::stable_sort(sortable.begin(), sortable.end(), [](const SP& a, const SP& b) { return a.dist < b.dist; });
+    std::map<unsigned, unsigned> open;
+    std::set<unsigned> open_lines;
+    bool opened = false;
+    V3 start;
+    for (const SP& pt : sortable) {
+        if (!open_lines.count(pt.seg3D)) { open_lines.insert(pt.seg3D); ++open[pt.cam]; }
+        else { open_lines.erase(pt.seg3D); if (--open[pt.cam] == 0) open.erase(pt.cam); }
+        if (opened && open.size() < 3) { aligned.emplace_back(start, pt.P); opened = false; }
+        else if (!opened && open.size() >= 3) { start = pt.P; opened = true; }
+    }
+}
+
+// Line3D::clusterSegments2D, line3D.cc:968-1252: candidate enumeration in the reference's order on the
+// host, all similarity_coll3D evaluations in one batched HIP launch, thresholds / first-touch node
+// numbering replayed sequentially.
+int cluster_segments_2D(L* h, bool perform_diff)
+{
+    const double t0 = now_s();
+    h->A.clear(); h->local2global.clear(); h->result.clear();
+    const size_t nh = h->hyps.size();
+    if (nh == 0) return L3D_OK;
+
+    // dense index of every 2-D segment of every view (for the `used` bookkeeping)
+    std::vector<size_t> voff(h->vlist.size() + 1, 0);
+    for (size_t i = 0; i < h->vlist.size(); ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
+    auto dense = [&](Key k) -> long long {
+        auto it = h->views.find(kcam(k));
+        if (it == h->views.end() || kseg(k) >= (uint32_t)it->second.S()) return -1;
+        return (long long)(voff[(size_t)it->second.index] + kseg(k));
+    };
+    std::vector<uint32_t> stamp(voff.back(), 0);
+    std::vector<std::vector<uint32_t>> enc(nh);       // per processed src (hyp index): sorted dense ids met
+    // foreign keys (camera not a view): adjacency of src key -> foreign tgt keys, and vice versa
+    auto pot_range = [&](Key src, std::vector<Key>& out) {
+        out.clear();
+        const View& v = h->views[kcam(src)];
+        const auto& p = h->pot[(size_t)v.index];
+        auto lo = std::lower_bound(p.begin(), p.end(), std::make_pair(kseg(src), (Key)0));
+        for (; lo != p.end() && lo->first == kseg(src); ++lo) out.push_back(lo->second);
+    };
+
+    struct Item { int a, b; int kind; float cw; };
+    std::vector<Item> items;
+    std::vector<Key> tg;
+    std::vector<uint32_t> met;
+    for (size_t si = 0; si < nh; ++si) {
+        const Key src = h->hyps[si].src;
+        const uint32_t st = (uint32_t)si + 1;
+        const long long dsrc = dense(src);
+        met.clear();
+        // used[src][x] <=> x met earlier in this iteration, or src met while x was the source
+        auto used = [&](Key x, long long dx) -> bool {
+            if (dx < 0) return false;                          // foreign keys appear at most once per source
+            if (stamp[(size_t)dx] == st) return true;
+            const int xb = best_of(h, x);
+            if (xb >= 0 && (size_t)xb < si && dsrc >= 0 &&
+                std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), (uint32_t)dsrc)) return true;
+            return false;
+        };
+        auto mark = [&](long long dx) { if (dx >= 0) { stamp[(size_t)dx] = st; met.push_back((uint32_t)dx); } };
+
+        pot_range(src, tg);
+        // potential correspondences whose camera is not a view sort by key among the others; they never
+        // have a best match, so they only need to be skipped
+        for (Key tgt : tg) {                                                     // :996-1138
+            const long long dt = dense(tgt);
+            if (used(tgt, dt)) continue;
+            mark(dt);
+            const int tb = best_of(h, tgt);
+            if (tb < 0) continue;
+            items.push_back({ (int)si, tb, 0, 0.0f });
+            const View& tv = h->views[kcam(tgt)];
+            for (int c = tv.coll_start[kseg(tgt)]; c < tv.coll_start[kseg(tgt) + 1]; ++c) {   // :1065-1136
+                const Key tgtc = mk(kcam(tgt), (uint32_t)tv.coll_other[(size_t)c]);
+                const long long dc = dense(tgtc);
+                if (used(tgtc, dc)) continue;
+                mark(dc);
+                const int cb = best_of(h, tgtc);
+                if (cb >= 0) items.push_back({ (int)si, cb, 1, 0.0f });
+            }
+        }
+        const View& sv = h->views[kcam(src)];
+        for (int c = sv.coll_start[kseg(src)]; c < sv.coll_start[kseg(src) + 1]; ++c) {       // :1141-1214
+            const Key tgt = mk(kcam(src), (uint32_t)sv.coll_other[(size_t)c]);
+            const long long dt = dense(tgt);
+            if (used(tgt, dt)) continue;
+            mark(dt);
+            const int tb = best_of(h, tgt);
+            if (tb >= 0) items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
+        }
+        std::sort(met.begin(), met.end());
+        enc[si] = met;
+    }
+
+    // batched similarity on the GPU
+    std::vector<l3d_hypothesis> hy(nh);
+    for (size_t i = 0; i < nh; ++i) {
+        const Hyp& s = h->hyps[i];
+        const View& v = h->views[kcam(s.src)];
+        l3d_hypothesis& o = hy[i];
+        o.P1[0] = s.P1.x; o.P1[1] = s.P1.y; o.P1[2] = s.P1.z;
+        o.P2[0] = s.P2.x; o.P2[1] = s.P2.y; o.P2[2] = s.P2.z;
+        o.dir[0] = s.dir.x; o.dir[1] = s.dir.y; o.dir[2] = s.dir.z;
+        o.depth_p1 = s.depth_p1; o.depth_p2 = s.depth_p2;
+        o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
+    }
+    std::vector<int32_t> pairs(items.size() * 2);
+    for (size_t k = 0; k < items.size(); ++k) { pairs[2 * k] = items[k].a; pairs[2 * k + 1] = items[k].b; }
+    std::vector<float> sim(items.size());
+    int rc = l3d_similarity_coll3D_batch(h->ctx, hy.data(), (int)nh, pairs.data(), (int)items.size(), h->sigma_a, sim.data());
+    if (rc) return h->fail(rc, std::string("similarity: ") + l3d_last_error(h->ctx));
+
+    // thresholds + first-touch node numbering, in enumeration order
+    std::vector<int> node(nh, -1);
+    auto node_of = [&](int hidx) {
+        if (node[(size_t)hidx] < 0) { node[(size_t)hidx] = (int)h->local2global.size(); h->local2global.push_back(h->hyps[(size_t)hidx].src); }
+        return node[(size_t)hidx];
+    };
+    for (size_t k = 0; k < items.size(); ++k) {
+        const Item& it = items[k];
+        const float s1 = h->hyps[(size_t)it.a].score, s2 = h->hyps[(size_t)it.b].score;
+        float w;
+        if (it.kind == 2) w = it.cw * 0.5f * (s1 + s2) * sim[k];                // :1163
+        else w = 0.5f * (s1 + s2) * sim[k];                                     // :1014,:1085
+        const float thr = it.kind == 0 ? 0.25f : 0.01f;                         // L3D_MIN_AFFINITY / 0.01f
+        if (w > thr) {
+            const int a = node_of(it.a);
+            const int b = node_of(it.b);
+            h->A.push_back({ a, b, w });
+            h->A.push_back({ b, a, w });
+        }
+    }
+    h->t_affinity = now_s() - t0;
+    if (h->A.empty()) return L3D_OK;                                            // :1232-1233
+
+    const double t1 = now_s();
+    const int n_nodes = (int)h->local2global.size();
+    std::vector<l3d_edge> edges = h->A;
+    if (perform_diff) { rc = perform_diffusion(h, edges, n_nodes); if (rc) return rc; }
+    std::vector<int> labels;
+    perform_clustering(edges, n_nodes, 1.0f, labels);                           // :1245
+
+    // processClusteredSegments, line3D.cc:1306-1368
+    std::map<int, std::vector<Key>> cl2seg;
+    std::map<int, std::set<uint32_t>> cl2cam;
+    for (int lid = 0; lid < n_nodes; ++lid) {
+        cl2seg[labels[(size_t)lid]].push_back(h->local2global[(size_t)lid]);
+        cl2cam[labels[(size_t)lid]].insert(kcam(h->local2global[(size_t)lid]));
+    }
+    for (auto& kv : cl2seg) {
+        if (cl2cam[kv.first].size() < 4) continue;
+        std::vector<Key> keys = kv.second;
+        std::sort(keys.begin(), keys.end());
+        std::vector<std::pair<Key, std::pair<V3, V3>>> t3;
+        for (Key k : keys) {
+            const int b = best_of(h, k);
+            if (b < 0) continue;
+            t3.push_back({ k, { inverse_transform(h, h->hyps[(size_t)b].P1), inverse_transform(h, h->hyps[(size_t)b].P2) } });
+        }
+        FinalLine fl;
+        align_cluster(t3, fl.segs3D);
+        if (fl.segs3D.empty()) continue;
+        for (auto& e : t3) fl.segs2D.push_back(e.first);
+        h->result.push_back(std::move(fl));
+    }
+    h->t_cluster = now_s() - t1;
+    return L3D_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float unc_lower, float sigma_p, float sigma_a,
+                      float min_baseline, int use_collinearity, int verbose, l3d_line3d** out)
+{
+    if (!out) return L3D_ERR_INVALID;
+    *out = nullptr;
+    l3d_ctx* ctx = nullptr;
+    int rc = l3d_ctx_create(device, &ctx);
+    if (rc) return rc;
+    L* h = new L();
+    h->ctx = ctx;
+    h->verbose = verbose != 0;
+    h->matching_neighbors = matching_neighbors;
+    h->unc_upper = fabsf(unc_upper);                     // line3D.cc:18-28
+    h->unc_lower = fabsf(unc_lower);
+    if (h->unc_lower < 1.0f) h->unc_lower = 1.0f;
+    if (h->unc_upper <= h->unc_lower) h->unc_upper = h->unc_lower + 1.0f;
+    h->sigma_p = sigma_p; h->sigma_a = sigma_a; h->min_baseline = min_baseline;
+    h->use_collinearity = use_collinearity != 0;
+    *out = h;
+    return L3D_OK;
+}
+
+void l3d_line3d_destroy(l3d_line3d* h)
+{
+    if (!h) return;
+    l3d_ctx_destroy(h->ctx);
+    delete h;
+}
+
+const char* l3d_line3d_last_error(const l3d_line3d* h) { return h ? h->err.c_str() : "null handle"; }
+l3d_ctx* l3d_line3d_context(l3d_line3d* h) { return h ? h->ctx : nullptr; }
+
+// Line3D::reset, line3D.cc:62-92
+int l3d_line3d_reset(l3d_line3d* h)
+{
+    if (!h) return L3D_ERR_INVALID;
+    for (auto& kv : h->views) { l3d_unregister_segments(h->ctx, kv.second.segs.data()); l3d_unregister_segments(h->ctx, kv.second.nb_segs.data()); }
+    h->views.clear(); h->vlist.clear(); h->view_similarities.clear(); h->num_wps.clear(); h->common_wps.clear();
+    h->worldpoints2views.clear(); h->visual_neighbors.clear(); h->fundamentals.clear(); h->matched.clear();
+    h->pot.clear(); h->pot_foreign.clear(); h->hyps.clear(); h->best_idx.clear(); h->A.clear(); h->local2global.clear(); h->result.clear();
+    h->computation = false; h->prepared = false;
+    return L3D_OK;
+}
+
+static int add_common(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
+                      const double* K, const double* R, const double* t, int n_links)
+{
+    if (!h) return L3D_ERR_INVALID;
+    // the guards of addImage, line3D.cc:101-127 (print-and-return in the reference; a status here)
+    if (h->computation) return h->fail(L3D_ERR_INVALID, "reconstruction already performed! cannot add more images (try reset first)");
+    if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
+    if (n_links == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
+    if (width == 0 || height == 0) return h->fail(L3D_ERR_INVALID, "image is empty!");
+    if (n <= 0 || !segs || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "no segments");   // detectLineSegments failed: no view, :186-190
+    return make_view(h, id, width, height, segs, n, K, R, t);
+}
+
+// addImage_fixed_sim with precomputed segments (the detector is out of scope), line3D.cc:220-342
+int l3d_line3d_add_image_fixed_sim(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
+                                   const double* K, const double* R, const double* t,
+                                   const uint32_t* sim_ids, const float* sims, int n_sims)
+{
+    int rc = add_common(h, id, width, height, segs, n, K, R, t, n_sims);
+    if (rc) return rc;
+    for (int i = 0; i < n_sims; ++i)                       // setViewSimilarity, :1938-1946
+        if (sims[i] > 0.01f) h->view_similarities[id][sim_ids[i]] = sims[i];
+    return L3D_OK;
+}
+
+// addImage with precomputed segments, line3D.cc:95-217
+int l3d_line3d_add_image(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
+                         const double* K, const double* R, const double* t, const uint32_t* worldpoints, int n_wps)
+{
+    int rc = add_common(h, id, width, height, segs, n, K, R, t, n_wps);
+    if (rc) return rc;
+    process_worldpoints(h, id, worldpoints, n_wps);
+    return L3D_OK;
+}
+
+int l3d_line3d_num_cameras(const l3d_line3d* h) { return h ? (int)h->views.size() : 0; }
+
+int l3d_line3d_prepare(l3d_line3d* h) { return h ? prepare(h) : L3D_ERR_INVALID; }
+int l3d_line3d_match_views(l3d_line3d* h)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    return match_views(h);
+}
+int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    greedy_selection(h);                                   // optimizeLocalMatches, :888-896
+    return cluster_segments_2D(h, perform_diffusion != 0);
+}
+// Line3D::compute3Dmodel, line3D.cc:345-374
+int l3d_line3d_compute3Dmodel(l3d_line3d* h, int perform_diffusion)
+{
+    if (!h) return L3D_ERR_INVALID;
+    int rc = prepare(h);
+    if (!rc) rc = match_views(h);
+    if (!rc) rc = l3d_line3d_finish(h, perform_diffusion);
+    return rc;
+}
+
+// ---- step-wise matching (multi-GPU: every rank computes a source-segment range of each view, the
+// kept lists are all-gathered, every rank commits the same merged list) ---------------------------
+int l3d_line3d_match_begin(l3d_line3d* h, int* n_order)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    match_begin(h);
+    if (n_order) *n_order = (int)h->order.size();
+    return L3D_OK;
+}
+int l3d_line3d_match_order(l3d_line3d* h, uint32_t* ids, int* n_segments)
+{
+    if (!h) return L3D_ERR_INVALID;
+    for (size_t i = 0; i < h->order.size(); ++i) { if (ids) ids[i] = h->order[i]; if (n_segments) n_segments[i] = h->views[h->order[i]].S(); }
+    return L3D_OK;
+}
+// number of neighbours still to be matched from this view (line3D.cc:732-736); 0 = the early-return case
+int l3d_line3d_view_num_to_be_matched(l3d_line3d* h, uint32_t view_id)
+{
+    if (!h) return -1;
+    auto it = h->visual_neighbors.find(view_id);
+    if (it == h->visual_neighbors.end()) return -1;
+    int n = 0;
+    for (uint32_t nb : it->second) if (!h->matched.count(((uint64_t)view_id << 32) | nb)) ++n;
+    return n;
+}
+int l3d_line3d_match_view_compute(l3d_line3d* h, uint32_t view_id, int seg_begin, int seg_end,
+                                  l3d_match** out, int* n_out, float* median, float** best, int* n_best)
+{
+    if (!h) return L3D_ERR_INVALID;
+    View* v = h->find_view(view_id);
+    if (!v) return h->fail(L3D_ERR_INVALID, "unknown view");
+    return compute_view(h, *v, seg_begin, seg_end, out, n_out, median, best, n_best);
+}
+// best_depths: the merged depth pairs of all ranges (2*n_best floats); pass n_best < 0 to use `median` as is
+int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_match* matches, int n,
+                                 const float* best_depths, int n_best, float median)
+{
+    if (!h) return L3D_ERR_INVALID;
+    View* v = h->find_view(view_id);
+    if (!v) return h->fail(L3D_ERR_INVALID, "unknown view");
+    if (n_best >= 0) {
+        median = -1.0f;                                    // cudawrapper.cu:1066-1073
+        if (n_best > 0) {
+            std::vector<float> d(best_depths, best_depths + (size_t)n_best * 2);
+            std::sort(d.begin(), d.end());
+            median = d[d.size() / 2];
+        }
+    }
+    commit_view(h, *v, matches, n, median);
+    return L3D_OK;
+}
+int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
+
+// ---- results ---------------------------------------------------------------------------------
+int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d)
+{
+    if (!h) return L3D_ERR_INVALID;
+    int a = 0, b = 0;
+    for (auto& l : h->result) { a += (int)l.segs3D.size(); b += (int)l.segs2D.size(); }
+    if (n_lines) *n_lines = (int)h->result.size();
+    if (n_seg3d) *n_seg3d = a;
+    if (n_seg2d) *n_seg2d = b;
+    return L3D_OK;
+}
+// per line: counts; seg3d: 6 doubles each (P1,P2); seg2d: (camID, segID) pairs  -- Line3D::getResult
+int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, double* seg3d, uint32_t* seg2d)
+{
+    if (!h) return L3D_ERR_INVALID;
+    size_t a = 0, b = 0, li = 0;
+    for (auto& l : h->result) {
+        line_n3d[li] = (int)l.segs3D.size(); line_n2d[li] = (int)l.segs2D.size(); ++li;
+        for (auto& s : l.segs3D) { seg3d[a++] = s.first.x; seg3d[a++] = s.first.y; seg3d[a++] = s.first.z; seg3d[a++] = s.second.x; seg3d[a++] = s.second.y; seg3d[a++] = s.second.z; }
+        for (Key k : l.segs2D) { seg2d[b++] = kcam(k); seg2d[b++] = kseg(k); }
+    }
+    return L3D_OK;
+}
+// Line3D::getSegment2D, line3D.cc:2004-2013
+int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4])
+{
+    if (!h) return L3D_ERR_INVALID;
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    auto it = h->views.find(cam);
+    if (it == h->views.end() || seg >= (uint32_t)it->second.S()) return L3D_ERR_INVALID;
+    memcpy(out, &it->second.segs[(size_t)seg * 4], 16);
+    return L3D_OK;
+}
+
+// ---- inspection for tests / bench ----------------------------------------------------------------
+int l3d_line3d_keep_view_matches(l3d_line3d* h, int on) { if (!h) return L3D_ERR_INVALID; h->keep_view_matches = on != 0; return L3D_OK; }
+int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median)
+{
+    if (!h) return L3D_ERR_INVALID;
+    auto it = h->view_matches.find(view_id);
+    if (m) *m = it == h->view_matches.end() ? nullptr : it->second.data();
+    if (n) *n = it == h->view_matches.end() ? 0 : (int)it->second.size();
+    auto vt = h->views.find(view_id);
+    if (median && vt != h->views.end()) *median = vt->second.median_depth;
+    return L3D_OK;
+}
+int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (A) *A = h->A.data();
+    if (nnz) *nnz = (int)h->A.size();
+    if (n_nodes) *n_nodes = (int)h->local2global.size();
+    return L3D_OK;
+}
+/* stats[12]: pairs, raw candidates, kept, #hypotheses, t_match, t_gpu_call, t_commit, t_finalize, t_affinity, t_cluster, #edges, #lines */
+int l3d_line3d_stats(const l3d_line3d* h, double* s)
+{
+    if (!h || !s) return L3D_ERR_INVALID;
+    s[0] = h->stat_pairs; s[1] = h->stat_raw; s[2] = h->stat_kept; s[3] = (double)h->hyps.size();
+    s[4] = h->t_match; s[5] = h->t_gpu_call; s[6] = h->t_commit; s[7] = h->t_finalize; s[8] = h->t_affinity; s[9] = h->t_cluster;
+    s[10] = (double)h->A.size(); s[11] = (double)h->result.size();
+    return L3D_OK;
+}
+
+}  // extern "C"

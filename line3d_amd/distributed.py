@@ -1,0 +1,72 @@
+"""View sharding across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+matchViews is a dependency chain over views (the verified matches of a view are candidates of its later
+neighbours), so views are NOT distributed; instead every rank computes the same view at the same time on a
+1/world slice of its SOURCE segments -- the verification of a source segment only reads candidates of that
+segment, so the slices are independent -- and the per-view kept lists (32-byte records, a few MB) are
+all-gathered before the replicated host bookkeeping (commit).  The concatenation in rank order is the
+(segment, camera, target)-sorted list of the unsharded run, bit for bit.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .capi import MATCH_DTYPE
+
+
+def seg_range(S: int, rank: int, world: int):
+    return (S * rank) // world, (S * (rank + 1)) // world
+
+
+def allgather_bytes(payload: np.ndarray, dist, device=None):
+    """Variable-length all-gather of a uint8 array: counts first, then one padded all_gather."""
+    import torch
+    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if payload.size:
+        buf[: payload.size] = torch.from_numpy(payload).to(device) if device is not None else torch.from_numpy(payload)
+    outs = [torch.zeros_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, buf)
+    return [o[:c].cpu().numpy() for o, c in zip(outs, counts)]
+
+
+def pack(matches: np.ndarray, best: np.ndarray) -> np.ndarray:
+    head = np.array([len(matches), len(best)], dtype=np.int64).view(np.uint8)
+    return np.concatenate([head, matches.view(np.uint8).ravel(), best.view(np.uint8).ravel()])
+
+
+def unpack(buf: np.ndarray):
+    nm, nb = np.frombuffer(buf[:16].tobytes(), dtype=np.int64)
+    m = np.frombuffer(buf[16:16 + 32 * nm].tobytes(), dtype=MATCH_DTYPE)
+    b = np.frombuffer(buf[16 + 32 * nm:16 + 32 * nm + 4 * nb].tobytes(), dtype=np.float32)
+    return m, b
+
+
+def match_views_sharded(l3d, rank: int, world: int, dist, compute=None, device=None):
+    """Line3D::matchViews (line3D.cc:620-648) with every view's source segments sharded over `world` ranks.
+    `compute(view_id, s0, s1) -> (matches, median, best_depths)` defaults to the HIP path of `l3d`; the CPU
+    tests inject the oracle here to exercise the protocol under gloo."""
+    import torch
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    if compute is None:
+        compute = l3d.match_view_compute
+    ids, ns = l3d.match_begin()
+    for vid, S in zip(ids.tolist(), ns.tolist()):
+        if l3d.view_num_to_be_matched(vid) == 0:
+            # cudawrapper.cu:877-878: nothing is computed, every rank holds the identical list already
+            m, med, _ = compute(vid, 0, S)
+            l3d.match_view_commit(vid, m, None, 1.0)
+            continue
+        s0, s1 = seg_range(S, rank, world)
+        m, _med, best = compute(vid, s0, s1)
+        parts = [unpack(b) for b in allgather_bytes(pack(m, best), dist, device)]
+        allm = np.concatenate([p[0] for p in parts]) if parts else m
+        allb = np.concatenate([p[1] for p in parts]) if parts else best
+        l3d.match_view_commit(vid, allm, allb)
+    l3d.match_end()

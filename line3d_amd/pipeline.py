@@ -1,0 +1,194 @@
+"""Python mirror of the reference's operator interface, class L3D::Line3D (line3D.h:61-101), over the
+C ABI (l3d_line3d_* in include/line3d_amd.h).  Same calls, argument meaning and defaults
+(commons.h:42-61); images are replaced by their detected segments."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import MATCH_DTYPE, EDGE_DTYPE, L3DError, _p
+
+
+class Line3D:
+    def __init__(self, data_directory: str = "", matchingNeighbors: int = 10, uncertainty_t_upper_2D: float = 5.0,
+                 uncertainty_t_lower_2D: float = 1.0, sigma_p: float = 3.5, sigma_a: float = 10.0,
+                 min_baseline: float = 0.25, useCollinearity: bool = True, verbose: bool = False, device: int = 0):
+        self.lib = capi.load_library()
+        self.lib.l3d_line3d_last_error.restype = C.c_char_p
+        self.lib.l3d_line3d_last_error.argtypes = [C.c_void_p]
+        self.lib.l3d_line3d_context.restype = C.c_void_p
+        self.lib.l3d_line3d_context.argtypes = [C.c_void_p]
+        self.lib.l3d_line3d_destroy.argtypes = [C.c_void_p]
+        self.data_directory = data_directory          # kept for signature parity; nothing is written to disk
+        h = C.c_void_p()
+        rc = self.lib.l3d_line3d_create(C.c_int(device), C.c_int(matchingNeighbors), C.c_float(uncertainty_t_upper_2D),
+                                        C.c_float(uncertainty_t_lower_2D), C.c_float(sigma_p), C.c_float(sigma_a),
+                                        C.c_float(min_baseline), C.c_int(int(useCollinearity)), C.c_int(int(verbose)), C.byref(h))
+        if rc != 0:
+            raise L3DError("l3d_line3d_create failed (code %d): no usable MI355X / HIP device -- no CPU fallback" % rc)
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.l3d_line3d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise L3DError("line3d_amd error %d: %s" % (rc, self.lib.l3d_line3d_last_error(self.h).decode()))
+
+    def context(self) -> capi.Context:
+        """The pipeline's l3d_ctx as a (non-owning) Context, for profiling."""
+        c = capi.Context.__new__(capi.Context)
+        c.lib = self.lib
+        c.h = C.c_void_p(self.lib.l3d_line3d_context(self.h))
+        c._keep = []
+        c.close = lambda: None
+        return c
+
+    # -- reference interface ------------------------------------------------------------------
+    def addImage(self, imageID, width, height, segments, K, R, t, worldpointIDs):
+        segs = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
+        K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))
+        wps = np.ascontiguousarray(list(worldpointIDs), dtype=np.uint32)
+        rc = self.lib.l3d_line3d_add_image(self.h, C.c_uint32(imageID), C.c_uint(width), C.c_uint(height), _p(segs),
+                                           C.c_int(len(segs)), _p(K), _p(R), _p(t), _p(wps), C.c_int(len(wps)))
+        return rc == 0          # the reference prints to cerr and returns (line3D.cc:101-127)
+
+    def addImage_fixed_sim(self, imageID, width, height, segments, K, R, t, viewSimilarity):
+        segs = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
+        K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))
+        ids = np.ascontiguousarray(sorted(viewSimilarity), dtype=np.uint32)
+        sims = np.ascontiguousarray([viewSimilarity[int(i)] for i in ids], dtype=np.float32)
+        rc = self.lib.l3d_line3d_add_image_fixed_sim(self.h, C.c_uint32(imageID), C.c_uint(width), C.c_uint(height), _p(segs),
+                                                     C.c_int(len(segs)), _p(K), _p(R), _p(t), _p(ids), _p(sims), C.c_int(len(ids)))
+        return rc == 0
+
+    def compute3Dmodel(self, perform_diffusion: bool = False):
+        self._chk(self.lib.l3d_line3d_compute3Dmodel(self.h, C.c_int(int(perform_diffusion))))
+
+    def getResult(self):
+        """list of (segments2D [(camID, segID)...], segments3D [(P1, P2)...]) -- L3DFinalLine3D (commons.h:215-238)."""
+        nl, n3, n2 = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.l3d_line3d_result_sizes(self.h, C.byref(nl), C.byref(n3), C.byref(n2)))
+        l3 = np.zeros(nl.value, np.int32)
+        l2 = np.zeros(nl.value, np.int32)
+        s3 = np.zeros((n3.value, 6), np.float64)
+        s2 = np.zeros((n2.value, 2), np.uint32)
+        if nl.value:
+            self._chk(self.lib.l3d_line3d_get_result(self.h, _p(l3), _p(l2), _p(s3), _p(s2)))
+        out, a, b = [], 0, 0
+        for k in range(nl.value):
+            seg3 = [(s3[a + i, :3].copy(), s3[a + i, 3:].copy()) for i in range(l3[k])]
+            seg2 = [(int(s2[b + i, 0]), int(s2[b + i, 1])) for i in range(l2[k])]
+            a += l3[k]
+            b += l2[k]
+            out.append((seg2, seg3))
+        return out
+
+    def getSegment2D(self, camID, segID):
+        o = (C.c_float * 4)()
+        self.lib.l3d_line3d_get_segment2D(self.h, C.c_uint32(camID), C.c_uint32(segID), o)
+        return tuple(o)
+
+    def numCameras(self):
+        return self.lib.l3d_line3d_num_cameras(self.h)
+
+    def reset(self):
+        self._chk(self.lib.l3d_line3d_reset(self.h))
+
+    # -- stages ----------------------------------------------------------------------------------
+    def prepare(self):
+        self._chk(self.lib.l3d_line3d_prepare(self.h))
+
+    def match_views(self):
+        self._chk(self.lib.l3d_line3d_match_views(self.h))
+
+    def finish(self, perform_diffusion=False):
+        self._chk(self.lib.l3d_line3d_finish(self.h, C.c_int(int(perform_diffusion))))
+
+    def match_begin(self):
+        n = C.c_int(0)
+        self._chk(self.lib.l3d_line3d_match_begin(self.h, C.byref(n)))
+        ids = np.zeros(n.value, np.uint32)
+        ns = np.zeros(n.value, np.int32)
+        self._chk(self.lib.l3d_line3d_match_order(self.h, _p(ids), _p(ns)))
+        return ids, ns
+
+    def view_num_to_be_matched(self, view_id):
+        return self.lib.l3d_line3d_view_num_to_be_matched(self.h, C.c_uint32(view_id))
+
+    def match_view_compute(self, view_id, seg_begin, seg_end):
+        out = C.c_void_p()
+        n = C.c_int(0)
+        med = C.c_float(1.0)
+        bd = C.POINTER(C.c_float)()
+        nb = C.c_int(0)
+        self._chk(self.lib.l3d_line3d_match_view_compute(self.h, C.c_uint32(view_id), C.c_int(seg_begin), C.c_int(seg_end),
+                                                         C.byref(out), C.byref(n), C.byref(med), C.byref(bd), C.byref(nb)))
+        res = np.zeros(n.value, dtype=MATCH_DTYPE)
+        if n.value:
+            C.memmove(res.ctypes.data, out, n.value * 32)
+        self.lib.l3d_free(out)
+        best = np.ctypeslib.as_array(bd, (nb.value * 2,)).copy() if nb.value else np.zeros(0, np.float32)
+        if bd:
+            self.lib.l3d_free(bd)
+        return res, med.value, best
+
+    def match_view_commit(self, view_id, matches, best_depths=None, median=1.0):
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        if best_depths is None:
+            self._chk(self.lib.l3d_line3d_match_view_commit(self.h, C.c_uint32(view_id), _p(m), C.c_int(len(m)), None,
+                                                            C.c_int(-1), C.c_float(median)))
+        else:
+            b = np.ascontiguousarray(best_depths, dtype=np.float32)
+            self._chk(self.lib.l3d_line3d_match_view_commit(self.h, C.c_uint32(view_id), _p(m), C.c_int(len(m)), _p(b),
+                                                            C.c_int(len(b) // 2), C.c_float(median)))
+
+    def match_end(self):
+        self._chk(self.lib.l3d_line3d_match_end(self.h))
+
+    # -- inspection ------------------------------------------------------------------------------
+    def keep_view_matches(self, on=True):
+        self._chk(self.lib.l3d_line3d_keep_view_matches(self.h, C.c_int(int(on))))
+
+    def view_matches(self, view_id):
+        p = C.c_void_p()
+        n = C.c_int(0)
+        med = C.c_float(0)
+        self._chk(self.lib.l3d_line3d_view_matches(self.h, C.c_uint32(view_id), C.byref(p), C.byref(n), C.byref(med)))
+        res = np.zeros(n.value, dtype=MATCH_DTYPE)
+        if n.value:
+            C.memmove(res.ctypes.data, p, n.value * 32)
+        return res, med.value
+
+    def affinity(self):
+        p = C.c_void_p()
+        nnz, nn = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.l3d_line3d_affinity(self.h, C.byref(p), C.byref(nnz), C.byref(nn)))
+        res = np.zeros(nnz.value, dtype=EDGE_DTYPE)
+        if nnz.value:
+            C.memmove(res.ctypes.data, p, nnz.value * 12)
+        return res, nn.value
+
+    def stats(self):
+        s = (C.c_double * 12)()
+        self._chk(self.lib.l3d_line3d_stats(self.h, s))
+        keys = ["pairs", "raw", "kept", "hypotheses", "t_match", "t_gpu_call", "t_commit", "t_finalize", "t_affinity",
+                "t_cluster", "edges", "lines"]
+        return dict(zip(keys, list(s)))
+
+
+def load_scene(l3d: Line3D, scene):
+    for v in scene.views:
+        ok = l3d.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        assert ok
