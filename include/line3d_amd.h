@@ -183,6 +183,8 @@ int l3d_line3d_match_view_compute(l3d_line3d* h, uint32_t view_id, int seg_begin
 int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_match* matches, int n,
                                  const float* best_depths, int n_best, float median);
 int l3d_line3d_match_end(l3d_line3d* h);
+/* performClustering (clustering.h:125, clustering.cc:6-47; stays on the host): labels[k] = CLUniverse::find(k) */
+int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */
 int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d);
 int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, double* seg3d, uint32_t* seg2d);

@@ -1008,6 +1008,19 @@ int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_matc
 }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 
+// performClustering (clustering.h:125, clustering.cc:6-47) as a host entry point: labels[k] = find(k)
+int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels)
+{
+    if (n_edges < 0 || num_nodes < 0 || (n_edges > 0 && !edges) || (num_nodes > 0 && !labels)) return L3D_ERR_INVALID;
+    for (int k = 0; k < n_edges; ++k)
+        if (edges[k].i < 0 || edges[k].i >= num_nodes || edges[k].j < 0 || edges[k].j >= num_nodes) return L3D_ERR_INVALID;
+    std::vector<l3d_edge> e(edges, edges + n_edges);
+    std::vector<int> lab;
+    perform_clustering(e, num_nodes, c, lab);
+    for (int k = 0; k < num_nodes; ++k) labels[k] = lab[(size_t)k];
+    return L3D_OK;
+}
+
 // ---- results ---------------------------------------------------------------------------------
 int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d)
 {

@@ -444,6 +444,8 @@ static void stable_sort_matches(l3do_match* m, size_t n)
  *   toBeMatched  : local neighbour indices (line3D.cc:732-736)
  *   offsets      : N x (start,count) into tgt_segs
  *   local2global : N entries
+ *   best_depths/n_best (optional): the depth pairs entering the median, in segment order, so that
+ *     segment ranges can be merged exactly.
  *   seg_begin/seg_end: restrict the SOURCE segments processed (whole view: 0,S_src); used
  *     only by the bounded cpu_baseline sample and the sharding tests. Verification of a
  *     source segment only reads candidates of the same segment, so a range is exact.
@@ -460,10 +462,12 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
                                   const uint32_t* local2global,
                                   float k_upper, float k_lower, float sigma_p, float sigma_a, float spatial_k,
                                   int seg_begin, int seg_end,
-                                  l3do_match** out_matches, int* out_n, float* median_depth, double* stats)
+                                  l3do_match** out_matches, int* out_n, float* median_depth, double* stats,
+                                  float* best_depths /* optional, 2*S_src floats */, int* n_best /* optional */)
 {
     (void)k_upper; (void)k_lower; /* only used for a verbose print in the reference (1074-1082) */
     *out_matches = NULL; *out_n = 0;
+    if (n_best) *n_best = 0;
     if (n_tbm == 0) {
         l3do_match* o = (l3do_match*)malloc((n_in > 0 ? n_in : 1) * sizeof(l3do_match));
         memcpy(o, in_matches, (size_t)n_in * sizeof(l3do_match));
@@ -570,6 +574,7 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
             }
         }
     }
+    if (best_depths && n_best) { memcpy(best_depths, dlist, nd * sizeof(float)); *n_best = (int)(nd / 2); }
     *median_depth = -1.0f;
     if (nd > 0) {
         qsort(dlist, nd, sizeof(float), cmp_float);

@@ -93,7 +93,7 @@ def pairwise_dense(lib, src_segs, RtKinv_src, C_src, tgt_segs, offset, width, ca
 
 def compute_pairwise_matches(lib, src_segs, RtKinv_src, C_src, tgt_segs, offsets, F, RtKinv, centers, P,
                              to_be_matched, in_matches, local2global, k_upper, k_lower, sigma_p, sigma_a,
-                             spatial_k, median_depth=1.0, seg_range=None, want_stats=False):
+                             spatial_k, median_depth=1.0, seg_range=None, want_stats=False, want_best=False):
     """cudawrapper.cu:858-1128.  Arrays are float32 row-major; in_matches is a MATCH_DTYPE array with
     LOCAL camera ids.  Returns (matches MATCH_DTYPE array, median_depth[, stats])."""
     src_segs = np.ascontiguousarray(src_segs, dtype=np.float32)
@@ -114,18 +114,22 @@ def compute_pairwise_matches(lib, src_segs, RtKinv_src, C_src, tgt_segs, offsets
     stats = np.zeros(4, dtype=np.float64)
     S = len(src_segs)
     s0, s1 = (0, S) if seg_range is None else seg_range
+    best = np.zeros(2 * S + 2, dtype=np.float32)
+    n_best = C.c_int(0)
     rc = lib.l3do_compute_pairwise_matches(
         _f(src_segs), C.c_int(S), _f(RtKinv_src), _f(C_src), _f(tgt_segs), _i(offsets), C.c_int(len(offsets)),
         _f(F), _f(RtKinv), _f(centers), _f(P), _i(tbm), C.c_int(len(tbm)),
         inm.ctypes.data_as(C.POINTER(Match)), C.c_int(len(inm)), l2g.ctypes.data_as(C.POINTER(C.c_uint32)),
         C.c_float(k_upper), C.c_float(k_lower), C.c_float(sigma_p), C.c_float(sigma_a), C.c_float(spatial_k),
-        C.c_int(s0), C.c_int(s1), C.byref(out), C.byref(n_out), C.byref(med), _d(stats))
+        C.c_int(s0), C.c_int(s1), C.byref(out), C.byref(n_out), C.byref(med), _d(stats), _f(best), C.byref(n_best))
     assert rc == 0
     n = n_out.value
     res = np.zeros(n, dtype=MATCH_DTYPE)
     if n:
         C.memmove(res.ctypes.data, out, n * C.sizeof(Match))
     lib.l3do_free(out)
+    if want_best:
+        return res, med.value, best[:2 * n_best.value].copy()
     if want_stats:
         return res, med.value, stats
     return res, med.value
@@ -438,10 +442,8 @@ class OracleLine3D:
                     k_upper=float(view.k_upper), k_lower=float(view.k_lower),
                     spatial_k=float(np.float32(view.specific_k(float(np.float32(2.0) * self.sigma_p)))))
 
-    def perform_matching(self, v):                              # line3D.cc:698-885
-        mv = self.marshal_view(v)
+    def existing_localized(self, v, mv):                        # loadAndLocalizeExistingMatches, view.cc:200-224
         view = self.views[v]
-        # loadAndLocalizeExistingMatches, view.cc:200-224
         existing = []
         if view.store is not None:
             for m in view.store:
@@ -449,12 +451,20 @@ class OracleLine3D:
                     mm = m.copy()
                     mm["camID2"] = mv["g2l"][int(m["camID2"])]
                     existing.append(mm)
-        in_arr = np.array(existing, dtype=MATCH_DTYPE) if existing else np.zeros(0, dtype=MATCH_DTYPE)
-        matches, median = compute_pairwise_matches(
+        return np.array(existing, dtype=MATCH_DTYPE) if existing else np.zeros(0, dtype=MATCH_DTYPE)
+
+    def matching_compute(self, v, seg_range=None):              # line3D.cc:698-822 (up to the seam call)
+        mv = self.marshal_view(v)
+        in_arr = self.existing_localized(v, mv)
+        matches, median, stats = compute_pairwise_matches(
             self.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"],
             mv["RtKinv"], mv["centers"], mv["P"], mv["tbm"], in_arr, mv["l2g"], mv["k_upper"], mv["k_lower"],
-            float(self.sigma_p), float(self.sigma_a), mv["spatial_k"], median_depth=1.0)
-        self.trace[v] = dict(marshal=mv, in_matches=in_arr, matches=matches.copy(), median=median)
+            float(self.sigma_p), float(self.sigma_a), mv["spatial_k"], median_depth=1.0, seg_range=seg_range,
+            want_stats=True)
+        return mv, in_arr, matches, median
+
+    def matching_commit(self, v, matches, median):              # line3D.cc:834-884
+        view = self.views[v]
         view.median_depth = np.float32(median)
         other = OrderedDict()
         for m in matches:                                       # 838-866
@@ -478,6 +488,11 @@ class OracleLine3D:
             if v in self.visual_neighbors.get(nb, []):
                 self.matched.setdefault(nb, {})[v] = True
         view.add_matches(list(matches), True, True)             # 884
+
+    def perform_matching(self, v):                              # line3D.cc:698-885
+        mv, in_arr, matches, median = self.matching_compute(v)
+        self.trace[v] = dict(marshal=mv, in_matches=in_arr, matches=matches.copy(), median=median)
+        self.matching_commit(v, matches, median)
 
     def greedy_selection(self):                                 # line3D.cc:899-965
         self.best_match = {}

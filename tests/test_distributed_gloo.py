@@ -1,0 +1,104 @@
+"""The N>1 path (line3d_amd/distributed.py) under torch.distributed/gloo, world_size 2, on CPU: the per-view
+source-segment sharding + all-gather + replicated commit must reproduce the unsharded run bit for bit.
+The device compute is replaced by the oracle here (tests may use it); on the GPU box the same protocol runs
+with the HIP path and RCCL (tests/test_gpu_pipeline_parity.py covers the HIP compute of ranges)."""
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import torch.distributed as dist
+import l3d_oracle_pipeline as op
+from line3d_amd.synth import make_scene
+from line3d_amd import distributed as l3dist
+
+class Shim:
+    """OracleLine3D behind the step-wise interface of line3d_amd.pipeline.Line3D."""
+    def __init__(self, o): self.o = o
+    def match_begin(self):
+        o = self.o
+        o.matched, o.potential, o.kept = {}, {}, {}
+        ids = [v for v in sorted(o.visual_neighbors) if len(o.visual_neighbors[v])]
+        for v in ids:
+            for n in o.visual_neighbors[v]: o._fundamental(v, n)
+        return np.array(ids, np.uint32), np.array([len(o.views[v].segments) for v in ids], np.int32)
+    def view_num_to_be_matched(self, v):
+        return sum(1 for nb in self.o.visual_neighbors[v] if nb not in self.o.matched.get(v, {}))
+    def compute(self, v, s0, s1):
+        o = self.o
+        mv = o.marshal_view(v)
+        return op.compute_pairwise_matches(o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"],
+                                           mv["F"], mv["RtKinv"], mv["centers"], mv["P"], mv["tbm"], o.existing_localized(v, mv),
+                                           mv["l2g"], mv["k_upper"], mv["k_lower"], 3.5, 10.0, mv["spatial_k"], seg_range=(s0, s1),
+                                           want_best=True)
+    def match_view_commit(self, v, matches, best=None, median=1.0):
+        if best is not None:
+            b = np.sort(best)
+            median = float(b[len(b) // 2]) if len(b) else -1.0
+        self.o.kept[v] = (np.array(matches).copy(), median)
+        self.o.matching_commit(v, np.array(matches), median)
+    def match_end(self): pass
+
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+sc = make_scene(10, 120, 6, seed=13)
+o = op.OracleLine3D(matching_neighbors=6)
+for v in sc.views:
+    o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+o.computation = True
+o.find_visual_neighbors(); o.transform_geometry()
+shim = Shim(o)
+l3dist.match_views_sharded(shim, rank, world, dist, compute=shim.compute)
+o.greedy_selection(); o.cluster_segments_2D(False)
+with open(sys.argv[2] + ".%d" % rank, "wb") as f:
+    pickle.dump(dict(kept={v: (m.tobytes(), med) for v, (m, med) in o.kept.items()}, A=o.affinity.tobytes(), n_lines=len(o.result)), f)
+dist.destroy_process_group()
+'''
+
+
+def test_world2_gloo_sharded_matching_is_bit_identical():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import l3d_oracle_pipeline as op
+    from line3d_amd.synth import make_scene
+    with tempfile.TemporaryDirectory() as td:
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(WORKER)
+        out = os.path.join(td, "out")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29611", script, ROOT, out]
+        subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        res = [pickle.load(open(out + ".%d" % r, "rb")) for r in range(2)]
+    ref = op.run_scene(make_scene(10, 120, 6, seed=13), 6)
+    assert res[0] == res[1]                                         # replicated state stays identical
+    assert sum(len(ref.trace[v]["matches"]) for v in ref.trace) > 500
+    for v in sorted(ref.trace):
+        b, med = res[0]["kept"][v]
+        assert b == ref.trace[v]["matches"].tobytes(), "view %d" % v
+        assert np.float32(med) == np.float32(ref.trace[v]["median"])
+    assert res[0]["A"] == ref.affinity.tobytes() and res[0]["n_lines"] == len(ref.result)
+
+
+def test_seg_ranges_partition():
+    from line3d_amd.distributed import seg_range, pack, unpack
+    from line3d_amd.capi import MATCH_DTYPE
+    for S in (0, 1, 7, 2000):
+        for w in (1, 2, 3, 8):
+            r = [seg_range(S, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == S and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    m = np.zeros(3, MATCH_DTYPE)
+    m["segID1"] = [1, 2, 3]
+    b = np.arange(4, dtype=np.float32)
+    m2, b2 = unpack(pack(m, b))
+    assert m2.tobytes() == m.tobytes() and np.array_equal(b2, b)
+    m2, b2 = unpack(pack(m[:0], b[:0]))
+    assert len(m2) == 0 and len(b2) == 0

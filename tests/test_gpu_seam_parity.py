@@ -136,3 +136,19 @@ def test_similarity_batch_matches_oracle(gpu_ctx, small_oracle):
     exp = np.array([o._similarity(o.best_match[keys[a]], o.best_match[keys[b]]) for a, b in pairs], dtype=np.float32)
     assert (exp > 0).sum() > 100
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_against_committed_golden_vectors(gpu_ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seam_small.npz"))
+    for v in (0, 4):
+        k = lambda name: g["v%d_%s" % (v, name)]  # noqa: E731
+        sc = k("scalars")
+        m, med = gpu_ctx.compute_pairwise_matches(k("src_segs"), k("RtKinv_src"), k("C_src"), k("tgt_segs"), k("offsets"), k("F"),
+                                                  k("RtKinv"), k("centers"), k("P"), k("tbm"), k("in"), k("l2g"),
+                                                  float(sc[0]), float(sc[1]), 3.5, 10.0, float(sc[2]))
+        assert m.tobytes() == k("out").astype(op.MATCH_DTYPE).tobytes() and np.float32(med) == sc[3]
+    gi, gj, gw = gpu_ctx.compute_collinearity(g["coll_segs"], 2.0)
+    assert np.array_equal(gi, g["coll_i"]) and np.array_equal(gj, g["coll_j"]) and np.array_equal(gw, g["coll_w"])
+    out = gpu_ctx.replicator_dynamics_diffusion(g["rdd_A"], int(g["rdd_n"]), 10)
+    assert out.tobytes() == g["rdd_out"].astype(op.EDGE_DTYPE).tobytes()
