@@ -1,0 +1,145 @@
+// line3D_amd.hpp -- C++ facade with the reference's public interface (class L3D::Line3D, line3D.h:61-101)
+// over the C ABI of include/line3d_amd.h.  Same method names, argument order and defaults (commons.h:42-61).
+// Differences forced by the scope: `cv::Mat image` is replaced by the segments the detector would have produced
+// (std::vector<float4>, the side door the reference itself has in L3DSegments(list<float4>&, bool), segments.h:60)
+// plus the image size; Eigen types are replaced by plain row-major double arrays.  When Eigen is available,
+// define L3D_AMD_WITH_EIGEN before including this header to get the Eigen-typed overloads the drivers use.
+#pragma once
+
+#include <array>
+#include <cstdio>
+#include <iostream>
+#include <list>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "line3d_amd.h"
+
+#ifdef L3D_AMD_WITH_EIGEN
+#include <Eigen/Core>
+#endif
+
+namespace L3D {
+
+#ifndef L3D_AMD_HAVE_FLOAT4
+struct float4 { float x, y, z, w; };      // the reference gets this type from the CUDA headers
+#endif
+typedef std::array<double, 3> Vec3d;
+
+// commons.h:81-99
+class L3DSegment2D {
+public:
+    L3DSegment2D() : camID_(0), segID_(0) {}
+    L3DSegment2D(unsigned int camID, unsigned int segID) : camID_(camID), segID_(segID) {}
+    unsigned int camID() const { return camID_; }
+    unsigned int segID() const { return segID_; }
+    bool operator==(const L3DSegment2D& r) const { return camID_ == r.camID_ && segID_ == r.segID_; }
+    bool operator<(const L3DSegment2D& r) const { return camID_ < r.camID_ || (camID_ == r.camID_ && segID_ < r.segID_); }
+    bool operator!=(const L3DSegment2D& r) const { return !(*this == r); }
+private:
+    unsigned int camID_, segID_;
+};
+
+// commons.h:215-238
+class L3DFinalLine3D {
+public:
+    L3DFinalLine3D(std::list<L3DSegment2D> segments2D, std::list<std::pair<Vec3d, Vec3d> > segments3D)
+        : segments3D_(std::move(segments3D)), segments2D_(std::move(segments2D)) {}
+    std::list<std::pair<Vec3d, Vec3d> >* segments3D() { return &segments3D_; }
+    std::list<L3DSegment2D>* segments2D() { return &segments2D_; }
+private:
+    std::list<std::pair<Vec3d, Vec3d> > segments3D_;
+    std::list<L3DSegment2D> segments2D_;
+};
+
+class Line3D {
+public:
+    // line3D.h:61-66 (data_directory is accepted and unused: nothing is cached on disk)
+    Line3D(const std::string data_directory, const int matchingNeighbors = 10,
+           const float uncertainty_t_upper_2D = 5.0f, const float uncertainty_t_lower_2D = 1.0f,
+           const float sigma_p = 3.5f, const float sigma_a = 10.0f, const float min_baseline = 0.25f,
+           bool useCollinearity = true, bool verbose = false, int device = 0)
+        : h_(nullptr), prefix_("[L3D] ")
+    {
+        (void)data_directory;
+        int rc = l3d_line3d_create(device, matchingNeighbors, uncertainty_t_upper_2D, uncertainty_t_lower_2D, sigma_p, sigma_a,
+                                   min_baseline, useCollinearity ? 1 : 0, verbose ? 1 : 0, &h_);
+        if (rc != L3D_OK) std::cerr << prefix_ << "no usable HIP device (code " << rc << "); this build has no CPU fallback" << std::endl;
+    }
+    ~Line3D() { l3d_line3d_destroy(h_); }
+    Line3D(const Line3D&) = delete;
+    Line3D& operator=(const Line3D&) = delete;
+    bool valid() const { return h_ != nullptr; }
+
+    // line3D.h:69-73; errors are printed and the call returns, like the reference (line3D.cc:101-127)
+    void addImage(const unsigned int imageID, const unsigned int width, const unsigned int height,
+                  const std::vector<float4>& segments, const double K[9], const double R[9], const double t[3],
+                  std::list<unsigned int>& worldpointIDs)
+    {
+        std::vector<uint32_t> wps(worldpointIDs.begin(), worldpointIDs.end());
+        report(l3d_line3d_add_image(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x, (int)segments.size(),
+                                    K, R, t, wps.data(), (int)wps.size()));
+    }
+    // line3D.h:75-79
+    void addImage_fixed_sim(const unsigned int imageID, const unsigned int width, const unsigned int height,
+                            const std::vector<float4>& segments, const double K[9], const double R[9], const double t[3],
+                            std::map<unsigned int, float>& viewSimilarity)
+    {
+        std::vector<uint32_t> ids;
+        std::vector<float> sims;
+        for (auto& kv : viewSimilarity) { ids.push_back(kv.first); sims.push_back(kv.second); }
+        report(l3d_line3d_add_image_fixed_sim(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x,
+                                              (int)segments.size(), K, R, t, ids.data(), sims.data(), (int)ids.size()));
+    }
+#ifdef L3D_AMD_WITH_EIGEN
+    void addImage(const unsigned int imageID, const unsigned int width, const unsigned int height, const std::vector<float4>& segments,
+                  const Eigen::Matrix3d K, const Eigen::Matrix3d R, const Eigen::Vector3d t, std::list<unsigned int>& worldpointIDs)
+    {
+        double k[9], r[9], tt[3];
+        for (int i = 0; i < 3; ++i) { tt[i] = t(i); for (int j = 0; j < 3; ++j) { k[i * 3 + j] = K(i, j); r[i * 3 + j] = R(i, j); } }
+        addImage(imageID, width, height, segments, k, r, tt, worldpointIDs);
+    }
+#endif
+    // line3D.h:82
+    void compute3Dmodel(bool perform_diffusion = false) { report(l3d_line3d_compute3Dmodel(h_, perform_diffusion ? 1 : 0)); }
+    // line3D.h:85
+    void getResult(std::list<L3DFinalLine3D>& result)
+    {
+        result.clear();
+        int nl = 0, n3 = 0, n2 = 0;
+        if (l3d_line3d_result_sizes(h_, &nl, &n3, &n2) != L3D_OK || nl == 0) return;
+        std::vector<int> l3((size_t)nl), l2((size_t)nl);
+        std::vector<double> s3((size_t)n3 * 6);
+        std::vector<uint32_t> s2((size_t)n2 * 2);
+        l3d_line3d_get_result(h_, l3.data(), l2.data(), s3.data(), s2.data());
+        size_t a = 0, b = 0;
+        for (int k = 0; k < nl; ++k) {
+            std::list<std::pair<Vec3d, Vec3d> > seg3;
+            std::list<L3DSegment2D> seg2;
+            for (int i = 0; i < l3[(size_t)k]; ++i, a += 6)
+                seg3.push_back({ Vec3d{ s3[a], s3[a + 1], s3[a + 2] }, Vec3d{ s3[a + 3], s3[a + 4], s3[a + 5] } });
+            for (int i = 0; i < l2[(size_t)k]; ++i, b += 2) seg2.push_back(L3DSegment2D(s2[b], s2[b + 1]));
+            result.push_back(L3DFinalLine3D(seg2, seg3));
+        }
+    }
+    // line3D.h:88
+    float4 getSegment2D(L3DSegment2D& seg2D)
+    {
+        float o[4];
+        if (l3d_line3d_get_segment2D(h_, seg2D.camID(), seg2D.segID(), o) != L3D_OK)
+            std::cerr << prefix_ << "no view with ID " << seg2D.camID() << "!" << std::endl;
+        return float4{ o[0], o[1], o[2], o[3] };
+    }
+    unsigned int numCameras() { return (unsigned int)l3d_line3d_num_cameras(h_); }   // line3D.h:98
+    void reset() { l3d_line3d_reset(h_); }                                            // line3D.h:101
+    l3d_line3d* handle() { return h_; }
+
+private:
+    void report(int rc) { if (rc != L3D_OK) std::cerr << prefix_ << l3d_line3d_last_error(h_) << std::endl; }
+    l3d_line3d* h_;
+    std::string prefix_;
+};
+
+}  // namespace L3D
