@@ -130,6 +130,9 @@ int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
  * l3d_profile_get returns the launch count and summed duration for one kernel name
  * ("pair_mask", "pair_fill", "verify", ...; l3d_profile_names lists them, ';'-separated). */
+/* stage-2 algorithm: 0 = depth-window search (default; falls back to all-pairs when a segment's candidates do
+ * not fit in LDS), 1 = all-pairs loop in the reference's formulation.  Results are bit-identical. */
+int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
 int l3d_profile_reset(l3d_ctx* ctx);
 int l3d_profile_get(l3d_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);

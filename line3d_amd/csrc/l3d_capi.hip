@@ -45,7 +45,7 @@ struct ProfEntry {
     double ms = 0.0;
 };
 
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;cand_prep;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
 
 }  // namespace
 
@@ -55,7 +55,8 @@ struct l3d_ctx {
     std::string err;
     // arenas of the matching path
     DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
-    DevBuf kept_cnt, kept_start, best, kept;
+    DevBuf kept_cnt, kept_start, best, kept, rec, scal;
+    int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
     // other paths
     DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;
@@ -153,7 +154,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     prof_resolve(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->rec, &c->scal,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
@@ -185,6 +186,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
     return L3D_OK;
 }
 
+int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
 int l3d_profile_reset(l3d_ctx* c)
 {
@@ -341,8 +343,12 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     }
     { ProfScope p(c, "exist"); launch_exist_hist(c->exist.as<ExistRec>(), n_ex, N, c->rowcnt.as<int>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->rowcnt.as<int>(), c->row_start.as<int>(), (int)nrow, st); }
-    int R = 0;
+    int R = 0, mmax = 0;
+    HIPCHK(c, c->scal.reserve(64));
+    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 4, st));
+    launch_seg_mmax(c->row_start.as<int>(), N, seg_begin, seg_end, c->scal.as<int>(), st);
     HIPCHK(c, hipMemcpyAsync(&R, c->row_start.as<int>() + nrow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&mmax, c->scal.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     c->stats[1] = R;
@@ -370,7 +376,17 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
-    { ProfScope p(c, "verify"); launch_verify(va, st); }
+    va.mmax = mmax;
+    const bool window = c->verify_mode == 0 && verify_window_lds_bytes(mmax) <= 150 * 1024;
+    if (window) {
+        HIPCHK(c, c->rec.reserve((size_t)R * 80 + 80));
+        for (int k = 0; k < 5; ++k) va.rec[k] = c->rec.as<float4>() + (size_t)k * R;
+        { ProfScope p(c, "cand_prep"); launch_cand_prep(va, st); }
+        { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+    } else {
+        for (int k = 0; k < 5; ++k) va.rec[k] = nullptr;
+        ProfScope p(c, "verify"); launch_verify(va, st);
+    }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
     { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), c->l2g.as<unsigned>(), c->kept.as<Match>(), st); }

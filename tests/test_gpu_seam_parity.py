@@ -152,3 +152,38 @@ def test_against_committed_golden_vectors(gpu_ctx):
     assert np.array_equal(gi, g["coll_i"]) and np.array_equal(gj, g["coll_j"]) and np.array_equal(gw, g["coll_w"])
     out = gpu_ctx.replicator_dynamics_diffusion(g["rdd_A"], int(g["rdd_n"]), 10)
     assert out.tobytes() == g["rdd_out"].astype(op.EDGE_DTYPE).tobytes()
+
+
+def test_window_and_all_pairs_verify_agree_bitwise(gpu_ctx, small_oracle):
+    """The depth-window search (default) and the all-pairs loop must produce identical kept lists."""
+    for mode in (1, 0):
+        gpu_ctx.set_verify_mode(mode)
+        for v in (0, 3, 6):
+            tr = small_oracle.trace[v]
+            got, med, _ = _run_view(gpu_ctx, tr)
+            assert got.tobytes() == tr["matches"].tobytes(), "mode %d view %d" % (mode, v)
+    gpu_ctx.set_verify_mode(0)
+
+
+def test_window_verify_stress_against_all_pairs(gpu_ctx):
+    """Larger, noisier views (more near-threshold witnesses): window search vs all-pairs on the GPU, every
+    confidence-derived output identical."""
+    from line3d_amd.synth import make_scene
+    for seed, noise in ((31, 0.5), (32, 2.0), (33, 0.05)):
+        sc = make_scene(9, 700, 8, seed=seed, noise_px=noise)
+        o = op.OracleLine3D(matching_neighbors=8, use_collinearity=False)
+        for v in sc.views:
+            o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        o.matched, o.potential = {}, {}
+        o.find_visual_neighbors()
+        o.transform_geometry()
+        for n in o.visual_neighbors[4]:
+            o._fundamental(4, n)
+        mv = o.marshal_view(4)                                 # all 8 neighbours to be matched
+        tr = dict(marshal=mv, in_matches=np.zeros(0, op.MATCH_DTYPE))
+        gpu_ctx.set_verify_mode(1)
+        a, ma, ba = _run_view(gpu_ctx, tr)
+        gpu_ctx.set_verify_mode(0)
+        b, mb, bb = _run_view(gpu_ctx, tr)
+        assert len(a) > 2000
+        assert a.tobytes() == b.tobytes() and ma == mb and np.array_equal(ba, bb)
