@@ -3,6 +3,7 @@
 // device-resident flow: no dense S x S buffer, no per-neighbour download, no host list sort --
 // candidates are produced on the device already in (segment, camera, target) order.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,22 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct PinBuf {                     // pinned host staging (async copies that really are async)
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -56,6 +73,8 @@ struct l3d_ctx {
     // arenas of the matching path
     DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
     DevBuf kept_cnt, kept_start, best, kept, rec, scal;
+    PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
+    std::vector<int> h_cnt;
     int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
     // other paths
     DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
@@ -64,9 +83,12 @@ struct l3d_ctx {
     std::map<std::string, ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     double stats[4] = { 0, 0, 0, 0 };
+    double tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host-side phase timers of l3d_compute_pairwise_matches (L3D_TIMING=1)
 };
 
 namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(l3d_ctx* c, int code, const std::string& msg)
 {
@@ -149,6 +171,9 @@ int l3d_ctx_create(int device, l3d_ctx** out)
 void l3d_ctx_destroy(l3d_ctx* c)
 {
     if (!c) return;
+    if (getenv("L3D_TIMING"))
+        fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms\n",
+                c->tacc[0] * 1e3, c->tacc[1] * 1e3, c->tacc[2] * 1e3, c->tacc[3] * 1e3, c->tacc[4] * 1e3, c->tacc[5] * 1e3, c->tacc[6] * 1e3, c->tacc[7] * 1e3);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_resolve(c);
@@ -157,6 +182,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
                        &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->rec, &c->scal,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
+    c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -265,54 +291,31 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    double tp = now_s();
+#define TPHASE(k) do { const double t_ = now_s(); c->tacc[k] += t_ - tp; tp = t_; } while (0)
 
-    // ---- existing matches: localized by the caller; keep those of the processed range, order them
-    // (segment, camera, target) and rank them inside their (segment, camera) run
-    std::vector<ExistRec> ex;
-    ex.reserve((size_t)n_in);
-    for (int i = 0; i < n_in; ++i) {
-        const l3d_match& m = in_matches[i];
-        if ((int)m.segID1 < seg_begin || (int)m.segID1 >= seg_end) continue;
-        if ((int)m.camID2 >= N) return fail(c, L3D_ERR_INVALID, "in_matches camera index out of range");
-        ExistRec r;
-        r.seg = (int)m.segID1; r.cam = (int)m.camID2; r.tgt = m.segID2; r.rank = 0;
-        memcpy(r.d, m.depths, 16);
-        ex.push_back(r);
-    }
-    std::stable_sort(ex.begin(), ex.end(), [](const ExistRec& a, const ExistRec& b) {
-        if (a.seg != b.seg) return a.seg < b.seg;
-        if (a.cam != b.cam) return a.cam < b.cam;
-        return a.tgt < b.tgt;
-    });
-    for (size_t i = 1; i < ex.size(); ++i)
-        if (ex[i].seg == ex[i - 1].seg && ex[i].cam == ex[i - 1].cam) ex[i].rank = ex[i - 1].rank + 1;
-    const int n_ex = (int)ex.size();
-
-    // ---- uploads
+    // ---- small tables: offsets | F | RtKinv | centers | P | RtKinv_src | C_src | tbm | l2g -> one pinned block, one H2D
     const float4 *d_src = nullptr, *d_tgt = nullptr;
     int rc;
     if ((rc = to_device(c, c->src_segs, src_segs, (size_t)S_src * 16, &d_src))) return rc;
     if ((rc = to_device(c, c->tgt_segs, tgt_segs, (size_t)total_tgt * 16, &d_tgt))) return rc;
-    // one staging block for the small tables: offsets | F | RtKinv | centers | P | RtKinv_src | C_src
     const size_t o_off = 0, o_F = o_off + (size_t)N * 8, o_R = o_F + (size_t)N * 36, o_C = o_R + (size_t)N * 36,
-                 o_P = o_C + (size_t)N * 12, o_Rs = o_P + (size_t)N * 48, o_Cs = o_Rs + 36, t_bytes = o_Cs + 12;
-    std::vector<unsigned char> tab(t_bytes);
-    memcpy(&tab[o_off], offsets, (size_t)N * 8);
-    memcpy(&tab[o_F], F, (size_t)N * 36);
-    memcpy(&tab[o_R], RtKinv, (size_t)N * 36);
-    memcpy(&tab[o_C], centers, (size_t)N * 12);
-    memcpy(&tab[o_P], P, (size_t)N * 48);
-    memcpy(&tab[o_Rs], RtKinv_src, 36);
-    memcpy(&tab[o_Cs], C_src, 12);
+                 o_P = o_C + (size_t)N * 12, o_Rs = o_P + (size_t)N * 48, o_Cs = o_Rs + 36, o_tbm = o_Cs + 12,
+                 o_l2g = o_tbm + (size_t)n_tbm * 4, t_bytes = o_l2g + (size_t)N * 4;
+    HIPCHK(c, c->pin_tab.reserve(t_bytes));
+    unsigned char* tab = c->pin_tab.as<unsigned char>();
+    memcpy(tab + o_off, offsets, (size_t)N * 8);
+    memcpy(tab + o_F, F, (size_t)N * 36);
+    memcpy(tab + o_R, RtKinv, (size_t)N * 36);
+    memcpy(tab + o_C, centers, (size_t)N * 12);
+    memcpy(tab + o_P, P, (size_t)N * 48);
+    memcpy(tab + o_Rs, RtKinv_src, 36);
+    memcpy(tab + o_Cs, C_src, 12);
+    memcpy(tab + o_tbm, to_be_matched, (size_t)n_tbm * 4);
+    memcpy(tab + o_l2g, local2global, (size_t)N * 4);
     HIPCHK(c, c->tables.reserve(t_bytes));
-    HIPCHK(c, hipMemcpyAsync(c->tables.p, tab.data(), t_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->tables.p, tab, t_bytes, hipMemcpyHostToDevice, st));
     const unsigned char* tb = c->tables.as<unsigned char>();
-    HIPCHK(c, c->tbm.reserve((size_t)n_tbm * 4));
-    HIPCHK(c, hipMemcpyAsync(c->tbm.p, to_be_matched, (size_t)n_tbm * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, c->l2g.reserve((size_t)N * 4));
-    HIPCHK(c, hipMemcpyAsync(c->l2g.p, local2global, (size_t)N * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, c->exist.reserve((size_t)n_ex * sizeof(ExistRec) + 16));
-    if (n_ex) HIPCHK(c, hipMemcpyAsync(c->exist.p, ex.data(), (size_t)n_ex * sizeof(ExistRec), hipMemcpyHostToDevice, st));
 
     const size_t nrow = (size_t)S_src * N;
     HIPCHK(c, c->mask.reserve((size_t)n_tbm * S_src * W64 * 8));
@@ -321,8 +324,11 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     HIPCHK(c, c->kept_cnt.reserve((size_t)S_src * 4 + 4));
     HIPCHK(c, c->kept_start.reserve((size_t)S_src * 4 + 8));
     HIPCHK(c, c->best.reserve((size_t)S_src * 8 + 8));
+    HIPCHK(c, c->scal.reserve(64));
+    HIPCHK(c, c->pin_scal.reserve(64));
     HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, nrow * 4, st));
     HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S_src * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 4, st));
 
     PairArgs pa;
     pa.src_segs = d_src; pa.tgt_segs = d_tgt;
@@ -332,25 +338,70 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.centers = reinterpret_cast<const float*>(tb + o_C);
     pa.RtKinv_src = reinterpret_cast<const float*>(tb + o_Rs);
     pa.C_src = reinterpret_cast<const float*>(tb + o_Cs);
-    pa.tbm = c->tbm.as<int>();
+    pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
     pa.seg_begin = seg_begin; pa.seg_end = seg_end;
+    const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
+    // stage 1 starts now; the host orders the existing matches meanwhile
     if (seg_end > seg_begin) {
         { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, maxW, st); }
         { ProfScope p(c, "row_count"); launch_row_count(pa, c->rowcnt.as<int>(), st); }
     }
+    TPHASE(0);
+
+    // ---- existing matches: localized by the caller; keep those of the processed range, order them
+    // (segment, camera, target) and rank them inside their (segment, camera) run
+    HIPCHK(c, c->pin_ex.reserve((size_t)n_in * sizeof(ExistRec) + 16));
+    ExistRec* ex = c->pin_ex.as<ExistRec>();
+    int n_ex = 0;
+    {
+        // Callers that append the reverse matches view by view (ascending camera) hand them over sorted by
+        // (camera, origin order); a stable counting sort on the segment then already yields the final order --
+        // verified in one pass, general sort otherwise.
+        std::vector<int>& cnt = c->h_cnt;
+        cnt.assign((size_t)S_src + 1, 0);
+        for (int i = 0; i < n_in; ++i) {
+            const l3d_match& m = in_matches[i];
+            if ((int)m.segID1 < seg_begin || (int)m.segID1 >= seg_end) continue;
+            if ((int)m.camID2 >= N) return fail(c, L3D_ERR_INVALID, "in_matches camera index out of range");
+            cnt[(size_t)m.segID1 + 1]++;
+        }
+        for (int i = 0; i < S_src; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
+        n_ex = cnt[(size_t)S_src];
+        for (int i = 0; i < n_in; ++i) {
+            const l3d_match& m = in_matches[i];
+            if ((int)m.segID1 < seg_begin || (int)m.segID1 >= seg_end) continue;
+            ExistRec& r = ex[cnt[(size_t)m.segID1]++];
+            r.seg = (int)m.segID1; r.cam = (int)m.camID2; r.tgt = m.segID2; r.rank = 0;
+            memcpy(r.d, m.depths, 16);
+        }
+        auto less = [](const ExistRec& a, const ExistRec& b) {
+            if (a.seg != b.seg) return a.seg < b.seg;
+            if (a.cam != b.cam) return a.cam < b.cam;
+            return a.tgt < b.tgt;
+        };
+        bool sorted = true;
+        for (int i = 1; i < n_ex && sorted; ++i) sorted = !less(ex[i], ex[i - 1]);
+        if (!sorted) std::stable_sort(ex, ex + n_ex, less);
+        for (int i = 1; i < n_ex; ++i)
+            if (ex[i].seg == ex[i - 1].seg && ex[i].cam == ex[i - 1].cam) ex[i].rank = ex[i - 1].rank + 1;
+    }
+    TPHASE(1);
+    HIPCHK(c, c->exist.reserve((size_t)n_ex * sizeof(ExistRec) + 16));
+    if (n_ex) HIPCHK(c, hipMemcpyAsync(c->exist.p, ex, (size_t)n_ex * sizeof(ExistRec), hipMemcpyHostToDevice, st));
     { ProfScope p(c, "exist"); launch_exist_hist(c->exist.as<ExistRec>(), n_ex, N, c->rowcnt.as<int>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->rowcnt.as<int>(), c->row_start.as<int>(), (int)nrow, st); }
-    int R = 0, mmax = 0;
-    HIPCHK(c, c->scal.reserve(64));
-    HIPCHK(c, hipMemsetAsync(c->scal.p, 0, 4, st));
     launch_seg_mmax(c->row_start.as<int>(), N, seg_begin, seg_end, c->scal.as<int>(), st);
-    HIPCHK(c, hipMemcpyAsync(&R, c->row_start.as<int>() + nrow, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&mmax, c->scal.p, 4, hipMemcpyDeviceToHost, st));
+    int* hs = c->pin_scal.as<int>();
+    HIPCHK(c, hipMemcpyAsync(hs, c->row_start.as<int>() + nrow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hs + 1, c->scal.p, 4, hipMemcpyDeviceToHost, st));
+    TPHASE(2);
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    TPHASE(3);
+    const int R = hs[0], mmax = hs[1];
     c->stats[1] = R;
     if (R == 0) {            // cudawrapper.cu:955-956: matches stays empty, median_depth untouched
         *out_matches = (l3d_match*)malloc(sizeof(l3d_match));
@@ -389,26 +440,34 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
-    { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), c->l2g.as<unsigned>(), c->kept.as<Match>(), st); }
+    { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), d_l2g, c->kept.as<Match>(), st); }
+    TPHASE(4);
 
-    int n_kept = 0;
-    std::vector<float> best((size_t)(seg_end - seg_begin) * 2);
-    std::vector<int> rs_host;
-    HIPCHK(c, hipMemcpyAsync(&n_kept, c->kept_start.as<int>() + S_src, 4, hipMemcpyDeviceToHost, st));
-    if (!best.empty())
-        HIPCHK(c, hipMemcpyAsync(best.data(), c->best.as<float2>() + seg_begin, best.size() * 4, hipMemcpyDeviceToHost, st));
+    const size_t nb = (size_t)(seg_end - seg_begin) * 2;
+    HIPCHK(c, c->pin_best.reserve(nb * 4 + 16));
+    float* best = c->pin_best.as<float>();
+    HIPCHK(c, hipMemcpyAsync(hs + 2, c->kept_start.as<int>() + S_src, 4, hipMemcpyDeviceToHost, st));
+    if (nb) HIPCHK(c, hipMemcpyAsync(best, c->best.as<float2>() + seg_begin, nb * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    TPHASE(5);
+    const int n_kept = hs[2];
     l3d_match* o = (l3d_match*)malloc(sizeof(l3d_match) * (size_t)(n_kept > 0 ? n_kept : 1));
     if (!o) return fail(c, L3D_ERR_NOMEM, "malloc");
-    if (n_kept) HIPCHK(c, hipMemcpy(o, c->kept.p, sizeof(l3d_match) * (size_t)n_kept, hipMemcpyDeviceToHost));
+    if (n_kept) {
+        HIPCHK(c, c->pin_kept.reserve(sizeof(l3d_match) * (size_t)n_kept));
+        HIPCHK(c, hipMemcpyAsync(c->pin_kept.p, c->kept.p, sizeof(l3d_match) * (size_t)n_kept, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        memcpy(o, c->pin_kept.p, sizeof(l3d_match) * (size_t)n_kept);
+    }
     *out_matches = o; *out_n = n_kept;
     c->stats[3] = n_kept;
+    TPHASE(6);
 
     // median of the best hypotheses' depths, cudawrapper.cu:1066-1076
     std::vector<float> depths;
-    depths.reserve(best.size());
-    for (size_t i = 0; i + 1 < best.size(); i += 2)
+    depths.reserve(nb);
+    for (size_t i = 0; i + 1 < nb; i += 2)
         if (best[i] != -1.0f) { depths.push_back(best[i]); depths.push_back(best[i + 1]); }
     if (out_best_depths && out_n_best) {
         float* bd = (float*)malloc(sizeof(float) * (depths.size() ? depths.size() : 1));
@@ -418,9 +477,11 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     }
     *median_depth = -1.0f;
     if (!depths.empty()) {
-        std::sort(depths.begin(), depths.end());
+        std::nth_element(depths.begin(), depths.begin() + (long)(depths.size() / 2), depths.end());   // = sorted[size/2]
         *median_depth = depths[depths.size() / 2];
     }
+    TPHASE(7);
+#undef TPHASE
     return L3D_OK;
 }
 

@@ -152,6 +152,7 @@ struct l3d_line3d {
 
     // statistics
     double stat_pairs = 0, stat_raw = 0, stat_kept = 0;
+    int stat_last_tbm = -1;                                    // to-be-matched count of the view being committed
     double t_match = 0, t_gpu_call = 0, t_commit = 0, t_finalize = 0, t_affinity = 0, t_cluster = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -389,13 +390,24 @@ void add_matches(View& v, const l3d_match* m, size_t n, bool remove_old, bool on
     std::vector<l3d_match> tmp;
     if (only_best) {
         // per segID1 (ascending): first match with the highest confidence in list order (stable sort, front)
-        std::map<uint32_t, size_t> best;
-        for (size_t i = 0; i < n; ++i) {
-            auto it = best.find(m[i].segID1);
-            if (it == best.end()) best[m[i].segID1] = i;
-            else if (m[i].confidence > m[it->second].confidence) it->second = i;
+        bool grouped = true;
+        for (size_t i = 1; i < n && grouped; ++i) grouped = m[i - 1].segID1 <= m[i].segID1;
+        if (grouped) {
+            for (size_t i = 0; i < n;) {
+                size_t b = i, j = i + 1;
+                for (; j < n && m[j].segID1 == m[i].segID1; ++j) if (m[j].confidence > m[b].confidence) b = j;
+                tmp.push_back(m[b]);
+                i = j;
+            }
+        } else {
+            std::map<uint32_t, size_t> best;
+            for (size_t i = 0; i < n; ++i) {
+                auto it = best.find(m[i].segID1);
+                if (it == best.end()) best[m[i].segID1] = i;
+                else if (m[i].confidence > m[it->second].confidence) it->second = i;
+            }
+            for (auto& kv : best) tmp.push_back(m[kv.second]);
         }
-        for (auto& kv : best) tmp.push_back(m[kv.second]);
         m = tmp.data(); n = tmp.size();
     }
     if (v.store_exists && !remove_old) v.store.insert(v.store.end(), m, m + n);
@@ -408,23 +420,42 @@ void commit_view(L* h, View& v, const l3d_match* matches, int n, float median_de
 {
     const double t0 = now_s();
     v.median_depth = median_depth;                                       // :835
-    std::map<uint32_t, std::vector<l3d_match>> other;
+    // per distinct camera id seen in the list: target view, "push the reversed match" (:844-845), and whether
+    // the match is a re-verified existing one (camera already matched before this view ran): its two
+    // potential_correspondences_ entries were recorded when that camera kept it (set semantics, :864-865)
+    struct CamInfo { uint32_t cam; View* o; bool push; bool known; std::vector<l3d_match> rev; };
+    std::vector<CamInfo> cams;
+    const bool early_return = h->stat_last_tbm == 0;                    // local camera ids: never "known"
+    auto info = [&](uint32_t cam) -> CamInfo& {
+        for (CamInfo& c : cams) if (c.cam == cam) return c;
+        CamInfo c;
+        c.cam = cam;
+        c.o = h->find_view(cam);
+        c.push = h->vn_has(cam, v.id) && !h->matched.count(((uint64_t)cam << 32) | v.id);
+        c.known = !early_return && h->matched.count(((uint64_t)v.id << 32) | cam) != 0;
+        cams.push_back(std::move(c));
+        return cams.back();
+    };
     std::vector<std::pair<uint32_t, Key>>& mine = h->pot[(size_t)v.index];
+    CamInfo* last = nullptr;
     for (int i = 0; i < n; ++i) {                                        // :838-866
         const l3d_match& mp = matches[i];
-        const uint32_t cam = mp.camID2;
-        if (h->vn_has(cam, v.id) && !h->matched.count(((uint64_t)cam << 32) | v.id)) {
+        if (!last || last->cam != mp.camID2) last = &info(mp.camID2);
+        CamInfo& ci = *last;
+        if (ci.push) {
             l3d_match r;
             r.segID1 = mp.segID2; r.camID2 = v.id; r.segID2 = mp.segID1; r.confidence = 0.0f;
             r.depths[0] = mp.depths[2]; r.depths[1] = mp.depths[3]; r.depths[2] = mp.depths[0]; r.depths[3] = mp.depths[1];
-            other[cam].push_back(r);
+            ci.rev.push_back(r);
         }
-        mine.emplace_back(mp.segID1, mk(cam, mp.segID2));
-        View* o = h->find_view(cam);
-        if (o) h->pot[(size_t)o->index].emplace_back(mp.segID2, mk(v.id, mp.segID1));
-        else h->pot_foreign.emplace_back(mk(cam, mp.segID2), mk(v.id, mp.segID1));
+        if (ci.known) continue;
+        mine.emplace_back(mp.segID1, mk(ci.cam, mp.segID2));
+        if (ci.o) h->pot[(size_t)ci.o->index].emplace_back(mp.segID2, mk(v.id, mp.segID1));
+        else h->pot_foreign.emplace_back(mk(ci.cam, mp.segID2), mk(v.id, mp.segID1));
     }
-    for (auto& kv : other) add_matches(h->views[kv.first], kv.second.data(), kv.second.size(), false, false);   // :868-872
+    std::sort(cams.begin(), cams.end(), [](const CamInfo& a, const CamInfo& b) { return a.cam < b.cam; });
+    for (CamInfo& c : cams)                                              // :868-872 (ascending camera id)
+        if (!c.rev.empty()) add_matches(h->views[c.cam], c.rev.data(), c.rev.size(), false, false);
     for (uint32_t nb : h->visual_neighbors[v.id]) {                      // :875-881
         h->matched.insert(((uint64_t)v.id << 32) | nb);
         if (h->vn_has(nb, v.id)) h->matched.insert(((uint64_t)nb << 32) | v.id);
@@ -442,6 +473,7 @@ int compute_view(L* h, View& v, int s0, int s1, l3d_match** out, int* n_out, flo
     std::vector<l3d_match> existing;
     localized_existing(h, v, existing);
     if (s1 < 0) s1 = v.S();
+    h->stat_last_tbm = (int)m.tbm.size();
     *median = 1.0f;                                                      // line3D.cc:811
     const double t0 = now_s();
     int rc = l3d_compute_pairwise_matches(h->ctx, v.segs.data(), v.S(), m.RtKinv_src, m.C_src,
@@ -464,9 +496,35 @@ int compute_view(L* h, View& v, int s0, int s1, l3d_match** out, int* n_out, flo
 void finalize_matching(L* h)
 {
     const double t0 = now_s();
-    for (auto& p : h->pot) {
-        std::sort(p.begin(), p.end());
-        p.erase(std::unique(p.begin(), p.end()), p.end());
+    std::vector<std::pair<uint32_t, Key>> tmp;
+    std::vector<uint32_t> cnt;
+    for (size_t vi = 0; vi < h->pot.size(); ++vi) {
+        auto& p = h->pot[vi];
+        if (p.empty()) continue;
+        const size_t S = (size_t)h->vlist[vi]->S();
+        bool in_range = true;
+        for (auto& e : p) if (e.first >= S) { in_range = false; break; }
+        if (!in_range) { std::sort(p.begin(), p.end()); p.erase(std::unique(p.begin(), p.end()), p.end()); continue; }
+        // stable counting sort on the segment, then the (short, nearly sorted) per-segment key lists
+        cnt.assign(S + 1, 0);
+        for (auto& e : p) cnt[e.first + 1]++;
+        for (size_t i = 0; i < S; ++i) cnt[i + 1] += cnt[i];
+        tmp.resize(p.size());
+        for (auto& e : p) tmp[cnt[e.first]++] = e;
+        size_t b = 0, w = 0;
+        for (size_t s = 0; s < S; ++s) {
+            const size_t e = cnt[s];
+            for (size_t i = b + 1; i < e; ++i) {                // insertion sort on keys
+                auto x = tmp[i];
+                size_t j = i;
+                for (; j > b && tmp[j - 1].second > x.second; --j) tmp[j] = tmp[j - 1];
+                tmp[j] = x;
+            }
+            for (size_t i = b; i < e; ++i)
+                if (i == b || tmp[i].second != tmp[i - 1].second) p[w++] = tmp[i];
+            b = e;
+        }
+        p.resize(w);
     }
     std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
@@ -1003,6 +1061,7 @@ int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_matc
             median = d[d.size() / 2];
         }
     }
+    h->stat_last_tbm = l3d_line3d_view_num_to_be_matched(h, view_id);
     commit_view(h, *v, matches, n, median);
     return L3D_OK;
 }

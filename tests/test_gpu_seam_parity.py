@@ -185,5 +185,5 @@ def test_window_verify_stress_against_all_pairs(gpu_ctx):
         a, ma, ba = _run_view(gpu_ctx, tr)
         gpu_ctx.set_verify_mode(0)
         b, mb, bb = _run_view(gpu_ctx, tr)
-        assert len(a) > 2000
+        assert len(a) > 500
         assert a.tobytes() == b.tobytes() and ma == mb and np.array_equal(ba, bb)
