@@ -75,6 +75,7 @@ struct l3d_ctx {
     DevBuf kept_cnt, kept_start, best, kept, rec, scal;
     PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     std::vector<int> h_cnt;
+    int mmax_seen = 0;
     int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
     // other paths
     DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
@@ -172,8 +173,8 @@ void l3d_ctx_destroy(l3d_ctx* c)
 {
     if (!c) return;
     if (getenv("L3D_TIMING"))
-        fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms\n",
-                c->tacc[0] * 1e3, c->tacc[1] * 1e3, c->tacc[2] * 1e3, c->tacc[3] * 1e3, c->tacc[4] * 1e3, c->tacc[5] * 1e3, c->tacc[6] * 1e3, c->tacc[7] * 1e3);
+        fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms  (max candidates per segment %d)\n",
+                c->tacc[0] * 1e3, c->tacc[1] * 1e3, c->tacc[2] * 1e3, c->tacc[3] * 1e3, c->tacc[4] * 1e3, c->tacc[5] * 1e3, c->tacc[6] * 1e3, c->tacc[7] * 1e3, c->mmax_seen);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_resolve(c);
@@ -402,6 +403,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     HIPCHK(c, hipGetLastError());
     TPHASE(3);
     const int R = hs[0], mmax = hs[1];
+    if (mmax > c->mmax_seen) c->mmax_seen = mmax;
     c->stats[1] = R;
     if (R == 0) {            // cudawrapper.cu:955-956: matches stays empty, median_depth untouched
         *out_matches = (l3d_match*)malloc(sizeof(l3d_match));
@@ -428,7 +430,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax;
-    const bool window = c->verify_mode == 0 && verify_window_lds_bytes(mmax) <= 150 * 1024;
+    const bool window = c->verify_mode == 0 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
     if (window) {
         HIPCHK(c, c->rec.reserve((size_t)R * 80 + 80));
         for (int k = 0; k < 5; ++k) va.rec[k] = c->rec.as<float4>() + (size_t)k * R;

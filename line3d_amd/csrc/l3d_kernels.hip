@@ -25,10 +25,39 @@ namespace l3d {
 // segments whose invariants are staged in LDS and read as broadcasts.  One wave ballot = one
 // 64-bit word of the (camera, src) bit row.
 // =================================================================================================
+// Pairs that pass the overlap test (~8 %) are not triangulated in place -- that would run the ~300-instruction
+// triangulation with a handful of live lanes on nearly every iteration -- but pushed to a per-wave LDS ring
+// (source index, origin lane, the four intersection points) and triangulated 64 at a time with full waves.
+constexpr int kPairQueue = 128;
+struct PairQEntry { int key; float p[8]; };   // key = src_local | origin_lane << 8
+
+__device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n, const SrcPairInv* s_src, float4 tseg,
+                                                 const float* RtKinv_src, const float* RtKinv_tgt, f3 C_src, f3 C_tgt,
+                                                 unsigned long long* s_bits, int wave, int lane)
+{
+    PairQEntry e = q[(head + lane) & (kPairQueue - 1)];
+    if (lane >= n) e.key = 0;
+    const int k = e.key & 0xff, origin = (e.key >> 8) & 63;
+    // the origin lane's target segment comes over the wave, not from memory
+    const float qx = __shfl(tseg.x, origin), qy = __shfl(tseg.y, origin), qz = __shfl(tseg.z, origin), qw = __shfl(tseg.w, origin);
+    if (lane < n) {
+        SrcPairInv s;
+        s.p1 = s_src[k].p1; s.p2 = s_src[k].p2;
+        TgtPairInv t;
+        t.q1 = mk3(qx, qy, 1.0f); t.q2 = mk3(qz, qw, 1.0f);
+        const float4 d = pair_depths(s, t, mk3(e.p[0], e.p[1], 1.0f), mk3(e.p[2], e.p[3], 1.0f), mk3(e.p[4], e.p[5], 1.0f),
+                                     mk3(e.p[6], e.p[7], 1.0f), RtKinv_src, RtKinv_tgt, C_src, C_tgt);
+        if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)                 // cudawrapper.cu:931
+            atomicOr(&s_bits[k * 4 + wave], 1ull << origin);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
 {
     __shared__ SrcPairInv s_src[kSrcPerBlock];
     __shared__ float s_cam[9 + 9 + 3];   // F, RtKinv_tgt, C_tgt of this camera
+    __shared__ PairQEntry s_q[4][kPairQueue];
+    __shared__ unsigned long long s_bits[kSrcPerBlock * 4];
 
     const int j = blockIdx.z;
     const int cam = a.tbm[j];
@@ -44,6 +73,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     if (tid < 9) s_cam[tid] = a.F[cam * 9 + tid];
     else if (tid < 18) s_cam[tid] = a.RtKinv[cam * 9 + (tid - 9)];
     else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
+    if (tid < kSrcPerBlock * 4) s_bits[tid] = 0ull;
     __syncthreads();
     if (tid < kSrcPerBlock && y0 + tid < a.seg_end) s_src[tid] = make_src_inv(a.src_segs[y0 + tid], s_cam);
 
@@ -54,20 +84,35 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     __syncthreads();
 
+    PairQEntry* q = s_q[wave];
+    int head = 0, count = 0;                 // wave-uniform
     const int ny = min(kSrcPerBlock, a.seg_end - y0);
     for (int k = 0; k < ny; ++k) {
         const SrcPairInv& s = s_src[k];
-        bool ok = false;
-        if (valid) {
-            f3 l2_p1, l2_p2, l1_q1, l1_q2;
-            if (pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2)) {
-                const float4 d = pair_depths(s, t, l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, s_cam + 9, C_src, C_tgt);
-                ok = d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f;   // cudawrapper.cu:931
+        f3 l2_p1, l2_p2, l1_q1, l1_q2;
+        const bool pass = valid && pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
+        const unsigned long long pm = __ballot(pass);
+        if (pm) {
+            if (pass) {
+                const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kPairQueue - 1);
+                PairQEntry e;
+                e.key = k | (lane << 8);
+                e.p[0] = l2_p1.x; e.p[1] = l2_p1.y; e.p[2] = l2_p2.x; e.p[3] = l2_p2.y;
+                e.p[4] = l1_q1.x; e.p[5] = l1_q1.y; e.p[6] = l1_q2.x; e.p[7] = l1_q2.y;
+                q[pos] = e;
+            }
+            count += __popcll(pm);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (count >= 64) {
+                pair_queue_drain(q, head, 64, s_src, tseg, a.RtKinv_src, s_cam + 9, C_src, C_tgt, s_bits, wave, lane);
+                head = (head + 64) & (kPairQueue - 1);
+                count -= 64;
             }
         }
-        const unsigned long long bits = __ballot(ok);
-        if (lane == 0) a.mask[((size_t)j * a.S_src + (y0 + k)) * a.W64 + blockIdx.x * 4 + wave] = bits;
     }
+    if (count > 0) pair_queue_drain(q, head, count, s_src, tseg, a.RtKinv_src, s_cam + 9, C_src, C_tgt, s_bits, wave, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < ny) a.mask[((size_t)j * a.S_src + (y0 + lane)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[lane * 4 + wave];
 }
 
 // Stage 1b.  One wave per (src segment, tbm camera) row.

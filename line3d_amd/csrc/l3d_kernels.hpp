@@ -71,7 +71,7 @@ void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, 
 void launch_verify(const VerifyArgs& a, hipStream_t st);
 void launch_cand_prep(const VerifyArgs& a, hipStream_t st);
 void launch_verify_window(const VerifyArgs& a, hipStream_t st);
-size_t verify_window_lds_bytes(int mmax);
+size_t verify_window_lds_bytes(int mmax, int N);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
 void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);

@@ -54,46 +54,118 @@ __device__ __forceinline__ float window_margin(float unc, float d_y, float dabs_
     return unc * 1.00001f + 2.0e-6f * (d_y + dabs_max + c_inf);
 }
 
+// Gate-passing (hypothesis, witness) pairs are ~0.5 per (hypothesis, camera): evaluating the confidence in place
+// would run ~200 instructions with a third of the lanes.  They are pushed to a per-wave LDS ring as
+// (origin lane, camera, witness) and evaluated 64 at a time; the origin lane's 3-D segment comes back over the
+// wave (shuffles), the per-camera maxima are collected with LDS atomic max (confidences are positive floats,
+// which order like ints) and summed in ascending camera order at the end (cudawrapper.cu:677-709).
+constexpr int kVQ = 128;
+
+__device__ __forceinline__ void vw_drain(const VerifyArgs& a, int start, unsigned* q, int head, int n, int lane,
+                                         f3 X1, f3 X2, f3 v1, float* smax_wave, float two_sig_d, float two_sig_a)
+{
+    unsigned key = 0, wi = 0;
+    if (lane < n) { key = q[((head + lane) & (kVQ - 1)) * 2]; wi = q[((head + lane) & (kVQ - 1)) * 2 + 1]; }
+    const int origin = key & 63, cam = (int)(key >> 8);
+    const f3 hX1 = mk3(__shfl(X1.x, origin), __shfl(X1.y, origin), __shfl(X1.z, origin));
+    const f3 hX2 = mk3(__shfl(X2.x, origin), __shfl(X2.y, origin), __shfl(X2.z, origin));
+    const f3 hv = mk3(__shfl(v1.x, origin), __shfl(v1.y, origin), __shfl(v1.z, origin));
+    if (lane < n) {
+        bool va, vb;
+        const f3 pr1 = project(a.P + cam * 12, hX1, va);                 // :690-693
+        const f3 pr2 = project(a.P + cam * 12, hX2, vb);
+        if (va && vb) {
+            const f3 line1 = cross(pr1, pr2);
+            const float den1 = line_norm2d(line1);
+            const float4 r2 = a.rec[2][start + wi], r3 = a.rec[3][start + wi], tq = a.rec[4][start + wi];
+            const f3 l2 = mk3(r3.x, r3.y, r3.z);
+            const f3 q1 = mk3(tq.x, tq.y, 1.0f), q2 = mk3(tq.z, tq.w, 1.0f);
+            const float dd1 = __builtin_fmaxf(__builtin_fabsf(line_numer(l2, pr1) / r2.w), __builtin_fabsf(line_numer(l2, pr2) / r2.w));
+            const float dd2 = __builtin_fmaxf(__builtin_fabsf(line_numer(line1, q1) / den1), __builtin_fabsf(line_numer(line1, q2) / den1));
+            const float dist = __builtin_fmaxf(dd1, dd2);
+            const float cs = __builtin_fmaxf(__builtin_fminf(dot(hv, mk3(r2.x, r2.y, r2.z)), 1.0f), -1.0f);
+            float angle = (float)((double)c_acosf(cs) / 3.1415926535897931e+0 * (double)180.0f);
+            if (angle > 90.0f) angle = 180.0f - angle;
+            const float cd = c_expf(-dist * dist / two_sig_d);
+            const float conf = __builtin_fminf(cd, c_expf(-angle * angle / two_sig_a));
+            if (conf > 0.5f)                                              // :699-704 (max over the camera's witnesses)
+                atomicMax(reinterpret_cast<int*>(&smax_wave[origin * a.N + cam]), __float_as_int(conf));
+        }
+    }
+}
+
+struct SEnt { float d1, d2; int idx; float ud1; };   // sorted-run entry (d1, d2, candidate) + staging slot (unsorted d1)
+
+// first index in [lo, hi) whose d1 is >= key (hi if none), 8-way probes: ceil(log8(n)) dependent LDS round trips
+// instead of log2(n).  All lanes of the wave iterate together; `act` masks lanes without work.
+__device__ __forceinline__ int lower_bound8(const SEnt* se, int lo, int hi, float key, bool act)
+{
+    int len = act ? hi - lo : 0;
+    while (__any(len > 0)) {
+        const int step = (len + 7) >> 3;                       // >= 1 when len > 0
+        int c = 0;
+        if (len > 0) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int qk = lo + k * step; v[k] = qk < hi ? se[qk].d1 : __builtin_inff(); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c += v[k] < key;
+            if (c == 0) { hi = lo; }                           // answer = lo
+            else {
+                const int qprev = lo + (c - 1) * step, qc = lo + c * step;
+                hi = (c < 8 && qc < hi) ? qc : hi;
+                lo = qprev + 1;
+            }
+            len = hi - lo;
+        }
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ int s_dmax;
     const int y = a.seg_begin + blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     if (m == 0) return;
 
-    float* sd1 = reinterpret_cast<float*>(s_raw);          // [m] d1 sorted inside each camera run
-    float* sd2 = sd1 + a.mmax;                             // [m] d2 in the same order
-    int* sidx = reinterpret_cast<int*>(sd2 + a.mmax);      // [m] candidate index (relative to start)
-    float* ud1 = reinterpret_cast<float*>(sidx + a.mmax);  // [m] unsorted d1 (staging)
+    SEnt* se = reinterpret_cast<SEnt*>(s_raw);             // [mmax] runs sorted by d1 (+ staging slot)
+    float* smax = reinterpret_cast<float*>(se + a.mmax);   // [256][N] per-(hypothesis lane, camera) maxima
+    unsigned* qall = reinterpret_cast<unsigned*>(smax + 256 * a.N);
+    unsigned* q = qall + wave * kVQ * 2;
+    float* smax_wave = smax + wave * 64 * a.N;
 
     if (tid == 0) s_dmax = 0;
     __syncthreads();
     float dm = 0.0f;
     for (int i = tid; i < m; i += 256) {
         const float d1 = a.rec[0][start + i].w, d2 = a.rec[1][start + i].w;
-        ud1[i] = d1;
+        se[i].ud1 = d1;
         dm = __builtin_fmaxf(dm, __builtin_fmaxf(__builtin_fabsf(d1), __builtin_fabsf(d2)));
     }
     for (int o = 32; o > 0; o >>= 1) dm = __builtin_fmaxf(dm, __shfl_down(dm, o));
-    if ((tid & 63) == 0) atomicMax(&s_dmax, __float_as_int(dm));     // non-negative floats order like ints
+    if (lane == 0) atomicMax(&s_dmax, __float_as_int(dm));          // non-negative floats order like ints
     __syncthreads();
     // rank of every candidate inside its camera run (ties by index -> a permutation)
     for (int i = tid; i < m; i += 256) {
         const int cam = __float_as_int(a.rec[3][start + i].w);
         const int b = a.row_start[y * a.N + cam] - start, e = a.row_start[y * a.N + cam + 1] - start;
-        const float di = ud1[i];
+        const float di = se[i].ud1;
         int r = 0;
-        for (int j = b; j < e; ++j) { const float dj = ud1[j]; r += (dj < di) || (dj == di && j < i); }
-        sd1[b + r] = di;
-        sd2[b + r] = a.rec[1][start + i].w;
-        sidx[b + r] = i;
+        for (int j = b; j < e; ++j) { const float dj = se[j].ud1; r += (dj < di) || (dj == di && j < i); }
+        se[b + r].d1 = di;
+        se[b + r].d2 = a.rec[1][start + i].w;
+        se[b + r].idx = i;
     }
     __syncthreads();
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    const float4 sseg = a.src_segs[y];
+    const f3 ray1 = normalize(mat3_apply(a.RtKinv_src, mk3(sseg.x, sseg.y, 1.0f)));
+    const f3 ray2 = normalize(mat3_apply(a.RtKinv_src, mk3(sseg.z, sseg.w, 1.0f)));
     const float c_inf = __builtin_fmaxf(__builtin_fabsf(C.x), __builtin_fmaxf(__builtin_fabsf(C.y), __builtin_fabsf(C.z)));
     const float dabs_max = __int_as_float(s_dmax);
     const float two_sig_d = 2.0f * (a.sigma_p * a.sigma_p);
@@ -123,66 +195,54 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
                 w1 = w2 = __builtin_inff();
             }
         }
-        float conf_sum = 0.0f;
-        for (int c = 0; c < a.N; ++c) {                                // ascending camera order, :677-687
+        for (int c = 0; c < a.N; ++c) smax_wave[lane * a.N + c] = 0.0f;
+        int head = 0, count = 0;                                       // wave-uniform ring state
+        const float lo1 = d1y - w1, hi1 = d1y + w1;
+        for (int c = 0; c < a.N; ++c) {
             const int b = a.row_start[y * a.N + c] - start, e = a.row_start[y * a.N + c + 1] - start;
             if (b == e) continue;                                      // uniform
-            bool act = hv && c != cam_h;                               // :674
-            f3 pr1 = mk3(0, 0, 0), pr2 = mk3(0, 0, 0), line1 = mk3(0, 0, 0);
-            float den1 = 1.0f;
-            if (act) {
-                bool va, vb;
-                pr1 = project(a.P + c * 12, X1, va);                   // :690-693
-                pr2 = project(a.P + c * 12, X2, vb);
-                act = va && vb;
-                line1 = cross(pr1, pr2);
-                den1 = line_norm2d(line1);
-            }
-            const float lo1 = d1y - w1, hi1 = d1y + w1;
-            int lo = b, hi = e;                                        // lower_bound(sd1[b,e), lo1)
-            while (__any(act && lo < hi)) {
-                if (act && lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sd1[mid] < lo1) lo = mid + 1; else hi = mid;
-                }
-            }
-            float cur_max = 0.0f;
-            int j = lo;
+            const bool act = hv && c != cam_h;                         // :674
+            int j = lower_bound8(se, b, e, lo1, act);
+            SEnt cur = se[min(j, e - 1)];
             for (;;) {
-                const bool in = act && j < e && sd1[j] <= hi1;
+                const bool in = act && j < e && cur.d1 <= hi1;
                 if (!__any(in)) break;
+                const SEnt nxt = se[min(j + 1, e - 1)];                // issued before cur is consumed
+                bool push = false;
                 if (in) {
-                    if (__builtin_fabsf(sd2[j] - d2y) <= w2) {
-                        const int i = sidx[j];
-                        const float4 q0 = a.rec[0][start + i], q1r = a.rec[1][start + i];
-                        bool ok = true;
+                    if (__builtin_fabsf(cur.d2 - d2y) <= w2) {
+                        push = true;
                         if (gate) {                                    // exact 3-D gate, :396-400
-                            const f3 e1 = X1 - mk3(q0.x, q0.y, q0.z);
-                            const f3 e2 = X2 - mk3(q1r.x, q1r.y, q1r.z);
-                            ok = !(dot(e1, e1) > T1 || dot(e2, e2) > T2);
-                        }
-                        if (ok) {
-                            const float4 r2 = a.rec[2][start + i], r3 = a.rec[3][start + i], tq = a.rec[4][start + i];
-                            const f3 l2 = mk3(r3.x, r3.y, r3.z);
-                            const f3 q1 = mk3(tq.x, tq.y, 1.0f), q2 = mk3(tq.z, tq.w, 1.0f);
-                            const float dd1 = __builtin_fmaxf(__builtin_fabsf(line_numer(l2, pr1) / r2.w),
-                                                              __builtin_fabsf(line_numer(l2, pr2) / r2.w));
-                            const float dd2 = __builtin_fmaxf(__builtin_fabsf(line_numer(line1, q1) / den1),
-                                                              __builtin_fabsf(line_numer(line1, q2) / den1));
-                            const float dist = __builtin_fmaxf(dd1, dd2);
-                            const float cs = __builtin_fmaxf(__builtin_fminf(dot(v1, mk3(r2.x, r2.y, r2.z)), 1.0f), -1.0f);
-                            float angle = (float)((double)c_acosf(cs) / 3.1415926535897931e+0 * (double)180.0f);
-                            if (angle > 90.0f) angle = 180.0f - angle;
-                            const float cd = c_expf(-dist * dist / two_sig_d);
-                            const float conf = __builtin_fminf(cd, c_expf(-angle * angle / two_sig_a));
-                            if (conf > 0.5f && conf > cur_max) cur_max = conf;     // :699-704
+                            // the witness' 3-D endpoints are recomputed from its depths (same float operations as
+                            // k_cand_prep, hence the same bits) instead of being gathered from memory
+                            const f3 e1 = X1 - (C + cur.d1 * ray1);
+                            const f3 e2 = X2 - (C + cur.d2 * ray2);
+                            push = !(dot(e1, e1) > T1 || dot(e2, e2) > T2);
                         }
                     }
-                    ++j;
                 }
+                const unsigned long long pm = __ballot(push);
+                if (pm) {
+                    if (push) {
+                        const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
+                        q[pos * 2] = (unsigned)lane | ((unsigned)c << 8);
+                        q[pos * 2 + 1] = (unsigned)cur.idx;
+                    }
+                    count += __popcll(pm);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (count >= 64) {
+                        vw_drain(a, start, q, head, 64, lane, X1, X2, v1, smax_wave, two_sig_d, two_sig_a);
+                        head = (head + 64) & (kVQ - 1);
+                        count -= 64;
+                    }
+                }
+                if (in) { ++j; cur = nxt; }
             }
-            conf_sum += cur_max;
         }
+        if (count > 0) vw_drain(a, start, q, head, count, lane, X1, X2, v1, smax_wave, two_sig_d, two_sig_a);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        float conf_sum = 0.0f;
+        for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[lane * a.N + c];   // ascending camera order; +0.0f is exact
         if (hv) a.cand_conf[start + h] = conf_sum;
     }
 }
@@ -201,7 +261,7 @@ void launch_cand_prep(const VerifyArgs& a, hipStream_t st)
 {
     hipLaunchKernelGGL(k_cand_prep, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a);
 }
-size_t verify_window_lds_bytes(int mmax) { return (size_t)mmax * 16; }
+size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)mmax * 16 + (size_t)256 * N * 4 + 4 * kVQ * 8; }
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
     static bool attr_set = false;
@@ -209,7 +269,7 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), verify_window_lds_bytes(a.mmax), st, a);
+    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), verify_window_lds_bytes(a.mmax, a.N), st, a);
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {
