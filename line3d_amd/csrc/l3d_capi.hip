@@ -430,7 +430,8 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax;
-    const bool window = c->verify_mode == 0 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
+    { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
+    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
     if (window) {
         HIPCHK(c, c->rec.reserve((size_t)R * 80 + 80));
         for (int k = 0; k < 5; ++k) va.rec[k] = c->rec.as<float4>() + (size_t)k * R;

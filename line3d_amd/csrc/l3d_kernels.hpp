@@ -59,6 +59,7 @@ struct VerifyArgs {
     float4* rec[5];                 // per-candidate records of the window search (l3d_verify_window.hip)
     int N, seg_begin, seg_end;
     int mmax;                       // max candidates of one segment (LDS sizing)
+    int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     float sigma_p, sigma_a, spatial_k;
 };
 

@@ -3,16 +3,17 @@
 // Observation: hypothesis y and witness i of the same source segment are unprojected along the SAME two
 // source rays (Q1 = C + d1_i*ray1, P1 = C + d1_y*ray1, cudawrapper.cu:644-645,671-672), so the reference's
 // 3-D gate |P1-Q1| <= k*depth1 && |P2-Q2| <= k*depth2 (:388-401) is, up to float rounding, a 1-D interval
-// test on the depths.  Sorting every (segment, camera) run by d1 turns the O(m^2) all-pairs loop into
-// O(m * N * (log n + window)) with the EXACT reference gate and confidence evaluated only inside a
+// test on the depths.  Bucketing a segment's candidates by d1 turns the O(m^2) all-pairs loop into
+// O(m * window) with the EXACT reference gate and confidence evaluated only inside a
 // conservative window (the window margin provably covers the rounding of the 3-D computation, see
 // window_margin below).  Results are bit-identical to the all-pairs kernel
 // (k_verify in l3d_kernels.hip, kept as the A/B reference and the fallback for huge segments).
 //
 //   k_cand_prep      one workgroup per source segment: per-candidate records (3-D endpoints, unit direction,
 //                    target line + norm, target segment, camera) in 5 float4 arrays (80 B / candidate)
-//   k_verify_window  one workgroup per source segment: LDS holds the runs sorted by d1 (d1, d2, index);
-//                    lane <-> hypothesis; for each camera: projection, lower_bound, window scan
+//   k_verify_window  one workgroup per source segment: LDS holds all its candidates bucketed by d1;
+//                    lane <-> hypothesis; window = a few contiguous buckets; gate passers go to a per-wave
+//                    ring and are evaluated 64 at a time
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
 
@@ -94,73 +95,89 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, int start, unsigne
     }
 }
 
-struct SEnt { float d1, d2; int idx; float ud1; };   // sorted-run entry (d1, d2, candidate) + staging slot (unsorted d1)
-
-// first index in [lo, hi) whose d1 is >= key (hi if none), 8-way probes: ceil(log8(n)) dependent LDS round trips
-// instead of log2(n).  All lanes of the wave iterate together; `act` masks lanes without work.
-__device__ __forceinline__ int lower_bound8(const SEnt* se, int lo, int hi, float key, bool act)
+// LDS image of one source segment: ALL its candidates bucketed by the first depth d1.  Depths are positive floats,
+// whose bit patterns are monotone in the value and roughly logarithmic, so (bits >> kBucketShift) is an order
+// preserving bucket id of relative width 2^-7 .. 2^-6 (0.8-1.6 %) -- about the width of the gate window
+// (spatial_k ~ 0.5 % of the depth).  A counting sort on that id (LDS atomics, O(m), no comparison sort) makes every
+// depth window a contiguous range of <= 3-4 buckets; the order inside a bucket is arbitrary, which cannot change
+// the result (per-camera maxima, summed in camera order).
+constexpr int kBucketShift = 17;
+constexpr int kBuckets = 512;                  // 8 octaves of depth; anything beyond is clamped into the last bucket
+// entry key = (d1 bits << 32) | (camera << 24) | candidate index
+__device__ __forceinline__ float key_d1(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_cam(unsigned long long k) { return (int)((k >> 24) & 0xffu); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0xffffffu); }
+__device__ __forceinline__ int bucket_of(float d, int base)
 {
-    int len = act ? hi - lo : 0;
-    while (__any(len > 0)) {
-        const int step = (len + 7) >> 3;                       // >= 1 when len > 0
-        int c = 0;
-        if (len > 0) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int qk = lo + k * step; v[k] = qk < hi ? se[qk].d1 : __builtin_inff(); }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c += v[k] < key;
-            if (c == 0) { hi = lo; }                           // answer = lo
-            else {
-                const int qprev = lo + (c - 1) * step, qc = lo + c * step;
-                hi = (c < 8 && qc < hi) ? qc : hi;
-                lo = qprev + 1;
-            }
-            len = hi - lo;
-        }
-    }
-    return lo;
+    if (!(d > 0.0f)) return 0;                                        // windows may reach below zero
+    const int raw = (int)(__float_as_uint(d) >> kBucketShift) - base;
+    return raw < 0 ? 0 : (raw > kBuckets - 1 ? kBuckets - 1 : raw);
 }
 
 __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    __shared__ int s_dmax;
+    __shared__ int s_dmax, s_base;
+    __shared__ int s_bstart[kBuckets + 1];
+    __shared__ int s_cursor[kBuckets];
     const int y = a.seg_begin + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     if (m == 0) return;
+    if (a.debug == 4) return;
 
-    SEnt* se = reinterpret_cast<SEnt*>(s_raw);             // [mmax] runs sorted by d1 (+ staging slot)
-    float* smax = reinterpret_cast<float*>(se + a.mmax);   // [256][N] per-(hypothesis lane, camera) maxima
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(s_raw);   // [mmax] keys grouped by bucket
+    float* sd2 = reinterpret_cast<float*>(sk + a.mmax);                      // [mmax] d2 in the same order
+    float* smax = sd2 + a.mmax;                                              // [256][N] per-(hypothesis lane, camera) maxima
     unsigned* qall = reinterpret_cast<unsigned*>(smax + 256 * a.N);
     unsigned* q = qall + wave * kVQ * 2;
     float* smax_wave = smax + wave * 64 * a.N;
 
-    if (tid == 0) s_dmax = 0;
+    // ---- counting sort of the candidates on the depth bucket
+    if (tid == 0) { s_dmax = 0; s_base = 0x7fffffff; }
+    for (int b = tid; b < kBuckets; b += 256) s_cursor[b] = 0;
     __syncthreads();
     float dm = 0.0f;
+    int rmin = 0x7fffffff;
     for (int i = tid; i < m; i += 256) {
         const float d1 = a.rec[0][start + i].w, d2 = a.rec[1][start + i].w;
-        se[i].ud1 = d1;
         dm = __builtin_fmaxf(dm, __builtin_fmaxf(__builtin_fabsf(d1), __builtin_fabsf(d2)));
+        rmin = min(rmin, (int)(__float_as_uint(d1) >> kBucketShift));
     }
-    for (int o = 32; o > 0; o >>= 1) dm = __builtin_fmaxf(dm, __shfl_down(dm, o));
-    if (lane == 0) atomicMax(&s_dmax, __float_as_int(dm));          // non-negative floats order like ints
+    for (int o = 32; o > 0; o >>= 1) { dm = __builtin_fmaxf(dm, __shfl_down(dm, o)); rmin = min(rmin, __shfl_down(rmin, o)); }
+    if (lane == 0) { atomicMax(&s_dmax, __float_as_int(dm)); atomicMin(&s_base, rmin); }   // non-negative floats order like ints
     __syncthreads();
-    // rank of every candidate inside its camera run (ties by index -> a permutation)
+    const int base = s_base;
+    for (int i = tid; i < m; i += 256) atomicAdd(&s_cursor[bucket_of(a.rec[0][start + i].w, base)], 1);
+    __syncthreads();
+    {   // exclusive scan of the 512 bucket counts: 2 per thread + wave scan + 4 wave totals
+        const int c0 = s_cursor[2 * tid], c1 = s_cursor[2 * tid + 1];
+        int incl = c0 + c1;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        __shared__ int s_wtot[4];
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w];
+        const int excl = off + incl - (c0 + c1);
+        s_bstart[2 * tid] = excl;
+        s_bstart[2 * tid + 1] = excl + c0;
+        if (tid == 255) s_bstart[kBuckets] = excl + c0 + c1;
+        __syncthreads();
+        s_cursor[2 * tid] = excl;
+        s_cursor[2 * tid + 1] = excl + c0;
+    }
+    __syncthreads();
     for (int i = tid; i < m; i += 256) {
-        const int cam = __float_as_int(a.rec[3][start + i].w);
-        const int b = a.row_start[y * a.N + cam] - start, e = a.row_start[y * a.N + cam + 1] - start;
-        const float di = se[i].ud1;
-        int r = 0;
-        for (int j = b; j < e; ++j) { const float dj = se[j].ud1; r += (dj < di) || (dj == di && j < i); }
-        se[b + r].d1 = di;
-        se[b + r].d2 = a.rec[1][start + i].w;
-        se[b + r].idx = i;
+        const float d1 = a.rec[0][start + i].w;
+        const unsigned cam = (unsigned)__float_as_int(a.rec[3][start + i].w);
+        const int pos = atomicAdd(&s_cursor[bucket_of(d1, base)], 1);
+        sk[pos] = ((unsigned long long)__float_as_uint(d1) << 32) | ((unsigned long long)cam << 24) | (unsigned)i;
+        sd2[pos] = a.rec[1][start + i].w;
     }
     __syncthreads();
+    if (a.debug == 1) return;
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     const float4 sseg = a.src_segs[y];
@@ -198,46 +215,44 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         for (int c = 0; c < a.N; ++c) smax_wave[lane * a.N + c] = 0.0f;
         int head = 0, count = 0;                                       // wave-uniform ring state
         const float lo1 = d1y - w1, hi1 = d1y + w1;
-        for (int c = 0; c < a.N; ++c) {
-            const int b = a.row_start[y * a.N + c] - start, e = a.row_start[y * a.N + c + 1] - start;
-            if (b == e) continue;                                      // uniform
-            const bool act = hv && c != cam_h;                         // :674
-            int j = lower_bound8(se, b, e, lo1, act);
-            SEnt cur = se[min(j, e - 1)];
-            for (;;) {
-                const bool in = act && j < e && cur.d1 <= hi1;
-                if (!__any(in)) break;
-                const SEnt nxt = se[min(j + 1, e - 1)];                // issued before cur is consumed
-                bool push = false;
-                if (in) {
-                    if (__builtin_fabsf(cur.d2 - d2y) <= w2) {
-                        push = true;
-                        if (gate) {                                    // exact 3-D gate, :396-400
-                            // the witness' 3-D endpoints are recomputed from its depths (same float operations as
-                            // k_cand_prep, hence the same bits) instead of being gathered from memory
-                            const f3 e1 = X1 - (C + cur.d1 * ray1);
-                            const f3 e2 = X2 - (C + cur.d2 * ray2);
-                            push = !(dot(e1, e1) > T1 || dot(e2, e2) > T2);
-                        }
-                    }
+        int j = 0, jend = 0;
+        if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
+        unsigned long long cur = sk[min(j, m - 1)];
+        float cur2 = sd2[min(j, m - 1)];
+        for (;;) {
+            const bool in = j < jend;
+            if (!__any(in)) break;
+            const unsigned long long nxt = sk[min(j + 1, m - 1)];      // issued before cur is consumed
+            const float nxt2 = sd2[min(j + 1, m - 1)];
+            bool push = false;
+            const float cd1 = key_d1(cur);
+            // :674 (other cameras only), then the 1-D pre-tests that every gate-passing witness satisfies
+            if (in && key_cam(cur) != cam_h && cd1 >= lo1 && cd1 <= hi1 && __builtin_fabsf(cur2 - d2y) <= w2) {
+                push = true;
+                if (gate) {                                            // exact 3-D gate, :396-400
+                    // the witness' 3-D endpoints are recomputed from its depths (same float operations as
+                    // k_cand_prep, hence the same bits) instead of being gathered from memory
+                    const f3 e1 = X1 - (C + cd1 * ray1);
+                    const f3 e2 = X2 - (C + cur2 * ray2);
+                    push = !(dot(e1, e1) > T1 || dot(e2, e2) > T2);
                 }
-                const unsigned long long pm = __ballot(push);
-                if (pm) {
-                    if (push) {
-                        const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
-                        q[pos * 2] = (unsigned)lane | ((unsigned)c << 8);
-                        q[pos * 2 + 1] = (unsigned)cur.idx;
-                    }
-                    count += __popcll(pm);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (count >= 64) {
-                        vw_drain(a, start, q, head, 64, lane, X1, X2, v1, smax_wave, two_sig_d, two_sig_a);
-                        head = (head + 64) & (kVQ - 1);
-                        count -= 64;
-                    }
-                }
-                if (in) { ++j; cur = nxt; }
             }
+            const unsigned long long pm = __ballot(push);
+            if (pm) {
+                if (push) {
+                    const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
+                    q[pos * 2] = (unsigned)lane | ((unsigned)key_cam(cur) << 8);
+                    q[pos * 2 + 1] = (unsigned)key_idx(cur);
+                }
+                count += __popcll(pm);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (count >= 64) {
+                    vw_drain(a, start, q, head, 64, lane, X1, X2, v1, smax_wave, two_sig_d, two_sig_a);
+                    head = (head + 64) & (kVQ - 1);
+                    count -= 64;
+                }
+            }
+            if (in) { ++j; cur = nxt; cur2 = nxt2; }
         }
         if (count > 0) vw_drain(a, start, q, head, count, lane, X1, X2, v1, smax_wave, two_sig_d, two_sig_a);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -261,15 +276,16 @@ void launch_cand_prep(const VerifyArgs& a, hipStream_t st)
 {
     hipLaunchKernelGGL(k_cand_prep, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a);
 }
-size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)mmax * 16 + (size_t)256 * N * 4 + 4 * kVQ * 8; }
+size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)mmax * 12 + (size_t)256 * N * 4 + 4 * kVQ * 8 + 16; }
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
+    const size_t lds = verify_window_lds_bytes(a.mmax, a.N);
     static bool attr_set = false;
-    if (!attr_set) {
+    if (lds > 48 * 1024 && !attr_set) {       // opt in to > default dynamic LDS only when a launch needs it
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), verify_window_lds_bytes(a.mmax, a.N), st, a);
+    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), lds, st, a);
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {
