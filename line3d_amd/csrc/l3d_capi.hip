@@ -62,7 +62,7 @@ struct ProfEntry {
     double ms = 0.0;
 };
 
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;cand_prep;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
 
 }  // namespace
 
@@ -72,7 +72,7 @@ struct l3d_ctx {
     std::string err;
     // arenas of the matching path
     DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
-    DevBuf kept_cnt, kept_start, best, kept, rec, scal;
+    DevBuf kept_cnt, kept_start, best, kept, rec, scal, stamps;
     PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     std::vector<int> h_cnt;
     int mmax_seen = 0;
@@ -172,6 +172,14 @@ int l3d_ctx_create(int device, l3d_ctx** out)
 void l3d_ctx_destroy(l3d_ctx* c)
 {
     if (!c) return;
+    if (c->stamps.p) {
+        unsigned long long h[8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, c->stamps.p, 64, hipMemcpyDeviceToHost);
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "[l3d verify_window wave-cycles] build %.1f%%  setup %.1f%%  scan %.1f%%  drain %.1f%%  final %.1f%%  (waves %llu, avg %.0f cycles)\n",
+                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, h[5], tot / (double)(h[5] ? h[5] : 1));
+    }
     if (getenv("L3D_TIMING"))
         fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms  (max candidates per segment %d)\n",
                 c->tacc[0] * 1e3, c->tacc[1] * 1e3, c->tacc[2] * 1e3, c->tacc[3] * 1e3, c->tacc[4] * 1e3, c->tacc[5] * 1e3, c->tacc[6] * 1e3, c->tacc[7] * 1e3, c->mmax_seen);
@@ -180,7 +188,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     prof_resolve(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->rec, &c->scal,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->rec, &c->scal, &c->stamps,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
@@ -431,16 +439,14 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax;
     { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
-    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
-    if (window) {
-        HIPCHK(c, c->rec.reserve((size_t)R * 80 + 80));
-        for (int k = 0; k < 5; ++k) va.rec[k] = c->rec.as<float4>() + (size_t)k * R;
-        { ProfScope p(c, "cand_prep"); launch_cand_prep(va, st); }
-        { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-    } else {
-        for (int k = 0; k < 5; ++k) va.rec[k] = nullptr;
-        ProfScope p(c, "verify"); launch_verify(va, st);
+    va.stamps = nullptr;
+    if (getenv("L3D_VW_STAMPS")) {
+        if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
+        va.stamps = c->stamps.as<unsigned long long>();
     }
+    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
+    if (window) { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+    else { ProfScope p(c, "verify"); launch_verify(va, st); }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
     { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), d_l2g, c->kept.as<Match>(), st); }

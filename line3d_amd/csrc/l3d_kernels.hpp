@@ -56,10 +56,10 @@ struct VerifyArgs {
     const uint2* cand_meta;         // (tgt, cam)
     const float4* cand_depths;
     float* cand_conf;
-    float4* rec[5];                 // per-candidate records of the window search (l3d_verify_window.hip)
     int N, seg_begin, seg_end;
     int mmax;                       // max candidates of one segment (LDS sizing)
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
+    unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
 };
 
@@ -70,7 +70,6 @@ void launch_scan(const int* in, int* out, int n, hipStream_t st);
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);
-void launch_cand_prep(const VerifyArgs& a, hipStream_t st);
 void launch_verify_window(const VerifyArgs& a, hipStream_t st);
 size_t verify_window_lds_bytes(int mmax, int N);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
