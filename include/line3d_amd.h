@@ -119,6 +119,37 @@ int l3d_replicator_dynamics_diffusion(l3d_ctx* ctx, const l3d_edge* A, int nnz, 
 int l3d_similarity_coll3D_batch(l3d_ctx* ctx, const l3d_hypothesis* hyp, int n_hyp,
                                 const int32_t* pairs, int n_pairs, float sigma_a, float* sim);
 
+
+/* ---- Line3D::matchViews as one device-resident chain --------------------------------------------------------
+ * The schedule of matchViews (line3D.cc:620-648) is static: which neighbours a view still has to match and
+ * which earlier views hand it reverse matches follows from the neighbour graph and the processing order alone.
+ * The caller describes every view of the chain (same arrays as l3d_compute_pairwise_matches) plus its sources:
+ * for each already-matched local camera `source_cam[i]`, the chain index `source_index[i]` (< own index) of that
+ * view, whose kept matches towards this view become the existing matches (line3D.cc:806,838-872) -- on the
+ * device, without touching the host.  Nothing waits for the host: stage 1 of all views is enqueued first, then
+ * the per-view verification; the callback is invoked once per view, in order, as its kept list arrives, while
+ * the GPU works on later views.  Results are bit-identical to calling l3d_compute_pairwise_matches per view.
+ * Views with n_tbm == 0 are not computed (cudawrapper.cu:877-878): callback with verified = 0.
+ * Callback arguments: kept matches (sorted, GLOBAL camera ids, confidence/2), the depth pairs entering the
+ * median (cudawrapper.cu:1058-1062) and the number of candidates verified (0: the reference returns before
+ * touching median_depth, cudawrapper.cu:955-956).  The buffers are only valid during the call.  Return non-zero
+ * from the callback to abort. */
+typedef struct l3d_chain_view {
+    uint32_t view_id;
+    const float* src_segs; int32_t S_src;
+    const float* RtKinv_src; const float* C_src;
+    const float* tgt_segs; int32_t n_tgt;
+    const int32_t* offsets; int32_t N;
+    const float* F; const float* RtKinv; const float* centers; const float* P;
+    const int32_t* to_be_matched; int32_t n_tbm;
+    const uint32_t* local2global;
+    const int32_t* source_cam; const int32_t* source_index; int32_t n_sources;
+    float sigma_p, sigma_a, spatial_k;
+} l3d_chain_view;
+typedef int (*l3d_chain_callback)(void* user, int index, int verified, const l3d_match* kept, int n_kept,
+                                  const float* best_depths, int n_best, int n_candidates);
+int l3d_match_chain(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user);
+
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
  * caller may instead register segment arrays once; l3d_compute_pairwise_matches recognises
@@ -193,6 +224,9 @@ int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int
 int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, double* seg3d, uint32_t* seg2d);
 int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4]);
 /* inspection */
+/* 1: matchViews through one l3d_compute_pairwise_matches call per view (the reference's control flow);
+ * 0 (default): the device-resident chain (l3d_match_chain).  Results are identical. */
+int l3d_line3d_set_sync_matching(l3d_line3d* h, int on);
 int l3d_line3d_keep_view_matches(l3d_line3d* h, int on);
 int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median);
 int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes);

@@ -13,8 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/line3d_amd.h"
-#include "l3d_kernels.hpp"
+#include "l3d_ctx.hpp"
 
 using namespace l3d;
 
@@ -23,133 +22,7 @@ static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
 static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
 
 namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        size_t want = bytes + bytes / 4 + 256;      // grow-only arena with slack
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct PinBuf {                     // pinned host staging (async copies that really are async)
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 2 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct ProfEntry {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    int64_t launches = 0;
-    double ms = 0.0;
-};
-
 const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
-
-}  // namespace
-
-struct l3d_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // arenas of the matching path
-    DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
-    DevBuf kept_cnt, kept_start, best, kept, rec, scal, stamps;
-    PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
-    std::vector<int> h_cnt;
-    int mmax_seen = 0;
-    int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
-    // other paths
-    DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
-    std::unordered_map<const void*, std::pair<void*, size_t>> resident;
-    bool prof_on = false;
-    std::map<std::string, ProfEntry> prof;
-    std::vector<hipEvent_t> event_pool;
-    double stats[4] = { 0, 0, 0, 0 };
-    double tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host-side phase timers of l3d_compute_pairwise_matches (L3D_TIMING=1)
-};
-
-namespace {
-
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-int fail(l3d_ctx* c, int code, const std::string& msg)
-{
-    if (c) c->err = msg;
-    return code;
-}
-
-#define HIPCHK(ctx, call)                                                                         \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(ctx, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
-    } while (0)
-
-hipEvent_t get_event(l3d_ctx* c)
-{
-    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
-}
-
-struct ProfScope {
-    l3d_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(l3d_ctx* c_, const char* n) : c(c_), name(n)
-    {
-        if (c->prof_on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
-    }
-    ~ProfScope()
-    {
-        if (c->prof_on) { (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
-    }
-};
-
-void prof_resolve(l3d_ctx* c)
-{
-    (void)hipStreamSynchronize(c->stream);
-    for (auto& kv : c->prof) {
-        for (auto& pr : kv.second.pending) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches += 1; }
-            c->event_pool.push_back(pr.first);
-            c->event_pool.push_back(pr.second);
-        }
-        kv.second.pending.clear();
-    }
-}
-
-// host pointer -> device pointer, uploading unless the array is registered as resident
-template <class T>
-int to_device(l3d_ctx* c, DevBuf& buf, const void* host, size_t bytes, const T** out)
-{
-    auto it = c->resident.find(host);
-    if (it != c->resident.end() && it->second.second == bytes) { *out = reinterpret_cast<const T*>(it->second.first); return L3D_OK; }
-    HIPCHK(c, buf.reserve(bytes ? bytes : 16));
-    if (bytes) HIPCHK(c, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, c->stream));
-    *out = buf.as<T>();
-    return L3D_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -165,6 +38,7 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP; }
     *out = c;
     return L3D_OK;
 }
@@ -188,11 +62,13 @@ void l3d_ctx_destroy(l3d_ctx* c)
     prof_resolve(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->rec, &c->scal, &c->stamps,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
+    c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
+    (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -350,7 +226,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
-    pa.seg_begin = seg_begin; pa.seg_end = seg_end;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0;
     const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
     // stage 1 starts now; the host orders the existing matches meanwhile
@@ -437,7 +313,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
-    va.mmax = mmax;
+    va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
     { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
     va.stamps = nullptr;
     if (getenv("L3D_VW_STAMPS")) {

@@ -1,0 +1,486 @@
+// l3d_chain.hip -- Line3D::matchViews (line3D.cc:620-648) as ONE device-resident chain.
+//
+// The reference processes views strictly one after the other and crosses the host<->device boundary several
+// times per view (uploads, a dense download per neighbour, host sort, download of confidences, and the
+// verified matches of a view travel through the host -- a file! -- to become candidates of later views,
+// line3D.cc:838-872, view.cc:162-224).  Here the whole schedule is static: which neighbours a view still has to
+// match (toBeMatched) and which earlier views feed it with reverse matches depends only on the neighbour graph
+// and the processing order, not on data.  So the host enqueues everything without ever waiting:
+//
+//   phase 1  stage 1 (pair test -> bit rows -> row counts) of ALL views: independent, back to back
+//   phase 2  per view, in order: reverse matches are pulled on the device out of the kept lists of the earlier
+//            views (they never leave HBM), prefix sums, depth records, verification, per-segment best/filter,
+//            ordered compaction of the kept matches into one arena
+//
+// and only trails behind the GPU to hand each view's kept list to the caller's bookkeeping (a callback), which
+// overlaps with the GPU working on later views.  Results are identical to the per-view entry point
+// (l3d_compute_pairwise_matches): same kernels, same candidate order.
+#include <algorithm>
+#include <vector>
+
+#include "l3d_ctx.hpp"
+
+using namespace l3d;
+
+namespace l3d {
+
+// reverse matches for view `view_id` out of the kept lists of earlier views (blockIdx.y = source): count per
+// (segment, camera) row.  (seg, tgt) swap roles and the depth pairs swap, line3D.cc:847-856.
+__global__ void k_exist_count(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                              const int* __restrict__ src_cam, unsigned view_id, int N, int S, int* __restrict__ rowcnt)
+{
+    const ChainResult* src = res + src_index[blockIdx.y];
+    const int cam = src_cam[blockIdx.y];
+    const int n = src->n_kept;
+    const Match* kept = arena + src->kept_base;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Match r = kept[i];
+        if (r.camID2 == view_id && (int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1);
+    }
+}
+
+__global__ void k_exist_scatter(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                                const int* __restrict__ src_cam, unsigned view_id, int N, int S, const int* __restrict__ row_start,
+                                int* __restrict__ cursor, uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
+{
+    if (row_start[(size_t)S * N] > cap) return;
+    const ChainResult* src = res + src_index[blockIdx.y];
+    const int cam = src_cam[blockIdx.y];
+    const int n = src->n_kept;
+    const Match* kept = arena + src->kept_base;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Match r = kept[i];
+        if (r.camID2 == view_id && (int)r.segID2 < S) {
+            const int row = r.segID2 * N + cam;
+            const int slot = row_start[row] + atomicAdd(&cursor[row], 1);
+            meta[slot] = make_uint2(r.segID1, (unsigned)cam);
+            depths[slot] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
+        }
+    }
+}
+
+// The scatter order inside a (segment, camera) run is arbitrary; runs are short (a handful of entries).  One thread
+// sorts one run by target id, which restores the (segment, camera, target) order of the reference's list sort:
+// runs of up to 16 entries are loaded once, sorted in registers (odd-even transposition) and written back.
+template <int K>
+__device__ __forceinline__ void sort_run_regs(uint2* meta, float4* depths, int b, int n)
+{
+    unsigned key[K];
+    float4 d[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { key[i] = i < n ? meta[b + i].x : 0xffffffffu; if (i < n) d[i] = depths[b + i]; }
+#pragma unroll
+    for (int pass = 0; pass < K; ++pass)
+#pragma unroll
+        for (int i = pass & 1; i + 1 < K; i += 2)
+            if (key[i] > key[i + 1]) { const unsigned t = key[i]; key[i] = key[i + 1]; key[i + 1] = t; const float4 td = d[i]; d[i] = d[i + 1]; d[i + 1] = td; }
+#pragma unroll
+    for (int i = 0; i < K; ++i) if (i < n) { meta[b + i].x = key[i]; depths[b + i] = d[i]; }
+}
+
+__global__ void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S, const int* __restrict__ row_start,
+                                  uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
+{
+    if (row_start[(size_t)S * N] > cap) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * n_cams) return;
+    const int seg = t / n_cams, cam = cams[t % n_cams];
+    const int b = row_start[seg * N + cam], n = row_start[seg * N + cam + 1] - b;
+    if (n < 2) return;
+    if (n <= 4) { sort_run_regs<4>(meta, depths, b, n); return; }
+    if (n <= 8) { sort_run_regs<8>(meta, depths, b, n); return; }
+    if (n <= 16) { sort_run_regs<16>(meta, depths, b, n); return; }
+    for (int i = b + 1; i < b + n; ++i) {               // long runs: in place
+        const uint2 m = meta[i];
+        const float4 d = depths[i];
+        int j = i;
+        for (; j > b && meta[j - 1].x > m.x; --j) { meta[j] = meta[j - 1]; depths[j] = depths[j - 1]; }
+        meta[j] = m; depths[j] = d;
+    }
+}
+
+// raw candidate total and the largest per-segment count of one view (phase 1 statistics): out2 = {total, max}
+__global__ __launch_bounds__(256) void k_raw_stats(const int* __restrict__ rowcnt, int S, int N, int* __restrict__ out2)
+{
+    int tot = 0, mx = 0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
+        int c = 0;
+        for (int k = 0; k < N; ++k) c += rowcnt[s * N + k];
+        tot += c; mx = max(mx, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) { tot += __shfl_down(tot, o); mx = max(mx, __shfl_down(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out2[0], tot); atomicMax(&out2[1], mx); }
+}
+
+// one thread: reserve the view's slice of the kept arena and publish (base, count, #candidates, overflow)
+__global__ void k_kept_alloc(const int* __restrict__ kept_start, int S, const int* __restrict__ row_start, int nrow,
+                             int* __restrict__ arena_cursor, int arena_cap, int cand_cap, ChainResult* __restrict__ res)
+{
+    ChainResult r;
+    r.R = row_start[nrow];
+    r.overflow = r.R > cand_cap ? 1 : 0;
+    r.n_kept = r.overflow ? 0 : kept_start[S];
+    r.kept_base = *arena_cursor;
+    if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
+    *arena_cursor = r.kept_base + r.n_kept;
+    *res = r;
+}
+
+__global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_start,
+                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena)
+{
+    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= a.seg_end || a.res->overflow) return;
+    Match* out = arena + a.res->kept_base;
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    int o = kept_start[y];
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        const float c = i < m ? a.cand_conf[start + i] : 0.0f;
+        const bool k = c > 1.0f;
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
+            const uint2 meta = a.cand_meta[start + i];
+            const float4 d = a.cand_depths[start + i];
+            Match r;
+            r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
+            r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
+            r.confidence = c / 2.0f;                 // confidence_norm, cudawrapper.cu:1089,1098
+            out[pos] = r;
+        }
+        o += __popcll(b);
+    }
+}
+
+void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                        int N, int S, int* rowcnt, hipStream_t st)
+{
+    if (n_src > 0) hipLaunchKernelGGL(k_exist_count, dim3(32, n_src), dim3(256), 0, st, arena, res, src_index, src_cam, view_id, N, S, rowcnt);
+}
+void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                          int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st)
+{
+    if (n_src > 0) hipLaunchKernelGGL(k_exist_scatter, dim3(32, n_src), dim3(256), 0, st, arena, res, src_index, src_cam, view_id, N, S, row_start, cursor, meta, depths, cap);
+}
+void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st)
+{
+    const int n = S * n_cams;
+    if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 255) / 256), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
+}
+void launch_raw_stats(const int* rowcnt, int S, int N, int* out2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_raw_stats, dim3(8), dim3(256), 0, st, rowcnt, S, N, out2);
+}
+void launch_kept_alloc(const int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap, int cand_cap,
+                       ChainResult* res, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kept_alloc, dim3(1), dim3(1), 0, st, kept_start, S, row_start, nrow, arena_cursor, arena_cap, cand_cap, res);
+}
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kept_write_chain, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, arena);
+}
+
+}  // namespace l3d
+
+namespace {
+
+struct ViewDev {            // device addresses of one view's static tables and per-view arenas
+    const float4 *src, *tgt;
+    const unsigned char* tab;
+    size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
+    unsigned long long* mask;
+    int* rowcnt;
+    int* stats;             // {raw total, raw max per segment}
+    float2* best;
+    int W64, maxW;
+    bool verified;
+};
+
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+}  // namespace
+
+extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (n_views < 0 || (n_views > 0 && (!views || !cb))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
+    if (n_views == 0) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
+
+    // ---- validation, table layout
+    std::vector<ViewDev> vd((size_t)n_views);
+    size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
+    int maxS = 0, maxN = 0;
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        if (v.S_src < 0 || v.N < 0 || v.n_tbm < 0 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0)
+            return fail(c, L3D_ERR_INVALID, "l3d_match_chain: inconsistent sizes");
+        ViewDev& d = vd[(size_t)k];
+        d.verified = v.n_tbm > 0;
+        if (!d.verified) continue;
+        if (!v.src_segs || !v.tgt_segs || !v.offsets || !v.F || !v.RtKinv || !v.centers || !v.P || !v.RtKinv_src || !v.C_src ||
+            !v.to_be_matched || !v.local2global || (v.n_sources && (!v.source_cam || !v.source_index)))
+            return fail(c, L3D_ERR_INVALID, "l3d_match_chain: null input pointer");
+        if (v.N > 255) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: more than 255 neighbours");
+        for (int s = 0; s < v.n_sources; ++s)
+            if (v.source_index[s] < 0 || v.source_index[s] >= k || v.source_cam[s] < 0 || v.source_cam[s] >= v.N)
+                return fail(c, L3D_ERR_INVALID, "l3d_match_chain: a source must be an earlier view of the chain");
+        int maxW = 0;
+        for (int j = 0; j < v.n_tbm; ++j) {
+            const int cam = v.to_be_matched[j];
+            if (cam < 0 || cam >= v.N) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: to_be_matched out of range");
+            maxW = std::max(maxW, v.offsets[2 * cam + 1]);
+        }
+        for (int i = 0; i < v.N; ++i)
+            if (v.offsets[2 * i] < 0 || v.offsets[2 * i + 1] < 0 || v.offsets[2 * i] + v.offsets[2 * i + 1] > v.n_tgt)
+                return fail(c, L3D_ERR_INVALID, "l3d_match_chain: offsets outside the target tile");
+        d.maxW = maxW;
+        d.W64 = 4 * ((maxW + 255) / 256);
+        if (d.W64 > kMaxW64) return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments");
+        // residency: segments stay in HBM; arrays not registered yet are registered now
+        if (!resident_ptr(c, v.src_segs, (size_t)v.S_src * 16)) { int rc = l3d_register_segments(c, v.src_segs, v.S_src); if (rc) return rc; }
+        if (!resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16)) { int rc = l3d_register_segments(c, v.tgt_segs, v.n_tgt); if (rc) return rc; }
+        d.src = reinterpret_cast<const float4*>(resident_ptr(c, v.src_segs, (size_t)v.S_src * 16));
+        d.tgt = reinterpret_cast<const float4*>(resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16));
+        const size_t N = (size_t)v.N;
+        size_t o = tab_bytes;
+        d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
+        d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
+        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
+        tab_bytes = align16(o);
+        mask_bytes += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        rowcnt_ints += (size_t)v.S_src * v.N;
+        best_elems += (size_t)v.S_src;
+        maxS = std::max(maxS, v.S_src); maxN = std::max(maxN, v.N);
+    }
+
+    // ---- upload all static tables in one block
+    HIPCHK(c, c->ch_pin_tables.reserve(tab_bytes + 16));
+    HIPCHK(c, c->ch_tables.reserve(tab_bytes + 16));
+    unsigned char* tab = c->ch_pin_tables.as<unsigned char>();
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        const ViewDev& d = vd[(size_t)k];
+        if (!d.verified) continue;
+        const size_t N = (size_t)v.N;
+        memcpy(tab + d.o_off, v.offsets, N * 8); memcpy(tab + d.o_F, v.F, N * 36); memcpy(tab + d.o_R, v.RtKinv, N * 36);
+        memcpy(tab + d.o_C, v.centers, N * 12); memcpy(tab + d.o_P, v.P, N * 48); memcpy(tab + d.o_Rs, v.RtKinv_src, 36);
+        memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
+        memcpy(tab + d.o_l2g, v.local2global, N * 4);
+        if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
+    const unsigned char* dtab = c->ch_tables.as<unsigned char>();
+
+    // ---- per-view arenas: bit rows, row counts, statistics, best depths, results
+    HIPCHK(c, c->ch_mask.reserve(mask_bytes + 16));
+    HIPCHK(c, c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
+    HIPCHK(c, c->ch_best.reserve(best_elems * 8 + 16));
+    HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
+    HIPCHK(c, c->ch_flags.reserve(64));
+    HIPCHK(c, c->ch_pin_res.reserve((size_t)n_views * (sizeof(ChainResult) + 8) + 64));
+    HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
+    HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
+    {
+        size_t mo = 0, ro = 0, bo = 0;
+        int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
+        for (int k = 0; k < n_views; ++k) {
+            ViewDev& d = vd[(size_t)k];
+            d.stats = stats_base + 2 * k;
+            if (!d.verified) continue;
+            const l3d_chain_view& v = views[k];
+            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
+            mo += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+            d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
+            d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
+        }
+    }
+    auto pair_args = [&](int k) {
+        const l3d_chain_view& v = views[k];
+        const ViewDev& d = vd[(size_t)k];
+        PairArgs pa;
+        pa.src_segs = d.src; pa.tgt_segs = d.tgt;
+        pa.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
+        pa.F = reinterpret_cast<const float*>(dtab + d.o_F);
+        pa.RtKinv = reinterpret_cast<const float*>(dtab + d.o_R);
+        pa.centers = reinterpret_cast<const float*>(dtab + d.o_C);
+        pa.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
+        pa.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
+        pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
+        pa.mask = d.mask;
+        pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
+        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0;
+        return pa;
+    };
+
+    { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain setup: ") + hipGetErrorString(e_)); }
+    // ---- phase 1: stage 1 of every view (independent of the chain)
+    double pairs = 0;
+    for (int k = 0; k < n_views; ++k) {
+        if (!vd[(size_t)k].verified || views[k].S_src == 0) continue;
+        const PairArgs pa = pair_args(k);
+        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, vd[(size_t)k].maxW, st); }
+        { ProfScope p(c, "row_count"); launch_row_count(pa, vd[(size_t)k].rowcnt, st); }
+        launch_raw_stats(vd[(size_t)k].rowcnt, views[k].S_src, views[k].N, vd[(size_t)k].stats, st);
+        { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("phase 1 launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
+        for (int j = 0; j < views[k].n_tbm; ++j) pairs += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
+    }
+    int* hstats = reinterpret_cast<int*>(c->ch_pin_res.as<unsigned char>() + (size_t)n_views * sizeof(ChainResult));
+    HIPCHK(c, hipMemcpyAsync(hstats, c->ch_rowcnt.as<int>() + rowcnt_ints, (size_t)n_views * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    long long raw_sum = 0;
+    int raw_max = 0;
+    for (int k = 0; k < n_views; ++k) { raw_sum += hstats[2 * k]; raw_max = std::max(raw_max, hstats[2 * k]); }
+    c->stats[0] = pairs; c->stats[1] = (double)raw_sum;
+
+    // ---- capacities (guarded on the device; an overflow restarts the chain at that view with more room)
+    size_t cand_cap = (size_t)raw_max + (size_t)raw_max / 2 + 65536;
+    size_t arena_cap = (size_t)(raw_sum / 8) + 1048576;
+    ChainResult* hres = c->ch_pin_res.as<ChainResult>();
+    std::vector<hipEvent_t> ev((size_t)n_views, nullptr);
+    const size_t nrow_max = (size_t)maxS * maxN;
+    HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));
+    HIPCHK(c, c->ch_cursor.reserve(nrow_max * 4 + 16));
+    HIPCHK(c, c->kept_cnt.reserve((size_t)maxS * 4 + 4));
+    HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
+    int* arena_cursor = c->ch_flags.as<int>();
+    int k_enq = 0;                      // next view to enqueue
+    const int kAhead = 16;
+    int rc_final = L3D_OK;
+
+    auto reserve_caps = [&]() -> int {
+        HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
+        HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
+        HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
+        HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
+        return L3D_OK;
+    };
+    { int rc = reserve_caps(); if (rc) return rc; }
+
+    auto enqueue_view = [&](int k) -> int {
+        const l3d_chain_view& v = views[k];
+        const ViewDev& d = vd[(size_t)k];
+        if (!d.verified) return L3D_OK;
+        const PairArgs pa0 = pair_args(k);
+        PairArgs pa = pa0;
+        pa.cand_cap = (int)cand_cap;
+        const int S = v.S_src, N = v.N;
+        const size_t nrow = (size_t)S * N;
+        Match* arena = c->ch_kept.as<Match>();
+        ChainResult* dres = c->ch_res.as<ChainResult>();
+        const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
+        HIPCHK(c, hipMemsetAsync(c->ch_cursor.p, 0, nrow * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S * 4, st));
+        const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
+        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
+        { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, st); }
+        if (S > 0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+        {
+            ProfScope p(c, "exist");
+            launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
+                                 c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
+            if (v.n_sources) launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(),
+                                                    c->cand_depths.as<float4>(), (int)cand_cap, st);
+        }
+        VerifyArgs va;
+        va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
+        va.P = reinterpret_cast<const float*>(dtab + d.o_P);
+        va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
+        va.row_start = c->row_start.as<int>();
+        va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
+        va.N = N; va.seg_begin = 0; va.seg_end = S;
+        va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
+        va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
+        // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the all-pairs kernel
+        int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
+        while (mmax > 64 && verify_window_lds_bytes(mmax, N) > 150 * 1024) mmax /= 2;
+        va.mmax = mmax;
+        if (c->verify_mode == 0) {
+            va.skip_above = 1; va.only_above = -1;
+            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+            va.only_above = mmax;
+            { ProfScope p(c, "verify"); launch_verify(va, st); }
+        } else {
+            va.skip_above = 0; va.only_above = -1;
+            ProfScope p(c, "verify"); launch_verify(va, st);
+        }
+        { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
+        { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, st); }
+        launch_kept_alloc(c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, arena_cursor, (int)arena_cap, (int)cand_cap, dres + k, st);
+        { ProfScope p(c, "kept_write"); launch_kept_write_chain(va, c->kept_start.as<int>(), reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, (int)arena_cap, st); }
+        HIPCHK(c, hipMemcpyAsync(hres + k, dres + k, sizeof(ChainResult), hipMemcpyDeviceToHost, st));
+        if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
+        HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
+        return L3D_OK;
+    };
+
+    // ---- phase 2 + trailing result loop
+    double kept_total = 0;
+    for (int k = 0; k < n_views && rc_final == L3D_OK; ++k) {
+        while (k_enq < n_views && k_enq <= k + kAhead) { int rc = enqueue_view(k_enq); if (rc) { rc_final = rc; break; } ++k_enq; }
+        if (rc_final) break;
+        const l3d_chain_view& v = views[k];
+        const ViewDev& d = vd[(size_t)k];
+        if (!d.verified) {                      // cudawrapper.cu:877-878: nothing to match, the caller keeps its list
+            if (cb(user, k, 0, nullptr, 0, nullptr, 0, 0)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
+            continue;
+        }
+        HIPCHK(c, hipEventSynchronize(ev[(size_t)k]));
+        const ChainResult r = hres[k];
+        if (r.overflow) {
+            // not enough room for this view's candidates / kept matches: everything before it is valid and stays
+            // in the arena; wait for the queue to drain, grow, and re-enqueue from this view
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
+            if (r.overflow & 2) {
+                // the arena cannot be reallocated without losing earlier lists that later views still read:
+                // copy it over
+                const size_t new_cap = arena_cap * 2;
+                void* np = nullptr;
+                HIPCHK(c, hipMalloc(&np, new_cap * sizeof(Match)));
+                HIPCHK(c, hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice));
+                (void)hipFree(c->ch_kept.p);
+                c->ch_kept.p = np; c->ch_kept.cap = new_cap * sizeof(Match);
+                arena_cap = new_cap;
+            }
+            { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
+            HIPCHK(c, hipMemcpy(arena_cursor, &r.kept_base, 4, hipMemcpyHostToDevice));
+            // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
+            for (int j = k; j < k_enq; ++j) {
+                if (!vd[(size_t)j].verified || views[j].S_src == 0) continue;
+                HIPCHK(c, hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st));
+                launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);
+            }
+            k_enq = k;
+            --k;
+            continue;
+        }
+        // kept slice and best depths: bulk copies on the copy stream, concurrent with the kernels of later views
+        HIPCHK(c, c->ch_pin_kept.reserve((size_t)r.n_kept * sizeof(Match) + 16));
+        HIPCHK(c, c->ch_pin_best.reserve((size_t)v.S_src * 8 + 16));
+        if (r.n_kept)
+            HIPCHK(c, hipMemcpyAsync(c->ch_pin_kept.p, c->ch_kept.as<Match>() + r.kept_base, (size_t)r.n_kept * sizeof(Match),
+                                     hipMemcpyDeviceToHost, c->copy_stream));
+        if (v.S_src) HIPCHK(c, hipMemcpyAsync(c->ch_pin_best.p, d.best, (size_t)v.S_src * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        float* best = c->ch_pin_best.as<float>();
+        int nb = 0;
+        if (r.R > 0)
+            for (int s = 0; s < v.S_src; ++s)
+                if (best[2 * s] != -1.0f) { best[2 * nb] = best[2 * s]; best[2 * nb + 1] = best[2 * s + 1]; ++nb; }   // in place: nb <= s
+        kept_total += r.n_kept;
+        if (cb(user, k, 1, c->ch_pin_kept.as<l3d_match>(), r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
+    c->stats[3] = kept_total;
+    return rc_final;
+}

@@ -1,0 +1,154 @@
+// l3d_ctx.hpp -- the context behind the C ABI (shared by l3d_capi.hip and l3d_chain.hip): device arenas,
+// pinned staging, per-kernel HIP-event profiling.
+#pragma once
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/line3d_amd.h"
+#include "l3d_kernels.hpp"
+
+namespace l3d {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;      // grow-only arena with slack
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinBuf {                     // pinned host staging (async copies that really are async)
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+
+}  // namespace l3d
+
+struct l3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;       // bulk D2H of the resident chain, concurrent with kernels
+    std::string err;
+    // arenas of the matching path
+    l3d::DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
+    l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps;
+    l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
+    // arenas of the resident chain (l3d_chain.hip)
+    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags;
+    l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    std::vector<int> h_cnt;
+    int mmax_seen = 0;
+    int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
+    // other paths
+    l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
+    std::unordered_map<const void*, std::pair<void*, size_t>> resident;
+    bool prof_on = false;
+    std::map<std::string, l3d::ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    double stats[4] = { 0, 0, 0, 0 };
+    double tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host-side phase timers of l3d_compute_pairwise_matches (L3D_TIMING=1)
+};
+
+namespace l3d {
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+inline int fail(l3d_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return l3d::fail(ctx, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipEvent_t get_event(l3d_ctx* c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    l3d_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(l3d_ctx* c_, const char* n) : c(c_), name(n)
+    {
+        if (c->prof_on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope()
+    {
+        if (c->prof_on) { (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
+    }
+};
+
+inline void prof_resolve(l3d_ctx* c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches += 1; }
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// host pointer -> device pointer, uploading unless the array is registered as resident
+template <class T>
+int to_device(l3d_ctx* c, DevBuf& buf, const void* host, size_t bytes, const T** out)
+{
+    auto it = c->resident.find(host);
+    if (it != c->resident.end() && it->second.second == bytes) { *out = reinterpret_cast<const T*>(it->second.first); return L3D_OK; }
+    HIPCHK(c, buf.reserve(bytes ? bytes : 16));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, c->stream));
+    *out = buf.as<T>();
+    return L3D_OK;
+}
+
+// device pointer of an array registered with l3d_register_segments, or null
+inline const void* resident_ptr(l3d_ctx* c, const void* host, size_t bytes)
+{
+    auto it = c->resident.find(host);
+    return (it != c->resident.end() && it->second.second == bytes) ? it->second.first : nullptr;
+}
+
+}  // namespace l3d

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
     const int total = base;
     if (lane == 0) s_pref[wave][nw] = total;
     if (total == 0) return;
+    if (a.cand_cap && row_start[(size_t)a.S_src * a.N] > a.cand_cap) return;   // overflow: the chain is re-run with more room
 
     const SrcPairInv s = make_src_inv(a.src_segs[y], a.F + cam * 9);
     const f3 C_tgt = mk3(a.centers[cam * 3], a.centers[cam * 3 + 1], a.centers[cam * 3 + 2]);
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(256) void k_verify(VerifyArgs a)
     const int tid = threadIdx.x;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    if (m == 0) return;
+    if (m == 0 || m <= a.only_above) return;
+    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) return;   // candidate overflow: the chain is re-run
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     if (tid == 0) {
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(256) void k_seg_post(VerifyArgs a, int* __restrict_
     const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (y >= a.seg_end) return;
+    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) { if (lane == 0) { kept_cnt[y] = 0; best_depths[y] = make_float2(-1.0f, -1.0f); } return; }
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     float best = 0.0f;

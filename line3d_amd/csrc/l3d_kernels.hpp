@@ -30,6 +30,10 @@ struct Hypothesis {                 // == l3d_hypothesis
     uint32_t pad;
 };
 
+struct ChainResult {                // per view of the resident chain (device -> pinned host)
+    int kept_base, n_kept, R, overflow;
+};
+
 struct PairArgs {
     const float4* src_segs;         // S_src
     const float4* tgt_segs;         // concatenated neighbours
@@ -43,6 +47,7 @@ struct PairArgs {
     unsigned long long* mask;       // [n_tbm][S_src][W64]
     int S_src, N, n_tbm, W64;
     int seg_begin, seg_end;
+    int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
 };
 
 struct VerifyArgs {
@@ -58,6 +63,10 @@ struct VerifyArgs {
     float* cand_conf;
     int N, seg_begin, seg_end;
     int mmax;                       // max candidates of one segment (LDS sizing)
+    int only_above;                 // k_verify (all-pairs): process only segments with more than this many candidates (-1: all)
+    int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to k_verify (0/1)
+    int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
+    const struct ChainResult* res;  // optional device record of the resident chain (kept base/count)
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
@@ -75,6 +84,16 @@ size_t verify_window_lds_bytes(int mmax, int N);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
 void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);
+// resident chain (l3d_chain.hip)
+void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                        int N, int S, int* rowcnt, hipStream_t st);
+void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                          int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
+void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st);
+void launch_raw_stats(const int* rowcnt, int S, int N, int* out2, hipStream_t st);
+void launch_kept_alloc(const int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap, int cand_cap,
+                       ChainResult* res, hipStream_t st);
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int arena_cap, hipStream_t st);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);

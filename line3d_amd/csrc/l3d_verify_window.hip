@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    if (m == 0) return;
+    if (m == 0 || (a.skip_above && m > a.mmax)) return;
+    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) return;     // candidate overflow: the chain is re-run
     if (a.debug == 4) return;
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)

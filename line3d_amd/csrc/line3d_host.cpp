@@ -142,6 +142,7 @@ struct l3d_line3d {
     std::vector<std::pair<Key, Key>> pot_foreign;              // keys whose camera is not a view (early-return quirk)
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
     bool keep_view_matches = false;
+    bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
 
     // final hypotheses
     std::vector<Hyp> hyps;                                     // best_match_ in key order
@@ -572,8 +573,8 @@ void match_begin(L* h)
     h->t_match = h->t_gpu_call = h->t_commit = h->t_finalize = 0;
 }
 
-// Line3D::matchViews, line3D.cc:620-648
-int match_views(L* h)
+// Line3D::matchViews, line3D.cc:620-648 -- one view after the other through the per-view seam call
+int match_views_sync(L* h)
 {
     const double t0 = now_s();
     match_begin(h);
@@ -585,6 +586,107 @@ int match_views(L* h)
         commit_view(h, v, m, n, med);
         l3d_free(m);
     }
+    finalize_matching(h);
+    h->t_match = now_s() - t0;
+    return L3D_OK;
+}
+
+// the static part of commit_view: matched_ after view v has been processed (line3D.cc:875-881)
+void mark_matched(L* h, const View& v)
+{
+    for (uint32_t nb : h->visual_neighbors[v.id]) {
+        h->matched.insert(((uint64_t)v.id << 32) | nb);
+        if (h->vn_has(nb, v.id)) h->matched.insert(((uint64_t)nb << 32) | v.id);
+    }
+}
+
+struct ChainUser { L* h; const std::vector<uint32_t>* order; const std::vector<int>* n_tbm; };
+
+int chain_callback(void* user, int index, int verified, const l3d_match* kept, int n_kept, const float* best, int n_best, int n_cand)
+{
+    ChainUser* u = static_cast<ChainUser*>(user);
+    L* h = u->h;
+    View& v = h->views[(*u->order)[(size_t)index]];
+    h->stat_last_tbm = (*u->n_tbm)[(size_t)index];
+    if (!verified) {                                    // cudawrapper.cu:877-878: the localized list comes back untouched
+        std::vector<l3d_match> existing;
+        localized_existing(h, v, existing);
+        commit_view(h, v, existing.data(), (int)existing.size(), 1.0f);
+        return 0;
+    }
+    float median = 1.0f;                                // line3D.cc:811; untouched when nothing was verified (:955-956)
+    if (n_cand > 0) {
+        median = -1.0f;                                 // cudawrapper.cu:1066-1073
+        if (n_best > 0) {
+            std::vector<float> d(best, best + (size_t)n_best * 2);
+            std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
+            median = d[d.size() / 2];
+        }
+    }
+    commit_view(h, v, kept, n_kept, median);
+    return 0;
+}
+
+// Line3D::matchViews as one device-resident chain (l3d_match_chain): the schedule is simulated first (it does not
+// depend on data), then the GPU runs ahead while the callback does the bookkeeping of each finished view.
+int match_views(L* h)
+{
+    if (h->force_sync) return match_views_sync(h);
+    const double t0 = now_s();
+    match_begin(h);
+    const size_t n = h->order.size();
+    std::vector<Marshal> ms(n);
+    std::vector<std::vector<int32_t>> src_cam(n), src_idx(n);
+    std::vector<l3d_chain_view> cv(n);
+    std::vector<int> n_tbm(n);
+    std::map<uint32_t, int> index_of;
+    bool chain_ok = true;
+    for (size_t k = 0; k < n && chain_ok; ++k) {
+        View& v = h->views[h->order[k]];
+        index_of[v.id] = (int)k;
+        Marshal& m = ms[k];
+        marshal_view(h, v, m);                          // toBeMatched from the simulated matched_ state
+        n_tbm[k] = (int)m.tbm.size();
+        std::vector<char> is_tbm(m.l2g.size(), 0);
+        for (int32_t c : m.tbm) is_tbm[(size_t)c] = 1;
+        for (size_t c = 0; c < m.l2g.size(); ++c) {
+            if (is_tbm[c]) continue;
+            auto it = index_of.find(m.l2g[c]);
+            if (it == index_of.end() || it->second >= (int)k) { chain_ok = false; break; }   // cannot happen: matched => processed earlier
+            src_cam[k].push_back((int32_t)c);
+            src_idx[k].push_back(it->second);
+        }
+        if (m.tbm.empty()) {
+            // the early return hands back LOCAL camera ids (cudawrapper.cu:877-878); if one of those numbers happens
+            // to be a view that would accept reverse matches (line3D.cc:844-845) the data flow is no longer the
+            // static one -> take the per-view path
+            for (uint32_t c = 0; c < (uint32_t)m.l2g.size(); ++c)
+                if (h->vn_has(c, v.id) && !h->matched.count(((uint64_t)c << 32) | v.id)) chain_ok = false;
+        }
+        l3d_chain_view& o = cv[k];
+        o.view_id = v.id;
+        o.src_segs = v.segs.data(); o.S_src = v.S();
+        o.RtKinv_src = m.RtKinv_src; o.C_src = m.C_src;
+        o.tgt_segs = v.nb_segs.data(); o.n_tgt = (int32_t)(v.nb_segs.size() / 4);
+        o.offsets = m.offsets.data(); o.N = (int32_t)m.l2g.size();
+        o.F = m.F.data(); o.RtKinv = m.RtKinv.data(); o.centers = m.centers.data(); o.P = m.P.data();
+        o.to_be_matched = m.tbm.data(); o.n_tbm = (int32_t)m.tbm.size();
+        o.local2global = m.l2g.data();
+        o.source_cam = src_cam[k].data(); o.source_index = src_idx[k].data(); o.n_sources = (int32_t)src_cam[k].size();
+        o.sigma_p = h->sigma_p; o.sigma_a = h->sigma_a; o.spatial_k = m.spatial_k;
+        mark_matched(h, v);
+    }
+    h->matched.clear();                                 // back to the state matchViews starts from
+    if (!chain_ok) return match_views_sync(h);
+    ChainUser user{ h, &h->order, &n_tbm };
+    const double t1 = now_s();
+    int rc = l3d_match_chain(h->ctx, cv.data(), (int)n, chain_callback, &user);
+    h->t_gpu_call += now_s() - t1 - h->t_commit;
+    if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
+    double st[4];
+    l3d_last_stats(h->ctx, st);
+    h->stat_pairs += st[0];
+    h->stat_raw += st[1];
     finalize_matching(h);
     h->t_match = now_s() - t0;
     return L3D_OK;
@@ -928,6 +1030,7 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
     if (h->unc_upper <= h->unc_lower) h->unc_upper = h->unc_lower + 1.0f;
     h->sigma_p = sigma_p; h->sigma_a = sigma_a; h->min_baseline = min_baseline;
     h->use_collinearity = use_collinearity != 0;
+    h->force_sync = getenv("L3D_MATCH_SYNC") != nullptr;
     *out = h;
     return L3D_OK;
 }
@@ -1115,6 +1218,7 @@ int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, fl
 }
 
 // ---- inspection for tests / bench ----------------------------------------------------------------
+int l3d_line3d_set_sync_matching(l3d_line3d* h, int on) { if (!h) return L3D_ERR_INVALID; h->force_sync = on != 0; return L3D_OK; }
 int l3d_line3d_keep_view_matches(l3d_line3d* h, int on) { if (!h) return L3D_ERR_INVALID; h->keep_view_matches = on != 0; return L3D_OK; }
 int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median)
 {

@@ -158,6 +158,9 @@ class Line3D:
         self._chk(self.lib.l3d_line3d_match_end(self.h))
 
     # -- inspection ------------------------------------------------------------------------------
+    def set_sync_matching(self, on=True):
+        self._chk(self.lib.l3d_line3d_set_sync_matching(self.h, C.c_int(int(on))))
+
     def keep_view_matches(self, on=True):
         self._chk(self.lib.l3d_line3d_keep_view_matches(self.h, C.c_int(int(on))))
 

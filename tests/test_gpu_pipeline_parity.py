@@ -109,3 +109,38 @@ def test_stepwise_sharded_matching_equals_whole(small_scene, small_oracle):
         assert np.float32(med) == np.float32(small_oracle.trace[v]["median"])
     assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
     l.close()
+
+
+def test_chain_and_per_view_matching_agree(small_scene, small_oracle):
+    """matchViews as the device-resident chain (default) and through the per-view seam call: identical kept lists,
+    affinity edges and lines (and both equal to the oracle)."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    outs = []
+    for sync in (False, True):
+        l = Line3D("", matchingNeighbors=6)
+        l.set_sync_matching(sync)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.compute3Dmodel(False)
+        per_view = {v: l.view_matches(v)[0].tobytes() for v in small_oracle.trace}
+        meds = {v: np.float32(l.view_matches(v)[1]) for v in small_oracle.trace}
+        outs.append((per_view, meds, l.affinity()[0].tobytes(), l.getResult()))
+        l.close()
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    for v in small_oracle.trace:
+        assert outs[0][0][v] == small_oracle.trace[v]["matches"].tobytes()
+    assert_lines_equal(outs[0][3], small_oracle.result, 1e-4)
+
+
+def test_chain_rerun_is_idempotent(small_scene):
+    from line3d_amd.pipeline import Line3D, load_scene
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.prepare()
+    l.match_views()
+    a = {v["id"]: l.view_matches(v["id"])[0].tobytes() for v in small_scene.views}
+    l.match_views()
+    b = {v["id"]: l.view_matches(v["id"])[0].tobytes() for v in small_scene.views}
+    assert a == b and sum(len(x) for x in a.values()) > 0
+    l.close()
