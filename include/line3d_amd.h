@@ -164,6 +164,9 @@ int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
 /* stage-2 algorithm: 0 = depth-window search (default; falls back to all-pairs when a segment's candidates do
  * not fit in LDS), 1 = all-pairs loop in the reference's formulation.  Results are bit-identical. */
 int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
+/* stage-1 conservative wedge pre-test in front of the exact epipolar/overlap test: 1 = on (default), 0 = off (A/B
+ * testing; results are bit-identical, the pre-test only rejects pairs the exact test rejects) */
+int l3d_set_pair_pretest(l3d_ctx* ctx, int on);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
 int l3d_profile_reset(l3d_ctx* ctx);
 int l3d_profile_get(l3d_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);

@@ -97,6 +97,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
     return L3D_OK;
 }
 
+int l3d_set_pair_pretest(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->wedge_pretest = on ? 1 : 0; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
 int l3d_profile_reset(l3d_ctx* c)
@@ -226,7 +227,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
-    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest;
     const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
     // stage 1 starts now; the host orders the existing matches meanwhile

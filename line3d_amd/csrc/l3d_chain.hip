@@ -316,34 +316,43 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
         pa.mask = d.mask;
         pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0;
+        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest;
         return pa;
     };
 
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain setup: ") + hipGetErrorString(e_)); }
-    // ---- phase 1: stage 1 of every view (independent of the chain)
-    double pairs = 0;
+    // ---- phase 1 (stage 1 of a view: pair test -> bit rows -> row counts -> statistics) is independent of the
+    // chain; it is enqueued a window ahead of phase 2 so that the GPU always has work while the host trails behind
+    double pairs = 0, max_pairs = 0;
     for (int k = 0; k < n_views; ++k) {
-        if (!vd[(size_t)k].verified || views[k].S_src == 0) continue;
-        const PairArgs pa = pair_args(k);
-        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, vd[(size_t)k].maxW, st); }
-        { ProfScope p(c, "row_count"); launch_row_count(pa, vd[(size_t)k].rowcnt, st); }
-        launch_raw_stats(vd[(size_t)k].rowcnt, views[k].S_src, views[k].N, vd[(size_t)k].stats, st);
-        { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("phase 1 launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-        for (int j = 0; j < views[k].n_tbm; ++j) pairs += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
+        if (!vd[(size_t)k].verified) continue;
+        double p = 0;
+        for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
+        pairs += p; max_pairs = std::max(max_pairs, p);
     }
     int* hstats = reinterpret_cast<int*>(c->ch_pin_res.as<unsigned char>() + (size_t)n_views * sizeof(ChainResult));
-    HIPCHK(c, hipMemcpyAsync(hstats, c->ch_rowcnt.as<int>() + rowcnt_ints, (size_t)n_views * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    long long raw_sum = 0;
-    int raw_max = 0;
-    for (int k = 0; k < n_views; ++k) { raw_sum += hstats[2 * k]; raw_max = std::max(raw_max, hstats[2 * k]); }
-    c->stats[0] = pairs; c->stats[1] = (double)raw_sum;
+    std::vector<hipEvent_t> ev1((size_t)n_views, nullptr);
+    int k_p1 = 0;                       // next view whose stage 1 is enqueued
+    auto enqueue_stage1 = [&](int k) -> int {
+        if (!vd[(size_t)k].verified) return L3D_OK;
+        if (views[k].S_src > 0) {
+            const PairArgs pa = pair_args(k);
+            { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, vd[(size_t)k].maxW, st); }
+            { ProfScope p(c, "row_count"); launch_row_count(pa, vd[(size_t)k].rowcnt, st); }
+            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].S_src, views[k].N, vd[(size_t)k].stats, st);
+        }
+        HIPCHK(c, hipMemcpyAsync(hstats + 2 * k, vd[(size_t)k].stats, 8, hipMemcpyDeviceToHost, st));
+        ev1[(size_t)k] = get_event(c);
+        HIPCHK(c, hipEventRecord(ev1[(size_t)k], st));
+        return L3D_OK;
+    };
+    c->stats[0] = pairs;
+    double raw_sum = 0;
 
     // ---- capacities (guarded on the device; an overflow restarts the chain at that view with more room)
-    size_t cand_cap = (size_t)raw_max + (size_t)raw_max / 2 + 65536;
-    size_t arena_cap = (size_t)(raw_sum / 8) + 1048576;
+    // first guess from the pair counts (raw density ~6 %, kept ~0.2 % of the pairs on the synthetic scenes)
+    size_t cand_cap = (size_t)(max_pairs * 0.10) + 65536;
+    size_t arena_cap = (size_t)(pairs * 0.004) + 1048576;
     ChainResult* hres = c->ch_pin_res.as<ChainResult>();
     std::vector<hipEvent_t> ev((size_t)n_views, nullptr);
     const size_t nrow_max = (size_t)maxS * maxN;
@@ -352,8 +361,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->kept_cnt.reserve((size_t)maxS * 4 + 4));
     HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
     int* arena_cursor = c->ch_flags.as<int>();
-    int k_enq = 0;                      // next view to enqueue
-    const int kAhead = 16;
+    int k_enq = 0;                      // next view whose phase 2 is enqueued
+    const int kAhead = 12, kStage1Ahead = 24;
     int rc_final = L3D_OK;
 
     auto reserve_caps = [&]() -> int {
@@ -368,9 +377,11 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     auto enqueue_view = [&](int k) -> int {
         const l3d_chain_view& v = views[k];
         const ViewDev& d = vd[(size_t)k];
+        while (k_p1 < n_views && k_p1 <= k + kStage1Ahead) { int rc = enqueue_stage1(k_p1); if (rc) return rc; ++k_p1; }
         if (!d.verified) return L3D_OK;
-        const PairArgs pa0 = pair_args(k);
-        PairArgs pa = pa0;
+        HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
+        raw_sum += hstats[2 * k];
+        PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
         const int S = v.S_src, N = v.N;
         const size_t nrow = (size_t)S * N;
@@ -481,6 +492,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     }
     HIPCHK(c, hipStreamSynchronize(st));
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
+    for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
+    c->stats[1] = raw_sum;
     c->stats[3] = kept_total;
     return rc_final;
 }

@@ -70,6 +70,7 @@ struct l3d_ctx {
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     std::vector<int> h_cnt;
     int mmax_seen = 0;
+    int wedge_pretest = 1;          // stage-1 wedge pre-test (0 only for A/B testing)
     int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;

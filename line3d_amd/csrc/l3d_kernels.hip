@@ -25,13 +25,22 @@ namespace l3d {
 // segments whose invariants are staged in LDS and read as broadcasts.  One wave ballot = one
 // 64-bit word of the (camera, src) bit row.
 // =================================================================================================
-// Pairs that pass the overlap test (~8 %) are not triangulated in place -- that would run the ~300-instruction
-// triangulation with a handful of live lanes on nearly every iteration -- but pushed to a per-wave LDS ring
-// (source index, origin lane, the four intersection points) and triangulated 64 at a time with full waves.
+// Three levels, each run with (nearly) full waves:
+//   1. wedge pre-test on ALL pairs (~45 instructions): the epipolar lines of the source endpoints bound a double wedge
+//      in the target image (x is on the epipolar line of some source point iff (epi_p1.x)(epi_p2.x) <= 0); a target
+//      segment entirely outside it, by a safety margin, cannot overlap [l2_p1, l2_p2] -- the reference's
+//      D_segment_overlap_2D returns 0 for it -- and symmetrically for the source segment and the target's wedge.
+//      The margin (1e-4 of the term magnitudes, i.e. ~0.2 px against ~1e-6 relative float error) keeps the pre-test
+//      strictly conservative: it only ever rejects pairs the full float test rejects (tests/: A/B on whole scenes).
+//   2. survivors (~12 %) go to a per-wave LDS ring and get the exact overlap test 64 at a time,
+//   3. its survivors (~8 %) go to a second ring and are triangulated 64 at a time.
 constexpr int kPairQueue = 128;
+constexpr float kWedgeTau = 1.0e-4f;
 struct PairQEntry { int key; float p[8]; };   // key = src_local | origin_lane << 8
 
-__device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n, const SrcPairInv* s_src, float4 tseg,
+struct SrcBlockInv { SrcPairInv s; float m1, m2; };   // + wedge margins of epi_p1 / epi_p2 against this tile's targets
+
+__device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n, const SrcBlockInv* s_src, float4 tseg,
                                                  const float* RtKinv_src, const float* RtKinv_tgt, f3 C_src, f3 C_tgt,
                                                  unsigned long long* s_bits, int wave, int lane)
 {
@@ -42,7 +51,7 @@ __device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n,
     const float qx = __shfl(tseg.x, origin), qy = __shfl(tseg.y, origin), qz = __shfl(tseg.z, origin), qw = __shfl(tseg.w, origin);
     if (lane < n) {
         SrcPairInv s;
-        s.p1 = s_src[k].p1; s.p2 = s_src[k].p2;
+        s.p1 = s_src[k].s.p1; s.p2 = s_src[k].s.p2;
         TgtPairInv t;
         t.q1 = mk3(qx, qy, 1.0f); t.q2 = mk3(qz, qw, 1.0f);
         const float4 d = pair_depths(s, t, mk3(e.p[0], e.p[1], 1.0f), mk3(e.p[2], e.p[3], 1.0f), mk3(e.p[4], e.p[5], 1.0f),
@@ -52,10 +61,21 @@ __device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n,
     }
 }
 
+// a and b: algebraic distances of the two endpoints of one segment to one line; true if both are on the same side,
+// farther than the margin; sgn returns that side
+__device__ __forceinline__ bool same_side(float a, float b, float m, bool& positive)
+{
+    positive = a > 0.0f;
+    return (a > m && b > m) || (a < -m && b < -m);
+}
+
 __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
 {
-    __shared__ SrcPairInv s_src[kSrcPerBlock];
+    __shared__ SrcBlockInv s_src[kSrcPerBlock];
+    __shared__ TgtPairInv s_tgt[256];
     __shared__ float s_cam[9 + 9 + 3];   // F, RtKinv_tgt, C_tgt of this camera
+    __shared__ float s_ext[4];           // max |x|, |y| of this tile's target endpoints / this block's source endpoints
+    __shared__ unsigned short s_qa[4][kPairQueue];
     __shared__ PairQEntry s_q[4][kPairQueue];
     __shared__ unsigned long long s_bits[kSrcPerBlock * 4];
 
@@ -74,29 +94,57 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     else if (tid < 18) s_cam[tid] = a.RtKinv[cam * 9 + (tid - 9)];
     else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
     if (tid < kSrcPerBlock * 4) s_bits[tid] = 0ull;
+    if (tid < 4) s_ext[tid] = 0.0f;
     __syncthreads();
-    if (tid < kSrcPerBlock && y0 + tid < a.seg_end) s_src[tid] = make_src_inv(a.src_segs[y0 + tid], s_cam);
 
     const bool valid = x < width;
     const float4 tseg = valid ? a.tgt_segs[toff + x] : make_float4(0.f, 0.f, 1.f, 1.f);
     const TgtPairInv t = make_tgt_inv(tseg, s_cam);
+    s_tgt[tid] = t;
+    const int ny = min(kSrcPerBlock, a.seg_end - y0);
+    {   // coordinate extents for the wedge margins (non-negative floats order like ints)
+        float ex = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.x), __builtin_fabsf(tseg.z)) : 0.0f;
+        float ey = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.y), __builtin_fabsf(tseg.w)) : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) { ex = __builtin_fmaxf(ex, __shfl_down(ex, o)); ey = __builtin_fmaxf(ey, __shfl_down(ey, o)); }
+        if (lane == 0) { atomicMax(reinterpret_cast<int*>(&s_ext[0]), __float_as_int(ex)); atomicMax(reinterpret_cast<int*>(&s_ext[1]), __float_as_int(ey)); }
+        if (tid < ny) {
+            const float4 sg = a.src_segs[y0 + tid];
+            atomicMax(reinterpret_cast<int*>(&s_ext[2]), __float_as_int(__builtin_fmaxf(__builtin_fabsf(sg.x), __builtin_fabsf(sg.z))));
+            atomicMax(reinterpret_cast<int*>(&s_ext[3]), __float_as_int(__builtin_fmaxf(__builtin_fabsf(sg.y), __builtin_fabsf(sg.w))));
+        }
+    }
+    __syncthreads();
+    if (tid < ny) {
+        SrcBlockInv b;
+        b.s = make_src_inv(a.src_segs[y0 + tid], s_cam);
+        b.m1 = kWedgeTau * (__builtin_fabsf(b.s.epi_p1.x) * s_ext[0] + __builtin_fabsf(b.s.epi_p1.y) * s_ext[1] + __builtin_fabsf(b.s.epi_p1.z));
+        b.m2 = kWedgeTau * (__builtin_fabsf(b.s.epi_p2.x) * s_ext[0] + __builtin_fabsf(b.s.epi_p2.y) * s_ext[1] + __builtin_fabsf(b.s.epi_p2.z));
+        s_src[tid] = b;
+    }
+    const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * s_ext[2] + __builtin_fabsf(t.epi_q1.y) * s_ext[3] + __builtin_fabsf(t.epi_q1.z));
+    const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * s_ext[2] + __builtin_fabsf(t.epi_q2.y) * s_ext[3] + __builtin_fabsf(t.epi_q2.z));
     const f3 C_tgt = mk3(s_cam[18], s_cam[19], s_cam[20]);
     const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     __syncthreads();
 
+    unsigned short* qa = s_qa[wave];
     PairQEntry* q = s_q[wave];
-    int head = 0, count = 0;                 // wave-uniform
-    const int ny = min(kSrcPerBlock, a.seg_end - y0);
-    for (int k = 0; k < ny; ++k) {
-        const SrcPairInv& s = s_src[k];
+    const TgtPairInv* tw = s_tgt + wave * 64;
+    int ha = 0, ca = 0, head = 0, count = 0;       // wave-uniform ring states
+
+    // level 2: exact overlap test for up to 64 queued pairs; survivors move on to the triangulation ring
+    auto drain_a = [&](int n) {
+        const unsigned key = qa[(ha + lane) & (kPairQueue - 1)];
+        const int k = key & 0xff, origin = (key >> 8) & 63;
         f3 l2_p1, l2_p2, l1_q1, l1_q2;
-        const bool pass = valid && pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
+        bool pass = false;
+        if (lane < n) pass = pair_overlap_test(s_src[k].s, tw[origin], l2_p1, l2_p2, l1_q1, l1_q2);
         const unsigned long long pm = __ballot(pass);
         if (pm) {
             if (pass) {
                 const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kPairQueue - 1);
                 PairQEntry e;
-                e.key = k | (lane << 8);
+                e.key = k | (origin << 8);
                 e.p[0] = l2_p1.x; e.p[1] = l2_p1.y; e.p[2] = l2_p2.x; e.p[3] = l2_p2.y;
                 e.p[4] = l1_q1.x; e.p[5] = l1_q1.y; e.p[6] = l1_q2.x; e.p[7] = l1_q2.y;
                 q[pos] = e;
@@ -109,7 +157,34 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
                 count -= 64;
             }
         }
+        ha = (ha + n) & (kPairQueue - 1);
+        ca -= n;
+    };
+
+    for (int k = 0; k < ny; ++k) {
+        // level 1: wedge pre-test (broadcast reads of the source invariants)
+        const SrcBlockInv& sb = s_src[k];
+        bool cand = valid;
+        if (a.wedge_pretest) {
+            bool pa, pb;
+            const bool sa = same_side(line_numer(sb.s.epi_p1, t.q1), line_numer(sb.s.epi_p1, t.q2), sb.m1, pa);
+            const bool sbb = same_side(line_numer(sb.s.epi_p2, t.q1), line_numer(sb.s.epi_p2, t.q2), sb.m2, pb);
+            const bool out2 = sa && sbb && (pa == pb);          // target segment strictly outside the source wedge
+            bool pc, pd;
+            const bool sc = same_side(line_numer(t.epi_q1, sb.s.p1), line_numer(t.epi_q1, sb.s.p2), mq1, pc);
+            const bool sd = same_side(line_numer(t.epi_q2, sb.s.p1), line_numer(t.epi_q2, sb.s.p2), mq2, pd);
+            const bool out1 = sc && sd && (pc == pd);           // source segment strictly outside the target wedge
+            cand = valid && !out1 && !out2;
+        }
+        const unsigned long long cm = __ballot(cand);
+        if (cm) {
+            if (cand) qa[(ha + ca + __popcll(cm & ((1ull << lane) - 1ull))) & (kPairQueue - 1)] = (unsigned short)(k | (lane << 8));
+            ca += __popcll(cm);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (ca >= 64) drain_a(64);
+        }
     }
+    if (ca > 0) drain_a(ca);
     if (count > 0) pair_queue_drain(q, head, count, s_src, tseg, a.RtKinv_src, s_cam + 9, C_src, C_tgt, s_bits, wave, lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < ny) a.mask[((size_t)j * a.S_src + (y0 + lane)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[lane * 4 + wave];

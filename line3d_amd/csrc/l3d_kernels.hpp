@@ -48,6 +48,7 @@ struct PairArgs {
     int S_src, N, n_tbm, W64;
     int seg_begin, seg_end;
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
+    int wedge_pretest;              // 1: conservative wedge pre-test in front of the exact overlap test (default)
 };
 
 struct VerifyArgs {

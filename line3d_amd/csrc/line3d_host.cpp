@@ -5,7 +5,9 @@
 // calls the HIP path exclusively through include/line3d_amd.h.  Cited line numbers refer to the
 // reference files under /root/reference.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -494,39 +496,49 @@ int compute_view(L* h, View& v, int s0, int s1, l3d_match** out, int* n_out, flo
 
 // potential_correspondences_ becomes a sorted, de-duplicated adjacency per view (it is a std::map of
 // std::maps in the reference: set semantics, ascending iteration)
+void finalize_view_pot(std::vector<std::pair<uint32_t, Key>>& p, size_t S)
+{
+    if (p.empty()) return;
+    bool in_range = true;
+    for (auto& e : p) if (e.first >= S) { in_range = false; break; }
+    if (!in_range) { std::sort(p.begin(), p.end()); p.erase(std::unique(p.begin(), p.end()), p.end()); return; }
+    // stable counting sort on the segment, then the (short, nearly sorted) per-segment key lists
+    std::vector<uint32_t> cnt(S + 1, 0);
+    for (auto& e : p) cnt[e.first + 1]++;
+    for (size_t i = 0; i < S; ++i) cnt[i + 1] += cnt[i];
+    std::vector<std::pair<uint32_t, Key>> tmp(p.size());
+    for (auto& e : p) tmp[cnt[e.first]++] = e;
+    size_t b = 0, w = 0;
+    for (size_t s = 0; s < S; ++s) {
+        const size_t e = cnt[s];
+        for (size_t i = b + 1; i < e; ++i) {                // insertion sort on keys
+            auto x = tmp[i];
+            size_t j = i;
+            for (; j > b && tmp[j - 1].second > x.second; --j) tmp[j] = tmp[j - 1];
+            tmp[j] = x;
+        }
+        for (size_t i = b; i < e; ++i)
+            if (i == b || tmp[i].second != tmp[i - 1].second) p[w++] = tmp[i];
+        b = e;
+    }
+    p.resize(w);
+}
+
 void finalize_matching(L* h)
 {
     const double t0 = now_s();
-    std::vector<std::pair<uint32_t, Key>> tmp;
-    std::vector<uint32_t> cnt;
-    for (size_t vi = 0; vi < h->pot.size(); ++vi) {
-        auto& p = h->pot[vi];
-        if (p.empty()) continue;
-        const size_t S = (size_t)h->vlist[vi]->S();
-        bool in_range = true;
-        for (auto& e : p) if (e.first >= S) { in_range = false; break; }
-        if (!in_range) { std::sort(p.begin(), p.end()); p.erase(std::unique(p.begin(), p.end()), p.end()); continue; }
-        // stable counting sort on the segment, then the (short, nearly sorted) per-segment key lists
-        cnt.assign(S + 1, 0);
-        for (auto& e : p) cnt[e.first + 1]++;
-        for (size_t i = 0; i < S; ++i) cnt[i + 1] += cnt[i];
-        tmp.resize(p.size());
-        for (auto& e : p) tmp[cnt[e.first]++] = e;
-        size_t b = 0, w = 0;
-        for (size_t s = 0; s < S; ++s) {
-            const size_t e = cnt[s];
-            for (size_t i = b + 1; i < e; ++i) {                // insertion sort on keys
-                auto x = tmp[i];
-                size_t j = i;
-                for (; j > b && tmp[j - 1].second > x.second; --j) tmp[j] = tmp[j - 1];
-                tmp[j] = x;
-            }
-            for (size_t i = b; i < e; ++i)
-                if (i == b || tmp[i].second != tmp[i - 1].second) p[w++] = tmp[i];
-            b = e;
-        }
-        p.resize(w);
-    }
+    // views are independent here: a few host threads
+    const size_t nv = h->pot.size();
+    const unsigned nt = std::max(1u, std::min(8u, std::min((unsigned)nv, std::thread::hardware_concurrency())));
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (size_t vi = next.fetch_add(1); vi < nv; vi = next.fetch_add(1))
+            finalize_view_pot(h->pot[vi], (size_t)h->vlist[vi]->S());
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
     std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
     h->t_finalize += now_s() - t0;

@@ -187,3 +187,32 @@ def test_window_verify_stress_against_all_pairs(gpu_ctx):
         b, mb, bb = _run_view(gpu_ctx, tr)
         assert len(a) > 500
         assert a.tobytes() == b.tobytes() and ma == mb and np.array_equal(ba, bb)
+
+
+def test_pair_pretest_is_conservative(gpu_ctx):
+    """The stage-1 wedge pre-test may only reject pairs the exact test rejects: with it on and off the number of raw
+    candidates and every output must be identical (several noise levels, ~10^8 pairs)."""
+    from line3d_amd.synth import make_scene
+    total_pairs = 0
+    for seed, noise, S in ((41, 0.5, 1500), (42, 3.0, 1200), (43, 0.0, 1000), (44, 10.0, 800)):
+        sc = make_scene(9, S, 8, seed=seed, noise_px=noise)
+        o = op.OracleLine3D(matching_neighbors=8, use_collinearity=False)
+        for v in sc.views:
+            o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        o.matched, o.potential = {}, {}
+        o.find_visual_neighbors()
+        o.transform_geometry()
+        for n in o.visual_neighbors[4]:
+            o._fundamental(4, n)
+        tr = dict(marshal=o.marshal_view(4), in_matches=np.zeros(0, op.MATCH_DTYPE))
+        res = []
+        for on in (False, True):
+            gpu_ctx.set_pair_pretest(on)
+            m, med, best = _run_view(gpu_ctx, tr)
+            st = gpu_ctx.last_stats()
+            res.append((m.tobytes(), med, best.tobytes(), st[1]))
+            total_pairs += st[0]
+        gpu_ctx.set_pair_pretest(True)
+        assert res[0] == res[1], "seed %d" % seed
+        assert res[0][3] > 10000
+    assert total_pairs > 5e7
