@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--neighbors", type=int, default=12)
     ap.add_argument("--seed", type=int, default=20260)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-segments", type=int, default=96)
+    ap.add_argument("--cpu-sample-segments", type=int, default=1500)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
 
@@ -148,19 +148,28 @@ def main():
         roof = None
         if prof:
             name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
-            # algorithmic HBM bytes per launch (DESIGN.md "Kernels"): per view, R candidates
-            R_per_launch = raw_local / max(1, len(scene.views))
-            pairs_per_launch = pairs_local / max(1, len(scene.views))
+            # algorithmic HBM bytes per launch: one launch = one view
+            nv = max(1, len(scene.views))
+            R_per_launch = raw_local / nv
+            pairs_per_launch = pairs_local / nv
+            n_tbm = args.neighbors / 2.0
             alg = {
-                "verify": 44.0 * R_per_launch,           # meta 8 + depths 16 + target segment 16 read, confidence 4 written
-                "pair_mask": pairs_per_launch / 8.0 + 16.0 * 2 * args.segments * args.neighbors / 2,  # bit rows + segments
-                "pair_fill": (24.0 + 8.0) * R_per_launch,
+                "pair_mask": 16.0 * args.segments * (1 + n_tbm) + pairs_per_launch / 8.0,   # segments read once + 1 bit per pair
+                "verify_window": 28.0 * R_per_launch,        # candidate meta 8 + depths 16 read, confidence 4 written
+                "verify": 44.0 * R_per_launch,
+                "pair_fill": pairs_per_launch / 8.0 + 24.0 * R_per_launch,
+                "exist": 2 * 32.0 * st["kept"] / nv * n_tbm,  # the sources' kept lists are read twice (count, scatter)
             }.get(name, 0.0)
             avg_ms = ms / max(1, launches)
             achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/README.md)
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
-                        traffic=None, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
-                        note="path is FP32-VALU bound, not HBM bound (SURVEY.md 8d); see kernels_ms for the split",
+                        traffic=traffic, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
+                        note="the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
+                             "view and stay in L2/LDS; kernels_ms gives the per-step time split",
                         kernels_ms={k: round(v[1] / args.steps, 3) for k, v in prof.items() if v[0]})
         out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",

@@ -59,43 +59,52 @@ __global__ void k_exist_scatter(const Match* __restrict__ arena, const ChainResu
     }
 }
 
-// The scatter order inside a (segment, camera) run is arbitrary; runs are short (a handful of entries).  One thread
-// sorts one run by target id, which restores the (segment, camera, target) order of the reference's list sort:
-// runs of up to 16 entries are loaded once, sorted in registers (odd-even transposition) and written back.
-template <int K>
-__device__ __forceinline__ void sort_run_regs(uint2* meta, float4* depths, int b, int n)
-{
-    unsigned key[K];
-    float4 d[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) { key[i] = i < n ? meta[b + i].x : 0xffffffffu; if (i < n) d[i] = depths[b + i]; }
-#pragma unroll
-    for (int pass = 0; pass < K; ++pass)
-#pragma unroll
-        for (int i = pass & 1; i + 1 < K; i += 2)
-            if (key[i] > key[i + 1]) { const unsigned t = key[i]; key[i] = key[i + 1]; key[i + 1] = t; const float4 td = d[i]; d[i] = d[i + 1]; d[i + 1] = td; }
-#pragma unroll
-    for (int i = 0; i < K; ++i) if (i < n) { meta[b + i].x = key[i]; depths[b + i] = d[i]; }
-}
-
-__global__ void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S, const int* __restrict__ row_start,
-                                  uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
+// The scatter order inside a (segment, camera) run is arbitrary.  One wave per run restores the (segment, camera,
+// target) order of the reference's list sort: every lane holds up to four entries in registers, ranks them by
+// counting (keys are broadcast with shuffles, target ids inside a run are distinct) and writes them to their place.
+__global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S,
+                                                         const int* __restrict__ row_start, uint2* __restrict__ meta,
+                                                         float4* __restrict__ depths, int cap)
 {
     if (row_start[(size_t)S * N] > cap) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (t >= S * n_cams) return;
     const int seg = t / n_cams, cam = cams[t % n_cams];
     const int b = row_start[seg * N + cam], n = row_start[seg * N + cam + 1] - b;
     if (n < 2) return;
-    if (n <= 4) { sort_run_regs<4>(meta, depths, b, n); return; }
-    if (n <= 8) { sort_run_regs<8>(meta, depths, b, n); return; }
-    if (n <= 16) { sort_run_regs<16>(meta, depths, b, n); return; }
-    for (int i = b + 1; i < b + n; ++i) {               // long runs: in place
-        const uint2 m = meta[i];
-        const float4 d = depths[i];
-        int j = i;
-        for (; j > b && meta[j - 1].x > m.x; --j) { meta[j] = meta[j - 1]; depths[j] = depths[j - 1]; }
-        meta[j] = m; depths[j] = d;
+    if (n > 256) {                                  // pathological run: one lane, in place
+        if (lane == 0)
+            for (int i = b + 1; i < b + n; ++i) {
+                const uint2 m = meta[i];
+                const float4 d = depths[i];
+                int j = i;
+                for (; j > b && meta[j - 1].x > m.x; --j) { meta[j] = meta[j - 1]; depths[j] = depths[j - 1]; }
+                meta[j] = m; depths[j] = d;
+            }
+        return;
+    }
+    unsigned key[4];
+    float4 d[4];
+    int rank[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane + 64 * r;
+        key[r] = i < n ? meta[b + i].x : 0xffffffffu;
+        if (i < n) d[r] = depths[b + i];
+    }
+    for (int r = 0; r < 4 && r * 64 < n; ++r) {
+        const int cnt = min(64, n - r * 64);
+        for (int l = 0; l < cnt; ++l) {
+            const unsigned other = __shfl(key[r], l);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane + 64 * r;
+        if (i < n) { meta[b + rank[r]] = make_uint2(key[r], (unsigned)cam); depths[b + rank[r]] = d[r]; }
     }
 }
 
@@ -168,7 +177,7 @@ void launch_exist_scatter(const Match* arena, const ChainResult* res, const int*
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st)
 {
     const int n = S * n_cams;
-    if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 255) / 256), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
+    if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
 }
 void launch_raw_stats(const int* rowcnt, int S, int N, int* out2, hipStream_t st)
 {
