@@ -7,11 +7,14 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -143,6 +146,7 @@ struct l3d_line3d {
     std::vector<std::vector<std::pair<uint32_t, Key>>> pot;    // per view index: (seg, other key), potential_correspondences_
     std::vector<std::pair<Key, Key>> pot_foreign;              // keys whose camera is not a view (early-return quirk)
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
+    std::vector<std::vector<l3d_match>> saved;                 // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
 
@@ -612,32 +616,156 @@ void mark_matched(L* h, const View& v)
     }
 }
 
-struct ChainUser { L* h; const std::vector<uint32_t>* order; const std::vector<int>* n_tbm; };
+struct ChainFinalizer;
+void chain_notify(ChainFinalizer* f, int k);
 
+struct ChainUser {
+    L* h;
+    const std::vector<uint32_t>* order;
+    const std::vector<int>* n_tbm;
+    const std::vector<std::vector<int32_t>>* src_idx;
+    struct ChainFinalizer* fin;
+};
+
+// In the chain the reverse matches travel on the device, so the host bookkeeping of a view shrinks to keeping its
+// list (performMatching's `matches`, line3D.cc:822-884); potential_correspondences_ and the only-best stores are
+// built from the kept lists afterwards, in parallel (finalize_chain).
 int chain_callback(void* user, int index, int verified, const l3d_match* kept, int n_kept, const float* best, int n_best, int n_cand)
 {
     ChainUser* u = static_cast<ChainUser*>(user);
     L* h = u->h;
+    const double t0 = now_s();
     View& v = h->views[(*u->order)[(size_t)index]];
-    h->stat_last_tbm = (*u->n_tbm)[(size_t)index];
-    if (!verified) {                                    // cudawrapper.cu:877-878: the localized list comes back untouched
-        std::vector<l3d_match> existing;
-        localized_existing(h, v, existing);
-        commit_view(h, v, existing.data(), (int)existing.size(), 1.0f);
-        return 0;
-    }
-    float median = 1.0f;                                // line3D.cc:811; untouched when nothing was verified (:955-956)
-    if (n_cand > 0) {
-        median = -1.0f;                                 // cudawrapper.cu:1066-1073
-        if (n_best > 0) {
-            std::vector<float> d(best, best + (size_t)n_best * 2);
-            std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
-            median = d[d.size() / 2];
+    std::vector<l3d_match>& mine = h->saved[(size_t)index];
+    if (!verified) {
+        // cudawrapper.cu:877-878: the localized existing list comes back untouched (LOCAL camera ids, confidence 0).
+        // It is what the earlier views pushed (line3D.cc:838-872), in push order: sources ascending, list order.
+        mine.clear();
+        const std::vector<uint32_t>& nbs = h->visual_neighbors[v.id];
+        for (int a : (*u->src_idx)[(size_t)index])
+            for (const l3d_match& mp : h->saved[(size_t)a]) {
+                if (mp.camID2 != v.id) continue;
+                l3d_match r;
+                r.segID1 = mp.segID2; r.segID2 = mp.segID1; r.confidence = 0.0f;
+                r.camID2 = (uint32_t)(std::lower_bound(nbs.begin(), nbs.end(), h->views[(*u->order)[(size_t)a]].id) - nbs.begin());
+                r.depths[0] = mp.depths[2]; r.depths[1] = mp.depths[3]; r.depths[2] = mp.depths[0]; r.depths[3] = mp.depths[1];
+                mine.push_back(r);
+            }
+        v.median_depth = 1.0f;                          // line3D.cc:811,835
+    } else {
+        float median = 1.0f;                            // untouched when nothing was verified (cudawrapper.cu:955-956)
+        if (n_cand > 0) {
+            median = -1.0f;                             // cudawrapper.cu:1066-1073
+            if (n_best > 0) {
+                std::vector<float> d(best, best + (size_t)n_best * 2);
+                std::nth_element(d.begin(), d.begin() + (long)(d.size() / 2), d.end());
+                median = d[d.size() / 2];
+            }
         }
+        v.median_depth = median;
+        mine.assign(kept, kept + n_kept);
     }
-    commit_view(h, v, kept, n_kept, median);
+    mark_matched(h, v);                                 // line3D.cc:875-881
+    h->stat_kept += (double)mine.size();
+    h->t_commit += now_s() - t0;
+    chain_notify(u->fin, index);
     return 0;
 }
+
+// potential_correspondences_ (line3D.cc:861-865) and the only-best match files (line3D.cc:884, view.cc:165-183) from
+// the kept lists, on a few host threads while the GPU is still busy with later views.  Two kinds of task:
+//   split(k)    when the list of processed view k arrives: its entries are bucketed by the camera they point to
+//               (reverse direction) and its own forward entries / only-best store are produced;
+//   merge(view) when all lists that can mention a view are split: concatenate, sort per segment, de-duplicate.
+struct ChainFinalizer {
+    L* h;
+    std::vector<int> own_index;                     // per view index: its position in the processing order or -1
+    std::vector<std::vector<int>> contributors;     // per view index: order indices of the views that list it as neighbour
+    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>> buckets;   // per order index: (target view index, entries)
+    std::vector<std::atomic<int>> pending;          // per view index: splits still missing
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (1 = merge, view index)
+    bool done = false;
+    std::vector<std::thread> workers;
+
+    explicit ChainFinalizer(size_t nviews) : pending(nviews) {}
+
+    void push(int kind, size_t id)
+    {
+        { std::lock_guard<std::mutex> lk(mu); queue.emplace_back(kind, id); }
+        cv.notify_one();
+    }
+    void split(size_t k)
+    {
+        const View& v = h->views[h->order[k]];
+        const std::vector<l3d_match>& lst = h->saved[k];
+        auto& bk = buckets[k];
+        const std::vector<uint32_t>& nbs = h->visual_neighbors.find(v.id)->second;
+        bk.clear();
+        for (uint32_t nb : nbs) { const View* o = h->find_view(nb); if (o) bk.emplace_back((size_t)o->index, std::vector<std::pair<uint32_t, Key>>()); }
+        std::vector<int> slot_of(nbs.size(), -1);
+        { int sidx = 0; for (size_t c = 0; c < nbs.size(); ++c) if (h->find_view(nbs[c])) slot_of[c] = sidx++; }
+        size_t last_c = (size_t)-1; uint32_t last_cam = 0xffffffffu;
+        for (const l3d_match& m : lst) {
+            if (m.camID2 != last_cam) {
+                last_cam = m.camID2;
+                auto it = std::lower_bound(nbs.begin(), nbs.end(), last_cam);
+                last_c = (it != nbs.end() && *it == last_cam) ? (size_t)(it - nbs.begin()) : (size_t)-1;
+            }
+            if (last_c != (size_t)-1 && slot_of[last_c] >= 0) bk[(size_t)slot_of[last_c]].second.emplace_back(m.segID2, mk(v.id, m.segID1));
+        }
+        // own forward entries (already grouped by segment) and the only-best store do not depend on other lists
+        std::vector<std::pair<uint32_t, Key>>& p = h->pot[(size_t)v.index];
+        p.clear();
+        p.reserve(lst.size() * 2);
+        for (const l3d_match& m : lst) p.emplace_back(m.segID1, mk(m.camID2, m.segID2));
+        add_matches(h->views[h->order[k]], lst.data(), lst.size(), true, true);
+        for (auto& e : bk) if (--pending[e.first] == 0) push(1, e.first);
+        if (--pending[(size_t)v.index] == 0) push(1, (size_t)v.index);
+    }
+    void merge(size_t vi)
+    {
+        View& v = *h->vlist[vi];
+        std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
+        if (own_index[vi] < 0) p.clear();               // otherwise split(own) has put the forward entries there
+        for (int k : contributors[vi])
+            for (auto& e : buckets[(size_t)k]) if (e.first == vi) p.insert(p.end(), e.second.begin(), e.second.end());
+        finalize_view_pot(p, (size_t)v.S());
+    }
+    void start(unsigned nthreads)
+    {
+        for (unsigned t = 0; t < nthreads; ++t)
+            workers.emplace_back([this]() {
+                for (;;) {
+                    std::pair<int, size_t> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this]() { return done || !queue.empty(); });
+                        if (queue.empty()) return;
+                        job = queue.back();
+                        queue.pop_back();
+                    }
+                    if (job.first == 0) split(job.second); else merge(job.second);
+                }
+            });
+    }
+    void notify(int k) { push(0, (size_t)k); }
+    void finish(bool drain)
+    {
+        // drain: wait until every job (splits spawn merges) has run
+        for (; drain;) {
+            { std::lock_guard<std::mutex> lk(mu); bool all = queue.empty(); if (all) { int left = 0; for (auto& p : pending) left += p.load() > 0; if (left == 0) break; } }
+            std::this_thread::yield();
+        }
+        { std::lock_guard<std::mutex> lk(mu); done = true; }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+        workers.clear();
+    }
+};
+
+void chain_notify(ChainFinalizer* f, int k) { if (f) f->notify(k); }
 
 // Line3D::matchViews as one device-resident chain (l3d_match_chain): the schedule is simulated first (it does not
 // depend on data), then the GPU runs ahead while the callback does the bookkeeping of each finished view.
@@ -690,16 +818,56 @@ int match_views(L* h)
     }
     h->matched.clear();                                 // back to the state matchViews starts from
     if (!chain_ok) return match_views_sync(h);
-    ChainUser user{ h, &h->order, &n_tbm };
+    h->saved.assign(n, {});
+    const size_t nvl = h->vlist.size();
+    ChainFinalizer fin(nvl);
+    fin.h = h;
+    fin.own_index.assign(nvl, -1); fin.contributors.assign(nvl, {}); fin.buckets.assign(n, {});
+    for (size_t vi = 0; vi < nvl; ++vi) fin.pending[vi] = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const View& v = h->views[h->order[k]];
+        fin.own_index[(size_t)v.index] = (int)k;
+        fin.pending[(size_t)v.index] += 1;              // its own list
+        for (uint32_t nb : h->visual_neighbors[v.id]) {
+            const View* o = h->find_view(nb);
+            if (!o) continue;
+            fin.contributors[(size_t)o->index].push_back((int)k);
+            fin.pending[(size_t)o->index] += 1;
+        }
+    }
+    fin.start(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)));
+    ChainUser user{ h, &h->order, &n_tbm, &src_idx, &fin };
     const double t1 = now_s();
     int rc = l3d_match_chain(h->ctx, cv.data(), (int)n, chain_callback, &user);
     h->t_gpu_call += now_s() - t1 - h->t_commit;
+    const double t2 = now_s();
+    fin.finish(rc == L3D_OK);
     if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
+    // early-return views (cudawrapper.cu:877-878) hand back LOCAL camera ids; where such a number names a view, the
+    // reference records the pair under that view as well (line3D.cc:861-865): append and re-normalise (rare, tiny)
+    h->pot_foreign.clear();
+    for (size_t k = 0; k < n; ++k) {
+        if (n_tbm[k] != 0) continue;
+        const uint32_t vid = h->order[k];
+        std::set<size_t> touched;
+        uint32_t last_cam = 0xffffffffu; View* o = nullptr;
+        for (const l3d_match& m : h->saved[k]) {
+            if (m.camID2 != last_cam) { last_cam = m.camID2; o = h->find_view(last_cam); if (o) touched.insert((size_t)o->index); }
+            if (o) h->pot[(size_t)o->index].emplace_back(m.segID2, mk(vid, m.segID1));
+            else h->pot_foreign.emplace_back(mk(m.camID2, m.segID2), mk(vid, m.segID1));
+        }
+        std::vector<std::thread> th;
+        for (size_t vi : touched) th.emplace_back([h, vi]() { finalize_view_pot(h->pot[vi], (size_t)h->vlist[vi]->S()); });
+        for (auto& t : th) t.join();
+    }
+    std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
+    h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
+    if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]] = h->saved[k];
+    h->t_finalize += now_s() - t2;
     double st[4];
     l3d_last_stats(h->ctx, st);
     h->stat_pairs += st[0];
     h->stat_raw += st[1];
-    finalize_matching(h);
     h->t_match = now_s() - t0;
     return L3D_OK;
 }
