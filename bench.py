@@ -75,7 +75,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("L3D_BENCH_FORCE_SHARDED") == "1"     # exercise the multi-GPU code path with world = 1
+    if world > 1 or (force_sharded and "RANK" in os.environ):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -103,8 +104,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    sharded_mode = {"name": "resident chain, source segments sharded, RCCL all-gather of per-view kept slots on the GPU stream"}
+
     def step():
-        if world > 1:
+        if dist is not None:
+            if sharded_mode["name"].startswith("resident"):
+                try:
+                    # rank 0 trails behind with the host bookkeeping; the other ranks only feed the collectives
+                    l3dist.match_views_chain_sharded(l3d, rank, world, dist, commit=(rank == 0),
+                                                     n_segments=args.segments, n_neighbors=args.neighbors)
+                    return
+                except Exception as e:          # keep the bench line alive: per-view path with host all-gathers
+                    print("rank %d: sharded chain failed (%r), falling back to the per-view path" % (rank, e), file=sys.stderr)
+                    sharded_mode["name"] = "per-view seam call, source segments sharded, all-gather of kept lists through the host"
             l3dist.match_views_sharded(l3d, rank, world, dist)
         else:
             l3d.match_views()
@@ -177,8 +189,7 @@ def main():
                    config=dict(workload="BASELINE configs[%d]: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
                                         % (1 if n_gpus == 1 else 2, V, args.segments, args.neighbors),
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
-                               parallelism="replicas of host state, source-segment ranges sharded x%d, RCCL all-gather of kept lists" % n_gpus
-                               if n_gpus > 1 else "single GPU"),
+                               parallelism=("x%d: " % n_gpus + sharded_mode["name"]) if dist is not None else "single GPU"),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
                    kept_per_step=st["kept"], setup_s=t_setup,
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))

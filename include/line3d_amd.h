@@ -17,6 +17,7 @@
 #ifndef LINE3D_AMD_H
 #define LINE3D_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -150,6 +151,25 @@ typedef int (*l3d_chain_callback)(void* user, int index, int verified, const l3d
                                   const float* best_depths, int n_best, int n_candidates);
 int l3d_match_chain(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user);
 
+/* ---- the resident chain with every view's source segments sharded over the GPUs of one node ---------------------
+ * One process per GPU.  Each rank opens the chain with (rank, world) and per view k: l3d_shard_chain_enqueue writes
+ * this rank's kept records for its source-segment range [S*rank/world, S*(rank+1)/world) into `send_slot`
+ * (*slot_bytes bytes, device memory); the CALLER all-gathers the ranks' slots of view k into
+ * gathered_base + (k*world + r)*slot_bytes (e.g. torch.distributed.all_gather_into_tensor = RCCL over xGMI, enqueued on
+ * l3d_ctx_stream(ctx)), then calls l3d_shard_chain_mark.  Later views pull their reverse matches out of the gathered
+ * slots on the device.  l3d_shard_chain_fetch (optional per rank, any time after mark) blocks the HOST until view k is
+ * complete and calls the callback with the ranks' kept lists concatenated in rank (= segment) order -- the sorted list
+ * of the unsharded run.  gathered_base must be zero-initialised (n_views*world*slot_bytes bytes) and stay valid until
+ * close; the `views` array must outlive the chain. */
+typedef struct l3d_shard_chain l3d_shard_chain;
+void* l3d_ctx_stream(l3d_ctx* ctx);                  /* the context's hipStream_t, for framework interop */
+int l3d_shard_chain_open(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, int rank, int world, int slot_records,
+                         l3d_shard_chain** out, size_t* slot_bytes);
+int l3d_shard_chain_enqueue(l3d_shard_chain* chain, int k, void* send_slot, const void* gathered_base);
+int l3d_shard_chain_mark(l3d_shard_chain* chain, int k);
+int l3d_shard_chain_fetch(l3d_shard_chain* chain, int k, l3d_chain_callback cb, void* user);
+int l3d_shard_chain_close(l3d_shard_chain* chain);
+
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
  * caller may instead register segment arrays once; l3d_compute_pairwise_matches recognises
@@ -220,6 +240,14 @@ int l3d_line3d_match_view_compute(l3d_line3d* h, uint32_t view_id, int seg_begin
 int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_match* matches, int n,
                                  const float* best_depths, int n_best, float median);
 int l3d_line3d_match_end(l3d_line3d* h);
+/* matchViews as the resident chain sharded over ranks: the facade builds the static schedule and forwards to
+ * l3d_shard_chain_* (same protocol: enqueue -> caller's all-gather -> mark; fetch = this rank's host bookkeeping) */
+int l3d_line3d_shard_open(l3d_line3d* h, int rank, int world, int slot_records, int* n_views, size_t* slot_bytes);
+int l3d_line3d_shard_view_verified(l3d_line3d* h, int k);
+int l3d_line3d_shard_enqueue(l3d_line3d* h, int k, void* send_slot, const void* gathered_base);
+int l3d_line3d_shard_mark(l3d_line3d* h, int k);
+int l3d_line3d_shard_fetch(l3d_line3d* h, int k);
+int l3d_line3d_shard_close(l3d_line3d* h, int committed);
 /* performClustering (clustering.h:125, clustering.cc:6-47; stays on the host): labels[k] = CLUniverse::find(k) */
 int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */

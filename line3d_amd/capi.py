@@ -25,6 +25,12 @@ def load_library():
     """dlopen libline3d_amd.so (built in-tree by __graft_entry__.build() / make -C line3d_amd/csrc)."""
     global _lib
     if _lib is None:
+        try:
+            # PyTorch-ROCm ships its own HIP runtime; when both live in one process (multi-GPU driver, tests) the
+            # framework's copy has to be loaded first or torch.cuda reports no devices.  Plumbing only.
+            import torch  # noqa: F401
+        except Exception:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)

@@ -312,7 +312,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
     va.row_start = c->row_start.as<int>();
     va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
-    va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end;
+    va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end; va.nrow_total = (int)nrow;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
     { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
@@ -321,7 +321,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
         if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
         va.stamps = c->stamps.as<unsigned long long>();
     }
-    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= 150 * 1024;
+    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= verify_window_max_lds();
     if (window) { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
     else { ProfScope p(c, "verify"); launch_verify(va, st); }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }

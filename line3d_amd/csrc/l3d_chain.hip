@@ -397,6 +397,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         Match* arena = c->ch_kept.as<Match>();
         ChainResult* dres = c->ch_res.as<ChainResult>();
         const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
+        (void)hipGetLastError();
         HIPCHK(c, hipMemsetAsync(c->ch_cursor.p, 0, nrow * 4, st));
         HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S * 4, st));
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
@@ -416,12 +417,12 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
         va.row_start = c->row_start.as<int>();
         va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
-        va.N = N; va.seg_begin = 0; va.seg_end = S;
+        va.N = N; va.seg_begin = 0; va.seg_end = S; va.nrow_total = (int)nrow;
         va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
         va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
         // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the all-pairs kernel
         int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
-        while (mmax > 64 && verify_window_lds_bytes(mmax, N) > 150 * 1024) mmax /= 2;
+        while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
         va.mmax = mmax;
         if (c->verify_mode == 0) {
             va.skip_above = 1; va.only_above = -1;
@@ -436,6 +437,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, st); }
         launch_kept_alloc(c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, arena_cursor, (int)arena_cap, (int)cand_cap, dres + k, st);
         { ProfScope p(c, "kept_write"); launch_kept_write_chain(va, c->kept_start.as<int>(), reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, (int)arena_cap, st); }
+        { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         HIPCHK(c, hipMemcpyAsync(hres + k, dres + k, sizeof(ChainResult), hipMemcpyDeviceToHost, st));
         if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));

@@ -1,0 +1,448 @@
+// l3d_chain_sharded.hip -- the resident matchViews chain (l3d_chain.hip) with every view's SOURCE segments sharded over
+// the GPUs of one node.
+//
+// matchViews is a dependency chain over views, so views are not distributed.  Each rank (one process per GPU) runs the
+// chain on its source-segment range [S*r/W, S*(r+1)/W) of every view: stage 1 and the verification of a source segment
+// only touch that segment's rows, so the ranges are independent and need no exchange.  The single exchange per view
+// is its kept list: a later view pulls its reverse matches (line3D.cc:838-872) from ALL ranks' kept records, so after a
+// view's kept records are written into this rank's fixed-size SLOT the caller all-gathers the slots of that view
+// (RCCL over xGMI, `torch.distributed.all_gather_into_tensor` on this context's stream, see
+// line3d_amd/distributed.py).  Nothing waits for the host: the library only enqueues (l3d_shard_chain_enqueue), the
+// framework enqueues the collective on the same stream, the host trails behind on events (l3d_shard_chain_fetch).
+// The concatenation of the ranks' kept lists in rank order is the sorted list of the unsharded run, bit for bit.
+//
+// slot layout: [SlotHeader 32 B][best depth pairs float2 x seg_cap][kept records l3d_match x slot_records]
+#include <algorithm>
+#include <vector>
+
+#include "l3d_ctx.hpp"
+
+using namespace l3d;
+
+namespace l3d {
+
+struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
+static_assert(sizeof(SlotHeader) == 32, "slot header");
+
+struct SlotGeom { size_t slot_bytes, best_off, rec_off; int seg_cap, slot_records, world; };
+
+// reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
+// (blockIdx.y = source * world + rank)
+__global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
+                                    const int* __restrict__ src_cam, unsigned view_id, int N, int s0, int s1, int* __restrict__ rowcnt)
+{
+    const int src = blockIdx.y / g.world, r = blockIdx.y % g.world;
+    const unsigned char* slot = G + ((size_t)src_index[src] * g.world + r) * g.slot_bytes;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    const int n = hd->overflow ? 0 : hd->n_kept;
+    const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
+    const int cam = src_cam[src];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Match m = kept[i];
+        if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) atomicAdd(&rowcnt[m.segID2 * N + cam], 1);
+    }
+}
+
+__global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
+                                      const int* __restrict__ src_cam, unsigned view_id, int N, int S, int s0, int s1,
+                                      const int* __restrict__ row_start, int* __restrict__ cursor,
+                                      uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
+{
+    if (row_start[(size_t)S * N] > cap) return;
+    const int src = blockIdx.y / g.world, r = blockIdx.y % g.world;
+    const unsigned char* slot = G + ((size_t)src_index[src] * g.world + r) * g.slot_bytes;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    const int n = hd->overflow ? 0 : hd->n_kept;
+    const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
+    const int cam = src_cam[src];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Match m = kept[i];
+        if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) {
+            const int row = m.segID2 * N + cam;
+            const int slotpos = row_start[row] + atomicAdd(&cursor[row], 1);
+            meta[slotpos] = make_uint2(m.segID1, (unsigned)cam);
+            depths[slotpos] = make_float4(m.depths[2], m.depths[3], m.depths[0], m.depths[1]);
+        }
+    }
+}
+
+// one thread: header of this rank's slot (count, #candidates, overflow)
+__global__ void k_slot_header(const int* __restrict__ kept_start, int S, const int* __restrict__ row_start, int nrow, int cand_cap,
+                              int slot_records, int s0, int s1, unsigned char* __restrict__ slot)
+{
+    SlotHeader h;
+    h.R = row_start[nrow];
+    h.overflow = h.R > cand_cap ? 1 : 0;
+    h.n_kept = h.overflow ? 0 : kept_start[S];
+    if (h.n_kept > slot_records) { h.overflow |= 2; h.n_kept = 0; }
+    h.s0 = s0; h.s1 = s1; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    *reinterpret_cast<SlotHeader*>(slot) = h;
+}
+
+__global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __restrict__ kept_start, const unsigned* __restrict__ local2global,
+                                                    const float2* __restrict__ best, SlotGeom g, unsigned char* __restrict__ slot)
+{
+    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= a.seg_end) return;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    if (lane == 0) reinterpret_cast<float2*>(slot + g.best_off)[y - a.seg_begin] = best[y];
+    if (hd->overflow) return;
+    Match* out = reinterpret_cast<Match*>(slot + g.rec_off);
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    int o = kept_start[y];
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        const float c = i < m ? a.cand_conf[start + i] : 0.0f;
+        const bool k = c > 1.0f;
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
+            const uint2 meta = a.cand_meta[start + i];
+            const float4 d = a.cand_depths[start + i];
+            Match r;
+            r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
+            r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
+            r.confidence = c / 2.0f;                 // confidence_norm, cudawrapper.cu:1089,1098
+            out[pos] = r;
+        }
+        o += __popcll(b);
+    }
+}
+
+}  // namespace l3d
+
+namespace {
+
+struct SViewDev {
+    const float4 *src, *tgt;
+    size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
+    unsigned long long* mask;
+    int* rowcnt;
+    int* stats;
+    float2* best;
+    int W64, maxW, s0, s1;
+    bool verified;
+};
+
+size_t salign(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct l3d_shard_chain {
+    l3d_ctx* c = nullptr;
+    const l3d_chain_view* views = nullptr;
+    int n_views = 0, rank = 0, world = 1;
+    SlotGeom geom;
+    std::vector<SViewDev> vd;
+    const unsigned char* dtab = nullptr;
+    int* hstats = nullptr;
+    std::vector<hipEvent_t> ev1, ev2;
+    int k_p1 = 0;
+    size_t cand_cap = 0;
+    int maxS = 0, maxN = 0;
+    const unsigned char* gathered = nullptr;
+    double pairs = 0, raw_sum = 0, kept_total = 0;
+};
+
+extern "C" {
+
+void* l3d_ctx_stream(l3d_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, int rank, int world, int slot_records,
+                         l3d_shard_chain** out, size_t* slot_bytes)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!out || !slot_bytes || n_views < 0 || world < 1 || rank < 0 || rank >= world || (n_views > 0 && !views) || slot_records < 1)
+        return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_open: bad argument");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    (void)hipGetLastError();
+    l3d_shard_chain* h = new l3d_shard_chain();
+    h->c = c; h->views = views; h->n_views = n_views; h->rank = rank; h->world = world;
+    h->vd.resize((size_t)n_views);
+    size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
+    double max_pairs = 0;
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        SViewDev& d = h->vd[(size_t)k];
+        d.verified = v.n_tbm > 0;
+        d.s0 = (int)(((long long)v.S_src * rank) / world);
+        d.s1 = (int)(((long long)v.S_src * (rank + 1)) / world);
+        h->maxS = std::max(h->maxS, v.S_src); h->maxN = std::max(h->maxN, v.N);
+        if (!d.verified) continue;
+        if (v.S_src < 0 || v.N < 0 || v.N > 255 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0 || !v.src_segs || !v.tgt_segs || !v.offsets ||
+            !v.F || !v.RtKinv || !v.centers || !v.P || !v.RtKinv_src || !v.C_src || !v.to_be_matched || !v.local2global ||
+            (v.n_sources && (!v.source_cam || !v.source_index))) { delete h; return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_open: bad view"); }
+        for (int s = 0; s < v.n_sources; ++s)
+            if (v.source_index[s] < 0 || v.source_index[s] >= k || v.source_cam[s] < 0 || v.source_cam[s] >= v.N) { delete h; return fail(c, L3D_ERR_INVALID, "a source must be an earlier view"); }
+        int maxW = 0;
+        double p = 0;
+        for (int j = 0; j < v.n_tbm; ++j) {
+            const int cam = v.to_be_matched[j];
+            if (cam < 0 || cam >= v.N) { delete h; return fail(c, L3D_ERR_INVALID, "to_be_matched out of range"); }
+            maxW = std::max(maxW, v.offsets[2 * cam + 1]);
+            p += (double)(d.s1 - d.s0) * v.offsets[2 * cam + 1];
+        }
+        h->pairs += p; max_pairs = std::max(max_pairs, p);
+        d.maxW = maxW; d.W64 = 4 * ((maxW + 255) / 256);
+        if (d.W64 > kMaxW64) { delete h; return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments"); }
+        if (!resident_ptr(c, v.src_segs, (size_t)v.S_src * 16)) { int rc = l3d_register_segments(c, v.src_segs, v.S_src); if (rc) { delete h; return rc; } }
+        if (!resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16)) { int rc = l3d_register_segments(c, v.tgt_segs, v.n_tgt); if (rc) { delete h; return rc; } }
+        d.src = reinterpret_cast<const float4*>(resident_ptr(c, v.src_segs, (size_t)v.S_src * 16));
+        d.tgt = reinterpret_cast<const float4*>(resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16));
+        const size_t N = (size_t)v.N;
+        size_t o = tab_bytes;
+        d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
+        d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
+        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
+        tab_bytes = salign(o, 16);
+        mask_bytes += salign((size_t)v.n_tbm * v.S_src * d.W64 * 8, 16);
+        rowcnt_ints += (size_t)v.S_src * v.N;
+        best_elems += (size_t)v.S_src;
+    }
+    h->geom.world = world;
+    h->geom.seg_cap = (h->maxS + world - 1) / world + 1;
+    h->geom.slot_records = slot_records;
+    h->geom.best_off = sizeof(SlotHeader);
+    h->geom.rec_off = salign(h->geom.best_off + (size_t)h->geom.seg_cap * 8, 32);
+    h->geom.slot_bytes = salign(h->geom.rec_off + (size_t)slot_records * sizeof(Match), 256);
+    *slot_bytes = h->geom.slot_bytes;
+
+    auto bail = [&](int rc) { delete h; return rc; };
+#define OCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(L3D_ERR_HIP); } } while (0)
+    OCHK(c->ch_pin_tables.reserve(tab_bytes + 16));
+    OCHK(c->ch_tables.reserve(tab_bytes + 16));
+    unsigned char* tab = c->ch_pin_tables.as<unsigned char>();
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        const SViewDev& d = h->vd[(size_t)k];
+        if (!d.verified) continue;
+        const size_t N = (size_t)v.N;
+        memcpy(tab + d.o_off, v.offsets, N * 8); memcpy(tab + d.o_F, v.F, N * 36); memcpy(tab + d.o_R, v.RtKinv, N * 36);
+        memcpy(tab + d.o_C, v.centers, N * 12); memcpy(tab + d.o_P, v.P, N * 48); memcpy(tab + d.o_Rs, v.RtKinv_src, 36);
+        memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
+        memcpy(tab + d.o_l2g, v.local2global, N * 4);
+        if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
+    }
+    OCHK(hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
+    h->dtab = c->ch_tables.as<unsigned char>();
+    OCHK(c->ch_mask.reserve(mask_bytes + 16));
+    OCHK(c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
+    OCHK(c->ch_best.reserve(best_elems * 8 + 16));
+    OCHK(c->ch_pin_res.reserve((size_t)n_views * 8 + 64));
+    OCHK(hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
+    {
+        size_t mo = 0, ro = 0, bo = 0;
+        int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
+        for (int k = 0; k < n_views; ++k) {
+            SViewDev& d = h->vd[(size_t)k];
+            d.stats = stats_base + 2 * k;
+            if (!d.verified) continue;
+            const l3d_chain_view& v = views[k];
+            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
+            mo += salign((size_t)v.n_tbm * v.S_src * d.W64 * 8, 16);
+            d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
+            d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
+        }
+    }
+    h->hstats = c->ch_pin_res.as<int>();
+    h->cand_cap = (size_t)(max_pairs * 0.12) + 65536;
+    const size_t nrow_max = (size_t)h->maxS * h->maxN;
+    OCHK(c->row_start.reserve((nrow_max + 1) * 4));
+    OCHK(c->ch_cursor.reserve(nrow_max * 4 + 16));
+    OCHK(c->kept_cnt.reserve((size_t)h->maxS * 4 + 4));
+    OCHK(c->kept_start.reserve((size_t)h->maxS * 4 + 8));
+    OCHK(c->cand_meta.reserve(h->cand_cap * 8));
+    OCHK(c->cand_depths.reserve(h->cand_cap * 16));
+    OCHK(c->cand_conf.reserve(h->cand_cap * 4));
+    OCHK(c->ch_pin_kept.reserve((size_t)world * h->geom.slot_bytes + 64));
+#undef OCHK
+    h->ev1.assign((size_t)n_views, nullptr);
+    h->ev2.assign((size_t)n_views, nullptr);
+    c->stats[0] = h->pairs;
+    *out = h;
+    return L3D_OK;
+}
+
+static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
+{
+    const l3d_chain_view& v = h->views[k];
+    const SViewDev& d = h->vd[(size_t)k];
+    const unsigned char* dtab = h->dtab;
+    PairArgs pa;
+    pa.src_segs = d.src; pa.tgt_segs = d.tgt;
+    pa.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
+    pa.F = reinterpret_cast<const float*>(dtab + d.o_F);
+    pa.RtKinv = reinterpret_cast<const float*>(dtab + d.o_R);
+    pa.centers = reinterpret_cast<const float*>(dtab + d.o_C);
+    pa.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
+    pa.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
+    pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
+    pa.mask = d.mask;
+    pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
+    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest;
+    return pa;
+}
+
+static int shard_stage1(l3d_shard_chain* h, int k)
+{
+    l3d_ctx* c = h->c;
+    hipStream_t st = c->stream;
+    const SViewDev& d = h->vd[(size_t)k];
+    if (!d.verified) return L3D_OK;
+    if (d.s1 > d.s0) {
+        const PairArgs pa = shard_pair_args(h, k);
+        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, d.maxW, st); }
+        { ProfScope p(c, "row_count"); launch_row_count(pa, d.rowcnt, st); }
+        launch_raw_stats(d.rowcnt, h->views[k].S_src, h->views[k].N, d.stats, st);
+    }
+    HIPCHK(c, hipMemcpyAsync(h->hstats + 2 * k, d.stats, 8, hipMemcpyDeviceToHost, st));
+    h->ev1[(size_t)k] = get_event(c);
+    HIPCHK(c, hipEventRecord(h->ev1[(size_t)k], st));
+    return L3D_OK;
+}
+
+// Enqueue view k up to (and including) the write of this rank's slot.  send_slot: device buffer of slot_bytes that the
+// caller all-gathers into gathered_base + (k*world + r)*slot_bytes for r = 0..world-1 (stream ordered, same stream).
+int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const void* gathered_base)
+{
+    if (!h || k < 0 || k >= h->n_views || !gathered_base) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    (void)hipGetLastError();            // the framework shares this thread: its (benign) sticky errors are not ours
+    const int kStage1Ahead = 24;
+    while (h->k_p1 < h->n_views && h->k_p1 <= k + kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
+    const l3d_chain_view& v = h->views[k];
+    const SViewDev& d = h->vd[(size_t)k];
+    h->gathered = reinterpret_cast<const unsigned char*>(gathered_base);
+    if (!d.verified) return L3D_OK;
+    if (!send_slot) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_enqueue: null slot");
+    HIPCHK(c, hipEventSynchronize(h->ev1[(size_t)k]));
+    h->raw_sum += h->hstats[2 * k];
+    PairArgs pa = shard_pair_args(h, k);
+    pa.cand_cap = (int)h->cand_cap;
+    const int S = v.S_src, N = v.N;
+    const size_t nrow = (size_t)S * N;
+    const unsigned char* dtab = h->dtab;
+    const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
+    const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
+    unsigned char* slot = reinterpret_cast<unsigned char*>(send_slot);
+    HIPCHK(c, hipMemsetAsync(c->ch_cursor.p, 0, nrow * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S * 4, st));
+    if (v.n_sources) {
+        ProfScope p(c, "exist");
+        hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
+    }
+    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, st); }
+    if (d.s1 > d.s0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+    if (v.n_sources) {
+        ProfScope p(c, "exist");
+        hipLaunchKernelGGL(k_exist_scatter_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1,
+                           c->row_start.as<int>(), c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
+        launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st);
+    }
+    VerifyArgs va;
+    va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
+    va.P = reinterpret_cast<const float*>(dtab + d.o_P);
+    va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
+    va.row_start = c->row_start.as<int>();
+    va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
+    va.N = N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = (int)nrow;
+    va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
+    va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)h->cand_cap; va.res = nullptr;
+    int mmax = h->hstats[2 * k + 1] + h->hstats[2 * k + 1] / 4 + 64;
+    while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
+    va.mmax = mmax;
+    if (d.s1 > d.s0) {
+        if (c->verify_mode == 0) {
+            va.skip_above = 1; va.only_above = -1;
+            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+            va.only_above = mmax;
+            { ProfScope p(c, "verify"); launch_verify(va, st); }
+        } else {
+            va.skip_above = 0; va.only_above = -1;
+            ProfScope p(c, "verify"); launch_verify(va, st);
+        }
+        { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
+    }
+    { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, st); }
+    hipLaunchKernelGGL(k_slot_header, dim3(1), dim3(1), 0, st, c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, (int)h->cand_cap,
+                       h->geom.slot_records, d.s0, d.s1, slot);
+    if (d.s1 > d.s0) {
+        ProfScope p(c, "kept_write");
+        hipLaunchKernelGGL(k_slot_write, dim3((d.s1 - d.s0 + 3) / 4), dim3(256), 0, st, va, c->kept_start.as<int>(),
+                           reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
+    }
+    { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("shard enqueue view ") + std::to_string(k) + " (mmax " + std::to_string(mmax) + ", lds " + std::to_string(verify_window_lds_bytes(mmax, N)) + ", range " + std::to_string(d.s0) + "-" + std::to_string(d.s1) + "): " + hipGetErrorString(e_)); }
+    return L3D_OK;
+}
+
+// Record "view k is complete" on the stream -- call after the all-gather of view k has been enqueued.
+int l3d_shard_chain_mark(l3d_shard_chain* h, int k)
+{
+    if (!h || k < 0 || k >= h->n_views) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    if (!h->ev2[(size_t)k]) h->ev2[(size_t)k] = get_event(c);
+    HIPCHK(c, hipEventRecord(h->ev2[(size_t)k], c->stream));
+    return L3D_OK;
+}
+
+// Wait for view k (host side only), copy its gathered slots, concatenate the ranks' kept lists and depth pairs in rank
+// (= segment) order and hand them to the callback.
+int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void* user)
+{
+    if (!h || k < 0 || k >= h->n_views || !cb) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    const l3d_chain_view& v = h->views[k];
+    if (!h->vd[(size_t)k].verified) return cb(user, k, 0, nullptr, 0, nullptr, 0, 0) ? fail(c, L3D_ERR_INVALID, "callback failed") : L3D_OK;
+    if (!h->ev2[(size_t)k]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_fetch: view not marked");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(h->ev2[(size_t)k]));
+    const size_t block = (size_t)h->world * h->geom.slot_bytes;
+    unsigned char* host = c->ch_pin_kept.as<unsigned char>();
+    HIPCHK(c, hipMemcpyAsync(host, h->gathered + (size_t)k * block, block, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    std::vector<l3d_match> kept;
+    std::vector<float> best;
+    long long R = 0;
+    for (int r = 0; r < h->world; ++r) {
+        const unsigned char* slot = host + (size_t)r * h->geom.slot_bytes;
+        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+        if (hd->overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
+        R += hd->R;
+    }
+    for (int r = 0; r < h->world; ++r) {
+        const unsigned char* slot = host + (size_t)r * h->geom.slot_bytes;
+        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+        const l3d_match* recs = reinterpret_cast<const l3d_match*>(slot + h->geom.rec_off);
+        kept.insert(kept.end(), recs, recs + hd->n_kept);
+        const float* b = reinterpret_cast<const float*>(slot + h->geom.best_off);
+        if (R > 0)
+            for (int s = 0; s < hd->s1 - hd->s0; ++s)
+                if (b[2 * s] != -1.0f) { best.push_back(b[2 * s]); best.push_back(b[2 * s + 1]); }
+    }
+    (void)v;
+    h->kept_total += (double)kept.size();
+    if (cb(user, k, 1, kept.data(), (int)kept.size(), best.data(), (int)(best.size() / 2), (int)std::min<long long>(R, 0x7fffffff)))
+        return fail(c, L3D_ERR_INVALID, "callback failed");
+    return L3D_OK;
+}
+
+int l3d_shard_chain_close(l3d_shard_chain* h)
+{
+    if (!h) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : h->ev1) if (e) c->event_pool.push_back(e);
+    for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);
+    c->stats[1] = h->raw_sum; c->stats[3] = h->kept_total;
+    delete h;
+    return L3D_OK;
+}
+
+}  // extern "C"

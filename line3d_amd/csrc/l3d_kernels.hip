@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_verify(VerifyArgs a)
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     if (m == 0 || m <= a.only_above) return;
-    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) return;   // candidate overflow: the chain is re-run
+    if (a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap) return;   // candidate overflow: the chain is re-run
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     if (tid == 0) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_seg_post(VerifyArgs a, int* __restrict_
     const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (y >= a.seg_end) return;
-    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) { if (lane == 0) { kept_cnt[y] = 0; best_depths[y] = make_float2(-1.0f, -1.0f); } return; }
+    if (a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap) { if (lane == 0) { kept_cnt[y] = 0; best_depths[y] = make_float2(-1.0f, -1.0f); } return; }
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     float best = 0.0f;

@@ -63,6 +63,7 @@ struct VerifyArgs {
     const float4* cand_depths;
     float* cand_conf;
     int N, seg_begin, seg_end;
+    int nrow_total;                 // S_src * N: row_start[nrow_total] = number of candidates
     int mmax;                       // max candidates of one segment (LDS sizing)
     int only_above;                 // k_verify (all-pairs): process only segments with more than this many candidates (-1: all)
     int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to k_verify (0/1)
@@ -82,6 +83,7 @@ void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, 
 void launch_verify(const VerifyArgs& a, hipStream_t st);
 void launch_verify_window(const VerifyArgs& a, hipStream_t st);
 size_t verify_window_lds_bytes(int mmax, int N);
+size_t verify_window_max_lds();
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
 void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);

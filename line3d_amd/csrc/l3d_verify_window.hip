@@ -13,6 +13,8 @@
 // records (24 B each), L2-resident gathers of target segments for the few gate survivors, and the confidence
 // store; everything else (3-D endpoints, directions, target lines) is recomputed from the depths with the same
 // float operations the reference uses, hence the same bits.
+#include <algorithm>
+
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
 
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     if (m == 0 || (a.skip_above && m > a.mmax)) return;
-    if (a.cand_cap && a.row_start[(size_t)a.N * a.seg_end] > a.cand_cap) return;     // candidate overflow: the chain is re-run
+    if (a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap) return;     // candidate overflow: the chain is re-run
     if (a.debug == 4) return;
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
@@ -288,15 +290,27 @@ __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_beg
 }
 
 size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)(mmax + 2) * 16 + (size_t)256 * N * 4 + 4 * kVQ * 8 + 16; }
+// Largest dynamic LDS a k_verify_window launch may ask for on this device/runtime (queried once): up to 160 KB per
+// workgroup on gfx950 once the kernel has opted in; runtimes that refuse the opt-in stay at the 48/64 KB default.
+size_t verify_window_max_lds()
+{
+    static size_t limit = 0;
+    if (limit) return limit;
+    int dev = 0, per_block = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || per_block <= 0) per_block = 64 * 1024;
+    size_t want = std::min<size_t>((size_t)per_block, 160 * 1024) - 8 * 1024 - 256;   // static LDS of the kernel (~8.3 KB) comes on top
+    if (want > 40 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = 40 * 1024;
+    }
+    limit = want;
+    return limit;
+}
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
-    const size_t lds = verify_window_lds_bytes(a.mmax, a.N);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {       // opt in to > default dynamic LDS only when a launch needs it
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), verify_window_lds_bytes(a.mmax, a.N), st, a);
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -148,6 +149,7 @@ struct l3d_line3d {
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
     std::vector<std::vector<l3d_match>> saved;                 // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
+    void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
 
     // final hypotheses
@@ -769,32 +771,41 @@ void chain_notify(ChainFinalizer* f, int k) { if (f) f->notify(k); }
 
 // Line3D::matchViews as one device-resident chain (l3d_match_chain): the schedule is simulated first (it does not
 // depend on data), then the GPU runs ahead while the callback does the bookkeeping of each finished view.
-int match_views(L* h)
+// The static schedule of matchViews + the host-side finaliser, shared by the single-GPU chain and the sharded chain.
+struct ChainPlan {
+    size_t n = 0;
+    std::vector<Marshal> ms;
+    std::vector<std::vector<int32_t>> src_cam, src_idx;
+    std::vector<l3d_chain_view> cv;
+    std::vector<int> n_tbm;
+    std::unique_ptr<ChainFinalizer> fin;
+    ChainUser user;
+    l3d_shard_chain* shard = nullptr;
+    double t0 = 0;
+};
+
+// simulate the schedule (it does not depend on data); false: fall back to the per-view path
+bool plan_chain(L* h, ChainPlan& P)
 {
-    if (h->force_sync) return match_views_sync(h);
-    const double t0 = now_s();
-    match_begin(h);
     const size_t n = h->order.size();
-    std::vector<Marshal> ms(n);
-    std::vector<std::vector<int32_t>> src_cam(n), src_idx(n);
-    std::vector<l3d_chain_view> cv(n);
-    std::vector<int> n_tbm(n);
+    P.n = n;
+    P.ms.assign(n, Marshal()); P.src_cam.assign(n, {}); P.src_idx.assign(n, {}); P.cv.assign(n, l3d_chain_view()); P.n_tbm.assign(n, 0);
     std::map<uint32_t, int> index_of;
     bool chain_ok = true;
     for (size_t k = 0; k < n && chain_ok; ++k) {
         View& v = h->views[h->order[k]];
         index_of[v.id] = (int)k;
-        Marshal& m = ms[k];
+        Marshal& m = P.ms[k];
         marshal_view(h, v, m);                          // toBeMatched from the simulated matched_ state
-        n_tbm[k] = (int)m.tbm.size();
+        P.n_tbm[k] = (int)m.tbm.size();
         std::vector<char> is_tbm(m.l2g.size(), 0);
         for (int32_t c : m.tbm) is_tbm[(size_t)c] = 1;
         for (size_t c = 0; c < m.l2g.size(); ++c) {
             if (is_tbm[c]) continue;
             auto it = index_of.find(m.l2g[c]);
             if (it == index_of.end() || it->second >= (int)k) { chain_ok = false; break; }   // cannot happen: matched => processed earlier
-            src_cam[k].push_back((int32_t)c);
-            src_idx[k].push_back(it->second);
+            P.src_cam[k].push_back((int32_t)c);
+            P.src_idx[k].push_back(it->second);
         }
         if (m.tbm.empty()) {
             // the early return hands back LOCAL camera ids (cudawrapper.cu:877-878); if one of those numbers happens
@@ -803,7 +814,7 @@ int match_views(L* h)
             for (uint32_t c = 0; c < (uint32_t)m.l2g.size(); ++c)
                 if (h->vn_has(c, v.id) && !h->matched.count(((uint64_t)c << 32) | v.id)) chain_ok = false;
         }
-        l3d_chain_view& o = cv[k];
+        l3d_chain_view& o = P.cv[k];
         o.view_id = v.id;
         o.src_segs = v.segs.data(); o.S_src = v.S();
         o.RtKinv_src = m.RtKinv_src; o.C_src = m.C_src;
@@ -812,15 +823,20 @@ int match_views(L* h)
         o.F = m.F.data(); o.RtKinv = m.RtKinv.data(); o.centers = m.centers.data(); o.P = m.P.data();
         o.to_be_matched = m.tbm.data(); o.n_tbm = (int32_t)m.tbm.size();
         o.local2global = m.l2g.data();
-        o.source_cam = src_cam[k].data(); o.source_index = src_idx[k].data(); o.n_sources = (int32_t)src_cam[k].size();
+        o.source_cam = P.src_cam[k].data(); o.source_index = P.src_idx[k].data(); o.n_sources = (int32_t)P.src_cam[k].size();
         o.sigma_p = h->sigma_p; o.sigma_a = h->sigma_a; o.spatial_k = m.spatial_k;
         mark_matched(h, v);
     }
     h->matched.clear();                                 // back to the state matchViews starts from
-    if (!chain_ok) return match_views_sync(h);
+    return chain_ok;
+}
+
+void start_finalizer(L* h, ChainPlan& P)
+{
+    const size_t n = P.n, nvl = h->vlist.size();
     h->saved.assign(n, {});
-    const size_t nvl = h->vlist.size();
-    ChainFinalizer fin(nvl);
+    P.fin.reset(new ChainFinalizer(nvl));
+    ChainFinalizer& fin = *P.fin;
     fin.h = h;
     fin.own_index.assign(nvl, -1); fin.contributors.assign(nvl, {}); fin.buckets.assign(n, {});
     for (size_t vi = 0; vi < nvl; ++vi) fin.pending[vi] = 0;
@@ -836,18 +852,21 @@ int match_views(L* h)
         }
     }
     fin.start(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)));
-    ChainUser user{ h, &h->order, &n_tbm, &src_idx, &fin };
-    const double t1 = now_s();
-    int rc = l3d_match_chain(h->ctx, cv.data(), (int)n, chain_callback, &user);
-    h->t_gpu_call += now_s() - t1 - h->t_commit;
+    P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin.get() };
+}
+
+// after the last callback: wait for the workers, the LOCAL-id entries of early-return views, inspection copies
+void finish_chain_host(L* h, ChainPlan& P, bool ok)
+{
     const double t2 = now_s();
-    fin.finish(rc == L3D_OK);
-    if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
+    P.fin->finish(ok);
+    if (!ok) return;
+    const size_t n = P.n;
     // early-return views (cudawrapper.cu:877-878) hand back LOCAL camera ids; where such a number names a view, the
     // reference records the pair under that view as well (line3D.cc:861-865): append and re-normalise (rare, tiny)
     h->pot_foreign.clear();
     for (size_t k = 0; k < n; ++k) {
-        if (n_tbm[k] != 0) continue;
+        if (P.n_tbm[k] != 0) continue;
         const uint32_t vid = h->order[k];
         std::set<size_t> touched;
         uint32_t last_cam = 0xffffffffu; View* o = nullptr;
@@ -864,6 +883,21 @@ int match_views(L* h)
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
     if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]] = h->saved[k];
     h->t_finalize += now_s() - t2;
+}
+
+int match_views(L* h)
+{
+    if (h->force_sync) return match_views_sync(h);
+    const double t0 = now_s();
+    match_begin(h);
+    ChainPlan P;
+    if (!plan_chain(h, P)) return match_views_sync(h);
+    start_finalizer(h, P);
+    const double t1 = now_s();
+    int rc = l3d_match_chain(h->ctx, P.cv.data(), (int)P.n, chain_callback, &P.user);
+    h->t_gpu_call += now_s() - t1 - h->t_commit;
+    finish_chain_host(h, P, rc == L3D_OK);
+    if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
     double st[4];
     l3d_last_stats(h->ctx, st);
     h->stat_pairs += st[0];
@@ -1347,6 +1381,64 @@ int l3d_line3d_match_view_commit(l3d_line3d* h, uint32_t view_id, const l3d_matc
     h->stat_last_tbm = l3d_line3d_view_num_to_be_matched(h, view_id);
     commit_view(h, *v, matches, n, median);
     return L3D_OK;
+}
+// ---- matchViews as the resident chain sharded over ranks (one process per GPU; see include/line3d_amd.h) -----------
+int l3d_line3d_shard_open(l3d_line3d* h, int rank, int world, int slot_records, int* n_views, size_t* slot_bytes)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    if (h->shard_plan_) return h->fail(L3D_ERR_INVALID, "a sharded chain is already open");
+    match_begin(h);
+    ChainPlan* P = new ChainPlan();
+    P->t0 = now_s();
+    if (!plan_chain(h, *P)) { delete P; return h->fail(L3D_ERR_INVALID, "schedule is not static (early-return quirk): use the per-view path"); }
+    int rc = l3d_shard_chain_open(h->ctx, P->cv.data(), (int)P->n, rank, world, slot_records, &P->shard, slot_bytes);
+    if (rc) { delete P; return h->fail(rc, std::string("shard_chain_open: ") + l3d_last_error(h->ctx)); }
+    start_finalizer(h, *P);
+    h->shard_plan_ = P;
+    if (n_views) *n_views = (int)P->n;
+    return L3D_OK;
+}
+int l3d_line3d_shard_view_verified(l3d_line3d* h, int k)
+{
+    if (!h || !h->shard_plan_) return -1;
+    ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
+    if (k < 0 || (size_t)k >= P->n) return -1;
+    return P->n_tbm[(size_t)k] > 0 ? 1 : 0;
+}
+int l3d_line3d_shard_enqueue(l3d_line3d* h, int k, void* send_slot, const void* gathered_base)
+{
+    if (!h || !h->shard_plan_) return L3D_ERR_INVALID;
+    int rc = l3d_shard_chain_enqueue(static_cast<ChainPlan*>(h->shard_plan_)->shard, k, send_slot, gathered_base);
+    return rc ? h->fail(rc, std::string("shard_chain_enqueue: ") + l3d_last_error(h->ctx)) : L3D_OK;
+}
+int l3d_line3d_shard_mark(l3d_line3d* h, int k)
+{
+    if (!h || !h->shard_plan_) return L3D_ERR_INVALID;
+    return l3d_shard_chain_mark(static_cast<ChainPlan*>(h->shard_plan_)->shard, k);
+}
+// host bookkeeping of view k on this rank (optional per rank; views must be fetched in order)
+int l3d_line3d_shard_fetch(l3d_line3d* h, int k)
+{
+    if (!h || !h->shard_plan_) return L3D_ERR_INVALID;
+    ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
+    int rc = l3d_shard_chain_fetch(P->shard, k, chain_callback, &P->user);
+    return rc ? h->fail(rc, std::string("shard_chain_fetch: ") + l3d_last_error(h->ctx)) : L3D_OK;
+}
+// committed != 0: this rank fetched every view -> its host state is finalised (finish() may follow)
+int l3d_line3d_shard_close(l3d_line3d* h, int committed)
+{
+    if (!h || !h->shard_plan_) return L3D_ERR_INVALID;
+    ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
+    int rc = l3d_shard_chain_close(P->shard);
+    finish_chain_host(h, *P, committed != 0 && rc == L3D_OK);
+    double st[4];
+    l3d_last_stats(h->ctx, st);
+    h->stat_pairs += st[0];
+    h->stat_raw += st[1];
+    h->t_match = now_s() - P->t0;
+    delete P;
+    h->shard_plan_ = nullptr;
+    return rc;
 }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 

@@ -70,3 +70,68 @@ def match_views_sharded(l3d, rank: int, world: int, dist, compute=None, device=N
         allb = np.concatenate([p[1] for p in parts]) if parts else best
         l3d.match_view_commit(vid, allm, allb)
     l3d.match_end()
+
+
+def default_slot_records(n_segments: int, n_neighbors: int, world: int) -> int:
+    """Kept matches one rank may produce for one view: about 1.5 per (source segment, neighbour) on the synthetic
+    scenes; 6x that leaves ample room (an overflow is reported by the fetch, never silent)."""
+    return max(1024, (6 * n_segments * n_neighbors) // (2 * world) + 1024)
+
+
+def match_views_chain_sharded(l3d, rank: int, world: int, dist, commit: bool = True, slot_records: int | None = None,
+                              n_segments: int = 2000, n_neighbors: int = 12, ahead: int = 12):
+    """Line3D::matchViews as the device-resident chain with every view's source segments sharded over `world` ranks
+    (one process per GPU).  Per view: the library enqueues this rank's kernels up to its kept-list slot, the slots are
+    all-gathered with RCCL (`all_gather_into_tensor`, enqueued on the library's stream: no host synchronisation), later
+    views read the gathered slots on the device.  Ranks with commit=True trail behind and do the host bookkeeping
+    (the concatenation of the ranks' lists in rank order is the sorted unsharded list)."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if slot_records is None:
+        slot_records = default_slot_records(n_segments, n_neighbors, world)
+    n_views, slot_bytes = l3d.shard_open(rank, world, slot_records)
+    ext = torch.cuda.ExternalStream(l3d.stream_ptr(), device=dev)
+    failure = None          # a rank that hits an error keeps feeding the collectives so that all ranks stay in lock step
+    try:
+        with torch.cuda.stream(ext):
+            gathered = torch.zeros(n_views * world * slot_bytes, dtype=torch.uint8, device=dev)
+            send = torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev)
+            gbase, sbase = gathered.data_ptr(), send.data_ptr()
+            fetched = 0
+
+            def guarded(fn, *a):
+                nonlocal failure
+                if failure is None:
+                    try:
+                        fn(*a)
+                    except Exception as e:      # noqa: BLE001
+                        failure = e
+
+            for k in range(n_views):
+                guarded(l3d.shard_enqueue, k, sbase + k * slot_bytes, gbase)
+                if l3d.shard_view_verified(k):
+                    out = gathered[k * world * slot_bytes:(k + 1) * world * slot_bytes]
+                    if dist is not None:
+                        dist.all_gather_into_tensor(out, send[k * slot_bytes:(k + 1) * slot_bytes])
+                    else:
+                        out.copy_(send[k * slot_bytes:(k + 1) * slot_bytes], non_blocking=True)
+                guarded(l3d.shard_mark, k)
+                if commit:
+                    while fetched <= k - ahead and failure is None:
+                        guarded(l3d.shard_fetch, fetched)
+                        fetched += 1
+            if commit:
+                while fetched < n_views and failure is None:
+                    guarded(l3d.shard_fetch, fetched)
+                    fetched += 1
+            ext.synchronize()
+            if dist is not None:                # every rank learns whether any rank failed (e.g. a slot overflow seen by rank 0)
+                flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) and failure is None:
+                    failure = RuntimeError("another rank reported a failure of the sharded chain")
+    finally:
+        l3d.shard_close(commit and failure is None)
+    if failure is not None:
+        raise failure
+    return n_views

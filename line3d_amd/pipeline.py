@@ -154,6 +154,33 @@ class Line3D:
             self._chk(self.lib.l3d_line3d_match_view_commit(self.h, C.c_uint32(view_id), _p(m), C.c_int(len(m)), _p(b),
                                                             C.c_int(len(b) // 2), C.c_float(median)))
 
+    # -- resident chain sharded over ranks (line3d_amd/distributed.py drives it) -------------------
+    def stream_ptr(self) -> int:
+        self.lib.l3d_ctx_stream.restype = C.c_void_p
+        self.lib.l3d_ctx_stream.argtypes = [C.c_void_p]
+        return int(self.lib.l3d_ctx_stream(C.c_void_p(self.lib.l3d_line3d_context(self.h))) or 0)
+
+    def shard_open(self, rank: int, world: int, slot_records: int):
+        n = C.c_int(0)
+        sb = C.c_size_t(0)
+        self._chk(self.lib.l3d_line3d_shard_open(self.h, C.c_int(rank), C.c_int(world), C.c_int(slot_records), C.byref(n), C.byref(sb)))
+        return n.value, sb.value
+
+    def shard_view_verified(self, k: int) -> bool:
+        return self.lib.l3d_line3d_shard_view_verified(self.h, C.c_int(k)) == 1
+
+    def shard_enqueue(self, k: int, send_slot_ptr: int, gathered_ptr: int):
+        self._chk(self.lib.l3d_line3d_shard_enqueue(self.h, C.c_int(k), C.c_void_p(send_slot_ptr), C.c_void_p(gathered_ptr)))
+
+    def shard_mark(self, k: int):
+        self._chk(self.lib.l3d_line3d_shard_mark(self.h, C.c_int(k)))
+
+    def shard_fetch(self, k: int):
+        self._chk(self.lib.l3d_line3d_shard_fetch(self.h, C.c_int(k)))
+
+    def shard_close(self, committed: bool):
+        self._chk(self.lib.l3d_line3d_shard_close(self.h, C.c_int(int(committed))))
+
     def match_end(self):
         self._chk(self.lib.l3d_line3d_match_end(self.h))
 

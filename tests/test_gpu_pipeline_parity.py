@@ -144,3 +144,70 @@ def test_chain_rerun_is_idempotent(small_scene):
     b = {v["id"]: l.view_matches(v["id"])[0].tobytes() for v in small_scene.views}
     assert a == b and sum(len(x) for x in a.values()) > 0
     l.close()
+
+
+def test_sharded_chain_world1_equals_oracle(small_scene, small_oracle):
+    """The sharded resident chain through the same Python driver the multi-GPU bench uses, world = 1 (the copy that
+    stands in for the all-gather runs on the library's stream): identical to the oracle."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.prepare()
+    l3dist.match_views_chain_sharded(l, 0, 1, None, commit=True, n_segments=300, n_neighbors=6)
+    l.finish(False)
+    for v in sorted(small_oracle.trace):
+        got, med = l.view_matches(v)
+        assert got.tobytes() == small_oracle.trace[v]["matches"].tobytes(), "view %d" % v
+        assert np.float32(med) == np.float32(small_oracle.trace[v]["median"])
+    assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+    l.close()
+
+
+def test_sharded_chain_three_virtual_ranks(small_scene, small_oracle):
+    """Three 'ranks' emulated on one GPU (three pipelines, each with its own context/stream, rank r of 3): per view
+    every rank enqueues its slot, the all-gather is emulated with device copies between the ranks' buffers, then the
+    views are marked; rank 0 does the host bookkeeping.  Bit-identical to the unsharded oracle run."""
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    W = 3
+    ls = []
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.prepare()
+        ls.append(l)
+    dev = torch.device("cuda", 0)
+    geo = [l.shard_open(r, W, 4096) for r, l in enumerate(ls)]
+    n_views, slot_bytes = geo[0]
+    assert all(g == geo[0] for g in geo)
+    gathered = [torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    try:
+        for k in range(n_views):
+            for r, l in enumerate(ls):
+                l.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered[r].data_ptr())
+            torch.cuda.synchronize()                       # all ranks' slots of view k are written
+            if ls[0].shard_view_verified(k):
+                for q in range(W):                         # the all-gather
+                    for r in range(W):
+                        gathered[q][(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+            torch.cuda.synchronize()
+            for l in ls:
+                l.shard_mark(k)
+            ls[0].shard_fetch(k)
+    finally:
+        for r, l in enumerate(ls):
+            l.shard_close(r == 0)
+    l0 = ls[0]
+    l0.finish(False)
+    for v in sorted(small_oracle.trace):
+        got, med = l0.view_matches(v)
+        assert got.tobytes() == small_oracle.trace[v]["matches"].tobytes(), "view %d" % v
+        assert np.float32(med) == np.float32(small_oracle.trace[v]["median"])
+    assert_lines_equal(l0.getResult(), small_oracle.result, 1e-4)
+    for l in ls:
+        l.close()
