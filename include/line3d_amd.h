@@ -187,6 +187,9 @@ int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
 /* stage-1 conservative wedge pre-test in front of the exact epipolar/overlap test: 1 = on (default), 0 = off (A/B
  * testing; results are bit-identical, the pre-test only rejects pairs the exact test rejects) */
 int l3d_set_pair_pretest(l3d_ctx* ctx, int on);
+/* testing: cap the LDS image of the depth-window kernel (bytes; 0 = device limit) so that segments take the
+ * global-scratch variant; process-wide */
+int l3d_set_verify_lds_budget(size_t bytes);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
 int l3d_profile_reset(l3d_ctx* ctx);
 int l3d_profile_get(l3d_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);

@@ -94,6 +94,9 @@ class Context:
     def profile_all(self):
         return {k: self.profile_get(k) for k in self.lib.l3d_profile_names().decode().split(";")}
 
+    def set_verify_lds_budget(self, nbytes: int):
+        self._chk(self.lib.l3d_set_verify_lds_budget(C.c_size_t(nbytes)))
+
     def set_pair_pretest(self, on: bool):
         self._chk(self.lib.l3d_set_pair_pretest(self.h, C.c_int(int(on))))
 

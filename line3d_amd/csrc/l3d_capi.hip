@@ -62,7 +62,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     prof_resolve(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
@@ -97,6 +97,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
     return L3D_OK;
 }
 
+int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes); return L3D_OK; }
 int l3d_set_pair_pretest(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->wedge_pretest = on ? 1 : 0; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
@@ -315,15 +316,25 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end; va.nrow_total = (int)nrow;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
+    va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
     { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
     va.stamps = nullptr;
     if (getenv("L3D_VW_STAMPS")) {
         if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
         va.stamps = c->stamps.as<unsigned long long>();
     }
-    const bool window = c->verify_mode == 0 && N <= 255 && verify_window_lds_bytes(mmax, N) <= verify_window_max_lds();
-    if (window) { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-    else { ProfScope p(c, "verify"); launch_verify(va, st); }
+    if (c->verify_mode == 0 && N <= 255) {
+        // segments that fit the LDS image in one launch, the (few) bigger ones in a second launch on a global scratch
+        int mfit = mmax;
+        while (mfit > 64 && verify_window_lds_bytes(mfit, N) > verify_window_max_lds()) mfit = mfit * 3 / 4;
+        va.mmax = mfit; va.skip_above = 1;
+        { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+        if (mfit < mmax) {
+            HIPCHK(c, c->vw_scratch.reserve(((size_t)R + 2) * 16));
+            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)R + 2;
+            ProfScope p(c, "verify_window"); launch_verify_window(va, st);
+        }
+    } else { ProfScope p(c, "verify"); launch_verify(va, st); }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
     { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
     { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), d_l2g, c->kept.as<Match>(), st); }

@@ -378,6 +378,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
         HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
         HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
+        HIPCHK(c, c->vw_scratch.reserve((cand_cap + 2) * 16));
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
         return L3D_OK;
     };
@@ -425,12 +426,14 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
         va.mmax = mmax;
         if (c->verify_mode == 0) {
-            va.skip_above = 1; va.only_above = -1;
+            va.skip_above = 1; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            va.only_above = mmax;
-            { ProfScope p(c, "verify"); launch_verify(va, st); }
+            // segments that outgrow the LDS image (reverse matches are not in the estimate): same algorithm on a global scratch
+            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + 2;
+            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+            va.big = 0;
         } else {
-            va.skip_above = 0; va.only_above = -1;
+            va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
             ProfScope p(c, "verify"); launch_verify(va, st);
         }
         { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }

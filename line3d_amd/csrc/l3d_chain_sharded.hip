@@ -258,6 +258,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->cand_meta.reserve(h->cand_cap * 8));
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
     OCHK(c->cand_conf.reserve(h->cand_cap * 4));
+    OCHK(c->vw_scratch.reserve((h->cand_cap + 2) * 16));
     OCHK(c->ch_pin_kept.reserve((size_t)world * h->geom.slot_bytes + 64));
 #undef OCHK
     h->ev1.assign((size_t)n_views, nullptr);
@@ -359,12 +360,14 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     va.mmax = mmax;
     if (d.s1 > d.s0) {
         if (c->verify_mode == 0) {
-            va.skip_above = 1; va.only_above = -1;
+            va.skip_above = 1; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            va.only_above = mmax;
-            { ProfScope p(c, "verify"); launch_verify(va, st); }
+            // segments that outgrow the LDS image (reverse matches are not in the estimate): same algorithm on a global scratch
+            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + 2;
+            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+            va.big = 0;
         } else {
-            va.skip_above = 0; va.only_above = -1;
+            va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
             ProfScope p(c, "verify"); launch_verify(va, st);
         }
         { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }

@@ -63,7 +63,7 @@ struct l3d_ctx {
     std::string err;
     // arenas of the matching path
     l3d::DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
-    l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps;
+    l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags;

@@ -66,7 +66,10 @@ struct VerifyArgs {
     int nrow_total;                 // S_src * N: row_start[nrow_total] = number of candidates
     int mmax;                       // max candidates of one segment (LDS sizing)
     int only_above;                 // k_verify (all-pairs): process only segments with more than this many candidates (-1: all)
-    int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to k_verify (0/1)
+    int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to the `big` launch (0/1)
+    int big;                        // k_verify_window: 1 = only segments with more than mmax candidates, arrays in `scratch`
+    float* scratch;                 // 4 arrays of scratch_stride floats (candidate capacity + 2), global memory
+    long long scratch_stride;
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
     const struct ChainResult* res;  // optional device record of the resident chain (kept base/count)
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
@@ -84,6 +87,7 @@ void launch_verify(const VerifyArgs& a, hipStream_t st);
 void launch_verify_window(const VerifyArgs& a, hipStream_t st);
 size_t verify_window_lds_bytes(int mmax, int N);
 size_t verify_window_max_lds();
+void verify_window_set_lds_budget(size_t bytes);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
 void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);

@@ -104,19 +104,27 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    if (m == 0 || (a.skip_above && m > a.mmax)) return;
+    // big == 0: segments whose candidates fit the LDS image (m <= mmax); big == 1: the rest, same algorithm with the
+    // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop
+    if (m == 0 || (a.big ? m <= a.mmax : (a.skip_above && m > a.mmax))) return;
     if (a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap) return;     // candidate overflow: the chain is re-run
     if (a.debug == 4) return;
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
-    const int cap = a.mmax + 2;                                          // +2: the scan prefetches one entry ahead
+    const int cap = a.big ? 0 : a.mmax + 2;                              // +2: the scan prefetches one entry ahead
     VWLds L;
     L.sd1 = reinterpret_cast<float*>(s_raw);
     L.sd2 = L.sd1 + cap;
     L.sci = reinterpret_cast<unsigned*>(L.sd2 + cap);
     L.stgt = L.sci + cap;
     float* smax = reinterpret_cast<float*>(L.stgt + cap);                // [256][N] per-(hypothesis lane, camera) maxima
+    if (a.big) {                                                         // the segment's own slice of the scratch (+2 per array)
+        float* g = a.scratch;
+        const size_t stride = (size_t)a.scratch_stride;
+        L.sd1 = g + start; L.sd2 = g + stride + start;
+        L.sci = reinterpret_cast<unsigned*>(g + 2 * stride) + start; L.stgt = reinterpret_cast<unsigned*>(g + 3 * stride) + start;
+    }
     unsigned* qall = reinterpret_cast<unsigned*>(smax + 256 * a.N);
     unsigned* q = qall + wave * kVQ * 2;
     float* smax_wave = smax + wave * 64 * a.N;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         L.sci[pos] = (mt.y << 24) | (unsigned)i;
         L.stgt[pos] = mt.x;
     }
-    if (tid < 2) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }
+    if (tid < 2 && !a.big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
     __syncthreads();
     if (a.debug == 1) return;
     VW_STAMP(0);
@@ -290,11 +298,15 @@ __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_beg
 }
 
 size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)(mmax + 2) * 16 + (size_t)256 * N * 4 + 4 * kVQ * 8 + 16; }
+size_t verify_window_lds_bytes_big(int N) { return (size_t)256 * N * 4 + 4 * kVQ * 8 + 64; }
 // Largest dynamic LDS a k_verify_window launch may ask for on this device/runtime (queried once): up to 160 KB per
 // workgroup on gfx950 once the kernel has opted in; runtimes that refuse the opt-in stay at the 48/64 KB default.
+static size_t g_lds_budget_override = 0;
+void verify_window_set_lds_budget(size_t bytes) { g_lds_budget_override = bytes; }
 size_t verify_window_max_lds()
 {
     static size_t limit = 0;
+    if (g_lds_budget_override) return g_lds_budget_override;
     if (limit) return limit;
     int dev = 0, per_block = 0;
     (void)hipGetDevice(&dev);
@@ -310,7 +322,8 @@ size_t verify_window_max_lds()
 }
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256), verify_window_lds_bytes(a.mmax, a.N), st, a);
+    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256),
+                       a.big ? verify_window_lds_bytes_big(a.N) : verify_window_lds_bytes(a.mmax, a.N), st, a);
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {

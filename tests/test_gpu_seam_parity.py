@@ -216,3 +216,24 @@ def test_pair_pretest_is_conservative(gpu_ctx):
         assert res[0] == res[1], "seed %d" % seed
         assert res[0][3] > 10000
     assert total_pairs > 5e7
+
+
+def test_window_verify_global_scratch_variant(gpu_ctx, small_oracle, small_scene):
+    """With the LDS budget capped most segments take the global-scratch variant of the window kernel; results stay
+    bit-identical (per-view seam call and the resident chain)."""
+    gpu_ctx.set_verify_lds_budget(8 * 1024 + 256 * 6 * 4 + 4096)       # ~512 candidates fit
+    try:
+        for v in (1, 4, 7):
+            tr = small_oracle.trace[v]
+            got, med, _ = _run_view(gpu_ctx, tr)
+            assert got.tobytes() == tr["matches"].tobytes(), "view %d" % v
+        from line3d_amd.pipeline import Line3D, load_scene
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.compute3Dmodel(False)
+        for v in sorted(small_oracle.trace):
+            assert l.view_matches(v)[0].tobytes() == small_oracle.trace[v]["matches"].tobytes(), "chain view %d" % v
+        l.close()
+    finally:
+        gpu_ctx.set_verify_lds_budget(0)
