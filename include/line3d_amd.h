@@ -191,6 +191,8 @@ int l3d_set_pair_pretest(l3d_ctx* ctx, int on);
  * global-scratch variant; process-wide */
 int l3d_set_verify_lds_budget(size_t bytes);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
+/* bracket only the named kernel with HIP events (NULL or "": all kernels) -- keeps a timed region nearly undisturbed */
+int l3d_profile_only(l3d_ctx* ctx, const char* kernel);
 int l3d_profile_reset(l3d_ctx* ctx);
 int l3d_profile_get(l3d_ctx* ctx, const char* kernel, int64_t* launches, double* total_ms);
 const char* l3d_profile_names(void);

@@ -82,6 +82,10 @@ class Context:
     def profile_enable(self, on=True):
         self._chk(self.lib.l3d_profile_enable(self.h, C.c_int(1 if on else 0)))
 
+    def profile_only(self, name: str | None):
+        """Bracket only this kernel with HIP events (None: all)."""
+        self._chk(self.lib.l3d_profile_only(self.h, (name or "").encode()))
+
     def profile_reset(self):
         self._chk(self.lib.l3d_profile_reset(self.h))
 

@@ -39,6 +39,9 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
+    }
     *out = c;
     return L3D_OK;
 }
@@ -68,6 +71,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
+    (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -101,6 +105,7 @@ int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes
 int l3d_set_pair_pretest(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->wedge_pretest = on ? 1 : 0; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
+int l3d_profile_only(l3d_ctx* c, const char* kernel) { if (!c) return L3D_ERR_INVALID; c->prof_only = kernel ? kernel : ""; return L3D_OK; }
 int l3d_profile_reset(l3d_ctx* c)
 {
     if (!c) return L3D_ERR_INVALID;
@@ -279,7 +284,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     HIPCHK(c, c->exist.reserve((size_t)n_ex * sizeof(ExistRec) + 16));
     if (n_ex) HIPCHK(c, hipMemcpyAsync(c->exist.p, ex, (size_t)n_ex * sizeof(ExistRec), hipMemcpyHostToDevice, st));
     { ProfScope p(c, "exist"); launch_exist_hist(c->exist.as<ExistRec>(), n_ex, N, c->rowcnt.as<int>(), st); }
-    { ProfScope p(c, "scan"); launch_scan(c->rowcnt.as<int>(), c->row_start.as<int>(), (int)nrow, st); }
+    { ProfScope p(c, "scan"); launch_scan(c->rowcnt.as<int>(), c->row_start.as<int>(), (int)nrow, nullptr, st); }
     launch_seg_mmax(c->row_start.as<int>(), N, seg_begin, seg_end, c->scal.as<int>(), st);
     int* hs = c->pin_scal.as<int>();
     HIPCHK(c, hipMemcpyAsync(hs, c->row_start.as<int>() + nrow, 4, hipMemcpyDeviceToHost, st));
@@ -316,7 +321,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end; va.nrow_total = (int)nrow;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
-    va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
+    va.big = 0; va.scratch = nullptr; va.scratch_stride = 0; va.kept_cnt = nullptr; va.best_depths = nullptr;
     { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
     va.stamps = nullptr;
     if (getenv("L3D_VW_STAMPS")) {
@@ -336,7 +341,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
         }
     } else { ProfScope p(c, "verify"); launch_verify(va, st); }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }
-    { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, st); }
+    { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S_src, nullptr, st); }
     { ProfScope p(c, "kept_write"); launch_kept_write(va, c->kept_start.as<int>(), d_l2g, c->kept.as<Match>(), st); }
     TPHASE(4);
 
@@ -403,7 +408,7 @@ int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float col
     HIPCHK(c, hipMemsetAsync(c->g2.p, 0, (size_t)S * 4, st));
     const float sigma_sqr = collin_s * collin_s;   // cudawrapper.cu:850
     { ProfScope p(c, "collinearity"); launch_collinearity(d_segs, S, sigma_sqr, c->g1.as<unsigned long long>(), W64, c->g2.as<int>(), st); }
-    { ProfScope p(c, "scan"); launch_scan(c->g2.as<int>(), c->g3.as<int>(), S, st); }
+    { ProfScope p(c, "scan"); launch_scan(c->g2.as<int>(), c->g3.as<int>(), S, nullptr, st); }
     int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, c->g3.as<int>() + S, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

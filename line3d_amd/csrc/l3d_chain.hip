@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "l3d_ctx.hpp"
+#include "l3d_scan.hpp"
 
 using namespace l3d;
 
@@ -91,14 +92,17 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
     for (int r = 0; r < 4; ++r) {
         const int i = lane + 64 * r;
         key[r] = i < n ? meta[b + i].x : 0xffffffffu;
-        if (i < n) d[r] = depths[b + i];
+        d[r] = i < n ? depths[b + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int r = 0; r < 4 && r * 64 < n; ++r) {
-        const int cnt = min(64, n - r * 64);
-        for (int l = 0; l < cnt; ++l) {
-            const unsigned other = __shfl(key[r], l);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
+    for (int r = 0; r < 4; ++r) {                   // (all indices static: the arrays stay in registers)
+        if (r * 64 < n) {
+            const int cnt = min(64, n - r * 64);
+            for (int l = 0; l < cnt; ++l) {
+                const unsigned other = __shfl(key[r], l);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
+            }
         }
     }
 #pragma unroll
@@ -108,31 +112,45 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
     }
 }
 
-// raw candidate total and the largest per-segment count of one view (phase 1 statistics): out2 = {total, max}
-__global__ __launch_bounds__(256) void k_raw_stats(const int* __restrict__ rowcnt, int S, int N, int* __restrict__ out2)
+// raw candidate total and the largest per-segment count of one view's segment range (phase 1 statistics), by one
+// workgroup; out2 = {total, max} lives in host-mapped pinned memory: no copy, the host reads it after the stage-1 event
+__global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowcnt, int N, int seg_begin, int seg_end, int* __restrict__ out2)
 {
+    __shared__ int s_t[16], s_m[16];
     int tot = 0, mx = 0;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < S; s += gridDim.x * blockDim.x) {
+    for (int s = seg_begin + (int)threadIdx.x; s < seg_end; s += 1024) {
         int c = 0;
         for (int k = 0; k < N; ++k) c += rowcnt[s * N + k];
         tot += c; mx = max(mx, c);
     }
     for (int o = 32; o > 0; o >>= 1) { tot += __shfl_down(tot, o); mx = max(mx, __shfl_down(mx, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out2[0], tot); atomicMax(&out2[1], mx); }
+    if ((threadIdx.x & 63) == 0) { s_t[threadIdx.x >> 6] = tot; s_m[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { tot += s_t[w]; mx = max(mx, s_m[w]); }
+        out2[0] = tot; out2[1] = mx;
+    }
 }
 
-// one thread: reserve the view's slice of the kept arena and publish (base, count, #candidates, overflow)
-__global__ void k_kept_alloc(const int* __restrict__ kept_start, int S, const int* __restrict__ row_start, int nrow,
-                             int* __restrict__ arena_cursor, int arena_cap, int cand_cap, ChainResult* __restrict__ res)
+// prefix sums of the per-segment kept counts and, in the same launch, the reservation of the view's slice of the kept
+// arena: (base, count, #candidates, overflow) published to the device record and to its host-mapped mirror
+__global__ __launch_bounds__(kScanThreads) void k_scan_kept_chain(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int S,
+                                                                  const int* __restrict__ row_start, int nrow, int* __restrict__ arena_cursor,
+                                                                  int arena_cap, int cand_cap, ChainResult* __restrict__ res,
+                                                                  ChainResult* __restrict__ res_host)
 {
+    __shared__ int s_w[16];
+    const int total = wg_scan_excl(kept_cnt, kept_start, S, nullptr, s_w);
+    if (threadIdx.x != 0) return;
     ChainResult r;
     r.R = row_start[nrow];
     r.overflow = r.R > cand_cap ? 1 : 0;
-    r.n_kept = r.overflow ? 0 : kept_start[S];
+    r.n_kept = r.overflow ? 0 : total;
     r.kept_base = *arena_cursor;
     if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
     *arena_cursor = r.kept_base + r.n_kept;
     *res = r;
+    *res_host = r;
 }
 
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_start,
@@ -179,18 +197,19 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
     const int n = S * n_cams;
     if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
 }
-void launch_raw_stats(const int* rowcnt, int S, int N, int* out2, hipStream_t st)
+void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_raw_stats, dim3(8), dim3(256), 0, st, rowcnt, S, N, out2);
+    hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
-void launch_kept_alloc(const int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap, int cand_cap,
-                       ChainResult* res, hipStream_t st)
+void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
+                            int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_kept_alloc, dim3(1), dim3(1), 0, st, kept_start, S, row_start, nrow, arena_cursor, arena_cap, cand_cap, res);
+    hipLaunchKernelGGL(k_scan_kept_chain, dim3(1), dim3(kScanThreads), 0, st, kept_cnt, kept_start, S, row_start, nrow, arena_cursor, arena_cap,
+                       cand_cap, res, res_host);
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_kept_write_chain, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, arena);
+    if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write_chain, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, arena);
 }
 
 }  // namespace l3d
@@ -219,7 +238,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     if (n_views < 0 || (n_views > 0 && (!views || !cb))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
     if (n_views == 0) return L3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
+    hipStream_t st = c->stream;         // phase 2 (the chain proper)
+    hipStream_t s1 = c->stage1_stream;  // stage 1 runs ahead here, concurrently with the latency-bound kernels of phase 2
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
 
     // ---- validation, table layout
@@ -297,6 +317,18 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
     HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
+    {   // stage 1 starts after the tables and the zeroed row counts are in place
+        hipEvent_t ready = get_event(c);
+        HIPCHK(c, hipEventRecord(ready, st));
+        HIPCHK(c, hipStreamWaitEvent(s1, ready, 0));
+        c->event_pool.push_back(ready);
+    }
+    // per-view results are written by the kernels straight into host-mapped pinned memory (no copy operations on the streams)
+    ChainResult* hres = c->ch_pin_res.as<ChainResult>();
+    int* hstats = reinterpret_cast<int*>(c->ch_pin_res.as<unsigned char>() + (size_t)n_views * sizeof(ChainResult));
+    ChainResult* hres_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&hres_dev), hres, 0));
+    int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
     {
         size_t mo = 0, ro = 0, bo = 0;
         int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
@@ -339,20 +371,19 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
         pairs += p; max_pairs = std::max(max_pairs, p);
     }
-    int* hstats = reinterpret_cast<int*>(c->ch_pin_res.as<unsigned char>() + (size_t)n_views * sizeof(ChainResult));
     std::vector<hipEvent_t> ev1((size_t)n_views, nullptr);
     int k_p1 = 0;                       // next view whose stage 1 is enqueued
     auto enqueue_stage1 = [&](int k) -> int {
         if (!vd[(size_t)k].verified) return L3D_OK;
+        hstats[2 * k] = hstats[2 * k + 1] = 0;
         if (views[k].S_src > 0) {
             const PairArgs pa = pair_args(k);
-            { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, vd[(size_t)k].maxW, st); }
-            { ProfScope p(c, "row_count"); launch_row_count(pa, vd[(size_t)k].rowcnt, st); }
-            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].S_src, views[k].N, vd[(size_t)k].stats, st);
+            { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, vd[(size_t)k].maxW, s1); }
+            { ProfScope p(c, "row_count", s1); launch_row_count(pa, vd[(size_t)k].rowcnt, s1); }
+            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
         }
-        HIPCHK(c, hipMemcpyAsync(hstats + 2 * k, vd[(size_t)k].stats, 8, hipMemcpyDeviceToHost, st));
         ev1[(size_t)k] = get_event(c);
-        HIPCHK(c, hipEventRecord(ev1[(size_t)k], st));
+        HIPCHK(c, hipEventRecord(ev1[(size_t)k], s1));
         return L3D_OK;
     };
     c->stats[0] = pairs;
@@ -362,7 +393,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // first guess from the pair counts (raw density ~6 %, kept ~0.2 % of the pairs on the synthetic scenes)
     size_t cand_cap = (size_t)(max_pairs * 0.10) + 65536;
     size_t arena_cap = (size_t)(pairs * 0.004) + 1048576;
-    ChainResult* hres = c->ch_pin_res.as<ChainResult>();
     std::vector<hipEvent_t> ev((size_t)n_views, nullptr);
     const size_t nrow_max = (size_t)maxS * maxN;
     HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));
@@ -390,6 +420,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         while (k_p1 < n_views && k_p1 <= k + kStage1Ahead) { int rc = enqueue_stage1(k_p1); if (rc) return rc; ++k_p1; }
         if (!d.verified) return L3D_OK;
         HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
+        HIPCHK(c, hipStreamWaitEvent(st, ev1[(size_t)k], 0));
         raw_sum += hstats[2 * k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
@@ -399,11 +430,9 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         ChainResult* dres = c->ch_res.as<ChainResult>();
         const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
         (void)hipGetLastError();
-        HIPCHK(c, hipMemsetAsync(c->ch_cursor.p, 0, nrow * 4, st));
-        HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S * 4, st));
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
         { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
-        { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, st); }
+        { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
         if (S > 0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
         {
             ProfScope p(c, "exist");
@@ -421,27 +450,27 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         va.N = N; va.seg_begin = 0; va.seg_end = S; va.nrow_total = (int)nrow;
         va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
         va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
-        // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the all-pairs kernel
+        // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
         int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
         while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
         va.mmax = mmax;
         if (c->verify_mode == 0) {
-            va.skip_above = 1; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
+            // one launch: segments that fit the LDS image, the ones that outgrow it (reverse matches are not in the estimate)
+            // on a global scratch, and the per-segment epilogue (best hypothesis, kept count)
+            va.skip_above = 1; va.only_above = -1; va.big = 2;
+            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + 2;
+            va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            // segments that outgrow the LDS image (reverse matches are not in the estimate): same algorithm on a global scratch
-            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + 2;
-            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            va.big = 0;
         } else {
             va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
-            ProfScope p(c, "verify"); launch_verify(va, st);
+            va.kept_cnt = nullptr; va.best_depths = nullptr;
+            { ProfScope p(c, "verify"); launch_verify(va, st); }
+            { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
         }
-        { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
-        { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, st); }
-        launch_kept_alloc(c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, arena_cursor, (int)arena_cap, (int)cand_cap, dres + k, st);
+        { ProfScope p(c, "scan"); launch_scan_kept_chain(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, arena_cursor,
+                                                         (int)arena_cap, (int)cand_cap, dres + k, hres_dev + k, st); }
         { ProfScope p(c, "kept_write"); launch_kept_write_chain(va, c->kept_start.as<int>(), reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, (int)arena_cap, st); }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-        HIPCHK(c, hipMemcpyAsync(hres + k, dres + k, sizeof(ChainResult), hipMemcpyDeviceToHost, st));
         if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
         return L3D_OK;
@@ -504,6 +533,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         kept_total += r.n_kept;
         if (cb(user, k, 1, c->ch_pin_kept.as<l3d_match>(), r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
     }
+    HIPCHK(c, hipStreamSynchronize(s1));
     HIPCHK(c, hipStreamSynchronize(st));
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);

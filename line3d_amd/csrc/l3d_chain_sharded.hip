@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "l3d_ctx.hpp"
+#include "l3d_scan.hpp"
 
 using namespace l3d;
 
@@ -66,14 +67,19 @@ __global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotG
     }
 }
 
-// one thread: header of this rank's slot (count, #candidates, overflow)
-__global__ void k_slot_header(const int* __restrict__ kept_start, int S, const int* __restrict__ row_start, int nrow, int cand_cap,
-                              int slot_records, int s0, int s1, unsigned char* __restrict__ slot)
+// prefix sums of the kept counts of this rank's segment range and, in the same launch, the header of its slot
+// (count, #candidates, overflow).  kept_cnt / kept_start point at the range's first segment.
+__global__ __launch_bounds__(kScanThreads) void k_scan_kept_slot(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int n_seg,
+                                                                 const int* __restrict__ row_start, int nrow, int cand_cap, int slot_records,
+                                                                 int s0, int s1, unsigned char* __restrict__ slot)
 {
+    __shared__ int s_w[16];
+    const int total = wg_scan_excl(kept_cnt, kept_start, n_seg, nullptr, s_w);
+    if (threadIdx.x != 0) return;
     SlotHeader h;
     h.R = row_start[nrow];
     h.overflow = h.R > cand_cap ? 1 : 0;
-    h.n_kept = h.overflow ? 0 : kept_start[S];
+    h.n_kept = h.overflow ? 0 : total;
     if (h.n_kept > slot_records) { h.overflow |= 2; h.n_kept = 0; }
     h.s0 = s0; h.s1 = s1; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     *reinterpret_cast<SlotHeader*>(slot) = h;
@@ -138,6 +144,7 @@ struct l3d_shard_chain {
     std::vector<SViewDev> vd;
     const unsigned char* dtab = nullptr;
     int* hstats = nullptr;
+    int* hstats_dev = nullptr;
     std::vector<hipEvent_t> ev1, ev2;
     int k_p1 = 0;
     size_t cand_cap = 0;
@@ -249,6 +256,13 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
         }
     }
     h->hstats = c->ch_pin_res.as<int>();
+    OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hstats_dev), h->hstats, 0));
+    {   // stage 1 (own stream) starts after the tables and the zeroed row counts are in place
+        hipEvent_t ready = get_event(c);
+        OCHK(hipEventRecord(ready, st));
+        OCHK(hipStreamWaitEvent(c->stage1_stream, ready, 0));
+        c->event_pool.push_back(ready);
+    }
     h->cand_cap = (size_t)(max_pairs * 0.12) + 65536;
     const size_t nrow_max = (size_t)h->maxS * h->maxN;
     OCHK(c->row_start.reserve((nrow_max + 1) * 4));
@@ -291,18 +305,18 @@ static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
 static int shard_stage1(l3d_shard_chain* h, int k)
 {
     l3d_ctx* c = h->c;
-    hipStream_t st = c->stream;
+    hipStream_t s1 = c->stage1_stream;
     const SViewDev& d = h->vd[(size_t)k];
     if (!d.verified) return L3D_OK;
+    h->hstats[2 * k] = h->hstats[2 * k + 1] = 0;
     if (d.s1 > d.s0) {
         const PairArgs pa = shard_pair_args(h, k);
-        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, d.maxW, st); }
-        { ProfScope p(c, "row_count"); launch_row_count(pa, d.rowcnt, st); }
-        launch_raw_stats(d.rowcnt, h->views[k].S_src, h->views[k].N, d.stats, st);
+        { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, d.maxW, s1); }
+        { ProfScope p(c, "row_count", s1); launch_row_count(pa, d.rowcnt, s1); }
+        launch_raw_stats(d.rowcnt, h->views[k].N, d.s0, d.s1, h->hstats_dev + 2 * k, s1);     // straight into host-mapped memory
     }
-    HIPCHK(c, hipMemcpyAsync(h->hstats + 2 * k, d.stats, 8, hipMemcpyDeviceToHost, st));
     h->ev1[(size_t)k] = get_event(c);
-    HIPCHK(c, hipEventRecord(h->ev1[(size_t)k], st));
+    HIPCHK(c, hipEventRecord(h->ev1[(size_t)k], s1));
     return L3D_OK;
 }
 
@@ -323,6 +337,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     if (!d.verified) return L3D_OK;
     if (!send_slot) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_enqueue: null slot");
     HIPCHK(c, hipEventSynchronize(h->ev1[(size_t)k]));
+    HIPCHK(c, hipStreamWaitEvent(st, h->ev1[(size_t)k], 0));
     h->raw_sum += h->hstats[2 * k];
     PairArgs pa = shard_pair_args(h, k);
     pa.cand_cap = (int)h->cand_cap;
@@ -332,13 +347,11 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
     const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
     unsigned char* slot = reinterpret_cast<unsigned char*>(send_slot);
-    HIPCHK(c, hipMemsetAsync(c->ch_cursor.p, 0, nrow * 4, st));
-    HIPCHK(c, hipMemsetAsync(c->kept_cnt.p, 0, (size_t)S * 4, st));
     if (v.n_sources) {
         ProfScope p(c, "exist");
         hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
     }
-    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, st); }
+    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
     if (d.s1 > d.s0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
     if (v.n_sources) {
         ProfScope p(c, "exist");
@@ -360,21 +373,23 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     va.mmax = mmax;
     if (d.s1 > d.s0) {
         if (c->verify_mode == 0) {
-            va.skip_above = 1; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
+            // one launch: LDS blocks, global-scratch blocks for segments that outgrow the LDS image, per-segment epilogue
+            va.skip_above = 1; va.only_above = -1; va.big = 2;
+            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + 2;
+            va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            // segments that outgrow the LDS image (reverse matches are not in the estimate): same algorithm on a global scratch
-            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + 2;
-            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-            va.big = 0;
         } else {
             va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
-            ProfScope p(c, "verify"); launch_verify(va, st);
+            va.kept_cnt = nullptr; va.best_depths = nullptr;
+            { ProfScope p(c, "verify"); launch_verify(va, st); }
+            { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
         }
-        { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
     }
-    { ProfScope p(c, "scan"); launch_scan(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, st); }
-    hipLaunchKernelGGL(k_slot_header, dim3(1), dim3(1), 0, st, c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, (int)h->cand_cap,
-                       h->geom.slot_records, d.s0, d.s1, slot);
+    {
+        ProfScope p(c, "scan");
+        hipLaunchKernelGGL(k_scan_kept_slot, dim3(1), dim3(kScanThreads), 0, st, c->kept_cnt.as<int>() + d.s0, c->kept_start.as<int>() + d.s0, d.s1 - d.s0,
+                           c->row_start.as<int>(), (int)nrow, (int)h->cand_cap, h->geom.slot_records, d.s0, d.s1, slot);
+    }
     if (d.s1 > d.s0) {
         ProfScope p(c, "kept_write");
         hipLaunchKernelGGL(k_slot_write, dim3((d.s1 - d.s0 + 3) / 4), dim3(256), 0, st, va, c->kept_start.as<int>(),
@@ -440,6 +455,7 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
     if (!h) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stage1_stream);
     (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : h->ev1) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);

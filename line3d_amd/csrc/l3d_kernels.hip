@@ -16,6 +16,7 @@
 //   k_similarity     batched similarity_coll3D for the affinity fill
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
+#include "l3d_scan.hpp"
 
 namespace l3d {
 
@@ -214,26 +215,11 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
     if (i < n) atomicAdd(&rowcnt[ex[i].seg * N + ex[i].cam], 1);
 }
 
-// Exclusive scan of n ints by ONE workgroup of 1024 threads; out has n+1 entries.
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n)
+// Exclusive scan of n ints by ONE workgroup (l3d_scan.hpp); out has n+1 entries, `zero` (optional) gets n zeros.
+__global__ __launch_bounds__(kScanThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero)
 {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int b = tid * chunk, e = min(n, b + chunk);
-    int sum = 0;
-    for (int i = b; i < e; ++i) sum += in[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int v = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = tid ? s_part[tid - 1] : 0;
-    for (int i = b; i < e; ++i) { out[i] = run; run += in[i]; }
-    if (tid == 1023) out[n] = s_part[1023];
+    __shared__ int s_w[16];
+    (void)wg_scan_excl(in, out, n, zero, s_w);
 }
 
 // r-th (0-based) set bit of a 64-bit word
@@ -708,9 +694,9 @@ void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_
 {
     if (n) hipLaunchKernelGGL(k_exist_hist, dim3((n + 255) / 256), dim3(256), 0, st, ex, n, N, rowcnt);
 }
-void launch_scan(const int* in, int* out, int n, hipStream_t st)
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, in, out, n, zero);
 }
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
 {

@@ -67,7 +67,10 @@ struct VerifyArgs {
     int mmax;                       // max candidates of one segment (LDS sizing)
     int only_above;                 // k_verify (all-pairs): process only segments with more than this many candidates (-1: all)
     int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to the `big` launch (0/1)
-    int big;                        // k_verify_window: 1 = only segments with more than mmax candidates, arrays in `scratch`
+    int big;                        // k_verify_window: 0 = segments with at most mmax candidates (LDS image), 1 = only the bigger ones
+                                    // (arrays in `scratch`), 2 = both in one launch (grid 2 x segments)
+    int* kept_cnt;                  // fused per-segment epilogue of k_verify_window (k_seg_post): number of kept matches ...
+    float2* best_depths;            // ... and depths of the first best hypothesis; null = separate k_seg_post launch
     float* scratch;                 // 4 arrays of scratch_stride floats (candidate capacity + 2), global memory
     long long scratch_stride;
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
@@ -80,7 +83,7 @@ struct VerifyArgs {
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
-void launch_scan(const int* in, int* out, int n, hipStream_t st);
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st);
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);
@@ -97,9 +100,9 @@ void launch_exist_count(const Match* arena, const ChainResult* res, const int* s
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st);
-void launch_raw_stats(const int* rowcnt, int S, int N, int* out2, hipStream_t st);
-void launch_kept_alloc(const int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap, int cand_cap,
-                       ChainResult* res, hipStream_t st);
+void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
+void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
+                            int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st);
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int arena_cap, hipStream_t st);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,

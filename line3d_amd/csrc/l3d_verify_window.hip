@@ -100,26 +100,34 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     __shared__ int s_bstart[kBuckets + 1];
     __shared__ int s_cursor[kBuckets];
     __shared__ int s_wtot[4];
-    const int y = a.seg_begin + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // big == false: segments whose candidates fit the LDS image (m <= mmax); big == true: the rest, same algorithm with the
+    // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop.
+    // a.big == 2 runs both kinds in one launch: blocks [0, nseg) are the LDS blocks, [nseg, 2 nseg) the scratch blocks.
+    const int nseg = a.seg_end - a.seg_begin;
+    const bool big = a.big == 2 ? (int)blockIdx.x >= nseg : a.big != 0;
+    const int y = a.seg_begin + ((int)blockIdx.x >= nseg ? (int)blockIdx.x - nseg : (int)blockIdx.x);
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    // big == 0: segments whose candidates fit the LDS image (m <= mmax); big == 1: the rest, same algorithm with the
-    // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop
-    if (m == 0 || (a.big ? m <= a.mmax : (a.skip_above && m > a.mmax))) return;
-    if (a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap) return;     // candidate overflow: the chain is re-run
+    const bool overflow = a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap;   // candidate overflow: the chain is re-run
+    const bool mine = big ? m > a.mmax : !((a.skip_above || a.big == 2) && m > a.mmax);
+    if (m == 0 || overflow || !mine) {
+        // nothing to verify: the LDS block of the segment still owns its epilogue (cudawrapper.cu:1037-1062, :1096)
+        if (!big && (m == 0 || overflow) && a.kept_cnt && tid == 0) { a.kept_cnt[y] = 0; a.best_depths[y] = make_float2(-1.0f, -1.0f); }
+        return;
+    }
     if (a.debug == 4) return;
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
-    const int cap = a.big ? 0 : a.mmax + 2;                              // +2: the scan prefetches one entry ahead
+    const int cap = big ? 0 : a.mmax + 2;                              // +2: the scan prefetches one entry ahead
     VWLds L;
     L.sd1 = reinterpret_cast<float*>(s_raw);
     L.sd2 = L.sd1 + cap;
     L.sci = reinterpret_cast<unsigned*>(L.sd2 + cap);
     L.stgt = L.sci + cap;
     float* smax = reinterpret_cast<float*>(L.stgt + cap);                // [256][N] per-(hypothesis lane, camera) maxima
-    if (a.big) {                                                         // the segment's own slice of the scratch (+2 per array)
+    if (big) {                                                           // the segment's own slice of the scratch (+2 per array)
         float* g = a.scratch;
         const size_t stride = (size_t)a.scratch_stride;
         L.sd1 = g + start; L.sd2 = g + stride + start;
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         L.sci[pos] = (mt.y << 24) | (unsigned)i;
         L.stgt[pos] = mt.x;
     }
-    if (tid < 2 && !a.big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
+    if (tid < 2 && !big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
     __syncthreads();
     if (a.debug == 1) return;
     VW_STAMP(0);
@@ -211,6 +219,10 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     const float two_sig_d = 2.0f * (a.sigma_p * a.sigma_p);
     const float two_sig_a = 2.0f * (a.sigma_a * a.sigma_a);
     const bool gate = a.spatial_k > 0.0f;
+
+    // fused per-segment epilogue (k_seg_post): kept count and the first strict maximum in candidate order
+    int kept_l = 0, besti_l = 0x7fffffff;
+    float best_l = 0.0f;
 
     // ---- hypotheses in bucket order: the lanes of a wave have neighbouring depths, hence nearly the same window
     for (int h0 = 0; h0 < m; h0 += 256) {
@@ -277,8 +289,37 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         VW_STAMP(3);
         float conf_sum = 0.0f;
         for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[lane * a.N + c];   // ascending camera order; +0.0f is exact
-        if (hv) a.cand_conf[start + idx_h] = conf_sum;
+        if (hv) {
+            a.cand_conf[start + idx_h] = conf_sum;
+            kept_l += conf_sum > 1.0f;
+            if (conf_sum > best_l || (conf_sum == best_l && (int)idx_h < besti_l)) { best_l = conf_sum; besti_l = (int)idx_h; }
+        }
         VW_STAMP(4);
+    }
+    if (a.kept_cnt) {
+        __shared__ int s_rk[4], s_ri[4];
+        __shared__ float s_rb[4];
+        for (int o = 32; o > 0; o >>= 1) {
+            kept_l += __shfl_down(kept_l, o);
+            const float ob = __shfl_down(best_l, o);
+            const int oi = __shfl_down(besti_l, o);
+            if (ob > best_l || (ob == best_l && oi < besti_l)) { best_l = ob; besti_l = oi; }
+        }
+        if (lane == 0) { s_rk[wave] = kept_l; s_rb[wave] = best_l; s_ri[wave] = besti_l; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) {
+                kept_l += s_rk[w];
+                if (s_rb[w] > best_l || (s_rb[w] == best_l && s_ri[w] < besti_l)) { best_l = s_rb[w]; besti_l = s_ri[w]; }
+            }
+            a.kept_cnt[y] = kept_l;
+            float2 bd = make_float2(-1.0f, -1.0f);         // marker: not part of the median list
+            if (best_l > 0.5f) {                           // conf_t/2.0f
+                const float4 d = a.cand_depths[start + besti_l];
+                bd = make_float2(d.x, d.y);
+            }
+            a.best_depths[y] = bd;
+        }
     }
     if (a.stamps && lane == 0) {
         for (int k = 0; k < 5; ++k) atomicAdd(&a.stamps[k], t_acc[k]);
@@ -322,8 +363,10 @@ size_t verify_window_max_lds()
 }
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_verify_window, dim3(a.seg_end - a.seg_begin), dim3(256),
-                       a.big ? verify_window_lds_bytes_big(a.N) : verify_window_lds_bytes(a.mmax, a.N), st, a);
+    const int nseg = a.seg_end - a.seg_begin;
+    if (nseg <= 0) return;
+    hipLaunchKernelGGL(k_verify_window, dim3(a.big == 2 ? 2 * nseg : nseg), dim3(256),
+                       a.big == 1 ? verify_window_lds_bytes_big(a.N) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N)), st, a);
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {

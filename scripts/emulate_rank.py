@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Per-rank critical path of the sharded resident chain at world size W, measured on ONE GPU.
+
+Pass 1 runs W virtual ranks (W pipelines on the same GPU, the all-gather emulated with device copies) and records
+every view's gathered slots.  Pass 2 replays rank R alone: its own kernels run for real, the all-gather of view k is
+replaced by one device copy of the recorded gathered block (a lower bound for the collective), rank 0 also does the
+host bookkeeping.  ms/view of pass 2 x (views of the W-GPU job) estimates the W-GPU wall time without a W-GPU node.
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--views", type=int, default=64)
+    ap.add_argument("--segments", type=int, default=2000)
+    ap.add_argument("--neighbors", type=int, default=12)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ahead", type=int, default=12)
+    args = ap.parse_args()
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from line3d_amd.distributed import default_slot_records
+    W = args.world
+    scene = make_scene(args.views, args.segments, args.neighbors, seed=20260)
+    dev = torch.device("cuda", 0)
+    slot_records = default_slot_records(args.segments, args.neighbors, W)
+
+    def mk():
+        l = Line3D("", matchingNeighbors=args.neighbors)
+        load_scene(l, scene)
+        l.prepare()
+        return l
+
+    # pass 1: record
+    ls = [mk() for _ in range(W)]
+    geo = [l.shard_open(r, W, slot_records) for r, l in enumerate(ls)]
+    n_views, slot_bytes = geo[0]
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, l in enumerate(ls):
+            l.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for l in ls:
+            l.shard_mark(k)
+        ls[0].shard_fetch(k)
+    for r, l in enumerate(ls):
+        l.shard_close(r == 0)
+    kept = ls[0].stats()["kept"]
+    for l in ls[1:]:
+        l.close()
+    recorded = gathered.clone()
+    del send
+
+    # pass 2: replay one rank
+    l = ls[0]
+    R = args.rank
+    for rep in range(args.reps + 1):
+        n_views, slot_bytes = l.shard_open(R, W, slot_records)
+        ext = torch.cuda.ExternalStream(l.stream_ptr(), device=dev)
+        with torch.cuda.stream(ext):
+            g = torch.zeros_like(recorded)
+            s = torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev)
+            ext.synchronize()
+            t0 = time.perf_counter()
+            fetched = 0
+            for k in range(n_views):
+                l.shard_enqueue(k, s.data_ptr() + k * slot_bytes, g.data_ptr())
+                if l.shard_view_verified(k):
+                    g[k * W * slot_bytes:(k + 1) * W * slot_bytes].copy_(recorded[k * W * slot_bytes:(k + 1) * W * slot_bytes], non_blocking=True)
+                l.shard_mark(k)
+                if R == 0:
+                    while fetched <= k - args.ahead:
+                        l.shard_fetch(fetched)
+                        fetched += 1
+            t_enq = time.perf_counter() - t0
+            if R == 0:
+                while fetched < n_views:
+                    l.shard_fetch(fetched)
+                    fetched += 1
+            ext.synchronize()
+            dt = time.perf_counter() - t0
+        l.shard_close(R == 0)
+        if rep:
+            print("world %d rank %d: %d views x %d segs: %.2f ms (%.1f us/view; host enqueue loop %.2f ms), kept %d (recorded %d), slot %d KB"
+                  % (W, R, n_views, args.segments, dt * 1e3, dt / n_views * 1e6, t_enq * 1e3, int(l.stats()["kept"]), int(kept), slot_bytes // 1024))
+    l.close()
+
+
+if __name__ == "__main__":
+    main()
