@@ -104,22 +104,52 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sharded_mode = {"name": "resident chain, source segments sharded, RCCL all-gather of per-view kept slots on the GPU stream"}
+    # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
+    # nobody is left waiting in a collective)
+    MODES = ["native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream",
+             "resident chain, source segments sharded, all-gather of per-view kept slots through torch.distributed on the library's stream",
+             "per-view seam call, source segments sharded, all-gather of kept lists through the host"]
+    sharded_mode = {"i": 0, "link": None}
+    if dist is not None:
+        try:
+            sharded_mode["link"] = l3dist.RcclLink(rank, world, dist, local_rank)
+        except Exception as e:      # noqa: BLE001
+            print("rank %d: RCCL link failed (%r)" % (rank, e), file=sys.stderr)
+        import torch
+        flag = torch.tensor([0 if sharded_mode["link"] is not None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            sharded_mode["i"] = 1
+
+    def step_once(mode):
+        if mode == 0:       # rank 0 trails behind with the host bookkeeping; the other ranks only feed the collectives
+            l3dist.match_views_chain_native(l3d, rank, world, sharded_mode["link"], commit=(rank == 0),
+                                            n_segments=args.segments, n_neighbors=args.neighbors)
+        elif mode == 1:
+            l3dist.match_views_chain_sharded(l3d, rank, world, dist, commit=(rank == 0),
+                                             n_segments=args.segments, n_neighbors=args.neighbors)
+        else:
+            l3dist.match_views_sharded(l3d, rank, world, dist)
 
     def step():
-        if dist is not None:
-            if sharded_mode["name"].startswith("resident"):
-                try:
-                    # rank 0 trails behind with the host bookkeeping; the other ranks only feed the collectives
-                    l3dist.match_views_chain_sharded(l3d, rank, world, dist, commit=(rank == 0),
-                                                     n_segments=args.segments, n_neighbors=args.neighbors)
-                    return
-                except Exception as e:          # keep the bench line alive: per-view path with host all-gathers
-                    print("rank %d: sharded chain failed (%r), falling back to the per-view path" % (rank, e), file=sys.stderr)
-                    sharded_mode["name"] = "per-view seam call, source segments sharded, all-gather of kept lists through the host"
-            l3dist.match_views_sharded(l3d, rank, world, dist)
-        else:
+        if dist is None:
             l3d.match_views()
+            return
+        import torch
+        while True:
+            failed = 0
+            try:
+                step_once(sharded_mode["i"])
+            except Exception as e:      # noqa: BLE001
+                failed = 1
+                print("rank %d: mode %d failed (%r)" % (rank, sharded_mode["i"], e), file=sys.stderr)
+            flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if not int(flag.item()):
+                return
+            if sharded_mode["i"] == len(MODES) - 1:
+                raise RuntimeError("every multi-GPU mode failed")
+            sharded_mode["i"] += 1
 
     for _ in range(args.warmup):
         step()
@@ -200,7 +230,7 @@ def main():
                    config=dict(workload="BASELINE configs[%d]: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
                                         % (1 if n_gpus == 1 else 2, V, args.segments, args.neighbors),
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
-                               parallelism=("x%d: " % n_gpus + sharded_mode["name"]) if dist is not None else "single GPU"),
+                               parallelism=("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU"),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
                    kept_per_step=st["kept"], setup_s=t_setup,
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))

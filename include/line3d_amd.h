@@ -169,6 +169,21 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* chain, int k, void* send_slot, cons
 int l3d_shard_chain_mark(l3d_shard_chain* chain, int k);
 int l3d_shard_chain_fetch(l3d_shard_chain* chain, int k, l3d_chain_callback cb, void* user);
 int l3d_shard_chain_close(l3d_shard_chain* chain);
+/* The same protocol as ONE native call (send/gathered buffers owned by the context): the calling thread enqueues view
+ * after view -- kernels, then `exchange` on the context's stream, then the completion event -- and a second host thread
+ * trails behind with fetch -> cb (cb == NULL: this rank does no host bookkeeping).  `exchange` must enqueue, on `stream`,
+ * the all-gather of the ranks' slots of one view: send_slot (slot_bytes) -> recv_block (world*slot_bytes, rank order);
+ * non-zero return = failure.  Adapters: l3d_exchange_rccl (user = l3d_rccl_link: an RCCL communicator of the `world`
+ * ranks and the address of ncclAllGather, both taken from the RCCL the process has already loaded -- this library does
+ * not link against RCCL), l3d_exchange_local (world == 1), l3d_exchange_replay (user = device address of the gathered
+ * blocks of a recorded run: measures one rank of a world-W job on a single GPU, scripts/emulate_rank.py). */
+typedef int (*l3d_exchange_fn)(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
+typedef struct l3d_rccl_link { void* comm; void* all_gather; } l3d_rccl_link;
+int l3d_shard_chain_run(l3d_shard_chain* chain, l3d_exchange_fn exchange, void* exchange_user, l3d_chain_callback cb, void* cb_user);
+int l3d_exchange_rccl(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
+int l3d_exchange_local(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
+int l3d_exchange_replay(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
+const void* l3d_shard_chain_gathered(l3d_shard_chain* chain);   /* device address of the gathered blocks after l3d_shard_chain_run */
 
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
@@ -253,6 +268,10 @@ int l3d_line3d_shard_enqueue(l3d_line3d* h, int k, void* send_slot, const void* 
 int l3d_line3d_shard_mark(l3d_line3d* h, int k);
 int l3d_line3d_shard_fetch(l3d_line3d* h, int k);
 int l3d_line3d_shard_close(l3d_line3d* h, int committed);
+/* open -> run -> close in one call (l3d_shard_chain_run); commit != 0: this rank does the host bookkeeping.
+ * gathered_out (optional) receives the device address of the gathered blocks (valid until the next chain) */
+int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
+                         const void** gathered_out, size_t* slot_bytes_out);
 /* performClustering (clustering.h:125, clustering.cc:6-47; stays on the host): labels[k] = CLUniverse::find(k) */
 int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */

@@ -238,6 +238,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     if (n_views < 0 || (n_views > 0 && (!views || !cb))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
     if (n_views == 0) return L3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    const double t_setup0 = now_s();
     hipStream_t st = c->stream;         // phase 2 (the chain proper)
     hipStream_t s1 = c->stage1_stream;  // stage 1 runs ahead here, concurrently with the latency-bound kernels of phase 2
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
@@ -477,7 +478,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     };
 
     // ---- phase 2 + trailing result loop
-    double kept_total = 0;
+    const double t_loop0 = now_s();
+    double kept_total = 0, t_cb = 0, t_wait = 0, t_d2h = 0;
     for (int k = 0; k < n_views && rc_final == L3D_OK; ++k) {
         while (k_enq < n_views && k_enq <= k + kAhead) { int rc = enqueue_view(k_enq); if (rc) { rc_final = rc; break; } ++k_enq; }
         if (rc_final) break;
@@ -487,7 +489,9 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             if (cb(user, k, 0, nullptr, 0, nullptr, 0, 0)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
             continue;
         }
+        const double tw0 = now_s();
         HIPCHK(c, hipEventSynchronize(ev[(size_t)k]));
+        t_wait += now_s() - tw0;
         const ChainResult r = hres[k];
         if (r.overflow) {
             // not enough room for this view's candidates / kept matches: everything before it is valid and stays
@@ -518,6 +522,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             continue;
         }
         // kept slice and best depths: bulk copies on the copy stream, concurrent with the kernels of later views
+        const double td0 = now_s();
         HIPCHK(c, c->ch_pin_kept.reserve((size_t)r.n_kept * sizeof(Match) + 16));
         HIPCHK(c, c->ch_pin_best.reserve((size_t)v.S_src * 8 + 16));
         if (r.n_kept)
@@ -531,8 +536,14 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             for (int s = 0; s < v.S_src; ++s)
                 if (best[2 * s] != -1.0f) { best[2 * nb] = best[2 * s]; best[2 * nb + 1] = best[2 * s + 1]; ++nb; }   // in place: nb <= s
         kept_total += r.n_kept;
+        const double tc0 = now_s();
+        t_d2h += tc0 - td0;
         if (cb(user, k, 1, c->ch_pin_kept.as<l3d_match>(), r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
+        t_cb += now_s() - tc0;
     }
+    if (getenv("L3D_TIMING"))
+        fprintf(stderr, "[l3d match_chain] setup %.2f ms | loop %.2f ms: waiting for the GPU %.2f, d2h %.2f, callback %.2f\n",
+                (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_d2h * 1e3, t_cb * 1e3);
     HIPCHK(c, hipStreamSynchronize(s1));
     HIPCHK(c, hipStreamSynchronize(st));
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);

@@ -13,6 +13,10 @@
 //
 // slot layout: [SlotHeader 32 B][best depth pairs float2 x seg_cap][kept records l3d_match x slot_records]
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "l3d_ctx.hpp"
@@ -117,6 +121,44 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     }
 }
 
+// Host hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment)
+// order, the raw depth-pair arrays and a summary are written straight into host-mapped pinned memory (16-byte stores
+// over PCIe) -- one launch and one wait instead of a header round trip plus one copy per rank.
+struct PackHeader { long long R; int n_kept, overflow, pad[4]; };
+static_assert(sizeof(PackHeader) == 32, "pack header");
+__global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restrict__ block, SlotGeom g, unsigned char* __restrict__ out)
+{
+    const int r = blockIdx.y;
+    int base = 0, bad = 0;
+    long long R = 0;
+    for (int q = 0; q < g.world; ++q) {
+        const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(block + (size_t)q * g.slot_bytes);
+        const bool ok = !hq->overflow && hq->n_kept >= 0 && hq->n_kept <= g.slot_records;
+        bad |= !ok;
+        if (q < r && ok) base += hq->n_kept;
+        R += hq->R;
+    }
+    const unsigned char* slot = block + (size_t)r * g.slot_bytes;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    const size_t best_bytes = (size_t)g.seg_cap * 8;
+    unsigned char* o_best = out + sizeof(PackHeader) + (size_t)r * best_bytes;
+    unsigned char* o_rec = out + sizeof(PackHeader) + (size_t)g.world * best_bytes;
+    const int n = bad ? 0 : hd->n_kept;
+    if (r == g.world - 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+        PackHeader ph;
+        ph.R = R; ph.n_kept = bad ? 0 : base + n; ph.overflow = bad; ph.pad[0] = ph.pad[1] = ph.pad[2] = ph.pad[3] = 0;
+        *reinterpret_cast<PackHeader*>(out) = ph;
+    }
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    // depth pairs of this rank's segment range (fixed stride seg_cap; the host skips the -1 markers)
+    const int nb = (hd->s1 - hd->s0);
+    for (int i = tid; i < nb; i += nt)
+        reinterpret_cast<float2*>(o_best)[i] = reinterpret_cast<const float2*>(slot + g.best_off)[i];
+    const float4* src = reinterpret_cast<const float4*>(slot + g.rec_off);
+    float4* dst = reinterpret_cast<float4*>(o_rec + (size_t)base * sizeof(Match));
+    for (int i = tid; i < 2 * n; i += nt) dst[i] = src[i];
+}
+
 }  // namespace l3d
 
 namespace {
@@ -151,6 +193,14 @@ struct l3d_shard_chain {
     int maxS = 0, maxN = 0;
     const unsigned char* gathered = nullptr;
     double pairs = 0, raw_sum = 0, kept_total = 0;
+    std::vector<float> best_scratch;
+    unsigned char* stage_host = nullptr;     // two hand-over buffers in host-mapped pinned memory (k_pack_view)
+    unsigned char* stage_dev = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t ev3[2] = { nullptr, nullptr };
+    int packed = 0;                          // views [0, packed) have their hand-over enqueued (fetch thread only)
+    std::atomic<int> marked{0};              // views [0, marked) carry their completion event
+    double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
 };
 
 extern "C" {
@@ -273,10 +323,15 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
     OCHK(c->cand_conf.reserve(h->cand_cap * 4));
     OCHK(c->vw_scratch.reserve((h->cand_cap + 2) * 16));
-    OCHK(c->ch_pin_kept.reserve((size_t)world * h->geom.slot_bytes + 64));
+    h->stage_bytes = salign(sizeof(PackHeader) + (size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
+    OCHK(c->ch_pin_kept.reserve(2 * h->stage_bytes + 64));
+    h->stage_host = c->ch_pin_kept.as<unsigned char>();
+    OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stage_dev), h->stage_host, 0));
 #undef OCHK
     h->ev1.assign((size_t)n_views, nullptr);
     h->ev2.assign((size_t)n_views, nullptr);
+    for (int k = 0; k < n_views; ++k) h->ev2[(size_t)k] = get_event(c);
+    h->ev3[0] = get_event(c); h->ev3[1] = get_event(c);
     c->stats[0] = h->pairs;
     *out = h;
     return L3D_OK;
@@ -404,51 +459,154 @@ int l3d_shard_chain_mark(l3d_shard_chain* h, int k)
 {
     if (!h || k < 0 || k >= h->n_views) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
-    if (!h->ev2[(size_t)k]) h->ev2[(size_t)k] = get_event(c);
     HIPCHK(c, hipEventRecord(h->ev2[(size_t)k], c->stream));
+    h->marked.store(k + 1, std::memory_order_release);
     return L3D_OK;
 }
 
-// Wait for view k (host side only), copy its gathered slots, concatenate the ranks' kept lists and depth pairs in rank
-// (= segment) order and hand them to the callback.
+// Enqueue (copy stream, after view k's completion event) the hand-over of view k into staging buffer k % 2.
+static int shard_pack(l3d_shard_chain* h, int k)
+{
+    l3d_ctx* c = h->c;
+    if (!h->vd[(size_t)k].verified) return L3D_OK;
+    if (!h->ev2[(size_t)k]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_fetch: view not marked");
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, h->ev2[(size_t)k], 0));
+    const size_t block = (size_t)h->world * h->geom.slot_bytes;
+    hipLaunchKernelGGL(k_pack_view, dim3(8, h->world), dim3(256), 0, c->copy_stream, h->gathered + (size_t)k * block, h->geom,
+                       h->stage_dev + (size_t)(k & 1) * h->stage_bytes);
+    HIPCHK(c, hipEventRecord(h->ev3[k & 1], c->copy_stream));     // (events are created in open: the pool is not thread safe)
+    h->packed = k + 1;
+    return L3D_OK;
+}
+
+// Wait for view k (host side only) and hand the ranks' kept lists, concatenated in rank (= segment) order, and the depth
+// pairs to the callback.  Views must be fetched in ascending order (the hand-over of view k+1 is prefetched when it is
+// already marked).
 int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void* user)
 {
     if (!h || k < 0 || k >= h->n_views || !cb) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
-    const l3d_chain_view& v = h->views[k];
     if (!h->vd[(size_t)k].verified) return cb(user, k, 0, nullptr, 0, nullptr, 0, 0) ? fail(c, L3D_ERR_INVALID, "callback failed") : L3D_OK;
-    if (!h->ev2[(size_t)k]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_fetch: view not marked");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(h->ev2[(size_t)k]));
-    const size_t block = (size_t)h->world * h->geom.slot_bytes;
-    unsigned char* host = c->ch_pin_kept.as<unsigned char>();
-    HIPCHK(c, hipMemcpyAsync(host, h->gathered + (size_t)k * block, block, hipMemcpyDeviceToHost, c->copy_stream));
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    std::vector<l3d_match> kept;
-    std::vector<float> best;
-    long long R = 0;
-    for (int r = 0; r < h->world; ++r) {
-        const unsigned char* slot = host + (size_t)r * h->geom.slot_bytes;
-        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
-        if (hd->overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
-        R += hd->R;
-    }
-    for (int r = 0; r < h->world; ++r) {
-        const unsigned char* slot = host + (size_t)r * h->geom.slot_bytes;
-        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
-        const l3d_match* recs = reinterpret_cast<const l3d_match*>(slot + h->geom.rec_off);
-        kept.insert(kept.end(), recs, recs + hd->n_kept);
-        const float* b = reinterpret_cast<const float*>(slot + h->geom.best_off);
-        if (R > 0)
-            for (int s = 0; s < hd->s1 - hd->s0; ++s)
+    const double tf0 = now_s();
+    if (h->packed <= k) { int rc = shard_pack(h, k); if (rc) return rc; }
+    HIPCHK(c, hipEventSynchronize(h->ev3[k & 1]));
+    const double tf1 = now_s();
+    const unsigned char* host = h->stage_host + (size_t)(k & 1) * h->stage_bytes;
+    const PackHeader* ph = reinterpret_cast<const PackHeader*>(host);
+    if (ph->overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
+    const size_t best_bytes = (size_t)h->geom.seg_cap * 8;
+    const l3d_match* kept = reinterpret_cast<const l3d_match*>(host + sizeof(PackHeader) + (size_t)h->world * best_bytes);
+    std::vector<float>& best = h->best_scratch;
+    best.clear();
+    if (ph->R > 0)
+        for (int r = 0; r < h->world; ++r) {
+            const int s0 = (int)(((long long)h->views[k].S_src * r) / h->world), s1 = (int)(((long long)h->views[k].S_src * (r + 1)) / h->world);
+            const float* b = reinterpret_cast<const float*>(host + sizeof(PackHeader) + (size_t)r * best_bytes);
+            for (int s = 0; s < s1 - s0; ++s)
                 if (b[2 * s] != -1.0f) { best.push_back(b[2 * s]); best.push_back(b[2 * s + 1]); }
+        }
+    // the next view's hand-over travels while this view's bookkeeping runs (only if the enqueue thread has marked it)
+    if (k + 1 < h->n_views && h->packed <= k + 1 && h->vd[(size_t)(k + 1)].verified && h->marked.load(std::memory_order_acquire) > k + 1) {
+        int rc = shard_pack(h, k + 1); if (rc) return rc;
     }
-    (void)v;
-    h->kept_total += (double)kept.size();
-    if (cb(user, k, 1, kept.data(), (int)kept.size(), best.data(), (int)(best.size() / 2), (int)std::min<long long>(R, 0x7fffffff)))
+    const double tf2 = now_s();
+    h->kept_total += (double)ph->n_kept;
+    if (cb(user, k, 1, kept, ph->n_kept, best.data(), (int)(best.size() / 2), (int)std::min<long long>(ph->R, 0x7fffffff)))
         return fail(c, L3D_ERR_INVALID, "callback failed");
+    h->t_wait += tf1 - tf0; h->t_copy += tf2 - tf1; h->t_cb += now_s() - tf2;
     return L3D_OK;
 }
+
+// ---- the whole sharded chain as ONE native call -------------------------------------------------------------------
+// The calling thread only enqueues: this rank's kernels of view k, then the exchange of the ranks' slots on the same
+// stream (RCCL all-gather over xGMI through l3d_exchange_rccl), then the "view complete" event.  A second host thread
+// trails behind on those events and does the host bookkeeping (fetch -> callback) of the ranks that commit.  No
+// interpreter, no host synchronisation on the enqueue path: per view the stream sees ~9 kernels + one collective.
+int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exchange_user, l3d_chain_callback cb, void* cb_user)
+{
+    if (!h || !exchange) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t slot = h->geom.slot_bytes, block = slot * (size_t)h->world;
+    HIPCHK(c, c->ch_send.reserve((size_t)h->n_views * slot + 256));
+    HIPCHK(c, c->ch_gathered.reserve((size_t)h->n_views * block + 256));
+    unsigned char* send = c->ch_send.as<unsigned char>();
+    unsigned char* gathered = c->ch_gathered.as<unsigned char>();
+    // every verified view's block is fully written by its exchange before anything reads it; only the blocks of views
+    // that are never verified (nothing to match) must read as "no kept records"
+    for (int k = 0; k < h->n_views; ++k)
+        if (!h->vd[(size_t)k].verified) HIPCHK(c, hipMemsetAsync(gathered + (size_t)k * block, 0, block, c->stream));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int marked = 0;                         // views [0, marked) carry their "complete" event
+    bool stop = false;
+    int fetch_rc = L3D_OK;
+    std::string fetch_err;
+    std::thread fetcher;
+    if (cb) {
+        fetcher = std::thread([&]() {
+            (void)hipSetDevice(c->device);
+            for (int k = 0; k < h->n_views; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&]() { return marked > k || stop; });
+                    if (marked <= k) return;
+                }
+                const int rc = l3d_shard_chain_fetch(h, k, cb, cb_user);
+                if (rc) { std::lock_guard<std::mutex> lk(mu); fetch_rc = rc; fetch_err = c->err; return; }
+            }
+        });
+    }
+    int rc = L3D_OK;
+    const double t_run0 = now_s();
+    for (int k = 0; k < h->n_views && rc == L3D_OK; ++k) {
+        const double te0 = now_s();
+        rc = l3d_shard_chain_enqueue(h, k, send + (size_t)k * slot, gathered);
+        const double te1 = now_s();
+        if (rc == L3D_OK && h->vd[(size_t)k].verified && exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream))
+            rc = fail(c, L3D_ERR_HIP, "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed");
+        h->t_enq += te1 - te0; h->t_ex += now_s() - te1;
+        if (rc == L3D_OK) rc = l3d_shard_chain_mark(h, k);
+        if (rc == L3D_OK) { { std::lock_guard<std::mutex> lk(mu); marked = k + 1; } cv.notify_one(); }
+        { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
+    }
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_one();
+    const double t_run1 = now_s();
+    (void)hipStreamSynchronize(c->stream);
+    const double t_run2 = now_s();
+    if (fetcher.joinable()) fetcher.join();
+    if (getenv("L3D_TIMING"))
+        fprintf(stderr, "[l3d shard chain run] enqueue loop %.2f ms, stream drained after %.2f ms, bookkeeping thread done after %.2f ms\n",
+                (t_run1 - t_run0) * 1e3, (t_run2 - t_run0) * 1e3, (now_s() - t_run0) * 1e3);
+    if (rc == L3D_OK && fetch_rc) rc = fail(c, fetch_rc, fetch_err);
+    return rc;
+}
+
+// exchange adapters.  RCCL: user = l3d_rccl_link {communicator, address of ncclAllGather}; the library does not link
+// against RCCL, the caller hands over what its process already has loaded (line3d_amd/distributed.py).
+int l3d_exchange_rccl(void* user, int, const void* send_slot, void* recv_block, size_t slot_bytes, int, void* stream)
+{
+    const l3d_rccl_link* L = static_cast<const l3d_rccl_link*>(user);
+    if (!L || !L->comm || !L->all_gather) return 1;
+    typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, void*);       // ncclAllGather(send, recv, count, dtype, comm, stream)
+    return reinterpret_cast<all_gather_t>(L->all_gather)(send_slot, recv_block, slot_bytes, 1 /* ncclUint8 */, L->comm, stream);
+}
+// a single rank: the gathered block is the slot itself
+int l3d_exchange_local(void*, int, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream)
+{
+    if (world != 1) return 1;
+    return hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+}
+// replay of a recorded run (user = device address of its gathered blocks): one rank of a world-W job measured on one GPU
+int l3d_exchange_replay(void* user, int view, const void*, void* recv_block, size_t slot_bytes, int world, void* stream)
+{
+    const size_t block = slot_bytes * (size_t)world;
+    return hipMemcpyAsync(recv_block, static_cast<const unsigned char*>(user) + (size_t)view * block, block, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+}
+const void* l3d_shard_chain_gathered(l3d_shard_chain* h) { return h ? h->c->ch_gathered.p : nullptr; }
 
 int l3d_shard_chain_close(l3d_shard_chain* h)
 {
@@ -459,7 +617,11 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
     (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : h->ev1) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);
+    for (hipEvent_t e : h->ev3) if (e) c->event_pool.push_back(e);
     c->stats[1] = h->raw_sum; c->stats[3] = h->kept_total;
+    if (getenv("L3D_TIMING"))
+        fprintf(stderr, "[l3d shard chain rank %d/%d] enqueue %.2f  exchange-call %.2f | fetch: wait %.2f  d2h %.2f  callback %.2f ms\n",
+                h->rank, h->world, h->t_enq * 1e3, h->t_ex * 1e3, h->t_wait * 1e3, h->t_copy * 1e3, h->t_cb * 1e3);
     delete h;
     return L3D_OK;
 }

@@ -93,13 +93,17 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const VWLds& L, co
         atomicMax(reinterpret_cast<int*>(&smax_wave[origin * a.N + cam]), __float_as_int(conf));
 }
 
-__global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
+// NT threads per workgroup: 256 when the grid fills the chip, 1024 when only a few segments are verified per launch
+// (one rank's slice of a view in the sharded chain): the segment's hypotheses then run 16 waves wide instead of 4.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
 {
+    constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ int s_dmax, s_base;
     __shared__ int s_bstart[kBuckets + 1];
     __shared__ int s_cursor[kBuckets];
-    __shared__ int s_wtot[4];
+    __shared__ int s_wtot[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // big == false: segments whose candidates fit the LDS image (m <= mmax); big == true: the rest, same algorithm with the
     // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop.
@@ -126,39 +130,39 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     L.sd2 = L.sd1 + cap;
     L.sci = reinterpret_cast<unsigned*>(L.sd2 + cap);
     L.stgt = L.sci + cap;
-    float* smax = reinterpret_cast<float*>(L.stgt + cap);                // [256][N] per-(hypothesis lane, camera) maxima
+    float* smax = reinterpret_cast<float*>(L.stgt + cap);                // [NT][N] per-(hypothesis lane, camera) maxima
     if (big) {                                                           // the segment's own slice of the scratch (+2 per array)
         float* g = a.scratch;
         const size_t stride = (size_t)a.scratch_stride;
         L.sd1 = g + start; L.sd2 = g + stride + start;
         L.sci = reinterpret_cast<unsigned*>(g + 2 * stride) + start; L.stgt = reinterpret_cast<unsigned*>(g + 3 * stride) + start;
     }
-    unsigned* qall = reinterpret_cast<unsigned*>(smax + 256 * a.N);
+    unsigned* qall = reinterpret_cast<unsigned*>(smax + NT * a.N);
     unsigned* q = qall + wave * kVQ * 2;
     float* smax_wave = smax + wave * 64 * a.N;
 
     // ---- one coalesced pass over the segment's candidates (kept in registers), counting sort on the depth bucket
-    constexpr int kMaxPerThread = 8;                                     // m <= 2048 in registers, more is re-read
+    constexpr int kMaxPerThread = 2048 / NT;                             // m <= 2048 in registers, more is re-read
     if (tid == 0) { s_dmax = 0; s_base = 0x7fffffff; }
-    for (int b = tid; b < kBuckets; b += 256) s_cursor[b] = 0;
+    for (int b = tid; b < kBuckets; b += NT) s_cursor[b] = 0;
     float4 rd[kMaxPerThread];
     uint2 rm[kMaxPerThread];
     float dm = 0.0f;
     int rmin = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < kMaxPerThread; ++k) {
-        const int i = tid + k * 256;
+        const int i = tid + k * NT;
         if (i < m) { rd[k] = a.cand_depths[start + i]; rm[k] = a.cand_meta[start + i]; }
     }
 #pragma unroll
     for (int k = 0; k < kMaxPerThread; ++k) {
-        const int i = tid + k * 256;
+        const int i = tid + k * NT;
         if (i < m) {
             dm = __builtin_fmaxf(dm, __builtin_fmaxf(__builtin_fabsf(rd[k].x), __builtin_fabsf(rd[k].y)));
             rmin = min(rmin, (int)(__float_as_uint(rd[k].x) >> kBucketShift));
         }
     }
-    for (int i = tid + kMaxPerThread * 256; i < m; i += 256) {
+    for (int i = tid + kMaxPerThread * NT; i < m; i += NT) {
         const float4 d = a.cand_depths[start + i];
         dm = __builtin_fmaxf(dm, __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)));
         rmin = min(rmin, (int)(__float_as_uint(d.x) >> kBucketShift));
@@ -169,13 +173,14 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     __syncthreads();
     const int base = s_base;
 #pragma unroll
-    for (int k = 0; k < kMaxPerThread; ++k) if (tid + k * 256 < m) atomicAdd(&s_cursor[bucket_of(rd[k].x, base)], 1);
-    for (int i = tid + kMaxPerThread * 256; i < m; i += 256) atomicAdd(&s_cursor[bucket_of(a.cand_depths[start + i].x, base)], 1);
+    for (int k = 0; k < kMaxPerThread; ++k) if (tid + k * NT < m) atomicAdd(&s_cursor[bucket_of(rd[k].x, base)], 1);
+    for (int i = tid + kMaxPerThread * NT; i < m; i += NT) atomicAdd(&s_cursor[bucket_of(a.cand_depths[start + i].x, base)], 1);
     __syncthreads();
-    {   // exclusive scan of the bucket counts: 4 per thread + wave scan + 4 wave totals
-        int c[4], tot = 0;
+    {   // exclusive scan of the bucket counts: kBuckets/NT per thread + wave scan + wave totals
+        constexpr int BPT = kBuckets / NT;
+        int c[BPT], tot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = s_cursor[4 * tid + k]; tot += c[k]; }
+        for (int k = 0; k < BPT; ++k) { c[k] = s_cursor[BPT * tid + k]; tot += c[k]; }
         int incl = tot;
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
         if (lane == 63) s_wtot[wave] = incl;
@@ -183,13 +188,13 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         int run = incl - tot;
         for (int w = 0; w < wave; ++w) run += s_wtot[w];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s_bstart[4 * tid + k] = run; s_cursor[4 * tid + k] = run; run += c[k]; }
-        if (tid == 255) s_bstart[kBuckets] = run;
+        for (int k = 0; k < BPT; ++k) { s_bstart[BPT * tid + k] = run; s_cursor[BPT * tid + k] = run; run += c[k]; }
+        if (tid == NT - 1) s_bstart[kBuckets] = run;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kMaxPerThread; ++k) {
-        const int i = tid + k * 256;
+        const int i = tid + k * NT;
         if (i < m) {
             const int pos = atomicAdd(&s_cursor[bucket_of(rd[k].x, base)], 1);
             L.sd1[pos] = rd[k].x; L.sd2[pos] = rd[k].y;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
             L.stgt[pos] = rm[k].x;
         }
     }
-    for (int i = tid + kMaxPerThread * 256; i < m; i += 256) {
+    for (int i = tid + kMaxPerThread * NT; i < m; i += NT) {
         const float4 d = a.cand_depths[start + i];
         const uint2 mt = a.cand_meta[start + i];
         const int pos = atomicAdd(&s_cursor[bucket_of(d.x, base)], 1);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
     float best_l = 0.0f;
 
     // ---- hypotheses in bucket order: the lanes of a wave have neighbouring depths, hence nearly the same window
-    for (int h0 = 0; h0 < m; h0 += 256) {
+    for (int h0 = 0; h0 < m; h0 += NT) {
         const int h = h0 + tid;
         const bool hv = h < m;
         f3 X1 = mk3(0, 0, 0), X2 = mk3(0, 0, 0), v1 = mk3(0, 0, 0);
@@ -297,8 +302,8 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         VW_STAMP(4);
     }
     if (a.kept_cnt) {
-        __shared__ int s_rk[4], s_ri[4];
-        __shared__ float s_rb[4];
+        __shared__ int s_rk[NW], s_ri[NW];
+        __shared__ float s_rb[NW];
         for (int o = 32; o > 0; o >>= 1) {
             kept_l += __shfl_down(kept_l, o);
             const float ob = __shfl_down(best_l, o);
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void k_verify_window(VerifyArgs a)
         if (lane == 0) { s_rk[wave] = kept_l; s_rb[wave] = best_l; s_ri[wave] = besti_l; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 kept_l += s_rk[w];
                 if (s_rb[w] > best_l || (s_rb[w] == best_l && s_ri[w] < besti_l)) { best_l = s_rb[w]; besti_l = s_ri[w]; }
             }
@@ -338,8 +343,9 @@ __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_beg
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
-size_t verify_window_lds_bytes(int mmax, int N) { return (size_t)(mmax + 2) * 16 + (size_t)256 * N * 4 + 4 * kVQ * 8 + 16; }
-size_t verify_window_lds_bytes_big(int N) { return (size_t)256 * N * 4 + 4 * kVQ * 8 + 64; }
+size_t verify_window_lds_bytes_nt(int mmax, int N, int nt) { return (size_t)(mmax + 2) * 16 + (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 16; }
+size_t verify_window_lds_bytes(int mmax, int N) { return verify_window_lds_bytes_nt(mmax, N, 256); }
+size_t verify_window_lds_bytes_big(int N, int nt) { return (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 64; }
 // Largest dynamic LDS a k_verify_window launch may ask for on this device/runtime (queried once): up to 160 KB per
 // workgroup on gfx950 once the kernel has opted in; runtimes that refuse the opt-in stay at the 48/64 KB default.
 static size_t g_lds_budget_override = 0;
@@ -354,7 +360,8 @@ size_t verify_window_max_lds()
     if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || per_block <= 0) per_block = 64 * 1024;
     size_t want = std::min<size_t>((size_t)per_block, 160 * 1024) - 8 * 1024 - 256;   // static LDS of the kernel (~8.3 KB) comes on top
     if (want > 40 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess)) {
         (void)hipGetLastError();
         want = 40 * 1024;
     }
@@ -365,8 +372,16 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
-    hipLaunchKernelGGL(k_verify_window, dim3(a.big == 2 ? 2 * nseg : nseg), dim3(256),
-                       a.big == 1 ? verify_window_lds_bytes_big(a.N) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N)), st, a);
+    const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
+    // few segments (less than ~1.5 workgroups per CU): 16 waves per segment, if the wider per-lane maxima still fit
+    const bool wide = nseg <= 384 && verify_window_lds_bytes_nt(a.mmax, a.N, 1024) <= verify_window_max_lds();
+    if (wide) {
+        const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 1024) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 1024), verify_window_lds_bytes_big(a.N, 1024));
+        hipLaunchKernelGGL(k_verify_window<1024>, grid, dim3(1024), lds, st, a);
+    } else {
+        const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 256) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
+        hipLaunchKernelGGL(k_verify_window<256>, grid, dim3(256), lds, st, a);
+    }
 }
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st)
 {

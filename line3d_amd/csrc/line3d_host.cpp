@@ -834,7 +834,8 @@ bool plan_chain(L* h, ChainPlan& P)
 void start_finalizer(L* h, ChainPlan& P)
 {
     const size_t n = P.n, nvl = h->vlist.size();
-    h->saved.assign(n, {});
+    h->saved.resize(n);                                 // (capacity of the per-view lists survives from an earlier pass)
+    for (auto& lst : h->saved) lst.clear();
     P.fin.reset(new ChainFinalizer(nvl));
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
@@ -890,13 +891,18 @@ int match_views(L* h)
     if (h->force_sync) return match_views_sync(h);
     const double t0 = now_s();
     match_begin(h);
+    const double ta = now_s();
     ChainPlan P;
     if (!plan_chain(h, P)) return match_views_sync(h);
+    const double tb = now_s();
     start_finalizer(h, P);
     const double t1 = now_s();
     int rc = l3d_match_chain(h->ctx, P.cv.data(), (int)P.n, chain_callback, &P.user);
     h->t_gpu_call += now_s() - t1 - h->t_commit;
+    const double t2 = now_s();
     finish_chain_host(h, P, rc == L3D_OK);
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d match_views] begin %.2f  schedule %.2f  finaliser start %.2f  chain %.2f  finish %.2f ms\n",
+                                      (ta - t0) * 1e3, (tb - ta) * 1e3, (t1 - tb) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
     double st[4];
     l3d_last_stats(h->ctx, st);
@@ -1439,6 +1445,26 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed)
     delete P;
     h->shard_plan_ = nullptr;
     return rc;
+}
+int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
+                         const void** gathered_out, size_t* slot_bytes_out)
+{
+    int n_views = 0;
+    size_t slot_bytes = 0;
+    const double t0 = now_s();
+    int rc = l3d_line3d_shard_open(h, rank, world, slot_records, &n_views, &slot_bytes);
+    if (rc) return rc;
+    const double t1 = now_s();
+    ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
+    rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, commit ? chain_callback : nullptr, commit ? &P->user : nullptr);
+    if (rc) h->fail(rc, std::string("shard_chain_run: ") + l3d_last_error(h->ctx));
+    if (gathered_out) *gathered_out = l3d_shard_chain_gathered(P->shard);
+    if (slot_bytes_out) *slot_bytes_out = slot_bytes;
+    const double t2 = now_s();
+    const int rc2 = l3d_line3d_shard_close(h, commit != 0 && rc == L3D_OK);
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
+                                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
+    return rc ? rc : rc2;
 }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 

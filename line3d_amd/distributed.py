@@ -135,3 +135,68 @@ def match_views_chain_sharded(l3d, rank: int, world: int, dist, commit: bool = T
     if failure is not None:
         raise failure
     return n_views
+
+
+# ---- the sharded chain as one native call, RCCL called directly -------------------------------------------------------
+
+class RcclLink:
+    """An RCCL communicator of the job's ranks for the library's own stream, created on the RCCL build the process
+    already has loaded (PyTorch-ROCm's librccl.so): the unique id travels through torch.distributed, the data path
+    (`ncclAllGather` per view, enqueued by libline3d_amd on its stream) never touches the interpreter."""
+
+    def __init__(self, rank: int, world: int, dist, device_index: int):
+        import ctypes as C
+        import os
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = C.CDLL(path)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        uid = UniqueId()
+        ok = 1
+        if rank == 0:
+            ok = 0 if self.lib.ncclGetUniqueId(C.byref(uid)) else 1
+        if dist is not None and world > 1:
+            # [ok flag | 128-byte id] from rank 0: a failure there reaches every rank instead of leaving them in the broadcast
+            t = torch.zeros(129, dtype=torch.uint8)
+            if rank == 0:
+                t[0] = ok
+                t[1:] = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8)
+            if dist.get_backend() == "nccl":
+                t = t.to(torch.device("cuda", device_index))
+            dist.broadcast(t, 0)
+            t = t.cpu()
+            ok = int(t[0])
+            C.memmove(C.byref(uid), t[1:].numpy().tobytes(), 128)
+        if not ok:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        torch.cuda.set_device(device_index)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), C.c_int(world), uid, C.c_int(rank))
+        if rc:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+
+        class Link(C.Structure):            # == l3d_rccl_link (include/line3d_amd.h)
+            _fields_ = [("comm", C.c_void_p), ("all_gather", C.c_void_p)]
+
+        self.link = Link(self.comm.value, C.cast(self.lib.ncclAllGather, C.c_void_p).value)
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def match_views_chain_native(l3d, rank: int, world: int, link: "RcclLink | None", commit: bool = True,
+                             slot_records: int | None = None, n_segments: int = 2000, n_neighbors: int = 12):
+    """Line3D::matchViews as the sharded resident chain in ONE native call (l3d_shard_chain_run): per view the library
+    enqueues this rank's kernels, the RCCL all-gather of the ranks' kept-list slots and a completion event on its own
+    stream; a host thread of the library trails behind with the bookkeeping on the ranks that commit."""
+    if slot_records is None:
+        slot_records = default_slot_records(n_segments, n_neighbors, world)
+    if world == 1 and link is None:
+        return l3d.shard_run(rank, world, slot_records, "local", None, commit)
+    return l3d.shard_run(rank, world, slot_records, "rccl", link.link, commit)

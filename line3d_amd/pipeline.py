@@ -178,6 +178,18 @@ class Line3D:
     def shard_fetch(self, k: int):
         self._chk(self.lib.l3d_line3d_shard_fetch(self.h, C.c_int(k)))
 
+    def shard_run(self, rank: int, world: int, slot_records: int, exchange: str = "local", exchange_user=None, commit: bool = True):
+        """The whole sharded chain as one native call (l3d_shard_chain_run).  exchange: "rccl" (exchange_user = a ctypes
+        l3d_rccl_link), "local" (world 1) or "replay" (exchange_user = device address of recorded gathered blocks).
+        Returns (device address of the gathered blocks, slot_bytes)."""
+        fn = {"rccl": self.lib.l3d_exchange_rccl, "local": self.lib.l3d_exchange_local, "replay": self.lib.l3d_exchange_replay}[exchange]
+        user = C.c_void_p(exchange_user) if isinstance(exchange_user, int) else (C.c_void_p(C.addressof(exchange_user)) if exchange_user is not None else None)
+        g = C.c_void_p(0)
+        sb = C.c_size_t(0)
+        self._chk(self.lib.l3d_line3d_shard_run(self.h, C.c_int(rank), C.c_int(world), C.c_int(slot_records), C.cast(fn, C.c_void_p), user,
+                                                C.c_int(int(commit)), C.byref(g), C.byref(sb)))
+        return g.value, sb.value
+
     def shard_close(self, committed: bool):
         self._chk(self.lib.l3d_line3d_shard_close(self.h, C.c_int(int(committed))))
 

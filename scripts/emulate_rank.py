@@ -65,38 +65,17 @@ def main():
     recorded = gathered.clone()
     del send
 
-    # pass 2: replay one rank
+    # pass 2: replay one rank through the native loop (l3d_shard_chain_run + the replay exchange)
     l = ls[0]
     R = args.rank
     for rep in range(args.reps + 1):
-        n_views, slot_bytes = l.shard_open(R, W, slot_records)
-        ext = torch.cuda.ExternalStream(l.stream_ptr(), device=dev)
-        with torch.cuda.stream(ext):
-            g = torch.zeros_like(recorded)
-            s = torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev)
-            ext.synchronize()
-            t0 = time.perf_counter()
-            fetched = 0
-            for k in range(n_views):
-                l.shard_enqueue(k, s.data_ptr() + k * slot_bytes, g.data_ptr())
-                if l.shard_view_verified(k):
-                    g[k * W * slot_bytes:(k + 1) * W * slot_bytes].copy_(recorded[k * W * slot_bytes:(k + 1) * W * slot_bytes], non_blocking=True)
-                l.shard_mark(k)
-                if R == 0:
-                    while fetched <= k - args.ahead:
-                        l.shard_fetch(fetched)
-                        fetched += 1
-            t_enq = time.perf_counter() - t0
-            if R == 0:
-                while fetched < n_views:
-                    l.shard_fetch(fetched)
-                    fetched += 1
-            ext.synchronize()
-            dt = time.perf_counter() - t0
-        l.shard_close(R == 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(), commit=(R == 0))
+        dt = time.perf_counter() - t0
         if rep:
-            print("world %d rank %d: %d views x %d segs: %.2f ms (%.1f us/view; host enqueue loop %.2f ms), kept %d (recorded %d), slot %d KB"
-                  % (W, R, n_views, args.segments, dt * 1e3, dt / n_views * 1e6, t_enq * 1e3, int(l.stats()["kept"]), int(kept), slot_bytes // 1024))
+            print("world %d rank %d: %d views x %d segs: %.2f ms (%.1f us/view), kept %d (recorded %d), slot %d KB"
+                  % (W, R, n_views, args.segments, dt * 1e3, dt / n_views * 1e6, int(l.stats()["kept"]), int(kept), slot_bytes // 1024))
     l.close()
 
 

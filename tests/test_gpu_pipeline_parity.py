@@ -211,3 +211,71 @@ def test_sharded_chain_three_virtual_ranks(small_scene, small_oracle):
     assert_lines_equal(l0.getResult(), small_oracle.result, 1e-4)
     for l in ls:
         l.close()
+
+
+def _check_against_oracle(l, small_oracle):
+    l.finish(False)
+    for v in sorted(small_oracle.trace):
+        got, med = l.view_matches(v)
+        assert got.tobytes() == small_oracle.trace[v]["matches"].tobytes(), "view %d" % v
+        assert np.float32(med) == np.float32(small_oracle.trace[v]["median"])
+    assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+
+
+def test_native_sharded_run_world1_local_and_rccl(small_scene, small_oracle):
+    """l3d_shard_chain_run (enqueue thread + trailing bookkeeping thread inside the library), world = 1: once with the
+    local exchange, once with a real RCCL communicator (ncclAllGather called by the library on its own stream)."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    for use_rccl in (False, True):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.prepare()
+        link = l3dist.RcclLink(0, 1, None, 0) if use_rccl else None
+        l3dist.match_views_chain_native(l, 0, 1, link, commit=True, n_segments=300, n_neighbors=6)
+        _check_against_oracle(l, small_oracle)
+        l.close()
+        if link is not None:
+            link.close()
+
+
+def test_native_sharded_run_replayed_ranks(small_scene, small_oracle):
+    """Every rank of a world-3 job replayed through the native loop on one GPU: the gathered blocks of a recorded run
+    (virtual ranks) stand in for the collective.  Each rank must reproduce its own slots bit for bit, and rank 0's
+    host bookkeeping the oracle's result."""
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    W, SLOT = 3, 4096
+    dev = torch.device("cuda", 0)
+    ls = []
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.prepare()
+        ls.append(l)
+    n_views, slot_bytes = [l.shard_open(r, W, SLOT) for r, l in enumerate(ls)][0]
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, l in enumerate(ls):
+            l.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for l in ls:
+            l.shard_mark(k)
+    for l in ls:
+        l.shard_close(False)
+    recorded = gathered.clone()
+    for r, l in enumerate(ls):
+        g_ptr, sb = l.shard_run(r, W, SLOT, "replay", recorded.data_ptr(), commit=(r == 0))
+        assert sb == slot_bytes
+        torch.cuda.synchronize()
+    _check_against_oracle(ls[0], small_oracle)
+    for l in ls:
+        l.close()
