@@ -121,12 +121,13 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     }
 }
 
-// Host hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment)
-// order, the raw depth-pair arrays and a summary are written straight into host-mapped pinned memory (16-byte stores
-// over PCIe) -- one launch and one wait instead of a header round trip plus one copy per rank.
+// Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
+// behind the raw depth-pair arrays, are packed into a contiguous device staging buffer (one SDMA copy of the exact size
+// brings them to the host); the summary goes straight into host-mapped pinned memory.
 struct PackHeader { long long R; int n_kept, overflow, pad[4]; };
 static_assert(sizeof(PackHeader) == 32, "pack header");
-__global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restrict__ block, SlotGeom g, unsigned char* __restrict__ out)
+__global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restrict__ block, SlotGeom g, unsigned char* __restrict__ out,
+                                                   PackHeader* __restrict__ hdr_host)
 {
     const int r = blockIdx.y;
     int base = 0, bad = 0;
@@ -141,13 +142,13 @@ __global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restri
     const unsigned char* slot = block + (size_t)r * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const size_t best_bytes = (size_t)g.seg_cap * 8;
-    unsigned char* o_best = out + sizeof(PackHeader) + (size_t)r * best_bytes;
-    unsigned char* o_rec = out + sizeof(PackHeader) + (size_t)g.world * best_bytes;
+    unsigned char* o_best = out + (size_t)r * best_bytes;
+    unsigned char* o_rec = out + (size_t)g.world * best_bytes;
     const int n = bad ? 0 : hd->n_kept;
     if (r == g.world - 1 && blockIdx.x == 0 && threadIdx.x == 0) {
         PackHeader ph;
         ph.R = R; ph.n_kept = bad ? 0 : base + n; ph.overflow = bad; ph.pad[0] = ph.pad[1] = ph.pad[2] = ph.pad[3] = 0;
-        *reinterpret_cast<PackHeader*>(out) = ph;
+        *hdr_host = ph;
     }
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     // depth pairs of this rank's segment range (fixed stride seg_cap; the host skips the -1 markers)
@@ -194,12 +195,16 @@ struct l3d_shard_chain {
     const unsigned char* gathered = nullptr;
     double pairs = 0, raw_sum = 0, kept_total = 0;
     std::vector<float> best_scratch;
-    unsigned char* stage_host = nullptr;     // two hand-over buffers in host-mapped pinned memory (k_pack_view)
-    unsigned char* stage_dev = nullptr;
+    // hand-over (k_pack_view): a ring of device staging buffers, per-view summaries in host-mapped pinned memory
+    static constexpr int kRing = 16;
     size_t stage_bytes = 0;
-    hipEvent_t ev3[2] = { nullptr, nullptr };
-    int packed = 0;                          // views [0, packed) have their hand-over enqueued (fetch thread only)
+    PackHeader* hdr_host = nullptr;
+    PackHeader* hdr_dev = nullptr;
+    bool eager_pack = false;                 // l3d_shard_chain_run on a committing rank: pack at mark time, on the chain's stream
+    std::vector<char> packed;                // per view: its pack kernel is enqueued (and covered by ev2)
+    hipEvent_t ev3 = nullptr;                // lazy pack (step-wise protocol): enqueued by fetch
     std::atomic<int> marked{0};              // views [0, marked) carry their completion event
+    std::atomic<int> fetched{0};             // views [0, fetched) have left their staging buffer
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
 };
 
@@ -323,15 +328,18 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
     OCHK(c->cand_conf.reserve(h->cand_cap * 4));
     OCHK(c->vw_scratch.reserve((h->cand_cap + 2) * 16));
-    h->stage_bytes = salign(sizeof(PackHeader) + (size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
-    OCHK(c->ch_pin_kept.reserve(2 * h->stage_bytes + 64));
-    h->stage_host = c->ch_pin_kept.as<unsigned char>();
-    OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stage_dev), h->stage_host, 0));
+    h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
+    OCHK(c->ch_pin_kept.reserve(h->stage_bytes + 64));
+    OCHK(c->ch_stage.reserve((size_t)l3d_shard_chain::kRing * h->stage_bytes + 64));
+    OCHK(c->ch_pin_best.reserve((size_t)n_views * sizeof(PackHeader) + 64));
+    h->hdr_host = c->ch_pin_best.as<PackHeader>();
+    OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hdr_dev), h->hdr_host, 0));
+    h->packed.assign((size_t)n_views, 0);
 #undef OCHK
     h->ev1.assign((size_t)n_views, nullptr);
     h->ev2.assign((size_t)n_views, nullptr);
     for (int k = 0; k < n_views; ++k) h->ev2[(size_t)k] = get_event(c);
-    h->ev3[0] = get_event(c); h->ev3[1] = get_event(c);
+    h->ev3 = get_event(c);
     c->stats[0] = h->pairs;
     *out = h;
     return L3D_OK;
@@ -454,65 +462,70 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     return L3D_OK;
 }
 
+// Enqueue the hand-over of view k (k_pack_view) into staging buffer k % kRing.
+static int shard_pack(l3d_shard_chain* h, int k, hipStream_t st)
+{
+    l3d_ctx* c = h->c;
+    const size_t block = (size_t)h->world * h->geom.slot_bytes;
+    hipLaunchKernelGGL(k_pack_view, dim3(8, h->world), dim3(256), 0, st, h->gathered + (size_t)k * block, h->geom,
+                       c->ch_stage.as<unsigned char>() + (size_t)(k % l3d_shard_chain::kRing) * h->stage_bytes, h->hdr_dev + k);
+    h->packed[(size_t)k] = 1;
+    return L3D_OK;
+}
+
 // Record "view k is complete" on the stream -- call after the all-gather of view k has been enqueued.
 int l3d_shard_chain_mark(l3d_shard_chain* h, int k)
 {
     if (!h || k < 0 || k >= h->n_views) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
+    if (h->eager_pack && h->vd[(size_t)k].verified) { int rc = shard_pack(h, k, c->stream); if (rc) return rc; }
     HIPCHK(c, hipEventRecord(h->ev2[(size_t)k], c->stream));
     h->marked.store(k + 1, std::memory_order_release);
     return L3D_OK;
 }
 
-// Enqueue (copy stream, after view k's completion event) the hand-over of view k into staging buffer k % 2.
-static int shard_pack(l3d_shard_chain* h, int k)
-{
-    l3d_ctx* c = h->c;
-    if (!h->vd[(size_t)k].verified) return L3D_OK;
-    if (!h->ev2[(size_t)k]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_fetch: view not marked");
-    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, h->ev2[(size_t)k], 0));
-    const size_t block = (size_t)h->world * h->geom.slot_bytes;
-    hipLaunchKernelGGL(k_pack_view, dim3(8, h->world), dim3(256), 0, c->copy_stream, h->gathered + (size_t)k * block, h->geom,
-                       h->stage_dev + (size_t)(k & 1) * h->stage_bytes);
-    HIPCHK(c, hipEventRecord(h->ev3[k & 1], c->copy_stream));     // (events are created in open: the pool is not thread safe)
-    h->packed = k + 1;
-    return L3D_OK;
-}
-
 // Wait for view k (host side only) and hand the ranks' kept lists, concatenated in rank (= segment) order, and the depth
-// pairs to the callback.  Views must be fetched in ascending order (the hand-over of view k+1 is prefetched when it is
-// already marked).
+// pairs to the callback.  Views must be fetched in ascending order.
 int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void* user)
 {
     if (!h || k < 0 || k >= h->n_views || !cb) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
-    if (!h->vd[(size_t)k].verified) return cb(user, k, 0, nullptr, 0, nullptr, 0, 0) ? fail(c, L3D_ERR_INVALID, "callback failed") : L3D_OK;
+    if (!h->vd[(size_t)k].verified) {
+        h->fetched.store(k + 1, std::memory_order_release);
+        return cb(user, k, 0, nullptr, 0, nullptr, 0, 0) ? fail(c, L3D_ERR_INVALID, "callback failed") : L3D_OK;
+    }
+    if (h->marked.load(std::memory_order_acquire) <= k) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_fetch: view not marked");
     HIPCHK(c, hipSetDevice(c->device));
     const double tf0 = now_s();
-    if (h->packed <= k) { int rc = shard_pack(h, k); if (rc) return rc; }
-    HIPCHK(c, hipEventSynchronize(h->ev3[k & 1]));
+    if (h->packed[(size_t)k]) {
+        HIPCHK(c, hipEventSynchronize(h->ev2[(size_t)k]));
+    } else {                                        // step-wise protocol: pack now, behind whatever the stream has queued
+        int rc = shard_pack(h, k, c->stream); if (rc) return rc;
+        HIPCHK(c, hipEventRecord(h->ev3, c->stream));
+        HIPCHK(c, hipEventSynchronize(h->ev3));
+    }
     const double tf1 = now_s();
-    const unsigned char* host = h->stage_host + (size_t)(k & 1) * h->stage_bytes;
-    const PackHeader* ph = reinterpret_cast<const PackHeader*>(host);
-    if (ph->overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
+    const PackHeader ph = h->hdr_host[k];
+    if (ph.overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
     const size_t best_bytes = (size_t)h->geom.seg_cap * 8;
-    const l3d_match* kept = reinterpret_cast<const l3d_match*>(host + sizeof(PackHeader) + (size_t)h->world * best_bytes);
+    unsigned char* host = c->ch_pin_kept.as<unsigned char>();
+    const unsigned char* stage = c->ch_stage.as<unsigned char>() + (size_t)(k % l3d_shard_chain::kRing) * h->stage_bytes;
+    HIPCHK(c, hipMemcpyAsync(host, stage, (size_t)h->world * best_bytes + (size_t)ph.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    h->fetched.store(k + 1, std::memory_order_release);          // the staging buffer of view k may be reused
+    const l3d_match* kept = reinterpret_cast<const l3d_match*>(host + (size_t)h->world * best_bytes);
     std::vector<float>& best = h->best_scratch;
     best.clear();
-    if (ph->R > 0)
+    if (ph.R > 0)
         for (int r = 0; r < h->world; ++r) {
             const int s0 = (int)(((long long)h->views[k].S_src * r) / h->world), s1 = (int)(((long long)h->views[k].S_src * (r + 1)) / h->world);
-            const float* b = reinterpret_cast<const float*>(host + sizeof(PackHeader) + (size_t)r * best_bytes);
+            const float* b = reinterpret_cast<const float*>(host + (size_t)r * best_bytes);
             for (int s = 0; s < s1 - s0; ++s)
                 if (b[2 * s] != -1.0f) { best.push_back(b[2 * s]); best.push_back(b[2 * s + 1]); }
         }
-    // the next view's hand-over travels while this view's bookkeeping runs (only if the enqueue thread has marked it)
-    if (k + 1 < h->n_views && h->packed <= k + 1 && h->vd[(size_t)(k + 1)].verified && h->marked.load(std::memory_order_acquire) > k + 1) {
-        int rc = shard_pack(h, k + 1); if (rc) return rc;
-    }
     const double tf2 = now_s();
-    h->kept_total += (double)ph->n_kept;
-    if (cb(user, k, 1, kept, ph->n_kept, best.data(), (int)(best.size() / 2), (int)std::min<long long>(ph->R, 0x7fffffff)))
+    h->kept_total += (double)ph.n_kept;
+    if (cb(user, k, 1, kept, ph.n_kept, best.data(), (int)(best.size() / 2), (int)std::min<long long>(ph.R, 0x7fffffff)))
         return fail(c, L3D_ERR_INVALID, "callback failed");
     h->t_wait += tf1 - tf0; h->t_copy += tf2 - tf1; h->t_cb += now_s() - tf2;
     return L3D_OK;
@@ -531,6 +544,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     const size_t slot = h->geom.slot_bytes, block = slot * (size_t)h->world;
     HIPCHK(c, c->ch_send.reserve((size_t)h->n_views * slot + 256));
     HIPCHK(c, c->ch_gathered.reserve((size_t)h->n_views * block + 256));
+    h->eager_pack = cb != nullptr;
     unsigned char* send = c->ch_send.as<unsigned char>();
     unsigned char* gathered = c->ch_gathered.as<unsigned char>();
     // every verified view's block is fully written by its exchange before anything reads it; only the blocks of views
@@ -562,6 +576,11 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     int rc = L3D_OK;
     const double t_run0 = now_s();
     for (int k = 0; k < h->n_views && rc == L3D_OK; ++k) {
+        // a committing rank stays less than a staging ring ahead of its bookkeeping thread (which trails the GPU closely)
+        while (cb && h->fetched.load(std::memory_order_acquire) < k - (l3d_shard_chain::kRing - 2)) {
+            { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
+            std::this_thread::yield();
+        }
         const double te0 = now_s();
         rc = l3d_shard_chain_enqueue(h, k, send + (size_t)k * slot, gathered);
         const double te1 = now_s();
@@ -617,7 +636,7 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
     (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : h->ev1) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);
-    for (hipEvent_t e : h->ev3) if (e) c->event_pool.push_back(e);
+    if (h->ev3) c->event_pool.push_back(h->ev3);
     c->stats[1] = h->raw_sum; c->stats[3] = h->kept_total;
     if (getenv("L3D_TIMING"))
         fprintf(stderr, "[l3d shard chain rank %d/%d] enqueue %.2f  exchange-call %.2f | fetch: wait %.2f  d2h %.2f  callback %.2f ms\n",
