@@ -199,9 +199,10 @@ int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
 /* stage-2 algorithm: 0 = depth-window search (default; falls back to all-pairs when a segment's candidates do
  * not fit in LDS), 1 = all-pairs loop in the reference's formulation.  Results are bit-identical. */
 int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
-/* stage-1 conservative wedge pre-test in front of the exact epipolar/overlap test: 1 = on (default), 0 = off (A/B
- * testing; results are bit-identical, the pre-test only rejects pairs the exact test rejects) */
-int l3d_set_pair_pretest(l3d_ctx* ctx, int on);
+/* stage-1 conservative filters in front of the exact epipolar/overlap/triangulation sequence: bit 0 = wedge test,
+ * bit 1 = depth-sign test; 3 = both (default), 0 = none (A/B testing: results are bit-identical, a filter only rejects
+ * pairs the exact sequence rejects) */
+int l3d_set_pair_pretest(l3d_ctx* ctx, int mask);
 /* testing: cap the LDS image of the depth-window kernel (bytes; 0 = device limit) so that segments take the
  * global-scratch variant; process-wide */
 int l3d_set_verify_lds_budget(size_t bytes);

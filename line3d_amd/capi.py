@@ -102,7 +102,7 @@ class Context:
         self._chk(self.lib.l3d_set_verify_lds_budget(C.c_size_t(nbytes)))
 
     def set_pair_pretest(self, on: bool):
-        self._chk(self.lib.l3d_set_pair_pretest(self.h, C.c_int(int(on))))
+        self._chk(self.lib.l3d_set_pair_pretest(self.h, C.c_int(3 if on is True else int(on))))
 
     def set_verify_mode(self, mode: int):
         self._chk(self.lib.l3d_set_verify_mode(self.h, C.c_int(mode)))

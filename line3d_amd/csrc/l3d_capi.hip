@@ -37,11 +37,13 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipSetDevice(device) != hipSuccess) return L3D_ERR_HIP;
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
+    if (const char* e = getenv("L3D_PRETEST")) c->wedge_pretest = atoi(e) & 3;      // diagnostic: stage-1 filter mask
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
     }
+    if (getenv("L3D_PAIR_STATS") && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 64) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 64);
     *out = c;
     return L3D_OK;
 }
@@ -56,6 +58,14 @@ void l3d_ctx_destroy(l3d_ctx* c)
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
         fprintf(stderr, "[l3d verify_window wave-cycles] build %.1f%%  setup %.1f%%  scan %.1f%%  drain %.1f%%  final %.1f%%  (waves %llu, avg %.0f cycles)\n",
                 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, h[5], tot / (double)(h[5] ? h[5] : 1));
+    }
+    if (c->pair_dbg) {
+        unsigned long long h[4];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, c->pair_dbg, 32, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after depth-sign test %.3f%%  candidates %.3f%%\n", h[0], 100.0 * h[1] / (double)h[0],
+                100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0]);
+        (void)hipFree(c->pair_dbg);
     }
     if (getenv("L3D_TIMING"))
         fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms  (max candidates per segment %d)\n",
@@ -102,7 +112,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
 }
 
 int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes); return L3D_OK; }
-int l3d_set_pair_pretest(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->wedge_pretest = on ? 1 : 0; return L3D_OK; }
+int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 3) return L3D_ERR_INVALID; c->wedge_pretest = mask; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
 int l3d_profile_only(l3d_ctx* c, const char* kernel) { if (!c) return L3D_ERR_INVALID; c->prof_only = kernel ? kernel : ""; return L3D_OK; }
@@ -233,7 +243,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
-    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg;
     const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
     // stage 1 starts now; the host orders the existing matches meanwhile

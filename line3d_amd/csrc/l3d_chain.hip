@@ -358,7 +358,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
         pa.mask = d.mask;
         pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest;
+        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg;
         return pa;
     };
 

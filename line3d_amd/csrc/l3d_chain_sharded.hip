@@ -361,7 +361,7 @@ static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
     pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
     pa.mask = d.mask;
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest;
+    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg;
     return pa;
 }
 

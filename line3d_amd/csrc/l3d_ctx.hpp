@@ -71,7 +71,8 @@ struct l3d_ctx {
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     std::vector<int> h_cnt;
     int mmax_seen = 0;
-    int wedge_pretest = 1;          // stage-1 wedge pre-test (0 only for A/B testing)
+    unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
+    int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 depth-sign test (cleared only for A/B testing)
     int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;

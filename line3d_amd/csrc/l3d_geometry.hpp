@@ -152,6 +152,20 @@ L3D_HD float4 pair_depths(const SrcPairInv& s, const TgtPairInv& t, f3 l2_p1, f3
     return d;
 }
 
+// The same four depths with the rays of the exact endpoints (per-segment invariants) already normalised by the caller
+// with the very same operations: ray_p = normalize(mat3_apply(RtKinv_src, p)), ray_q = normalize(mat3_apply(RtKinv_tgt, q)).
+L3D_HD float4 pair_depths_pre(f3 ray_p1, f3 ray_p2, f3 ray_q1, f3 ray_q2, f3 l2_p1, f3 l2_p2, f3 l1_q1, f3 l1_q2,
+                              const float* RtKinv_src, const float* RtKinv_tgt, f3 C_src, f3 C_tgt)
+{
+    const f3 w0 = C_src - C_tgt;
+    float4 d;
+    d.x = tri_depth(ray_p1, normalize(mat3_apply(RtKinv_tgt, l2_p1)), w0, true);
+    d.y = tri_depth(ray_p2, normalize(mat3_apply(RtKinv_tgt, l2_p2)), w0, true);
+    d.z = tri_depth(normalize(mat3_apply(RtKinv_src, l1_q1)), ray_q1, w0, false);
+    d.w = tri_depth(normalize(mat3_apply(RtKinv_src, l1_q2)), ray_q2, w0, false);
+    return d;
+}
+
 // Largest float x with sqrtf(x) <= u (u >= 0): lets the verification gate compare squared
 // distances and stay bit-identical to `length(P-Q) > unc` (cudawrapper.cu:396-400).
 L3D_HD float sq_threshold(float u)

@@ -22,62 +22,74 @@ namespace l3d {
 
 // =================================================================================================
 // Stage 1a.  grid = (tgt tiles of 256, src blocks of kSrcPerBlock, n_tbm); block = 256.
-// Lane <-> target segment (its invariants live in registers), the block walks kSrcPerBlock source
-// segments whose invariants are staged in LDS and read as broadcasts.  One wave ballot = one
-// 64-bit word of the (camera, src) bit row.
+// Lane <-> target segment, the block walks kSrcPerBlock source segments whose invariants are staged in LDS and read as
+// broadcasts.  One wave ballot = one 64-bit word of the (camera, src) bit row.
+//
+// The reference evaluates, for EVERY pair, four line intersections with divisions, two overlap ratios with square
+// roots and four triangulations (K_pairwise_matches, cudawrapper.cu:537-611) and keeps 0.7 % of the pairs.  Here the
+// exact float sequence runs only on pairs that two cheap CONSERVATIVE filters could not reject; a filter only ever
+// rejects a pair the exact sequence rejects too, so the bit rows are identical with the filters on or off
+// (tests/: A/B on whole scenes).  Each level runs with (nearly) full waves: survivors are compacted through per-wave
+// LDS rings and processed 64 at a time.
+//   1. wedge test on ALL pairs (~30 VALU ops, FMA): the epipolar lines of the source endpoints bound a double wedge in
+//      the target image; a target segment entirely outside it, by a safety margin, cannot overlap [l2_p1, l2_p2] --
+//      D_segment_overlap_2D returns 0 for it -- and symmetrically for the source segment and the target's wedge.  The
+//      lines are pre-divided by their margins (1e-4 of the term magnitudes, ~0.2 px, against ~1e-6 relative float
+//      error), so the test is two min3/max3 chains against +-1.  ~12 % of the pairs survive.
+//   2. overlap-bound test on the survivors (~110 ops, FMA, reciprocals, no square root): D_segment_overlap_2D of
+//      collinear points is the 1-D intersection-over-union of two intervals; with t = a/(a-b) (a, b: the two endpoints
+//      against one epipolar line -- the numbers level 1 already looked at) the interval of the intersection points is
+//      known in the segment's own parameter without computing the points.  The test evaluates an UPPER bound of both
+//      ratios -- t widened by e = 1e-2 (1+|t|)/|a-b| (conditioning of the intersection, in margin units) + coordinate
+//      rounding -- and drops the pair when the bound misses the thresholds (min > 0.1, max > 0.3, cudawrapper.cu:586-588)
+//      or the intersection pair is surely shorter than a pixel (:211).  Ill-conditioned pairs (e >= 10) are kept.
+//      ~8 % of the pairs survive (6 % are candidates).
+//   3. the exact overlap test and triangulation on those.
 // =================================================================================================
-// Three levels, each run with (nearly) full waves:
-//   1. wedge pre-test on ALL pairs (~45 instructions): the epipolar lines of the source endpoints bound a double wedge
-//      in the target image (x is on the epipolar line of some source point iff (epi_p1.x)(epi_p2.x) <= 0); a target
-//      segment entirely outside it, by a safety margin, cannot overlap [l2_p1, l2_p2] -- the reference's
-//      D_segment_overlap_2D returns 0 for it -- and symmetrically for the source segment and the target's wedge.
-//      The margin (1e-4 of the term magnitudes, i.e. ~0.2 px against ~1e-6 relative float error) keeps the pre-test
-//      strictly conservative: it only ever rejects pairs the full float test rejects (tests/: A/B on whole scenes).
-//   2. survivors (~12 %) go to a per-wave LDS ring and get the exact overlap test 64 at a time,
-//   3. its survivors (~8 %) go to a second ring and are triangulated 64 at a time.
 constexpr int kPairQueue = 128;
 constexpr float kWedgeTau = 1.0e-4f;
-struct PairQEntry { int key; float p[8]; };   // key = src_local | origin_lane << 8
+constexpr float kIouCond = 1.0e-2f;           // error of t = a/(a-b) in units of (1+|t|)/|a-b| (a, b in margin units)
+constexpr float kIouSlack = 1.0e-3f;
 
-struct SrcBlockInv { SrcPairInv s; float m1, m2; };   // + wedge margins of epi_p1 / epi_p2 against this tile's targets
+struct SrcBlockInv {                          // 29 words: odd stride, gathers by segment index spread over the LDS banks
+    SrcPairInv s;                             // exact invariants of the pair test
+    f3 e1s, e2s;                              // epipolar lines of p1 / p2 divided by their wedge margins
+    f3 ray1, ray2;                            // normalize(RtKinv_src * p1), (* p2): the reference's float sequence
+    float pad;
+};
+struct TgtBlockInv {                          // 29 words
+    TgtPairInv t;
+    f3 e1s, e2s;                              // epipolar lines of q1 / q2 (in the source image) divided by their margins
+    f3 ray1, ray2;                            // normalize(RtKinv_tgt * q1), (* q2)
+    float pad;
+};
 
-__device__ __forceinline__ void pair_queue_drain(PairQEntry* q, int head, int n, const SrcBlockInv* s_src, float4 tseg,
-                                                 const float* RtKinv_src, const float* RtKinv_tgt, f3 C_src, f3 C_tgt,
-                                                 unsigned long long* s_bits, int wave, int lane)
+__device__ __forceinline__ float fdot(f3 a, f3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ float fline(f3 l, float x, float y) { return __builtin_fmaf(l.x, x, __builtin_fmaf(l.y, y, l.z)); }
+// Upper bound of D_segment_overlap_2D(segment [0,1] of length len, intersection points at parameters t1, t2) where
+// ti = ai/(ai - bi) and ri = 1/(ai - bi); ext_over_len = (largest coordinate)/len.  2.0f = "cannot tell".
+__device__ __forceinline__ float iou_upper(float t1, float r1, float t2, float r2, float len, float ext_over_len)
 {
-    PairQEntry e = q[(head + lane) & (kPairQueue - 1)];
-    if (lane >= n) e.key = 0;
-    const int k = e.key & 0xff, origin = (e.key >> 8) & 63;
-    // the origin lane's target segment comes over the wave, not from memory
-    const float qx = __shfl(tseg.x, origin), qy = __shfl(tseg.y, origin), qz = __shfl(tseg.z, origin), qw = __shfl(tseg.w, origin);
-    if (lane < n) {
-        SrcPairInv s;
-        s.p1 = s_src[k].s.p1; s.p2 = s_src[k].s.p2;
-        TgtPairInv t;
-        t.q1 = mk3(qx, qy, 1.0f); t.q2 = mk3(qz, qw, 1.0f);
-        const float4 d = pair_depths(s, t, mk3(e.p[0], e.p[1], 1.0f), mk3(e.p[2], e.p[3], 1.0f), mk3(e.p[4], e.p[5], 1.0f),
-                                     mk3(e.p[6], e.p[7], 1.0f), RtKinv_src, RtKinv_tgt, C_src, C_tgt);
-        if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)                 // cudawrapper.cu:931
-            atomicOr(&s_bits[k * 4 + wave], 1ull << origin);
-    }
-}
-
-// a and b: algebraic distances of the two endpoints of one segment to one line; true if both are on the same side,
-// farther than the margin; sgn returns that side
-__device__ __forceinline__ bool same_side(float a, float b, float m, bool& positive)
-{
-    positive = a > 0.0f;
-    return (a > m && b > m) || (a < -m && b < -m);
+    const float e1 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t1)), __builtin_fabsf(r1), 1.0e-6f * (ext_over_len + __builtin_fabsf(t1)));
+    const float e2 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t2)), __builtin_fabsf(r2), 1.0e-6f * (ext_over_len + __builtin_fabsf(t2)));
+    const float e = __builtin_fmaxf(e1, e2);
+    if (!(e < 10.0f)) return 2.0f;                                       // ill-conditioned, infinite or NaN
+    const float lo = __builtin_fminf(t1, t2), hi = __builtin_fmaxf(t1, t2);
+    if ((hi - lo + 2.0f * e) * len < 1.0f - kIouSlack) return 0.0f;      // the intersection pair is shorter than a pixel (:211)
+    const float inter = __builtin_fminf(hi, 1.0f) - __builtin_fmaxf(lo, 0.0f) + 2.0f * e;
+    const float uni = __builtin_fmaxf(hi, 1.0f) - __builtin_fminf(lo, 0.0f) - 2.0f * e;
+    if (!(uni > 0.0f)) return 2.0f;
+    return inter * __builtin_amdgcn_rcpf(uni) * (1.0f + 1.0e-5f);
 }
 
 __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
 {
     __shared__ SrcBlockInv s_src[kSrcPerBlock];
-    __shared__ TgtPairInv s_tgt[256];
-    __shared__ float s_cam[9 + 9 + 3];   // F, RtKinv_tgt, C_tgt of this camera
+    __shared__ TgtBlockInv s_tgt[256];
+    __shared__ float s_cam[9 + 9 + 3 + 9];   // F, RtKinv_tgt, C_tgt of this camera, RtKinv_src
     __shared__ float s_ext[4];           // max |x|, |y| of this tile's target endpoints / this block's source endpoints
     __shared__ unsigned short s_qa[4][kPairQueue];
-    __shared__ PairQEntry s_q[4][kPairQueue];
+    __shared__ unsigned short s_qb[4][kPairQueue];
     __shared__ unsigned long long s_bits[kSrcPerBlock * 4];
 
     const int j = blockIdx.z;
@@ -94,14 +106,22 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     if (tid < 9) s_cam[tid] = a.F[cam * 9 + tid];
     else if (tid < 18) s_cam[tid] = a.RtKinv[cam * 9 + (tid - 9)];
     else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
+    else if (tid < 30) s_cam[tid] = a.RtKinv_src[tid - 21];
     if (tid < kSrcPerBlock * 4) s_bits[tid] = 0ull;
     if (tid < 4) s_ext[tid] = 0.0f;
     __syncthreads();
 
+    const f3 C_tgt = mk3(s_cam[18], s_cam[19], s_cam[20]);
+    const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    const float* Rt = s_cam + 9;
+    const float* Rs = s_cam + 21;
+
     const bool valid = x < width;
     const float4 tseg = valid ? a.tgt_segs[toff + x] : make_float4(0.f, 0.f, 1.f, 1.f);
     const TgtPairInv t = make_tgt_inv(tseg, s_cam);
-    s_tgt[tid] = t;
+    s_tgt[tid].t = t;
+    s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
+    s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
     const int ny = min(kSrcPerBlock, a.seg_end - y0);
     {   // coordinate extents for the wedge margins (non-negative floats order like ints)
         float ex = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.x), __builtin_fabsf(tseg.z)) : 0.0f;
@@ -116,79 +136,129 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     }
     __syncthreads();
     if (tid < ny) {
-        SrcBlockInv b;
-        b.s = make_src_inv(a.src_segs[y0 + tid], s_cam);
-        b.m1 = kWedgeTau * (__builtin_fabsf(b.s.epi_p1.x) * s_ext[0] + __builtin_fabsf(b.s.epi_p1.y) * s_ext[1] + __builtin_fabsf(b.s.epi_p1.z));
-        b.m2 = kWedgeTau * (__builtin_fabsf(b.s.epi_p2.x) * s_ext[0] + __builtin_fabsf(b.s.epi_p2.y) * s_ext[1] + __builtin_fabsf(b.s.epi_p2.z));
-        s_src[tid] = b;
+        SrcBlockInv& b = s_src[tid];
+        const SrcPairInv si = make_src_inv(a.src_segs[y0 + tid], s_cam);
+        // a zero margin (degenerate line) gives inf/nan below: comparisons fail, nothing is culled
+        const float m1 = kWedgeTau * (__builtin_fabsf(si.epi_p1.x) * s_ext[0] + __builtin_fabsf(si.epi_p1.y) * s_ext[1] + __builtin_fabsf(si.epi_p1.z));
+        const float m2 = kWedgeTau * (__builtin_fabsf(si.epi_p2.x) * s_ext[0] + __builtin_fabsf(si.epi_p2.y) * s_ext[1] + __builtin_fabsf(si.epi_p2.z));
+        const float i1 = 1.0f / m1, i2 = 1.0f / m2;
+        b.s = si;
+        b.e1s = i1 * si.epi_p1; b.e2s = i2 * si.epi_p2;
+        b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2));
     }
-    const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * s_ext[2] + __builtin_fabsf(t.epi_q1.y) * s_ext[3] + __builtin_fabsf(t.epi_q1.z));
-    const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * s_ext[2] + __builtin_fabsf(t.epi_q2.y) * s_ext[3] + __builtin_fabsf(t.epi_q2.z));
-    const f3 C_tgt = mk3(s_cam[18], s_cam[19], s_cam[20]);
-    const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    f3 eq1s, eq2s;                           // this lane's epipolar lines (in the source image) over their margins
+    {
+        const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * s_ext[2] + __builtin_fabsf(t.epi_q1.y) * s_ext[3] + __builtin_fabsf(t.epi_q1.z));
+        const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * s_ext[2] + __builtin_fabsf(t.epi_q2.y) * s_ext[3] + __builtin_fabsf(t.epi_q2.z));
+        eq1s = (1.0f / mq1) * t.epi_q1; eq2s = (1.0f / mq2) * t.epi_q2;
+        s_tgt[tid].e1s = eq1s; s_tgt[tid].e2s = eq2s;
+    }
+    const float ext = __builtin_fmaxf(__builtin_fmaxf(s_ext[0], s_ext[1]), __builtin_fmaxf(s_ext[2], s_ext[3]));
     __syncthreads();
 
     unsigned short* qa = s_qa[wave];
-    PairQEntry* q = s_q[wave];
-    const TgtPairInv* tw = s_tgt + wave * 64;
-    int ha = 0, ca = 0, head = 0, count = 0;       // wave-uniform ring states
+    unsigned short* qb = s_qb[wave];
+    const TgtBlockInv* tw = s_tgt + wave * 64;
+    int ha = 0, ca = 0, hb = 0, cb = 0;            // wave-uniform ring states
+    int n_l1 = 0, n_l2 = 0;                        // diagnostic counters
+    const bool use_wedge = (a.wedge_pretest & 1) != 0, use_iou = (a.wedge_pretest & 2) != 0;
 
-    // level 2: exact overlap test for up to 64 queued pairs; survivors move on to the triangulation ring
-    auto drain_a = [&](int n) {
-        const unsigned key = qa[(ha + lane) & (kPairQueue - 1)];
-        const int k = key & 0xff, origin = (key >> 8) & 63;
-        f3 l2_p1, l2_p2, l1_q1, l1_q2;
-        bool pass = false;
-        if (lane < n) pass = pair_overlap_test(s_src[k].s, tw[origin], l2_p1, l2_p2, l1_q1, l1_q2);
-        const unsigned long long pm = __ballot(pass);
-        if (pm) {
-            if (pass) {
-                const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kPairQueue - 1);
-                PairQEntry e;
-                e.key = k | (origin << 8);
-                e.p[0] = l2_p1.x; e.p[1] = l2_p1.y; e.p[2] = l2_p2.x; e.p[3] = l2_p2.y;
-                e.p[4] = l1_q1.x; e.p[5] = l1_q1.y; e.p[6] = l1_q2.x; e.p[7] = l1_q2.y;
-                q[pos] = e;
+    // One extra iteration (k == ny) flushes the rings.  Each level's body appears exactly once (a single loop drains
+    // whichever ring is due), so nothing is outlined and no state lives in scratch.
+    for (int k = 0; k <= ny; ++k) {
+        const bool last = k == ny;
+        if (!last) {
+            // level 1: wedge test (broadcast reads of the source invariants)
+            const SrcBlockInv& sb = s_src[k];
+            bool cand = valid;
+            if (use_wedge) {
+                const float a1 = fline(sb.e1s, t.q1.x, t.q1.y), a2 = fline(sb.e1s, t.q2.x, t.q2.y);
+                const float a3 = fline(sb.e2s, t.q1.x, t.q1.y), a4 = fline(sb.e2s, t.q2.x, t.q2.y);
+                const float lo2 = __builtin_fminf(__builtin_fminf(a1, a2), __builtin_fminf(a3, a4));
+                const float hi2 = __builtin_fmaxf(__builtin_fmaxf(a1, a2), __builtin_fmaxf(a3, a4));
+                const bool out2 = lo2 > 1.0f || hi2 < -1.0f;        // target segment strictly outside the source wedge
+                const float b1 = fline(eq1s, sb.s.p1.x, sb.s.p1.y), b2 = fline(eq1s, sb.s.p2.x, sb.s.p2.y);
+                const float b3 = fline(eq2s, sb.s.p1.x, sb.s.p1.y), b4 = fline(eq2s, sb.s.p2.x, sb.s.p2.y);
+                const float lo1 = __builtin_fminf(__builtin_fminf(b1, b2), __builtin_fminf(b3, b4));
+                const float hi1 = __builtin_fmaxf(__builtin_fmaxf(b1, b2), __builtin_fmaxf(b3, b4));
+                const bool out1 = lo1 > 1.0f || hi1 < -1.0f;        // source segment strictly outside the target wedge
+                cand = valid && !out1 && !out2;
             }
-            count += __popcll(pm);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (count >= 64) {
-                pair_queue_drain(q, head, 64, s_src, tseg, a.RtKinv_src, s_cam + 9, C_src, C_tgt, s_bits, wave, lane);
-                head = (head + 64) & (kPairQueue - 1);
-                count -= 64;
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                if (cand) qa[(ha + ca + __popcll(cm & ((1ull << lane) - 1ull))) & (kPairQueue - 1)] = (unsigned short)(k | (lane << 8));
+                ca += __popcll(cm);
+                n_l1 += __popcll(cm);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
         }
-        ha = (ha + n) & (kPairQueue - 1);
-        ca -= n;
-    };
-
-    for (int k = 0; k < ny; ++k) {
-        // level 1: wedge pre-test (broadcast reads of the source invariants)
-        const SrcBlockInv& sb = s_src[k];
-        bool cand = valid;
-        if (a.wedge_pretest) {
-            bool pa, pb;
-            const bool sa = same_side(line_numer(sb.s.epi_p1, t.q1), line_numer(sb.s.epi_p1, t.q2), sb.m1, pa);
-            const bool sbb = same_side(line_numer(sb.s.epi_p2, t.q1), line_numer(sb.s.epi_p2, t.q2), sb.m2, pb);
-            const bool out2 = sa && sbb && (pa == pb);          // target segment strictly outside the source wedge
-            bool pc, pd;
-            const bool sc = same_side(line_numer(t.epi_q1, sb.s.p1), line_numer(t.epi_q1, sb.s.p2), mq1, pc);
-            const bool sd = same_side(line_numer(t.epi_q2, sb.s.p1), line_numer(t.epi_q2, sb.s.p2), mq2, pd);
-            const bool out1 = sc && sd && (pc == pd);           // source segment strictly outside the target wedge
-            cand = valid && !out1 && !out2;
-        }
-        const unsigned long long cm = __ballot(cand);
-        if (cm) {
-            if (cand) qa[(ha + ca + __popcll(cm & ((1ull << lane) - 1ull))) & (kPairQueue - 1)] = (unsigned short)(k | (lane << 8));
-            ca += __popcll(cm);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (ca >= 64) drain_a(64);
+        for (;;) {
+            if (cb >= 64 || (last && ca == 0 && cb > 0)) {
+                // level 3: exact overlap test + triangulation (the reference's float sequence) for up to 64 queued pairs
+                const int n = min(cb, 64);
+                const unsigned key = qb[(hb + lane) & (kPairQueue - 1)];
+                const int kk = key & 0xff, origin = (key >> 8) & 63;
+                if (lane < n) {
+                    const SrcBlockInv& sb = s_src[kk];
+                    const TgtBlockInv& tb = tw[origin];
+                    f3 l2_p1, l2_p2, l1_q1, l1_q2;
+                    if (pair_overlap_test(sb.s, tb.t, l2_p1, l2_p2, l1_q1, l1_q2)) {
+                        const float4 d = pair_depths_pre(sb.ray1, sb.ray2, tb.ray1, tb.ray2, l2_p1, l2_p2, l1_q1, l1_q2, Rs, Rt, C_src, C_tgt);
+                        if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)         // cudawrapper.cu:931
+                            atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
+                    }
+                }
+                hb = (hb + n) & (kPairQueue - 1);
+                cb -= n;
+                continue;
+            }
+            if (ca >= 64 || (last && ca > 0)) {
+                // level 2: overlap-bound test for up to 64 queued pairs; survivors move on to the exact ring (cb < 64 here)
+                const int n = min(ca, 64);
+                const unsigned key = qa[(ha + lane) & (kPairQueue - 1)];
+                const int kk = key & 0xff, origin = (key >> 8) & 63;
+                bool pass = lane < n;
+                if (pass && use_iou) {
+                    const SrcBlockInv& sb = s_src[kk];
+                    const TgtBlockInv& tb = tw[origin];
+                    const f3 p1 = sb.s.p1, p2 = sb.s.p2, q1 = tb.t.q1, q2 = tb.t.q2;
+                    // interval of the epipolar lines of q1/q2 on the source segment, of p1/p2 on the target segment
+                    const float b1 = fline(tb.e1s, p1.x, p1.y), b2 = fline(tb.e1s, p2.x, p2.y);
+                    const float b3 = fline(tb.e2s, p1.x, p1.y), b4 = fline(tb.e2s, p2.x, p2.y);
+                    const float a1 = fline(sb.e1s, q1.x, q1.y), a2 = fline(sb.e1s, q2.x, q2.y);
+                    const float a3 = fline(sb.e2s, q1.x, q1.y), a4 = fline(sb.e2s, q2.x, q2.y);
+                    const float rb1 = __builtin_amdgcn_rcpf(b1 - b2), rb2 = __builtin_amdgcn_rcpf(b3 - b4);
+                    const float ra1 = __builtin_amdgcn_rcpf(a1 - a2), ra2 = __builtin_amdgcn_rcpf(a3 - a4);
+                    const float ls = sb.s.len, lt = tb.t.len;
+                    const float u1 = iou_upper(b1 * rb1, rb1, b3 * rb2, rb2, ls, ext * __builtin_amdgcn_rcpf(ls));
+                    const float u2 = iou_upper(a1 * ra1, ra1, a3 * ra2, ra2, lt, ext * __builtin_amdgcn_rcpf(lt));
+                    const bool rej = __builtin_fmaxf(u1, u2) < kMinOverlapUpper - kIouSlack || __builtin_fminf(u1, u2) < kMinOverlapLower - kIouSlack;
+                    pass = !rej;
+                }
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    if (pass) qb[(hb + cb + __popcll(pm & ((1ull << lane) - 1ull))) & (kPairQueue - 1)] = (unsigned short)key;
+                    cb += __popcll(pm);
+                    n_l2 += __popcll(pm);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                ha = (ha + n) & (kPairQueue - 1);
+                ca -= n;
+                continue;
+            }
+            break;
         }
     }
-    if (ca > 0) drain_a(ca);
-    if (count > 0) pair_queue_drain(q, head, count, s_src, tseg, a.RtKinv_src, s_cam + 9, C_src, C_tgt, s_bits, wave, lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < ny) a.mask[((size_t)j * a.S_src + (y0 + lane)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[lane * 4 + wave];
+    if (a.dbg) {
+        int nbits = lane < ny ? __popcll(s_bits[lane * 4 + wave]) : 0;
+        for (int o = 32; o > 0; o >>= 1) nbits += __shfl_down(nbits, o);
+        if (lane == 0) {
+            atomicAdd(&a.dbg[0], (unsigned long long)ny * (unsigned long long)min(64, width - (blockIdx.x * 256 + wave * 64) > 0 ? width - (blockIdx.x * 256 + wave * 64) : 0));
+            atomicAdd(&a.dbg[1], (unsigned long long)n_l1); atomicAdd(&a.dbg[2], (unsigned long long)n_l2); atomicAdd(&a.dbg[3], (unsigned long long)nbits);
+        }
+    }
 }
 
 // Stage 1b.  One wave per (src segment, tbm camera) row.

@@ -67,7 +67,7 @@ class Scene:
 
 def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234,
                noise_px: float = 0.5, width: int = 1920, height: int = 1080, f: float = 1500.0,
-               first_id: int = 0) -> Scene:
+               first_id: int = 0, step: float = 0.12) -> Scene:
     rng = SplitMix64(seed)
     K = np.array([[f, 0.0, width / 2.0], [0.0, f, height / 2.0], [0.0, 0.0, 1.0]])
 
@@ -75,7 +75,7 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
     cams = []
     jit = rng.normal(6 * n_views).reshape(n_views, 6)
     for i in range(n_views):
-        th = 0.12 * i
+        th = step * i
         turn = int(th // (2.0 * np.pi))
         r = 4.0 + 0.35 * turn
         h = 0.3 * np.sin(0.7 * i) + 0.25 * turn
@@ -123,7 +123,7 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
         views.append(dict(id=first_id + i, K=K.copy(), R=R.copy(), t=t.copy(), width=width, height=height,
                           segments=np.ascontiguousarray(segs, dtype=np.float32), sims=sims, gt=perm.copy()))
     params = dict(n_views=n_views, n_segments=n_segments, n_neighbors=n_neighbors, seed=seed,
-                  noise_px=noise_px, width=width, height=height, f=f)
+                  noise_px=noise_px, width=width, height=height, f=f, step=step)
     return Scene(views, np.concatenate([start, end], axis=1), params)
 
 

@@ -190,12 +190,14 @@ def test_window_verify_stress_against_all_pairs(gpu_ctx):
 
 
 def test_pair_pretest_is_conservative(gpu_ctx):
-    """The stage-1 wedge pre-test may only reject pairs the exact test rejects: with it on and off the number of raw
-    candidates and every output must be identical (several noise levels, ~10^8 pairs)."""
+    """The stage-1 filters (wedge test, depth-sign test) may only reject pairs the exact float sequence rejects: with
+    none, either or both of them the number of raw candidates and every output must be identical (several noise
+    levels and baselines -- tiny baselines make the triangulation rays nearly parallel --, ~10^8 pairs)."""
     from line3d_amd.synth import make_scene
     total_pairs = 0
-    for seed, noise, S in ((41, 0.5, 1500), (42, 3.0, 1200), (43, 0.0, 1000), (44, 10.0, 800)):
-        sc = make_scene(9, S, 8, seed=seed, noise_px=noise)
+    for seed, noise, S, step in ((41, 0.5, 1500, 0.12), (42, 3.0, 1200, 0.12), (43, 0.0, 1000, 0.12), (44, 10.0, 800, 0.12),
+                                 (45, 0.5, 1000, 0.004), (46, 1.0, 1000, 0.0005), (47, 0.5, 1000, 0.45)):
+        sc = make_scene(9, S, 8, seed=seed, noise_px=noise, step=step)
         o = op.OracleLine3D(matching_neighbors=8, use_collinearity=False)
         for v in sc.views:
             o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
@@ -206,16 +208,17 @@ def test_pair_pretest_is_conservative(gpu_ctx):
             o._fundamental(4, n)
         tr = dict(marshal=o.marshal_view(4), in_matches=np.zeros(0, op.MATCH_DTYPE))
         res = []
-        for on in (False, True):
-            gpu_ctx.set_pair_pretest(on)
+        for mask in (0, 1, 2, 3):
+            gpu_ctx.set_pair_pretest(mask)
             m, med, best = _run_view(gpu_ctx, tr)
             st = gpu_ctx.last_stats()
             res.append((m.tobytes(), med, best.tobytes(), st[1]))
             total_pairs += st[0]
-        gpu_ctx.set_pair_pretest(True)
-        assert res[0] == res[1], "seed %d" % seed
-        assert res[0][3] > 10000
-    assert total_pairs > 5e7
+        gpu_ctx.set_pair_pretest(3)
+        assert res[0] == res[1] == res[2] == res[3], "seed %d" % seed
+        if step == 0.12:
+            assert res[0][3] > 10000
+    assert total_pairs > 1e8
 
 
 def test_window_verify_global_scratch_variant(gpu_ctx, small_oracle, small_scene):
