@@ -338,7 +338,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
         if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
         va.stamps = c->stamps.as<unsigned long long>();
     }
-    if (c->verify_mode == 0 && N <= 255) {
+    if (c->verify_mode == 0 && verify_window_supported(N)) {
         // segments that fit the LDS image in one launch, the (few) bigger ones in a second launch on a global scratch
         int mfit = mmax;
         while (mfit > 64 && verify_window_lds_bytes(mfit, N) > verify_window_max_lds()) mfit = mfit * 3 / 4;

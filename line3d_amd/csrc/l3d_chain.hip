@@ -455,7 +455,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
         while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
         va.mmax = mmax;
-        if (c->verify_mode == 0) {
+        if (c->verify_mode == 0 && verify_window_supported(N)) {
             // one launch: segments that fit the LDS image, the ones that outgrow it (reverse matches are not in the estimate)
             // on a global scratch, and the per-segment epilogue (best hypothesis, kept count)
             va.skip_above = 1; va.only_above = -1; va.big = 2;

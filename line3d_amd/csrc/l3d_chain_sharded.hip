@@ -435,7 +435,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
     va.mmax = mmax;
     if (d.s1 > d.s0) {
-        if (c->verify_mode == 0) {
+        if (c->verify_mode == 0 && verify_window_supported(N)) {
             // one launch: LDS blocks, global-scratch blocks for segments that outgrow the LDS image, per-segment epilogue
             va.skip_above = 1; va.only_above = -1; va.big = 2;
             va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + 2;

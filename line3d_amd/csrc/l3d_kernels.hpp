@@ -91,6 +91,7 @@ void launch_verify(const VerifyArgs& a, hipStream_t st);
 void launch_verify_window(const VerifyArgs& a, hipStream_t st);
 size_t verify_window_lds_bytes(int mmax, int N);
 size_t verify_window_max_lds();
+bool verify_window_supported(int N);
 void verify_window_set_lds_budget(size_t bytes);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);
 void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream_t st);

@@ -14,6 +14,7 @@
 // store; everything else (3-D endpoints, directions, target lines) is recomputed from the depths with the same
 // float operations the reference uses, hence the same bits.
 #include <algorithm>
+#include <cstdlib>
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
@@ -93,8 +94,8 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const VWLds& L, co
         atomicMax(reinterpret_cast<int*>(&smax_wave[origin * a.N + cam]), __float_as_int(conf));
 }
 
-// NT threads per workgroup: 256 when the grid fills the chip, 1024 when only a few segments are verified per launch
-// (one rank's slice of a view in the sharded chain): the segment's hypotheses then run 16 waves wide instead of 4.
+// NT threads per workgroup: 256 when the grid fills the chip, 512 when only a few segments are verified per launch
+// (one rank's slice of a view in the sharded chain): the segment's hypotheses then run 8 waves wide instead of 4.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
 {
@@ -354,32 +355,33 @@ size_t verify_window_max_lds()
 {
     static size_t limit = 0;
     if (g_lds_budget_override) return g_lds_budget_override;
+    { static const char* e = getenv("L3D_VW_LDS"); if (e && atoi(e) > 0) return (size_t)atoi(e); }     // diagnostic: dynamic LDS budget in bytes
     if (limit) return limit;
-    int dev = 0, per_block = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || per_block <= 0) per_block = 64 * 1024;
-    size_t want = std::min<size_t>((size_t)per_block, 160 * 1024) - 8 * 1024 - 256;   // static LDS of the kernel (~8.3 KB) comes on top
-    if (want > 40 * 1024 &&
-        (hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess)) {
-        (void)hipGetLastError();
-        want = 40 * 1024;
-    }
+    // Measured on MI355X (config 2): the kernel is latency bound and gains more from resident workgroups than from a
+    // large LDS image -- 24 KB of dynamic LDS (+8 KB static -> 5 workgroups per CU, the VGPR limit) beats 48 KB by 8 %,
+    // and segments that outgrow the image lose nothing on the global-scratch (L2) variant.  So the budget is small.
+    size_t want = 24 * 1024;
     limit = want;
     return limit;
 }
+// The per-(hypothesis lane, camera) maxima alone need 1 KB per camera: beyond ~50 neighbours the kernel does not fit the
+// 64 KB a workgroup may ask for and the caller takes the all-pairs kernel.
+bool verify_window_supported(int N) { return verify_window_lds_bytes(64, N) <= 60 * 1024; }
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
     const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
-    // few segments (less than ~1.5 workgroups per CU): 16 waves per segment, if the wider per-lane maxima still fit
-    const bool wide = nseg <= 384 && verify_window_lds_bytes_nt(a.mmax, a.N, 1024) <= verify_window_max_lds();
-    if (wide) {
-        const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 1024) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 1024), verify_window_lds_bytes_big(a.N, 1024));
-        hipLaunchKernelGGL(k_verify_window<1024>, grid, dim3(1024), lds, st, a);
+    // few segments (about one workgroup per CU or less): 8 waves per segment, if the wider per-lane maxima still fit
+    const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
+    if (nseg <= 320 && lds512 <= 60 * 1024) {
+        static bool once = false;
+        if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024); (void)hipGetLastError(); }
+        hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);
     } else {
         const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 256) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
+        static bool once = false;
+        if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024); (void)hipGetLastError(); }
         hipLaunchKernelGGL(k_verify_window<256>, grid, dim3(256), lds, st, a);
     }
 }
