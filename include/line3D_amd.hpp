@@ -132,6 +132,41 @@ public:
             std::cerr << prefix_ << "no view with ID " << seg2D.camID() << "!" << std::endl;
         return float4{ o[0], o[1], o[2], o[3] };
     }
+    // line3D.h:91,94 -- `result` is written as given (the caller may have filtered it); formats as in line3D.cc:384-473
+    void save3DLinesAsSTL(std::list<L3DFinalLine3D>& result, std::string filename)
+    {
+        FILE* f = fopen(filename.c_str(), "w");
+        if (!f) return;
+        fprintf(f, "solid lineModel\n");
+        for (L3DFinalLine3D& l : result)
+            for (auto& sg : *l.segments3D()) {
+                fprintf(f, " facet normal 1.0e+000 0.0e+000 0.0e+000\n  outer loop\n");
+                fprintf(f, "   vertex %e %e %e\n", (double)sg.first[0], (double)sg.first[1], (double)sg.first[2]);
+                fprintf(f, "   vertex %e %e %e\n", (double)sg.second[0], (double)sg.second[1], (double)sg.second[2]);
+                fprintf(f, "   vertex %e %e %e\n", (double)sg.first[0], (double)sg.first[1], (double)sg.first[2]);
+                fprintf(f, "  endloop\n endfacet\n");
+            }
+        fprintf(f, "endsolid lineModel\n");
+        fclose(f);
+    }
+    void save3DLinesAsTXT(std::list<L3DFinalLine3D>& result, std::string filename)
+    {
+        FILE* f = fopen(filename.c_str(), "w");
+        if (!f) return;
+        for (L3DFinalLine3D& l : result) {
+            if (l.segments3D()->empty()) continue;
+            fprintf(f, "%zu ", l.segments3D()->size());
+            for (auto& sg : *l.segments3D())
+                fprintf(f, "%g %g %g %g %g %g ", (double)sg.first[0], (double)sg.first[1], (double)sg.first[2], (double)sg.second[0], (double)sg.second[1], (double)sg.second[2]);
+            fprintf(f, "%zu ", l.segments2D()->size());
+            for (L3DSegment2D& s2 : *l.segments2D()) {
+                const float4 c = getSegment2D(s2);
+                fprintf(f, "%u %u %g %g %g %g ", s2.camID(), s2.segID(), (double)c.x, (double)c.y, (double)c.z, (double)c.w);
+            }
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
     unsigned int numCameras() { return (unsigned int)l3d_line3d_num_cameras(h_); }   // line3D.h:98
     void reset() { l3d_line3d_reset(h_); }                                            // line3D.h:101
     l3d_line3d* handle() { return h_; }

@@ -279,6 +279,11 @@ int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, fl
 int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d);
 int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, double* seg3d, uint32_t* seg2d);
 int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4]);
+/* Line3D::save3DLinesAsSTL / save3DLinesAsTXT (line3D.h:91-95, line3D.cc:384-473; TXT format README.txt:177-185) for
+ * the current result, with the reference's number formatting ("%e" / stream default = "%g") */
+#define L3D_FORMAT_STL 0
+#define L3D_FORMAT_TXT 1
+int l3d_line3d_save_result(const l3d_line3d* h, const char* filename, int format);
 /* inspection */
 /* 1: matchViews through one l3d_compute_pairwise_matches call per view (the reference's control flow);
  * 0 (default): the device-resident chain (l3d_match_chain).  Results are identical. */

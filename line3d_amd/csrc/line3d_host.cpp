@@ -147,6 +147,7 @@ struct l3d_line3d {
     std::vector<std::vector<std::pair<uint32_t, Key>>> pot;    // per view index: (seg, other key), potential_correspondences_
     std::vector<std::pair<Key, Key>> pot_foreign;              // keys whose camera is not a view (early-return quirk)
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
+    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>> fin_buckets;   // finaliser scratch, reused across passes
     std::vector<std::vector<l3d_match>> saved;                 // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
@@ -509,10 +510,12 @@ void finalize_view_pot(std::vector<std::pair<uint32_t, Key>>& p, size_t S)
     for (auto& e : p) if (e.first >= S) { in_range = false; break; }
     if (!in_range) { std::sort(p.begin(), p.end()); p.erase(std::unique(p.begin(), p.end()), p.end()); return; }
     // stable counting sort on the segment, then the (short, nearly sorted) per-segment key lists
-    std::vector<uint32_t> cnt(S + 1, 0);
+    static thread_local std::vector<uint32_t> cnt;                      // scratch reused by the worker thread
+    static thread_local std::vector<std::pair<uint32_t, Key>> tmp;
+    cnt.assign(S + 1, 0);
     for (auto& e : p) cnt[e.first + 1]++;
     for (size_t i = 0; i < S; ++i) cnt[i + 1] += cnt[i];
-    std::vector<std::pair<uint32_t, Key>> tmp(p.size());
+    if (tmp.size() < p.size()) tmp.resize(p.size());
     for (auto& e : p) tmp[cnt[e.first]++] = e;
     size_t b = 0, w = 0;
     for (size_t s = 0; s < S; ++s) {
@@ -580,7 +583,8 @@ int prepare(L* h)
 void match_begin(L* h)
 {
     h->matched.clear();
-    h->pot.assign(h->vlist.size(), {});
+    h->pot.resize(h->vlist.size());                     // (capacities survive from an earlier pass)
+    for (auto& pv : h->pot) pv.clear();
     h->pot_foreign.clear();
     h->view_matches.clear();
     h->order.clear();
@@ -683,13 +687,16 @@ struct ChainFinalizer {
     L* h;
     std::vector<int> own_index;                     // per view index: its position in the processing order or -1
     std::vector<std::vector<int>> contributors;     // per view index: order indices of the views that list it as neighbour
-    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>> buckets;   // per order index: (target view index, entries)
+    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>>* buckets = nullptr;   // per order index: (target view index, entries); storage owned by the pipeline object
     std::vector<std::atomic<int>> pending;          // per view index: splits still missing
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (1 = merge, view index)
     bool done = false;
     std::vector<std::thread> workers;
+    bool timing = getenv("L3D_TIMING") != nullptr;
+    double t_split = 0, t_merge = 0, t_last_done = 0;
+    int n_split = 0, n_merge = 0;
 
     explicit ChainFinalizer(size_t nviews) : pending(nviews) {}
 
@@ -702,10 +709,15 @@ struct ChainFinalizer {
     {
         const View& v = h->views[h->order[k]];
         const std::vector<l3d_match>& lst = h->saved[k];
-        auto& bk = buckets[k];
+        auto& bk = (*buckets)[k];
         const std::vector<uint32_t>& nbs = h->visual_neighbors.find(v.id)->second;
-        bk.clear();
-        for (uint32_t nb : nbs) { const View* o = h->find_view(nb); if (o) bk.emplace_back((size_t)o->index, std::vector<std::pair<uint32_t, Key>>()); }
+        {   // same targets as in the previous pass: keep the entry vectors' capacity
+            size_t nb_ok = 0;
+            for (uint32_t nb : nbs) if (h->find_view(nb)) ++nb_ok;
+            if (bk.size() != nb_ok) bk.assign(nb_ok, {});
+            size_t i = 0;
+            for (uint32_t nb : nbs) { const View* o = h->find_view(nb); if (o) { bk[i].first = (size_t)o->index; bk[i].second.clear(); ++i; } }
+        }
         std::vector<int> slot_of(nbs.size(), -1);
         { int sidx = 0; for (size_t c = 0; c < nbs.size(); ++c) if (h->find_view(nbs[c])) slot_of[c] = sidx++; }
         size_t last_c = (size_t)-1; uint32_t last_cam = 0xffffffffu;
@@ -732,7 +744,7 @@ struct ChainFinalizer {
         std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
         if (own_index[vi] < 0) p.clear();               // otherwise split(own) has put the forward entries there
         for (int k : contributors[vi])
-            for (auto& e : buckets[(size_t)k]) if (e.first == vi) p.insert(p.end(), e.second.begin(), e.second.end());
+            for (auto& e : (*buckets)[(size_t)k]) if (e.first == vi) p.insert(p.end(), e.second.begin(), e.second.end());
         finalize_view_pot(p, (size_t)v.S());
     }
     void start(unsigned nthreads)
@@ -748,7 +760,9 @@ struct ChainFinalizer {
                         job = queue.back();
                         queue.pop_back();
                     }
+                    const double tj0 = now_s();
                     if (job.first == 0) split(job.second); else merge(job.second);
+                    if (timing) { const double dt = now_s() - tj0; std::lock_guard<std::mutex> lk(mu); (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s(); }
                 }
             });
     }
@@ -764,6 +778,8 @@ struct ChainFinalizer {
         cv.notify_all();
         for (auto& t : workers) t.join();
         workers.clear();
+        if (timing) fprintf(stderr, "[l3d finaliser] %d splits %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", n_split, t_split * 1e3,
+                            n_split ? t_split * 1e3 / n_split : 0.0, n_merge, t_merge * 1e3, n_merge ? t_merge * 1e3 / n_merge : 0.0);
     }
 };
 
@@ -839,7 +855,9 @@ void start_finalizer(L* h, ChainPlan& P)
     P.fin.reset(new ChainFinalizer(nvl));
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
-    fin.own_index.assign(nvl, -1); fin.contributors.assign(nvl, {}); fin.buckets.assign(n, {});
+    fin.own_index.assign(nvl, -1); fin.contributors.assign(nvl, {});
+    fin.buckets = &h->fin_buckets;                      // (capacities survive from an earlier pass)
+    if (h->fin_buckets.size() != n) h->fin_buckets.assign(n, {});
     for (size_t vi = 0; vi < nvl; ++vi) fin.pending[vi] = 0;
     for (size_t k = 0; k < n; ++k) {
         const View& v = h->views[h->order[k]];
@@ -1505,6 +1523,42 @@ int l3d_line3d_get_result(const l3d_line3d* h, int* line_n3d, int* line_n2d, dou
     return L3D_OK;
 }
 // Line3D::getSegment2D, line3D.cc:2004-2013
+// Line3D::save3DLinesAsSTL / save3DLinesAsTXT (line3D.cc:384-473; TXT format: README.txt:177-185) for the current result.
+// Numbers are formatted the way the reference formats them: "%e" in the STL file, the stream default (6 significant
+// digits, "%g") in the TXT file; lines without 3-D segments are skipped in the TXT file only.
+int l3d_line3d_save_result(const l3d_line3d* h, const char* filename, int format)
+{
+    if (!h || !filename || (format != L3D_FORMAT_STL && format != L3D_FORMAT_TXT)) return L3D_ERR_INVALID;
+    FILE* f = fopen(filename, "w");
+    if (!f) return L3D_ERR_INVALID;
+    if (format == L3D_FORMAT_STL) {
+        fprintf(f, "solid lineModel\n");
+        for (auto& l : h->result)
+            for (auto& sg : l.segs3D) {
+                fprintf(f, " facet normal 1.0e+000 0.0e+000 0.0e+000\n  outer loop\n");
+                fprintf(f, "   vertex %e %e %e\n", sg.first.x, sg.first.y, sg.first.z);
+                fprintf(f, "   vertex %e %e %e\n", sg.second.x, sg.second.y, sg.second.z);
+                fprintf(f, "   vertex %e %e %e\n", sg.first.x, sg.first.y, sg.first.z);
+                fprintf(f, "  endloop\n endfacet\n");
+            }
+        fprintf(f, "endsolid lineModel\n");
+    } else {
+        for (auto& l : h->result) {
+            if (l.segs3D.empty()) continue;
+            fprintf(f, "%zu ", l.segs3D.size());
+            for (auto& sg : l.segs3D) fprintf(f, "%g %g %g %g %g %g ", sg.first.x, sg.first.y, sg.first.z, sg.second.x, sg.second.y, sg.second.z);
+            fprintf(f, "%zu ", l.segs2D.size());
+            for (Key k : l.segs2D) {
+                float c[4] = { 0, 0, 0, 0 };
+                (void)l3d_line3d_get_segment2D(h, kcam(k), kseg(k), c);
+                fprintf(f, "%u %u %g %g %g %g ", kcam(k), kseg(k), (double)c[0], (double)c[1], (double)c[2], (double)c[3]);
+            }
+            fprintf(f, "\n");
+        }
+    }
+    return fclose(f) == 0 ? L3D_OK : L3D_ERR_INVALID;
+}
+
 int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4])
 {
     if (!h) return L3D_ERR_INVALID;

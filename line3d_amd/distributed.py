@@ -148,6 +148,9 @@ class RcclLink:
         import ctypes as C
         import os
         import torch
+        if world == 1:      # a single-rank communicator needs no network: keep RCCL's bootstrap away from interface probing
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self.lib = C.CDLL(path)
 

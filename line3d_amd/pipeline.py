@@ -100,6 +100,13 @@ class Line3D:
         self.lib.l3d_line3d_get_segment2D(self.h, C.c_uint32(camID), C.c_uint32(segID), o)
         return tuple(o)
 
+    # line3D.h:91-95 -- result writers (formats: line3D.cc:384-473, README.txt:177-185)
+    def save3DLinesAsSTL(self, filename: str):
+        self._chk(self.lib.l3d_line3d_save_result(self.h, filename.encode(), C.c_int(0)))
+
+    def save3DLinesAsTXT(self, filename: str):
+        self._chk(self.lib.l3d_line3d_save_result(self.h, filename.encode(), C.c_int(1)))
+
     def numCameras(self):
         return self.lib.l3d_line3d_num_cameras(self.h)
 

@@ -690,6 +690,36 @@ class OracleLine3D:
         return aligned
 
 
+def save_result_txt(o, path):
+    """Line3D::save3DLinesAsTXT (line3D.cc:434-473; README.txt:177-185): stream-default formatting = "%g"."""
+    with open(path, "w") as f:
+        for seg2, seg3 in o.result:
+            if len(seg3) == 0:
+                continue
+            f.write("%d " % len(seg3))
+            for P, Q in seg3:
+                f.write("%g %g %g %g %g %g " % (P[0], P[1], P[2], Q[0], Q[1], Q[2]))
+            f.write("%d " % len(seg2))
+            for cam, seg in seg2:
+                c = o.views[cam].segments[seg]
+                f.write("%d %d %g %g %g %g " % (cam, seg, c[0], c[1], c[2], c[3]))
+            f.write("\n")
+
+
+def save_result_stl(o, path):
+    """Line3D::save3DLinesAsSTL (line3D.cc:384-431): one degenerate facet per 3-D segment, "%e"."""
+    with open(path, "w") as f:
+        f.write("solid lineModel\n")
+        for _seg2, seg3 in o.result:
+            for P, Q in seg3:
+                f.write(" facet normal 1.0e+000 0.0e+000 0.0e+000\n  outer loop\n")
+                f.write("   vertex %e %e %e\n" % (P[0], P[1], P[2]))
+                f.write("   vertex %e %e %e\n" % (Q[0], Q[1], Q[2]))
+                f.write("   vertex %e %e %e\n" % (P[0], P[1], P[2]))
+                f.write("  endloop\n endfacet\n")
+        f.write("endsolid lineModel\n")
+
+
 def run_scene(scene, matching_neighbors, perform_diffusion=False, libm=False, use_collinearity=True):
     o = OracleLine3D(matching_neighbors=matching_neighbors, libm=libm, use_collinearity=use_collinearity)
     for v in scene.views:

@@ -279,3 +279,36 @@ def test_native_sharded_run_replayed_ranks(small_scene, small_oracle):
     _check_against_oracle(ls[0], small_oracle)
     for l in ls:
         l.close()
+
+
+def test_result_writers_match_oracle(small_scene, small_oracle, tmp_path):
+    """save3DLinesAsTXT / save3DLinesAsSTL (line3D.cc:384-473) through the C ABI against the oracle's writers: same
+    lines, same ids, same 6-digit numbers (up to the 1e-4 endpoint tolerance), readable by line3d_amd.io.load_txt."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.io import load_txt
+    l = Line3D("", matchingNeighbors=6)
+    load_scene(l, small_scene)
+    l.compute3Dmodel(False)
+    a, b = str(tmp_path / "gpu.txt"), str(tmp_path / "oracle.txt")
+    l.save3DLinesAsTXT(a)
+    op.save_result_txt(small_oracle, b)
+    ga, gb = load_txt(a), load_txt(b)
+    assert len(ga) == len(gb) > 0
+    key = lambda ln: tuple((c, s) for c, s, _ in ln[0])
+    ea, eb = {key(x): x for x in ga}, {key(x): x for x in gb}
+    assert set(ea) == set(eb)
+    for k in ea:
+        (s2a, s3a), (s2b, s3b) = ea[k], eb[k]
+        assert [c for _, _, c in s2a] == [c for _, _, c in s2b]                 # 2-D residual coordinates: same floats, same text
+        assert len(s3a) == len(s3b)
+        for (pa, qa), (pb, qb) in zip(s3a, s3b):
+            assert np.allclose(pa, pb, atol=2e-4, rtol=1e-5) and np.allclose(qa, qb, atol=2e-4, rtol=1e-5)
+    same = sum(1 for x, y in zip(sorted(open(a).read().splitlines()), sorted(open(b).read().splitlines())) if x == y)
+    assert same >= 0.9 * len(ga), "only %d of %d text lines identical" % (same, len(ga))
+    sa, sb = str(tmp_path / "gpu.stl"), str(tmp_path / "oracle.stl")
+    l.save3DLinesAsSTL(sa)
+    op.save_result_stl(small_oracle, sb)
+    ta, tb = open(sa).read().splitlines(), open(sb).read().splitlines()
+    assert len(ta) == len(tb) and ta[0] == tb[0] == "solid lineModel" and ta[-1] == tb[-1] == "endsolid lineModel"
+    assert sum(1 for x in ta if x.startswith("   vertex")) == 3 * sum(len(s3) for _, s3 in ga)
+    l.close()

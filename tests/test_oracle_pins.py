@@ -185,3 +185,34 @@ def test_pipeline_recovers_ground_truth_lines(small_scene, small_oracle):
         vals, counts = np.unique(ids, return_counts=True)
         pure += counts.max() >= 0.8 * len(ids)
     assert pure >= 0.9 * len(small_oracle.result)
+
+
+def test_txt_result_format_round_trip(tmp_path):
+    """README.txt:177-185 / line3D.cc:434-473: the oracle's TXT writer and the dependency-free loader agree; lines without
+    3-D segments are skipped; numbers carry 6 significant digits."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from line3d_amd.io import load_txt
+
+    class V:
+        def __init__(self, segs):
+            self.segments = np.asarray(segs, dtype=np.float32)
+
+    class O:
+        pass
+
+    o = O()
+    o.views = {3: V([[1.5, 2.25, 300.125, 4.0]]), 7: V([[0, 0, 1, 1], [10.5, 20.5, 30.5, 40.5]])}
+    o.result = [([(3, 0), (7, 1)], [(np.array([0.1234567, -2.0, 3e-7]), np.array([1.0, 2.0, 3.0]))]),
+                ([(7, 0)], [])]
+    path = str(tmp_path / "r.txt")
+    op.save_result_txt(o, path)
+    text = open(path).read()
+    assert text == "1 0.123457 -2 3e-07 1 2 3 2 3 0 1.5 2.25 300.125 4 7 1 10.5 20.5 30.5 40.5 \n"
+    got = load_txt(path)
+    assert len(got) == 1 and [(c, s) for c, s, _ in got[0][0]] == [(3, 0), (7, 1)]
+    assert np.allclose(got[0][1][0][0], [0.123457, -2.0, 3e-07])
+    stl = str(tmp_path / "r.stl")
+    op.save_result_stl(o, stl)
+    lines = open(stl).read().splitlines()
+    assert lines[0] == "solid lineModel" and lines[3] == "   vertex 1.234567e-01 -2.000000e+00 3.000000e-07" and lines[-1] == "endsolid lineModel"
