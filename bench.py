@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-segments", type=int, default=1500)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) rest of compute3Dmodel after the timed passes")
     return ap.parse_args()
 
 
@@ -62,7 +63,34 @@ def cpu_baseline(scene, n_neighbors, sample_segments):
         mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"],
         3.5, 10.0, mv["spatial_k"], seg_range=(0, sample_segments), want_stats=True)
     dt = time.time() - t0
-    return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port",
+    # the same formulation on all host threads: one source-segment range of the same view per thread (the C oracle releases
+    # the GIL), bounded to ~the same wall time
+    import threading
+    nthreads = max(1, min(os.cpu_count() or 1, 64))
+    S = len(mv["src_segs"])
+    per = max(1, min(S // nthreads, max(1, sample_segments // 2)))
+    res = [None] * nthreads
+
+    def work(i):
+        s0 = (i * per) % max(1, S - per + 1)
+        _m, _med, st = op.compute_pairwise_matches(
+            o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
+            mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"],
+            3.5, 10.0, mv["spatial_k"], seg_range=(s0, s0 + per), want_stats=True)
+        res[i] = st[3]
+
+    all_threads = None
+    if nthreads > 1 and per * nthreads <= 8 * S:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t1 = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dta = time.time() - t1
+        all_threads = dict(value=float(sum(r for r in res if r)) / dta, cores=nthreads, seconds=dta,
+                           sample="%d threads x %d source segments of view 0" % (nthreads, per))
+    return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
                 sample="view 0 of the bench scene, first %d of %d source segments x %d neighbours: %d pairs, %d raw candidates, "
                        "%.3g verify inner iterations, %.1f s on 1 thread (oracle/l3d_oracle.c, reference formulation)"
                        % (sample_segments, len(mv["src_segs"]), len(mv["tbm"]), int(stats[3]), int(stats[0]), stats[2], dt),
@@ -218,8 +246,16 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
             if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/README.md)
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            valu = None
+            vpath = os.path.join(ROOT, "profiles", "r1_valu.json")
+            if os.path.exists(vpath) and avg_ms > 0:   # wave-level VALU instructions per launch (PMC pass of this same command)
+                vi = json.load(open(vpath)).get(name, {}).get("valu_wave_insts_per_launch")
+                if vi:
+                    peak_issue = 256 * 4 * 2.4e9 / 4.0      # one wave64 VALU instruction per SIMD every 4 cycles
+                    valu = dict(wave_insts_per_launch=vi, issue_frac=vi / (avg_ms * 1e-3) / peak_issue,
+                                note="SQ_INSTS_VALU per launch / launch duration / (256 CUs x 4 SIMDs x 2.4 GHz / 4)")
             roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
-                        traffic=traffic, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
+                        traffic=traffic, valu=valu, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
                         note="the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
                              "view and stay in L2/LDS; kernels_ms = per-kernel time of one untimed pass with every kernel bracketed; "
                              "in the timed region only the dominant kernel carries HIP events",
@@ -236,6 +272,18 @@ def main():
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))
         if roof:
             out["roofline"] = roof
+        if dist is None and not args.no_extras:
+            # the rest of compute3Dmodel on the same scene, once, untimed w.r.t. `value` (affinity edges/s,
+            # diffusion): greedy selection + affinity fill (batched similarity on the GPU) + clustering + line fit
+            ex = {}
+            for diff in (False, True):
+                t1 = time.perf_counter()
+                l3d.finish(diff)
+                st2 = l3d.stats()
+                ex["diffusion" if diff else "no_diffusion"] = dict(finish_s=time.perf_counter() - t1, affinity_s=st2["t_affinity"], cluster_s=st2["t_cluster"],
+                                                                   affinity_edges=st2["edges"], lines=st2["lines"],
+                                                                   affinity_edges_per_s=st2["edges"] / st2["t_affinity"] if st2["t_affinity"] > 0 else None)
+            out["rest_of_compute3Dmodel"] = ex
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments)
         print(json.dumps(out))

@@ -30,12 +30,13 @@ def load(path, counter):
     return {k: (tot[k] / max(1, len(launches[k])), len(launches[k])) for k in tot}
 
 
-f = load(sys.argv[1], "FETCH_SIZE")
-w = load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(f) | set(w)):
-    fk, n = f.get(k, (0.0, 0))
-    wk, n2 = w.get(k, (0.0, 0))
-    out[k] = dict(FETCH_SIZE_KB_per_launch=fk, WRITE_SIZE_KB_per_launch=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, launches=max(n, n2),
-                  note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, per-launch average")
-json.dump(out, sys.stdout, indent=1)
+if __name__ == "__main__":
+    f = load(sys.argv[1], "FETCH_SIZE")
+    w = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fk, n = f.get(k, (0.0, 0))
+        wk, n2 = w.get(k, (0.0, 0))
+        out[k] = dict(FETCH_SIZE_KB_per_launch=fk, WRITE_SIZE_KB_per_launch=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, launches=max(n, n2),
+                      note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, per-launch average")
+    json.dump(out, sys.stdout, indent=1)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""VALU instructions per launch per kernel from a rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES pass:
+   make_valu.py <counter_collection.csv> > profiles/<round>_valu.json"""
+import json
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+import collections
+import csv
+
+from make_traffic import short  # noqa: E402  (same kernel-name mapping)
+
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = short(r["Kernel_Name"])
+    tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    launches[k].add(r["Dispatch_Id"])
+out = {k: dict(valu_wave_insts_per_launch=tot[k].get("SQ_INSTS_VALU", 0.0) / max(1, len(launches[k])),
+               waves_per_launch=tot[k].get("SQ_WAVES", 0.0) / max(1, len(launches[k])), launches=len(launches[k]),
+               note="SQ_INSTS_VALU / SQ_WAVES summed over all shader engines, per-launch average")
+       for k in sorted(tot)}
+json.dump(out, sys.stdout, indent=1)
