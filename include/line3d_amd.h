@@ -219,6 +219,9 @@ int l3d_last_stats(l3d_ctx* ctx, double stats[4]);
 
 /* contract math exported for tests (device evaluation of c_expf / c_acosf / c_acos) */
 int l3d_test_contract_math(l3d_ctx* ctx, const float* x, int n, float* out_expf, float* out_acosf, double* out_acos);
+/* the squared-distance gate threshold T(u) = largest float whose correctly rounded square root is <= u:
+ * the ulp walk and the closed form the kernels use, evaluated on the device (tests) */
+int l3d_test_sq_threshold(l3d_ctx* ctx, const float* u, int n, float* out_walk, float* out_closed);
 
 /* =================================================================================================
  * Host pipeline behind the reference's public operator interface, class L3D::Line3D

@@ -98,6 +98,12 @@ class Context:
     def profile_all(self):
         return {k: self.profile_get(k) for k in self.lib.l3d_profile_names().decode().split(";")}
 
+    def test_sq_threshold(self, u: np.ndarray):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        a, b = np.zeros_like(u), np.zeros_like(u)
+        self._chk(self.lib.l3d_test_sq_threshold(self.h, _p(u), C.c_int(len(u)), _p(a), _p(b)))
+        return a, b
+
     def set_verify_lds_budget(self, nbytes: int):
         self._chk(self.lib.l3d_set_verify_lds_budget(C.c_size_t(nbytes)))
 

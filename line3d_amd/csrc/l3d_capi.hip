@@ -530,6 +530,20 @@ int l3d_similarity_coll3D_batch(l3d_ctx* c, const l3d_hypothesis* hyp, int n_hyp
     return L3D_OK;
 }
 
+int l3d_test_sq_threshold(l3d_ctx* c, const float* u, int n, float* out_walk, float* out_closed)
+{
+    if (!c || n < 0 || (n > 0 && (!u || !out_walk || !out_closed))) return L3D_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->g0.reserve((size_t)n * 4 + 16)); HIPCHK(c, c->g1.reserve((size_t)n * 4 + 16)); HIPCHK(c, c->g2.reserve((size_t)n * 4 + 16));
+    HIPCHK(c, hipMemcpyAsync(c->g0.p, u, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    launch_test_sqthr(c->g0.as<float>(), n, c->g1.as<float>(), c->g2.as<float>(), st);
+    HIPCHK(c, hipMemcpyAsync(out_walk, c->g1.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(out_closed, c->g2.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return L3D_OK;
+}
+
 int l3d_test_contract_math(l3d_ctx* c, const float* x, int n, float* e, float* ac, double* acd)
 {
     if (!c || n < 0 || (n > 0 && (!x || !e || !ac || !acd))) return L3D_ERR_INVALID;

@@ -139,6 +139,16 @@ L3D_HD bool pair_overlap_test(const SrcPairInv& s, const TgtPairInv& t, f3& l2_p
     return __builtin_fminf(overlap1, overlap2) > kMinOverlapLower && __builtin_fmaxf(overlap1, overlap2) > kMinOverlapUpper;
 }
 
+// Only the four intersection points of pair_overlap_test (:563-575), for pairs already known to pass it.
+L3D_HD void pair_intersections(const SrcPairInv& s, const TgtPairInv& t, f3& l2_p1, f3& l2_p2, f3& l1_q1, f3& l1_q2)
+{
+    bool v;
+    l2_p1 = hom_normalize(cross(t.line2, s.epi_p1), v);
+    l2_p2 = hom_normalize(cross(t.line2, s.epi_p2), v);
+    l1_q1 = hom_normalize(cross(s.line1, t.epi_q1), v);
+    l1_q2 = hom_normalize(cross(s.line1, t.epi_q2), v);
+}
+
 // The four triangulated depths (:590-601).  RtKinv_src / RtKinv_tgt 3x3 row-major.
 L3D_HD float4 pair_depths(const SrcPairInv& s, const TgtPairInv& t, f3 l2_p1, f3 l2_p2, f3 l1_q1, f3 l1_q2,
                           const float* RtKinv_src, const float* RtKinv_tgt, f3 C_src, f3 C_tgt)
@@ -168,7 +178,7 @@ L3D_HD float4 pair_depths_pre(f3 ray_p1, f3 ray_p2, f3 ray_q1, f3 ray_q2, f3 l2_
 
 // Largest float x with sqrtf(x) <= u (u >= 0): lets the verification gate compare squared
 // distances and stay bit-identical to `length(P-Q) > unc` (cudawrapper.cu:396-400).
-L3D_HD float sq_threshold(float u)
+L3D_HD float sq_threshold_walk(float u)
 {
     union { float f; uint32_t i; } t;
     t.f = u * u;
@@ -180,6 +190,24 @@ L3D_HD float sq_threshold(float u)
         n.i = t.i + 1;
         if (__builtin_sqrtf(n.f) <= u) t.i = n.i; else break;
     }
+    return t.f;
+}
+
+// The same threshold without the walk.  sqrtf is the correctly rounded square root, so sqrtf(x) <= u  <=>  sqrt(x) lies
+// below the midpoint u + h between u and the next float above it (a tie would need x = (u+h)^2, which has ~50
+// significant bits and is not a float)  <=>  x < (u+h)^2.  u + h has 25 significant bits, so its square is exact in
+// double; the threshold is the largest float strictly below it.  Equal to sq_threshold_walk for every input (tests).
+L3D_HD float sq_threshold(float u)
+{
+    union { float f; uint32_t i; } t, up;
+    t.f = u * u;
+    if (!(t.f == t.f) || t.f >= 3.0e38f || !(u >= 0.0f)) return sq_threshold_walk(u);
+    up.f = u;
+    up.i += 1;                                        // next float above u (u >= 0, finite)
+    const double m = (double)u + ((double)up.f - (double)u) * 0.5;
+    const double M = m * m;
+    t.f = (float)M;                                   // round to nearest ...
+    if ((double)t.f >= M) t.i -= 1;                   // ... then step below (M > 0, so t.f > 0 here)
     return t.f;
 }
 

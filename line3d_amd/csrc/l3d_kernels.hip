@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
     const SrcPairInv s = make_src_inv(a.src_segs[y], a.F + cam * 9);
     const f3 C_tgt = mk3(a.centers[cam * 3], a.centers[cam * 3 + 1], a.centers[cam * 3 + 2]);
     const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    const f3 ray_p1 = normalize(mat3_apply(a.RtKinv_src, s.p1)), ray_p2 = normalize(mat3_apply(a.RtKinv_src, s.p2));   // row invariants
     const int slot0 = row_start[y * a.N + cam];
 
     for (int k = lane; k < total; k += 64) {
@@ -350,9 +351,11 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[wave][mid] <= k) lo = mid; else hi = mid; }
         const int x = lo * 64 + select_bit(s_words[wave][lo], k - s_pref[wave][lo]);
         const TgtPairInv t = make_tgt_inv(a.tgt_segs[toff + x], a.F + cam * 9);
+        // the bit is set, so the overlap test passed: only its intersection points are needed again
         f3 l2_p1, l2_p2, l1_q1, l1_q2;
-        pair_overlap_test(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
-        const float4 d = pair_depths(s, t, l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
+        pair_intersections(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
+        const float4 d = pair_depths_pre(ray_p1, ray_p2, normalize(mat3_apply(a.RtKinv + cam * 9, t.q1)), normalize(mat3_apply(a.RtKinv + cam * 9, t.q2)),
+                                         l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
         cand_meta[slot0 + k] = make_uint2((unsigned)x, (unsigned)cam);
         cand_depths[slot0 + k] = d;
     }
@@ -739,6 +742,12 @@ __global__ void k_similarity(const Hypothesis* __restrict__ hyp, const int2* __r
     sim[k] = s <= 0.01f ? 0.0f : s;
 }
 
+__global__ void k_test_sqthr(const float* __restrict__ u, int n, float* __restrict__ walk, float* __restrict__ fast)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { walk[i] = sq_threshold_walk(u[i]); fast[i] = sq_threshold(u[i]); }
+}
+
 __global__ void k_test_math(const float* __restrict__ x, int n, float* __restrict__ e, float* __restrict__ ac, double* __restrict__ acd)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -810,6 +819,10 @@ void launch_diffusion_step(const float4* P, const float4* W, const int* P_rows, 
 void launch_similarity(const Hypothesis* hyp, const int2* pairs, int n, float sigma_a, float two_log, float* sim, hipStream_t st)
 {
     if (n) hipLaunchKernelGGL(k_similarity, dim3((n + 255) / 256), dim3(256), 0, st, hyp, pairs, n, sigma_a, two_log, sim);
+}
+void launch_test_sqthr(const float* u, int n, float* walk, float* fast, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_test_sqthr, dim3((n + 255) / 256), dim3(256), 0, st, u, n, walk, fast);
 }
 void launch_test_math(const float* x, int n, float* e, float* ac, double* acd, hipStream_t st)
 {

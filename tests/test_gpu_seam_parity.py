@@ -240,3 +240,17 @@ def test_window_verify_global_scratch_variant(gpu_ctx, small_oracle, small_scene
         l.close()
     finally:
         gpu_ctx.set_verify_lds_budget(0)
+
+
+def test_sq_threshold_closed_form_equals_walk(gpu_ctx):
+    """T(u) = largest float x with sqrtf(x) <= u: the closed form used by the verification kernels against the ulp walk,
+    and both against the definition evaluated with numpy's correctly rounded float32 sqrt."""
+    rng = np.random.default_rng(7)
+    u = np.concatenate([np.exp(rng.uniform(-40, 40, 200000)), rng.uniform(0, 1, 50000), 2.0 ** rng.integers(-60, 60, 2000),
+                        np.array([0.0, 1e-45, 1e-38, 1.17549435e-38, 1.0, 3.0, 1.8e19])]).astype(np.float32)
+    walk, closed = gpu_ctx.test_sq_threshold(u)
+    assert walk.tobytes() == closed.tobytes()
+    sel = np.isfinite(closed) & (closed < 1e38) & (closed > 1e-36)
+    T = closed[sel]
+    assert np.all(np.sqrt(T) <= u[sel])
+    assert np.all(np.sqrt(np.nextafter(T, np.float32(np.inf))) > u[sel])
