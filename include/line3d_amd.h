@@ -296,6 +296,25 @@ int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_mat
 int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes);
 int l3d_line3d_stats(const l3d_line3d* h, double* stats12);
 
+/* =================================================================================================
+ * SfM front ends of the reference's drivers: VisualSfM NVM (main_vsfm.cpp:121-223) and bundler
+ * bundle.rd.out (main_bundler.cpp:110-204), reduced to what feeds Line3D::addImage -- focal length, R, t, distortion
+ * coefficients, observed world point ids per camera.  Image decoding / undistortion / LSD stay outside.
+ * A failed read still returns a scene object carrying the message (l3d_sfm_last_error); free it with l3d_sfm_free.
+ * ================================================================================================= */
+typedef struct l3d_sfm_scene l3d_sfm_scene;
+int l3d_sfm_read_nvm(const char* path, l3d_sfm_scene** out);
+int l3d_sfm_read_bundler(const char* path, l3d_sfm_scene** out);
+void l3d_sfm_free(l3d_sfm_scene* scene);
+const char* l3d_sfm_last_error(const l3d_sfm_scene* scene);
+int l3d_sfm_num_cameras(const l3d_sfm_scene* scene);
+int l3d_sfm_num_points(const l3d_sfm_scene* scene);
+int l3d_sfm_camera(const l3d_sfm_scene* scene, int i, double* focal, double dist[2], double R[9], double t[3], int* n_worldpoints);
+const char* l3d_sfm_camera_name(const l3d_sfm_scene* scene, int i);
+int l3d_sfm_camera_worldpoints(const l3d_sfm_scene* scene, int i, uint32_t* ids);
+/* the drivers' K from a focal length and the image size (main_vsfm.cpp:232-241): [[f,0,w/2],[0,f,h/2],[0,0,1]] */
+void l3d_sfm_intrinsics(double focal, unsigned int width, unsigned int height, double K[9]);
+
 #ifdef __cplusplus
 }
 #endif

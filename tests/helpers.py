@@ -24,3 +24,59 @@ def assert_lines_equal(got, exp, tol=1e-4):
             worst = max(worst, float(np.max(np.abs(np.array(ga) - np.array(ea)))), float(np.max(np.abs(np.array(gb) - np.array(eb)))))
     assert worst <= tol, "endpoint mismatch %g > %g" % (worst, tol)
     return worst
+
+
+# ---- synthetic SfM files (test data writers; the product only reads these formats) ----------------------------------
+def synth_worldpoints(scene, n_points=400, seed=5):
+    """Random 3-D points in the scene box and, per point, the cameras that see it: list of (xyz, [(cam, key, x, y)...])."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-1, -0.6, -1], [1, 0.6, 1], (n_points, 3))
+    out = []
+    for X in pts:
+        obs = []
+        for ci, v in enumerate(scene.views):
+            xc = v["R"] @ X + v["t"]
+            if xc[2] <= 0.1:
+                continue
+            p = v["K"] @ xc
+            x, y = p[0] / p[2], p[1] / p[2]
+            if 0 <= x < v["width"] and 0 <= y < v["height"]:
+                obs.append((ci, len(obs), x - v["width"] / 2.0, y - v["height"] / 2.0))
+        out.append((X, obs))
+    return out
+
+
+def _quat_from_R(R):
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    x = (R[2, 1] - R[1, 2]) / (4.0 * w)
+    y = (R[0, 2] - R[2, 0]) / (4.0 * w)
+    z = (R[1, 0] - R[0, 1]) / (4.0 * w)
+    return w, x, y, z
+
+
+def write_nvm(path, scene, points):
+    with open(path, "w") as f:
+        f.write("NVM_V3\n\n%d\n" % len(scene.views))
+        for i, v in enumerate(scene.views):
+            w, x, y, z = _quat_from_R(v["R"])
+            Cc = -v["R"].T @ v["t"]
+            f.write("img_%04d.jpg %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g 0 0\n" % (i, v["K"][0, 0], w, x, y, z, Cc[0], Cc[1], Cc[2]))
+        f.write("\n%d\n" % len(points))
+        for X, obs in points:
+            f.write("%.17g %.17g %.17g 128 128 128 %d " % (X[0], X[1], X[2], len(obs)) + " ".join("%d %d %.3f %.3f" % o for o in obs) + "\n")
+        f.write("\n0\n")
+
+
+def write_bundler(path, scene, points):
+    with open(path, "w") as f:
+        f.write("# Bundle file v0.3\n%d %d\n" % (len(scene.views), len(points)))
+        for v in scene.views:
+            R, t = v["R"].copy(), v["t"].copy()
+            R[1:] *= -1.0
+            t[1:] *= -1.0
+            f.write("%.17g 0 0\n" % v["K"][0, 0])
+            for r in range(3):
+                f.write("%.17g %.17g %.17g\n" % tuple(R[r]))
+            f.write("%.17g %.17g %.17g\n" % tuple(t))
+        for X, obs in points:
+            f.write("%.17g %.17g %.17g\n128 128 128\n%d " % (X[0], X[1], X[2], len(obs)) + " ".join("%d %d %.3f %.3f" % o for o in obs) + "\n")

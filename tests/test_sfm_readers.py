@@ -1,0 +1,97 @@
+"""SfM front ends: the C++ readers behind the C ABI against the oracle's pure-Python readers on files written
+from known cameras.  No GPU needed for the readers themselves."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import l3d_oracle_sfm as osfm  # noqa: E402
+from helpers import synth_worldpoints, write_bundler, write_nvm, assert_lines_equal  # noqa: E402
+from line3d_amd.synth import make_scene  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sfm_scene():
+    sc = make_scene(10, 300, 6, seed=77)
+    return sc, synth_worldpoints(sc, 400, seed=5)
+
+
+def _same(cams_a, cams_b):
+    assert len(cams_a) == len(cams_b)
+    for a, b in zip(cams_a, cams_b):
+        assert a["name"] == b["name"] and a["focal"] == b["focal"]
+        assert np.array_equal(a["dist"], b["dist"]) and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
+        assert np.array_equal(a["worldpoints"], b["worldpoints"])
+
+
+def test_nvm_reader_matches_oracle_and_truth(sfm_scene, tmp_path):
+    from line3d_amd import sfm
+    sc, pts = sfm_scene
+    path = str(tmp_path / "scene.nvm")
+    write_nvm(path, sc, pts)
+    got = sfm.read_nvm(path)
+    exp, npts = osfm.read_nvm(path)
+    assert got.n_points == npts == len(pts)
+    _same(got.cameras, exp)
+    for cam, v in zip(got.cameras, sc.views):
+        assert np.allclose(cam["R"], v["R"], atol=1e-12) and np.allclose(cam["t"], v["t"], atol=1e-11)
+        assert cam["focal"] == float(np.float32(v["K"][0, 0]))
+        assert np.array_equal(sfm.intrinsics(cam["focal"], v["width"], v["height"]), osfm.intrinsics(cam["focal"], v["width"], v["height"]))
+        assert np.array_equal(sfm.intrinsics(cam["focal"], v["width"], v["height"]), v["K"])
+    assert sum(len(c["worldpoints"]) for c in got.cameras) == sum(len(o) for _, o in pts) > 1000
+
+
+def test_bundler_reader_matches_oracle_and_truth(sfm_scene, tmp_path):
+    from line3d_amd import sfm
+    sc, pts = sfm_scene
+    path = str(tmp_path / "bundle.rd.out")
+    write_bundler(path, sc, pts)
+    got = sfm.read_bundler(path)
+    exp, npts = osfm.read_bundler(path)
+    assert got.n_points == npts == len(pts)
+    _same(got.cameras, exp)
+    for i, (cam, v) in enumerate(zip(got.cameras, sc.views)):
+        assert np.array_equal(cam["R"], v["R"]) and np.array_equal(cam["t"], v["t"]) and cam["name"] == "%08d" % i
+
+
+def test_reader_errors(tmp_path):
+    from line3d_amd import sfm
+    with pytest.raises(RuntimeError, match="does not exist"):
+        sfm.read_nvm(str(tmp_path / "missing.nvm"))
+    p = str(tmp_path / "empty.nvm")
+    open(p, "w").write("NVM_V3\n\n0\n")
+    with pytest.raises(RuntimeError, match="No aligned cameras"):
+        sfm.read_nvm(p)
+    assert sfm.result_basename(neighbors=10) == "line3D_result__W_-1__N_10__tL_1__tU_5__sigmaP_3.5__sigmaA_10__COLLIN__NO_DIFFUSION"
+
+
+@pytest.mark.gpu
+def test_driver_flow_from_nvm_matches_oracle(sfm_scene, tmp_path):
+    """main_vsfm's flow with segments in place of images: NVM -> addImage with world point lists (similarity from shared
+    world points, line3D.cc:1874-1935) -> compute3Dmodel -> TXT/STL, against the oracle fed by its own reader."""
+    import l3d_oracle_pipeline as op
+    from line3d_amd import sfm
+    from line3d_amd.io import load_txt
+    sc, pts = sfm_scene
+    path = str(tmp_path / "scene.nvm")
+    write_nvm(path, sc, pts)
+    scene = sfm.read_nvm(path)
+    segs = [v["segments"] for v in sc.views]
+    sizes = [(v["width"], v["height"]) for v in sc.views]
+    l3d = sfm.reconstruct(scene, segs, sizes, out_dir=str(tmp_path / "out"), neighbors=6)
+    cams, _ = osfm.read_nvm(path)
+    o = op.OracleLine3D(matching_neighbors=6)
+    for i, c in enumerate(cams):
+        assert o.add_image(i, sizes[i][0], sizes[i][1], segs[i], osfm.intrinsics(c["focal"], *sizes[i]), c["R"], c["t"], list(c["worldpoints"]))
+    o.compute3Dmodel(False)
+    assert len(o.result) > 0
+    assert_lines_equal(l3d.getResult(), o.result, 1e-4)
+    txt = os.path.join(str(tmp_path / "out"), sfm.result_basename(neighbors=6) + ".txt")
+    assert len(load_txt(txt)) == len(o.result) and os.path.exists(txt[:-4] + ".stl")
+    l3d.close()
