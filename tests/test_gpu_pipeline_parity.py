@@ -312,3 +312,44 @@ def test_result_writers_match_oracle(small_scene, small_oracle, tmp_path):
     assert len(ta) == len(tb) and ta[0] == tb[0] == "solid lineModel" and ta[-1] == tb[-1] == "endsolid lineModel"
     assert sum(1 for x in ta if x.startswith("   vertex")) == 3 * sum(len(s3) for _, s3 in ga)
     l.close()
+
+
+def test_ragged_scene_all_paths_equal_oracle():
+    """Views with very different segment counts (1, 2, 5, 37 ... 260; a view without segments cannot exist: addImage
+    refuses it like the reference, line3D.cc:186-190) and image ids not starting at 0: the resident chain, the per-view
+    path and the native sharded run must all reproduce the oracle."""
+    from line3d_amd.pipeline import Line3D
+    from line3d_amd.synth import make_scene
+    from line3d_amd import distributed as l3dist
+    sc = make_scene(11, 260, 6, seed=909, first_id=3)
+    keep = {3: 260, 4: 2, 5: 1, 6: 37, 7: 260, 8: 131, 9: 260, 10: 200, 11: 260, 12: 5, 13: 260}
+    for v in sc.views:
+        v["segments"] = np.ascontiguousarray(v["segments"][:keep[v["id"]]])
+    o = op.OracleLine3D(matching_neighbors=6)
+    for v in sc.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    o.compute3Dmodel(False)
+    assert sum(len(t["matches"]) for t in o.trace.values()) > 100
+
+    def load(l):
+        assert not l.addImage_fixed_sim(99, 1920, 1080, np.zeros((0, 4), np.float32), sc.views[0]["K"], sc.views[0]["R"], sc.views[0]["t"], {3: 1.0})
+        for v in sc.views:
+            assert l.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+
+    for mode in ("chain", "sync", "native"):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        l.set_sync_matching(mode == "sync")
+        load(l)
+        if mode == "native":
+            l.prepare()
+            l3dist.match_views_chain_native(l, 0, 1, None, commit=True, n_segments=260, n_neighbors=6)
+            l.finish(False)
+        else:
+            l.compute3Dmodel(False)
+        for vid in sorted(o.trace):
+            got, med = l.view_matches(vid)
+            assert got.tobytes() == o.trace[vid]["matches"].tobytes(), "%s view %d" % (mode, vid)
+            assert np.float32(med) == np.float32(o.trace[vid]["median"]), "%s view %d" % (mode, vid)
+        assert_lines_equal(l.getResult(), o.result, 1e-4)
+        l.close()
