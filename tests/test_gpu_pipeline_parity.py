@@ -353,3 +353,20 @@ def test_ragged_scene_all_paths_equal_oracle():
             assert np.float32(med) == np.float32(o.trace[vid]["median"]), "%s view %d" % (mode, vid)
         assert_lines_equal(l.getResult(), o.result, 1e-4)
         l.close()
+
+
+@pytest.mark.parametrize("n_views,S,N", [(27, 180, 24), (64, 48, 60)])
+def test_many_neighbours_parity(n_views, S, N):
+    """BASELINE config 5's neighbourhood size (N = 24) and one beyond the window kernel's LDS limit (N = 60: the chain
+    takes the all-pairs verification kernel) on small views: per-view kept lists bit-exact, lines within 1e-4."""
+    from line3d_amd.synth import make_scene
+    sc = make_scene(n_views, S, N, seed=500 + N)
+    o = op.run_scene(sc, N)
+    assert sum(len(t["matches"]) for t in o.trace.values()) > 500
+    l = _run_gpu(sc, N)
+    for vid in sorted(o.trace):
+        got, med = l.view_matches(vid)
+        assert got.tobytes() == o.trace[vid]["matches"].tobytes(), "view %d" % vid
+        assert np.float32(med) == np.float32(o.trace[vid]["median"])
+    assert_lines_equal(l.getResult(), o.result, 1e-4)
+    l.close()
