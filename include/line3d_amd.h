@@ -206,6 +206,9 @@ int l3d_set_pair_pretest(l3d_ctx* ctx, int mask);
 /* testing: cap the LDS image of the depth-window kernel (bytes; 0 = device limit) so that segments take the
  * global-scratch variant; process-wide */
 int l3d_set_verify_lds_budget(size_t bytes);
+/* testing: initial candidate / kept-arena capacities (records) of the resident chain, 0 = the built-in estimate; small
+ * values force the overflow -> grow -> restart-at-that-view path */
+int l3d_set_chain_capacities(l3d_ctx* ctx, size_t cand_cap, size_t arena_cap);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
 /* bracket only the named kernel with HIP events (NULL or "": all kernels) -- keeps a timed region nearly undisturbed */
 int l3d_profile_only(l3d_ctx* ctx, const char* kernel);

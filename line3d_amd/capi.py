@@ -104,6 +104,9 @@ class Context:
         self._chk(self.lib.l3d_test_sq_threshold(self.h, _p(u), C.c_int(len(u)), _p(a), _p(b)))
         return a, b
 
+    def set_chain_capacities(self, cand_cap: int, arena_cap: int):
+        self._chk(self.lib.l3d_set_chain_capacities(self.h, C.c_size_t(cand_cap), C.c_size_t(arena_cap)))
+
     def set_verify_lds_budget(self, nbytes: int):
         self._chk(self.lib.l3d_set_verify_lds_budget(C.c_size_t(nbytes)))
 

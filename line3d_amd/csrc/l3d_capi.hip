@@ -22,7 +22,7 @@ static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
 static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
 
 namespace {
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
 }  // namespace
 
 extern "C" {
@@ -75,7 +75,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     prof_resolve(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
@@ -111,6 +111,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
     return L3D_OK;
 }
 
+int l3d_set_chain_capacities(l3d_ctx* c, size_t cand_cap, size_t arena_cap) { if (!c) return L3D_ERR_INVALID; c->test_cand_cap = cand_cap; c->test_arena_cap = arena_cap; return L3D_OK; }
 int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes); return L3D_OK; }
 int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 3) return L3D_ERR_INVALID; c->wedge_pretest = mask; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }

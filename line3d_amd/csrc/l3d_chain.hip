@@ -112,6 +112,23 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
     }
 }
 
+// Stage-1 candidates of a view are written (k_pair_fill, stage-1 stream, well ahead of the chain) in their own
+// (segment, to-be-matched camera) row order; once the reverse matches of the view are counted, each row is moved to its
+// place in the combined (segment, camera, target) order -- a 24-byte copy per candidate instead of the triangulation on the
+// chain's critical path.  One wave per row.
+__global__ __launch_bounds__(256) void k_cand_move(const int* __restrict__ tbm, int n_tbm, int N, int seg_begin, int seg_end,
+                                                   const int* __restrict__ rowA, const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
+                                                   const int* __restrict__ row_start, int nrow_total, int cand_cap,
+                                                   uint2* __restrict__ meta, float4* __restrict__ depths)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= (seg_end - seg_begin) * n_tbm) return;
+    if (row_start[nrow_total] > cand_cap) return;                 // overflow: the chain is re-run with more room
+    const int y = seg_begin + row / n_tbm, cam = tbm[row % n_tbm];
+    const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
+    for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
+}
+
 // raw candidate total and the largest per-segment count of one view's segment range (phase 1 statistics), by one
 // workgroup; out2 = {total, max} lives in host-mapped pinned memory: no copy, the host reads it after the stage-1 event
 __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowcnt, int N, int seg_begin, int seg_end, int* __restrict__ out2)
@@ -197,6 +214,13 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
     const int n = S * n_cams;
     if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
 }
+void launch_cand_move(const int* tbm, int n_tbm, int N, int seg_begin, int seg_end, const int* rowA, const uint2* metaA, const float4* depthsA,
+                      const int* row_start, int nrow_total, int cand_cap, uint2* meta, float4* depths, hipStream_t st)
+{
+    const int nrows = (seg_end - seg_begin) * n_tbm;
+    if (nrows > 0) hipLaunchKernelGGL(k_cand_move, dim3((nrows + 3) / 4), dim3(256), 0, st, tbm, n_tbm, N, seg_begin, seg_end, rowA, metaA, depthsA,
+                                      row_start, nrow_total, cand_cap, meta, depths);
+}
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
 {
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
@@ -222,6 +246,7 @@ struct ViewDev {            // device addresses of one view's static tables and 
     size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
     unsigned long long* mask;
     int* rowcnt;
+    int* rowA;              // row starts of the stage-1 candidates alone (S*N + 1)
     int* stats;             // {raw total, raw max per segment}
     float2* best;
     int W64, maxW;
@@ -311,6 +336,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // ---- per-view arenas: bit rows, row counts, statistics, best depths, results
     HIPCHK(c, c->ch_mask.reserve(mask_bytes + 16));
     HIPCHK(c, c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
+    HIPCHK(c, c->ch_rowA.reserve((rowcnt_ints + 4 * (size_t)n_views) * 4 + 64));
     HIPCHK(c, c->ch_best.reserve(best_elems * 8 + 16));
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
     HIPCHK(c, c->ch_flags.reserve(64));
@@ -331,7 +357,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&hres_dev), hres, 0));
     int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
     {
-        size_t mo = 0, ro = 0, bo = 0;
+        size_t mo = 0, ro = 0, bo = 0, ao = 0;
         int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
         for (int k = 0; k < n_views; ++k) {
             ViewDev& d = vd[(size_t)k];
@@ -341,6 +367,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
             mo += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
             d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
+            d.rowA = c->ch_rowA.as<int>() + ao; ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
             d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
         }
     }
@@ -374,19 +401,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     }
     std::vector<hipEvent_t> ev1((size_t)n_views, nullptr);
     int k_p1 = 0;                       // next view whose stage 1 is enqueued
-    auto enqueue_stage1 = [&](int k) -> int {
-        if (!vd[(size_t)k].verified) return L3D_OK;
-        hstats[2 * k] = hstats[2 * k + 1] = 0;
-        if (views[k].S_src > 0) {
-            const PairArgs pa = pair_args(k);
-            { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, vd[(size_t)k].maxW, s1); }
-            { ProfScope p(c, "row_count", s1); launch_row_count(pa, vd[(size_t)k].rowcnt, s1); }
-            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
-        }
-        ev1[(size_t)k] = get_event(c);
-        HIPCHK(c, hipEventRecord(ev1[(size_t)k], s1));
-        return L3D_OK;
-    };
     c->stats[0] = pairs;
     double raw_sum = 0;
 
@@ -402,8 +416,10 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
     int* arena_cursor = c->ch_flags.as<int>();
     int k_enq = 0;                      // next view whose phase 2 is enqueued
-    const int kAhead = 12, kStage1Ahead = 24;
+    const int kAhead = 12, kStage1Ahead = 24, kRing = kStage1Ahead + 2;
     int rc_final = L3D_OK;
+    if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
+    if (c->test_arena_cap) arena_cap = c->test_arena_cap;
 
     auto reserve_caps = [&]() -> int {
         HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
@@ -411,9 +427,38 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
         HIPCHK(c, c->vw_scratch.reserve((cand_cap + 2) * 16));
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
+        // ring of stage-1 candidate buffers: stage 1 (incl. the triangulation of its candidates) runs kStage1Ahead views ahead
+        HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
+        HIPCHK(c, c->ch_ringA_depths.reserve((size_t)kRing * cand_cap * 16));
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
+    auto ringA_meta = [&](int k) { return c->ch_ringA_meta.as<uint2>() + (size_t)(k % kRing) * cand_cap; };
+    auto ringA_depths = [&](int k) { return c->ch_ringA_depths.as<float4>() + (size_t)(k % kRing) * cand_cap; };
+    // row starts + depth records of a view's stage-1 candidates alone (its reverse matches are not known yet)
+    auto enqueue_fillA = [&](int k, hipStream_t s) {
+        const ViewDev& d = vd[(size_t)k];
+        PairArgs pa = pair_args(k);
+        pa.cand_cap = (int)cand_cap;
+        { ProfScope p(c, "scan", s); launch_scan(d.rowcnt, d.rowA, views[k].S_src * views[k].N, nullptr, s); }
+        { ProfScope p(c, "pair_fill", s); launch_pair_fill(pa, d.rowA, ringA_meta(k), ringA_depths(k), s); }
+    };
+    auto enqueue_stage1 = [&](int k) -> int {
+        if (!vd[(size_t)k].verified) return L3D_OK;
+        hstats[2 * k] = hstats[2 * k + 1] = 0;
+        if (views[k].S_src > 0) {
+            const PairArgs pa = pair_args(k);
+            { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, vd[(size_t)k].maxW, s1); }
+            { ProfScope p(c, "row_count", s1); launch_row_count(pa, vd[(size_t)k].rowcnt, s1); }
+            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
+            // the ring slot was last used by view k - kRing: wait until its chain has consumed it
+            for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(s1, ev[(size_t)j], 0)); break; }
+            enqueue_fillA(k, s1);
+        }
+        ev1[(size_t)k] = get_event(c);
+        HIPCHK(c, hipEventRecord(ev1[(size_t)k], s1));
+        return L3D_OK;
+    };
 
     auto enqueue_view = [&](int k) -> int {
         const l3d_chain_view& v = views[k];
@@ -434,7 +479,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
         { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
-        if (S > 0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+        { ProfScope p(c, "cand_move"); launch_cand_move(pa.tbm, v.n_tbm, N, 0, S, d.rowA, ringA_meta(k), ringA_depths(k), c->row_start.as<int>(), (int)nrow,
+                                                        (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
         {
             ProfScope p(c, "exist");
             launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
@@ -497,6 +543,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             // not enough room for this view's candidates / kept matches: everything before it is valid and stays
             // in the arena; wait for the queue to drain, grow, and re-enqueue from this view
             HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipStreamSynchronize(s1));
             if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
             if (r.overflow & 2) {
                 // the arena cannot be reallocated without losing earlier lists that later views still read:
@@ -512,10 +559,14 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
             HIPCHK(c, hipMemcpy(arena_cursor, &r.kept_base, 4, hipMemcpyHostToDevice));
             // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
-            for (int j = k; j < k_enq; ++j) {
+            // and the stage-1 candidate buffers of every view in flight live in the (re-sized) ring: refill them
+            for (int j = k; j < k_p1; ++j) {
                 if (!vd[(size_t)j].verified || views[j].S_src == 0) continue;
-                HIPCHK(c, hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st));
-                launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);
+                if (j < k_enq) {
+                    HIPCHK(c, hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st));
+                    launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);
+                }
+                enqueue_fillA(j, st);
             }
             k_enq = k;
             --k;

@@ -169,6 +169,7 @@ struct SViewDev {
     size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
     unsigned long long* mask;
     int* rowcnt;
+    int* rowA;                               // row starts of the stage-1 candidates alone
     int* stats;
     float2* best;
     int W64, maxW, s0, s1;
@@ -191,6 +192,7 @@ struct l3d_shard_chain {
     std::vector<hipEvent_t> ev1, ev2;
     int k_p1 = 0;
     size_t cand_cap = 0;
+    static constexpr int kStage1Ahead = 24, kRingA = kStage1Ahead + 2;   // ring of stage-1 candidate buffers
     int maxS = 0, maxN = 0;
     const unsigned char* gathered = nullptr;
     double pairs = 0, raw_sum = 0, kept_total = 0;
@@ -205,6 +207,7 @@ struct l3d_shard_chain {
     hipEvent_t ev3 = nullptr;                // lazy pack (step-wise protocol): enqueued by fetch
     std::atomic<int> marked{0};              // views [0, marked) carry their completion event
     std::atomic<int> fetched{0};             // views [0, fetched) have left their staging buffer
+    int copy_issued = -1;                    // view whose D2H copy the previous fetch has already issued (fetch thread only)
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
 };
 
@@ -293,11 +296,12 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     h->dtab = c->ch_tables.as<unsigned char>();
     OCHK(c->ch_mask.reserve(mask_bytes + 16));
     OCHK(c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
+    OCHK(c->ch_rowA.reserve((rowcnt_ints + 4 * (size_t)n_views) * 4 + 64));
     OCHK(c->ch_best.reserve(best_elems * 8 + 16));
     OCHK(c->ch_pin_res.reserve((size_t)n_views * 8 + 64));
     OCHK(hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
     {
-        size_t mo = 0, ro = 0, bo = 0;
+        size_t mo = 0, ro = 0, bo = 0, ao = 0;
         int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
         for (int k = 0; k < n_views; ++k) {
             SViewDev& d = h->vd[(size_t)k];
@@ -307,6 +311,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
             d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
             mo += salign((size_t)v.n_tbm * v.S_src * d.W64 * 8, 16);
             d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
+            d.rowA = c->ch_rowA.as<int>() + ao; ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;
             d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
         }
     }
@@ -328,8 +333,10 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
     OCHK(c->cand_conf.reserve(h->cand_cap * 4));
     OCHK(c->vw_scratch.reserve((h->cand_cap + 2) * 16));
+    OCHK(c->ch_ringA_meta.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 8));
+    OCHK(c->ch_ringA_depths.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 16));
     h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
-    OCHK(c->ch_pin_kept.reserve(h->stage_bytes + 64));
+    OCHK(c->ch_pin_kept.reserve(2 * (h->stage_bytes + 64) + 64));
     OCHK(c->ch_stage.reserve((size_t)l3d_shard_chain::kRing * h->stage_bytes + 64));
     OCHK(c->ch_pin_best.reserve((size_t)n_views * sizeof(PackHeader) + 64));
     h->hdr_host = c->ch_pin_best.as<PackHeader>();
@@ -377,6 +384,14 @@ static int shard_stage1(l3d_shard_chain* h, int k)
         { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, d.maxW, s1); }
         { ProfScope p(c, "row_count", s1); launch_row_count(pa, d.rowcnt, s1); }
         launch_raw_stats(d.rowcnt, h->views[k].N, d.s0, d.s1, h->hstats_dev + 2 * k, s1);     // straight into host-mapped memory
+        // depth records of the stage-1 candidates, in their own row order, into the ring slot last used by view k - kRingA
+        // (its completion event is recorded by l3d_shard_chain_mark before this view's stage 1 is enqueued)
+        if (k - l3d_shard_chain::kRingA >= 0) HIPCHK(c, hipStreamWaitEvent(s1, h->ev2[(size_t)(k - l3d_shard_chain::kRingA)], 0));
+        PairArgs pf = pa;
+        pf.cand_cap = (int)h->cand_cap;
+        { ProfScope p(c, "scan", s1); launch_scan(d.rowcnt, d.rowA, h->views[k].S_src * h->views[k].N, nullptr, s1); }
+        { ProfScope p(c, "pair_fill", s1); launch_pair_fill(pf, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                                                             c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, s1); }
     }
     h->ev1[(size_t)k] = get_event(c);
     HIPCHK(c, hipEventRecord(h->ev1[(size_t)k], s1));
@@ -392,8 +407,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     (void)hipGetLastError();            // the framework shares this thread: its (benign) sticky errors are not ours
-    const int kStage1Ahead = 24;
-    while (h->k_p1 < h->n_views && h->k_p1 <= k + kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
+    while (h->k_p1 < h->n_views && h->k_p1 <= k + l3d_shard_chain::kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
     const l3d_chain_view& v = h->views[k];
     const SViewDev& d = h->vd[(size_t)k];
     h->gathered = reinterpret_cast<const unsigned char*>(gathered_base);
@@ -415,7 +429,12 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
     }
     { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
-    if (d.s1 > d.s0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+    {
+        ProfScope p(c, "cand_move");
+        launch_cand_move(pa.tbm, v.n_tbm, N, d.s0, d.s1, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                         c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, c->row_start.as<int>(), (int)nrow,
+                         (int)h->cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+    }
     if (v.n_sources) {
         ProfScope p(c, "exist");
         hipLaunchKernelGGL(k_exist_scatter_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1,
@@ -508,11 +527,24 @@ int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void
     const PackHeader ph = h->hdr_host[k];
     if (ph.overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
     const size_t best_bytes = (size_t)h->geom.seg_cap * 8;
-    unsigned char* host = c->ch_pin_kept.as<unsigned char>();
-    const unsigned char* stage = c->ch_stage.as<unsigned char>() + (size_t)(k % l3d_shard_chain::kRing) * h->stage_bytes;
-    HIPCHK(c, hipMemcpyAsync(host, stage, (size_t)h->world * best_bytes + (size_t)ph.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream));
+    const size_t pin_bytes = h->stage_bytes + 64;
+    unsigned char* host = c->ch_pin_kept.as<unsigned char>() + (size_t)(k & 1) * pin_bytes;      // two pinned buffers
+    auto issue_copy = [&](int v, const PackHeader& hd) -> hipError_t {
+        const unsigned char* stage = c->ch_stage.as<unsigned char>() + (size_t)(v % l3d_shard_chain::kRing) * h->stage_bytes;
+        return hipMemcpyAsync(c->ch_pin_kept.as<unsigned char>() + (size_t)(v & 1) * pin_bytes, stage,
+                              (size_t)h->world * best_bytes + (size_t)hd.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream);
+    };
+    if (h->copy_issued != k) HIPCHK(c, issue_copy(k, ph));       // (otherwise the previous fetch has issued it already)
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     h->fetched.store(k + 1, std::memory_order_release);          // the staging buffer of view k may be reused
+    // the next view's copy travels while this view's bookkeeping runs, if the GPU is already done with it
+    if (k + 1 < h->n_views && h->vd[(size_t)(k + 1)].verified && h->marked.load(std::memory_order_acquire) > k + 1 && h->packed[(size_t)(k + 1)] &&
+        hipEventQuery(h->ev2[(size_t)(k + 1)]) == hipSuccess && !h->hdr_host[k + 1].overflow) {
+        HIPCHK(c, issue_copy(k + 1, h->hdr_host[k + 1]));
+        h->copy_issued = k + 1;
+    } else {
+        (void)hipGetLastError();                                 // hipEventQuery reports "not ready" as an error
+    }
     const l3d_match* kept = reinterpret_cast<const l3d_match*>(host + (size_t)h->world * best_bytes);
     std::vector<float>& best = h->best_scratch;
     best.clear();

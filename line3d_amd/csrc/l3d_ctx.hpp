@@ -67,10 +67,11 @@ struct l3d_ctx {
     l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
-    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage;
+    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     std::vector<int> h_cnt;
     int mmax_seen = 0;
+    size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
     int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 depth-sign test (cleared only for A/B testing)
     int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs

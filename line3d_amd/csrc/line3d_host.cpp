@@ -870,7 +870,7 @@ void start_finalizer(L* h, ChainPlan& P)
             fin.pending[(size_t)o->index] += 1;
         }
     }
-    fin.start(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)));
+    fin.start(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)));    // (one process per GPU shares the host)
     P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin.get() };
 }
 

@@ -370,3 +370,19 @@ def test_many_neighbours_parity(n_views, S, N):
         assert np.float32(med) == np.float32(o.trace[vid]["median"])
     assert_lines_equal(l.getResult(), o.result, 1e-4)
     l.close()
+
+
+def test_chain_capacity_overflow_restarts(small_scene, small_oracle):
+    """Candidate / kept-arena capacities far too small: the device-side guards flag the overflow, the chain grows the
+    buffers (the stage-1 candidate ring included) and restarts at that view -- results unchanged."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    for caps in ((3000, 1 << 20), (1 << 22, 700), (2500, 500)):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.context().set_chain_capacities(*caps)
+        l.compute3Dmodel(False)
+        for v in sorted(small_oracle.trace):
+            assert l.view_matches(v)[0].tobytes() == small_oracle.trace[v]["matches"].tobytes(), "caps %r view %d" % (caps, v)
+        assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+        l.close()
