@@ -5,6 +5,7 @@
 // calls the HIP path exclusively through include/line3d_amd.h.  Cited line numbers refer to the
 // reference files under /root/reference.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -147,9 +148,11 @@ struct l3d_line3d {
     std::vector<std::vector<std::pair<uint32_t, Key>>> pot;    // per view index: (seg, other key), potential_correspondences_
     std::vector<std::pair<Key, Key>> pot_foreign;              // keys whose camera is not a view (early-return quirk)
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
-    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>> fin_buckets;   // finaliser scratch, reused across passes
+    std::vector<std::vector<std::pair<size_t, std::array<std::vector<std::pair<uint32_t, Key>>, 4>>>> fin_buckets;   // finaliser scratch, reused across passes
+    std::vector<std::array<std::vector<std::pair<uint32_t, Key>>, 4>> fin_parts;
     std::vector<std::vector<l3d_match>> saved;                 // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
+    bool pot_check_failed = false;                             // L3D_CHECK_POT=1 (tests)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
 
@@ -410,13 +413,24 @@ void add_matches(View& v, const l3d_match* m, size_t n, bool remove_old, bool on
                 i = j;
             }
         } else {
-            std::map<uint32_t, size_t> best;
-            for (size_t i = 0; i < n; ++i) {
-                auto it = best.find(m[i].segID1);
-                if (it == best.end()) best[m[i].segID1] = i;
-                else if (m[i].confidence > m[it->second].confidence) it->second = i;
+            uint32_t mx = 0;
+            for (size_t i = 0; i < n; ++i) mx = std::max(mx, m[i].segID1);
+            if ((size_t)mx <= 16 * n + 1024) {                 // dense segment ids: one table instead of a map
+                std::vector<size_t> best((size_t)mx + 1, (size_t)-1);
+                for (size_t i = 0; i < n; ++i) {
+                    size_t& b = best[m[i].segID1];
+                    if (b == (size_t)-1 || m[i].confidence > m[b].confidence) b = i;
+                }
+                for (size_t b : best) if (b != (size_t)-1) tmp.push_back(m[b]);
+            } else {
+                std::map<uint32_t, size_t> best;
+                for (size_t i = 0; i < n; ++i) {
+                    auto it = best.find(m[i].segID1);
+                    if (it == best.end()) best[m[i].segID1] = i;
+                    else if (m[i].confidence > m[it->second].confidence) it->second = i;
+                }
+                for (auto& kv : best) tmp.push_back(m[kv.second]);
             }
-            for (auto& kv : best) tmp.push_back(m[kv.second]);
         }
         m = tmp.data(); n = tmp.size();
     }
@@ -501,6 +515,34 @@ int compute_view(L* h, View& v, int s0, int s1, l3d_match** out, int* n_out, flo
     return L3D_OK;
 }
 
+// One segment's entries tmp[b, e) -> sorted by key, duplicates dropped, appended at out[w...]; returns the new w.
+// The list is the view's own forward entries (ascending key) followed by the reverse entries of the views that matched it
+// (ascending view, ascending segment = ascending key): two sorted runs, merged linearly; anything else (more runs) falls
+// back to an insertion sort.
+inline size_t emit_sorted_unique(std::pair<uint32_t, Key>* tmp, size_t b, size_t e, std::pair<uint32_t, Key>* out, size_t w)
+{
+    if (b >= e) return w;
+    size_t cut = e, descents = 0;
+    for (size_t i = b + 1; i < e; ++i) if (tmp[i].second < tmp[i - 1].second) { if (!descents) cut = i; ++descents; }
+    const size_t w0 = w;
+    auto put = [&](const std::pair<uint32_t, Key>& x) { if (w == w0 || out[w - 1].second != x.second) out[w++] = x; };
+    if (descents <= 1) {
+        size_t i = b, j = cut;
+        while (i < cut && j < e) { if (tmp[j].second < tmp[i].second) put(tmp[j++]); else put(tmp[i++]); }
+        while (i < cut) put(tmp[i++]);
+        while (j < e) put(tmp[j++]);
+        return w;
+    }
+    for (size_t i = b + 1; i < e; ++i) {
+        auto x = tmp[i];
+        size_t j = i;
+        for (; j > b && tmp[j - 1].second > x.second; --j) tmp[j] = tmp[j - 1];
+        tmp[j] = x;
+    }
+    for (size_t i = b; i < e; ++i) put(tmp[i]);
+    return w;
+}
+
 // potential_correspondences_ becomes a sorted, de-duplicated adjacency per view (it is a std::map of
 // std::maps in the reference: set semantics, ascending iteration)
 void finalize_view_pot(std::vector<std::pair<uint32_t, Key>>& p, size_t S)
@@ -520,14 +562,31 @@ void finalize_view_pot(std::vector<std::pair<uint32_t, Key>>& p, size_t S)
     size_t b = 0, w = 0;
     for (size_t s = 0; s < S; ++s) {
         const size_t e = cnt[s];
-        for (size_t i = b + 1; i < e; ++i) {                // insertion sort on keys
-            auto x = tmp[i];
-            size_t j = i;
-            for (; j > b && tmp[j - 1].second > x.second; --j) tmp[j] = tmp[j - 1];
-            tmp[j] = x;
-        }
-        for (size_t i = b; i < e; ++i)
-            if (i == b || tmp[i].second != tmp[i - 1].second) p[w++] = tmp[i];
+        w = emit_sorted_unique(tmp.data(), b, e, p.data(), w);
+        b = e;
+    }
+    p.resize(w);
+}
+
+// the same normal form for the entries of one segment range [lo, hi) (one of the parallel parts of a view's merge)
+void finalize_pot_range(std::vector<std::pair<uint32_t, Key>>& p, uint32_t lo, uint32_t hi)
+{
+    if (p.empty()) return;
+    bool in_range = true;
+    for (auto& e : p) if (e.first < lo || e.first >= hi) { in_range = false; break; }
+    if (!in_range || hi - lo > (1u << 24)) { std::sort(p.begin(), p.end()); p.erase(std::unique(p.begin(), p.end()), p.end()); return; }
+    static thread_local std::vector<uint32_t> cnt;
+    static thread_local std::vector<std::pair<uint32_t, Key>> tmp;
+    const size_t n = hi - lo;
+    cnt.assign(n + 1, 0);
+    for (auto& e : p) cnt[e.first - lo + 1]++;
+    for (size_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+    if (tmp.size() < p.size()) tmp.resize(p.size());
+    for (auto& e : p) tmp[cnt[e.first - lo]++] = e;
+    size_t b = 0, w = 0;
+    for (size_t s = 0; s < n; ++s) {
+        const size_t e = cnt[s];
+        w = emit_sorted_unique(tmp.data(), b, e, p.data(), w);
         b = e;
     }
     p.resize(w);
@@ -686,19 +745,28 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
 struct ChainFinalizer {
     L* h;
     std::vector<int> own_index;                     // per view index: its position in the processing order or -1
+    std::vector<char> own_sorted;                   // per view index: its own forward entries ascend by segment
+    std::vector<std::vector<std::pair<uint32_t, size_t>>> targets;   // per order index: (camera id, view index) receiving reverse entries, ascending id
     std::vector<std::vector<int>> contributors;     // per view index: order indices of the views that list it as neighbour
-    std::vector<std::vector<std::pair<size_t, std::vector<std::pair<uint32_t, Key>>>>>* buckets = nullptr;   // per order index: (target view index, entries); storage owned by the pipeline object
+    std::vector<std::vector<std::pair<size_t, std::array<std::vector<std::pair<uint32_t, Key>>, 4>>>>* buckets = nullptr;   // per order index: (target view index, entries); storage owned by the pipeline object
     std::vector<std::atomic<int>> pending;          // per view index: splits still missing
+    static constexpr int kParts = 4;                // a view's merge runs as kParts independent segment ranges
+    std::vector<std::atomic<int>> parts_left;       // per view index
+    std::vector<std::array<std::vector<std::pair<uint32_t, Key>>, 4>>* parts = nullptr;   // storage owned by the pipeline object
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (1 = merge, view index)
     bool done = false;
     std::vector<std::thread> workers;
     bool timing = getenv("L3D_TIMING") != nullptr;
+    bool trace = getenv("L3D_TIMING") && atoi(getenv("L3D_TIMING")) >= 2;
+    struct LogRec { int kind, id; double t0, t1; };
+    std::vector<LogRec> log;
     double t_split = 0, t_merge = 0, t_last_done = 0;
     int n_split = 0, n_merge = 0;
 
-    explicit ChainFinalizer(size_t nviews) : pending(nviews) {}
+    explicit ChainFinalizer(size_t nviews) : pending(nviews), parts_left(nviews) {}
+    void push_merge(size_t vi) { parts_left[vi] = kParts; for (int r = 0; r < kParts; ++r) push(2, vi * kParts + (size_t)r); }
 
     void push(int kind, size_t id)
     {
@@ -710,33 +778,63 @@ struct ChainFinalizer {
         const View& v = h->views[h->order[k]];
         const std::vector<l3d_match>& lst = h->saved[k];
         auto& bk = (*buckets)[k];
-        const std::vector<uint32_t>& nbs = h->visual_neighbors.find(v.id)->second;
-        {   // same targets as in the previous pass: keep the entry vectors' capacity
-            size_t nb_ok = 0;
-            for (uint32_t nb : nbs) if (h->find_view(nb)) ++nb_ok;
-            if (bk.size() != nb_ok) bk.assign(nb_ok, {});
-            size_t i = 0;
-            for (uint32_t nb : nbs) { const View* o = h->find_view(nb); if (o) { bk[i].first = (size_t)o->index; bk[i].second.clear(); ++i; } }
-        }
-        std::vector<int> slot_of(nbs.size(), -1);
-        { int sidx = 0; for (size_t c = 0; c < nbs.size(); ++c) if (h->find_view(nbs[c])) slot_of[c] = sidx++; }
-        size_t last_c = (size_t)-1; uint32_t last_cam = 0xffffffffu;
+        // cameras whose views receive the reverse entry of a kept match: the neighbours -- or, for an early-return view
+        // (cudawrapper.cu:877-878: LOCAL camera ids come back), whatever views those numbers happen to name
+        // (line3D.cc:861-865); ascending camera id, slot = position
+        const std::vector<std::pair<uint32_t, size_t>>& tg = targets[k];
+        if (bk.size() != tg.size()) bk.assign(tg.size(), {});        // (otherwise keep the entry vectors' capacity)
+        std::vector<uint32_t> S_of(tg.size(), 1);       // segment count of each target: entries are pre-sorted into its merge ranges
+        for (size_t i = 0; i < tg.size(); ++i) { bk[i].first = tg[i].second; for (auto& q : bk[i].second) q.clear(); S_of[i] = (uint32_t)std::max(1, h->vlist[tg[i].second]->S()); }
+        size_t sl = (size_t)-1; uint32_t last_cam = 0xffffffffu;
         for (const l3d_match& m : lst) {
             if (m.camID2 != last_cam) {
                 last_cam = m.camID2;
-                auto it = std::lower_bound(nbs.begin(), nbs.end(), last_cam);
-                last_c = (it != nbs.end() && *it == last_cam) ? (size_t)(it - nbs.begin()) : (size_t)-1;
+                auto it = std::lower_bound(tg.begin(), tg.end(), std::make_pair(last_cam, (size_t)0));
+                sl = (it != tg.end() && it->first == last_cam) ? (size_t)(it - tg.begin()) : (size_t)-1;
             }
-            if (last_c != (size_t)-1 && slot_of[last_c] >= 0) bk[(size_t)slot_of[last_c]].second.emplace_back(m.segID2, mk(v.id, m.segID1));
+            if (sl != (size_t)-1) {
+                const uint32_t part = m.segID2 >= S_of[sl] ? (uint32_t)(kParts - 1) : (uint32_t)((uint64_t)m.segID2 * kParts / S_of[sl]);
+                bk[sl].second[part].emplace_back(m.segID2, mk(v.id, m.segID1));
+            }
         }
         // own forward entries (already grouped by segment) and the only-best store do not depend on other lists
         std::vector<std::pair<uint32_t, Key>>& p = h->pot[(size_t)v.index];
         p.clear();
         p.reserve(lst.size() * 2);
-        for (const l3d_match& m : lst) p.emplace_back(m.segID1, mk(m.camID2, m.segID2));
+        bool sorted = true;                             // (an early-return view's list is grouped by source view instead)
+        for (const l3d_match& m : lst) { if (!p.empty() && m.segID1 < p.back().first) sorted = false; p.emplace_back(m.segID1, mk(m.camID2, m.segID2)); }
+        own_sorted[(size_t)v.index] = sorted ? 1 : 0;
         add_matches(h->views[h->order[k]], lst.data(), lst.size(), true, true);
-        for (auto& e : bk) if (--pending[e.first] == 0) push(1, e.first);
-        if (--pending[(size_t)v.index] == 0) push(1, (size_t)v.index);
+        for (auto& e : bk) if (--pending[e.first] == 0) push_merge(e.first);
+        if (--pending[(size_t)v.index] == 0) push_merge((size_t)v.index);
+    }
+    // one segment range of a view's merge: gather (own forward entries are grouped by segment, the contributions are
+    // not), normal form; the part that finishes last concatenates the ranges
+    void merge_part(size_t vi, int r)
+    {
+        View& v = *h->vlist[vi];
+        const uint32_t S = (uint32_t)v.S();
+        // range r = segments s with floor(s * kParts / S) == r (the split has pre-sorted the contributions accordingly)
+        const uint32_t lo = (uint32_t)(((uint64_t)S * (uint32_t)r + kParts - 1) / kParts), hi = r == kParts - 1 ? 0xffffffffu : (uint32_t)(((uint64_t)S * (uint32_t)(r + 1) + kParts - 1) / kParts);
+        std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
+        std::vector<std::pair<uint32_t, Key>>& out = (*parts)[vi][(size_t)r];
+        out.clear();
+        if (own_index[vi] >= 0 && own_sorted[vi]) {     // split(own) has put the forward entries there, ascending segment
+            auto first = [](const std::pair<uint32_t, Key>& e, uint32_t x) { return e.first < x; };
+            auto b = std::lower_bound(p.begin(), p.end(), lo, first);
+            auto e = hi == 0xffffffffu ? p.end() : std::lower_bound(b, p.end(), hi, first);
+            out.insert(out.end(), b, e);
+        } else if (own_index[vi] >= 0) {
+            for (auto& x : p) if (x.first >= lo && x.first < hi) out.push_back(x);
+        }
+        for (int k : contributors[vi])
+            for (auto& e : (*buckets)[(size_t)k])
+                if (e.first == vi) out.insert(out.end(), e.second[(size_t)r].begin(), e.second[(size_t)r].end());
+        finalize_pot_range(out, lo, hi == 0xffffffffu ? std::max(S, lo) : hi);
+        if (--parts_left[vi] == 0) {
+            p.clear();
+            for (int q = 0; q < kParts; ++q) p.insert(p.end(), (*parts)[vi][(size_t)q].begin(), (*parts)[vi][(size_t)q].end());
+        }
     }
     void merge(size_t vi)
     {
@@ -744,7 +842,7 @@ struct ChainFinalizer {
         std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
         if (own_index[vi] < 0) p.clear();               // otherwise split(own) has put the forward entries there
         for (int k : contributors[vi])
-            for (auto& e : (*buckets)[(size_t)k]) if (e.first == vi) p.insert(p.end(), e.second.begin(), e.second.end());
+            for (auto& e : (*buckets)[(size_t)k]) if (e.first == vi) for (auto& q : e.second) p.insert(p.end(), q.begin(), q.end());
         finalize_view_pot(p, (size_t)v.S());
     }
     void start(unsigned nthreads)
@@ -761,8 +859,9 @@ struct ChainFinalizer {
                         queue.pop_back();
                     }
                     const double tj0 = now_s();
-                    if (job.first == 0) split(job.second); else merge(job.second);
-                    if (timing) { const double dt = now_s() - tj0; std::lock_guard<std::mutex> lk(mu); (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s(); }
+                    if (job.first == 0) split(job.second); else if (job.first == 1) merge(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
+                    if (timing) { const double dt = now_s() - tj0; std::lock_guard<std::mutex> lk(mu); (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s();
+                                  if (trace) log.push_back({ job.first, (int)job.second, tj0, t_last_done }); }
                 }
             });
     }
@@ -770,14 +869,19 @@ struct ChainFinalizer {
     void finish(bool drain)
     {
         // drain: wait until every job (splits spawn merges) has run
+        const double td0 = now_s();
         for (; drain;) {
-            { std::lock_guard<std::mutex> lk(mu); bool all = queue.empty(); if (all) { int left = 0; for (auto& p : pending) left += p.load() > 0; if (left == 0) break; } }
+            { std::lock_guard<std::mutex> lk(mu); bool all = queue.empty(); if (all) { int left = 0; for (auto& p : pending) left += p.load() > 0; for (auto& p : parts_left) left += p.load() > 0; if (left == 0) break; } }
             std::this_thread::yield();
         }
+        const double td1 = now_s();
         { std::lock_guard<std::mutex> lk(mu); done = true; }
         cv.notify_all();
         for (auto& t : workers) t.join();
         workers.clear();
+        if (trace) for (size_t i = log.size() > 48 ? log.size() - 48 : 0; i < log.size(); ++i)
+            fprintf(stderr, "[l3d finaliser job] kind %d id %d: start %+.3f end %+.3f ms (relative to the drain start)\n", log[i].kind, log[i].id, (log[i].t0 - td0) * 1e3, (log[i].t1 - td0) * 1e3);
+        if (timing) fprintf(stderr, "[l3d finaliser] drain %.2f ms (last job done %.2f ms after the drain began), join %.2f ms\n", (td1 - td0) * 1e3, (t_last_done - td0) * 1e3, (now_s() - td1) * 1e3);
         if (timing) fprintf(stderr, "[l3d finaliser] %d splits %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", n_split, t_split * 1e3,
                             n_split ? t_split * 1e3 / n_split : 0.0, n_merge, t_merge * 1e3, n_merge ? t_merge * 1e3 / n_merge : 0.0);
     }
@@ -855,19 +959,29 @@ void start_finalizer(L* h, ChainPlan& P)
     P.fin.reset(new ChainFinalizer(nvl));
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
-    fin.own_index.assign(nvl, -1); fin.contributors.assign(nvl, {});
+    fin.own_index.assign(nvl, -1); fin.own_sorted.assign(nvl, 1); fin.contributors.assign(nvl, {});
     fin.buckets = &h->fin_buckets;                      // (capacities survive from an earlier pass)
+    fin.parts = &h->fin_parts;
+    if (h->fin_parts.size() != nvl) h->fin_parts.assign(nvl, {});
+    for (size_t vi = 0; vi < nvl; ++vi) fin.parts_left[vi] = 0;
     if (h->fin_buckets.size() != n) h->fin_buckets.assign(n, {});
     for (size_t vi = 0; vi < nvl; ++vi) fin.pending[vi] = 0;
+    fin.targets.assign(n, {});
     for (size_t k = 0; k < n; ++k) {
         const View& v = h->views[h->order[k]];
         fin.own_index[(size_t)v.index] = (int)k;
         fin.pending[(size_t)v.index] += 1;              // its own list
-        for (uint32_t nb : h->visual_neighbors[v.id]) {
-            const View* o = h->find_view(nb);
-            if (!o) continue;
-            fin.contributors[(size_t)o->index].push_back((int)k);
-            fin.pending[(size_t)o->index] += 1;
+        auto& tg = fin.targets[k];
+        if (P.n_tbm[k] != 0) {
+            for (uint32_t nb : h->visual_neighbors[v.id]) { const View* o = h->find_view(nb); if (o) tg.emplace_back(nb, (size_t)o->index); }
+        } else {                                        // early return: local camera ids 0..N-1 read as view ids
+            const uint32_t N = (uint32_t)h->visual_neighbors[v.id].size();
+            for (uint32_t c = 0; c < N; ++c) { const View* o = h->find_view(c); if (o) tg.emplace_back(c, (size_t)o->index); }
+        }
+        std::sort(tg.begin(), tg.end());
+        for (auto& t : tg) {
+            fin.contributors[t.second].push_back((int)k);
+            fin.pending[t.second] += 1;
         }
     }
     fin.start(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)));    // (one process per GPU shares the host)
@@ -887,21 +1001,34 @@ void finish_chain_host(L* h, ChainPlan& P, bool ok)
     for (size_t k = 0; k < n; ++k) {
         if (P.n_tbm[k] != 0) continue;
         const uint32_t vid = h->order[k];
-        std::set<size_t> touched;
-        uint32_t last_cam = 0xffffffffu; View* o = nullptr;
-        for (const l3d_match& m : h->saved[k]) {
-            if (m.camID2 != last_cam) { last_cam = m.camID2; o = h->find_view(last_cam); if (o) touched.insert((size_t)o->index); }
-            if (o) h->pot[(size_t)o->index].emplace_back(m.segID2, mk(vid, m.segID1));
-            else h->pot_foreign.emplace_back(mk(m.camID2, m.segID2), mk(vid, m.segID1));
+        uint32_t last_cam = 0xffffffffu; bool foreign = false;
+        for (const l3d_match& m : h->saved[k]) {        // (numbers that name a view went through the finaliser like any reverse entry)
+            if (m.camID2 != last_cam) { last_cam = m.camID2; foreign = h->find_view(last_cam) == nullptr; }
+            if (foreign) h->pot_foreign.emplace_back(mk(m.camID2, m.segID2), mk(vid, m.segID1));
         }
-        std::vector<std::thread> th;
-        for (size_t vi : touched) th.emplace_back([h, vi]() { finalize_view_pot(h->pot[vi], (size_t)h->vlist[vi]->S()); });
-        for (auto& t : th) t.join();
     }
     std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
     if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]] = h->saved[k];
     h->t_finalize += now_s() - t2;
+    if (getenv("L3D_CHECK_POT")) {
+        // self-check (tests): every per-view list must be the plain normal form (sort + unique) of all its entries,
+        // rebuilt here from the kept lists the slow way
+        std::vector<std::vector<std::pair<uint32_t, Key>>> ref(h->pot.size());
+        for (size_t k = 0; k < n; ++k) {
+            const View& v = h->views[h->order[k]];
+            for (const l3d_match& m : h->saved[k]) {
+                ref[(size_t)v.index].emplace_back(m.segID1, mk(m.camID2, m.segID2));
+                View* o = h->find_view(m.camID2);
+                if (o) ref[(size_t)o->index].emplace_back(m.segID2, mk(v.id, m.segID1));
+            }
+        }
+        for (size_t vi = 0; vi < ref.size(); ++vi) {
+            std::sort(ref[vi].begin(), ref[vi].end());
+            ref[vi].erase(std::unique(ref[vi].begin(), ref[vi].end()), ref[vi].end());
+            if (ref[vi] != h->pot[vi]) { h->pot_check_failed = true; fprintf(stderr, "[l3d] potential-correspondence list of view index %zu differs from its normal form (%zu vs %zu entries)\n", vi, h->pot[vi].size(), ref[vi].size()); }
+        }
+    }
 }
 
 int match_views(L* h)
@@ -919,6 +1046,7 @@ int match_views(L* h)
     h->t_gpu_call += now_s() - t1 - h->t_commit;
     const double t2 = now_s();
     finish_chain_host(h, P, rc == L3D_OK);
+    if (h->pot_check_failed) return h->fail(L3D_ERR_INVALID, "L3D_CHECK_POT: a potential-correspondence list is not in normal form");
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d match_views] begin %.2f  schedule %.2f  finaliser start %.2f  chain %.2f  finish %.2f ms\n",
                                       (ta - t0) * 1e3, (tb - ta) * 1e3, (t1 - tb) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
@@ -1455,6 +1583,7 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed)
     ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
     int rc = l3d_shard_chain_close(P->shard);
     finish_chain_host(h, *P, committed != 0 && rc == L3D_OK);
+    if (h->pot_check_failed && rc == L3D_OK) rc = h->fail(L3D_ERR_INVALID, "L3D_CHECK_POT: a potential-correspondence list is not in normal form");
     double st[4];
     l3d_last_stats(h->ctx, st);
     h->stat_pairs += st[0];

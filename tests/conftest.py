@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+os.environ.setdefault("L3D_CHECK_POT", "1")     # host pipeline self-check of the merged potential-correspondence lists (tests only)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     # the oracle is test infrastructure: build it on demand (gcc only, ~1 s)
