@@ -38,7 +38,16 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
     if (const char* e = getenv("L3D_PRETEST")) c->wedge_pretest = atoi(e) & 3;      // diagnostic: stage-1 filter mask
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
+    {   // L3D_STREAM_PRIO=1: the chain's stream (per-view critical path) at the highest priority.  Measured on config 2: no
+        // difference to plain streams (21.5 ms either way), so plain streams are the default.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool prio = getenv("L3D_STREAM_PRIO") && atoi(getenv("L3D_STREAM_PRIO")) == 1;
+        if (!prio || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
+        }
+    }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
