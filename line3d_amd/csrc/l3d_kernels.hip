@@ -65,6 +65,12 @@ struct TgtBlockInv {                          // 29 words
 };
 
 __device__ __forceinline__ float fdot(f3 a, f3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_line(f3 l, v2f x, v2f y)
+{
+    const v2f lx = { l.x, l.x }, ly = { l.y, l.y }, lz = { l.z, l.z };
+    return __builtin_elementwise_fma(lx, x, __builtin_elementwise_fma(ly, y, lz));
+}
 __device__ __forceinline__ float fline(f3 l, float x, float y) { return __builtin_fmaf(l.x, x, __builtin_fmaf(l.y, y, l.z)); }
 // Upper bound of D_segment_overlap_2D(segment [0,1] of length len, intersection points at parameters t1, t2) where
 // ti = ai/(ai - bi) and ri = 1/(ai - bi); ext_over_len = (largest coordinate)/len.  2.0f = "cannot tell".
@@ -172,15 +178,16 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
             const SrcBlockInv& sb = s_src[k];
             bool cand = valid;
             if (use_wedge) {
-                const float a1 = fline(sb.e1s, t.q1.x, t.q1.y), a2 = fline(sb.e1s, t.q2.x, t.q2.y);
-                const float a3 = fline(sb.e2s, t.q1.x, t.q1.y), a4 = fline(sb.e2s, t.q2.x, t.q2.y);
-                const float lo2 = __builtin_fminf(__builtin_fminf(a1, a2), __builtin_fminf(a3, a4));
-                const float hi2 = __builtin_fmaxf(__builtin_fmaxf(a1, a2), __builtin_fmaxf(a3, a4));
+                // both endpoints against one line at once: packed FP32 FMAs (v_pk_fma_f32), two lanes of work per instruction
+                const v2f qx = { t.q1.x, t.q2.x }, qy = { t.q1.y, t.q2.y };
+                const v2f a12 = pk_line(sb.e1s, qx, qy), a34 = pk_line(sb.e2s, qx, qy);
+                const float lo2 = __builtin_fminf(__builtin_fminf(a12.x, a12.y), __builtin_fminf(a34.x, a34.y));
+                const float hi2 = __builtin_fmaxf(__builtin_fmaxf(a12.x, a12.y), __builtin_fmaxf(a34.x, a34.y));
                 const bool out2 = lo2 > 1.0f || hi2 < -1.0f;        // target segment strictly outside the source wedge
-                const float b1 = fline(eq1s, sb.s.p1.x, sb.s.p1.y), b2 = fline(eq1s, sb.s.p2.x, sb.s.p2.y);
-                const float b3 = fline(eq2s, sb.s.p1.x, sb.s.p1.y), b4 = fline(eq2s, sb.s.p2.x, sb.s.p2.y);
-                const float lo1 = __builtin_fminf(__builtin_fminf(b1, b2), __builtin_fminf(b3, b4));
-                const float hi1 = __builtin_fmaxf(__builtin_fmaxf(b1, b2), __builtin_fmaxf(b3, b4));
+                const v2f px = { sb.s.p1.x, sb.s.p2.x }, py = { sb.s.p1.y, sb.s.p2.y };
+                const v2f b12 = pk_line(eq1s, px, py), b34 = pk_line(eq2s, px, py);
+                const float lo1 = __builtin_fminf(__builtin_fminf(b12.x, b12.y), __builtin_fminf(b34.x, b34.y));
+                const float hi1 = __builtin_fmaxf(__builtin_fmaxf(b12.x, b12.y), __builtin_fmaxf(b34.x, b34.y));
                 const bool out1 = lo1 > 1.0f || hi1 < -1.0f;        // source segment strictly outside the target wedge
                 cand = valid && !out1 && !out2;
             }
