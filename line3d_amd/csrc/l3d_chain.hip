@@ -20,6 +20,7 @@
 
 #include "l3d_ctx.hpp"
 #include "l3d_scan.hpp"
+#include "l3d_kept.hpp"
 
 using namespace l3d;
 
@@ -176,27 +177,7 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
     const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (y >= a.seg_end || a.res->overflow) return;
-    Match* out = arena + a.res->kept_base;
-    const int start = a.row_start[y * a.N];
-    const int m = a.row_start[(y + 1) * a.N] - start;
-    int o = kept_start[y];
-    for (int i0 = 0; i0 < m; i0 += 64) {
-        const int i = i0 + lane;
-        const float c = i < m ? a.cand_conf[start + i] : 0.0f;
-        const bool k = c > 1.0f;
-        const unsigned long long b = __ballot(k);
-        if (k) {
-            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
-            const uint2 meta = a.cand_meta[start + i];
-            const float4 d = a.cand_depths[start + i];
-            Match r;
-            r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
-            r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
-            r.confidence = c / 2.0f;                 // confidence_norm, cudawrapper.cu:1089,1098
-            out[pos] = r;
-        }
-        o += __popcll(b);
-    }
+    write_kept_segment(a, y, lane, kept_start[y], local2global, arena + a.res->kept_base);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,

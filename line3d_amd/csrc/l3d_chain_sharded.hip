@@ -21,6 +21,7 @@
 
 #include "l3d_ctx.hpp"
 #include "l3d_scan.hpp"
+#include "l3d_kept.hpp"
 
 using namespace l3d;
 
@@ -98,27 +99,7 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     if (lane == 0) reinterpret_cast<float2*>(slot + g.best_off)[y - a.seg_begin] = best[y];
     if (hd->overflow) return;
-    Match* out = reinterpret_cast<Match*>(slot + g.rec_off);
-    const int start = a.row_start[y * a.N];
-    const int m = a.row_start[(y + 1) * a.N] - start;
-    int o = kept_start[y];
-    for (int i0 = 0; i0 < m; i0 += 64) {
-        const int i = i0 + lane;
-        const float c = i < m ? a.cand_conf[start + i] : 0.0f;
-        const bool k = c > 1.0f;
-        const unsigned long long b = __ballot(k);
-        if (k) {
-            const int pos = o + __popcll(b & ((1ull << lane) - 1ull));
-            const uint2 meta = a.cand_meta[start + i];
-            const float4 d = a.cand_depths[start + i];
-            Match r;
-            r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
-            r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
-            r.confidence = c / 2.0f;                 // confidence_norm, cudawrapper.cu:1089,1098
-            out[pos] = r;
-        }
-        o += __popcll(b);
-    }
+    write_kept_segment(a, y, lane, kept_start[y], local2global, reinterpret_cast<Match*>(slot + g.rec_off));
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
