@@ -741,7 +741,9 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
 // the kept lists, on a few host threads while the GPU is still busy with later views.  Two kinds of task:
 //   split(k)    when the list of processed view k arrives: its entries are bucketed by the camera they point to
 //               (reverse direction) and its own forward entries / only-best store are produced;
-//   merge(view) when all lists that can mention a view are split: concatenate, sort per segment, de-duplicate.
+//   merge(view) when all lists that can mention a view are split: as kParts independent segment ranges (the split has
+//               pre-sorted its entries into them) -- gather, counting sort by segment, linear merge of each segment's
+//               two sorted runs, de-duplicate; the part that finishes last concatenates the ranges.
 struct ChainFinalizer {
     L* h;
     std::vector<int> own_index;                     // per view index: its position in the processing order or -1
@@ -755,7 +757,7 @@ struct ChainFinalizer {
     std::vector<std::array<std::vector<std::pair<uint32_t, Key>>, 4>>* parts = nullptr;   // storage owned by the pipeline object
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (1 = merge, view index)
+    std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (2 = merge part, view index * kParts + part)
     bool done = false;
     std::vector<std::thread> workers;
     bool timing = getenv("L3D_TIMING") != nullptr;
@@ -836,15 +838,6 @@ struct ChainFinalizer {
             for (int q = 0; q < kParts; ++q) p.insert(p.end(), (*parts)[vi][(size_t)q].begin(), (*parts)[vi][(size_t)q].end());
         }
     }
-    void merge(size_t vi)
-    {
-        View& v = *h->vlist[vi];
-        std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
-        if (own_index[vi] < 0) p.clear();               // otherwise split(own) has put the forward entries there
-        for (int k : contributors[vi])
-            for (auto& e : (*buckets)[(size_t)k]) if (e.first == vi) for (auto& q : e.second) p.insert(p.end(), q.begin(), q.end());
-        finalize_view_pot(p, (size_t)v.S());
-    }
     void start(unsigned nthreads)
     {
         for (unsigned t = 0; t < nthreads; ++t)
@@ -859,7 +852,7 @@ struct ChainFinalizer {
                         queue.pop_back();
                     }
                     const double tj0 = now_s();
-                    if (job.first == 0) split(job.second); else if (job.first == 1) merge(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
+                    if (job.first == 0) split(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
                     if (timing) { const double dt = now_s() - tj0; std::lock_guard<std::mutex> lk(mu); (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s();
                                   if (trace) log.push_back({ job.first, (int)job.second, tj0, t_last_done }); }
                 }
