@@ -355,8 +355,8 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
         va.mmax = mfit; va.skip_above = 1;
         { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
         if (mfit < mmax) {
-            HIPCHK(c, c->vw_scratch.reserve(((size_t)R + 2) * 16));
-            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)R + 2;
+            HIPCHK(c, c->vw_scratch.reserve(((size_t)R + kVWSlack) * 16));
+            va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)R + kVWSlack;
             ProfScope p(c, "verify_window"); launch_verify_window(va, st);
         }
     } else { ProfScope p(c, "verify"); launch_verify(va, st); }

@@ -406,7 +406,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
         HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
         HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
-        HIPCHK(c, c->vw_scratch.reserve((cand_cap + 2) * 16));
+        HIPCHK(c, c->vw_scratch.reserve((cand_cap + kVWSlack) * 16));
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
         // ring of stage-1 candidate buffers: stage 1 (incl. the triangulation of its candidates) runs kStage1Ahead views ahead
         HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
@@ -486,7 +486,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             // one launch: segments that fit the LDS image, the ones that outgrow it (reverse matches are not in the estimate)
             // on a global scratch, and the per-segment epilogue (best hypothesis, kept count)
             va.skip_above = 1; va.only_above = -1; va.big = 2;
-            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + 2;
+            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + kVWSlack;
             va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
         } else {

@@ -313,7 +313,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->cand_meta.reserve(h->cand_cap * 8));
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
     OCHK(c->cand_conf.reserve(h->cand_cap * 4));
-    OCHK(c->vw_scratch.reserve((h->cand_cap + 2) * 16));
+    OCHK(c->vw_scratch.reserve((h->cand_cap + kVWSlack) * 16));
     OCHK(c->ch_ringA_meta.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 8));
     OCHK(c->ch_ringA_depths.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 16));
     h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
@@ -438,7 +438,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         if (c->verify_mode == 0 && verify_window_supported(N)) {
             // one launch: LDS blocks, global-scratch blocks for segments that outgrow the LDS image, per-segment epilogue
             va.skip_above = 1; va.only_above = -1; va.big = 2;
-            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + 2;
+            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + kVWSlack;
             va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
         } else {

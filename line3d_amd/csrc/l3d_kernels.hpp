@@ -8,7 +8,8 @@ namespace l3d {
 
 constexpr int kSrcPerBlock = 32;    // source segments walked by one k_pair_mask workgroup
 constexpr int kMaxW64 = 256;        // bit-row words per camera: up to 16384 segments per view
-constexpr int kVerifyTile = 256;    // witnesses staged in LDS per step of k_verify
+constexpr int kVerifyTile = 256;
+constexpr int kVWSlack = 8;          // entries readable past the end of a k_verify_window image (the scan loads a group ahead)    // witnesses staged in LDS per step of k_verify
 
 struct Match {                      // == l3d_match (include/line3d_amd.h)
     uint32_t segID1, camID2, segID2;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
-    const int cap = big ? 0 : a.mmax + 2;                              // +2: the scan prefetches one entry ahead
+    const int cap = big ? 0 : a.mmax + kVWSlack;                       // slack: the scan loads a group of entries ahead
     VWLds L;
     L.sd1 = reinterpret_cast<float*>(s_raw);
     L.sd2 = L.sd1 + cap;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         L.sci[pos] = (mt.y << 24) | (unsigned)i;
         L.stgt[pos] = mt.x;
     }
-    if (tid < 2 && !big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
+    if (tid < kVWSlack && !big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
     __syncthreads();
     if (a.debug == 1) return;
     VW_STAMP(0);
@@ -259,35 +259,47 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         const float lo1 = d1y - w1, hi1 = d1y + w1;
         int j = 0, jend = 0;
         if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
-        float c1 = L.sd1[j], c2 = L.sd2[j];
-        unsigned cc = L.sci[j];
+        // the window is walked in groups of kG entries: the next group's loads (3 per entry, LDS or L2) are in flight while
+        // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
+        constexpr int kG = 4;
+        float c1[kG], c2[kG];
+        unsigned cc[kG];
+#pragma unroll
+        for (int g = 0; g < kG; ++g) { c1[g] = L.sd1[j + g]; c2[g] = L.sd2[j + g]; cc[g] = L.sci[j + g]; }
         VW_STAMP(1);
         for (;;) {
-            const bool in = j < jend;
-            if (!__any(in)) break;
-            const float n1 = L.sd1[j + 1], n2 = L.sd2[j + 1];          // next entry, issued before the current one is used
-            const unsigned nc = L.sci[j + 1];
-            // :674 (other cameras only) and the 1-D tests every gate-passing witness satisfies; the exact 3-D gate
-            // and the confidence run on the compacted survivors (vw_drain)
-            const bool push = in && (cc >> 24) != cam_h && c1 >= lo1 && c1 <= hi1 && __builtin_fabsf(c2 - d2y) <= w2;
-            const unsigned long long pm = __ballot(push);
-            if (pm) {
-                if (push) {
-                    const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
-                    q[pos * 2] = (unsigned)lane | ((cc >> 24) << 8);
-                    q[pos * 2 + 1] = (unsigned)j;
-                }
-                count += __popcll(pm);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (count >= 64) {
-                    VW_STAMP(2);
-                    vw_drain(a, L, q, head, 64, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
-                    head = (head + 64) & (kVQ - 1);
-                    count -= 64;
-                    VW_STAMP(3);
+            if (!__any(j < jend)) break;
+            float n1[kG], n2[kG];
+            unsigned nc[kG];
+            const int jn = j < jend ? j + kG : j;                          // (lanes that are done keep re-reading in range)
+#pragma unroll
+            for (int g = 0; g < kG; ++g) { n1[g] = L.sd1[jn + g]; n2[g] = L.sd2[jn + g]; nc[g] = L.sci[jn + g]; }
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                // :674 (other cameras only) and the 1-D tests every gate-passing witness satisfies; the exact 3-D gate
+                // and the confidence run on the compacted survivors (vw_drain)
+                const bool push = j + g < jend && (cc[g] >> 24) != cam_h && c1[g] >= lo1 && c1[g] <= hi1 && __builtin_fabsf(c2[g] - d2y) <= w2;
+                const unsigned long long pm = __ballot(push);
+                if (pm) {
+                    if (push) {
+                        const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
+                        q[pos * 2] = (unsigned)lane | ((cc[g] >> 24) << 8);
+                        q[pos * 2 + 1] = (unsigned)(j + g);
+                    }
+                    count += __popcll(pm);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (count >= 64) {
+                        VW_STAMP(2);
+                        vw_drain(a, L, q, head, 64, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
+                        head = (head + 64) & (kVQ - 1);
+                        count -= 64;
+                        VW_STAMP(3);
+                    }
                 }
             }
-            if (in) { ++j; c1 = n1; c2 = n2; cc = nc; }
+            j = jn;
+#pragma unroll
+            for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; }
         }
         VW_STAMP(2);
         if (count > 0) vw_drain(a, L, q, head, count, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
@@ -344,7 +356,7 @@ __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_beg
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
-size_t verify_window_lds_bytes_nt(int mmax, int N, int nt) { return (size_t)(mmax + 2) * 16 + (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 16; }
+size_t verify_window_lds_bytes_nt(int mmax, int N, int nt) { return (size_t)(mmax + kVWSlack) * 16 + (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 16; }
 size_t verify_window_lds_bytes(int mmax, int N) { return verify_window_lds_bytes_nt(mmax, N, 256); }
 size_t verify_window_lds_bytes_big(int N, int nt) { return (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 64; }
 // Largest dynamic LDS a k_verify_window launch may ask for on this device/runtime (queried once): up to 160 KB per
