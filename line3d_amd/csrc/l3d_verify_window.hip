@@ -53,31 +53,38 @@ struct VWLds {
 // Evaluate up to 64 queued (hypothesis lane, witness position) pairs with all lanes busy: exact 3-D gate first
 // (cudawrapper.cu:388-401), then projection validity (:690-693) and the 2-D/angle confidence (:404-426); the
 // per-camera maximum goes to LDS with an integer atomic max (confidences are positive floats).
-__device__ __forceinline__ void vw_drain(const VerifyArgs& a, const VWLds& L, const unsigned* q, int head, int n, int lane,
+__device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, const int* sOff, const unsigned* q, int head, int n, int lane,
                                          f3 C, f3 ray1, f3 ray2, f3 X1, f3 X2, f3 v1, float T1, float T2, bool gate,
                                          float* smax_wave, float two_sig_d, float two_sig_a)
 {
-    unsigned key = 0, wj = 0;
-    if (lane < n) { key = q[((head + lane) & (kVQ - 1)) * 2]; wj = q[((head + lane) & (kVQ - 1)) * 2 + 1]; }
+    // a ring entry carries everything the witness contributes (camera, target id, both depths): the only global access of
+    // the evaluation is the gather of the target segment, issued straight after the ring read
+    unsigned key = 0, tgt = 0;
+    float wd1 = 0.0f, wd2 = 0.0f;
+    if (lane < n) {
+        const uint4 e = reinterpret_cast<const uint4*>(q)[(head + lane) & (kVQ - 1)];
+        key = e.x; tgt = e.y; wd1 = __uint_as_float(e.z); wd2 = __uint_as_float(e.w);
+    }
     const int origin = key & 63, cam = (int)(key >> 8);
+    float4 tq = make_float4(0.f, 0.f, 1.f, 1.f);
+    if (lane < n) tq = a.tgt_segs[sOff[cam] + tgt];
     const f3 hX1 = mk3(__shfl(X1.x, origin), __shfl(X1.y, origin), __shfl(X1.z, origin));
     const f3 hX2 = mk3(__shfl(X2.x, origin), __shfl(X2.y, origin), __shfl(X2.z, origin));
     const f3 hv = mk3(__shfl(v1.x, origin), __shfl(v1.y, origin), __shfl(v1.z, origin));
     const float hT1 = __shfl(T1, origin), hT2 = __shfl(T2, origin);
     if (lane >= n) return;
-    const f3 Q1 = C + L.sd1[wj] * ray1;                                  // D_unproject_point_src, :669-672
-    const f3 Q2 = C + L.sd2[wj] * ray2;
+    const f3 Q1 = C + wd1 * ray1;                                        // D_unproject_point_src, :669-672
+    const f3 Q2 = C + wd2 * ray2;
     if (gate) {
         const f3 e1 = hX1 - Q1, e2 = hX2 - Q2;
         if (dot(e1, e1) > hT1 || dot(e2, e2) > hT2) return;              // :396-400 on squared distances
     }
     bool va, vb;
-    const f3 pr1 = project(a.P + cam * 12, hX1, va);
-    const f3 pr2 = project(a.P + cam * 12, hX2, vb);
+    const f3 pr1 = project(sP + cam * 12, hX1, va);
+    const f3 pr2 = project(sP + cam * 12, hX2, vb);
     if (!(va && vb)) return;
     const f3 line1 = cross(pr1, pr2);
     const float den1 = line_norm2d(line1);
-    const float4 tq = a.tgt_segs[a.offsets[cam].x + L.stgt[wj]];
     const f3 q1 = mk3(tq.x, tq.y, 1.0f), q2 = mk3(tq.z, tq.w, 1.0f);
     const f3 l2 = cross(q1, q2);
     const float den2 = line_norm2d(l2);
@@ -138,8 +145,12 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         L.sd1 = g + start; L.sd2 = g + stride + start;
         L.sci = reinterpret_cast<unsigned*>(g + 2 * stride) + start; L.stgt = reinterpret_cast<unsigned*>(g + 3 * stride) + start;
     }
-    unsigned* qall = reinterpret_cast<unsigned*>(smax + NT * a.N);
-    unsigned* q = qall + wave * kVQ * 2;
+    unsigned* qall = reinterpret_cast<unsigned*>(smax + NT * a.N);           // 16-byte entries (the image sizes keep it aligned)
+    unsigned* q = qall + wave * kVQ * 4;
+    float* sP = reinterpret_cast<float*>(qall + NW * kVQ * 4);               // projection matrices and target offsets of the N cameras
+    int* sOff = reinterpret_cast<int*>(sP + a.N * 12);
+    for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
+    for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
     float* smax_wave = smax + wave * 64 * a.N;
 
     // ---- one coalesced pass over the segment's candidates (kept in registers), counting sort on the depth bucket
@@ -263,17 +274,17 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
         constexpr int kG = 4;
         float c1[kG], c2[kG];
-        unsigned cc[kG];
+        unsigned cc[kG], ct[kG];
 #pragma unroll
-        for (int g = 0; g < kG; ++g) { c1[g] = L.sd1[j + g]; c2[g] = L.sd2[j + g]; cc[g] = L.sci[j + g]; }
+        for (int g = 0; g < kG; ++g) { c1[g] = L.sd1[j + g]; c2[g] = L.sd2[j + g]; cc[g] = L.sci[j + g]; ct[g] = L.stgt[j + g]; }
         VW_STAMP(1);
         for (;;) {
             if (!__any(j < jend)) break;
             float n1[kG], n2[kG];
-            unsigned nc[kG];
+            unsigned nc[kG], nt[kG];
             const int jn = j < jend ? j + kG : j;                          // (lanes that are done keep re-reading in range)
 #pragma unroll
-            for (int g = 0; g < kG; ++g) { n1[g] = L.sd1[jn + g]; n2[g] = L.sd2[jn + g]; nc[g] = L.sci[jn + g]; }
+            for (int g = 0; g < kG; ++g) { n1[g] = L.sd1[jn + g]; n2[g] = L.sd2[jn + g]; nc[g] = L.sci[jn + g]; nt[g] = L.stgt[jn + g]; }
 #pragma unroll
             for (int g = 0; g < kG; ++g) {
                 // :674 (other cameras only) and the 1-D tests every gate-passing witness satisfies; the exact 3-D gate
@@ -283,14 +294,13 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
                 if (pm) {
                     if (push) {
                         const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
-                        q[pos * 2] = (unsigned)lane | ((cc[g] >> 24) << 8);
-                        q[pos * 2 + 1] = (unsigned)(j + g);
+                        reinterpret_cast<uint4*>(q)[pos] = make_uint4((unsigned)lane | ((cc[g] >> 24) << 8), ct[g], __float_as_uint(c1[g]), __float_as_uint(c2[g]));
                     }
                     count += __popcll(pm);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     if (count >= 64) {
                         VW_STAMP(2);
-                        vw_drain(a, L, q, head, 64, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
+                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
                         head = (head + 64) & (kVQ - 1);
                         count -= 64;
                         VW_STAMP(3);
@@ -299,10 +309,10 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
             }
             j = jn;
 #pragma unroll
-            for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; }
+            for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; ct[g] = nt[g]; }
         }
         VW_STAMP(2);
-        if (count > 0) vw_drain(a, L, q, head, count, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
+        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         VW_STAMP(3);
         float conf_sum = 0.0f;
@@ -356,9 +366,9 @@ __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_beg
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
-size_t verify_window_lds_bytes_nt(int mmax, int N, int nt) { return (size_t)(mmax + kVWSlack) * 16 + (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 16; }
+size_t verify_window_lds_bytes_nt(int mmax, int N, int nt) { return (size_t)(mmax + kVWSlack) * 16 + (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 16 + (size_t)N * 52 + 16; }
 size_t verify_window_lds_bytes(int mmax, int N) { return verify_window_lds_bytes_nt(mmax, N, 256); }
-size_t verify_window_lds_bytes_big(int N, int nt) { return (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 8 + 64; }
+size_t verify_window_lds_bytes_big(int N, int nt) { return (size_t)nt * N * 4 + (size_t)(nt / 64) * kVQ * 16 + (size_t)N * 52 + 64; }
 // Largest dynamic LDS a k_verify_window launch may ask for on this device/runtime (queried once): up to 160 KB per
 // workgroup on gfx950 once the kernel has opted in; runtimes that refuse the opt-in stay at the 48/64 KB default.
 static size_t g_lds_budget_override = 0;
