@@ -36,8 +36,8 @@ __device__ __forceinline__ float window_margin(float unc, float d_y, float dabs_
 // (spatial_k ~ 0.5 % of the depth).  A counting sort on that id (LDS atomics, O(m), no comparison sort) makes every
 // depth window a contiguous range of a few buckets; the order inside a bucket is arbitrary, which cannot change
 // the result (per-camera maxima, summed in camera order).
-constexpr int kBucketShift = 16;               // 128 buckets per octave of depth
-constexpr int kBuckets = 1024;                 // 8 octaves; anything beyond is clamped into the last bucket
+constexpr int kBucketShift = 15;               // 256 buckets per octave of depth
+constexpr int kBuckets = 2048;                 // 8 octaves; anything beyond is clamped into the last bucket
 constexpr int kVQ = 128;                       // per-wave ring of gate candidates
 __device__ __forceinline__ int bucket_of(float d, int base)
 {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
     const float cd = c_expf(-dist * dist / two_sig_d);
     const float conf = __builtin_fminf(cd, c_expf(-angle * angle / two_sig_a));
     if (conf > 0.5f)                                                     // :699-704 (max over the camera's witnesses)
-        atomicMax(reinterpret_cast<int*>(&smax_wave[origin * a.N + cam]), __float_as_int(conf));
+        atomicMax(reinterpret_cast<int*>(&smax_wave[cam * 64 + origin]), __float_as_int(conf));
 }
 
 // NT threads per workgroup: 256 when the grid fills the chip, 512 when only a few segments are verified per launch
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
                 w1 = w2 = __builtin_inff();
             }
         }
-        for (int c = 0; c < a.N; ++c) smax_wave[lane * a.N + c] = 0.0f;
+        for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;        // [camera][lane]: conflict-free rows
         int head = 0, count = 0;                                       // wave-uniform ring state
         const float lo1 = d1y - w1, hi1 = d1y + w1;
         int j = 0, jend = 0;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         VW_STAMP(3);
         float conf_sum = 0.0f;
-        for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[lane * a.N + c];   // ascending camera order; +0.0f is exact
+        for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[c * 64 + lane];   // ascending camera order; +0.0f is exact
         if (hv) {
             a.cand_conf[start + idx_h] = conf_sum;
             kept_l += conf_sum > 1.0f;
