@@ -148,6 +148,8 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             sharded_mode["i"] = 1
+        if os.environ.get("L3D_BENCH_MODE"):            # testing: start at a given multi-GPU mode (0 native, 1 torch-driven, 2 per-view)
+            sharded_mode["i"] = max(sharded_mode["i"], int(os.environ["L3D_BENCH_MODE"]))
 
     def step_once(mode):
         if mode == 0:       # rank 0 trails behind with the host bookkeeping; the other ranks only feed the collectives
