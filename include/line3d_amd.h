@@ -147,6 +147,9 @@ typedef struct l3d_chain_view {
     const int32_t* source_cam; const int32_t* source_index; int32_t n_sources;
     float sigma_p, sigma_a, spatial_k;
 } l3d_chain_view;
+/* `kept` points into pinned host memory owned by the context and stays valid until the next chain (l3d_match_chain /
+ * l3d_shard_chain_open) starts on it or the context is destroyed: a callback may keep the pointer instead of copying.
+ * `best_depths` is only valid during the call. */
 typedef int (*l3d_chain_callback)(void* user, int index, int verified, const l3d_match* kept, int n_kept,
                                   const float* best_depths, int n_best, int n_candidates);
 int l3d_match_chain(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user);

@@ -88,7 +88,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
-    c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release();
+    c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
     (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);

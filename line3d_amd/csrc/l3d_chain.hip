@@ -245,6 +245,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     if (n_views == 0) return L3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const double t_setup0 = now_s();
+    c->pin_arena.reset();
     hipStream_t st = c->stream;         // phase 2 (the chain proper)
     hipStream_t s1 = c->stage1_stream;  // stage 1 runs ahead here, concurrently with the latency-bound kernels of phase 2
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
@@ -553,12 +554,15 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             --k;
             continue;
         }
-        // kept slice and best depths: bulk copies on the copy stream, concurrent with the kernels of later views
         const double td0 = now_s();
-        HIPCHK(c, c->ch_pin_kept.reserve((size_t)r.n_kept * sizeof(Match) + 16));
+        // kept slice and best depths: bulk copies on the copy stream, concurrent with the kernels of later views; the kept
+        // list lands in the pinned arena, where it stays valid for the caller until the next chain starts
+        hipError_t ae = hipSuccess;
+        l3d_match* kept_host = static_cast<l3d_match*>(c->pin_arena.alloc((size_t)r.n_kept * sizeof(Match) + 16, &ae));
+        HIPCHK(c, ae);
         HIPCHK(c, c->ch_pin_best.reserve((size_t)v.S_src * 8 + 16));
         if (r.n_kept)
-            HIPCHK(c, hipMemcpyAsync(c->ch_pin_kept.p, c->ch_kept.as<Match>() + r.kept_base, (size_t)r.n_kept * sizeof(Match),
+            HIPCHK(c, hipMemcpyAsync(kept_host, c->ch_kept.as<Match>() + r.kept_base, (size_t)r.n_kept * sizeof(Match),
                                      hipMemcpyDeviceToHost, c->copy_stream));
         if (v.S_src) HIPCHK(c, hipMemcpyAsync(c->ch_pin_best.p, d.best, (size_t)v.S_src * 8, hipMemcpyDeviceToHost, c->copy_stream));
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
@@ -570,7 +574,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         kept_total += r.n_kept;
         const double tc0 = now_s();
         t_d2h += tc0 - td0;
-        if (cb(user, k, 1, c->ch_pin_kept.as<l3d_match>(), r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
+        if (cb(user, k, 1, kept_host, r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
         t_cb += now_s() - tc0;
     }
     if (getenv("L3D_TIMING"))

@@ -189,6 +189,7 @@ struct l3d_shard_chain {
     std::atomic<int> marked{0};              // views [0, marked) carry their completion event
     std::atomic<int> fetched{0};             // views [0, fetched) have left their staging buffer
     int copy_issued = -1;                    // view whose D2H copy the previous fetch has already issued (fetch thread only)
+    l3d_match* copy_dst = nullptr;           // ... and where its records go (pinned arena)
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
 };
 
@@ -317,7 +318,8 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->ch_ringA_meta.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 8));
     OCHK(c->ch_ringA_depths.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 16));
     h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
-    OCHK(c->ch_pin_kept.reserve(2 * (h->stage_bytes + 64) + 64));
+    OCHK(c->ch_pin_kept.reserve(2 * ((size_t)world * (size_t)h->geom.seg_cap * 8 + 64) + 64));
+    c->pin_arena.reset();
     OCHK(c->ch_stage.reserve((size_t)l3d_shard_chain::kRing * h->stage_bytes + 64));
     OCHK(c->ch_pin_best.reserve((size_t)n_views * sizeof(PackHeader) + 64));
     h->hdr_host = c->ch_pin_best.as<PackHeader>();
@@ -508,25 +510,32 @@ int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void
     const PackHeader ph = h->hdr_host[k];
     if (ph.overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
     const size_t best_bytes = (size_t)h->geom.seg_cap * 8;
-    const size_t pin_bytes = h->stage_bytes + 64;
-    unsigned char* host = c->ch_pin_kept.as<unsigned char>() + (size_t)(k & 1) * pin_bytes;      // two pinned buffers
-    auto issue_copy = [&](int v, const PackHeader& hd) -> hipError_t {
+    const size_t pin_bytes = (size_t)h->world * best_bytes + 64;
+    unsigned char* host = c->ch_pin_kept.as<unsigned char>() + (size_t)(k & 1) * pin_bytes;      // depth pairs: two small pinned buffers
+    // the records go straight into the pinned arena (valid for the caller until the next chain), the depth pairs to staging
+    auto issue_copy = [&](int v, const PackHeader& hd, l3d_match** dst) -> int {
         const unsigned char* stage = c->ch_stage.as<unsigned char>() + (size_t)(v % l3d_shard_chain::kRing) * h->stage_bytes;
-        return hipMemcpyAsync(c->ch_pin_kept.as<unsigned char>() + (size_t)(v & 1) * pin_bytes, stage,
-                              (size_t)h->world * best_bytes + (size_t)hd.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream);
+        hipError_t ae = hipSuccess;
+        *dst = static_cast<l3d_match*>(c->pin_arena.alloc((size_t)hd.n_kept * sizeof(Match) + 16, &ae));
+        HIPCHK(c, ae);
+        HIPCHK(c, hipMemcpyAsync(c->ch_pin_kept.as<unsigned char>() + (size_t)(v & 1) * pin_bytes, stage, (size_t)h->world * best_bytes,
+                                 hipMemcpyDeviceToHost, c->copy_stream));
+        if (hd.n_kept) HIPCHK(c, hipMemcpyAsync(*dst, stage + (size_t)h->world * best_bytes, (size_t)hd.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream));
+        return L3D_OK;
     };
-    if (h->copy_issued != k) HIPCHK(c, issue_copy(k, ph));       // (otherwise the previous fetch has issued it already)
+    l3d_match* kept_dst = h->copy_dst;
+    if (h->copy_issued != k) { int rc = issue_copy(k, ph, &kept_dst); if (rc) return rc; }       // (otherwise the previous fetch has issued it already)
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     h->fetched.store(k + 1, std::memory_order_release);          // the staging buffer of view k may be reused
     // the next view's copy travels while this view's bookkeeping runs, if the GPU is already done with it
     if (k + 1 < h->n_views && h->vd[(size_t)(k + 1)].verified && h->marked.load(std::memory_order_acquire) > k + 1 && h->packed[(size_t)(k + 1)] &&
         hipEventQuery(h->ev2[(size_t)(k + 1)]) == hipSuccess && !h->hdr_host[k + 1].overflow) {
-        HIPCHK(c, issue_copy(k + 1, h->hdr_host[k + 1]));
+        int rc = issue_copy(k + 1, h->hdr_host[k + 1], &h->copy_dst); if (rc) return rc;
         h->copy_issued = k + 1;
     } else {
         (void)hipGetLastError();                                 // hipEventQuery reports "not ready" as an error
     }
-    const l3d_match* kept = reinterpret_cast<const l3d_match*>(host + (size_t)h->world * best_bytes);
+    const l3d_match* kept = kept_dst;
     std::vector<float>& best = h->best_scratch;
     best.clear();
     if (ph.R > 0)

@@ -2,6 +2,7 @@
 // pinned staging, per-kernel HIP-event profiling.
 #pragma once
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +49,31 @@ struct PinBuf {                     // pinned host staging (async copies that re
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// Pinned host memory handed out in slices that stay valid until the next reset: the kept lists of a chain are copied
+// (SDMA) straight to where the caller's bookkeeping will read them -- no staging buffer, no second host copy.
+struct PinArena {
+    static constexpr size_t kChunk = 64u << 20;
+    std::vector<PinBuf> chunks;
+    size_t cur = 0, used = 0;
+    void reset() { cur = 0; used = 0; }
+    void* alloc(size_t bytes, hipError_t* err)
+    {
+        *err = hipSuccess;
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (;;) {
+            if (cur < chunks.size()) {
+                if (used + bytes <= chunks[cur].cap) { void* r = static_cast<char*>(chunks[cur].p) + used; used += bytes; return r; }
+                ++cur; used = 0;
+                continue;
+            }
+            chunks.emplace_back();
+            *err = chunks.back().reserve(std::max(bytes, kChunk));
+            if (*err != hipSuccess) { chunks.pop_back(); return nullptr; }
+        }
+    }
+    void release() { for (auto& b : chunks) b.release(); chunks.clear(); reset(); }
+};
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -69,6 +95,7 @@ struct l3d_ctx {
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    l3d::PinArena pin_arena;                 // kept lists of the running / last chain (valid until the next chain starts)
     std::vector<int> h_cnt;
     int mmax_seen = 0;
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)

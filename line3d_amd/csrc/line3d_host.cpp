@@ -110,6 +110,20 @@ struct Hyp {                                    // L3DCorrespondenceRRW + L3DSeg
     float depth_p1, depth_p2;
 };
 
+// A processed view's kept list in chain mode: a slice of the context's pinned arena (valid until the next chain starts,
+// include/line3d_amd.h) -- or an own vector for the lists the host builds itself (early-return views).
+struct KeptList {
+    const l3d_match* p = nullptr;
+    size_t n = 0;
+    std::vector<l3d_match> own;
+    const l3d_match* begin() const { return p; }
+    const l3d_match* end() const { return p + n; }
+    const l3d_match* data() const { return p; }
+    size_t size() const { return n; }
+    void reset() { p = nullptr; n = 0; own.clear(); }
+    void use_own() { p = own.data(); n = own.size(); }
+};
+
 struct FinalLine {
     std::vector<Key> segs2D;
     std::vector<std::pair<V3, V3>> segs3D;
@@ -150,7 +164,7 @@ struct l3d_line3d {
     std::map<uint32_t, std::vector<l3d_match>> view_matches;   // kept matches per view (for inspection)
     std::vector<std::vector<std::pair<size_t, std::array<std::vector<std::pair<uint32_t, Key>>, 4>>>> fin_buckets;   // finaliser scratch, reused across passes
     std::vector<std::array<std::vector<std::pair<uint32_t, Key>>, 4>> fin_parts;
-    std::vector<std::vector<l3d_match>> saved;                 // chain mode: performMatching's `matches` per processed view
+    std::vector<KeptList> saved;                               // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
     bool pot_check_failed = false;                             // L3D_CHECK_POT=1 (tests)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
@@ -701,11 +715,11 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
     L* h = u->h;
     const double t0 = now_s();
     View& v = h->views[(*u->order)[(size_t)index]];
-    std::vector<l3d_match>& mine = h->saved[(size_t)index];
+    KeptList& mine = h->saved[(size_t)index];
     if (!verified) {
         // cudawrapper.cu:877-878: the localized existing list comes back untouched (LOCAL camera ids, confidence 0).
         // It is what the earlier views pushed (line3D.cc:838-872), in push order: sources ascending, list order.
-        mine.clear();
+        mine.reset();
         const std::vector<uint32_t>& nbs = h->visual_neighbors[v.id];
         for (int a : (*u->src_idx)[(size_t)index])
             for (const l3d_match& mp : h->saved[(size_t)a]) {
@@ -714,8 +728,9 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
                 r.segID1 = mp.segID2; r.segID2 = mp.segID1; r.confidence = 0.0f;
                 r.camID2 = (uint32_t)(std::lower_bound(nbs.begin(), nbs.end(), h->views[(*u->order)[(size_t)a]].id) - nbs.begin());
                 r.depths[0] = mp.depths[2]; r.depths[1] = mp.depths[3]; r.depths[2] = mp.depths[0]; r.depths[3] = mp.depths[1];
-                mine.push_back(r);
+                mine.own.push_back(r);
             }
+        mine.use_own();
         v.median_depth = 1.0f;                          // line3D.cc:811,835
     } else {
         float median = 1.0f;                            // untouched when nothing was verified (cudawrapper.cu:955-956)
@@ -728,7 +743,8 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
             }
         }
         v.median_depth = median;
-        mine.assign(kept, kept + n_kept);
+        mine.reset();
+        mine.p = kept; mine.n = (size_t)n_kept;         // no copy: the list lives in the context's pinned arena
     }
     mark_matched(h, v);                                 // line3D.cc:875-881
     h->stat_kept += (double)mine.size();
@@ -778,7 +794,7 @@ struct ChainFinalizer {
     void split(size_t k)
     {
         const View& v = h->views[h->order[k]];
-        const std::vector<l3d_match>& lst = h->saved[k];
+        const KeptList& lst = h->saved[k];
         auto& bk = (*buckets)[k];
         // cameras whose views receive the reverse entry of a kept match: the neighbours -- or, for an early-return view
         // (cudawrapper.cu:877-878: LOCAL camera ids come back), whatever views those numbers happen to name
@@ -948,7 +964,7 @@ void start_finalizer(L* h, ChainPlan& P)
 {
     const size_t n = P.n, nvl = h->vlist.size();
     h->saved.resize(n);                                 // (capacity of the per-view lists survives from an earlier pass)
-    for (auto& lst : h->saved) lst.clear();
+    for (auto& lst : h->saved) lst.reset();
     P.fin.reset(new ChainFinalizer(nvl));
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
@@ -1002,7 +1018,7 @@ void finish_chain_host(L* h, ChainPlan& P, bool ok)
     }
     std::sort(h->pot_foreign.begin(), h->pot_foreign.end());
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
-    if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]] = h->saved[k];
+    if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]].assign(h->saved[k].begin(), h->saved[k].end());
     h->t_finalize += now_s() - t2;
     if (getenv("L3D_CHECK_POT")) {
         // self-check (tests): every per-view list must be the plain normal form (sort + unique) of all its entries,
