@@ -16,6 +16,10 @@
 // overlaps with the GPU working on later views.  Results are identical to the per-view entry point
 // (l3d_compute_pairwise_matches): same kernels, same candidate order.
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "l3d_ctx.hpp"
@@ -442,12 +446,15 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         return L3D_OK;
     };
 
+    double t_ev1 = 0;                   // host time spent waiting for stage-1 statistics
     auto enqueue_view = [&](int k) -> int {
         const l3d_chain_view& v = views[k];
         const ViewDev& d = vd[(size_t)k];
         while (k_p1 < n_views && k_p1 <= k + kStage1Ahead) { int rc = enqueue_stage1(k_p1); if (rc) return rc; ++k_p1; }
         if (!d.verified) return L3D_OK;
+        const double te0 = now_s();
         HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
+        t_ev1 += now_s() - te0;
         HIPCHK(c, hipStreamWaitEvent(st, ev1[(size_t)k], 0));
         raw_sum += hstats[2 * k];
         PairArgs pa = pair_args(k);
@@ -505,83 +512,139 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         return L3D_OK;
     };
 
-    // ---- phase 2 + trailing result loop
+    // ---- phase 2 + trailing result loop.  This thread enqueues and watches the per-view result records (overflow ->
+    // grow and restart at that view); finished views are handed, in order, to a delivery thread that copies the kept slice
+    // and the depth pairs (copy stream, SDMA) and runs the caller's bookkeeping -- so the ~13 launches per view of this
+    // thread are never held up by host work.
     const double t_loop0 = now_s();
     double kept_total = 0, t_cb = 0, t_wait = 0, t_d2h = 0;
+    struct Item { int k; int verified; ChainResult r; };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<Item> work;
+    bool done = false, busy = false;
+    int deliver_rc = L3D_OK;
+    std::string deliver_err;
+    std::thread deliverer([&]() {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&]() { return done || !work.empty(); });
+                if (work.empty()) return;
+                it = work.front();
+                work.pop_front();
+                busy = true;
+            }
+            int rc = L3D_OK;
+            std::string err;
+            if (deliver_rc == L3D_OK) {
+                const l3d_chain_view& v = views[it.k];
+                const ViewDev& d = vd[(size_t)it.k];
+                if (!it.verified) {                     // cudawrapper.cu:877-878: nothing to match, the caller keeps its list
+                    if (cb(user, it.k, 0, nullptr, 0, nullptr, 0, 0)) { rc = L3D_ERR_INVALID; err = "callback failed"; }
+                } else {
+                    const double td0 = now_s();
+                    // the kept list lands in the pinned arena, where it stays valid for the caller until the next chain starts
+                    hipError_t e = hipSuccess;
+                    l3d_match* kept_host = static_cast<l3d_match*>(c->pin_arena.alloc((size_t)it.r.n_kept * sizeof(Match) + 16, &e));
+                    if (e == hipSuccess) e = c->ch_pin_best.reserve((size_t)v.S_src * 8 + 16);
+                    if (e == hipSuccess && it.r.n_kept)
+                        e = hipMemcpyAsync(kept_host, c->ch_kept.as<Match>() + it.r.kept_base, (size_t)it.r.n_kept * sizeof(Match), hipMemcpyDeviceToHost, c->copy_stream);
+                    if (e == hipSuccess && v.S_src) e = hipMemcpyAsync(c->ch_pin_best.p, d.best, (size_t)v.S_src * 8, hipMemcpyDeviceToHost, c->copy_stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+                    if (e != hipSuccess) { rc = L3D_ERR_HIP; err = std::string("chain delivery, view ") + std::to_string(it.k) + ": " + hipGetErrorString(e); }
+                    else {
+                        float* best = c->ch_pin_best.as<float>();
+                        int nb = 0;
+                        if (it.r.R > 0)
+                            for (int s = 0; s < v.S_src; ++s)
+                                if (best[2 * s] != -1.0f) { best[2 * nb] = best[2 * s]; best[2 * nb + 1] = best[2 * s + 1]; ++nb; }   // in place: nb <= s
+                        kept_total += it.r.n_kept;
+                        const double tc0 = now_s();
+                        t_d2h += tc0 - td0;
+                        if (cb(user, it.k, 1, kept_host, it.r.n_kept, best, nb, it.r.R)) { rc = L3D_ERR_INVALID; err = "callback failed"; }
+                        t_cb += now_s() - tc0;
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && deliver_rc == L3D_OK) { deliver_rc = rc; deliver_err = err; }
+                busy = false;
+            }
+            cv_idle.notify_all();
+        }
+    });
+    auto hand_over = [&](int k, int verified, const ChainResult& r) {
+        { std::lock_guard<std::mutex> lk(mu); work.push_back(Item{ k, verified, r }); }
+        cv_work.notify_one();
+    };
+    auto wait_delivered = [&]() {                       // every handed-over view has left the device arena
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&]() { return work.empty() && !busy; });
+    };
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        rc_final = fail(c, L3D_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return false;
+    };
     for (int k = 0; k < n_views && rc_final == L3D_OK; ++k) {
         while (k_enq < n_views && k_enq <= k + kAhead) { int rc = enqueue_view(k_enq); if (rc) { rc_final = rc; break; } ++k_enq; }
         if (rc_final) break;
-        const l3d_chain_view& v = views[k];
+        { std::lock_guard<std::mutex> lk(mu); if (deliver_rc) break; }
         const ViewDev& d = vd[(size_t)k];
-        if (!d.verified) {                      // cudawrapper.cu:877-878: nothing to match, the caller keeps its list
-            if (cb(user, k, 0, nullptr, 0, nullptr, 0, 0)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
-            continue;
-        }
+        if (!d.verified) { hand_over(k, 0, ChainResult()); continue; }
         const double tw0 = now_s();
-        HIPCHK(c, hipEventSynchronize(ev[(size_t)k]));
+        if (!hip_ok(hipEventSynchronize(ev[(size_t)k]), "hipEventSynchronize")) break;
         t_wait += now_s() - tw0;
         const ChainResult r = hres[k];
         if (r.overflow) {
             // not enough room for this view's candidates / kept matches: everything before it is valid and stays
-            // in the arena; wait for the queue to drain, grow, and re-enqueue from this view
-            HIPCHK(c, hipStreamSynchronize(st));
-            HIPCHK(c, hipStreamSynchronize(s1));
+            // in the arena; wait for the queue (and the delivery of earlier views) to drain, grow, and re-enqueue from this view
+            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(s1), "hipStreamSynchronize")) break;
+            wait_delivered();
             if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
             if (r.overflow & 2) {
                 // the arena cannot be reallocated without losing earlier lists that later views still read:
                 // copy it over
                 const size_t new_cap = arena_cap * 2;
                 void* np = nullptr;
-                HIPCHK(c, hipMalloc(&np, new_cap * sizeof(Match)));
-                HIPCHK(c, hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice));
+                if (!hip_ok(hipMalloc(&np, new_cap * sizeof(Match)), "hipMalloc")) break;
+                if (!hip_ok(hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice), "hipMemcpy")) break;
                 (void)hipFree(c->ch_kept.p);
                 c->ch_kept.p = np; c->ch_kept.cap = new_cap * sizeof(Match);
                 arena_cap = new_cap;
             }
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
-            HIPCHK(c, hipMemcpy(arena_cursor, &r.kept_base, 4, hipMemcpyHostToDevice));
+            if (!hip_ok(hipMemcpy(arena_cursor, &r.kept_base, 4, hipMemcpyHostToDevice), "hipMemcpy")) break;
             // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
             // and the stage-1 candidate buffers of every view in flight live in the (re-sized) ring: refill them
             for (int j = k; j < k_p1; ++j) {
                 if (!vd[(size_t)j].verified || views[j].S_src == 0) continue;
                 if (j < k_enq) {
-                    HIPCHK(c, hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st));
+                    if (!hip_ok(hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st), "hipMemsetAsync")) break;
                     launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);
                 }
                 enqueue_fillA(j, st);
             }
+            if (rc_final) break;
             k_enq = k;
             --k;
             continue;
         }
-        const double td0 = now_s();
-        // kept slice and best depths: bulk copies on the copy stream, concurrent with the kernels of later views; the kept
-        // list lands in the pinned arena, where it stays valid for the caller until the next chain starts
-        hipError_t ae = hipSuccess;
-        l3d_match* kept_host = static_cast<l3d_match*>(c->pin_arena.alloc((size_t)r.n_kept * sizeof(Match) + 16, &ae));
-        HIPCHK(c, ae);
-        HIPCHK(c, c->ch_pin_best.reserve((size_t)v.S_src * 8 + 16));
-        if (r.n_kept)
-            HIPCHK(c, hipMemcpyAsync(kept_host, c->ch_kept.as<Match>() + r.kept_base, (size_t)r.n_kept * sizeof(Match),
-                                     hipMemcpyDeviceToHost, c->copy_stream));
-        if (v.S_src) HIPCHK(c, hipMemcpyAsync(c->ch_pin_best.p, d.best, (size_t)v.S_src * 8, hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-        float* best = c->ch_pin_best.as<float>();
-        int nb = 0;
-        if (r.R > 0)
-            for (int s = 0; s < v.S_src; ++s)
-                if (best[2 * s] != -1.0f) { best[2 * nb] = best[2 * s]; best[2 * nb + 1] = best[2 * s + 1]; ++nb; }   // in place: nb <= s
-        kept_total += r.n_kept;
-        const double tc0 = now_s();
-        t_d2h += tc0 - td0;
-        if (cb(user, k, 1, kept_host, r.n_kept, best, nb, r.R)) { rc_final = fail(c, L3D_ERR_INVALID, "callback failed"); break; }
-        t_cb += now_s() - tc0;
+        hand_over(k, 1, r);
     }
+    { std::lock_guard<std::mutex> lk(mu); done = true; }
+    cv_work.notify_one();
+    deliverer.join();
+    if (rc_final == L3D_OK && deliver_rc) rc_final = fail(c, deliver_rc, deliver_err);
     if (getenv("L3D_TIMING"))
-        fprintf(stderr, "[l3d match_chain] setup %.2f ms | loop %.2f ms: waiting for the GPU %.2f, d2h %.2f, callback %.2f\n",
-                (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_d2h * 1e3, t_cb * 1e3);
-    HIPCHK(c, hipStreamSynchronize(s1));
-    HIPCHK(c, hipStreamSynchronize(st));
+        fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
+                (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
+    (void)hipStreamSynchronize(s1);
+    (void)hipStreamSynchronize(st);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
     c->stats[1] = raw_sum;
