@@ -37,6 +37,7 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipSetDevice(device) != hipSuccess) return L3D_ERR_HIP;
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
+    if (const char* e = getenv("L3D_CHAIN_RING")) c->chain_ring = atoi(e) != 0;
     if (const char* e = getenv("L3D_PRETEST")) c->wedge_pretest = atoi(e) & 3;      // diagnostic: stage-1 filter mask
     {   // L3D_STREAM_PRIO=1: the chain's stream (per-view critical path) at the highest priority.  Measured on config 2: no
         // difference to plain streams (21.5 ms either way), so plain streams are the default.

@@ -414,15 +414,23 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         HIPCHK(c, c->vw_scratch.reserve((cand_cap + kVWSlack) * 16));
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
         // ring of stage-1 candidate buffers: stage 1 (incl. the triangulation of its candidates) runs kStage1Ahead views ahead
-        HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
-        HIPCHK(c, c->ch_ringA_depths.reserve((size_t)kRing * cand_cap * 16));
+        if (c->chain_ring) {
+            HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
+            HIPCHK(c, c->ch_ringA_depths.reserve((size_t)kRing * cand_cap * 16));
+        }
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
     auto ringA_meta = [&](int k) { return c->ch_ringA_meta.as<uint2>() + (size_t)(k % kRing) * cand_cap; };
     auto ringA_depths = [&](int k) { return c->ch_ringA_depths.as<float4>() + (size_t)(k % kRing) * cand_cap; };
     // row starts + depth records of a view's stage-1 candidates alone (its reverse matches are not known yet)
+    // L3D_CHAIN_RING=0 (A/B): triangulation on the chain stream, straight into the combined order -- measured 5 % slower on
+    // config 2 than the ring scheme, which keeps the chain stream short.  (Also measured: letting the verification read the
+    // stage-1 candidates in place instead of copying them with k_cand_move -- 20 % SLOWER: the copy is a streaming pass that
+    // leaves the candidates cache-hot for the latency-bound kernels that follow.)
+    const bool use_ring = c->chain_ring != 0;
     auto enqueue_fillA = [&](int k, hipStream_t s) {
+        if (!use_ring) return;
         const ViewDev& d = vd[(size_t)k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
@@ -468,8 +476,14 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
         { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
-        { ProfScope p(c, "cand_move"); launch_cand_move(pa.tbm, v.n_tbm, N, 0, S, d.rowA, ringA_meta(k), ringA_depths(k), c->row_start.as<int>(), (int)nrow,
-                                                        (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
+        if (use_ring) {
+            ProfScope p(c, "cand_move");
+            launch_cand_move(pa.tbm, v.n_tbm, N, 0, S, d.rowA, ringA_meta(k), ringA_depths(k), c->row_start.as<int>(), (int)nrow,
+                             (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+        } else if (S > 0) {
+            ProfScope p(c, "pair_fill");
+            launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+        }
         {
             ProfScope p(c, "exist");
             launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
