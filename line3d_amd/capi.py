@@ -9,6 +9,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libline3d_amd.so")
+if os.environ.get("L3D_LIBRARY"):      # A/B measurements: an alternative build of the library
+    LIB_PATH = os.environ["L3D_LIBRARY"]
 
 MATCH_DTYPE = np.dtype([("segID1", "<u4"), ("camID2", "<u4"), ("segID2", "<u4"),
                         ("depths", "<f4", (4,)), ("confidence", "<f4")])
