@@ -402,7 +402,13 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
     int* arena_cursor = c->ch_flags.as<int>();
     int k_enq = 0;                      // next view whose phase 2 is enqueued
-    const int kAhead = 12, kStage1Ahead = 24, kRing = kStage1Ahead + 2;
+    // run-ahead depths, A/B measured on one box (ms per config-2 pass): (12, 24) 19.1, (6, 12) 18.7, (4, 8) 18.4, (2, 4) 18.3,
+    // (24, 40) 20.0 -- a shallow queue keeps the stage-1 candidates of a view cache-warm until its chain consumes them
+#ifndef L3D_AHEAD
+#define L3D_AHEAD 4
+#define L3D_S1AHEAD 8
+#endif
+    const int kAhead = L3D_AHEAD, kStage1Ahead = L3D_S1AHEAD, kRing = kStage1Ahead + 2;
     int rc_final = L3D_OK;
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;

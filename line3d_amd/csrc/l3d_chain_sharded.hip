@@ -173,7 +173,7 @@ struct l3d_shard_chain {
     std::vector<hipEvent_t> ev1, ev2;
     int k_p1 = 0;
     size_t cand_cap = 0;
-    static constexpr int kStage1Ahead = 24, kRingA = kStage1Ahead + 2;   // ring of stage-1 candidate buffers
+    static constexpr int kStage1Ahead = 8, kRingA = kStage1Ahead + 2;   // ring of stage-1 candidate buffers
     int maxS = 0, maxN = 0;
     const unsigned char* gathered = nullptr;
     double pairs = 0, raw_sum = 0, kept_total = 0;

@@ -36,8 +36,12 @@ __device__ __forceinline__ float window_margin(float unc, float d_y, float dabs_
 // (spatial_k ~ 0.5 % of the depth).  A counting sort on that id (LDS atomics, O(m), no comparison sort) makes every
 // depth window a contiguous range of a few buckets; the order inside a bucket is arbitrary, which cannot change
 // the result (per-camera maxima, summed in camera order).
-constexpr int kBucketShift = 15;               // 256 buckets per octave of depth
-constexpr int kBuckets = 2048;                 // 8 octaves; anything beyond is clamped into the last bucket
+#ifndef L3D_BUCKET_SHIFT
+#define L3D_BUCKET_SHIFT 15
+#define L3D_BUCKETS 2048
+#endif
+constexpr int kBucketShift = L3D_BUCKET_SHIFT;               // 256 buckets per octave of depth
+constexpr int kBuckets = L3D_BUCKETS;                 // 8 octaves; anything beyond is clamped into the last bucket
 constexpr int kVQ = 128;                       // per-wave ring of gate candidates
 __device__ __forceinline__ int bucket_of(float d, int base)
 {
@@ -272,7 +276,10 @@ __global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
         if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
         // the window is walked in groups of kG entries: the next group's loads (3 per entry, LDS or L2) are in flight while
         // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
-        constexpr int kG = 4;
+#ifndef L3D_KG
+#define L3D_KG 4
+#endif
+        constexpr int kG = L3D_KG;
         float c1[kG], c2[kG];
         unsigned cc[kG], ct[kG];
 #pragma unroll
