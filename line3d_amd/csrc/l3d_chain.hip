@@ -408,7 +408,9 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
 #define L3D_AHEAD 4
 #define L3D_S1AHEAD 8
 #endif
-    const int kAhead = L3D_AHEAD, kStage1Ahead = L3D_S1AHEAD, kRing = kStage1Ahead + 2;
+    // the ring covers every view that can be in flight between the one being collected and the newest stage 1: after an
+    // overflow ALL of them are refilled before any of their chains runs again
+    const int kAhead = L3D_AHEAD, kStage1Ahead = L3D_S1AHEAD, kRing = kAhead + kStage1Ahead + 3;
     int rc_final = L3D_OK;
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;

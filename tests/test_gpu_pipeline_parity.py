@@ -386,3 +386,31 @@ def test_chain_capacity_overflow_restarts(small_scene, small_oracle):
             assert l.view_matches(v)[0].tobytes() == small_oracle.trace[v]["matches"].tobytes(), "caps %r view %d" % (caps, v)
         assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
         l.close()
+
+
+def test_chain_overflow_restart_with_more_views_than_ring_slots():
+    """30 views: more views in flight than the stage-1 candidate ring has slots when an overflow forces a restart.  The kept
+    lists must equal those of an undisturbed run (capacities large enough)."""
+    import hashlib
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    sc = make_scene(30, 400, 10, seed=4242)
+    digests = []
+    for caps in (None, (6000, 1 << 22), (1 << 22, 900), (5000, 700)):
+        l = Line3D("", matchingNeighbors=10)
+        l.keep_view_matches(True)
+        load_scene(l, sc)
+        l.prepare()
+        if caps:
+            l.context().set_chain_capacities(*caps)
+        l.match_views()
+        h = hashlib.sha256()
+        n = 0
+        for v in sc.views:
+            m, med = l.view_matches(v["id"])
+            h.update(m.tobytes()); h.update(np.float32(med).tobytes())
+            n += len(m)
+        digests.append(h.hexdigest())
+        assert n > 5000
+        l.close()
+    assert len(set(digests)) == 1, digests
