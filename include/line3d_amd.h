@@ -199,11 +199,12 @@ int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
  * l3d_profile_get returns the launch count and summed duration for one kernel name
  * ("pair_mask", "pair_fill", "verify", ...; l3d_profile_names lists them, ';'-separated). */
-/* stage-2 algorithm: 0 = depth-window search (default; falls back to all-pairs when a segment's candidates do
- * not fit in LDS), 1 = all-pairs loop in the reference's formulation.  Results are bit-identical. */
+/* stage-2 algorithm: 0 = depth-window search (default; segments that outgrow the kernel's LDS image use its global-scratch
+ * variant; views with more than ~50 neighbours take the all-pairs kernel), 1 = all-pairs loop in the reference's formulation.
+ * Results are bit-identical. */
 int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
 /* stage-1 conservative filters in front of the exact epipolar/overlap/triangulation sequence: bit 0 = wedge test,
- * bit 1 = depth-sign test; 3 = both (default), 0 = none (A/B testing: results are bit-identical, a filter only rejects
+ * bit 1 = overlap-bound test; 3 = both (default), 0 = none (A/B testing: results are bit-identical, a filter only rejects
  * pairs the exact sequence rejects) */
 int l3d_set_pair_pretest(l3d_ctx* ctx, int mask);
 /* testing: cap the LDS image of the depth-window kernel (bytes; 0 = device limit) so that segments take the

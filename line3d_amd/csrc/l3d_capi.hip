@@ -73,7 +73,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
         unsigned long long h[4];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, c->pair_dbg, 32, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after depth-sign test %.3f%%  candidates %.3f%%\n", h[0], 100.0 * h[1] / (double)h[0],
+        fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after overlap-bound test %.3f%%  candidates %.3f%%\n", h[0], 100.0 * h[1] / (double)h[0],
                 100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0]);
         (void)hipFree(c->pair_dbg);
     }

@@ -101,8 +101,8 @@ struct l3d_ctx {
     int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_cand_move (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
-    int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 depth-sign test (cleared only for A/B testing)
-    int verify_mode = 0;            // 0: depth-window search (all-pairs fallback for huge segments), 1: all-pairs
+    int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing)
+    int verify_mode = 0;            // 0: depth-window search (all-pairs kernel only beyond ~50 neighbours), 1: all-pairs
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;
