@@ -107,8 +107,15 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
 
 // NT threads per workgroup: 256 when the grid fills the chip, 512 when only a few segments are verified per launch
 // (one rank's slice of a view in the sharded chain): the segment's hypotheses then run 8 waves wide instead of 4.
+#ifndef L3D_VW_WAVES
+#define L3D_VW_WAVES 0
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void k_verify_window(VerifyArgs a)
+__global__ __launch_bounds__(NT)
+#if L3D_VW_WAVES
+__attribute__((amdgpu_waves_per_eu(L3D_VW_WAVES, L3D_VW_WAVES)))
+#endif
+void k_verify_window(VerifyArgs a)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
