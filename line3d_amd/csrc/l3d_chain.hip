@@ -399,6 +399,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));
     HIPCHK(c, c->ch_cursor.reserve(nrow_max * 4 + 16));
     HIPCHK(c, c->kept_cnt.reserve((size_t)maxS * 4 + 4));
+    HIPCHK(c, c->ch_segorder.reserve((size_t)maxS * 4 + 16));
     HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
     int* arena_cursor = c->ch_flags.as<int>();
     int k_enq = 0;                      // next view whose phase 2 is enqueued
@@ -483,7 +484,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         (void)hipGetLastError();
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
         { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
-        { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
+        // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
+        { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
         if (use_ring) {
             ProfScope p(c, "cand_move");
             launch_cand_move(pa.tbm, v.n_tbm, N, 0, S, d.rowA, ringA_meta(k), ringA_depths(k), c->row_start.as<int>(), (int)nrow,
@@ -508,6 +510,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         va.N = N; va.seg_begin = 0; va.seg_end = S; va.nrow_total = (int)nrow;
         va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
         va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
+        va.seg_order = c->ch_segorder.as<int>();
         // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
         int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
         while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;

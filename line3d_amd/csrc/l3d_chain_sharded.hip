@@ -310,6 +310,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     OCHK(c->row_start.reserve((nrow_max + 1) * 4));
     OCHK(c->ch_cursor.reserve(nrow_max * 4 + 16));
     OCHK(c->kept_cnt.reserve((size_t)h->maxS * 4 + 4));
+    OCHK(c->ch_segorder.reserve((size_t)h->maxS * 4 + 16));
     OCHK(c->kept_start.reserve((size_t)h->maxS * 4 + 8));
     OCHK(c->cand_meta.reserve(h->cand_cap * 8));
     OCHK(c->cand_depths.reserve(h->cand_cap * 16));
@@ -411,7 +412,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         ProfScope p(c, "exist");
         hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
     }
-    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st); }   // + zeroed scatter cursors
+    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, d.s0, d.s1); }   // + zeroed scatter cursors, segment order
     {
         ProfScope p(c, "cand_move");
         launch_cand_move(pa.tbm, v.n_tbm, N, d.s0, d.s1, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
@@ -433,6 +434,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     va.N = N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = (int)nrow;
     va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
     va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)h->cand_cap; va.res = nullptr;
+    va.seg_order = c->ch_segorder.as<int>();
     int mmax = h->hstats[2 * k + 1] + h->hstats[2 * k + 1] / 4 + 64;
     while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
     va.mmax = mmax;

@@ -294,10 +294,17 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
 }
 
 // Exclusive scan of n ints by ONE workgroup (l3d_scan.hpp); out has n+1 entries, `zero` (optional) gets n zeros.
-__global__ __launch_bounds__(kScanThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero)
+__global__ __launch_bounds__(kScanThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
+                                                       int* __restrict__ seg_order, int N, int seg_begin, int seg_end)
 {
     __shared__ int s_w[16];
+    __shared__ int s_hist[130];
     (void)wg_scan_excl(in, out, n, zero, s_w);
+    if (seg_order) {                                // rows -> segments, longest first (the scan's own stores are visible to the workgroup)
+        __threadfence();
+        __syncthreads();
+        wg_segment_order(out, N, seg_begin, seg_end, seg_order, s_hist);
+    }
 }
 
 // r-th (0-based) set bit of a 64-bit word
@@ -762,9 +769,9 @@ void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_
 {
     if (n) hipLaunchKernelGGL(k_exist_hist, dim3((n + 255) / 256), dim3(256), 0, st, ex, n, N, rowcnt);
 }
-void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st)
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order, int N, int seg_begin, int seg_end)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, in, out, n, zero);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end);
 }
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
 {

@@ -71,6 +71,7 @@ struct VerifyArgs {
     int skip_above;                 // k_verify_window: leave segments with more than mmax candidates to the `big` launch (0/1)
     int big;                        // k_verify_window: 0 = segments with at most mmax candidates (LDS image), 1 = only the bigger ones
                                     // (arrays in `scratch`), 2 = both in one launch (grid 2 x segments)
+    const int* seg_order;           // k_verify_window: workgroup i takes segment seg_order[i] (longest first); null = seg_begin + i
     int* kept_cnt;                  // fused per-segment epilogue of k_verify_window (k_seg_post): number of kept matches ...
     float2* best_depths;            // ... and depths of the first best hypothesis; null = separate k_seg_post launch
     float* scratch;                 // 4 arrays of scratch_stride floats (candidate capacity + 2), global memory
@@ -85,7 +86,7 @@ struct VerifyArgs {
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
-void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st);
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order = nullptr, int N = 0, int seg_begin = 0, int seg_end = 0);
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);

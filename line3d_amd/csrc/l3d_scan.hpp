@@ -62,4 +62,26 @@ __device__ __forceinline__ int wg_scan_excl(const int* __restrict__ in, int* __r
     return carry;
 }
 
+// Segments [seg_begin, seg_end) ordered by descending candidate count (64 bins of 32): the verification kernel takes its
+// workgroups in this order, longest first, so that the last round of workgroups is made of short ones (the order changes
+// nothing in the results).  Runs in the tail of the single-workgroup scan that produced row_start.  s_hist: 130 ints of LDS.
+__device__ __forceinline__ void wg_segment_order(const int* __restrict__ row_start, int N, int seg_begin, int seg_end,
+                                                 int* __restrict__ order, int* s_hist)
+{
+    const int tid = threadIdx.x;
+    if (tid < 130) s_hist[tid] = 0;
+    __syncthreads();
+    for (int y = seg_begin + tid; y < seg_end; y += kScanThreads) {
+        const int m = row_start[(y + 1) * N] - row_start[y * N];
+        atomicAdd(&s_hist[63 - min(63, m >> 5)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int b = 0; b < 64; ++b) { s_hist[65 + b] = run; run += s_hist[b]; } }
+    __syncthreads();
+    for (int y = seg_begin + tid; y < seg_end; y += kScanThreads) {
+        const int m = row_start[(y + 1) * N] - row_start[y * N];
+        order[atomicAdd(&s_hist[65 + 63 - min(63, m >> 5)], 1)] = y;
+    }
+}
+
 }  // namespace l3d

@@ -129,7 +129,12 @@ void k_verify_window(VerifyArgs a)
     // a.big == 2 runs both kinds in one launch: blocks [0, nseg) are the LDS blocks, [nseg, 2 nseg) the scratch blocks.
     const int nseg = a.seg_end - a.seg_begin;
     const bool big = a.big == 2 ? (int)blockIdx.x >= nseg : a.big != 0;
-    const int y = a.seg_begin + ((int)blockIdx.x >= nseg ? (int)blockIdx.x - nseg : (int)blockIdx.x);
+    const int widx = (int)blockIdx.x >= nseg ? (int)blockIdx.x - nseg : (int)blockIdx.x;
+#ifdef L3D_NO_SEG_ORDER
+    const int y = a.seg_begin + widx;
+#else
+    const int y = a.seg_order ? a.seg_order[widx] : a.seg_begin + widx;
+#endif
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
     const bool overflow = a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap;   // candidate overflow: the chain is re-run
