@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     else if (tid < 18) s_cam[tid] = a.RtKinv[cam * 9 + (tid - 9)];
     else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
     else if (tid < 30) s_cam[tid] = a.RtKinv_src[tid - 21];
-    if (tid < kSrcPerBlock * 4) s_bits[tid] = 0ull;
+    for (int i = tid; i < kSrcPerBlock * 4; i += 256) s_bits[i] = 0ull;
     if (tid < 4) s_ext[tid] = 0.0f;
     __syncthreads();
 
@@ -258,9 +258,10 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (lane < ny) a.mask[((size_t)j * a.S_src + (y0 + lane)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[lane * 4 + wave];
+    for (int r = lane; r < ny; r += 64) a.mask[((size_t)j * a.S_src + (y0 + r)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[r * 4 + wave];
     if (a.dbg) {
-        int nbits = lane < ny ? __popcll(s_bits[lane * 4 + wave]) : 0;
+        int nbits = 0;
+        for (int r = lane; r < ny; r += 64) nbits += __popcll(s_bits[r * 4 + wave]);
         for (int o = 32; o > 0; o >>= 1) nbits += __shfl_down(nbits, o);
         if (lane == 0) {
             atomicAdd(&a.dbg[0], (unsigned long long)ny * (unsigned long long)min(64, width - (blockIdx.x * 256 + wave * 64) > 0 ? width - (blockIdx.x * 256 + wave * 64) : 0));

@@ -6,7 +6,10 @@
 
 namespace l3d {
 
-constexpr int kSrcPerBlock = 64;    // source segments walked by one k_pair_mask workgroup (A/B on one box: 16 -> 21.1, 32 -> 19.7, 64 -> 19.4 ms per pass)
+#ifndef L3D_SRC_PER_BLOCK
+#define L3D_SRC_PER_BLOCK 64
+#endif
+constexpr int kSrcPerBlock = L3D_SRC_PER_BLOCK;    // source segments walked by one k_pair_mask workgroup (A/B, ms per config-2 pass: 32 -> +0.3, 48 -> +0.9, 64 best, 96 -> +0.4, 128 -> +0.8)
 constexpr int kMaxW64 = 256;        // bit-row words per camera: up to 16384 segments per view
 constexpr int kVerifyTile = 256;
 constexpr int kVWSlack = 8;          // entries readable past the end of a k_verify_window image (the scan loads a group ahead)    // witnesses staged in LDS per step of k_verify
