@@ -42,7 +42,10 @@ __device__ __forceinline__ float window_margin(float unc, float d_y, float dabs_
 #endif
 constexpr int kBucketShift = L3D_BUCKET_SHIFT;               // 256 buckets per octave of depth
 constexpr int kBuckets = L3D_BUCKETS;                 // 8 octaves; anything beyond is clamped into the last bucket
-constexpr int kVQ = 128;                       // per-wave ring of gate candidates
+#ifndef L3D_VQ
+#define L3D_VQ 128
+#endif
+constexpr int kVQ = L3D_VQ;                       // per-wave ring of gate candidates
 __device__ __forceinline__ int bucket_of(float d, int base)
 {
     if (!(d > 0.0f)) return 0;                                        // windows may reach below zero
