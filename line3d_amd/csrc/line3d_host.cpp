@@ -167,6 +167,8 @@ struct l3d_line3d {
     std::vector<KeptList> saved;                               // chain mode: performMatching's `matches` per processed view
     bool keep_view_matches = false;
     bool pot_check_failed = false;                             // L3D_CHECK_POT=1 (tests)
+    void* finalizer = nullptr;                                 // ChainFinalizer with its worker threads (created on first use)
+    void* plan_cache = nullptr;                                // ChainPlan of the current set of views (the schedule is static)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
 
@@ -626,8 +628,11 @@ void finalize_matching(L* h)
     h->t_finalize += now_s() - t0;
 }
 
+void drop_plan(L* h);           // the cached matchViews schedule depends on the set of views and their neighbours
+
 int prepare(L* h)
 {
+    drop_plan(h);
     if (h->views.size() < 4) return h->fail(L3D_ERR_INVALID, "not enough images! can't compute 3D model...");   // line3D.cc:347-351
     h->computation = true;
     find_visual_neighbors(h);
@@ -783,7 +788,23 @@ struct ChainFinalizer {
     double t_split = 0, t_merge = 0, t_last_done = 0;
     int n_split = 0, n_merge = 0;
 
-    explicit ChainFinalizer(size_t nviews) : pending(nviews), parts_left(nviews) {}
+    int active = 0;                                 // jobs being executed (under mu)
+    std::condition_variable cv_idle;
+    ChainFinalizer() {}
+    ~ChainFinalizer()
+    {
+        { std::lock_guard<std::mutex> lk(mu); done = true; }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    // the worker threads live as long as the pipeline object; a pass only re-arms the counters (threads are idle here)
+    void begin_pass(size_t nviews)
+    {
+        if (pending.size() != nviews) { pending = std::vector<std::atomic<int>>(nviews); parts_left = std::vector<std::atomic<int>>(nviews); }
+        for (auto& p : pending) p = 0;
+        for (auto& p : parts_left) p = 0;
+        t_split = t_merge = 0; n_split = n_merge = 0; log.clear();
+    }
     void push_merge(size_t vi) { parts_left[vi] = kParts; for (int r = 0; r < kParts; ++r) push(2, vi * kParts + (size_t)r); }
 
     void push(int kind, size_t id)
@@ -856,42 +877,44 @@ struct ChainFinalizer {
     }
     void start(unsigned nthreads)
     {
-        for (unsigned t = 0; t < nthreads; ++t)
+        for (unsigned t = (unsigned)workers.size(); t < nthreads; ++t)
             workers.emplace_back([this]() {
                 for (;;) {
                     std::pair<int, size_t> job;
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [this]() { return done || !queue.empty(); });
-                        if (queue.empty()) return;
+                        if (queue.empty()) return;      // (done)
                         job = queue.back();
                         queue.pop_back();
+                        ++active;
                     }
                     const double tj0 = now_s();
                     if (job.first == 0) split(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
-                    if (timing) { const double dt = now_s() - tj0; std::lock_guard<std::mutex> lk(mu); (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s();
-                                  if (trace) log.push_back({ job.first, (int)job.second, tj0, t_last_done }); }
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        --active;
+                        if (timing) { const double dt = now_s() - tj0; (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s();
+                                      if (trace) log.push_back({ job.first, (int)job.second, tj0, t_last_done }); }
+                    }
+                    cv_idle.notify_all();
                 }
             });
     }
     void notify(int k) { push(0, (size_t)k); }
     void finish(bool drain)
     {
-        // drain: wait until every job (splits spawn merges) has run
+        // wait until every job has run (splits spawn merges while they run, so "no job queued or running" is final); without
+        // `drain` (a failed chain) whatever was queued is dropped first
         const double td0 = now_s();
-        for (; drain;) {
-            { std::lock_guard<std::mutex> lk(mu); bool all = queue.empty(); if (all) { int left = 0; for (auto& p : pending) left += p.load() > 0; for (auto& p : parts_left) left += p.load() > 0; if (left == 0) break; } }
-            std::this_thread::yield();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!drain) queue.clear();
+            cv_idle.wait(lk, [this]() { return queue.empty() && active == 0; });
         }
-        const double td1 = now_s();
-        { std::lock_guard<std::mutex> lk(mu); done = true; }
-        cv.notify_all();
-        for (auto& t : workers) t.join();
-        workers.clear();
         if (trace) for (size_t i = log.size() > 48 ? log.size() - 48 : 0; i < log.size(); ++i)
             fprintf(stderr, "[l3d finaliser job] kind %d id %d: start %+.3f end %+.3f ms (relative to the drain start)\n", log[i].kind, log[i].id, (log[i].t0 - td0) * 1e3, (log[i].t1 - td0) * 1e3);
-        if (timing) fprintf(stderr, "[l3d finaliser] drain %.2f ms (last job done %.2f ms after the drain began), join %.2f ms\n", (td1 - td0) * 1e3, (t_last_done - td0) * 1e3, (now_s() - td1) * 1e3);
-        if (timing) fprintf(stderr, "[l3d finaliser] %d splits %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", n_split, t_split * 1e3,
+        if (timing) fprintf(stderr, "[l3d finaliser] drain %.2f ms; %d splits %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", (now_s() - td0) * 1e3, n_split, t_split * 1e3,
                             n_split ? t_split * 1e3 / n_split : 0.0, n_merge, t_merge * 1e3, n_merge ? t_merge * 1e3 / n_merge : 0.0);
     }
 };
@@ -907,7 +930,7 @@ struct ChainPlan {
     std::vector<std::vector<int32_t>> src_cam, src_idx;
     std::vector<l3d_chain_view> cv;
     std::vector<int> n_tbm;
-    std::unique_ptr<ChainFinalizer> fin;
+    ChainFinalizer* fin = nullptr;                  // the pipeline object's persistent finaliser
     ChainUser user;
     l3d_shard_chain* shard = nullptr;
     double t0 = 0;
@@ -960,21 +983,36 @@ bool plan_chain(L* h, ChainPlan& P)
     return chain_ok;
 }
 
+// the schedule is static: build it once per set of views (prepare() drops it)
+ChainPlan* get_plan(L* h)
+{
+    if (h->plan_cache) return static_cast<ChainPlan*>(h->plan_cache);
+    ChainPlan* P = new ChainPlan();
+    if (!plan_chain(h, *P)) { delete P; return nullptr; }
+    h->plan_cache = P;
+    return P;
+}
+void drop_plan(L* h)
+{
+    delete static_cast<ChainPlan*>(h->plan_cache);
+    h->plan_cache = nullptr;
+}
+
 void start_finalizer(L* h, ChainPlan& P)
 {
     const size_t n = P.n, nvl = h->vlist.size();
     h->saved.resize(n);                                 // (capacity of the per-view lists survives from an earlier pass)
     for (auto& lst : h->saved) lst.reset();
-    P.fin.reset(new ChainFinalizer(nvl));
+    if (!h->finalizer) h->finalizer = new ChainFinalizer();
+    P.fin = static_cast<ChainFinalizer*>(h->finalizer);
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
+    fin.begin_pass(nvl);
     fin.own_index.assign(nvl, -1); fin.own_sorted.assign(nvl, 1); fin.contributors.assign(nvl, {});
     fin.buckets = &h->fin_buckets;                      // (capacities survive from an earlier pass)
     fin.parts = &h->fin_parts;
     if (h->fin_parts.size() != nvl) h->fin_parts.assign(nvl, {});
-    for (size_t vi = 0; vi < nvl; ++vi) fin.parts_left[vi] = 0;
     if (h->fin_buckets.size() != n) h->fin_buckets.assign(n, {});
-    for (size_t vi = 0; vi < nvl; ++vi) fin.pending[vi] = 0;
     fin.targets.assign(n, {});
     for (size_t k = 0; k < n; ++k) {
         const View& v = h->views[h->order[k]];
@@ -994,7 +1032,7 @@ void start_finalizer(L* h, ChainPlan& P)
         }
     }
     fin.start(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)));    // (one process per GPU shares the host)
-    P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin.get() };
+    P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin };
 }
 
 // after the last callback: wait for the workers, the LOCAL-id entries of early-return views, inspection copies
@@ -1046,8 +1084,9 @@ int match_views(L* h)
     const double t0 = now_s();
     match_begin(h);
     const double ta = now_s();
-    ChainPlan P;
-    if (!plan_chain(h, P)) return match_views_sync(h);
+    ChainPlan* Pp = get_plan(h);
+    if (!Pp) return match_views_sync(h);
+    ChainPlan& P = *Pp;
     const double tb = now_s();
     start_finalizer(h, P);
     const double t1 = now_s();
@@ -1413,6 +1452,8 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
 void l3d_line3d_destroy(l3d_line3d* h)
 {
     if (!h) return;
+    delete static_cast<ChainFinalizer*>(h->finalizer);      // joins the worker threads
+    drop_plan(h);
     l3d_ctx_destroy(h->ctx);
     delete h;
 }
@@ -1429,6 +1470,7 @@ int l3d_line3d_reset(l3d_line3d* h)
     h->worldpoints2views.clear(); h->visual_neighbors.clear(); h->fundamentals.clear(); h->matched.clear();
     h->pot.clear(); h->pot_foreign.clear(); h->hyps.clear(); h->best_idx.clear(); h->A.clear(); h->local2global.clear(); h->result.clear();
     h->computation = false; h->prepared = false;
+    drop_plan(h);
     return L3D_OK;
 }
 
@@ -1549,11 +1591,11 @@ int l3d_line3d_shard_open(l3d_line3d* h, int rank, int world, int slot_records, 
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
     if (h->shard_plan_) return h->fail(L3D_ERR_INVALID, "a sharded chain is already open");
     match_begin(h);
-    ChainPlan* P = new ChainPlan();
+    ChainPlan* P = get_plan(h);
+    if (!P) return h->fail(L3D_ERR_INVALID, "schedule is not static (early-return quirk): use the per-view path");
     P->t0 = now_s();
-    if (!plan_chain(h, *P)) { delete P; return h->fail(L3D_ERR_INVALID, "schedule is not static (early-return quirk): use the per-view path"); }
     int rc = l3d_shard_chain_open(h->ctx, P->cv.data(), (int)P->n, rank, world, slot_records, &P->shard, slot_bytes);
-    if (rc) { delete P; return h->fail(rc, std::string("shard_chain_open: ") + l3d_last_error(h->ctx)); }
+    if (rc) return h->fail(rc, std::string("shard_chain_open: ") + l3d_last_error(h->ctx));
     start_finalizer(h, *P);
     h->shard_plan_ = P;
     if (n_views) *n_views = (int)P->n;
@@ -1598,7 +1640,7 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed)
     h->stat_pairs += st[0];
     h->stat_raw += st[1];
     h->t_match = now_s() - P->t0;
-    delete P;
+    P->shard = nullptr;
     h->shard_plan_ = nullptr;
     return rc;
 }
