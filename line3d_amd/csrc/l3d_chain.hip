@@ -156,13 +156,13 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
 
 // prefix sums of the per-segment kept counts and, in the same launch, the reservation of the view's slice of the kept
 // arena: (base, count, #candidates, overflow) published to the device record and to its host-mapped mirror
-__global__ __launch_bounds__(kScanThreads) void k_scan_kept_chain(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int S,
+__global__ __launch_bounds__(kTileThreads) void k_scan_kept_chain(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int S,
                                                                   const int* __restrict__ row_start, int nrow, int* __restrict__ arena_cursor,
                                                                   int arena_cap, int cand_cap, ChainResult* __restrict__ res,
                                                                   ChainResult* __restrict__ res_host)
 {
-    __shared__ int s_w[16];
-    const int total = wg_scan_excl(kept_cnt, kept_start, S, nullptr, s_w);
+    __shared__ int s_w[4];
+    const int total = wg_scan_excl<kTileThreads>(kept_cnt, kept_start, S, nullptr, s_w);     // (a small workgroup: see wg_scan_excl_tile)
     if (threadIdx.x != 0) return;
     ChainResult r;
     r.R = row_start[nrow];
@@ -213,7 +213,7 @@ void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int*
 void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
                             int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan_kept_chain, dim3(1), dim3(kScanThreads), 0, st, kept_cnt, kept_start, S, row_start, nrow, arena_cursor, arena_cap,
+    hipLaunchKernelGGL(k_scan_kept_chain, dim3(1), dim3(kTileThreads), 0, st, kept_cnt, kept_start, S, row_start, nrow, arena_cursor, arena_cap,
                        cand_cap, res, res_host);
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int, hipStream_t st)

@@ -74,12 +74,12 @@ __global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotG
 
 // prefix sums of the kept counts of this rank's segment range and, in the same launch, the header of its slot
 // (count, #candidates, overflow).  kept_cnt / kept_start point at the range's first segment.
-__global__ __launch_bounds__(kScanThreads) void k_scan_kept_slot(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int n_seg,
+__global__ __launch_bounds__(kTileThreads) void k_scan_kept_slot(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int n_seg,
                                                                  const int* __restrict__ row_start, int nrow, int cand_cap, int slot_records,
                                                                  int s0, int s1, unsigned char* __restrict__ slot)
 {
-    __shared__ int s_w[16];
-    const int total = wg_scan_excl(kept_cnt, kept_start, n_seg, nullptr, s_w);
+    __shared__ int s_w[4];
+    const int total = wg_scan_excl<kTileThreads>(kept_cnt, kept_start, n_seg, nullptr, s_w);
     if (threadIdx.x != 0) return;
     SlotHeader h;
     h.R = row_start[nrow];
@@ -454,7 +454,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     }
     {
         ProfScope p(c, "scan");
-        hipLaunchKernelGGL(k_scan_kept_slot, dim3(1), dim3(kScanThreads), 0, st, c->kept_cnt.as<int>() + d.s0, c->kept_start.as<int>() + d.s0, d.s1 - d.s0,
+        hipLaunchKernelGGL(k_scan_kept_slot, dim3(1), dim3(kTileThreads), 0, st, c->kept_cnt.as<int>() + d.s0, c->kept_start.as<int>() + d.s0, d.s1 - d.s0,
                            c->row_start.as<int>(), (int)nrow, (int)h->cand_cap, h->geom.slot_records, d.s0, d.s1, slot);
     }
     if (d.s1 > d.s0) {

@@ -14,6 +14,8 @@
 //   k_collinearity   per-view 2-D collinearity relation (upper triangle, bit + value)
 //   k_rownorm / k_diffusion_step   replicator dynamics diffusion
 //   k_similarity     batched similarity_coll3D for the affinity fill
+#include <algorithm>
+
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
 #include "l3d_scan.hpp"
@@ -295,17 +297,14 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
 }
 
 // Exclusive scan of n ints by ONE workgroup (l3d_scan.hpp); out has n+1 entries, `zero` (optional) gets n zeros.
-__global__ __launch_bounds__(kScanThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
+__global__ __launch_bounds__(kTileThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
                                                        int* __restrict__ seg_order, int N, int seg_begin, int seg_end)
 {
-    __shared__ int s_w[16];
+    __shared__ int s_w[5];
     __shared__ int s_hist[130];
-    (void)wg_scan_excl(in, out, n, zero, s_w);
-    if (seg_order) {                                // rows -> segments, longest first (the scan's own stores are visible to the workgroup)
-        __threadfence();
-        __syncthreads();
-        wg_segment_order(out, N, seg_begin, seg_end, seg_order, s_hist);
-    }
+    const int n_tiles = max(1, (n + kTileInts - 1) / kTileInts);
+    if ((int)blockIdx.x < n_tiles) wg_scan_excl_tile(in, out, n, zero, blockIdx.x, s_w);     // one independent workgroup per tile
+    else if (seg_order) wg_segment_order(in, N, seg_begin, seg_end, seg_order, s_hist);        // rows -> segments, longest first
 }
 
 // r-th (0-based) set bit of a 64-bit word
@@ -772,7 +771,8 @@ void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_
 }
 void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order, int N, int seg_begin, int seg_end)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end);
+    const int n_tiles = std::max(1, (n + kTileInts - 1) / kTileInts);
+    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end);
 }
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
 {
