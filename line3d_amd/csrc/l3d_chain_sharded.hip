@@ -187,6 +187,8 @@ struct l3d_shard_chain {
     std::vector<char> packed;                // per view: its pack kernel is enqueued (and covered by ev2)
     hipEvent_t ev3 = nullptr;                // lazy pack (step-wise protocol): enqueued by fetch
     std::atomic<int> marked{0};              // views [0, marked) carry their completion event
+    std::atomic<int> s1_done{0};             // l3d_shard_chain_run with a stage-1 thread: views [0, s1_done) have their stage 1 enqueued
+    bool s1_thread = false;
     std::atomic<int> fetched{0};             // views [0, fetched) have left their staging buffer
     int copy_issued = -1;                    // view whose D2H copy the previous fetch has already issued (fetch thread only)
     l3d_match* copy_dst = nullptr;           // ... and where its records go (pinned arena)
@@ -329,7 +331,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
 #undef OCHK
     h->ev1.assign((size_t)n_views, nullptr);
     h->ev2.assign((size_t)n_views, nullptr);
-    for (int k = 0; k < n_views; ++k) h->ev2[(size_t)k] = get_event(c);
+    for (int k = 0; k < n_views; ++k) { h->ev2[(size_t)k] = get_event(c); h->ev1[(size_t)k] = get_event(c); }
     h->ev3 = get_event(c);
     c->stats[0] = h->pairs;
     *out = h;
@@ -377,7 +379,6 @@ static int shard_stage1(l3d_shard_chain* h, int k)
         { ProfScope p(c, "pair_fill", s1); launch_pair_fill(pf, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                                              c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, s1); }
     }
-    h->ev1[(size_t)k] = get_event(c);
     HIPCHK(c, hipEventRecord(h->ev1[(size_t)k], s1));
     return L3D_OK;
 }
@@ -391,7 +392,10 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     (void)hipGetLastError();            // the framework shares this thread: its (benign) sticky errors are not ours
-    while (h->k_p1 < h->n_views && h->k_p1 <= k + l3d_shard_chain::kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
+    if (!h->s1_thread)
+        while (h->k_p1 < h->n_views && h->k_p1 <= k + l3d_shard_chain::kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
+    else
+        while (h->s1_done.load(std::memory_order_acquire) <= k) std::this_thread::yield();     // the stage-1 thread enqueues it
     const l3d_chain_view& v = h->views[k];
     const SViewDev& d = h->vd[(size_t)k];
     h->gathered = reinterpret_cast<const unsigned char*>(gathered_base);
@@ -597,10 +601,30 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             }
         });
     }
+    // a second enqueue thread feeds the stage-1 stream (7 of the ~17 calls per view): with small per-rank slices the host
+    // launch rate, not the GPU, limits the chain otherwise.  It stays kStage1Ahead views ahead of the chain thread; the ring
+    // slot it writes was released by view k - kRingA, whose completion event the chain thread has recorded by then.
+    std::atomic<int> s1_rc{L3D_OK};
+    std::atomic<bool> s1_stop{false};
+    std::thread stage1;
+    h->s1_thread = true;
+    h->s1_done.store(0);
+    stage1 = std::thread([&]() {
+        (void)hipSetDevice(c->device);
+        for (int k = 0; k < h->n_views && !s1_stop.load(); ++k) {
+            while (!s1_stop.load() && h->marked.load(std::memory_order_acquire) < k - l3d_shard_chain::kStage1Ahead) std::this_thread::yield();
+            if (s1_stop.load()) break;
+            const int r = shard_stage1(h, k);
+            if (r) { s1_rc.store(r); break; }
+            h->s1_done.store(k + 1, std::memory_order_release);
+        }
+        h->s1_done.store(h->n_views + 1, std::memory_order_release);      // (never leave the chain thread waiting)
+    });
     int rc = L3D_OK;
     const double t_run0 = now_s();
     for (int k = 0; k < h->n_views && rc == L3D_OK; ++k) {
         // a committing rank stays less than a staging ring ahead of its bookkeeping thread (which trails the GPU closely)
+        if (s1_rc.load()) { rc = fail(c, s1_rc.load(), "l3d_shard_chain_run: stage 1 failed"); break; }
         while (cb && h->fetched.load(std::memory_order_acquire) < k - (l3d_shard_chain::kRing - 2)) {
             { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
             std::this_thread::yield();
@@ -615,6 +639,10 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         if (rc == L3D_OK) { { std::lock_guard<std::mutex> lk(mu); marked = k + 1; } cv.notify_one(); }
         { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
     }
+    s1_stop.store(true);
+    stage1.join();
+    h->s1_thread = false;
+    if (rc == L3D_OK && s1_rc.load()) rc = fail(c, s1_rc.load(), "l3d_shard_chain_run: stage 1 failed");
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_one();
     const double t_run1 = now_s();

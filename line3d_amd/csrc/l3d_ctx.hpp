@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -110,6 +111,7 @@ struct l3d_ctx {
     std::string prof_only;          // bracket only this kernel (keeps the timed region of bench.py nearly undisturbed)
     std::map<std::string, l3d::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
+    std::mutex event_mu;
     double stats[4] = { 0, 0, 0, 0 };
     double tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host-side phase timers of l3d_compute_pairwise_matches (L3D_TIMING=1)
 };
@@ -133,6 +135,7 @@ inline int fail(l3d_ctx* c, int code, const std::string& msg)
 
 inline hipEvent_t get_event(l3d_ctx* c)
 {
+    std::lock_guard<std::mutex> lk(c->event_mu);         // (the sharded run enqueues from two threads)
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e;
     (void)hipEventCreate(&e);
@@ -150,7 +153,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
-        if (on) { (void)hipEventRecord(b, st); c->prof[name].pending.emplace_back(a, b); }
+        if (on) { (void)hipEventRecord(b, st); std::lock_guard<std::mutex> lk(c->event_mu); c->prof[name].pending.emplace_back(a, b); }
     }
 };
 
