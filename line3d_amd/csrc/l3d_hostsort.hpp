@@ -1,0 +1,85 @@
+// l3d_hostsort.hpp -- stable host-side ordering of edge lists (the reference sorts std::lists of CLEdge / sparse entries
+// with std::list::sort and std::stable_sort: sparsematrix.cc:81-86,157-167, clustering.cc:14; equal keys keep their input
+// order).  Bucket by the major key, sort inside the buckets, on several threads.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <thread>
+#include <vector>
+
+namespace l3d {
+
+inline unsigned host_threads()         // worker threads of the host-side stages that run alone (finish of compute3Dmodel)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hw / 2));
+}
+
+template <class F>
+inline void on_threads(unsigned nt, F fn)   // fn(thread) on nt threads, the caller being thread 0
+{
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
+    fn(0u);
+    for (auto& x : th) x.join();
+}
+
+// Order of n records by (major(i), minor(i), i), major in [0, n_major), on nt threads: a counting sort on the major key
+// with one private histogram per thread (thread t owns the t-th contiguous slice of the input, so the scatter is stable and
+// needs no atomics), then every bucket ordered by (minor, input index) -- skipped when it already is, as for runs of equal
+// keys.  bucket_start (optional) receives the n_major + 1 bucket boundaries.
+template <class Major, class Minor>
+inline void parallel_stable_order(size_t n, size_t n_major, Major major, Minor minor, unsigned nt, std::vector<uint32_t>& order,
+                                  std::vector<uint32_t>* bucket_start = nullptr)
+{
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / 8192 + 1));
+    std::vector<uint32_t> hist((size_t)nt * n_major, 0), start(n_major + 1, 0);
+    on_threads(nt, [&](unsigned t) {
+        uint32_t* h = hist.data() + (size_t)t * n_major;
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) ++h[(size_t)major(i)];
+    });
+    on_threads(nt, [&](unsigned t) {                       // bucket totals
+        for (size_t b = n_major * t / nt; b < n_major * (t + 1) / nt; ++b) {
+            uint32_t tot = 0;
+            for (unsigned q = 0; q < nt; ++q) tot += hist[(size_t)q * n_major + b];
+            start[b + 1] = tot;
+        }
+    });
+    for (size_t b = 0; b < n_major; ++b) start[b + 1] += start[b];
+    on_threads(nt, [&](unsigned t) {                       // hist[q][b] -> first output slot of thread q in bucket b
+        for (size_t b = n_major * t / nt; b < n_major * (t + 1) / nt; ++b) {
+            uint32_t run = start[b];
+            for (unsigned q = 0; q < nt; ++q) { const uint32_t c = hist[(size_t)q * n_major + b]; hist[(size_t)q * n_major + b] = run; run += c; }
+        }
+    });
+    std::unique_ptr<uint64_t[]> rec(new uint64_t[n]);      // (minor << 32) | input index
+    on_threads(nt, [&](unsigned t) {
+        uint32_t* h = hist.data() + (size_t)t * n_major;
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) rec[h[(size_t)major(i)]++] = ((uint64_t)(uint32_t)minor(i) << 32) | (uint32_t)i;
+    });
+    order.resize(n);
+    on_threads(nt, [&](unsigned t) {                       // buckets in slices of about n / nt records
+        const size_t lo = std::lower_bound(start.begin(), start.end(), (uint32_t)(n * t / nt)) - start.begin();
+        const size_t hi = t + 1 == nt ? n_major : std::lower_bound(start.begin(), start.end(), (uint32_t)(n * (t + 1) / nt)) - start.begin();
+        for (size_t b = lo; b < hi && b < n_major; ++b) {
+            const uint32_t s = start[b], e = start[b + 1];
+            if (e - s > 1 && !std::is_sorted(rec.get() + s, rec.get() + e)) std::sort(rec.get() + s, rec.get() + e);
+            for (uint32_t k = s; k < e; ++k) order[k] = (uint32_t)rec[k];
+        }
+    });
+    if (bucket_start) bucket_start->swap(start);
+}
+
+// monotone map of a float to an unsigned key (-0 == +0; NaNs are not expected in weight lists)
+inline uint32_t float_order_key(float w)
+{
+    if (w == 0.0f) w = 0.0f;
+    uint32_t u;
+    memcpy(&u, &w, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+}  // namespace l3d

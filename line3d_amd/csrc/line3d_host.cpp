@@ -25,6 +25,7 @@
 
 #include "../../include/line3d_amd.h"
 #include "l3d_linalg.hpp"
+#include "l3d_hostsort.hpp"
 
 using namespace l3d::la;
 
@@ -1121,30 +1122,59 @@ void unproject_segment(const View& v, uint32_t id, float d1, float d2, Hyp& o)
     o.depth_p1 = d1; o.depth_p2 = d2;
 }
 
+// ---- small thread helpers of the finishing stages (greedy selection .. line fit run alone on the host) ----------
+unsigned finish_threads() { return l3d::host_threads(); }
+
+// fn(begin, end, thread) over [0, n) in contiguous slices
+template <class F>
+void parallel_slices(size_t n, unsigned nt, F fn)
+{
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n));
+    if (nt == 1) { fn((size_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, t); });
+    fn((size_t)0, n / nt, 0u);
+    for (auto& x : th) x.join();
+}
+
+struct SpinBarrier {                                 // short phases between barriers: spin, then yield
+    explicit SpinBarrier(unsigned n) : n_(n) {}
+    void wait()
+    {
+        const unsigned g = gen_.load(std::memory_order_acquire);
+        if (cnt_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) { cnt_.store(0, std::memory_order_relaxed); gen_.store(g + 1, std::memory_order_release); }
+        else { int spins = 0; while (gen_.load(std::memory_order_acquire) == g) if (++spins > 2000) std::this_thread::yield(); }
+    }
+    unsigned n_;
+    std::atomic<unsigned> cnt_{ 0 }, gen_{ 0 };
+};
+
 // Line3D::greedySelection, line3D.cc:899-965: the stored list holds one (best) match per segment
 void greedy_selection(L* h)
 {
     h->hyps.clear();
     h->best_idx.assign(h->vlist.size(), {});
+    std::vector<int> best;
     for (View* v : h->vlist) {
         std::vector<int>& bi = h->best_idx[(size_t)v->index];
-        bi.assign((size_t)v->S(), -1);
+        const uint32_t S = (uint32_t)v->S();
+        bi.assign((size_t)S, -1);
         if (!v->store_exists) continue;
         // group by segment (ascending), first of the highest confidence
-        std::map<uint32_t, size_t> best;
+        best.assign((size_t)S, -1);
         for (size_t i = 0; i < v->store.size(); ++i) {
-            auto it = best.find(v->store[i].segID1);
-            if (it == best.end()) best[v->store[i].segID1] = i;
-            else if (v->store[i].confidence > v->store[it->second].confidence) it->second = i;
+            const uint32_t sg = v->store[i].segID1;
+            if (sg >= S) continue;
+            if (best[sg] < 0 || v->store[i].confidence > v->store[(size_t)best[sg]].confidence) best[sg] = (int)i;
         }
-        for (auto& kv : best) {
-            const l3d_match& mp = v->store[kv.second];
-            if (kv.first >= (uint32_t)v->S()) continue;
+        for (uint32_t sg = 0; sg < S; ++sg) {
+            if (best[sg] < 0) continue;
+            const l3d_match& mp = v->store[(size_t)best[sg]];
             Hyp hy;
-            hy.src = mk(v->id, kv.first);
+            hy.src = mk(v->id, sg);
             hy.score = fminf(mp.confidence, 1.0f);
-            unproject_segment(*v, kv.first, mp.depths[0], mp.depths[1], hy);
-            bi[kv.first] = (int)h->hyps.size();
+            unproject_segment(*v, sg, mp.depths[0], mp.depths[1], hy);
+            bi[sg] = (int)h->hyps.size();
             h->hyps.push_back(hy);
         }
     }
@@ -1161,13 +1191,21 @@ int best_of(const L* h, Key k)
 // Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115 (stays on the host)
 void perform_clustering(const std::vector<l3d_edge>& edges_in, int numNodes, float c, std::vector<int>& labels)
 {
-    std::vector<l3d_edge> e(edges_in);
-    std::stable_sort(e.begin(), e.end(), [](const l3d_edge& a, const l3d_edge& b) { return a.w < b.w; });
+    // stable ascending order of the weights (clustering.cc:14: std::stable_sort over CLEdge::operator<)
+    std::vector<uint32_t> order;
+    const double t_sort = now_s();
+    {
+        const l3d_edge* e = edges_in.data();
+        l3d::parallel_stable_order(edges_in.size(), (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
+                                   [e](size_t i) { return l3d::float_order_key(e[i].w) & 0xffffu; }, finish_threads(), order);
+    }
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
     std::vector<int> rank((size_t)numNodes, 0), cid((size_t)numNodes), size((size_t)numNodes, 1);
     std::vector<float> thr((size_t)numNodes, c);
     for (int i = 0; i < numNodes; ++i) cid[i] = i;
     auto find = [&](int node) { int y = node; while (y != cid[y]) y = cid[y]; cid[node] = y; return y; };
-    for (const l3d_edge& ed : e) {
+    for (const uint32_t ei : order) {
+        const l3d_edge& ed = edges_in[ei];
         int a = find(ed.i), b = find(ed.j);
         if (a != b && ed.w <= thr[a] && ed.w <= thr[b]) {
             if (rank[a] > rank[b]) { cid[b] = a; size[a] += size[b]; }
@@ -1186,6 +1224,35 @@ int perform_diffusion(L* h, std::vector<l3d_edge>& A, int n)
     std::vector<l3d_edge> W(A.size());
     int rc = l3d_replicator_dynamics_diffusion(h->ctx, A.data(), (int)A.size(), n, L3D_RDD_MAX_ITER, W.data());
     if (rc) return h->fail(rc, std::string("rdd: ") + l3d_last_error(h->ctx));
+    const double t_sym = now_s();
+    // symmetrise by the minimum and rebuild A sorted by (i,j) (:1275-1301).  The diffused entries come back sorted by
+    // (row, column); when they are unique and the pattern is symmetric -- always the case for the affinity list built by
+    // clusterSegments2D -- the reference's map arithmetic reduces to A(i,j) = A(j,i) = min(W(i,j), W(j,i)) in that same order.
+    bool fast = true;
+    for (size_t k = 1; k < W.size() && fast; ++k) fast = W[k - 1].i < W[k].i || (W[k - 1].i == W[k].i && W[k - 1].j < W[k].j);
+    if (fast) {
+        std::vector<int> row((size_t)n + 1, 0);
+        for (const l3d_edge& e : W) ++row[(size_t)e.i + 1];
+        for (int r = 0; r < n; ++r) row[(size_t)r + 1] += row[(size_t)r];
+        std::vector<float> wmin(W.size());
+        std::atomic<int> missing{ 0 };
+        parallel_slices(W.size(), finish_threads(), [&](size_t k0, size_t k1, unsigned) {
+            for (size_t k = k0; k < k1; ++k) {
+                const l3d_edge& e = W[k];
+                const l3d_edge* lo = W.data() + row[(size_t)e.j];
+                const l3d_edge* hi = W.data() + row[(size_t)e.j + 1];
+                const l3d_edge* t = std::lower_bound(lo, hi, e.i, [](const l3d_edge& x, int col) { return x.j < col; });
+                if (t == hi || t->j != e.i) { missing.fetch_add(1, std::memory_order_relaxed); continue; }
+                wmin[k] = e.i <= e.j ? fminf(t->w, e.w) : fminf(e.w, t->w);     // the visit of the later entry decides
+            }
+        });
+        if (missing.load() == 0) {
+            A.swap(W);
+            for (size_t k = 0; k < A.size(); ++k) A[k].w = wmin[k];
+            if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d rdd] %-24s %8.2f ms\n", "symmetrise", (now_s() - t_sym) * 1e3);
+            return L3D_OK;
+        }
+    }
     std::map<std::pair<int, int>, float> entries;
     for (const l3d_edge& e : W) {
         const float w12 = e.w;
@@ -1270,153 +1337,255 @@ void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std
 int cluster_segments_2D(L* h, bool perform_diff)
 {
     const double t0 = now_s();
+    const bool timing = getenv("L3D_TIMING") != nullptr;
+    double tm_last = t0;
+    auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", what, (t - tm_last) * 1e3); tm_last = t; } };
     h->A.clear(); h->local2global.clear(); h->result.clear();
     const size_t nh = h->hyps.size();
     if (nh == 0) return L3D_OK;
 
     // dense index of every 2-D segment of every view (for the `used` bookkeeping)
-    std::vector<size_t> voff(h->vlist.size() + 1, 0);
-    for (size_t i = 0; i < h->vlist.size(); ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
-    auto dense = [&](Key k) -> long long {
-        auto it = h->views.find(kcam(k));
-        if (it == h->views.end() || kseg(k) >= (uint32_t)it->second.S()) return -1;
-        return (long long)(voff[(size_t)it->second.index] + kseg(k));
+    const size_t nv = h->vlist.size();
+    std::vector<size_t> voff(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
+    // camera id -> view index (ascending ids; ids are small in practice, else binary search)
+    std::vector<uint32_t> cam_ids(nv);
+    for (size_t i = 0; i < nv; ++i) cam_ids[i] = h->vlist[i]->id;
+    std::vector<int> cam_direct;
+    if (nv && cam_ids.back() < (1u << 22)) { cam_direct.assign((size_t)cam_ids.back() + 1, -1); for (size_t i = 0; i < nv; ++i) cam_direct[cam_ids[i]] = (int)i; }
+    auto view_of = [&](uint32_t cam) -> int {
+        if (!cam_direct.empty()) return cam < cam_direct.size() ? cam_direct[cam] : -1;
+        auto it = std::lower_bound(cam_ids.begin(), cam_ids.end(), cam);
+        return it != cam_ids.end() && *it == cam ? (int)(it - cam_ids.begin()) : -1;
     };
-    std::vector<uint32_t> stamp(voff.back(), 0);
-    std::vector<std::vector<uint32_t>> enc(nh);       // per processed src (hyp index): sorted dense ids met
-    // foreign keys (camera not a view): adjacency of src key -> foreign tgt keys, and vice versa
-    auto pot_range = [&](Key src, std::vector<Key>& out) {
-        out.clear();
-        const View& v = h->views[kcam(src)];
-        const auto& p = h->pot[(size_t)v.index];
-        auto lo = std::lower_bound(p.begin(), p.end(), std::make_pair(kseg(src), (Key)0));
-        for (; lo != p.end() && lo->first == kseg(src); ++lo) out.push_back(lo->second);
-    };
-
-    struct Item { int a, b; int kind; float cw; };
-    std::vector<Item> items;
-    std::vector<Key> tg;
-    std::vector<uint32_t> met;
-    for (size_t si = 0; si < nh; ++si) {
-        const Key src = h->hyps[si].src;
-        const uint32_t st = (uint32_t)si + 1;
-        const long long dsrc = dense(src);
-        met.clear();
-        // used[src][x] <=> x met earlier in this iteration, or src met while x was the source
-        auto used = [&](Key x, long long dx) -> bool {
-            if (dx < 0) return false;                          // foreign keys appear at most once per source
-            if (stamp[(size_t)dx] == st) return true;
-            const int xb = best_of(h, x);
-            if (xb >= 0 && (size_t)xb < si && dsrc >= 0 &&
-                std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), (uint32_t)dsrc)) return true;
-            return false;
-        };
-        auto mark = [&](long long dx) { if (dx >= 0) { stamp[(size_t)dx] = st; met.push_back((uint32_t)dx); } };
-
-        pot_range(src, tg);
-        // potential correspondences whose camera is not a view sort by key among the others; they never
-        // have a best match, so they only need to be skipped
-        for (Key tgt : tg) {                                                     // :996-1138
-            const long long dt = dense(tgt);
-            if (used(tgt, dt)) continue;
-            mark(dt);
-            const int tb = best_of(h, tgt);
-            if (tb < 0) continue;
-            items.push_back({ (int)si, tb, 0, 0.0f });
-            const View& tv = h->views[kcam(tgt)];
-            for (int c = tv.coll_start[kseg(tgt)]; c < tv.coll_start[kseg(tgt) + 1]; ++c) {   // :1065-1136
-                const Key tgtc = mk(kcam(tgt), (uint32_t)tv.coll_other[(size_t)c]);
-                const long long dc = dense(tgtc);
-                if (used(tgtc, dc)) continue;
-                mark(dc);
-                const int cb = best_of(h, tgtc);
-                if (cb >= 0) items.push_back({ (int)si, cb, 1, 0.0f });
-            }
-        }
-        const View& sv = h->views[kcam(src)];
-        for (int c = sv.coll_start[kseg(src)]; c < sv.coll_start[kseg(src) + 1]; ++c) {       // :1141-1214
-            const Key tgt = mk(kcam(src), (uint32_t)sv.coll_other[(size_t)c]);
-            const long long dt = dense(tgt);
-            if (used(tgt, dt)) continue;
-            mark(dt);
-            const int tb = best_of(h, tgt);
-            if (tb >= 0) items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
-        }
-        std::sort(met.begin(), met.end());
-        enc[si] = met;
+    // hypotheses are in (view, segment) order: the range of each view
+    std::vector<size_t> hyp_begin(nv + 1, nh);
+    {
+        std::vector<size_t> cnt(nv, 0);
+        for (const Hyp& hy : h->hyps) ++cnt[(size_t)view_of(kcam(hy.src))];
+        size_t run = 0;
+        for (size_t i = 0; i < nv; ++i) { hyp_begin[i] = run; run += cnt[i]; }
     }
+
+    // Candidate enumeration in the reference's order.  used[src][x] <=> x met earlier in this iteration, or src met while x was
+    // the source (an earlier iteration).  The iterations of ONE view are independent of each other: a source only asks what
+    // sources of EARLIER views met (potential correspondences and their collinear segments live in other views), except for
+    // its own view's collinear segments (:1141-1214), where "x met src" is simply "src is in x's collinear list" (x's iteration
+    // walks that whole list and marks what it has not marked yet).  So: views in order, a barrier between views, the
+    // segments of a view in parallel chunks; the chunks' item lists are concatenated in order afterwards.
+    struct Item { int a, b; int kind; float cw; };
+    constexpr size_t kChunk = 32;
+    struct Chunk { size_t begin, end; std::vector<Item> items; };
+    std::vector<Chunk> chunks;
+    std::vector<size_t> view_chunk_begin(nv + 1, 0);
+    for (size_t vi = 0; vi < nv; ++vi) {
+        view_chunk_begin[vi] = chunks.size();
+        for (size_t bgn = hyp_begin[vi]; bgn < hyp_begin[vi + 1]; bgn += kChunk) chunks.push_back({ bgn, std::min(hyp_begin[vi + 1], bgn + kChunk), {} });
+    }
+    view_chunk_begin[nv] = chunks.size();
+    std::vector<std::vector<uint32_t>> enc(nh);       // per processed src (hyp index): sorted dense ids met
+    const unsigned nt = finish_threads();
+    {
+        SpinBarrier bar(nt);
+        std::vector<std::atomic<size_t>> next(nv);
+        for (size_t vi = 0; vi < nv; ++vi) next[vi].store(view_chunk_begin[vi]);
+        auto worker = [&](unsigned) {
+            std::vector<uint32_t> stamp(voff.back(), 0), met;
+            uint32_t st = 0;
+            for (size_t vi = 0; vi < nv; ++vi) {
+                const View& sv = *h->vlist[vi];
+                const auto& pot = h->pot[vi];
+                const std::vector<int>& sbi = h->best_idx[vi];
+                for (;;) {
+                    const size_t ci = next[vi].fetch_add(1, std::memory_order_relaxed);
+                    if (ci >= view_chunk_begin[vi + 1]) break;
+                    Chunk& ch = chunks[ci];
+                    for (size_t si = ch.begin; si < ch.end; ++si) {
+                        const uint32_t sseg = kseg(h->hyps[si].src);
+                        const uint32_t dsrc = (uint32_t)(voff[vi] + sseg);
+                        ++st;
+                        met.clear();
+                        auto lo = std::lower_bound(pot.begin(), pot.end(), std::make_pair(sseg, (Key)0));
+                        for (; lo != pot.end() && lo->first == sseg; ++lo) {                     // :996-1138
+                            const Key tgt = lo->second;
+                            // keys whose camera is not a view (early-return quirk) sort among the others, never have a best
+                            // match and appear at most once per source: they only need to be skipped
+                            const int tvi = view_of(kcam(tgt));
+                            if (tvi < 0) continue;
+                            const View& tv = *h->vlist[(size_t)tvi];
+                            const uint32_t tseg = kseg(tgt);
+                            if (tseg >= (uint32_t)tv.S()) continue;
+                            const std::vector<int>& tbi = h->best_idx[(size_t)tvi];
+                            auto used = [&](uint32_t xs) -> bool {
+                                if (stamp[voff[(size_t)tvi] + xs] == st) return true;
+                                const int xb = tbi[xs];
+                                return xb >= 0 && (size_t)xb < si && std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), dsrc);
+                            };
+                            auto mark = [&](uint32_t xs) { const uint32_t d = (uint32_t)(voff[(size_t)tvi] + xs); stamp[d] = st; met.push_back(d); };
+                            if (used(tseg)) continue;
+                            mark(tseg);
+                            const int tb = tbi[tseg];
+                            if (tb < 0) continue;
+                            ch.items.push_back({ (int)si, tb, 0, 0.0f });
+                            for (int c = tv.coll_start[tseg]; c < tv.coll_start[tseg + 1]; ++c) {  // :1065-1136
+                                const uint32_t cs = (uint32_t)tv.coll_other[(size_t)c];
+                                if (used(cs)) continue;
+                                mark(cs);
+                                const int cb = tbi[cs];
+                                if (cb >= 0) ch.items.push_back({ (int)si, cb, 1, 0.0f });
+                            }
+                        }
+                        for (int c = sv.coll_start[sseg]; c < sv.coll_start[sseg + 1]; ++c) {     // :1141-1214
+                            const uint32_t xs = (uint32_t)sv.coll_other[(size_t)c];
+                            const uint32_t dx = (uint32_t)(voff[vi] + xs);
+                            bool u = stamp[dx] == st;
+                            if (!u) {
+                                const int xb = sbi[xs];
+                                if (xb >= 0 && (size_t)xb < si)
+                                    for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
+                            }
+                            if (u) continue;
+                            stamp[dx] = st; met.push_back(dx);
+                            const int tb = sbi[xs];
+                            if (tb >= 0) ch.items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
+                        }
+                        std::sort(met.begin(), met.end());
+                        enc[si] = met;
+                    }
+                }
+                bar.wait();
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker, t);
+        worker(0);
+        for (auto& x : th) x.join();
+    }
+    std::vector<size_t> chunk_off(chunks.size() + 1, 0);
+    for (size_t c = 0; c < chunks.size(); ++c) chunk_off[c + 1] = chunk_off[c] + chunks[c].items.size();
+    const size_t n_items = chunk_off.back();
+    lap("enumerate candidates");
 
     // batched similarity on the GPU
-    std::vector<l3d_hypothesis> hy(nh);
-    for (size_t i = 0; i < nh; ++i) {
-        const Hyp& s = h->hyps[i];
-        const View& v = h->views[kcam(s.src)];
-        l3d_hypothesis& o = hy[i];
-        o.P1[0] = s.P1.x; o.P1[1] = s.P1.y; o.P1[2] = s.P1.z;
-        o.P2[0] = s.P2.x; o.P2[1] = s.P2.y; o.P2[2] = s.P2.z;
-        o.dir[0] = s.dir.x; o.dir[1] = s.dir.y; o.dir[2] = s.dir.z;
-        o.depth_p1 = s.depth_p1; o.depth_p2 = s.depth_p2;
-        o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
-    }
-    std::vector<int32_t> pairs(items.size() * 2);
-    for (size_t k = 0; k < items.size(); ++k) { pairs[2 * k] = items[k].a; pairs[2 * k + 1] = items[k].b; }
-    std::vector<float> sim(items.size());
-    int rc = l3d_similarity_coll3D_batch(h->ctx, hy.data(), (int)nh, pairs.data(), (int)items.size(), h->sigma_a, sim.data());
+    // (plain arrays: first touched -- and paged in -- by the worker threads, not zero-filled by this one)
+    std::unique_ptr<l3d_hypothesis[]> hy(new l3d_hypothesis[nh]);
+    std::unique_ptr<int32_t[]> pairs(new int32_t[n_items * 2 + 1]);
+    std::unique_ptr<Item[]> items(new Item[n_items + 1]);
+    parallel_slices(nh, nt, [&](size_t b0, size_t b1, unsigned) {
+        for (size_t i = b0; i < b1; ++i) {
+            const Hyp& sh = h->hyps[i];
+            const View& v = *h->vlist[(size_t)view_of(kcam(sh.src))];
+            l3d_hypothesis& o = hy[i];
+            o.P1[0] = sh.P1.x; o.P1[1] = sh.P1.y; o.P1[2] = sh.P1.z;
+            o.P2[0] = sh.P2.x; o.P2[1] = sh.P2.y; o.P2[2] = sh.P2.z;
+            o.dir[0] = sh.dir.x; o.dir[1] = sh.dir.y; o.dir[2] = sh.dir.z;
+            o.depth_p1 = sh.depth_p1; o.depth_p2 = sh.depth_p2;
+            o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
+        }
+    });
+    parallel_slices(chunks.size(), nt, [&](size_t c0, size_t c1, unsigned) {
+        for (size_t c = c0; c < c1; ++c) {
+            size_t k = chunk_off[c];
+            for (const Item& it : chunks[c].items) { items[k] = it; pairs[2 * k] = it.a; pairs[2 * k + 1] = it.b; ++k; }
+            std::vector<Item>().swap(chunks[c].items);
+        }
+    });
+    std::unique_ptr<float[]> sim(new float[n_items + 1]), wgt(new float[n_items + 1]);
+    lap("pack hypotheses / pairs");
+    int rc = l3d_similarity_coll3D_batch(h->ctx, hy.get(), (int)nh, pairs.get(), (int)n_items, h->sigma_a, sim.get());
     if (rc) return h->fail(rc, std::string("similarity: ") + l3d_last_error(h->ctx));
+    lap("similarity (GPU call)");
 
-    // thresholds + first-touch node numbering, in enumeration order
+    // thresholds (parallel) + first-touch node numbering in enumeration order (sequential, over the edges only)
+    parallel_slices(n_items, nt, [&](size_t k0, size_t k1, unsigned) {
+        for (size_t k = k0; k < k1; ++k) {
+            const Item& it = items[k];
+            const float s1 = h->hyps[(size_t)it.a].score, s2 = h->hyps[(size_t)it.b].score;
+            float w;
+            if (it.kind == 2) w = it.cw * 0.5f * (s1 + s2) * sim[k];                // :1163
+            else w = 0.5f * (s1 + s2) * sim[k];                                     // :1014,:1085
+            const float thr = it.kind == 0 ? 0.25f : 0.01f;                         // L3D_MIN_AFFINITY / 0.01f
+            wgt[k] = w > thr ? w : -1.0f;
+        }
+    });
     std::vector<int> node(nh, -1);
+    h->A.reserve(2 * n_items);
+    h->local2global.reserve(nh);
     auto node_of = [&](int hidx) {
         if (node[(size_t)hidx] < 0) { node[(size_t)hidx] = (int)h->local2global.size(); h->local2global.push_back(h->hyps[(size_t)hidx].src); }
         return node[(size_t)hidx];
     };
-    for (size_t k = 0; k < items.size(); ++k) {
-        const Item& it = items[k];
-        const float s1 = h->hyps[(size_t)it.a].score, s2 = h->hyps[(size_t)it.b].score;
-        float w;
-        if (it.kind == 2) w = it.cw * 0.5f * (s1 + s2) * sim[k];                // :1163
-        else w = 0.5f * (s1 + s2) * sim[k];                                     // :1014,:1085
-        const float thr = it.kind == 0 ? 0.25f : 0.01f;                         // L3D_MIN_AFFINITY / 0.01f
-        if (w > thr) {
-            const int a = node_of(it.a);
-            const int b = node_of(it.b);
-            h->A.push_back({ a, b, w });
-            h->A.push_back({ b, a, w });
-        }
+    for (size_t k = 0; k < n_items; ++k) {
+        if (!(wgt[k] > 0.0f)) continue;
+        const int a = node_of(items[k].a);
+        const int b = node_of(items[k].b);
+        h->A.push_back({ a, b, wgt[k] });
+        h->A.push_back({ b, a, wgt[k] });
     }
+    if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %zu candidate pairs, %zu edges, %u threads\n", nh, n_items, h->A.size(), nt);
+    lap("thresholds / numbering");
     h->t_affinity = now_s() - t0;
     if (h->A.empty()) return L3D_OK;                                            // :1232-1233
 
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
-    std::vector<l3d_edge> edges = h->A;
-    if (perform_diff) { rc = perform_diffusion(h, edges, n_nodes); if (rc) return rc; }
+    std::vector<l3d_edge> diffused;
+    if (perform_diff) { diffused = h->A; rc = perform_diffusion(h, diffused, n_nodes); if (rc) return rc; }
+    const std::vector<l3d_edge>& edges = perform_diff ? diffused : h->A;
     std::vector<int> labels;
+    lap(perform_diff ? "copy + diffusion" : "-");
     perform_clustering(edges, n_nodes, 1.0f, labels);                           // :1245
+    lap("clustering");
 
-    // processClusteredSegments, line3D.cc:1306-1368
-    std::map<int, std::vector<Key>> cl2seg;
-    std::map<int, std::set<uint32_t>> cl2cam;
-    for (int lid = 0; lid < n_nodes; ++lid) {
-        cl2seg[labels[(size_t)lid]].push_back(h->local2global[(size_t)lid]);
-        cl2cam[labels[(size_t)lid]].insert(kcam(h->local2global[(size_t)lid]));
+    // processClusteredSegments, line3D.cc:1306-1368: clusters in ascending label order (the reference's std::map), their
+    // segments in key order; clusters seen from >= 4 cameras are fitted, independently of each other, by the worker threads
+    std::vector<int> lstart((size_t)n_nodes + 1, 0), lnodes((size_t)n_nodes);
+    for (int lid = 0; lid < n_nodes; ++lid) ++lstart[(size_t)labels[(size_t)lid] + 1];
+    for (int l = 0; l < n_nodes; ++l) lstart[(size_t)l + 1] += lstart[(size_t)l];
+    {
+        std::vector<int> cur(lstart.begin(), lstart.end() - 1);
+        for (int lid = 0; lid < n_nodes; ++lid) lnodes[(size_t)cur[(size_t)labels[(size_t)lid]]++] = lid;
     }
-    for (auto& kv : cl2seg) {
-        if (cl2cam[kv.first].size() < 4) continue;
-        std::vector<Key> keys = kv.second;
-        std::sort(keys.begin(), keys.end());
-        std::vector<std::pair<Key, std::pair<V3, V3>>> t3;
-        for (Key k : keys) {
-            const int b = best_of(h, k);
-            if (b < 0) continue;
-            t3.push_back({ k, { inverse_transform(h, h->hyps[(size_t)b].P1), inverse_transform(h, h->hyps[(size_t)b].P2) } });
-        }
-        FinalLine fl;
-        align_cluster(t3, fl.segs3D);
-        if (fl.segs3D.empty()) continue;
-        for (auto& e : t3) fl.segs2D.push_back(e.first);
-        h->result.push_back(std::move(fl));
+    std::vector<int> groups;                                                    // labels with >= 4 members (>= 4 cameras needs that)
+    for (int l = 0; l < n_nodes; ++l) if (lstart[(size_t)l + 1] - lstart[(size_t)l] >= 4) groups.push_back(l);
+    std::vector<FinalLine> fitted(groups.size());
+    {
+        std::atomic<size_t> next{ 0 };
+        auto worker = [&]() {
+            std::vector<Key> keys;
+            std::vector<std::pair<Key, std::pair<V3, V3>>> t3;
+            for (;;) {
+                const size_t g0 = next.fetch_add(16, std::memory_order_relaxed);
+                if (g0 >= groups.size()) break;
+                for (size_t g = g0; g < std::min(groups.size(), g0 + 16); ++g) {
+                    const int l = groups[g];
+                    keys.clear();
+                    for (int q = lstart[(size_t)l]; q < lstart[(size_t)l + 1]; ++q) keys.push_back(h->local2global[(size_t)lnodes[(size_t)q]]);
+                    std::sort(keys.begin(), keys.end());
+                    int ncam = 1;
+                    for (size_t q = 1; q < keys.size(); ++q) ncam += kcam(keys[q]) != kcam(keys[q - 1]);
+                    if (ncam < 4) continue;
+                    t3.clear();
+                    for (Key k : keys) {
+                        const int bb = best_of(h, k);
+                        if (bb < 0) continue;
+                        t3.push_back({ k, { inverse_transform(h, h->hyps[(size_t)bb].P1), inverse_transform(h, h->hyps[(size_t)bb].P2) } });
+                    }
+                    FinalLine& fl = fitted[g];
+                    align_cluster(t3, fl.segs3D);
+                    if (fl.segs3D.empty()) continue;
+                    for (auto& e : t3) fl.segs2D.push_back(e.first);
+                }
+            }
+        };
+        const unsigned ntf = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, groups.size() / 64 + 1));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < ntf; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
     }
+    for (FinalLine& fl : fitted) if (!fl.segs3D.empty()) h->result.push_back(std::move(fl));
+    lap("line fit");
     h->t_cluster = now_s() - t1;
     return L3D_OK;
 }
@@ -1520,7 +1689,9 @@ int l3d_line3d_match_views(l3d_line3d* h)
 int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    const double t0 = now_s();
     greedy_selection(h);                                   // optimizeLocalMatches, :888-896
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
     return cluster_segments_2D(h, perform_diffusion != 0);
 }
 // Line3D::compute3Dmodel, line3D.cc:345-374

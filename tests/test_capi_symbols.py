@@ -71,3 +71,32 @@ def test_host_clustering_matches_reference_golden():
         rc = lib.l3d_perform_clustering(e.ctypes.data_as(C.c_void_p), C.c_int(len(e)), C.c_int(n), C.c_float(float(nm.split("_")[1])),
                                         labels.ctypes.data_as(C.c_void_p))
         assert rc == 0 and np.array_equal(labels, g[nm + "_labels"]), nm
+
+
+def test_host_clustering_large_lists_with_ties(oracle_lib):
+    """The product orders large edge lists on several threads (bucket + sort, l3d_hostsort.hpp); the result must be the
+    stable order of clustering.cc:14 whatever the list size: many equal weights, against the pinned oracle (and the
+    reference's own clustering.cc when oracle/_ref is built)."""
+    import numpy as np
+    import l3d_oracle_pipeline as op
+    from line3d_amd import capi
+    lib = capi.load_library()
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libclustering_ref.so")
+    ref = C.CDLL(ref_path) if os.path.exists(ref_path) else None
+    rng = np.random.default_rng(7)
+    for n, E, q in ((3000, 40000, 2), (20000, 300000, 3), (50, 70000, 1)):
+        e = np.zeros(E, dtype=capi.EDGE_DTYPE)
+        e["i"], e["j"] = rng.integers(0, n, E), rng.integers(0, n, E)
+        e["w"] = np.where(rng.random(E) < 0.3, 1.0, np.round(rng.random(E), q)).astype(np.float32)
+        labels = np.zeros(n, np.int32)
+        rc = lib.l3d_perform_clustering(e.ctypes.data_as(C.c_void_p), C.c_int(E), C.c_int(n), C.c_float(1.0), labels.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        eo = np.zeros(E, dtype=op.EDGE_DTYPE)
+        eo["i"], eo["j"], eo["w"] = e["i"], e["j"], e["w"]
+        assert np.array_equal(labels, op.clustering(oracle_lib, eo, n, 1.0)), (n, E)
+        if ref is not None:
+            want = np.zeros(n, np.int32)
+            ei, ej, ew = (np.ascontiguousarray(e[k]) for k in ("i", "j", "w"))
+            assert ref.l3dref_clustering(ei.ctypes.data_as(C.c_void_p), ej.ctypes.data_as(C.c_void_p), ew.ctypes.data_as(C.c_void_p),
+                                         C.c_int(E), C.c_int(n), C.c_float(1.0), want.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(labels, want), (n, E)
