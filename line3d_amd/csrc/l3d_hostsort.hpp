@@ -4,6 +4,7 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -14,6 +15,7 @@ namespace l3d {
 
 inline unsigned host_threads()         // worker threads of the host-side stages that run alone (finish of compute3Dmodel)
 {
+    if (const char* e = getenv("L3D_HOST_THREADS")) return (unsigned)std::max(1, std::min(64, atoi(e)));
     const unsigned hw = std::thread::hardware_concurrency();
     return std::max(1u, std::min(16u, hw / 2));
 }

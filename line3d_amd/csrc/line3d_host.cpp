@@ -1441,8 +1441,10 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             bool u = stamp[dx] == st;
                             if (!u) {
                                 const int xb = sbi[xs];
-                                if (xb >= 0 && (size_t)xb < si)
-                                    for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
+                                if (xb >= 0 && (size_t)xb < si) {
+                                    if (nt == 1) u = std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), dsrc);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
+                                    else for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
+                                }
                             }
                             if (u) continue;
                             stamp[dx] = st; met.push_back(dx);

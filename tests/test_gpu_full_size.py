@@ -158,3 +158,24 @@ def test_full_size_diffusion_equals_oracle(chain_run, oracle_lib):
     exp = op.rdd(oracle_lib, A, n_nodes)
     assert got.tobytes() == exp.tobytes()
     ctx.close()
+
+
+def test_full_size_finish_threads_do_not_change_results(chain_run, monkeypatch):
+    """The finishing stages (candidate enumeration of clusterSegments2D, edge ordering, line fit) run on worker threads;
+    on one thread the enumeration applies the reference's `used` rule literally.  Same affinity list, same lines."""
+    l, _ = chain_run
+    out = {}
+    for threads in ("1", "16", "5"):
+        monkeypatch.setenv("L3D_HOST_THREADS", threads)
+        for diffusion in (False, True):
+            l.finish(diffusion)
+            A, n_nodes = l.affinity()[:2]
+            lines = l.getResult()
+            sig = hashlib.sha256(np.ascontiguousarray(A).tobytes())
+            for seg2, seg3 in lines:
+                sig.update(np.asarray(seg2, dtype=np.int64).tobytes())
+                sig.update(np.asarray([np.concatenate(p) for p in seg3], dtype=np.float64).tobytes())
+            out[(threads, diffusion)] = (len(A), n_nodes, len(lines), sig.hexdigest())
+    for diffusion in (False, True):
+        assert out[("1", diffusion)][0] > 100000 and out[("1", diffusion)][2] > 100
+        assert out[("1", diffusion)] == out[("16", diffusion)] == out[("5", diffusion)], diffusion
