@@ -55,6 +55,27 @@ def test_no_collinearity_and_nonzero_ids():
     l.close()
 
 
+def test_sparse_large_camera_ids():
+    """Image ids are arbitrary 32-bit numbers (the SfM readers use the file's indices): huge, non-contiguous ids go
+    through the sorted-table lookups instead of the direct tables; local ids of the early-return quirk name no view."""
+    from line3d_amd.synth import make_scene
+    sc = make_scene(10, 220, 6, seed=33)
+    remap = lambda i: 4000000000 + 977 * int(i)
+    for v in sc.views:
+        v["id"] = remap(v["id"])
+        v["sims"] = {remap(k): w for k, w in v["sims"].items()}
+    o = op.run_scene(sc, 6)
+    l = _run_gpu(sc, 6)
+    assert len(o.result) > 20
+    for v in sorted(o.trace):
+        got, med = l.view_matches(v)
+        assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
+    A, n_nodes = l.affinity()
+    assert n_nodes == len(o.local2global) and A.tobytes() == o.affinity.tobytes()
+    assert_lines_equal(l.getResult(), o.result, 1e-4)
+    l.close()
+
+
 def test_config1_literal_is_empty(gpu_ctx):
     """BASELINE config 1 as written (8 views, N=4): with +-2 neighbourhoods no hypothesis can be supported by
     two other cameras, so the reference semantics keep nothing -- the degenerate case must not crash."""
