@@ -274,6 +274,13 @@ def main():
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))
         if roof:
             out["roofline"] = roof
+            km = roof["kernels_ms"]
+            s1 = sum(km.get(k, 0.0) for k in ("pair_mask", "row_count", "pair_fill"))
+            s2 = sum(km.get(k, 0.0) for k in ("cand_move", "exist", "verify_window", "verify", "seg_post", "kept_write"))
+            if s1 > 0 and s2 > 0:      # stage-1-only and stage-2-only rates (kernel time of one pass; the stages overlap on two streams)
+                out["stage_rates"] = dict(stage1_pairs_per_s=pairs_local / (s1 * 1e-3), stage1_kernel_ms=round(s1, 3),
+                                          stage2_candidates_per_s=raw_local / (s2 * 1e-3), stage2_kernel_ms=round(s2, 3),
+                                          note="per-pass kernel time of each stage measured with every kernel bracketed (untimed pass)")
         if dist is None and not args.no_extras:
             # the rest of compute3Dmodel on the same scene, once, untimed w.r.t. `value` (affinity edges/s,
             # diffusion): greedy selection + affinity fill (batched similarity on the GPU) + clustering + line fit
@@ -285,6 +292,17 @@ def main():
                 ex["diffusion" if diff else "no_diffusion"] = dict(finish_s=time.perf_counter() - t1, affinity_s=st2["t_affinity"], cluster_s=st2["t_cluster"],
                                                                    affinity_edges=st2["edges"], lines=st2["lines"],
                                                                    affinity_edges_per_s=st2["edges"] / st2["t_affinity"] if st2["t_affinity"] > 0 else None)
+            try:                       # a11 alone: 10 iterations of row-normalise + positional product on the affinity list
+                l3d.finish(False)
+                A, n_nodes = l3d.affinity()[:2]
+                ctx.replicator_dynamics_diffusion(A, n_nodes)
+                t1 = time.perf_counter()
+                ctx.replicator_dynamics_diffusion(A, n_nodes)
+                t_rdd = time.perf_counter() - t1
+                ex["rdd"] = dict(seconds=t_rdd, entries=int(len(A)), iterations=10, iterations_per_s=10.0 / t_rdd,
+                                 entry_updates_per_s=10.0 * len(A) / t_rdd, note="host sorts + upload + 21 launches + download")
+            except Exception as e:     # noqa: BLE001
+                ex["rdd"] = dict(error=str(e))
             out["rest_of_compute3Dmodel"] = ex
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments)

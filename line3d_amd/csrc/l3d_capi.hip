@@ -479,8 +479,8 @@ int l3d_replicator_dynamics_diffusion(l3d_ctx* c, const l3d_edge* A, int nnz, in
     // re-sorted by row (cudawrapper.cu:1145 -> sparsematrix.cc:157-167).  Entries and first-entry tables as sparsematrix.cc:99-131.
     const unsigned nt = host_threads();
     std::vector<uint32_t> ordW, ordP, startW, startP;
-    parallel_stable_order((size_t)nnz, (size_t)n, [&](size_t k) { return A[k].j; }, [&](size_t k) { return A[k].i; }, nt, ordW, &startW);
-    parallel_stable_order((size_t)nnz, (size_t)n, [&](size_t k) { return A[ordW[k]].i; }, [&](size_t k) { return A[ordW[k]].j; }, nt, ordP, &startP);
+    parallel_stable_order((size_t)nnz, (size_t)n, (size_t)n, [&](size_t k) { return A[k].j; }, [&](size_t k) { return A[k].i; }, nt, ordW, &startW);
+    parallel_stable_order((size_t)nnz, (size_t)n, (size_t)n, [&](size_t k) { return A[ordW[k]].i; }, [&](size_t k) { return A[ordW[k]].j; }, nt, ordP, &startP);
     HostSparse W, Pm;
     W.entries.reset(new float4[(size_t)nnz]); Pm.entries.reset(new float4[(size_t)nnz]);
     W.start.reset(new int[(size_t)n]); Pm.start.reset(new int[(size_t)n]);

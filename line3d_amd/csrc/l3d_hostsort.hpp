@@ -29,12 +29,12 @@ inline void on_threads(unsigned nt, F fn)   // fn(thread) on nt threads, the cal
     for (auto& x : th) x.join();
 }
 
-// Order of n records by (major(i), minor(i), i), major in [0, n_major), on nt threads: a counting sort on the major key
+// Order of n records by (major(i), minor(i), i), major in [0, n_major), minor in [0, n_minor), on nt threads: a counting sort on the major key
 // with one private histogram per thread (thread t owns the t-th contiguous slice of the input, so the scatter is stable and
 // needs no atomics), then every bucket ordered by (minor, input index) -- skipped when it already is, as for runs of equal
 // keys.  bucket_start (optional) receives the n_major + 1 bucket boundaries.
 template <class Major, class Minor>
-inline void parallel_stable_order(size_t n, size_t n_major, Major major, Minor minor, unsigned nt, std::vector<uint32_t>& order,
+inline void parallel_stable_order(size_t n, size_t n_major, size_t n_minor, Major major, Minor minor, unsigned nt, std::vector<uint32_t>& order,
                                   std::vector<uint32_t>* bucket_start = nullptr)
 {
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / 8192 + 1));
@@ -64,11 +64,29 @@ inline void parallel_stable_order(size_t n, size_t n_major, Major major, Minor m
     });
     order.resize(n);
     on_threads(nt, [&](unsigned t) {                       // buckets in slices of about n / nt records
+        std::vector<uint64_t> tmp;
         const size_t lo = std::lower_bound(start.begin(), start.end(), (uint32_t)(n * t / nt)) - start.begin();
         const size_t hi = t + 1 == nt ? n_major : std::lower_bound(start.begin(), start.end(), (uint32_t)(n * (t + 1) / nt)) - start.begin();
         for (size_t b = lo; b < hi && b < n_major; ++b) {
             const uint32_t s = start[b], e = start[b + 1];
-            if (e - s > 1 && !std::is_sorted(rec.get() + s, rec.get() + e)) std::sort(rec.get() + s, rec.get() + e);
+            uint64_t* r = rec.get() + s;
+            const size_t m = e - s;
+            if (m > 1 && !std::is_sorted(r, r + m)) {
+                if (m < 4096) std::sort(r, r + m);
+                else {                                     // a heavy bucket (skewed keys): byte-wise LSD passes over the minor key, stable
+                    tmp.resize(m);
+                    uint64_t *a = r, *b = tmp.data();
+                    for (int shift = 32; shift < 64 && ((uint64_t)(n_minor - 1) >> (shift - 32)) != 0; shift += 8) {
+                        size_t cnt[257];
+                        memset(cnt, 0, sizeof(cnt));
+                        for (size_t i = 0; i < m; ++i) ++cnt[((a[i] >> shift) & 255) + 1];
+                        for (int k = 1; k < 256; ++k) cnt[k] += cnt[k - 1];
+                        for (size_t i = 0; i < m; ++i) b[cnt[(a[i] >> shift) & 255]++] = a[i];
+                        std::swap(a, b);
+                    }
+                    if (a != r) memcpy(r, a, m * sizeof(uint64_t));
+                }
+            }
             for (uint32_t k = s; k < e; ++k) order[k] = (uint32_t)rec[k];
         }
     });

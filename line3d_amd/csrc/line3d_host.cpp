@@ -125,6 +125,22 @@ struct KeptList {
     void use_own() { p = own.data(); n = own.size(); }
 };
 
+// std::vector whose resize() leaves trivially-constructible elements uninitialised (large edge lists are written in full by
+// worker threads right after the resize; a zero fill by the calling thread would cost more than the write)
+template <class T>
+struct NoInitAlloc {
+    typedef T value_type;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { ::operator delete(p); }
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... a) { ::new ((void*)p) U(std::forward<Args>(a)...); }
+    template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+typedef std::vector<l3d_edge, NoInitAlloc<l3d_edge>> EdgeVec;
+
 struct FinalLine {
     std::vector<Key> segs2D;
     std::vector<std::pair<V3, V3>> segs3D;
@@ -176,7 +192,7 @@ struct l3d_line3d {
     // final hypotheses
     std::vector<Hyp> hyps;                                     // best_match_ in key order
     std::vector<std::vector<int>> best_idx;                    // per view index: seg -> hyp index or -1
-    std::vector<l3d_edge> A;
+    EdgeVec A;
     std::vector<Key> local2global;
     std::vector<FinalLine> result;
 
@@ -1189,14 +1205,14 @@ int best_of(const L* h, Key k)
 }
 
 // Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115 (stays on the host)
-void perform_clustering(const std::vector<l3d_edge>& edges_in, int numNodes, float c, std::vector<int>& labels)
+void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, float c, std::vector<int>& labels)
 {
     // stable ascending order of the weights (clustering.cc:14: std::stable_sort over CLEdge::operator<)
     std::vector<uint32_t> order;
     const double t_sort = now_s();
     {
-        const l3d_edge* e = edges_in.data();
-        l3d::parallel_stable_order(edges_in.size(), (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
+        const l3d_edge* e = edges_in;
+        l3d::parallel_stable_order(n_edges, (size_t)65536, (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
                                    [e](size_t i) { return l3d::float_order_key(e[i].w) & 0xffffu; }, finish_threads(), order);
     }
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
@@ -1218,37 +1234,40 @@ void perform_clustering(const std::vector<l3d_edge>& edges_in, int numNodes, flo
     for (int k = 0; k < numNodes; ++k) labels[k] = find(k);
 }
 
-// Line3D::performDiffusion, line3D.cc:1255-1303
-int perform_diffusion(L* h, std::vector<l3d_edge>& A, int n)
+// Line3D::performDiffusion, line3D.cc:1255-1303: A (read) -> diffused, symmetrised list sorted by (i,j) in `out`
+int perform_diffusion(L* h, const EdgeVec& A, int n, EdgeVec& out)
 {
-    std::vector<l3d_edge> W(A.size());
+    EdgeVec W;
+    W.resize(A.size());
     int rc = l3d_replicator_dynamics_diffusion(h->ctx, A.data(), (int)A.size(), n, L3D_RDD_MAX_ITER, W.data());
     if (rc) return h->fail(rc, std::string("rdd: ") + l3d_last_error(h->ctx));
     const double t_sym = now_s();
     // symmetrise by the minimum and rebuild A sorted by (i,j) (:1275-1301).  The diffused entries come back sorted by
     // (row, column); when they are unique and the pattern is symmetric -- always the case for the affinity list built by
     // clusterSegments2D -- the reference's map arithmetic reduces to A(i,j) = A(j,i) = min(W(i,j), W(j,i)) in that same order.
-    bool fast = true;
-    for (size_t k = 1; k < W.size() && fast; ++k) fast = W[k - 1].i < W[k].i || (W[k - 1].i == W[k].i && W[k - 1].j < W[k].j);
-    if (fast) {
+    const unsigned nt = finish_threads();
+    std::atomic<int> unsorted{ 0 };
+    parallel_slices(W.size(), nt, [&](size_t k0, size_t k1, unsigned) {
+        for (size_t k = std::max<size_t>(k0, 1); k < k1; ++k)
+            if (!(W[k - 1].i < W[k].i || (W[k - 1].i == W[k].i && W[k - 1].j < W[k].j))) { unsorted.store(1, std::memory_order_relaxed); break; }
+    });
+    if (!unsorted.load()) {
         std::vector<int> row((size_t)n + 1, 0);
         for (const l3d_edge& e : W) ++row[(size_t)e.i + 1];
         for (int r = 0; r < n; ++r) row[(size_t)r + 1] += row[(size_t)r];
-        std::vector<float> wmin(W.size());
+        out.resize(W.size());
         std::atomic<int> missing{ 0 };
-        parallel_slices(W.size(), finish_threads(), [&](size_t k0, size_t k1, unsigned) {
+        parallel_slices(W.size(), nt, [&](size_t k0, size_t k1, unsigned) {
             for (size_t k = k0; k < k1; ++k) {
                 const l3d_edge& e = W[k];
                 const l3d_edge* lo = W.data() + row[(size_t)e.j];
                 const l3d_edge* hi = W.data() + row[(size_t)e.j + 1];
                 const l3d_edge* t = std::lower_bound(lo, hi, e.i, [](const l3d_edge& x, int col) { return x.j < col; });
-                if (t == hi || t->j != e.i) { missing.fetch_add(1, std::memory_order_relaxed); continue; }
-                wmin[k] = e.i <= e.j ? fminf(t->w, e.w) : fminf(e.w, t->w);     // the visit of the later entry decides
+                if (t == hi || t->j != e.i) { missing.fetch_add(1, std::memory_order_relaxed); break; }
+                out[k] = { e.i, e.j, e.i <= e.j ? fminf(t->w, e.w) : fminf(e.w, t->w) };     // the visit of the later entry decides
             }
         });
         if (missing.load() == 0) {
-            A.swap(W);
-            for (size_t k = 0; k < A.size(); ++k) A[k].w = wmin[k];
             if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d rdd] %-24s %8.2f ms\n", "symmetrise", (now_s() - t_sym) * 1e3);
             return L3D_OK;
         }
@@ -1263,8 +1282,8 @@ int perform_diffusion(L* h, std::vector<l3d_edge>& A, int n)
         entries[{ e.i, e.j }] = w;
         entries[{ e.j, e.i }] = w;
     }
-    A.clear();
-    for (auto& kv : entries) A.push_back({ kv.first.first, kv.first.second, kv.second });
+    out.clear();
+    for (auto& kv : entries) out.push_back({ kv.first.first, kv.first.second, kv.second });
     return L3D_OK;
 }
 
@@ -1375,15 +1394,20 @@ int cluster_segments_2D(L* h, bool perform_diff)
     // segments of a view in parallel chunks; the chunks' item lists are concatenated in order afterwards.
     struct Item { int a, b; int kind; float cw; };
     constexpr size_t kChunk = 32;
-    struct Chunk { size_t begin, end; std::vector<Item> items; };
+    struct Chunk { size_t begin, end; std::vector<Item> items; std::vector<uint32_t> met; };   // met: the sources' sorted lists, back to back
     std::vector<Chunk> chunks;
     std::vector<size_t> view_chunk_begin(nv + 1, 0);
     for (size_t vi = 0; vi < nv; ++vi) {
         view_chunk_begin[vi] = chunks.size();
-        for (size_t bgn = hyp_begin[vi]; bgn < hyp_begin[vi + 1]; bgn += kChunk) chunks.push_back({ bgn, std::min(hyp_begin[vi + 1], bgn + kChunk), {} });
+        for (size_t bgn = hyp_begin[vi]; bgn < hyp_begin[vi + 1]; bgn += kChunk) chunks.push_back({ bgn, std::min(hyp_begin[vi + 1], bgn + kChunk), {}, {} });
     }
     view_chunk_begin[nv] = chunks.size();
-    std::vector<std::vector<uint32_t>> enc(nh);       // per processed src (hyp index): sorted dense ids met
+    // per processed src (hyp index): sorted dense ids met = chunks[enc_chunk].met[enc_off .. enc_off + enc_len)
+    std::unique_ptr<uint32_t[]> enc_chunk(new uint32_t[nh]), enc_off(new uint32_t[nh]), enc_len(new uint32_t[nh]);
+    auto met_has = [&](size_t xb, uint32_t d) {
+        const uint32_t* p = chunks[enc_chunk[xb]].met.data() + enc_off[xb];
+        return std::binary_search(p, p + enc_len[xb], d);
+    };
     const unsigned nt = finish_threads();
     {
         SpinBarrier bar(nt);
@@ -1419,7 +1443,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             auto used = [&](uint32_t xs) -> bool {
                                 if (stamp[voff[(size_t)tvi] + xs] == st) return true;
                                 const int xb = tbi[xs];
-                                return xb >= 0 && (size_t)xb < si && std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), dsrc);
+                                return xb >= 0 && (size_t)xb < si && met_has((size_t)xb, dsrc);
                             };
                             auto mark = [&](uint32_t xs) { const uint32_t d = (uint32_t)(voff[(size_t)tvi] + xs); stamp[d] = st; met.push_back(d); };
                             if (used(tseg)) continue;
@@ -1442,7 +1466,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             if (!u) {
                                 const int xb = sbi[xs];
                                 if (xb >= 0 && (size_t)xb < si) {
-                                    if (nt == 1) u = std::binary_search(enc[(size_t)xb].begin(), enc[(size_t)xb].end(), dsrc);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
+                                    if (nt == 1) u = met_has((size_t)xb, dsrc);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
                                     else for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
                                 }
                             }
@@ -1452,7 +1476,8 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             if (tb >= 0) ch.items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
                         }
                         std::sort(met.begin(), met.end());
-                        enc[si] = met;
+                        enc_chunk[si] = (uint32_t)ci; enc_off[si] = (uint32_t)ch.met.size(); enc_len[si] = (uint32_t)met.size();
+                        ch.met.insert(ch.met.end(), met.begin(), met.end());
                     }
                 }
                 bar.wait();
@@ -1498,8 +1523,11 @@ int cluster_segments_2D(L* h, bool perform_diff)
     if (rc) return h->fail(rc, std::string("similarity: ") + l3d_last_error(h->ctx));
     lap("similarity (GPU call)");
 
-    // thresholds (parallel) + first-touch node numbering in enumeration order (sequential, over the edges only)
-    parallel_slices(n_items, nt, [&](size_t k0, size_t k1, unsigned) {
+    // thresholds (parallel), first-touch node numbering in enumeration order (sequential, integers only), edge list (parallel)
+    std::vector<size_t> slice_edges((size_t)nt + 1, 0);
+    const unsigned nts = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n_items));
+    parallel_slices(n_items, nts, [&](size_t k0, size_t k1, unsigned t) {
+        size_t cnt = 0;
         for (size_t k = k0; k < k1; ++k) {
             const Item& it = items[k];
             const float s1 = h->hyps[(size_t)it.a].score, s2 = h->hyps[(size_t)it.b].score;
@@ -1508,22 +1536,29 @@ int cluster_segments_2D(L* h, bool perform_diff)
             else w = 0.5f * (s1 + s2) * sim[k];                                     // :1014,:1085
             const float thr = it.kind == 0 ? 0.25f : 0.01f;                         // L3D_MIN_AFFINITY / 0.01f
             wgt[k] = w > thr ? w : -1.0f;
+            cnt += w > thr;
         }
+        slice_edges[(size_t)t + 1] = cnt;
     });
+    for (unsigned t = 0; t < nts; ++t) slice_edges[(size_t)t + 1] += slice_edges[t];
     std::vector<int> node(nh, -1);
-    h->A.reserve(2 * n_items);
     h->local2global.reserve(nh);
-    auto node_of = [&](int hidx) {
-        if (node[(size_t)hidx] < 0) { node[(size_t)hidx] = (int)h->local2global.size(); h->local2global.push_back(h->hyps[(size_t)hidx].src); }
-        return node[(size_t)hidx];
-    };
     for (size_t k = 0; k < n_items; ++k) {
         if (!(wgt[k] > 0.0f)) continue;
-        const int a = node_of(items[k].a);
-        const int b = node_of(items[k].b);
-        h->A.push_back({ a, b, wgt[k] });
-        h->A.push_back({ b, a, wgt[k] });
+        for (const int hidx : { items[k].a, items[k].b })
+            if (node[(size_t)hidx] < 0) { node[(size_t)hidx] = (int)h->local2global.size(); h->local2global.push_back(h->hyps[(size_t)hidx].src); }
     }
+    h->A.resize(2 * slice_edges[nts]);
+    parallel_slices(n_items, nts, [&](size_t k0, size_t k1, unsigned t) {
+        size_t r = slice_edges[t];
+        for (size_t k = k0; k < k1; ++k) {
+            if (!(wgt[k] > 0.0f)) continue;
+            const int a = node[(size_t)items[k].a], b = node[(size_t)items[k].b];
+            h->A[2 * r] = { a, b, wgt[k] };
+            h->A[2 * r + 1] = { b, a, wgt[k] };
+            ++r;
+        }
+    });
     if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %zu candidate pairs, %zu edges, %u threads\n", nh, n_items, h->A.size(), nt);
     lap("thresholds / numbering");
     h->t_affinity = now_s() - t0;
@@ -1531,12 +1566,11 @@ int cluster_segments_2D(L* h, bool perform_diff)
 
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
-    std::vector<l3d_edge> diffused;
-    if (perform_diff) { diffused = h->A; rc = perform_diffusion(h, diffused, n_nodes); if (rc) return rc; }
-    const std::vector<l3d_edge>& edges = perform_diff ? diffused : h->A;
+    EdgeVec diffused;
+    if (perform_diff) { rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
+    const EdgeVec& edges = perform_diff ? diffused : h->A;
     std::vector<int> labels;
-    lap(perform_diff ? "copy + diffusion" : "-");
-    perform_clustering(edges, n_nodes, 1.0f, labels);                           // :1245
+    perform_clustering(edges.data(), edges.size(), n_nodes, 1.0f, labels);      // :1245
     lap("clustering");
 
     // processClusteredSegments, line3D.cc:1306-1368: clusters in ascending label order (the reference's std::map), their
@@ -1694,7 +1728,9 @@ int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
     const double t0 = now_s();
     greedy_selection(h);                                   // optimizeLocalMatches, :888-896
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
-    return cluster_segments_2D(h, perform_diffusion != 0);
+    const int rc = cluster_segments_2D(h, perform_diffusion != 0);
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "total", (now_s() - t0) * 1e3);
+    return rc;
 }
 // Line3D::compute3Dmodel, line3D.cc:345-374
 int l3d_line3d_compute3Dmodel(l3d_line3d* h, int perform_diffusion)
@@ -1845,9 +1881,8 @@ int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, fl
     if (n_edges < 0 || num_nodes < 0 || (n_edges > 0 && !edges) || (num_nodes > 0 && !labels)) return L3D_ERR_INVALID;
     for (int k = 0; k < n_edges; ++k)
         if (edges[k].i < 0 || edges[k].i >= num_nodes || edges[k].j < 0 || edges[k].j >= num_nodes) return L3D_ERR_INVALID;
-    std::vector<l3d_edge> e(edges, edges + n_edges);
     std::vector<int> lab;
-    perform_clustering(e, num_nodes, c, lab);
+    perform_clustering(edges, (size_t)n_edges, num_nodes, c, lab);
     for (int k = 0; k < num_nodes; ++k) labels[k] = lab[(size_t)k];
     return L3D_OK;
 }

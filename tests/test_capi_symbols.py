@@ -84,10 +84,13 @@ def test_host_clustering_large_lists_with_ties(oracle_lib):
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libclustering_ref.so")
     ref = C.CDLL(ref_path) if os.path.exists(ref_path) else None
     rng = np.random.default_rng(7)
-    for n, E, q in ((3000, 40000, 2), (20000, 300000, 3), (50, 70000, 1)):
+    for n, E, q in ((3000, 40000, 2), (20000, 300000, 3), (50, 70000, 1), (20000, 250000, -1)):
         e = np.zeros(E, dtype=capi.EDGE_DTYPE)
         e["i"], e["j"] = rng.integers(0, n, E), rng.integers(0, n, E)
-        e["w"] = np.where(rng.random(E) < 0.3, 1.0, np.round(rng.random(E), q)).astype(np.float32)
+        if q < 0:     # skewed: most weights inside one bucket of the major key, with repeats
+            e["w"] = (0.997 + np.round(rng.random(E) * 0.002, 5)).astype(np.float32)
+        else:
+            e["w"] = np.where(rng.random(E) < 0.3, 1.0, np.round(rng.random(E), q)).astype(np.float32)
         labels = np.zeros(n, np.int32)
         rc = lib.l3d_perform_clustering(e.ctypes.data_as(C.c_void_p), C.c_int(E), C.c_int(n), C.c_float(1.0), labels.ctypes.data_as(C.c_void_p))
         assert rc == 0
