@@ -72,34 +72,40 @@ __global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotG
     }
 }
 
-// prefix sums of the kept counts of this rank's segment range and, in the same launch, the header of its slot
-// (count, #candidates, overflow).  kept_cnt / kept_start point at the range's first segment.
-__global__ __launch_bounds__(kTileThreads) void k_scan_kept_slot(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int n_seg,
-                                                                 const int* __restrict__ row_start, int nrow, int cand_cap, int slot_records,
-                                                                 int s0, int s1, unsigned char* __restrict__ slot)
+// Kept records of this rank's source-segment range [s0,s1) into its slot, in ONE launch behind the verification (every
+// launch of the sharded chain sits on the per-view critical path): each workgroup (4 segments, one per wave) sums the kept
+// counts in front of its segments itself -- a few hundred to 2000 ints out of L2 -- instead of waiting for a scan launch;
+// workgroup 0 also writes the slot header (count, #candidates, overflow).  kept_cnt points at the range's first segment.
+__global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, int slot_records,
+                                                    const unsigned* __restrict__ local2global, const float2* __restrict__ best, SlotGeom g,
+                                                    unsigned char* __restrict__ slot)
 {
-    __shared__ int s_w[4];
-    const int total = wg_scan_excl<kTileThreads>(kept_cnt, kept_start, n_seg, nullptr, s_w);
-    if (threadIdx.x != 0) return;
+    __shared__ int s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = a.seg_end - a.seg_begin;
+    const int first = blockIdx.x * 4;
+    int before = 0, total = 0;
+    for (int i = tid; i < nseg; i += 256) { const int v = kept_cnt[i]; total += v; if (i < first) before += v; }
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); total += __shfl_down(total, o); }
+    if (lane == 0) { s_red[wave] = before; s_red[4 + wave] = total; }
+    __syncthreads();
+    before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    total = s_red[4] + s_red[5] + s_red[6] + s_red[7];
     SlotHeader h;
-    h.R = row_start[nrow];
-    h.overflow = h.R > cand_cap ? 1 : 0;
+    h.R = a.row_start[nrow];
+    h.overflow = h.R > a.cand_cap ? 1 : 0;
     h.n_kept = h.overflow ? 0 : total;
     if (h.n_kept > slot_records) { h.overflow |= 2; h.n_kept = 0; }
-    h.s0 = s0; h.s1 = s1; h.pad[0] = h.pad[1] = h.pad[2] = 0;
-    *reinterpret_cast<SlotHeader*>(slot) = h;
-}
-
-__global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __restrict__ kept_start, const unsigned* __restrict__ local2global,
-                                                    const float2* __restrict__ best, SlotGeom g, unsigned char* __restrict__ slot)
-{
-    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (y >= a.seg_end) return;
-    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
-    if (lane == 0) reinterpret_cast<float2*>(slot + g.best_off)[y - a.seg_begin] = best[y];
-    if (hd->overflow) return;
-    write_kept_segment(a, y, lane, kept_start[y], local2global, reinterpret_cast<Match*>(slot + g.rec_off));
+    h.s0 = a.seg_begin; h.s1 = a.seg_end; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<SlotHeader*>(slot) = h;
+    const int yl = first + wave;
+    if (yl >= nseg) return;
+    const int y = a.seg_begin + yl;
+    if (lane == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
+    if (h.overflow) return;
+    int o = before;
+    for (int q = 0; q < wave; ++q) o += kept_cnt[first + q];
+    write_kept_segment(a, y, lane, o, local2global, reinterpret_cast<Match*>(slot + g.rec_off));
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -457,14 +463,9 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         }
     }
     {
-        ProfScope p(c, "scan");
-        hipLaunchKernelGGL(k_scan_kept_slot, dim3(1), dim3(kTileThreads), 0, st, c->kept_cnt.as<int>() + d.s0, c->kept_start.as<int>() + d.s0, d.s1 - d.s0,
-                           c->row_start.as<int>(), (int)nrow, (int)h->cand_cap, h->geom.slot_records, d.s0, d.s1, slot);
-    }
-    if (d.s1 > d.s0) {
         ProfScope p(c, "kept_write");
-        hipLaunchKernelGGL(k_slot_write, dim3((d.s1 - d.s0 + 3) / 4), dim3(256), 0, st, va, c->kept_start.as<int>(),
-                           reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
+        hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, (d.s1 - d.s0 + 3) / 4)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
+                           h->geom.slot_records, reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("shard enqueue view ") + std::to_string(k) + " (mmax " + std::to_string(mmax) + ", lds " + std::to_string(verify_window_lds_bytes(mmax, N)) + ", range " + std::to_string(d.s0) + "-" + std::to_string(d.s1) + "): " + hipGetErrorString(e_)); }
     return L3D_OK;
