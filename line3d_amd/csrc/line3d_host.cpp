@@ -784,10 +784,12 @@ int chain_callback(void* user, int index, int verified, const l3d_match* kept, i
 //               two sorted runs, de-duplicate; the part that finishes last concatenates the ranges.
 struct ChainFinalizer {
     L* h;
-    std::vector<int> own_index;                     // per view index: its position in the processing order or -1
+    // static tables of the schedule (owned by the cached ChainPlan):
+    const std::vector<int>* own_index_ = nullptr;   // per view index: its position in the processing order or -1
+    const std::vector<std::vector<std::pair<uint32_t, size_t>>>* targets_ = nullptr;   // per order index: (camera id, view index) receiving reverse entries, ascending id
+    const std::vector<std::vector<int>>* contributors_ = nullptr;     // per view index: order indices of the views that list it as neighbour
     std::vector<char> own_sorted;                   // per view index: its own forward entries ascend by segment
-    std::vector<std::vector<std::pair<uint32_t, size_t>>> targets;   // per order index: (camera id, view index) receiving reverse entries, ascending id
-    std::vector<std::vector<int>> contributors;     // per view index: order indices of the views that list it as neighbour
+    std::vector<std::atomic<int>> split_left;       // per order index: halves of the split still running (reverse entries / own entries)
     std::vector<std::vector<std::pair<size_t, std::array<std::vector<std::pair<uint32_t, Key>>, 4>>>>* buckets = nullptr;   // per order index: (target view index, entries); storage owned by the pipeline object
     std::vector<std::atomic<int>> pending;          // per view index: splits still missing
     static constexpr int kParts = 4;                // a view's merge runs as kParts independent segment ranges
@@ -795,7 +797,7 @@ struct ChainFinalizer {
     std::vector<std::array<std::vector<std::pair<uint32_t, Key>>, 4>>* parts = nullptr;   // storage owned by the pipeline object
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::pair<int, size_t>> queue;      // (0 = split, order index) or (2 = merge part, view index * kParts + part)
+    std::vector<std::pair<int, size_t>> queue;      // (0 / 1 = the two halves of a split, order index) or (2 = merge part, view index * kParts + part)
     bool done = false;
     std::vector<std::thread> workers;
     bool timing = getenv("L3D_TIMING") != nullptr;
@@ -815,11 +817,13 @@ struct ChainFinalizer {
         for (auto& t : workers) t.join();
     }
     // the worker threads live as long as the pipeline object; a pass only re-arms the counters (threads are idle here)
-    void begin_pass(size_t nviews)
+    void begin_pass(size_t nviews, size_t norder, const std::vector<int>& pending0)
     {
         if (pending.size() != nviews) { pending = std::vector<std::atomic<int>>(nviews); parts_left = std::vector<std::atomic<int>>(nviews); }
-        for (auto& p : pending) p = 0;
+        if (split_left.size() != norder) split_left = std::vector<std::atomic<int>>(norder);
+        for (size_t i = 0; i < nviews; ++i) pending[i] = pending0[i];
         for (auto& p : parts_left) p = 0;
+        for (auto& p : split_left) p = 2;
         t_split = t_merge = 0; n_split = n_merge = 0; log.clear();
     }
     void push_merge(size_t vi) { parts_left[vi] = kParts; for (int r = 0; r < kParts; ++r) push(2, vi * kParts + (size_t)r); }
@@ -829,7 +833,10 @@ struct ChainFinalizer {
         { std::lock_guard<std::mutex> lk(mu); queue.emplace_back(kind, id); }
         cv.notify_one();
     }
-    void split(size_t k)
+    // A finished view's kept list is split in two independent halves (two jobs, so that the LAST view's split -- the tail of
+    // matchViews -- takes half as long): (0) the reverse entries, pre-sorted per target view and merge range; (1) its own
+    // forward entries and the only-best store.  Whoever finishes second releases the merges that waited for this view.
+    void split_reverse(size_t k)
     {
         const View& v = h->views[h->order[k]];
         const KeptList& lst = h->saved[k];
@@ -837,7 +844,7 @@ struct ChainFinalizer {
         // cameras whose views receive the reverse entry of a kept match: the neighbours -- or, for an early-return view
         // (cudawrapper.cu:877-878: LOCAL camera ids come back), whatever views those numbers happen to name
         // (line3D.cc:861-865); ascending camera id, slot = position
-        const std::vector<std::pair<uint32_t, size_t>>& tg = targets[k];
+        const std::vector<std::pair<uint32_t, size_t>>& tg = (*targets_)[k];
         if (bk.size() != tg.size()) bk.assign(tg.size(), {});        // (otherwise keep the entry vectors' capacity)
         std::vector<uint32_t> S_of(tg.size(), 1);       // segment count of each target: entries are pre-sorted into its merge ranges
         for (size_t i = 0; i < tg.size(); ++i) { bk[i].first = tg[i].second; for (auto& q : bk[i].second) q.clear(); S_of[i] = (uint32_t)std::max(1, h->vlist[tg[i].second]->S()); }
@@ -853,6 +860,12 @@ struct ChainFinalizer {
                 bk[sl].second[part].emplace_back(m.segID2, mk(v.id, m.segID1));
             }
         }
+        split_done(k);
+    }
+    void split_own(size_t k)
+    {
+        const View& v = h->views[h->order[k]];
+        const KeptList& lst = h->saved[k];
         // own forward entries (already grouped by segment) and the only-best store do not depend on other lists
         std::vector<std::pair<uint32_t, Key>>& p = h->pot[(size_t)v.index];
         p.clear();
@@ -861,7 +874,13 @@ struct ChainFinalizer {
         for (const l3d_match& m : lst) { if (!p.empty() && m.segID1 < p.back().first) sorted = false; p.emplace_back(m.segID1, mk(m.camID2, m.segID2)); }
         own_sorted[(size_t)v.index] = sorted ? 1 : 0;
         add_matches(h->views[h->order[k]], lst.data(), lst.size(), true, true);
-        for (auto& e : bk) if (--pending[e.first] == 0) push_merge(e.first);
+        split_done(k);
+    }
+    void split_done(size_t k)
+    {
+        if (--split_left[k] != 0) return;
+        const View& v = h->views[h->order[k]];
+        for (auto& e : (*buckets)[k]) if (--pending[e.first] == 0) push_merge(e.first);
         if (--pending[(size_t)v.index] == 0) push_merge((size_t)v.index);
     }
     // one segment range of a view's merge: gather (own forward entries are grouped by segment, the contributions are
@@ -875,6 +894,7 @@ struct ChainFinalizer {
         std::vector<std::pair<uint32_t, Key>>& p = h->pot[vi];
         std::vector<std::pair<uint32_t, Key>>& out = (*parts)[vi][(size_t)r];
         out.clear();
+        const std::vector<int>& own_index = *own_index_;
         if (own_index[vi] >= 0 && own_sorted[vi]) {     // split(own) has put the forward entries there, ascending segment
             auto first = [](const std::pair<uint32_t, Key>& e, uint32_t x) { return e.first < x; };
             auto b = std::lower_bound(p.begin(), p.end(), lo, first);
@@ -883,7 +903,7 @@ struct ChainFinalizer {
         } else if (own_index[vi] >= 0) {
             for (auto& x : p) if (x.first >= lo && x.first < hi) out.push_back(x);
         }
-        for (int k : contributors[vi])
+        for (int k : (*contributors_)[vi])
             for (auto& e : (*buckets)[(size_t)k])
                 if (e.first == vi) out.insert(out.end(), e.second[(size_t)r].begin(), e.second[(size_t)r].end());
         finalize_pot_range(out, lo, hi == 0xffffffffu ? std::max(S, lo) : hi);
@@ -907,18 +927,22 @@ struct ChainFinalizer {
                         ++active;
                     }
                     const double tj0 = now_s();
-                    if (job.first == 0) split(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
+                    if (job.first == 0) split_reverse(job.second); else if (job.first == 1) split_own(job.second); else merge_part(job.second / kParts, (int)(job.second % kParts));
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         --active;
-                        if (timing) { const double dt = now_s() - tj0; (job.first == 0 ? t_split : t_merge) += dt; (job.first == 0 ? n_split : n_merge) += 1; t_last_done = now_s();
+                        if (timing) { const double dt = now_s() - tj0; (job.first < 2 ? t_split : t_merge) += dt; (job.first < 2 ? n_split : n_merge) += 1; t_last_done = now_s();
                                       if (trace) log.push_back({ job.first, (int)job.second, tj0, t_last_done }); }
                     }
                     cv_idle.notify_all();
                 }
             });
     }
-    void notify(int k) { push(0, (size_t)k); }
+    void notify(int k)
+    {
+        { std::lock_guard<std::mutex> lk(mu); queue.emplace_back(0, (size_t)k); queue.emplace_back(1, (size_t)k); }
+        cv.notify_all();
+    }
     void finish(bool drain)
     {
         // wait until every job has run (splits spawn merges while they run, so "no job queued or running" is final); without
@@ -931,7 +955,7 @@ struct ChainFinalizer {
         }
         if (trace) for (size_t i = log.size() > 48 ? log.size() - 48 : 0; i < log.size(); ++i)
             fprintf(stderr, "[l3d finaliser job] kind %d id %d: start %+.3f end %+.3f ms (relative to the drain start)\n", log[i].kind, log[i].id, (log[i].t0 - td0) * 1e3, (log[i].t1 - td0) * 1e3);
-        if (timing) fprintf(stderr, "[l3d finaliser] drain %.2f ms; %d splits %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", (now_s() - td0) * 1e3, n_split, t_split * 1e3,
+        if (timing) fprintf(stderr, "[l3d finaliser] drain %.2f ms; %d split halves %.2f ms (avg %.3f), %d merges %.2f ms (avg %.3f)\n", (now_s() - td0) * 1e3, n_split, t_split * 1e3,
                             n_split ? t_split * 1e3 / n_split : 0.0, n_merge, t_merge * 1e3, n_merge ? t_merge * 1e3 / n_merge : 0.0);
     }
 };
@@ -948,6 +972,11 @@ struct ChainPlan {
     std::vector<l3d_chain_view> cv;
     std::vector<int> n_tbm;
     ChainFinalizer* fin = nullptr;                  // the pipeline object's persistent finaliser
+    // static tables of the finaliser (ChainFinalizer)
+    bool fin_tables = false;
+    std::vector<int> own_index, pending0;
+    std::vector<std::vector<std::pair<uint32_t, size_t>>> targets;
+    std::vector<std::vector<int>> contributors;
     ChainUser user;
     l3d_shard_chain* shard = nullptr;
     double t0 = 0;
@@ -1024,30 +1053,34 @@ void start_finalizer(L* h, ChainPlan& P)
     P.fin = static_cast<ChainFinalizer*>(h->finalizer);
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
-    fin.begin_pass(nvl);
-    fin.own_index.assign(nvl, -1); fin.own_sorted.assign(nvl, 1); fin.contributors.assign(nvl, {});
+    if (!P.fin_tables) {                                // who sends reverse entries to whom: part of the (static) schedule
+        P.own_index.assign(nvl, -1); P.pending0.assign(nvl, 0); P.contributors.assign(nvl, {}); P.targets.assign(n, {});
+        for (size_t k = 0; k < n; ++k) {
+            const View& v = h->views[h->order[k]];
+            P.own_index[(size_t)v.index] = (int)k;
+            P.pending0[(size_t)v.index] += 1;           // its own list
+            auto& tg = P.targets[k];
+            if (P.n_tbm[k] != 0) {
+                for (uint32_t nb : h->visual_neighbors[v.id]) { const View* o = h->find_view(nb); if (o) tg.emplace_back(nb, (size_t)o->index); }
+            } else {                                    // early return: local camera ids 0..N-1 read as view ids
+                const uint32_t N = (uint32_t)h->visual_neighbors[v.id].size();
+                for (uint32_t c = 0; c < N; ++c) { const View* o = h->find_view(c); if (o) tg.emplace_back(c, (size_t)o->index); }
+            }
+            std::sort(tg.begin(), tg.end());
+            for (auto& t : tg) {
+                P.contributors[t.second].push_back((int)k);
+                P.pending0[t.second] += 1;
+            }
+        }
+        P.fin_tables = true;
+    }
+    fin.own_index_ = &P.own_index; fin.targets_ = &P.targets; fin.contributors_ = &P.contributors;
+    fin.begin_pass(nvl, n, P.pending0);
+    fin.own_sorted.assign(nvl, 1);
     fin.buckets = &h->fin_buckets;                      // (capacities survive from an earlier pass)
     fin.parts = &h->fin_parts;
     if (h->fin_parts.size() != nvl) h->fin_parts.assign(nvl, {});
     if (h->fin_buckets.size() != n) h->fin_buckets.assign(n, {});
-    fin.targets.assign(n, {});
-    for (size_t k = 0; k < n; ++k) {
-        const View& v = h->views[h->order[k]];
-        fin.own_index[(size_t)v.index] = (int)k;
-        fin.pending[(size_t)v.index] += 1;              // its own list
-        auto& tg = fin.targets[k];
-        if (P.n_tbm[k] != 0) {
-            for (uint32_t nb : h->visual_neighbors[v.id]) { const View* o = h->find_view(nb); if (o) tg.emplace_back(nb, (size_t)o->index); }
-        } else {                                        // early return: local camera ids 0..N-1 read as view ids
-            const uint32_t N = (uint32_t)h->visual_neighbors[v.id].size();
-            for (uint32_t c = 0; c < N; ++c) { const View* o = h->find_view(c); if (o) tg.emplace_back(c, (size_t)o->index); }
-        }
-        std::sort(tg.begin(), tg.end());
-        for (auto& t : tg) {
-            fin.contributors[t.second].push_back((int)k);
-            fin.pending[t.second] += 1;
-        }
-    }
     fin.start(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)));    // (one process per GPU shares the host)
     P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin };
 }
