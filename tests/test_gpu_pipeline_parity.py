@@ -435,3 +435,26 @@ def test_chain_overflow_restart_with_more_views_than_ring_slots():
         assert n > 5000
         l.close()
     assert len(set(digests)) == 1, digests
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404])
+def test_random_small_scenes_full_parity(seed):
+    """Randomised end-to-end parity: number of views, segments per view (ragged), neighbours, noise, first image id,
+    collinearity and diffusion drawn per seed; kept lists and affinity list bit-exact, lines within 1e-4."""
+    from line3d_amd.synth import make_scene
+    rng = np.random.default_rng(seed)
+    V, S, N = int(rng.integers(7, 13)), int(rng.integers(120, 260)), int(2 * rng.integers(2, 5))
+    sc = make_scene(V, S, N, seed=seed, noise_px=float(rng.choice([0.3, 0.5, 1.5])), first_id=int(rng.choice([0, 3, 50])))
+    for v in sc.views:                                   # ragged: every view keeps a random prefix of its segments
+        keep = int(rng.integers(S // 2, S + 1))
+        v["segments"] = np.ascontiguousarray(v["segments"][:keep])
+        v["gt"] = v["gt"][:keep]
+    collin, diffusion = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    o = op.run_scene(sc, N, use_collinearity=collin, perform_diffusion=diffusion)
+    l = _run_gpu(sc, N, diffusion=diffusion, collin=collin)
+    for v in sorted(o.trace):
+        got, med = l.view_matches(v)
+        assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
+        assert np.float32(med) == np.float32(o.trace[v]["median"])
+    assert_lines_equal(l.getResult(), o.result, 1e-4)
+    l.close()

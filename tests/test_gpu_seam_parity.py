@@ -114,6 +114,15 @@ def test_rdd_matches_oracle(gpu_ctx, oracle_lib, small_oracle):
     rows = set(e["i"].tolist())
     e = np.concatenate([e, np.array([(k, k, 0.5) for k in range(30) if k not in rows], dtype=op.EDGE_DTYPE)])
     assert gpu_ctx.replicator_dynamics_diffusion(e, 30, 3).tobytes() == op.rdd(oracle_lib, e, 30, 3).tobytes()
+    # a large unsymmetric list in random order: the host builds the column- and row-sorted matrices with a multi-threaded
+    # ordering (sparsematrix.cc:81-86,157-167).  Keys are unique: with duplicate (i,j) entries the reference's diffusion
+    # kernel has two threads writing the same slot (cudawrapper.cu:809-826), i.e. no defined result to compare with.
+    n, E = 3000, 60000
+    key = rng.choice(n * n, size=E, replace=False)
+    e = np.zeros(E, dtype=op.EDGE_DTYPE)
+    e["i"], e["j"] = key // n, key % n
+    e["w"] = rng.random(E).astype(np.float32)
+    assert gpu_ctx.replicator_dynamics_diffusion(e, n, 4).tobytes() == op.rdd(oracle_lib, e, n, 4).tobytes()
 
 
 def test_similarity_batch_matches_oracle(gpu_ctx, small_oracle):
