@@ -1248,13 +1248,18 @@ void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, 
         l3d::parallel_stable_order(n_edges, (size_t)65536, (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
                                    [e](size_t i) { return l3d::float_order_key(e[i].w) & 0xffffu; }, finish_threads(), order);
     }
+    // the edges in that order, gathered by the worker threads (the merge loop below then reads them sequentially)
+    std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[n_edges + 1]);
+    parallel_slices(n_edges, finish_threads(), [&](size_t k0, size_t k1, unsigned) { for (size_t k = k0; k < k1; ++k) sorted[k] = edges_in[order[k]]; });
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
     std::vector<int> rank((size_t)numNodes, 0), cid((size_t)numNodes), size((size_t)numNodes, 1);
     std::vector<float> thr((size_t)numNodes, c);
     for (int i = 0; i < numNodes; ++i) cid[i] = i;
-    auto find = [&](int node) { int y = node; while (y != cid[y]) y = cid[y]; cid[node] = y; return y; };
-    for (const uint32_t ei : order) {
-        const l3d_edge& ed = edges_in[ei];
+    // universe.h:81-89 compresses only the queried node's link; halving every link on the way finds the same root (unions
+    // go by rank, which no compression touches) with shorter chains afterwards
+    auto find = [&](int node) { int y = node; while (y != cid[y]) { cid[y] = cid[cid[y]]; y = cid[y]; } return y; };
+    for (size_t q = 0; q < n_edges; ++q) {
+        const l3d_edge& ed = sorted[q];
         int a = find(ed.i), b = find(ed.j);
         if (a != b && ed.w <= thr[a] && ed.w <= thr[b]) {
             if (rank[a] > rank[b]) { cid[b] = a; size[a] += size[b]; }
