@@ -68,15 +68,15 @@ __global__ void k_exist_scatter(const Match* __restrict__ arena, const ChainResu
 // The scatter order inside a (segment, camera) run is arbitrary.  One wave per run restores the (segment, camera,
 // target) order of the reference's list sort: every lane holds up to four entries in registers, ranks them by
 // counting (keys are broadcast with shuffles, target ids inside a run are distinct) and writes them to their place.
-__global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S,
+__global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S, int seg_begin, int seg_end,
                                                          const int* __restrict__ row_start, uint2* __restrict__ meta,
                                                          float4* __restrict__ depths, int cap)
 {
     if (row_start[(size_t)S * N] > cap) return;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (t >= S * n_cams) return;
-    const int seg = t / n_cams, cam = cams[t % n_cams];
+    if (t >= (seg_end - seg_begin) * n_cams) return;
+    const int seg = seg_begin + t / n_cams, cam = cams[t % n_cams];
     const int b = row_start[seg * N + cam], n = row_start[seg * N + cam + 1] - b;
     if (n < 2) return;
     if (n > 256) {                                  // pathological run: one lane, in place
@@ -194,10 +194,12 @@ void launch_exist_scatter(const Match* arena, const ChainResult* res, const int*
 {
     if (n_src > 0) hipLaunchKernelGGL(k_exist_scatter, dim3(32, n_src), dim3(256), 0, st, arena, res, src_index, src_cam, view_id, N, S, row_start, cursor, meta, depths, cap);
 }
-void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st)
+void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
+                            int seg_begin, int seg_end)
 {
-    const int n = S * n_cams;
-    if (n > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((n + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, row_start, meta, depths, cap);
+    if (seg_end < 0) seg_end = S;
+    const int runs = (seg_end - seg_begin) * n_cams;
+    if (runs > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((runs + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, seg_begin, seg_end, row_start, meta, depths, cap);
 }
 void launch_cand_move(const int* tbm, int n_tbm, int N, int seg_begin, int seg_end, const int* rowA, const uint2* metaA, const float4* depthsA,
                       const int* row_start, int nrow_total, int cand_cap, uint2* meta, float4* depths, hipStream_t st)

@@ -422,7 +422,8 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         ProfScope p(c, "exist");
         hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
     }
-    { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, d.s0, d.s1); }   // + zeroed scatter cursors, segment order
+    // row starts of this rank's rows only (+ zeroed scatter cursors, segment order); row_start[nrow] = their total
+    { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
     {
         ProfScope p(c, "cand_move");
         launch_cand_move(pa.tbm, v.n_tbm, N, d.s0, d.s1, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
@@ -433,7 +434,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         ProfScope p(c, "exist");
         hipLaunchKernelGGL(k_exist_scatter_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1,
                            c->row_start.as<int>(), c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
-        launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st);
+        launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
     }
     VerifyArgs va;
     va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;

@@ -298,13 +298,14 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
 
 // Exclusive scan of n ints by ONE workgroup (l3d_scan.hpp); out has n+1 entries, `zero` (optional) gets n zeros.
 __global__ __launch_bounds__(kTileThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
-                                                       int* __restrict__ seg_order, int N, int seg_begin, int seg_end)
+                                                       int* __restrict__ seg_order, int N, int seg_begin, int seg_end,
+                                                       const int* __restrict__ rowcnt_all, int* __restrict__ total_out)
 {
     __shared__ int s_w[5];
     __shared__ int s_hist[130];
     const int n_tiles = max(1, (n + kTileInts - 1) / kTileInts);
-    if ((int)blockIdx.x < n_tiles) wg_scan_excl_tile(in, out, n, zero, blockIdx.x, s_w);     // one independent workgroup per tile
-    else if (seg_order) wg_segment_order(in, N, seg_begin, seg_end, seg_order, s_hist);        // rows -> segments, longest first
+    if ((int)blockIdx.x < n_tiles) wg_scan_excl_tile(in, out, n, zero, blockIdx.x, s_w, total_out);     // one independent workgroup per tile
+    else if (seg_order) wg_segment_order(rowcnt_all, N, seg_begin, seg_end, seg_order, s_hist);           // rows -> segments, longest first
 }
 
 // r-th (0-based) set bit of a 64-bit word
@@ -772,7 +773,16 @@ void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_
 void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order, int N, int seg_begin, int seg_end)
 {
     const int n_tiles = std::max(1, (n + kTileInts - 1) / kTileInts);
-    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end);
+    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end, in, nullptr);
+}
+// the rows of segments [seg_begin, seg_end) only (one rank's range of a view): out[row] for those rows, out[nrow_total] = their total
+void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st)
+{
+    const int n = (seg_end - seg_begin) * N;
+    const size_t o = (size_t)seg_begin * N;
+    const int n_tiles = std::max(1, (n + kTileInts - 1) / kTileInts);
+    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, rowcnt + o, row_start + o, n, zero ? zero + o : nullptr, seg_order, N,
+                       seg_begin, seg_end, rowcnt, row_start + nrow_total);
 }
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
 {

@@ -90,6 +90,7 @@ void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
 void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order = nullptr, int N = 0, int seg_begin = 0, int seg_end = 0);
+void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st);
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);
@@ -106,7 +107,8 @@ void launch_exist_count(const Match* arena, const ChainResult* res, const int* s
                         int N, int S, int* rowcnt, hipStream_t st);
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
-void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st);
+void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
+                            int seg_begin = 0, int seg_end = -1);
 void launch_cand_move(const int* tbm, int n_tbm, int N, int seg_begin, int seg_end, const int* rowA, const uint2* metaA, const float4* depthsA,
                       const int* row_start, int nrow_total, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);

@@ -71,7 +71,8 @@ __device__ __forceinline__ int wg_scan_excl(const int* __restrict__ in, int* __r
 // to wait until one CU has 16 free wave slots (measured 40 us for a 9 us kernel).  s_w: 5 ints of LDS.
 constexpr int kTileThreads = 256;
 constexpr int kTileInts = 4096;
-__device__ __forceinline__ void wg_scan_excl_tile(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero, int tile, int* s_w)
+__device__ __forceinline__ void wg_scan_excl_tile(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero, int tile, int* s_w,
+                                                  int* __restrict__ total_out = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // 4 waves
     const bool vec_in = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void wg_scan_excl_tile(const int* __restrict__ in, in
         }
         carry += sub;
     }
-    if (base + kTileInts >= n && tid == 0) out[n] = carry;     // the last tile also writes the total
+    if (base + kTileInts >= n && tid == 0) { out[n] = carry; if (total_out) *total_out = carry; }     // the last tile also writes the total
 }
 
 // Segments [seg_begin, seg_end) ordered by descending candidate count (64 bins of 32): the verification kernel takes its
