@@ -179,3 +179,45 @@ def test_full_size_finish_threads_do_not_change_results(chain_run, monkeypatch):
     for diffusion in (False, True):
         assert out[("1", diffusion)][0] > 100000 and out[("1", diffusion)][2] > 100
         assert out[("1", diffusion)] == out[("16", diffusion)] == out[("5", diffusion)], diffusion
+
+
+def test_near_maximum_segments_per_view():
+    """12 000 segments per view (the bit rows hold at most 16 384 targets per camera): the resident chain and the per-view
+    seam path agree byte for byte, and the first source segments of the first view equal the oracle."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    Vb, Sb, Nb = 6, 12000, 6
+    sc = make_scene(Vb, Sb, Nb, seed=77)
+    digests, first = [], None
+    for sync in (False, True):
+        l = Line3D("", matchingNeighbors=Nb, useCollinearity=False)
+        l.keep_view_matches(True)
+        l.set_sync_matching(sync)
+        load_scene(l, sc)
+        l.prepare()
+        l.match_views()
+        lists = {v["id"]: l.view_matches(v["id"]) for v in sc.views}
+        digests.append(_digest(lists))
+        if first is None:
+            first = lists[0][0].copy()
+        l.close()
+    assert digests[0] == digests[1]
+    assert len(first) > 10000
+    o = op.OracleLine3D(matching_neighbors=Nb, use_collinearity=False)
+    for v in sc.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    o.computation = True
+    o.matched, o.potential = {}, {}
+    o.find_visual_neighbors()
+    o.transform_geometry()
+    for n in o.visual_neighbors[0]:
+        o._fundamental(0, n)
+    mv = o.marshal_view(0)
+    assert len(mv["tbm"]) == len(mv["l2g"]) == 3
+    s1 = 40
+    exp, _med, _ = op.compute_pairwise_matches(
+        o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
+        mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"], 3.5, 10.0,
+        mv["spatial_k"], seg_range=(0, s1), want_stats=True)
+    got = first[first["segID1"] < s1]
+    assert len(exp) > 50 and got.tobytes() == exp.tobytes()
