@@ -103,6 +103,16 @@ def test_too_few_images_and_guards():
     with pytest.raises(L3DError):
         l.compute3Dmodel()                                   # < 4 images, line3D.cc:347-351
     l.close()
+    # more segments in a view than a bit row holds (16 384): refused loudly by both matching paths, nothing silently dropped
+    big = make_scene(5, 16500, 4, seed=3)
+    for sync in (False, True):
+        l = Line3D("", matchingNeighbors=4, useCollinearity=False)
+        l.set_sync_matching(sync)
+        for v in big.views:
+            assert l.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        with pytest.raises(L3DError, match="16384"):
+            l.compute3Dmodel()
+        l.close()
 
 
 def test_stepwise_sharded_matching_equals_whole(small_scene, small_oracle):
