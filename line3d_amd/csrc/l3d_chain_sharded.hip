@@ -25,6 +25,18 @@
 
 using namespace l3d;
 
+// Host-side waits of the enqueue threads: yield for a while, then sleep -- a thread that is far ahead (the stage-1 thread
+// almost always is) must not burn a core of a CPU-quota'd container shared by eight ranks.
+template <class Pred>
+static inline void wait_until(Pred pred, int spins_before_sleep)
+{
+    int spins = 0;
+    while (!pred()) {
+        if (++spins < spins_before_sleep) std::this_thread::yield();
+        else { static const int us = getenv("L3D_WAIT_SLEEP_US") ? atoi(getenv("L3D_WAIT_SLEEP_US")) : 20; if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us)); else std::this_thread::yield(); }
+    }
+}
+
 namespace l3d {
 
 struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
@@ -401,7 +413,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     if (!h->s1_thread)
         while (h->k_p1 < h->n_views && h->k_p1 <= k + l3d_shard_chain::kStage1Ahead) { int rc = shard_stage1(h, h->k_p1); if (rc) return rc; ++h->k_p1; }
     else
-        while (h->s1_done.load(std::memory_order_acquire) <= k) std::this_thread::yield();     // the stage-1 thread enqueues it
+        wait_until([&]() { return h->s1_done.load(std::memory_order_acquire) > k; }, 4000);     // the stage-1 thread enqueues it (normally long done)
     const l3d_chain_view& v = h->views[k];
     const SViewDev& d = h->vd[(size_t)k];
     h->gathered = reinterpret_cast<const unsigned char*>(gathered_base);
@@ -614,7 +626,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     stage1 = std::thread([&]() {
         (void)hipSetDevice(c->device);
         for (int k = 0; k < h->n_views && !s1_stop.load(); ++k) {
-            while (!s1_stop.load() && h->marked.load(std::memory_order_acquire) < k - l3d_shard_chain::kStage1Ahead) std::this_thread::yield();
+            wait_until([&]() { return s1_stop.load() || h->marked.load(std::memory_order_acquire) >= k - l3d_shard_chain::kStage1Ahead; }, 64);
             if (s1_stop.load()) break;
             const int r = shard_stage1(h, k);
             if (r) { s1_rc.store(r); break; }

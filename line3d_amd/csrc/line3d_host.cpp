@@ -1186,18 +1186,6 @@ void parallel_slices(size_t n, unsigned nt, F fn)
     for (auto& x : th) x.join();
 }
 
-struct SpinBarrier {                                 // short phases between barriers: spin, then yield
-    explicit SpinBarrier(unsigned n) : n_(n) {}
-    void wait()
-    {
-        const unsigned g = gen_.load(std::memory_order_acquire);
-        if (cnt_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) { cnt_.store(0, std::memory_order_relaxed); gen_.store(g + 1, std::memory_order_release); }
-        else { int spins = 0; while (gen_.load(std::memory_order_acquire) == g) if (++spins > 2000) std::this_thread::yield(); }
-    }
-    unsigned n_;
-    std::atomic<unsigned> cnt_{ 0 }, gen_{ 0 };
-};
-
 // Line3D::greedySelection, line3D.cc:899-965: the stored list holds one (best) match per segment
 void greedy_selection(L* h)
 {
@@ -1428,8 +1416,9 @@ int cluster_segments_2D(L* h, bool perform_diff)
     // the source (an earlier iteration).  The iterations of ONE view are independent of each other: a source only asks what
     // sources of EARLIER views met (potential correspondences and their collinear segments live in other views), except for
     // its own view's collinear segments (:1141-1214), where "x met src" is simply "src is in x's collinear list" (x's iteration
-    // walks that whole list and marks what it has not marked yet).  So: views in order, a barrier between views, the
-    // segments of a view in parallel chunks; the chunks' item lists are concatenated in order afterwards.
+    // walks that whole list and marks what it has not marked yet).  So the sources are handed out in order, in chunks of one
+    // view's segments, to the worker threads; a lookup into an earlier view's chunk waits for that chunk (the oldest unfinished
+    // chunk never waits, so there is always progress); the chunks' item lists are concatenated in order afterwards.
     struct Item { int a, b; int kind; float cw; };
     constexpr size_t kChunk = 32;
     struct Chunk { size_t begin, end; std::vector<Item> items; std::vector<uint32_t> met; };   // met: the sources' sorted lists, back to back
@@ -1442,25 +1431,33 @@ int cluster_segments_2D(L* h, bool perform_diff)
     view_chunk_begin[nv] = chunks.size();
     // per processed src (hyp index): sorted dense ids met = chunks[enc_chunk].met[enc_off .. enc_off + enc_len)
     std::unique_ptr<uint32_t[]> enc_chunk(new uint32_t[nh]), enc_off(new uint32_t[nh]), enc_len(new uint32_t[nh]);
-    auto met_has = [&](size_t xb, uint32_t d) {
-        const uint32_t* p = chunks[enc_chunk[xb]].met.data() + enc_off[xb];
+    std::vector<uint32_t> chunk_view(chunks.size());
+    for (size_t vi = 0; vi < nv; ++vi) for (size_t c = view_chunk_begin[vi]; c < view_chunk_begin[vi + 1]; ++c) chunk_view[c] = (uint32_t)vi;
+    for (size_t c = 0; c < chunks.size(); ++c) for (size_t si = chunks[c].begin; si < chunks[c].end; ++si) enc_chunk[si] = (uint32_t)c;   // (static)
+    std::vector<std::atomic<int>> chunk_done(chunks.size());
+    for (auto& f : chunk_done) f.store(0, std::memory_order_relaxed);
+    // was dense id d met while hypothesis xb was the source?  (cur: the caller's own chunk -- only a single thread ever asks
+    // about its own, still growing, chunk)
+    auto met_has = [&](size_t xb, uint32_t d, size_t cur) {
+        const size_t cx = enc_chunk[xb];
+        if (cx != cur) { int spins = 0; while (!chunk_done[cx].load(std::memory_order_acquire)) if (++spins > 200) std::this_thread::yield(); }
+        const uint32_t* p = chunks[cx].met.data() + enc_off[xb];
         return std::binary_search(p, p + enc_len[xb], d);
     };
     const unsigned nt = finish_threads();
     {
-        SpinBarrier bar(nt);
-        std::vector<std::atomic<size_t>> next(nv);
-        for (size_t vi = 0; vi < nv; ++vi) next[vi].store(view_chunk_begin[vi]);
+        std::atomic<size_t> next{ 0 };
         auto worker = [&](unsigned) {
             std::vector<uint32_t> stamp(voff.back(), 0), met;
             uint32_t st = 0;
-            for (size_t vi = 0; vi < nv; ++vi) {
-                const View& sv = *h->vlist[vi];
-                const auto& pot = h->pot[vi];
-                const std::vector<int>& sbi = h->best_idx[vi];
+            {
                 for (;;) {
-                    const size_t ci = next[vi].fetch_add(1, std::memory_order_relaxed);
-                    if (ci >= view_chunk_begin[vi + 1]) break;
+                    const size_t ci = next.fetch_add(1, std::memory_order_relaxed);
+                    if (ci >= chunks.size()) break;
+                    const size_t vi = chunk_view[ci];
+                    const View& sv = *h->vlist[vi];
+                    const auto& pot = h->pot[vi];
+                    const std::vector<int>& sbi = h->best_idx[vi];
                     Chunk& ch = chunks[ci];
                     for (size_t si = ch.begin; si < ch.end; ++si) {
                         const uint32_t sseg = kseg(h->hyps[si].src);
@@ -1481,7 +1478,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             auto used = [&](uint32_t xs) -> bool {
                                 if (stamp[voff[(size_t)tvi] + xs] == st) return true;
                                 const int xb = tbi[xs];
-                                return xb >= 0 && (size_t)xb < si && met_has((size_t)xb, dsrc);
+                                return xb >= 0 && (size_t)xb < si && met_has((size_t)xb, dsrc, ci);
                             };
                             auto mark = [&](uint32_t xs) { const uint32_t d = (uint32_t)(voff[(size_t)tvi] + xs); stamp[d] = st; met.push_back(d); };
                             if (used(tseg)) continue;
@@ -1504,7 +1501,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             if (!u) {
                                 const int xb = sbi[xs];
                                 if (xb >= 0 && (size_t)xb < si) {
-                                    if (nt == 1) u = met_has((size_t)xb, dsrc);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
+                                    if (nt == 1) u = met_has((size_t)xb, dsrc, ci);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
                                     else for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
                                 }
                             }
@@ -1514,11 +1511,11 @@ int cluster_segments_2D(L* h, bool perform_diff)
                             if (tb >= 0) ch.items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
                         }
                         std::sort(met.begin(), met.end());
-                        enc_chunk[si] = (uint32_t)ci; enc_off[si] = (uint32_t)ch.met.size(); enc_len[si] = (uint32_t)met.size();
+                        enc_off[si] = (uint32_t)ch.met.size(); enc_len[si] = (uint32_t)met.size();
                         ch.met.insert(ch.met.end(), met.begin(), met.end());
                     }
+                    chunk_done[ci].store(1, std::memory_order_release);
                 }
-                bar.wait();
             }
         };
         std::vector<std::thread> th;
