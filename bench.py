@@ -23,6 +23,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup quota (a container can see 256 CPUs and own 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,7 +78,7 @@ def cpu_baseline(scene, n_neighbors, sample_segments):
     # the same formulation on all host threads: one source-segment range of the same view per thread (the C oracle releases
     # the GIL), bounded to ~the same wall time
     import threading
-    nthreads = max(1, min(os.cpu_count() or 1, 64))
+    nthreads = max(1, min(usable_cpus(), 64))
     S = len(mv["src_segs"])
     per = max(1, min(S // nthreads, max(1, sample_segments // 2)))
     res = [None] * nthreads
@@ -89,7 +101,7 @@ def cpu_baseline(scene, n_neighbors, sample_segments):
             t.join()
         dta = time.time() - t1
         all_threads = dict(value=float(sum(r for r in res if r)) / dta, cores=nthreads, seconds=dta,
-                           sample="%d threads x %d source segments of view 0" % (nthreads, per))
+                           sample="%d threads (usable CPUs of this container) x %d source segments of view 0" % (nthreads, per))
     return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
                 sample="view 0 of the bench scene, first %d of %d source segments x %d neighbours: %d pairs, %d raw candidates, "
                        "%.3g verify inner iterations, %.1f s on 1 thread (oracle/l3d_oracle.c, reference formulation)"

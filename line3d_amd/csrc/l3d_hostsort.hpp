@@ -4,6 +4,8 @@
 #pragma once
 
 #include <stdint.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -13,11 +15,31 @@
 
 namespace l3d {
 
+// CPUs this process may actually use: affinity mask and cgroup CPU quota (a container can see 256 CPUs and own 16; more busy
+// threads than that only get throttled)
+inline unsigned usable_cpus()
+{
+    static const unsigned n = [] {
+        unsigned v = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) v = std::min(v, (unsigned)c); }
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32]; long long period = 0;
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long long quota = atoll(q);
+                if (quota > 0) v = std::min(v, (unsigned)std::max(1LL, quota / period));
+            }
+            fclose(f);
+        }
+        return v;
+    }();
+    return n;
+}
+
 inline unsigned host_threads()         // worker threads of the host-side stages that run alone (finish of compute3Dmodel)
 {
     if (const char* e = getenv("L3D_HOST_THREADS")) return (unsigned)std::max(1, std::min(64, atoi(e)));
-    const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(16u, hw / 2));
+    return std::max(1u, std::min(16u, usable_cpus()));
 }
 
 template <class F>

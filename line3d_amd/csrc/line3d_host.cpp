@@ -630,7 +630,7 @@ void finalize_matching(L* h)
     const double t0 = now_s();
     // views are independent here: a few host threads
     const size_t nv = h->pot.size();
-    const unsigned nt = std::max(1u, std::min(8u, std::min((unsigned)nv, std::thread::hardware_concurrency())));
+    const unsigned nt = std::max(1u, std::min(8u, std::min((unsigned)nv, l3d::usable_cpus())));
     std::atomic<size_t> next(0);
     auto work = [&]() {
         for (size_t vi = next.fetch_add(1); vi < nv; vi = next.fetch_add(1))
@@ -1081,7 +1081,7 @@ void start_finalizer(L* h, ChainPlan& P)
     fin.parts = &h->fin_parts;
     if (h->fin_parts.size() != nvl) h->fin_parts.assign(nvl, {});
     if (h->fin_buckets.size() != n) h->fin_buckets.assign(n, {});
-    fin.start(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 4)));    // (one process per GPU shares the host)
+    fin.start(std::max(1u, std::min(16u, l3d::usable_cpus())));
     P.user = ChainUser{ h, &h->order, &P.n_tbm, &P.src_idx, P.fin };
 }
 
