@@ -277,8 +277,9 @@ def main():
         out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="BASELINE configs[%d]: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
-                                        % (1 if n_gpus == 1 else 2, V, args.segments, args.neighbors),
+                   config=dict(workload="%s: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
+                                        % ("BASELINE configs[1]" if n_gpus == 1 else ("BASELINE configs[2]" if V == 512 else "BASELINE configs[1] grown to 64 views per GPU"),
+                                           V, args.segments, args.neighbors),
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
                                parallelism=("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU"),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
