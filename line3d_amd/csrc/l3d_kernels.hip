@@ -5,7 +5,7 @@
 //   k_pair_mask      stage 1a: epipolar/overlap test + triangulation, one bit per (src,tgt) pair
 //   k_row_count      stage 1b: per (src segment, camera) candidate counts from the bit rows
 //   k_exist_hist     counts of the already existing (reverse) matches
-//   k_scan           exclusive scan (single workgroup)
+//   k_scan           exclusive scan (independent tile workgroups, l3d_scan.hpp)
 //   k_pair_fill      stage 1c: depth records for the set bits, written in (seg,cam,tgt) order
 //   k_exist_place    existing matches into their candidate slots
 //   k_verify         stage 2: multi-view support score of every candidate (K_verify_matches)
@@ -296,7 +296,8 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
     if (i < n) atomicAdd(&rowcnt[ex[i].seg * N + ex[i].cam], 1);
 }
 
-// Exclusive scan of n ints by ONE workgroup (l3d_scan.hpp); out has n+1 entries, `zero` (optional) gets n zeros.
+// Exclusive scan of n ints, one independent workgroup per 4096-int tile (l3d_scan.hpp); out has n+1 entries, `zero`
+// (optional) gets n zeros; one more workgroup orders the segments longest first (optional); total_out (optional) gets the total.
 __global__ __launch_bounds__(kTileThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
                                                        int* __restrict__ seg_order, int N, int seg_begin, int seg_end,
                                                        const int* __restrict__ rowcnt_all, int* __restrict__ total_out)

@@ -1,4 +1,5 @@
-// l3d_scan.hpp -- exclusive prefix sum of n ints by ONE workgroup of 1024 threads (16 waves).
+// l3d_scan.hpp -- exclusive prefix sums of small int arrays: wg_scan_excl (one workgroup, for kernels that continue with the
+// total in the same launch) and wg_scan_excl_tile (independent workgroups, one per tile: the row scans of the chains).
 //
 // The arrays scanned on the matching path are small (rows of one view: S*N ints, a few ten thousand), so one
 // workgroup and no second pass beat a multi-block scan whose launches would sit on the per-view critical path.
