@@ -60,6 +60,7 @@ inline void parallel_stable_order(size_t n, size_t n_major, size_t n_minor, Majo
                                   std::vector<uint32_t>* bucket_start = nullptr)
 {
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / 8192 + 1));
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, ((size_t)1 << 26) / std::max<size_t>(1, n_major)));      // histograms: at most 256 MB
     std::vector<uint32_t> hist((size_t)nt * n_major, 0), start(n_major + 1, 0);
     on_threads(nt, [&](unsigned t) {
         uint32_t* h = hist.data() + (size_t)t * n_major;
