@@ -15,6 +15,7 @@
 //   k_rownorm / k_diffusion_step   replicator dynamics diffusion
 //   k_similarity     batched similarity_coll3D for the affinity fill
 #include <algorithm>
+#include <cstdlib>
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
@@ -24,7 +25,7 @@
 namespace l3d {
 
 // =================================================================================================
-// Stage 1a.  grid = (tgt tiles of 256, src blocks of kSrcPerBlock, n_tbm); block = 256.
+// Stage 1a.  grid = (tgt tiles of 256, src blocks of src_per_block <= kSrcPerBlock, n_tbm); block = 256.
 // Lane <-> target segment, the block walks kSrcPerBlock source segments whose invariants are staged in LDS and read as
 // broadcasts.  One wave ballot = one 64-bit word of the (camera, src) bit row.
 //
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     const int x = blockIdx.x * 256 + tid;
     const int width = a.offsets[cam].y;
     const int toff = a.offsets[cam].x;
-    const int y0 = a.seg_begin + blockIdx.y * kSrcPerBlock;
+    const int y0 = a.seg_begin + blockIdx.y * a.src_per_block;
 
     if (blockIdx.x * 256 >= width) return;   // whole tile beyond this camera's segments (uniform)
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     s_tgt[tid].t = t;
     s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
     s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
-    const int ny = min(kSrcPerBlock, a.seg_end - y0);
+    const int ny = min(a.src_per_block, a.seg_end - y0);
     {   // coordinate extents for the wedge margins (non-negative floats order like ints)
         float ex = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.x), __builtin_fabsf(tseg.z)) : 0.0f;
         float ey = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.y), __builtin_fabsf(tseg.w)) : 0.0f;
@@ -757,9 +758,23 @@ __global__ void k_test_math(const float* __restrict__ x, int n, float* __restric
 }
 
 // ---- launchers (host) ---------------------------------------------------------------------------
-void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st)
+// Source segments per workgroup: kSrcPerBlock when that still fills the GPU, fewer for short source ranges (one rank's share
+// of a view in the sharded chain: 250 segments at 8 GPUs would be 192 workgroups walking 64 sources each -- a launch bound by
+// the latency of one workgroup).
+int pair_mask_src_per_block(int n_src, int maxW, int n_tbm)
 {
-    dim3 grid((maxW + 255) / 256, (a.seg_end - a.seg_begin + kSrcPerBlock - 1) / kSrcPerBlock, a.n_tbm);
+    static const int forced = getenv("L3D_PAIR_SPB") ? atoi(getenv("L3D_PAIR_SPB")) : 0;
+    if (forced > 0) return std::min(forced, kSrcPerBlock);
+    const int tiles = (maxW + 255) / 256;
+    int spb = kSrcPerBlock;
+    while (spb > 8 && (long long)tiles * ((n_src + spb - 1) / spb) * n_tbm < 768) spb /= 2;
+    return spb;
+}
+void launch_pair_mask(const PairArgs& a0, int maxW, hipStream_t st)
+{
+    PairArgs a = a0;
+    a.src_per_block = pair_mask_src_per_block(a.seg_end - a.seg_begin, maxW, a.n_tbm);
+    dim3 grid((maxW + 255) / 256, (a.seg_end - a.seg_begin + a.src_per_block - 1) / a.src_per_block, a.n_tbm);
     hipLaunchKernelGGL(k_pair_mask, grid, dim3(256), 0, st, a);
 }
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st)

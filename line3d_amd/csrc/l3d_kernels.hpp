@@ -53,6 +53,7 @@ struct PairArgs {
     int seg_begin, seg_end;
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
     unsigned long long* dbg;        // diagnostic (L3D_PAIR_STATS=1): {pairs, level-1 survivors, level-2 survivors, set bits}, else null
+    int src_per_block;              // set by launch_pair_mask (<= kSrcPerBlock)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test (default 3)
 };
 
