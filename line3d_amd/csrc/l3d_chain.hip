@@ -178,10 +178,10 @@ __global__ __launch_bounds__(kTileThreads) void k_scan_kept_chain(const int* __r
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_start,
                                                           const unsigned* __restrict__ local2global, Match* __restrict__ arena)
 {
-    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (y >= a.seg_end || a.res->overflow) return;
-    write_kept_segment(a, y, lane, kept_start[y], local2global, arena + a.res->kept_base);
+    __shared__ int s_cnt[32];
+    const int y = a.seg_begin + blockIdx.x;                  // one workgroup per segment
+    if (a.res->overflow) return;
+    write_kept_segment_wg(a, y, kept_start[y], local2global, arena + a.res->kept_base, s_cnt);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
@@ -220,7 +220,7 @@ void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const i
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int, hipStream_t st)
 {
-    if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write_chain, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, arena);
+    if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write_chain, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a, kept_start, l2g, arena);
 }
 
 }  // namespace l3d

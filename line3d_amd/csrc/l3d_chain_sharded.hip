@@ -85,19 +85,20 @@ __global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotG
 }
 
 // Kept records of this rank's source-segment range [s0,s1) into its slot, in ONE launch behind the verification (every
-// launch of the sharded chain sits on the per-view critical path): each workgroup (4 segments, one per wave) sums the kept
-// counts in front of its segments itself -- a few hundred to 2000 ints out of L2 -- instead of waiting for a scan launch;
+// launch of the sharded chain sits on the per-view critical path): each workgroup (one segment) sums the kept counts in
+// front of its segment itself -- a few hundred to 2000 ints out of L2 -- instead of waiting for a scan launch;
 // workgroup 0 also writes the slot header (count, #candidates, overflow).  kept_cnt points at the range's first segment.
 __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, int slot_records,
                                                     const unsigned* __restrict__ local2global, const float2* __restrict__ best, SlotGeom g,
                                                     unsigned char* __restrict__ slot)
 {
     __shared__ int s_red[8];
+    __shared__ int s_cnt[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
-    const int first = blockIdx.x * 4;
+    const int yl = blockIdx.x;
     int before = 0, total = 0;
-    for (int i = tid; i < nseg; i += 256) { const int v = kept_cnt[i]; total += v; if (i < first) before += v; }
+    for (int i = tid; i < nseg; i += 256) { const int v = kept_cnt[i]; total += v; if (i < yl) before += v; }
     for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); total += __shfl_down(total, o); }
     if (lane == 0) { s_red[wave] = before; s_red[4 + wave] = total; }
     __syncthreads();
@@ -110,14 +111,11 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     if (h.n_kept > slot_records) { h.overflow |= 2; h.n_kept = 0; }
     h.s0 = a.seg_begin; h.s1 = a.seg_end; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<SlotHeader*>(slot) = h;
-    const int yl = first + wave;
-    if (yl >= nseg) return;
+    if (yl >= nseg) return;                                  // (an empty range still launches workgroup 0 for the header)
     const int y = a.seg_begin + yl;
-    if (lane == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
+    if (tid == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
     if (h.overflow) return;
-    int o = before;
-    for (int q = 0; q < wave; ++q) o += kept_cnt[first + q];
-    write_kept_segment(a, y, lane, o, local2global, reinterpret_cast<Match*>(slot + g.rec_off));
+    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt);
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -477,7 +475,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     }
     {
         ProfScope p(c, "kept_write");
-        hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, (d.s1 - d.s0 + 3) / 4)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
+        hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, d.s1 - d.s0)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
                            h->geom.slot_records, reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
     }
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("shard enqueue view ") + std::to_string(k) + " (mmax " + std::to_string(mmax) + ", lds " + std::to_string(verify_window_lds_bytes(mmax, N)) + ", range " + std::to_string(d.s0) + "-" + std::to_string(d.s1) + "): " + hipGetErrorString(e_)); }

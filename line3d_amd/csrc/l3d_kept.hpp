@@ -1,47 +1,53 @@
-// l3d_kept.hpp -- ordered compaction of one source segment's kept matches (conf > 1, cudawrapper.cu:1089-1110) by one
-// wave: the confidences of up to 1024 candidates are fetched in ONE round of loads (16 per lane in flight) before the
-// ballots, instead of one dependent load -> ballot -> store round per 64 candidates; the record loads of the few kept
-// candidates (~1.6 %) follow.  Shared by the per-view, chain and sharded-chain writers.
+// l3d_kept.hpp -- ordered compaction of one source segment's kept matches (conf > 1, cudawrapper.cu:1089-1110): the
+// confidences of up to 2048 candidates are fetched in ONE round of loads by the 4 waves of a workgroup before the ballots,
+// instead of one dependent load -> ballot -> store round per 64 candidates; the record loads of the few kept candidates
+// (~1.6 %) follow.  Shared by the per-view, chain and sharded-chain writers.
 #pragma once
 
 #include "l3d_kernels.hpp"
 
 namespace l3d {
 
-__device__ __forceinline__ void write_kept_segment(const VerifyArgs& a, int y, int lane, int o, const unsigned* __restrict__ local2global,
-                                                   Match* __restrict__ out)
+// A whole workgroup of 256 threads (4 waves) for ONE segment: rounds of 32 chunks of 64 candidates
+// (2048 candidates) whose confidences are all loaded at once; the chunks' kept counts go through LDS, every wave then knows
+// the output offset of its chunks.  A segment of config 2 (about 1500 candidates) is one round of loads instead of a chain of
+// dependent ones.  s_cnt: 32 ints of LDS.  All 256 threads must call.
+__device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y, int o, const unsigned* __restrict__ local2global,
+                                                      Match* __restrict__ out, int* s_cnt)
 {
-    constexpr int kPre = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    auto emit = [&](int i, float c, int pos) {
-        const uint2 meta = a.cand_meta[start + i];
-        const float4 d = a.cand_depths[start + i];
-        Match r;
-        r.segID1 = (unsigned)y; r.camID2 = local2global[meta.y]; r.segID2 = meta.x;
-        r.depths[0] = d.x; r.depths[1] = d.y; r.depths[2] = d.z; r.depths[3] = d.w;
-        r.confidence = c / 2.0f;                     // confidence_norm, cudawrapper.cu:1089,1098
-        out[pos] = r;
-    };
-    float c[kPre];
+    for (int base = 0; base < m; base += 2048) {
+        float c[8];
 #pragma unroll
-    for (int r = 0; r < kPre; ++r) { const int i = r * 64 + lane; c[r] = i < m ? a.cand_conf[start + i] : 0.0f; }
+        for (int r = 0; r < 8; ++r) { const int i = base + (wave + 4 * r) * 64 + lane; c[r] = i < m ? a.cand_conf[start + i] : 0.0f; }
+        unsigned long long b[8];
 #pragma unroll
-    for (int r = 0; r < kPre; ++r) {
-        if (r * 64 < m) {
-            const bool k = c[r] > 1.0f;
-            const unsigned long long b = __ballot(k);
-            if (k) emit(r * 64 + lane, c[r], o + __popcll(b & ((1ull << lane) - 1ull)));
-            o += __popcll(b);
+        for (int r = 0; r < 8; ++r) { b[r] = __ballot(c[r] > 1.0f); if (lane == 0) s_cnt[wave + 4 * r] = __popcll(b[r]); }
+        __syncthreads();
+        const int v = lane < 32 ? s_cnt[lane] : 0;
+        int incl = v;
+        for (int d = 1; d < 32; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        const int excl = incl - v;
+        const int total = __shfl(incl, 31);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int q = wave + 4 * r;
+            const int off = __shfl(excl, q);
+            if (c[r] > 1.0f) {
+                const int i = base + q * 64 + lane;
+                const uint2 meta = a.cand_meta[start + i];
+                const float4 d = a.cand_depths[start + i];
+                Match rec;
+                rec.segID1 = (unsigned)y; rec.camID2 = local2global[meta.y]; rec.segID2 = meta.x;
+                rec.depths[0] = d.x; rec.depths[1] = d.y; rec.depths[2] = d.z; rec.depths[3] = d.w;
+                rec.confidence = c[r] / 2.0f;                    // confidence_norm, cudawrapper.cu:1089,1098
+                out[o + off + __popcll(b[r] & ((1ull << lane) - 1ull))] = rec;
+            }
         }
-    }
-    for (int i0 = kPre * 64; i0 < m; i0 += 64) {
-        const int i = i0 + lane;
-        const float cc = i < m ? a.cand_conf[start + i] : 0.0f;
-        const bool k = cc > 1.0f;
-        const unsigned long long b = __ballot(k);
-        if (k) emit(i, cc, o + __popcll(b & ((1ull << lane) - 1ull)));
-        o += __popcll(b);
+        o += total;
+        __syncthreads();                                       // s_cnt is rewritten by the next round
     }
 }
 

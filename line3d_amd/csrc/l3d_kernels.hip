@@ -563,10 +563,9 @@ __global__ __launch_bounds__(256) void k_seg_post(VerifyArgs a, int* __restrict_
 __global__ __launch_bounds__(256) void k_kept_write(VerifyArgs a, const int* __restrict__ kept_start,
                                                     const unsigned* __restrict__ local2global, Match* __restrict__ out)
 {
-    const int y = a.seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (y >= a.seg_end) return;
-    write_kept_segment(a, y, lane, kept_start[y], local2global, out);
+    __shared__ int s_cnt[32];
+    const int y = a.seg_begin + blockIdx.x;                  // one workgroup per segment
+    write_kept_segment_wg(a, y, kept_start[y], local2global, out, s_cnt);
 }
 
 // =================================================================================================
@@ -819,7 +818,7 @@ void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream
 }
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_kept_write, dim3((a.seg_end - a.seg_begin + 3) / 4), dim3(256), 0, st, a, kept_start, l2g, out);
+    if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a, kept_start, l2g, out);
 }
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st)
 {
