@@ -445,7 +445,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         const ViewDev& d = vd[(size_t)k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
-        { ProfScope p(c, "scan", s); launch_scan(d.rowcnt, d.rowA, views[k].S_src * views[k].N, nullptr, s); }
         { ProfScope p(c, "pair_fill", s); launch_pair_fill(pa, d.rowA, ringA_meta(k), ringA_depths(k), s); }
     };
     auto enqueue_stage1 = [&](int k) -> int {
@@ -455,7 +454,9 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             const PairArgs pa = pair_args(k);
             { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, vd[(size_t)k].maxW, s1); }
             { ProfScope p(c, "row_count", s1); launch_row_count(pa, vd[(size_t)k].rowcnt, s1); }
-            launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
+            // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch)
+            if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
+            else launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
             // the ring slot was last used by view k - kRing: wait until its chain has consumed it
             for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(s1, ev[(size_t)j], 0)); break; }
             enqueue_fillA(k, s1);

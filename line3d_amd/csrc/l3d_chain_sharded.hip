@@ -385,13 +385,13 @@ static int shard_stage1(l3d_shard_chain* h, int k)
         const PairArgs pa = shard_pair_args(h, k);
         { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, d.maxW, s1); }
         { ProfScope p(c, "row_count", s1); launch_row_count(pa, d.rowcnt, s1); }
-        launch_raw_stats(d.rowcnt, h->views[k].N, d.s0, d.s1, h->hstats_dev + 2 * k, s1);     // straight into host-mapped memory
+        // row starts of the stage-1 candidates of the rank's rows + their statistics straight into host-mapped memory (one launch)
+        { ProfScope p(c, "scan", s1); launch_scan_range(d.rowcnt, d.rowA, h->views[k].N, d.s0, d.s1, h->views[k].S_src * h->views[k].N, nullptr, nullptr, s1, h->hstats_dev + 2 * k); }
         // depth records of the stage-1 candidates, in their own row order, into the ring slot last used by view k - kRingA
         // (its completion event is recorded by l3d_shard_chain_mark before this view's stage 1 is enqueued)
         if (k - l3d_shard_chain::kRingA >= 0) HIPCHK(c, hipStreamWaitEvent(s1, h->ev2[(size_t)(k - l3d_shard_chain::kRingA)], 0));
         PairArgs pf = pa;
         pf.cand_cap = (int)h->cand_cap;
-        { ProfScope p(c, "scan", s1); launch_scan(d.rowcnt, d.rowA, h->views[k].S_src * h->views[k].N, nullptr, s1); }
         { ProfScope p(c, "pair_fill", s1); launch_pair_fill(pf, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                                              c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, s1); }
     }

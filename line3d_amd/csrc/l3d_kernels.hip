@@ -301,13 +301,15 @@ __global__ void k_exist_hist(const ExistRec* __restrict__ ex, int n, int N, int*
 // (optional) gets n zeros; one more workgroup orders the segments longest first (optional); total_out (optional) gets the total.
 __global__ __launch_bounds__(kTileThreads) void k_scan(const int* __restrict__ in, int* __restrict__ out, int n, int* __restrict__ zero,
                                                        int* __restrict__ seg_order, int N, int seg_begin, int seg_end,
-                                                       const int* __restrict__ rowcnt_all, int* __restrict__ total_out)
+                                                       const int* __restrict__ rowcnt_all, int* __restrict__ total_out, int* __restrict__ stats_out)
 {
-    __shared__ int s_w[5];
+    __shared__ int s_w[8];
     __shared__ int s_hist[130];
     const int n_tiles = max(1, (n + kTileInts - 1) / kTileInts);
-    if ((int)blockIdx.x < n_tiles) wg_scan_excl_tile(in, out, n, zero, blockIdx.x, s_w, total_out);     // one independent workgroup per tile
-    else if (seg_order) wg_segment_order(rowcnt_all, N, seg_begin, seg_end, seg_order, s_hist);           // rows -> segments, longest first
+    const int b = (int)blockIdx.x;
+    if (b < n_tiles) wg_scan_excl_tile(in, out, n, zero, b, s_w, total_out);                          // one independent workgroup per tile
+    else if (seg_order && b == n_tiles) wg_segment_order(rowcnt_all, N, seg_begin, seg_end, seg_order, s_hist);   // rows -> segments, longest first
+    else if (stats_out) wg_raw_stats(rowcnt_all, N, seg_begin, seg_end, stats_out, s_w);              // total and per-segment maximum
 }
 
 // r-th (0-based) set bit of a 64-bit word
@@ -785,19 +787,20 @@ void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_
 {
     if (n) hipLaunchKernelGGL(k_exist_hist, dim3((n + 255) / 256), dim3(256), 0, st, ex, n, N, rowcnt);
 }
-void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order, int N, int seg_begin, int seg_end)
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order, int N, int seg_begin, int seg_end, int* stats_out)
 {
     const int n_tiles = std::max(1, (n + kTileInts - 1) / kTileInts);
-    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end, in, nullptr);
+    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0) + (stats_out ? 1 : 0)), dim3(kTileThreads), 0, st, in, out, n, zero, seg_order, N, seg_begin, seg_end,
+                       in, nullptr, stats_out);
 }
 // the rows of segments [seg_begin, seg_end) only (one rank's range of a view): out[row] for those rows, out[nrow_total] = their total
-void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st)
+void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st, int* stats_out)
 {
     const int n = (seg_end - seg_begin) * N;
     const size_t o = (size_t)seg_begin * N;
     const int n_tiles = std::max(1, (n + kTileInts - 1) / kTileInts);
-    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0)), dim3(kTileThreads), 0, st, rowcnt + o, row_start + o, n, zero ? zero + o : nullptr, seg_order, N,
-                       seg_begin, seg_end, rowcnt, row_start + nrow_total);
+    hipLaunchKernelGGL(k_scan, dim3(n_tiles + (seg_order ? 1 : 0) + (stats_out ? 1 : 0)), dim3(kTileThreads), 0, st, rowcnt + o, row_start + o, n, zero ? zero + o : nullptr,
+                       seg_order, N, seg_begin, seg_end, rowcnt, row_start + nrow_total, stats_out);
 }
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st)
 {

@@ -90,8 +90,10 @@ struct VerifyArgs {
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
-void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order = nullptr, int N = 0, int seg_begin = 0, int seg_end = 0);
-void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st);
+void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order = nullptr, int N = 0, int seg_begin = 0, int seg_end = 0,
+                 int* stats_out = nullptr);
+void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st,
+                       int* stats_out = nullptr);
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);

@@ -161,4 +161,24 @@ __device__ __forceinline__ void wg_segment_order(const int* __restrict__ rowcnt,
     }
 }
 
+// Sum and per-segment maximum of the candidate counts of segments [seg_begin, seg_end) (sizes the verification launch of
+// the view; written straight into host-mapped memory).  One more workgroup of the row scan's launch.  s_red: 8 ints of LDS.
+__device__ __forceinline__ void wg_raw_stats(const int* __restrict__ rowcnt, int N, int seg_begin, int seg_end, int* __restrict__ out2, int* s_red)
+{
+    int tot = 0, mx = 0;
+    for (int s = seg_begin + (int)threadIdx.x; s < seg_end; s += (int)blockDim.x) {
+        int c = 0;
+        for (int k = 0; k < N; ++k) c += rowcnt[s * N + k];
+        tot += c; mx = max(mx, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) { tot += __shfl_down(tot, o); mx = max(mx, __shfl_down(mx, o)); }
+    const int wave = threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0 && wave < 4) { s_red[wave] = tot; s_red[4 + wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < min(nw, 4); ++w) { tot += s_red[w]; mx = max(mx, s_red[4 + w]); }
+        out2[0] = tot; out2[1] = mx;
+    }
+}
+
 }  // namespace l3d
