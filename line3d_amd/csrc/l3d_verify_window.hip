@@ -416,9 +416,11 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
     const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
-    // few segments (about one workgroup per CU or less): 8 waves per segment, if the wider per-lane maxima still fit
+    // few segments (up to about two workgroups per CU): 8 waves per segment, if the wider per-lane maxima still fit
+    // (replayed ranks, 2000 segments per view: 250 segments 90 -> 74 us per view, 500 segments 98 -> 94, 1000 segments 135 -> 196)
     const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
-    if (nseg <= 320 && lds512 <= 60 * 1024) {
+    static const int wide_max = getenv("L3D_VW_WIDE_MAX") ? atoi(getenv("L3D_VW_WIDE_MAX")) : 640;
+    if (nseg <= wide_max && lds512 <= 60 * 1024) {
         static bool once = false;
         if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024); (void)hipGetLastError(); }
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);
