@@ -61,19 +61,34 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
     }
 }
 
-__global__ void k_exist_scatter_slots(const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
-                                      const int* __restrict__ src_cam, unsigned view_id, int N, int S, int s0, int s1,
-                                      const int* __restrict__ row_start, int* __restrict__ cursor,
-                                      uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
+// Both writers of the combined candidate arrays in one launch (they are independent: stage-1 candidates go to the rows of the
+// cameras to be matched, reverse matches to the rows of the source cameras): the first `blocks_move` workgroups copy the
+// stage-1 candidates of the rank's rows (a wave per row, k_cand_move), the others scatter the reverse matches
+// (k_exist_scatter_slots, 16 workgroups per (source view, rank) list).
+__global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
+                                                     const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
+                                                     const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
+                                                     const int* __restrict__ src_cam, unsigned view_id, int N, int S, int s0, int s1,
+                                                     const int* __restrict__ row_start, int* __restrict__ cursor,
+                                                     uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
 {
-    if (row_start[(size_t)S * N] > cap) return;
-    const int src = blockIdx.y / g.world, r = blockIdx.y % g.world;
+    if (row_start[(size_t)S * N] > cap) return;                  // overflow: the chain is re-run with more room
+    if ((int)blockIdx.x < blocks_move) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= (s1 - s0) * n_tbm) return;
+        const int y = s0 + row / n_tbm, cam = tbm[row % n_tbm];
+        const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
+        for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
+        return;
+    }
+    const int e = (int)blockIdx.x - blocks_move, list = e / 16, bx = e % 16;
+    const int src = list / g.world, r = list % g.world;
     const unsigned char* slot = G + ((size_t)src_index[src] * g.world + r) * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
     const int cam = src_cam[src];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += 16 * 256) {
         const Match m = kept[i];
         if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) {
             const int row = m.segID2 * N + cam;
@@ -436,14 +451,17 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
     {
         ProfScope p(c, "cand_move");
-        launch_cand_move(pa.tbm, v.n_tbm, N, d.s0, d.s1, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
-                         c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, c->row_start.as<int>(), (int)nrow,
-                         (int)h->cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+        const int blocks_move = ((d.s1 - d.s0) * v.n_tbm + 3) / 4;
+        const int blocks = blocks_move + 16 * v.n_sources * h->world;
+        if (blocks > 0)
+            hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, pa.tbm, v.n_tbm, d.rowA,
+                               c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                               c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                               h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
+                               c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
     }
     if (v.n_sources) {
         ProfScope p(c, "exist");
-        hipLaunchKernelGGL(k_exist_scatter_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1,
-                           c->row_start.as<int>(), c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
         launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
     }
     VerifyArgs va;
