@@ -120,18 +120,40 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
 // Stage-1 candidates of a view are written (k_pair_fill, stage-1 stream, well ahead of the chain) in their own
 // (segment, to-be-matched camera) row order; once the reverse matches of the view are counted, each row is moved to its
 // place in the combined (segment, camera, target) order -- a 24-byte copy per candidate instead of the triangulation on the
-// chain's critical path.  One wave per row.
-__global__ __launch_bounds__(256) void k_cand_move(const int* __restrict__ tbm, int n_tbm, int N, int seg_begin, int seg_end,
-                                                   const int* __restrict__ rowA, const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
-                                                   const int* __restrict__ row_start, int nrow_total, int cand_cap,
-                                                   uint2* __restrict__ meta, float4* __restrict__ depths)
+// chain's critical path.  One wave per row (the first workgroups of k_place).
+// Both writers of the combined candidate arrays in one launch (independent: stage-1 candidates go to the rows of the cameras
+// to be matched, reverse matches to the rows of the source cameras): the first `blocks_move` workgroups move the stage-1 rows, the
+// others scatter the reverse matches (as k_exist_scatter, 32 workgroups per source view).
+__global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
+                                               const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
+                                               const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                                               const int* __restrict__ src_cam, unsigned view_id, int N, int S,
+                                               const int* __restrict__ row_start, int* __restrict__ cursor,
+                                               uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= (seg_end - seg_begin) * n_tbm) return;
-    if (row_start[nrow_total] > cand_cap) return;                 // overflow: the chain is re-run with more room
-    const int y = seg_begin + row / n_tbm, cam = tbm[row % n_tbm];
-    const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
-    for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
+    if (row_start[(size_t)S * N] > cap) return;                  // overflow: the chain is re-run with more room
+    if ((int)blockIdx.x < blocks_move) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= S * n_tbm) return;
+        const int y = row / n_tbm, cam = tbm[row % n_tbm];
+        const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
+        for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
+        return;
+    }
+    const int e = (int)blockIdx.x - blocks_move, si = e / 32, bx = e % 32;
+    const ChainResult* src = res + src_index[si];
+    const int cam = src_cam[si];
+    const int n = src->n_kept;
+    const Match* kept = arena + src->kept_base;
+    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += 32 * 256) {
+        const Match r = kept[i];
+        if (r.camID2 == view_id && (int)r.segID2 < S) {
+            const int row = r.segID2 * N + cam;
+            const int slot = row_start[row] + atomicAdd(&cursor[row], 1);
+            meta[slot] = make_uint2(r.segID1, (unsigned)cam);
+            depths[slot] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
+        }
+    }
 }
 
 // raw candidate total and the largest per-segment count of one view's segment range (phase 1 statistics), by one
@@ -201,12 +223,14 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
     const int runs = (seg_end - seg_begin) * n_cams;
     if (runs > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((runs + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, seg_begin, seg_end, row_start, meta, depths, cap);
 }
-void launch_cand_move(const int* tbm, int n_tbm, int N, int seg_begin, int seg_end, const int* rowA, const uint2* metaA, const float4* depthsA,
-                      const int* row_start, int nrow_total, int cand_cap, uint2* meta, float4* depths, hipStream_t st)
+void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
+                  const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st)
 {
-    const int nrows = (seg_end - seg_begin) * n_tbm;
-    if (nrows > 0) hipLaunchKernelGGL(k_cand_move, dim3((nrows + 3) / 4), dim3(256), 0, st, tbm, n_tbm, N, seg_begin, seg_end, rowA, metaA, depthsA,
-                                      row_start, nrow_total, cand_cap, meta, depths);
+    const int blocks_move = (S * n_tbm + 3) / 4;
+    const int blocks = blocks_move + 32 * n_src;
+    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, tbm, n_tbm, rowA, metaA, depthsA, arena, res, src_index, src_cam,
+                                       view_id, N, S, row_start, cursor, meta, depths, cand_cap);
 }
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
 {
@@ -437,7 +461,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // row starts + depth records of a view's stage-1 candidates alone (its reverse matches are not known yet)
     // L3D_CHAIN_RING=0 (A/B): triangulation on the chain stream, straight into the combined order -- measured 5 % slower on
     // config 2 than the ring scheme, which keeps the chain stream short.  (Also measured: letting the verification read the
-    // stage-1 candidates in place instead of copying them with k_cand_move -- 20 % SLOWER: the copy is a streaming pass that
+    // stage-1 candidates in place instead of copying them (k_place) -- 20 % SLOWER: the copy is a streaming pass that
     // leaves the candidates cache-hot for the latency-bound kernels that follow.)
     const bool use_ring = c->chain_ring != 0;
     auto enqueue_fillA = [&](int k, hipStream_t s) {
@@ -490,14 +514,17 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
         if (use_ring) {
-            ProfScope p(c, "cand_move");
-            launch_cand_move(pa.tbm, v.n_tbm, N, 0, S, d.rowA, ringA_meta(k), ringA_depths(k), c->row_start.as<int>(), (int)nrow,
-                             (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
-        } else if (S > 0) {
-            ProfScope p(c, "pair_fill");
-            launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
-        }
-        {
+            {
+                ProfScope p(c, "cand_move");
+                launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
+                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+            }
+            if (v.n_sources) {
+                ProfScope p(c, "exist");
+                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
+            }
+        } else {
+            if (S > 0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
             ProfScope p(c, "exist");
             launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
                                  c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);

@@ -63,7 +63,7 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
 
 // Both writers of the combined candidate arrays in one launch (they are independent: stage-1 candidates go to the rows of the
 // cameras to be matched, reverse matches to the rows of the source cameras): the first `blocks_move` workgroups copy the
-// stage-1 candidates of the rank's rows (a wave per row, k_cand_move), the others scatter the reverse matches
+// stage-1 candidates of the rank's rows (a wave per row), the others scatter the reverse matches
 // (k_exist_scatter_slots, 16 workgroups per (source view, rank) list).
 __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                      const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,

@@ -99,7 +99,7 @@ struct l3d_ctx {
     l3d::PinArena pin_arena;                 // kept lists of the running / last chain (valid until the next chain starts)
     std::vector<int> h_cnt;
     int mmax_seen = 0;
-    int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_cand_move (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
+    int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_place (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
     int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing)

@@ -112,8 +112,9 @@ void launch_exist_scatter(const Match* arena, const ChainResult* res, const int*
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
                             int seg_begin = 0, int seg_end = -1);
-void launch_cand_move(const int* tbm, int n_tbm, int N, int seg_begin, int seg_end, const int* rowA, const uint2* metaA, const float4* depthsA,
-                      const int* row_start, int nrow_total, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
+void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
+                  const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
 void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
                             int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st);
