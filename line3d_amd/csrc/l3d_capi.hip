@@ -256,7 +256,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
-    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
     const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
     // stage 1 starts now; the host orders the existing matches meanwhile

@@ -397,7 +397,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
         pa.mask = d.mask;
         pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg;
+        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
         return pa;
     };
 
@@ -476,8 +476,12 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         hstats[2 * k] = hstats[2 * k + 1] = 0;
         if (views[k].S_src > 0) {
             const PairArgs pa = pair_args(k);
-            { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, vd[(size_t)k].maxW, s1); }
-            { ProfScope p(c, "row_count", s1); launch_row_count(pa, vd[(size_t)k].rowcnt, s1); }
+            {   // bit rows + row counts (added into the rows zeroed at chain start) in one launch
+                PairArgs pm = pa;
+                pm.rowcnt = vd[(size_t)k].rowcnt;
+                ProfScope p(c, "pair_mask", s1);
+                launch_pair_mask(pm, vd[(size_t)k].maxW, s1);
+            }
             // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch)
             if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
             else launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);

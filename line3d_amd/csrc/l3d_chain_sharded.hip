@@ -385,7 +385,7 @@ static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
     pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
     pa.mask = d.mask;
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg;
+    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg; pa.rowcnt = nullptr;
     return pa;
 }
 
@@ -398,8 +398,12 @@ static int shard_stage1(l3d_shard_chain* h, int k)
     h->hstats[2 * k] = h->hstats[2 * k + 1] = 0;
     if (d.s1 > d.s0) {
         const PairArgs pa = shard_pair_args(h, k);
-        { ProfScope p(c, "pair_mask", s1); launch_pair_mask(pa, d.maxW, s1); }
-        { ProfScope p(c, "row_count", s1); launch_row_count(pa, d.rowcnt, s1); }
+        {   // bit rows + row counts (added into the rows zeroed when the chain was opened) in one launch
+            PairArgs pm = pa;
+            pm.rowcnt = d.rowcnt;
+            ProfScope p(c, "pair_mask", s1);
+            launch_pair_mask(pm, d.maxW, s1);
+        }
         // row starts of the stage-1 candidates of the rank's rows + their statistics straight into host-mapped memory (one launch)
         { ProfScope p(c, "scan", s1); launch_scan_range(d.rowcnt, d.rowA, h->views[k].N, d.s0, d.s1, h->views[k].S_src * h->views[k].N, nullptr, nullptr, s1, h->hstats_dev + 2 * k); }
         // depth records of the stage-1 candidates, in their own row order, into the ring slot last used by view k - kRingA

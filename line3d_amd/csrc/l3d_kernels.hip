@@ -262,6 +262,14 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (int r = lane; r < ny; r += 64) a.mask[((size_t)j * a.S_src + (y0 + r)) * a.W64 + blockIdx.x * 4 + wave] = s_bits[r * 4 + wave];
+    if (a.rowcnt) {
+        // this tile's share of the row counts (stage 1b folded in: one atomic per source segment and workgroup)
+        __syncthreads();                                       // every wave's bits of the tile are in s_bits
+        if (tid < ny) {
+            const int cnt = __popcll(s_bits[tid * 4]) + __popcll(s_bits[tid * 4 + 1]) + __popcll(s_bits[tid * 4 + 2]) + __popcll(s_bits[tid * 4 + 3]);
+            if (cnt) atomicAdd(&a.rowcnt[(y0 + tid) * a.N + cam], cnt);
+        }
+    }
     if (a.dbg) {
         int nbits = 0;
         for (int r = lane; r < ny; r += 64) nbits += __popcll(s_bits[r * 4 + wave]);

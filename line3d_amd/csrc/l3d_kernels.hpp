@@ -54,6 +54,8 @@ struct PairArgs {
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)
     unsigned long long* dbg;        // diagnostic (L3D_PAIR_STATS=1): {pairs, level-1 survivors, level-2 survivors, set bits}, else null
     int src_per_block;              // set by launch_pair_mask (<= kSrcPerBlock)
+    int* rowcnt;                    // chains: the per-(segment, camera) candidate counts are added here by k_pair_mask itself (rows zeroed at
+                                    // chain start); null: a separate k_row_count launch (per-view seam call, chain restarts)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test (default 3)
 };
 
