@@ -176,34 +176,35 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
     }
 }
 
-// prefix sums of the per-segment kept counts and, in the same launch, the reservation of the view's slice of the kept
-// arena: (base, count, #candidates, overflow) published to the device record and to its host-mapped mirror
-__global__ __launch_bounds__(kTileThreads) void k_scan_kept_chain(const int* __restrict__ kept_cnt, int* __restrict__ kept_start, int S,
-                                                                  const int* __restrict__ row_start, int nrow, int* __restrict__ arena_cursor,
-                                                                  int arena_cap, int cand_cap, ChainResult* __restrict__ res,
-                                                                  ChainResult* __restrict__ res_host)
-{
-    __shared__ int s_w[4];
-    const int total = wg_scan_excl<kTileThreads>(kept_cnt, kept_start, S, nullptr, s_w);     // (a small workgroup: see wg_scan_excl_tile)
-    if (threadIdx.x != 0) return;
-    ChainResult r;
-    r.R = row_start[nrow];
-    r.overflow = r.R > cand_cap ? 1 : 0;
-    r.n_kept = r.overflow ? 0 : total;
-    r.kept_base = *arena_cursor;
-    if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
-    *arena_cursor = r.kept_base + r.n_kept;
-    *res = r;
-    *res_host = r;
-}
-
-__global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_start,
+// Kept records of a view into its slice of the arena, in ONE launch behind the verification: each workgroup (one segment) sums
+// the kept counts in front of its segment itself (at most a few thousand ints out of L2) instead of waiting for a scan
+// launch, and the slice starts where the previous verified view's ended (its result record) -- no cursor, no atomics.
+// Workgroup 0 also writes the view's result record (device copy for later views, host-mapped copy for the host).
+__global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, const ChainResult* __restrict__ prev,
+                                                          int arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
                                                           const unsigned* __restrict__ local2global, Match* __restrict__ arena)
 {
+    __shared__ int s_red[8];
     __shared__ int s_cnt[32];
-    const int y = a.seg_begin + blockIdx.x;                  // one workgroup per segment
-    if (a.res->overflow) return;
-    write_kept_segment_wg(a, y, kept_start[y], local2global, arena + a.res->kept_base, s_cnt);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = a.seg_end - a.seg_begin;
+    const int yl = blockIdx.x;
+    int before = 0, total = 0;
+    for (int i = tid; i < nseg; i += 256) { const int v = kept_cnt[a.seg_begin + i]; total += v; if (i < yl) before += v; }
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); total += __shfl_down(total, o); }
+    if (lane == 0) { s_red[wave] = before; s_red[4 + wave] = total; }
+    __syncthreads();
+    before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    total = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    ChainResult r;
+    r.R = a.row_start[nrow];
+    r.overflow = r.R > a.cand_cap ? 1 : 0;
+    r.n_kept = r.overflow ? 0 : total;
+    r.kept_base = prev ? prev->kept_base + prev->n_kept : 0;
+    if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
+    if (blockIdx.x == 0 && tid == 0) { *res = r; *res_host = r; }
+    if (yl >= nseg || r.overflow) return;
+    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
@@ -236,15 +237,10 @@ void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int*
 {
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
-void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
-                            int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st)
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan_kept_chain, dim3(1), dim3(kTileThreads), 0, st, kept_cnt, kept_start, S, row_start, nrow, arena_cursor, arena_cap,
-                       cand_cap, res, res_host);
-}
-void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int, hipStream_t st)
-{
-    if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write_chain, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a, kept_start, l2g, arena);
+    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena);
 }
 
 }  // namespace l3d
@@ -427,7 +423,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->kept_cnt.reserve((size_t)maxS * 4 + 4));
     HIPCHK(c, c->ch_segorder.reserve((size_t)maxS * 4 + 16));
     HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
-    int* arena_cursor = c->ch_flags.as<int>();
     int k_enq = 0;                      // next view whose phase 2 is enqueued
     // run-ahead depths, A/B measured on one box (ms per config-2 pass): (12, 24) 19.1, (6, 12) 18.7, (4, 8) 18.4, (2, 4) 18.3,
     // (24, 40) 20.0 -- a shallow queue keeps the stage-1 candidates of a view cache-warm until its chain consumes them
@@ -562,9 +557,13 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             { ProfScope p(c, "verify"); launch_verify(va, st); }
             { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
         }
-        { ProfScope p(c, "scan"); launch_scan_kept_chain(c->kept_cnt.as<int>(), c->kept_start.as<int>(), S, c->row_start.as<int>(), (int)nrow, arena_cursor,
-                                                         (int)arena_cap, (int)cand_cap, dres + k, hres_dev + k, st); }
-        { ProfScope p(c, "kept_write"); launch_kept_write_chain(va, c->kept_start.as<int>(), reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, (int)arena_cap, st); }
+        {
+            ProfScope p(c, "kept_write");
+            int pv = k - 1;
+            while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
+            launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (int)arena_cap, dres + k, hres_dev + k,
+                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st);
+        }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
@@ -677,7 +676,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
                 arena_cap = new_cap;
             }
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
-            if (!hip_ok(hipMemcpy(arena_cursor, &r.kept_base, 4, hipMemcpyHostToDevice), "hipMemcpy")) break;
             // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
             // and the stage-1 candidate buffers of every view in flight live in the (re-sized) ring: refill them
             for (int j = k; j < k_p1; ++j) {

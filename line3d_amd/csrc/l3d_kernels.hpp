@@ -118,9 +118,8 @@ void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, cons
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
-void launch_scan_kept_chain(const int* kept_cnt, int* kept_start, int S, const int* row_start, int nrow, int* arena_cursor, int arena_cap,
-                            int cand_cap, ChainResult* res, ChainResult* res_host, hipStream_t st);
-void launch_kept_write_chain(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* arena, int arena_cap, hipStream_t st);
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);
