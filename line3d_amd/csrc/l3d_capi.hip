@@ -336,6 +336,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     { ProfScope p(c, "exist"); launch_exist_place(c->exist.as<ExistRec>(), n_ex, N, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
 
     VerifyArgs va;
+    va.exist_cams = nullptr; va.n_exist_cams = 0;
     va.src_segs = d_src; va.tgt_segs = d_tgt; va.offsets = pa.offsets;
     va.P = reinterpret_cast<const float*>(tb + o_P);
     va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;

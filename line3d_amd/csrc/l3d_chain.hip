@@ -78,43 +78,7 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
     if (t >= (seg_end - seg_begin) * n_cams) return;
     const int seg = seg_begin + t / n_cams, cam = cams[t % n_cams];
     const int b = row_start[seg * N + cam], n = row_start[seg * N + cam + 1] - b;
-    if (n < 2) return;
-    if (n > 256) {                                  // pathological run: one lane, in place
-        if (lane == 0)
-            for (int i = b + 1; i < b + n; ++i) {
-                const uint2 m = meta[i];
-                const float4 d = depths[i];
-                int j = i;
-                for (; j > b && meta[j - 1].x > m.x; --j) { meta[j] = meta[j - 1]; depths[j] = depths[j - 1]; }
-                meta[j] = m; depths[j] = d;
-            }
-        return;
-    }
-    unsigned key[4];
-    float4 d[4];
-    int rank[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = lane + 64 * r;
-        key[r] = i < n ? meta[b + i].x : 0xffffffffu;
-        d[r] = i < n ? depths[b + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                   // (all indices static: the arrays stay in registers)
-        if (r * 64 < n) {
-            const int cnt = min(64, n - r * 64);
-            for (int l = 0; l < cnt; ++l) {
-                const unsigned other = __shfl(key[r], l);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = lane + 64 * r;
-        if (i < n) { meta[b + rank[r]] = make_uint2(key[r], (unsigned)cam); depths[b + rank[r]] = d[r]; }
-    }
+    sort_exist_run(lane, b, n, cam, meta, depths);
 }
 
 // Stage-1 candidates of a view are written (k_pair_fill, stage-1 stream, well ahead of the chain) in their own
@@ -518,7 +482,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
                 launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
                              c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
             }
-            if (v.n_sources) {
+            if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");
                 launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
             }
@@ -527,10 +491,11 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             ProfScope p(c, "exist");
             launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
                                  c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
-            if (v.n_sources) launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(),
-                                                    c->cand_depths.as<float4>(), (int)cand_cap, st);
+            if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N)))
+                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
         }
         VerifyArgs va;
+        va.exist_cams = nullptr; va.n_exist_cams = 0;
         va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
         va.P = reinterpret_cast<const float*>(dtab + d.o_P);
         va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
@@ -550,6 +515,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             va.skip_above = 1; va.only_above = -1; va.big = 2;
             va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + kVWSlack;
             va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
+            va.exist_cams = d_sc; va.n_exist_cams = v.n_sources;            // reverse-match runs are ordered by the segment's workgroup
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
         } else {
             va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;

@@ -464,11 +464,12 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
                                h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
                                c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
     }
-    if (v.n_sources) {
+    if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {          // (the window kernel orders the runs itself)
         ProfScope p(c, "exist");
         launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
     }
     VerifyArgs va;
+    va.exist_cams = nullptr; va.n_exist_cams = 0;
     va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
     va.P = reinterpret_cast<const float*>(dtab + d.o_P);
     va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
@@ -487,6 +488,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
             va.skip_above = 1; va.only_above = -1; va.big = 2;
             va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + kVWSlack;
             va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
+            va.exist_cams = d_sc; va.n_exist_cams = v.n_sources;            // reverse-match runs are ordered by the segment's workgroup
             { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
         } else {
             va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;

@@ -51,4 +51,47 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
     }
 }
 
+// One (segment, source camera) run of existing (reverse) matches, scattered in arbitrary order, into ascending target order:
+// one wave, ranks by all-to-all comparison in registers (runs are short; targets inside a run are distinct).
+__device__ __forceinline__ void sort_exist_run(int lane, int b, int n, int cam, uint2* meta, float4* depths)
+{
+    if (n < 2) return;
+    if (n > 256) {                                  // pathological run: one lane, in place
+        if (lane == 0)
+            for (int i = b + 1; i < b + n; ++i) {
+                const uint2 m = meta[i];
+                const float4 d = depths[i];
+                int j = i;
+                for (; j > b && meta[j - 1].x > m.x; --j) { meta[j] = meta[j - 1]; depths[j] = depths[j - 1]; }
+                meta[j] = m; depths[j] = d;
+            }
+        return;
+    }
+    unsigned key[4];
+    float4 d[4];
+    int rank[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane + 64 * r;
+        key[r] = i < n ? meta[b + i].x : 0xffffffffu;
+        d[r] = i < n ? depths[b + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                   // (all indices static: the arrays stay in registers)
+        if (r * 64 < n) {
+            const int cnt = min(64, n - r * 64);
+            for (int l = 0; l < cnt; ++l) {
+                const unsigned other = __shfl(key[r], l);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = lane + 64 * r;
+        if (i < n) { meta[b + rank[r]] = make_uint2(key[r], (unsigned)cam); depths[b + rank[r]] = d[r]; }
+    }
+}
+
 }  // namespace l3d

@@ -80,6 +80,8 @@ struct VerifyArgs {
     const int* seg_order;           // k_verify_window: workgroup i takes segment seg_order[i] (longest first); null = seg_begin + i
     int* kept_cnt;                  // fused per-segment epilogue of k_verify_window (k_seg_post): number of kept matches ...
     float2* best_depths;            // ... and depths of the first best hypothesis; null = separate k_seg_post launch
+    const int* exist_cams;          // k_verify_window: local ids of the cameras whose rows hold reverse matches in arbitrary order; the
+    int n_exist_cams;               // workgroup of a segment puts those runs into ascending target order itself (0: already ordered)
     float* scratch;                 // 4 arrays of scratch_stride floats (candidate capacity + 2), global memory
     long long scratch_stride;
     int cand_cap;                   // candidate capacity guard of the resident chain (0: none)

@@ -18,6 +18,7 @@
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
+#include "l3d_kept.hpp"
 
 namespace l3d {
 
@@ -148,6 +149,19 @@ void k_verify_window(VerifyArgs a)
         return;
     }
     if (a.debug == 4) return;
+    if (a.n_exist_cams > 0) {
+        // the reverse matches of this segment were scattered into their rows in arbitrary order: a wave per (source camera) run
+        // ranks them by target id (k_exist_sort_runs folded in -- one launch less on the per-view path)
+        uint2* meta_w = const_cast<uint2*>(a.cand_meta);
+        float4* depths_w = const_cast<float4*>(a.cand_depths);
+        for (int t = wave; t < a.n_exist_cams; t += NW) {
+            const int cam = a.exist_cams[t];
+            const int b = a.row_start[y * a.N + cam], n = a.row_start[y * a.N + cam + 1] - b;
+            sort_exist_run(lane, b, n, cam, meta_w, depths_w);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
 #define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
