@@ -127,7 +127,7 @@ public:
     // line3D.h:88
     float4 getSegment2D(L3DSegment2D& seg2D)
     {
-        float o[4];
+        float o[4] = { 0.0f, 0.0f, 0.0f, 0.0f };   // (stays zero when the handle is null: the constructor found no HIP device)
         if (l3d_line3d_get_segment2D(h_, seg2D.camID(), seg2D.segID(), o) != L3D_OK)
             std::cerr << prefix_ << "no view with ID " << seg2D.camID() << "!" << std::endl;
         return float4{ o[0], o[1], o[2], o[3] };

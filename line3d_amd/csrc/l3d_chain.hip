@@ -463,7 +463,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
         t_ev1 += now_s() - te0;
         HIPCHK(c, hipStreamWaitEvent(st, ev1[(size_t)k], 0));
-        raw_sum += hstats[2 * k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
         const int S = v.S_src, N = v.N;
@@ -657,6 +656,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             --k;
             continue;
         }
+        raw_sum += hstats[2 * k];           // counted when the view is final (a restart enqueues views a second time)
         hand_over(k, 1, r);
     }
     { std::lock_guard<std::mutex> lk(mu); done = true; }

@@ -88,7 +88,8 @@ struct l3d_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // bulk D2H of the resident chain, concurrent with kernels
     hipStream_t stage1_stream = nullptr;     // stage 1 of the resident chain (independent of the chain state) runs ahead here
-    std::string err;
+    std::string err;                         // written under err_mu: the chains report from several host threads
+    std::mutex err_mu;
     // arenas of the matching path
     l3d::DevBuf src_segs, tgt_segs, tables, tbm, l2g, exist, mask, rowcnt, row_start, cand_meta, cand_depths, cand_conf;
     l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
@@ -122,7 +123,7 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 inline int fail(l3d_ctx* c, int code, const std::string& msg)
 {
-    if (c) c->err = msg;
+    if (c) { std::lock_guard<std::mutex> lk(c->err_mu); c->err = msg; }
     return code;
 }
 

@@ -15,6 +15,7 @@
 // float operations the reference uses, hence the same bits.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
@@ -425,6 +426,22 @@ size_t verify_window_max_lds()
 // The per-(hypothesis lane, camera) maxima alone need 1 KB per camera: beyond ~50 neighbours the kernel does not fit the
 // 64 KB a workgroup may ask for and the caller takes the all-pairs kernel.
 bool verify_window_supported(int N) { return verify_window_lds_bytes(64, N) <= 60 * 1024; }
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device: the opt-in is tracked per (device, kernel
+// instantiation), under a mutex (several contexts on several GPUs may launch from different threads).  A refused opt-in
+// leaves the launch error for the caller's hipGetLastError check: nothing is launched with an LDS request the device
+// would reject silently.
+static bool lds_opt_in(const void* fn, int which)
+{
+    static std::mutex mu;
+    static unsigned char done[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[which][dev]) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024) != hipSuccess) return false;   // (error stays pending)
+    done[which][dev] = 1;
+    return true;
+}
 void launch_verify_window(const VerifyArgs& a, hipStream_t st)
 {
     const int nseg = a.seg_end - a.seg_begin;
@@ -435,13 +452,11 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
     const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
     static const int wide_max = getenv("L3D_VW_WIDE_MAX") ? atoi(getenv("L3D_VW_WIDE_MAX")) : 640;
     if (nseg <= wide_max && lds512 <= 60 * 1024) {
-        static bool once = false;
-        if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024); (void)hipGetLastError(); }
+        if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<512>), 1)) return;
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);
     } else {
         const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 256) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
-        static bool once = false;
-        if (!once) { once = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_verify_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024); (void)hipGetLastError(); }
+        if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<256>), 0)) return;
         hipLaunchKernelGGL(k_verify_window<256>, grid, dim3(256), lds, st, a);
     }
 }

@@ -1984,8 +1984,8 @@ int l3d_line3d_save_result(const l3d_line3d* h, const char* filename, int format
 
 int l3d_line3d_get_segment2D(const l3d_line3d* h, uint32_t cam, uint32_t seg, float out[4])
 {
-    if (!h) return L3D_ERR_INVALID;
-    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (out) out[0] = out[1] = out[2] = out[3] = 0.0f;        // zeroed before any early return
+    if (!h || !out) return L3D_ERR_INVALID;
     auto it = h->views.find(cam);
     if (it == h->views.end() || seg >= (uint32_t)it->second.S()) return L3D_ERR_INVALID;
     memcpy(out, &it->second.segs[(size_t)seg * 4], 16);

@@ -127,6 +127,53 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
     return Scene(views, np.concatenate([start, end], axis=1), params)
 
 
+def make_scene_from_poses(centers, targets, n_segments: int, seed: int = 77, noise_px: float = 0.5, width: int = 1920,
+                          height: int = 1080, f: float = 1500.0, all_neighbors: bool = True) -> Scene:
+    """Cameras at arbitrary poses (centre, look-at point) observing one pool of 3-D segments near the origin: opposing
+    cameras, forward motion (epipole inside the image), ... -- geometries the helix of make_scene never produces.  Every
+    view is every other view's neighbour."""
+    rng = SplitMix64(seed)
+    K = np.array([[f, 0.0, width / 2.0], [0.0, f, height / 2.0], [0.0, 0.0, 1.0]])
+    cams = []
+    for C, T in zip(centers, targets):
+        C = np.asarray(C, float)
+        R = _look_at(C, np.asarray(T, float))
+        cams.append((R, -R @ C))
+    pool = n_segments * 3 + 64
+    u = rng.uniform(pool * 3).reshape(pool, 3)
+    start = np.stack([1.6 * u[:, 0] - 0.8, 1.0 * u[:, 1] - 0.5, 1.6 * u[:, 2] - 0.8], axis=1)
+    d = rng.normal(pool * 3).reshape(pool, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    end = start + d * (0.1 + 0.3 * np.abs(2.0 * rng.uniform(pool) - 1.0))[:, None]
+
+    def project(R, t, X):
+        x = (K @ (R @ X.T + t[:, None])).T
+        return x[:, :2] / x[:, 2:3], x[:, 2]
+
+    visible = np.ones(pool, dtype=bool)
+    for R, t in cams:
+        for X in (start, end):
+            p, z = project(R, t, X)
+            visible &= (z > 0.1) & (p[:, 0] >= 1.0) & (p[:, 0] < width - 1.0) & (p[:, 1] >= 1.0) & (p[:, 1] < height - 1.0)
+    keep = np.nonzero(visible)[0][:n_segments]
+    if len(keep) < n_segments:
+        raise RuntimeError("synthetic pool too small: %d < %d" % (len(keep), n_segments))
+    start, end = start[keep], end[keep]
+    views = []
+    for i, (R, t) in enumerate(cams):
+        p1, _ = project(R, t, start)
+        p2, _ = project(R, t, end)
+        noise = noise_px * rng.normal(4 * n_segments).reshape(n_segments, 4)
+        perm = rng.permutation(n_segments)
+        segs = np.concatenate([p1, p2], axis=1)[perm] + noise
+        sims = {j: 1.0 / (1.0 + abs(i - j)) for j in range(len(cams)) if j != i} if all_neighbors else {}
+        views.append(dict(id=i, K=K.copy(), R=R.copy(), t=t.copy(), width=width, height=height,
+                          segments=np.ascontiguousarray(segs, dtype=np.float32), sims=sims, gt=perm.copy()))
+    params = dict(n_views=len(cams), n_segments=n_segments, n_neighbors=len(cams) - 1, seed=seed, noise_px=noise_px,
+                  width=width, height=height, f=f)
+    return Scene(views, np.concatenate([start, end], axis=1), params)
+
+
 def pair_work(scene: Scene) -> int:
     """Stage-1 segment pairs as the reference schedules them: each mutual
     view pair is evaluated once, from the view processed first (ascending id)."""

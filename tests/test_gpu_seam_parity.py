@@ -230,6 +230,58 @@ def test_pair_pretest_is_conservative(gpu_ctx):
     assert total_pairs > 1e8
 
 
+def _sector_rejected(mv, cam, accepted):
+    """Oracle-accepted pairs of (source view, local camera `cam`) whose target segment lies inside ONE same-sign sector of the
+    source endpoints' epipolar lines -- the pairs a sector test without the e_d condition would drop (float64 geometry)."""
+    o0, n = mv["offsets"][cam]
+    s1 = mv["src_segs"].astype(np.float64)
+    s2 = mv["tgt_segs"][o0:o0 + n].astype(np.float64)
+    F = mv["F"][cam].astype(np.float64)
+    one = lambda a: np.concatenate([a, np.ones((len(a), 1))], 1)
+    e1, e2 = one(s1[:, :2]) @ F.T, one(s1[:, 2:]) @ F.T
+    q1, q2 = one(s2[:, :2]), one(s2[:, 2:])
+    a = np.stack([e1 @ q1.T, e1 @ q2.T, e2 @ q1.T, e2 @ q2.T])
+    return int((accepted & ((a > 0).all(0) | (a < 0).all(0))).sum())
+
+
+def test_pair_pretest_wrapping_epipolar_transfer(gpu_ctx, oracle_lib):
+    """Cameras that face each other / move forward: the epipolar transfer of a source segment can wrap through infinity, the
+    reference then keeps pairs whose target segment lies in a same-sign sector of the two epipolar lines (all four depths
+    positive although one 3-D endpoint is behind the other camera, cudawrapper.cu:931 does not look).  The stage-1 filters
+    must keep them too: every filter mask gives the oracle's kept list, bit for bit, and the scene provably contains such pairs."""
+    from line3d_amd.synth import make_scene_from_poses
+    O = (0.0, 0.0, 0.0)
+    centers = [(0, 0, -4), (0.3, 0.1, 4), (-0.4, 0.2, 4.2), (0.1, 0.05, -3.0), (0.0, -0.1, -5.0), (4, 0.2, 0.3), (0.5, 0.3, -4.1)]
+    sc = make_scene_from_poses(centers, [O] * len(centers), 500, seed=91)
+    o = op.OracleLine3D(matching_neighbors=len(centers) - 1, use_collinearity=False)
+    for v in sc.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    o.matched, o.potential = {}, {}
+    o.find_visual_neighbors()
+    o.transform_geometry()
+    wrapped = 0
+    for src in (0, 1):
+        for n in o.visual_neighbors[src]:
+            o._fundamental(src, n)
+        mv = o.marshal_view(src)
+        for cam in range(len(mv["l2g"])):
+            o0, n = mv["offsets"][cam]
+            buf = op.pairwise_dense(oracle_lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], int(o0), int(n), cam,
+                                    mv["F"], mv["RtKinv"], mv["centers"])
+            wrapped += _sector_rejected(mv, cam, (buf > 0).all(axis=2))
+        tr = dict(marshal=mv, in_matches=np.zeros(0, op.MATCH_DTYPE))
+        exp, exp_med = op.compute_pairwise_matches(oracle_lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"],
+                                                   mv["F"], mv["RtKinv"], mv["centers"], mv["P"], mv["tbm"], tr["in_matches"], mv["l2g"],
+                                                   mv["k_upper"], mv["k_lower"], 3.5, 10.0, mv["spatial_k"])[:2]
+        for mask in (0, 1, 2, 3):
+            gpu_ctx.set_pair_pretest(mask)
+            m, med, _ = _run_view(gpu_ctx, tr)
+            assert m.tobytes() == exp.tobytes(), "view %d, filter mask %d: differs from the oracle" % (src, mask)
+            assert np.float32(med) == np.float32(exp_med)
+        gpu_ctx.set_pair_pretest(3)
+    assert wrapped > 20, "the scene does not exercise the wrapping case (%d pairs)" % wrapped
+
+
 def test_window_verify_global_scratch_variant(gpu_ctx, small_oracle, small_scene):
     """With the LDS budget capped most segments take the global-scratch variant of the window kernel; results stay
     bit-identical (per-view seam call and the resident chain)."""
