@@ -46,10 +46,12 @@ namespace l3d {
 //      has [l1_q1, l1_q2] strictly containing [p1, p2] (the transfer wraps through infinity), both overlaps can pass and
 //      the reference keeps the pair whenever its four triangulated depths happen to be positive -- which they are for
 //      cameras that face each other (the 3-D segment then lies behind one camera for one endpoint, which :931 does not
-//      look at; measured: 1 % of the reference's candidates of an opposing camera pair).  e_d is only evaluated when it
-//      can matter: per source segment one scalar test tells whether e_d misses the bounding box of the tile's target
-//      endpoints (it nearly always does unless the epipole is in or near the image); then the plain sector test is exact.
-//      Symmetrically for the source segment and the target's lines.  The lines are pre-divided by their margins (1e-4 of
+//      look at; measured: 1 % of the reference's candidates of an opposing camera pair).  e_d is tested once per source
+//      segment against the bounding box of the tile's target endpoints (it nearly always misses it unless the epipole is
+//      in or near the image): then no target segment of the tile can cross it and the plain sector test is exact; otherwise
+//      the sector test of that source segment is switched off (its lines are zeroed for level 1) and level 2, which works
+//      with the finite interval between the intersection points like the reference, decides.  Symmetrically for the source
+//      segment and each target's lines.  The lines are pre-divided by their margins (1e-4 of
 //      the term magnitudes, ~0.2 px, against ~1e-6 relative float error), so the test is min/max chains against +-1.
 //      ~12 % of the pairs survive.
 //   2. overlap-bound test on the survivors (~110 ops, FMA, reciprocals, no square root): D_segment_overlap_2D of
@@ -67,13 +69,12 @@ constexpr float kWedgeTau = 1.0e-4f;
 constexpr float kIouCond = 1.0e-2f;           // error of t = a/(a-b) in units of (1+|t|)/|a-b| (a, b in margin units)
 constexpr float kIouSlack = 1.0e-3f;
 
-struct SrcBlockInv {                          // 33 words: odd stride, gathers by segment index spread over the LDS banks
+struct SrcBlockInv {                          // 35 words: odd stride, gathers by segment index spread over the LDS banks
     SrcPairInv s;                             // exact invariants of the pair test
     f3 e1s, e2s;                              // epipolar lines of p1 / p2 divided by their wedge margins
     f3 ray1, ray2;                            // normalize(RtKinv_src * p1), (* p2): the reference's float sequence
-    f3 eds;                                   // e_d = e1 - e2 divided by its margin
-    int dsafe;                                // 1: e_d misses the bounding box of this tile's target endpoints (plain sector test is exact)
-    float pad;
+    f3 e1w, e2w;                              // the same two lines for the level-1 sector test, or zero where e_d = e1 - e2 may cross the tile
+    float pad;                                // (35 words)
 };
 struct TgtBlockInv {                          // 29 words
     TgtPairInv t;
@@ -111,7 +112,6 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     __shared__ SrcBlockInv s_src[kSrcPerBlock];
     __shared__ TgtBlockInv s_tgt[256];
     __shared__ float s_cam[9 + 9 + 3 + 9];   // F, RtKinv_tgt, C_tgt of this camera, RtKinv_src
-    __shared__ float s_ext[4];           // max |x|, |y| of this tile's target endpoints / this block's source endpoints
     __shared__ float s_boxw[4][8];       // per wave: {min x, max x, min y, max y} of its target endpoints, of its source endpoints
     __shared__ unsigned short s_qa[4][kPairQueue];
     __shared__ unsigned short s_qb[4][kPairQueue];
@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     else if (tid < 21) s_cam[tid] = a.centers[cam * 3 + (tid - 18)];
     else if (tid < 30) s_cam[tid] = a.RtKinv_src[tid - 21];
     for (int i = tid; i < kSrcPerBlock * 4; i += 256) s_bits[i] = 0ull;
-    if (tid < 4) s_ext[tid] = 0.0f;
     __syncthreads();
 
     const f3 C_tgt = mk3(s_cam[18], s_cam[19], s_cam[20]);
@@ -148,30 +147,26 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
     s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
     const int ny = min(a.src_per_block, a.seg_end - y0);
-    {   // coordinate extents for the wedge margins (non-negative floats order like ints)
-        float ex = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.x), __builtin_fabsf(tseg.z)) : 0.0f;
-        float ey = valid ? __builtin_fmaxf(__builtin_fabsf(tseg.y), __builtin_fabsf(tseg.w)) : 0.0f;
-        for (int o = 32; o > 0; o >>= 1) { ex = __builtin_fmaxf(ex, __shfl_down(ex, o)); ey = __builtin_fmaxf(ey, __shfl_down(ey, o)); }
-        if (lane == 0) { atomicMax(reinterpret_cast<int*>(&s_ext[0]), __float_as_int(ex)); atomicMax(reinterpret_cast<int*>(&s_ext[1]), __float_as_int(ey)); }
-        if (tid < ny) {
-            const float4 sg = a.src_segs[y0 + tid];
-            atomicMax(reinterpret_cast<int*>(&s_ext[2]), __float_as_int(__builtin_fmaxf(__builtin_fabsf(sg.x), __builtin_fabsf(sg.z))));
-            atomicMax(reinterpret_cast<int*>(&s_ext[3]), __float_as_int(__builtin_fmaxf(__builtin_fabsf(sg.y), __builtin_fabsf(sg.w))));
-        }
-        // signed bounding boxes (for the e_d tests): wave reductions, combined by every thread after the barrier
+    {   // bounding boxes of this tile's target endpoints and this block's source endpoints: wave reductions, combined by every
+        // thread after the barrier (the source segments sit in the first waves only)
         const float big = 3.0e38f;
-        float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool sv = tid < ny;
-        if (sv) sg = a.src_segs[y0 + tid];
         float bx0 = valid ? __builtin_fminf(tseg.x, tseg.z) : big, bx1 = valid ? __builtin_fmaxf(tseg.x, tseg.z) : -big;
         float by0 = valid ? __builtin_fminf(tseg.y, tseg.w) : big, by1 = valid ? __builtin_fmaxf(tseg.y, tseg.w) : -big;
-        float cx0 = sv ? __builtin_fminf(sg.x, sg.z) : big, cx1 = sv ? __builtin_fmaxf(sg.x, sg.z) : -big;
-        float cy0 = sv ? __builtin_fminf(sg.y, sg.w) : big, cy1 = sv ? __builtin_fmaxf(sg.y, sg.w) : -big;
         for (int o = 32; o > 0; o >>= 1) {
             bx0 = __builtin_fminf(bx0, __shfl_down(bx0, o)); bx1 = __builtin_fmaxf(bx1, __shfl_down(bx1, o));
             by0 = __builtin_fminf(by0, __shfl_down(by0, o)); by1 = __builtin_fmaxf(by1, __shfl_down(by1, o));
-            cx0 = __builtin_fminf(cx0, __shfl_down(cx0, o)); cx1 = __builtin_fmaxf(cx1, __shfl_down(cx1, o));
-            cy0 = __builtin_fminf(cy0, __shfl_down(cy0, o)); cy1 = __builtin_fmaxf(cy1, __shfl_down(cy1, o));
+        }
+        float cx0 = big, cx1 = -big, cy0 = big, cy1 = -big;
+        if (wave * 64 < ny) {                                                       // (wave-uniform)
+            if (tid < ny) {
+                const float4 sg = a.src_segs[y0 + tid];
+                cx0 = __builtin_fminf(sg.x, sg.z); cx1 = __builtin_fmaxf(sg.x, sg.z);
+                cy0 = __builtin_fminf(sg.y, sg.w); cy1 = __builtin_fmaxf(sg.y, sg.w);
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                cx0 = __builtin_fminf(cx0, __shfl_down(cx0, o)); cx1 = __builtin_fmaxf(cx1, __shfl_down(cx1, o));
+                cy0 = __builtin_fminf(cy0, __shfl_down(cy0, o)); cy1 = __builtin_fmaxf(cy1, __shfl_down(cy1, o));
+            }
         }
         if (lane == 0) {
             s_boxw[wave][0] = bx0; s_boxw[wave][1] = bx1; s_boxw[wave][2] = by0; s_boxw[wave][3] = by1;
@@ -185,40 +180,43 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         const float v0 = s_boxw[0][i], v1 = s_boxw[1][i], v2 = s_boxw[2][i], v3 = s_boxw[3][i];
         box[i] = (i & 1) ? __builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3)) : __builtin_fminf(__builtin_fminf(v0, v1), __builtin_fminf(v2, v3));
     }
+    // coordinate extents for the margins: max |x|, |y| of the target endpoints (0, 1) / of the source endpoints (2, 3)
+    const float ext0 = __builtin_fmaxf(__builtin_fabsf(box[0]), __builtin_fabsf(box[1])), ext1 = __builtin_fmaxf(__builtin_fabsf(box[2]), __builtin_fabsf(box[3]));
+    const float ext2 = __builtin_fmaxf(__builtin_fabsf(box[4]), __builtin_fabsf(box[5])), ext3 = __builtin_fmaxf(__builtin_fabsf(box[6]), __builtin_fabsf(box[7]));
     if (tid < ny) {
         SrcBlockInv& b = s_src[tid];
         const SrcPairInv si = make_src_inv(a.src_segs[y0 + tid], s_cam);
         // a zero margin (degenerate line) gives inf/nan below: comparisons fail, nothing is culled
-        const float m1 = kWedgeTau * (__builtin_fabsf(si.epi_p1.x) * s_ext[0] + __builtin_fabsf(si.epi_p1.y) * s_ext[1] + __builtin_fabsf(si.epi_p1.z));
-        const float m2 = kWedgeTau * (__builtin_fabsf(si.epi_p2.x) * s_ext[0] + __builtin_fabsf(si.epi_p2.y) * s_ext[1] + __builtin_fabsf(si.epi_p2.z));
+        const float m1 = kWedgeTau * (__builtin_fabsf(si.epi_p1.x) * ext0 + __builtin_fabsf(si.epi_p1.y) * ext1 + __builtin_fabsf(si.epi_p1.z));
+        const float m2 = kWedgeTau * (__builtin_fabsf(si.epi_p2.x) * ext0 + __builtin_fabsf(si.epi_p2.y) * ext1 + __builtin_fabsf(si.epi_p2.z));
         const float i1 = 1.0f / m1, i2 = 1.0f / m2;
         b.s = si;
         b.e1s = i1 * si.epi_p1; b.e2s = i2 * si.epi_p2;
         b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2));
-        // e_d = e1 - e2 cancels: its margin is the sum of the two lines' margins, not 1e-4 of its own (small) terms
+        // e_d = e1 - e2 against the bounding box of the tile's target endpoints (e_d cancels: its margin is the sum of the two
+        // lines' margins, not 1e-4 of its own small terms).  Where it may cross the box the sector test of this source segment
+        // is switched off (zero lines: all four values 0, never > 1 or < -1); level 2 decides those pairs.
         const f3 ed = si.epi_p1 - si.epi_p2;
         const float md = m1 + m2;
-        b.eds = (1.0f / md) * ed;
         const float lo = ed.z + __builtin_fminf(ed.x * box[0], ed.x * box[1]) + __builtin_fminf(ed.y * box[2], ed.y * box[3]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[0], ed.x * box[1]) + __builtin_fmaxf(ed.y * box[2], ed.y * box[3]);
-        b.dsafe = (lo > md || hi < -md) ? 1 : 0;               // (NaN/inf: comparisons fail, the line is evaluated per pair)
+        const bool dsafe = lo > md || hi < -md;                // (NaN/inf: comparisons fail -> not safe)
+        b.e1w = dsafe ? b.e1s : mk3(0.0f, 0.0f, 0.0f);
+        b.e2w = dsafe ? b.e2s : mk3(0.0f, 0.0f, 0.0f);
     }
-    f3 eq1s, eq2s, eqds;                     // this lane's epipolar lines (in the source image) and their difference e_d, over their margins
-    bool t_safe;                             // this lane's e_d misses the bounding box of the block's source endpoints
+    f3 eq1s, eq2s;                           // this lane's epipolar lines (in the source image) over their margins, for level 1
     {
-        const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * s_ext[2] + __builtin_fabsf(t.epi_q1.y) * s_ext[3] + __builtin_fabsf(t.epi_q1.z));
-        const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * s_ext[2] + __builtin_fabsf(t.epi_q2.y) * s_ext[3] + __builtin_fabsf(t.epi_q2.z));
+        const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * ext2 + __builtin_fabsf(t.epi_q1.y) * ext3 + __builtin_fabsf(t.epi_q1.z));
+        const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * ext2 + __builtin_fabsf(t.epi_q2.y) * ext3 + __builtin_fabsf(t.epi_q2.z));
         eq1s = (1.0f / mq1) * t.epi_q1; eq2s = (1.0f / mq2) * t.epi_q2;
-        s_tgt[tid].e1s = eq1s; s_tgt[tid].e2s = eq2s;
+        s_tgt[tid].e1s = eq1s; s_tgt[tid].e2s = eq2s;                              // (level 2 reads the real lines from LDS)
         const f3 ed = t.epi_q1 - t.epi_q2;
         const float md = mq1 + mq2;
-        eqds = (1.0f / md) * ed;
         const float lo = ed.z + __builtin_fminf(ed.x * box[4], ed.x * box[5]) + __builtin_fminf(ed.y * box[6], ed.y * box[7]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[4], ed.x * box[5]) + __builtin_fmaxf(ed.y * box[6], ed.y * box[7]);
-        t_safe = !valid || lo > md || hi < -md;
+        if (!(lo > md || hi < -md)) { eq1s = mk3(0.0f, 0.0f, 0.0f); eq2s = mk3(0.0f, 0.0f, 0.0f); }   // this target's sector test is off
     }
-    const bool wave_tsafe = __all(t_safe);        // wave-uniform: the target lines' e_d is evaluated per pair only where it can matter
-    const float ext = __builtin_fmaxf(__builtin_fmaxf(s_ext[0], s_ext[1]), __builtin_fmaxf(s_ext[2], s_ext[3]));
+    const float ext = __builtin_fmaxf(__builtin_fmaxf(ext0, ext1), __builtin_fmaxf(ext2, ext3));
     __syncthreads();
 
     unsigned short* qa = s_qa[wave];
@@ -239,23 +237,15 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
             if (use_wedge) {
                 // both endpoints against one line at once: packed FP32 FMAs (v_pk_fma_f32), two lanes of work per instruction
                 const v2f qx = { t.q1.x, t.q2.x }, qy = { t.q1.y, t.q2.y };
-                const v2f a12 = pk_line(sb.e1s, qx, qy), a34 = pk_line(sb.e2s, qx, qy);
+                const v2f a12 = pk_line(sb.e1w, qx, qy), a34 = pk_line(sb.e2w, qx, qy);
                 const float lo2 = __builtin_fminf(__builtin_fminf(a12.x, a12.y), __builtin_fminf(a34.x, a34.y));
                 const float hi2 = __builtin_fmaxf(__builtin_fmaxf(a12.x, a12.y), __builtin_fmaxf(a34.x, a34.y));
-                bool out2 = lo2 > 1.0f || hi2 < -1.0f;              // target segment strictly inside one same-sign sector ...
-                if (!__builtin_amdgcn_readfirstlane(sb.dsafe)) {    // ... and, where e_d crosses the tile, strictly on one side of it
-                    const v2f c12 = pk_line(sb.eds, qx, qy);
-                    out2 = out2 && (__builtin_fminf(c12.x, c12.y) > 1.0f || __builtin_fmaxf(c12.x, c12.y) < -1.0f);
-                }
+                const bool out2 = lo2 > 1.0f || hi2 < -1.0f;        // target segment strictly inside one same-sign sector of e1, e2 (and off e_d)
                 const v2f px = { sb.s.p1.x, sb.s.p2.x }, py = { sb.s.p1.y, sb.s.p2.y };
                 const v2f b12 = pk_line(eq1s, px, py), b34 = pk_line(eq2s, px, py);
                 const float lo1 = __builtin_fminf(__builtin_fminf(b12.x, b12.y), __builtin_fminf(b34.x, b34.y));
                 const float hi1 = __builtin_fmaxf(__builtin_fmaxf(b12.x, b12.y), __builtin_fmaxf(b34.x, b34.y));
-                bool out1 = lo1 > 1.0f || hi1 < -1.0f;              // the same for the source segment and the target's lines
-                if (!wave_tsafe) {
-                    const v2f d12 = pk_line(eqds, px, py);
-                    out1 = out1 && (t_safe || __builtin_fminf(d12.x, d12.y) > 1.0f || __builtin_fmaxf(d12.x, d12.y) < -1.0f);
-                }
+                const bool out1 = lo1 > 1.0f || hi1 < -1.0f;        // the same for the source segment and the target's lines
                 cand = valid && !out1 && !out2;
             }
             const unsigned long long cm = __ballot(cand);
