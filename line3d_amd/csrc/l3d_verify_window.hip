@@ -20,17 +20,9 @@
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
 #include "l3d_kept.hpp"
+#include "l3d_verify_eval.hpp"
 
 namespace l3d {
-
-// Window half-width for depth d_y: any witness that passes the reference gate sqrtf(|X_y - X_i|^2) <= unc
-// satisfies |d_y - d_i| <= unc*(1+8u) + 3.5u*(|d_y| + |d_i| + |C|_inf) with u = 2^-24 (two roundings per
-// coordinate of X = C + d*ray, one for the difference, dot/sqrt relative 3u, |ray| = 1 +- 3u).  The margin
-// below is > 5x that bound; dabs_max bounds |d_i| for the whole segment.
-__device__ __forceinline__ float window_margin(float unc, float d_y, float dabs_max, float c_inf)
-{
-    return unc * 1.00001f + 2.0e-6f * (d_y + dabs_max + c_inf);
-}
 
 // LDS image of one source segment: ALL its candidates bucketed by the first depth d1.  Depths are positive floats,
 // whose bit patterns are monotone in the value and roughly logarithmic, so (bits >> kBucketShift) is an order
@@ -82,30 +74,7 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
     const f3 hv = mk3(__shfl(v1.x, origin), __shfl(v1.y, origin), __shfl(v1.z, origin));
     const float hT1 = __shfl(T1, origin), hT2 = __shfl(T2, origin);
     if (lane >= n) return;
-    const f3 Q1 = C + wd1 * ray1;                                        // D_unproject_point_src, :669-672
-    const f3 Q2 = C + wd2 * ray2;
-    if (gate) {
-        const f3 e1 = hX1 - Q1, e2 = hX2 - Q2;
-        if (dot(e1, e1) > hT1 || dot(e2, e2) > hT2) return;              // :396-400 on squared distances
-    }
-    bool va, vb;
-    const f3 pr1 = project(sP + cam * 12, hX1, va);
-    const f3 pr2 = project(sP + cam * 12, hX2, vb);
-    if (!(va && vb)) return;
-    const f3 line1 = cross(pr1, pr2);
-    const float den1 = line_norm2d(line1);
-    const f3 q1 = mk3(tq.x, tq.y, 1.0f), q2 = mk3(tq.z, tq.w, 1.0f);
-    const f3 l2 = cross(q1, q2);
-    const float den2 = line_norm2d(l2);
-    const float dd1 = __builtin_fmaxf(__builtin_fabsf(line_numer(l2, pr1) / den2), __builtin_fabsf(line_numer(l2, pr2) / den2));
-    const float dd2 = __builtin_fmaxf(__builtin_fabsf(line_numer(line1, q1) / den1), __builtin_fabsf(line_numer(line1, q2) / den1));
-    const float dist = __builtin_fmaxf(dd1, dd2);
-    const f3 v2 = normalize(Q1 - Q2);
-    const float cs = __builtin_fmaxf(__builtin_fminf(dot(hv, v2), 1.0f), -1.0f);
-    float angle = (float)((double)c_acosf(cs) / 3.1415926535897931e+0 * (double)180.0f);
-    if (angle > 90.0f) angle = 180.0f - angle;
-    const float cd = c_expf(-dist * dist / two_sig_d);
-    const float conf = __builtin_fminf(cd, c_expf(-angle * angle / two_sig_a));
+    const float conf = witness_conf(C, ray1, ray2, hX1, hX2, hv, hT1, hT2, gate, wd1, wd2, sP + cam * 12, tq, two_sig_d, two_sig_a);
     if (conf > 0.5f)                                                     // :699-704 (max over the camera's witnesses)
         atomicMax(reinterpret_cast<int*>(&smax_wave[cam * 64 + origin]), __float_as_int(conf));
 }
@@ -185,6 +154,8 @@ void k_verify_window(VerifyArgs a)
     int* sOff = reinterpret_cast<int*>(sP + a.N * 12);
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
+    __shared__ int s_tbm[64];                                                // part A of the split chain: cameras whose maxima are stored
+    if (a.max_out) for (int i = tid; i < 64; i += NT) s_tbm[i] = i < a.n_tbm ? a.tbm[i] : 0;
     float* smax_wave = smax + wave * 64 * a.N;
 
     // ---- one coalesced pass over the segment's candidates (kept in registers), counting sort on the depth bucket
@@ -356,6 +327,17 @@ void k_verify_window(VerifyArgs a)
         for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[c * 64 + lane];   // ascending camera order; +0.0f is exact
         if (hv) {
             a.cand_conf[start + idx_h] = conf_sum;
+            if (a.max_out && conf_sum != 0.0f) {                    // (a zero sum of non-negative terms: every maximum is zero, nothing to store)
+                float4* mo = reinterpret_cast<float4*>(a.max_out + (size_t)(start + (int)idx_h) * a.max_stride);
+                for (int j = 0; j < a.max_stride; j += 4) {
+                    float4 v;
+                    v.x = smax_wave[s_tbm[j] * 64 + lane];
+                    v.y = j + 1 < a.n_tbm ? smax_wave[s_tbm[j + 1] * 64 + lane] : 0.0f;
+                    v.z = j + 2 < a.n_tbm ? smax_wave[s_tbm[j + 2] * 64 + lane] : 0.0f;
+                    v.w = j + 3 < a.n_tbm ? smax_wave[s_tbm[j + 3] * 64 + lane] : 0.0f;
+                    mo[j >> 2] = v;
+                }
+            }
             kept_l += conf_sum > 1.0f;
             if (conf_sum > best_l || (conf_sum == best_l && (int)idx_h < besti_l)) { best_l = conf_sum; besti_l = (int)idx_h; }
         }
