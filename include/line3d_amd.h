@@ -187,6 +187,14 @@ int l3d_exchange_rccl(void* user, int view, const void* send_slot, void* recv_bl
 int l3d_exchange_local(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
 int l3d_exchange_replay(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream);
 const void* l3d_shard_chain_gathered(l3d_shard_chain* chain);   /* device address of the gathered blocks after l3d_shard_chain_run */
+/* A rank that fails inside l3d_shard_chain_run (capacity, HIP error, failing callback) keeps calling `exchange` for every
+ * remaining view with a slot that says "gave up": no rank is left waiting in a collective.  Afterwards every rank reads the
+ * same verdict out of the gathered slot headers: L3D_ERR_NOMEM on ALL ranks when any slot overflowed.  l3d_shard_chain_info
+ * (any out pointer may be NULL): this chain's candidate capacity and slot_records, and after a run the OR of the ranks'
+ * overflow bits (1 candidate capacity, 2 slot_records, 4 a rank gave up) and the largest candidate / kept count one rank
+ * reported for one view -- what a caller needs to reopen with more room (l3d_set_chain_capacities sets the candidate capacity
+ * of the next chain); l3d_line3d_shard_run does exactly that, up to three times. */
+int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept);
 
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A

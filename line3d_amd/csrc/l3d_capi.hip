@@ -24,7 +24,7 @@ static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
 static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
 
 namespace {
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;chain_verify;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
 }  // namespace
 
 extern "C" {
@@ -55,11 +55,6 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
     }
-    if (hipStreamCreateWithFlags(&c->ahead_stream, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipStreamDestroy(c->stage1_stream); (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
-    }
-    if (const char* e = getenv("L3D_CHAIN_SPLIT")) c->chain_split = atoi(e) != 0;
-    if (const char* e = getenv("L3D_BIN_CAP")) c->bin_cap = std::max(1, std::min(64, atoi(e)));
     if (getenv("L3D_PAIR_STATS") && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 64) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 64);
     *out = c;
     return L3D_OK;
@@ -93,14 +88,11 @@ void l3d_ctx_destroy(l3d_ctx* c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
                        &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
-                       &c->sp_bin_cnt, &c->sp_bin_id, &c->sp_bin_depth, &c->sp_ovf_cnt, &c->sp_ovf_key, &c->sp_ovf_depth, &c->sp_vflags, &c->sp_confA, &c->sp_maxA,
-                       &c->sp_rev_meta, &c->sp_rev_depth, &c->sp_rev_conf, &c->sp_rev_max, &c->sp_rev_tmp_meta, &c->sp_rev_tmp_depth, &c->sp_rev_seg, &c->sp_kept_cnt, &c->sp_segorder,
                        &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);
-    (void)hipStreamDestroy(c->ahead_stream);
     (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);

@@ -222,9 +222,6 @@ struct ViewDev {            // device addresses of one view's static tables and 
     float2* best;
     int W64, maxW;
     bool verified;
-    // split chain: this view's bins in the global bin space, static tables (slot offsets per camera to be matched, sources)
-    int bin_first = 0, n_bins = 0;
-    size_t o_bso = 0, o_ss = 0;
 };
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -248,10 +245,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // ---- validation, table layout
     std::vector<ViewDev> vd((size_t)n_views);
     size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
-    int maxS = 0, maxN = 0, maxTbm = 0, maxSrc = 0;
-    long long total_bins = 0;
-    // the split chain (l3d_chain_split.hip) applies when every view can take the depth-window kernel and the chain kernel's LDS image
-    bool split = c->chain_split != 0 && c->chain_ring != 0 && c->verify_mode == 0;
+    int maxS = 0, maxN = 0;
     for (int k = 0; k < n_views; ++k) {
         const l3d_chain_view& v = views[k];
         if (v.S_src < 0 || v.N < 0 || v.n_tbm < 0 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0)
@@ -288,16 +282,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
         d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
         d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
-        d.o_bso = o; o += (size_t)v.n_tbm * 4;
-        o = align16(o);
-        d.o_ss = o; o += (size_t)v.n_sources * sizeof(SplitSource);
         tab_bytes = align16(o);
-        if (!verify_window_supported(v.N) || !chain_split_supported(v.N) || v.S_src > 65535 || maxW > 65535) split = false;
-        d.bin_first = (int)total_bins;
-        for (int j = 0; j < v.n_tbm; ++j) total_bins += v.offsets[2 * v.to_be_matched[j] + 1];
-        d.n_bins = (int)(total_bins - d.bin_first);
-        if (total_bins > 0x7fff0000ll) split = false;
-        maxTbm = std::max(maxTbm, v.n_tbm); maxSrc = std::max(maxSrc, v.n_sources);
         mask_bytes += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
         rowcnt_ints += (size_t)v.S_src * v.N;
         best_elems += (size_t)v.S_src;
@@ -318,28 +303,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
         memcpy(tab + d.o_l2g, v.local2global, N * 4);
         if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
-        {   // split chain: where the bins of each camera to be matched start; where each source keeps its bins towards this view
-            int* bso = reinterpret_cast<int*>(tab + d.o_bso);
-            int run = 0;
-            for (int j = 0; j < v.n_tbm; ++j) { bso[j] = run; run += v.offsets[2 * v.to_be_matched[j] + 1]; }
-            SplitSource* ss = reinterpret_cast<SplitSource*>(tab + d.o_ss);
-            for (int s2 = 0; s2 < v.n_sources; ++s2) {
-                const int a = v.source_index[s2];
-                const l3d_chain_view& u = views[a];
-                const ViewDev& du = vd[(size_t)a];
-                SplitSource e;
-                e.bin_first = -1; e.n_bins = 0; e.view = a; e.cam = v.source_cam[s2];
-                if (du.verified) {
-                    int off = 0;
-                    for (int j = 0; j < u.n_tbm; ++j) {
-                        const int cu = u.to_be_matched[j];
-                        if (u.local2global[cu] == v.view_id) { e.bin_first = du.bin_first + off; e.n_bins = u.offsets[2 * cu + 1]; break; }
-                        off += u.offsets[2 * cu + 1];
-                    }
-                }
-                ss[s2] = e;
-            }
-        }
     }
     HIPCHK(c, hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
     const unsigned char* dtab = c->ch_tables.as<unsigned char>();
@@ -355,20 +318,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
     HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
-    const int B = c->bin_cap;
-    size_t ovf_cap = c->test_ovf_cap ? c->test_ovf_cap : 4096;          // records per view beyond the bins (guarded; grows on restart)
-    if (split) {
-        HIPCHK(c, c->sp_bin_cnt.reserve(((size_t)total_bins + 4) * 4));
-        HIPCHK(c, c->sp_bin_id.reserve(((size_t)total_bins * B + 4) * 4));
-        HIPCHK(c, c->sp_bin_depth.reserve(((size_t)total_bins * B + 1) * 16));
-        HIPCHK(c, c->sp_ovf_cnt.reserve((size_t)n_views * 4 + 16));
-        HIPCHK(c, c->sp_ovf_key.reserve((size_t)n_views * ovf_cap * 8 + 16));
-        HIPCHK(c, c->sp_ovf_depth.reserve((size_t)n_views * ovf_cap * 16 + 16));
-        HIPCHK(c, c->sp_vflags.reserve((size_t)n_views * 8 + 16));      // per view: reverse-store cursor, overflow flags
-        HIPCHK(c, hipMemsetAsync(c->sp_bin_cnt.p, 0, ((size_t)total_bins + 4) * 4, st));
-        HIPCHK(c, hipMemsetAsync(c->sp_ovf_cnt.p, 0, (size_t)n_views * 4, st));
-        HIPCHK(c, hipMemsetAsync(c->sp_vflags.p, 0, (size_t)n_views * 8, st));
-    }
     {   // stage 1 starts after the tables and the zeroed row counts are in place
         hipEvent_t ready = get_event(c);
         HIPCHK(c, hipEventRecord(ready, st));
@@ -454,30 +403,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;
 
-    size_t rev_cap = 0;                 // reverse matches of one view (split chain): a fixed slot per segment + a guarded tail that grows on restart
-    const int kRevStride = 32;
     auto reserve_caps = [&]() -> int {
-        if (split) {
-            // everything the views in flight produce lives in ring slots: stage-1 candidates, their part-A confidences and
-            // per-camera maxima, the view's ordered reverse matches, per-segment tables
-            if (!rev_cap) rev_cap = (size_t)maxS * kRevStride + (c->test_rev_cap ? c->test_rev_cap : cand_cap / 16 + 65536);
-            HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
-            HIPCHK(c, c->ch_ringA_depths.reserve((size_t)kRing * cand_cap * 16));
-            HIPCHK(c, c->sp_confA.reserve((size_t)kRing * cand_cap * 4));
-            HIPCHK(c, c->sp_maxA.reserve((size_t)kRing * cand_cap * 4 * (size_t)((std::max(1, maxTbm) + 3) & ~3) + 64));
-            HIPCHK(c, c->sp_rev_meta.reserve((size_t)kRing * rev_cap * 8));
-            HIPCHK(c, c->sp_rev_depth.reserve((size_t)kRing * rev_cap * 16));
-            HIPCHK(c, c->sp_rev_conf.reserve((size_t)kRing * rev_cap * 4));
-            HIPCHK(c, c->sp_rev_max.reserve((size_t)kRing * rev_cap * 4 * (size_t)std::max(1, maxN)));
-            HIPCHK(c, c->sp_rev_tmp_meta.reserve((size_t)kRing * rev_cap * 8));
-            HIPCHK(c, c->sp_rev_tmp_depth.reserve((size_t)kRing * rev_cap * 16));
-            HIPCHK(c, c->sp_rev_seg.reserve((size_t)kRing * ((size_t)maxS + 2) * 8));
-            HIPCHK(c, c->sp_kept_cnt.reserve((size_t)kRing * ((size_t)maxS + 4) * 4));
-            HIPCHK(c, c->sp_segorder.reserve((size_t)kRing * ((size_t)maxS + 4) * 4));
-            HIPCHK(c, c->vw_scratch.reserve((cand_cap + kVWSlack) * 16));
-            HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
-            return L3D_OK;
-        }
         HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
         HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
         HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
@@ -499,12 +425,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // stage-1 candidates in place instead of copying them (k_place) -- 20 % SLOWER: the copy is a streaming pass that
     // leaves the candidates cache-hot for the latency-bound kernels that follow.)
     const bool use_ring = c->chain_ring != 0;
-    // ring-slot products of the split chain
-    auto slot_confA = [&](int k) { return c->sp_confA.as<float>() + (size_t)(k % kRing) * cand_cap; };
-    const size_t max_stride = (size_t)((std::max(1, maxTbm) + 3) & ~3);       // floats per row of part A's per-camera maxima
-    auto slot_maxA = [&](int k) { return c->sp_maxA.as<float>() + (size_t)(k % kRing) * cand_cap * max_stride; };
-    auto slot_segorder = [&](int k) { return c->sp_segorder.as<int>() + (size_t)(k % kRing) * ((size_t)maxS + 4); };
-    auto slot_kept_cnt = [&](int k) { return c->sp_kept_cnt.as<int>() + (size_t)(k % kRing) * ((size_t)maxS + 4); };
     auto enqueue_fillA = [&](int k, hipStream_t s) {
         if (!use_ring) return;
         const ViewDev& d = vd[(size_t)k];
@@ -523,12 +443,11 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
                 ProfScope p(c, "pair_mask", s1);
                 launch_pair_mask(pm, vd[(size_t)k].maxW, s1);
             }
+            // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch)
+            if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
+            else launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
             // the ring slot was last used by view k - kRing: wait until its chain has consumed it
             for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(s1, ev[(size_t)j], 0)); break; }
-            // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch; split chain: +
-            // the segments ordered longest first for part A's verification launch)
-            if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, split ? slot_segorder(k) : nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
-            else launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
             enqueue_fillA(k, s1);
         }
         ev1[(size_t)k] = get_event(c);
@@ -537,102 +456,10 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     };
 
     double t_ev1 = 0;                   // host time spent waiting for stage-1 statistics
-    // ---- split chain, part A: stage-1 hypotheses against stage-1 witnesses -- no dependency on earlier views; runs a few views
-    // ahead of the chain on its own stream (the heavy, latency-bound launch of a view overlaps stage 1 of later views)
-    hipStream_t s2 = serial ? st : c->ahead_stream;
-    std::vector<hipEvent_t> evA((size_t)n_views, nullptr);
-    int k_pA = 0;                       // next view whose part A is enqueued
-    const int kAAhead = 3;
-    auto enqueue_A = [&](int k) -> int {
-        const l3d_chain_view& v = views[k];
-        const ViewDev& d = vd[(size_t)k];
-        if (!d.verified) return L3D_OK;
-        const double te0 = now_s();
-        HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
-        t_ev1 += now_s() - te0;
-        HIPCHK(c, hipStreamWaitEvent(s2, ev1[(size_t)k], 0));
-        if (v.S_src > 0) {
-            const PairArgs pa = pair_args(k);
-            VerifyArgs va;
-            va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
-            va.P = reinterpret_cast<const float*>(dtab + d.o_P);
-            va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
-            va.row_start = d.rowA;
-            va.cand_meta = ringA_meta(k); va.cand_depths = ringA_depths(k); va.cand_conf = slot_confA(k);
-            va.N = v.N; va.seg_begin = 0; va.seg_end = v.S_src; va.nrow_total = v.S_src * v.N;
-            va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
-            va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = nullptr;
-            va.seg_order = slot_segorder(k);
-            int mmax = hstats[2 * k + 1] + 8;
-            while (mmax > 64 && verify_window_lds_bytes(mmax, v.N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
-            va.mmax = mmax;
-            va.skip_above = 1; va.only_above = -1; va.big = 2;
-            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + kVWSlack;
-            va.kept_cnt = nullptr; va.best_depths = nullptr; va.exist_cams = nullptr; va.n_exist_cams = 0;
-            va.max_out = slot_maxA(k); va.tbm = pa.tbm; va.n_tbm = v.n_tbm; va.max_stride = (v.n_tbm + 3) & ~3;
-            (void)hipGetLastError();
-            { ProfScope p(c, "verify_window", s2); launch_verify_window(va, s2); }
-            { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch (part A), view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-        }
-        if (!evA[(size_t)k]) evA[(size_t)k] = get_event(c);
-        HIPCHK(c, hipEventRecord(evA[(size_t)k], s2));
-        return L3D_OK;
-    };
-    auto split_args = [&](int k) {
-        const l3d_chain_view& v = views[k];
-        const ViewDev& d = vd[(size_t)k];
-        const PairArgs pa = pair_args(k);
-        ChainSplitArgs sa;
-        sa.src_segs = d.src; sa.tgt_segs = d.tgt; sa.offsets = pa.offsets;
-        sa.P = reinterpret_cast<const float*>(dtab + d.o_P);
-        sa.RtKinv_src = pa.RtKinv_src; sa.C_src = pa.C_src;
-        sa.tbm = pa.tbm; sa.local2global = reinterpret_cast<const unsigned*>(dtab + d.o_l2g);
-        sa.n_tbm = v.n_tbm; sa.N = v.N; sa.S = v.S_src;
-        sa.sigma_p = v.sigma_p; sa.sigma_a = v.sigma_a; sa.spatial_k = v.spatial_k;
-        sa.rowA = d.rowA; sa.metaA = ringA_meta(k); sa.depthsA = ringA_depths(k); sa.confA = slot_confA(k); sa.maxA = slot_maxA(k);
-        sa.cand_cap = (int)cand_cap; sa.max_stride = (v.n_tbm + 3) & ~3;
-        for (int i = 0; i < std::min(v.n_sources, kSplitInlineSrc); ++i) sa.src_inl[i] = reinterpret_cast<const SplitSource*>(tab + d.o_ss)[i];
-        sa.sources = reinterpret_cast<const SplitSource*>(dtab + d.o_ss); sa.n_src = v.n_sources;
-        sa.bin_cnt = c->sp_bin_cnt.as<int>(); sa.bin_id = c->sp_bin_id.as<unsigned>(); sa.bin_depth = c->sp_bin_depth.as<float4>(); sa.B = B;
-        sa.bin_first = d.bin_first; sa.bin_slot_off = reinterpret_cast<const int*>(dtab + d.o_bso);
-        sa.ovf_cnt_all = c->sp_ovf_cnt.as<int>(); sa.ovf_key_all = c->sp_ovf_key.as<int2>(); sa.ovf_depth_all = c->sp_ovf_depth.as<float4>();
-        sa.ovf_cap = (int)ovf_cap; sa.view_index = k;
-        const size_t so = (size_t)(k % kRing) * rev_cap;
-        sa.rev_meta = c->sp_rev_meta.as<uint2>() + so; sa.rev_depth = c->sp_rev_depth.as<float4>() + so; sa.rev_conf = c->sp_rev_conf.as<float>() + so;
-        sa.rev_tmp_meta = c->sp_rev_tmp_meta.as<uint2>() + so; sa.rev_tmp_depth = c->sp_rev_tmp_depth.as<float4>() + so;
-        sa.rev_max = c->sp_rev_max.as<float>() + so * (size_t)std::max(1, maxN);
-        sa.seg_order = slot_segorder(k);
-        sa.rev_cap = (int)rev_cap; sa.rev_stride = kRevStride;
-        sa.rev_total = c->sp_vflags.as<int>() + 2 * k; sa.flags = c->sp_vflags.as<int>() + 2 * k + 1;
-        sa.rev_seg = c->sp_rev_seg.as<int2>() + (size_t)(k % kRing) * ((size_t)maxS + 2);
-        sa.kept_cnt = slot_kept_cnt(k); sa.best_depths = d.best;
-        { static const int dbg = getenv("L3D_SPLIT_DEBUG") ? atoi(getenv("L3D_SPLIT_DEBUG")) : 0; sa.debug = dbg; }
-        return sa;
-    };
     auto enqueue_view = [&](int k) -> int {
         const l3d_chain_view& v = views[k];
         const ViewDev& d = vd[(size_t)k];
         while (k_p1 < n_views && k_p1 <= k + kStage1Ahead) { int rc = enqueue_stage1(k_p1); if (rc) return rc; ++k_p1; }
-        if (split) {
-            // ONE launch per view on the chain's critical path (k_chain_verify reads its reverse matches straight out of the earlier
-            // views' bins) + the kept-list writer
-            while (k_pA < n_views && k_pA <= k + kAAhead) { int rc = enqueue_A(k_pA); if (rc) return rc; ++k_pA; }
-            if (!d.verified) return L3D_OK;
-            HIPCHK(c, hipStreamWaitEvent(st, evA[(size_t)k], 0));
-            const ChainSplitArgs sa = split_args(k);
-            (void)hipGetLastError();
-            { ProfScope p(c, "chain_verify"); launch_chain_verify(sa, st); }
-            {
-                ProfScope p(c, "kept_write");
-                int pv = k - 1;
-                while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
-                launch_chain_kept(sa, pv >= 0 ? c->ch_res.as<ChainResult>() + pv : nullptr, (int)arena_cap, c->ch_res.as<ChainResult>() + k, hres_dev + k, c->ch_kept.as<Match>(), st);
-            }
-            { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-            if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
-            HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
-            return L3D_OK;
-        }
         if (!d.verified) return L3D_OK;
         const double te0 = now_s();
         HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
@@ -803,30 +630,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             // in the arena; wait for the queue (and the delivery of earlier views) to drain, grow, and re-enqueue from this view
             if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(s1), "hipStreamSynchronize")) break;
             wait_delivered();
-            if (split && !hip_ok(hipStreamSynchronize(s2), "hipStreamSynchronize")) break;
-            const size_t raw_k = split ? (size_t)hstats[2 * k] : (size_t)r.R;   // stage-1 candidates of the view
-            if (r.overflow & 1) cand_cap = raw_k + raw_k / 4 + 65536;
-            if (r.overflow & 8) { const size_t need = (size_t)r.R > raw_k ? (size_t)r.R - raw_k : 0; rev_cap = (size_t)maxS * kRevStride + std::max((rev_cap - (size_t)maxS * kRevStride) * 2, need + need / 4 + 65536); }
-            if (r.overflow & 4) {
-                // more hand-over records beyond the bins than the overflow lists hold: larger lists, the earlier views' entries move over
-                const size_t new_cap = ovf_cap * 4;
-                std::vector<int> cnt((size_t)n_views, 0);
-                void *nk = nullptr, *nd = nullptr;
-                if (!hip_ok(hipMemcpy(cnt.data(), c->sp_ovf_cnt.p, (size_t)n_views * 4, hipMemcpyDeviceToHost), "hipMemcpy")) break;
-                if (!hip_ok(hipMalloc(&nk, (size_t)n_views * new_cap * 8 + 16), "hipMalloc") || !hip_ok(hipMalloc(&nd, (size_t)n_views * new_cap * 16 + 16), "hipMalloc")) break;
-                bool ok = true;
-                for (int j = 0; j < k && ok; ++j) {
-                    const size_t n = std::min((size_t)std::max(cnt[(size_t)j], 0), ovf_cap);
-                    if (!n) continue;
-                    ok = hip_ok(hipMemcpy(static_cast<char*>(nk) + (size_t)j * new_cap * 8, c->sp_ovf_key.as<char>() + (size_t)j * ovf_cap * 8, n * 8, hipMemcpyDeviceToDevice), "hipMemcpy") &&
-                         hip_ok(hipMemcpy(static_cast<char*>(nd) + (size_t)j * new_cap * 16, c->sp_ovf_depth.as<char>() + (size_t)j * ovf_cap * 16, n * 16, hipMemcpyDeviceToDevice), "hipMemcpy");
-                }
-                if (!ok) break;
-                c->sp_ovf_key.release(); c->sp_ovf_depth.release();
-                c->sp_ovf_key.p = nk; c->sp_ovf_key.cap = (size_t)n_views * new_cap * 8 + 16;
-                c->sp_ovf_depth.p = nd; c->sp_ovf_depth.cap = (size_t)n_views * new_cap * 16 + 16;
-                ovf_cap = new_cap;
-            }
+            if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
             if (r.overflow & 2) {
                 // the arena cannot be reallocated without losing earlier lists that later views still read:
                 // copy it over
@@ -841,29 +645,6 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
             // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
             // and the stage-1 candidate buffers of every view in flight live in the (re-sized) ring: refill them
-            if (split) {
-                // the views from k on run again: their counters and bins start from zero, the (re-sized) ring slots of every view in
-                // flight are refilled (stage-1 stream), part A follows from view k
-                for (int j = k; j < k_enq; ++j) {
-                    const ViewDev& dj = vd[(size_t)j];
-                    if (!dj.verified) continue;
-                    if (!hip_ok(hipMemsetAsync(c->sp_vflags.as<int>() + 2 * j, 0, 8, st), "hipMemsetAsync") ||
-                        !hip_ok(hipMemsetAsync(c->sp_ovf_cnt.as<int>() + j, 0, 4, st), "hipMemsetAsync") ||
-                        (dj.n_bins && !hip_ok(hipMemsetAsync(c->sp_bin_cnt.as<int>() + dj.bin_first, 0, (size_t)dj.n_bins * 4, st), "hipMemsetAsync"))) break;
-                }
-                if (rc_final) break;
-                if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) break;
-                for (int j = k; j < k_p1; ++j) {
-                    if (!vd[(size_t)j].verified) continue;
-                    if (views[j].S_src > 0) enqueue_fillA(j, s1);
-                    if (!hip_ok(hipEventRecord(ev1[(size_t)j], s1), "hipEventRecord")) break;
-                }
-                if (rc_final) break;
-                k_pA = k;
-                k_enq = k;
-                --k;
-                continue;
-            }
             for (int j = k; j < k_p1; ++j) {
                 if (!vd[(size_t)j].verified || views[j].S_src == 0) continue;
                 if (j < k_enq) {
@@ -888,9 +669,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
                 (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
     (void)hipStreamSynchronize(s1);
-    (void)hipStreamSynchronize(s2);
     (void)hipStreamSynchronize(st);
-    for (hipEvent_t e : evA) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
     c->stats[1] = raw_sum;

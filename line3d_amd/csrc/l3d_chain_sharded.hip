@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     h.overflow = h.R > a.cand_cap ? 1 : 0;
     h.n_kept = h.overflow ? 0 : total;
     if (h.n_kept > slot_records) { h.overflow |= 2; h.n_kept = 0; }
-    h.s0 = a.seg_begin; h.s1 = a.seg_end; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    h.s0 = a.seg_begin; h.s1 = a.seg_end; h.pad[0] = total; h.pad[1] = h.pad[2] = 0;      // pad[0]: the kept count even when it did not fit
     if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<SlotHeader*>(slot) = h;
     if (yl >= nseg) return;                                  // (an empty range still launches workgroup 0 for the header)
     const int y = a.seg_begin + yl;
@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restri
     const float4* src = reinterpret_cast<const float4*>(slot + g.rec_off);
     float4* dst = reinterpret_cast<float4*>(o_rec + (size_t)base * sizeof(Match));
     for (int i = tid; i < 2 * n; i += nt) dst[i] = src[i];
+}
+
+// After the last exchange: the OR of the overflow bits of every gathered slot header (1 candidate capacity, 2 slot records,
+// 4 a rank gave up) and, for sizing a retry, the largest candidate / kept count any rank reported.  Every rank holds the same
+// gathered blocks, so every rank computes the same answer: the ranks agree on the outcome without another collective.
+__global__ void k_check_slots(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int* __restrict__ out3)
+{
+    int bits = 0, maxR = 0, maxK = 0;
+    const int n = n_views * g.world;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!verified[i / g.world]) continue;
+        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(G + (size_t)i * g.slot_bytes);
+        bits |= hd->overflow & 7;
+        maxR = max(maxR, hd->R);
+        maxK = max(maxK, hd->pad[0]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { bits |= __shfl_down(bits, o); maxR = max(maxR, __shfl_down(maxR, o)); maxK = max(maxK, __shfl_down(maxK, o)); }
+    if ((threadIdx.x & 63) == 0) { if (bits) atomicOr(&out3[0], bits); atomicMax(&out3[1], maxR); atomicMax(&out3[2], maxK); }
 }
 
 }  // namespace l3d
@@ -224,6 +242,7 @@ struct l3d_shard_chain {
     int copy_issued = -1;                    // view whose D2H copy the previous fetch has already issued (fetch thread only)
     l3d_match* copy_dst = nullptr;           // ... and where its records go (pinned arena)
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
+    int outcome[3] = { 0, 0, 0 };            // after l3d_shard_chain_run: OR of the ranks' overflow bits, largest candidate / kept count of a slot
 };
 
 extern "C" {
@@ -338,7 +357,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
         OCHK(hipStreamWaitEvent(c->stage1_stream, ready, 0));
         c->event_pool.push_back(ready);
     }
-    h->cand_cap = (size_t)(max_pairs * 0.12) + 65536;
+    h->cand_cap = c->test_cand_cap ? c->test_cand_cap : (size_t)(max_pairs * 0.12) + 65536;     // (l3d_set_chain_capacities: tests, retries with more room)
     const size_t nrow_max = (size_t)h->maxS * h->maxN;
     OCHK(c->row_start.reserve((nrow_max + 1) * 4));
     OCHK(c->ch_cursor.reserve(nrow_max * 4 + 16));
@@ -550,7 +569,7 @@ int l3d_shard_chain_fetch(l3d_shard_chain* h, int k, l3d_chain_callback cb, void
     }
     const double tf1 = now_s();
     const PackHeader ph = h->hdr_host[k];
-    if (ph.overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: slot or candidate capacity exceeded (reopen with larger slot_records)");
+    if (ph.overflow) return fail(c, L3D_ERR_NOMEM, "l3d_shard_chain: view " + std::to_string(k) + ": a rank ran out of candidate or slot capacity, or gave up (l3d_shard_chain_info tells which)");
     const size_t best_bytes = (size_t)h->geom.seg_cap * 8;
     const size_t pin_bytes = (size_t)h->world * best_bytes + 64;
     unsigned char* host = c->ch_pin_kept.as<unsigned char>() + (size_t)(k & 1) * pin_bytes;      // depth pairs: two small pinned buffers
@@ -657,23 +676,55 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         h->s1_done.store(h->n_views + 1, std::memory_order_release);      // (never leave the chain thread waiting)
     });
     int rc = L3D_OK;
+    std::string rc_msg;
     const double t_run0 = now_s();
-    for (int k = 0; k < h->n_views && rc == L3D_OK; ++k) {
-        // a committing rank stays less than a staging ring ahead of its bookkeeping thread (which trails the GPU closely)
-        if (s1_rc.load()) { rc = fail(c, s1_rc.load(), "l3d_shard_chain_run: stage 1 failed"); break; }
-        while (cb && h->fetched.load(std::memory_order_acquire) < k - (l3d_shard_chain::kRing - 2)) {
-            { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
-            std::this_thread::yield();
+    // A rank that fails -- its own enqueue, its stage-1 thread, or (committing rank) the bookkeeping thread reading a slot that
+    // overflowed -- must NOT stop calling the exchange: the other ranks keep enqueueing one collective per verified view and would
+    // wait for it forever.  From the failure on it sends a header that says "gave up" for every remaining view (no kernels) and
+    // keeps exchanging; k_check_slots then gives every rank the same verdict.  Only a failing exchange call itself ends the loop.
+    SlotHeader* abort_hdr = nullptr;
+    {
+        hipError_t ae = hipSuccess;
+        abort_hdr = static_cast<SlotHeader*>(c->pin_arena.alloc(sizeof(SlotHeader), &ae));
+        HIPCHK(c, ae);
+        memset(abort_hdr, 0, sizeof(SlotHeader));
+        abort_hdr->overflow = 4;
+    }
+    bool draining = false, exchange_broken = false;
+    for (int k = 0; k < h->n_views; ++k) {
+        if (!draining) {
+            // a committing rank stays less than a staging ring ahead of its bookkeeping thread (which trails the GPU closely)
+            if (s1_rc.load()) { rc = s1_rc.load(); rc_msg = "l3d_shard_chain_run: stage 1 failed: " + c->err; draining = true; }
+            while (!draining && cb && h->fetched.load(std::memory_order_acquire) < k - (l3d_shard_chain::kRing - 2)) {
+                { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) { draining = true; break; } }
+                std::this_thread::yield();
+            }
+            { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) draining = true; }
         }
-        const double te0 = now_s();
-        rc = l3d_shard_chain_enqueue(h, k, send + (size_t)k * slot, gathered);
-        const double te1 = now_s();
-        if (rc == L3D_OK && h->vd[(size_t)k].verified && exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream))
-            rc = fail(c, L3D_ERR_HIP, "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed");
-        h->t_enq += te1 - te0; h->t_ex += now_s() - te1;
-        if (rc == L3D_OK) rc = l3d_shard_chain_mark(h, k);
-        if (rc == L3D_OK) { { std::lock_guard<std::mutex> lk(mu); marked = k + 1; } cv.notify_one(); }
-        { std::lock_guard<std::mutex> lk(mu); if (fetch_rc) break; }
+        const bool verified = h->vd[(size_t)k].verified;
+        if (!draining) {
+            const double te0 = now_s();
+            const int r2 = l3d_shard_chain_enqueue(h, k, send + (size_t)k * slot, gathered);
+            h->t_enq += now_s() - te0;
+            if (r2) { rc = r2; rc_msg = c->err; draining = true; }
+        }
+        if (draining && verified) {
+            if (hipMemcpyAsync(send + (size_t)k * slot, abort_hdr, sizeof(SlotHeader), hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); }
+        }
+        if (verified) {
+            const double te1 = now_s();
+            if (exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream)) {
+                if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed"; }
+                exchange_broken = true;
+                break;
+            }
+            h->t_ex += now_s() - te1;
+        }
+        if (!draining) {
+            const int r3 = l3d_shard_chain_mark(h, k);
+            if (r3) { rc = r3; rc_msg = c->err; draining = true; }
+            else { { std::lock_guard<std::mutex> lk(mu); marked = k + 1; } cv.notify_one(); }
+        }
     }
     s1_stop.store(true);
     stage1.join();
@@ -688,8 +739,32 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     if (getenv("L3D_TIMING"))
         fprintf(stderr, "[l3d shard chain run] enqueue loop %.2f ms, stream drained after %.2f ms, bookkeeping thread done after %.2f ms\n",
                 (t_run1 - t_run0) * 1e3, (t_run2 - t_run0) * 1e3, (now_s() - t_run0) * 1e3);
-    if (rc == L3D_OK && fetch_rc) rc = fail(c, fetch_rc, fetch_err);
-    return rc;
+    if (rc == L3D_OK && fetch_rc) { rc = fetch_rc; rc_msg = fetch_err; }
+    // the verdict every rank shares: the overflow bits of all gathered headers
+    if (!exchange_broken) {
+        std::vector<unsigned char> ver((size_t)h->n_views);
+        for (int k = 0; k < h->n_views; ++k) ver[(size_t)k] = h->vd[(size_t)k].verified ? 1 : 0;
+        hipError_t e = c->ch_flags.reserve((size_t)h->n_views + 64);
+        int host3[3] = { 0, 0, 0 };
+        if (e == hipSuccess) e = hipMemsetAsync(c->ch_flags.p, 0, 16, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->ch_flags.as<unsigned char>() + 16, ver.data(), (size_t)h->n_views, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_check_slots, dim3(8), dim3(256), 0, c->stream, gathered, h->geom, c->ch_flags.as<unsigned char>() + 16, h->n_views, c->ch_flags.as<int>());
+            e = hipMemcpyAsync(host3, c->ch_flags.p, 12, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = std::string("l3d_shard_chain_run: reading the slot headers: ") + hipGetErrorString(e); } }
+        else {
+            h->outcome[0] = host3[0]; h->outcome[1] = host3[1]; h->outcome[2] = host3[2];
+            if (host3[0] && (rc == L3D_OK || rc == L3D_ERR_NOMEM)) {
+                rc = L3D_ERR_NOMEM;
+                rc_msg = std::string("l3d_shard_chain_run:") + ((host3[0] & 1) ? " candidate capacity exceeded on a rank (" + std::to_string(host3[1]) + " candidates in one view's range; l3d_set_chain_capacities);" : "") +
+                         ((host3[0] & 2) ? " slot_records too small (" + std::to_string(host3[2]) + " kept matches in one view's range);" : "") +
+                         ((host3[0] & 4) ? " a rank gave up;" : "");
+            }
+        }
+    }
+    return rc ? fail(c, rc, rc_msg) : L3D_OK;
 }
 
 // exchange adapters.  RCCL: user = l3d_rccl_link {communicator, address of ncclAllGather}; the library does not link
@@ -714,6 +789,16 @@ int l3d_exchange_replay(void* user, int view, const void*, void* recv_block, siz
     return hipMemcpyAsync(recv_block, static_cast<const unsigned char*>(user) + (size_t)view * block, block, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
 }
 const void* l3d_shard_chain_gathered(l3d_shard_chain* h) { return h ? h->c->ch_gathered.p : nullptr; }
+int l3d_shard_chain_info(l3d_shard_chain* h, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (cand_cap) *cand_cap = h->cand_cap;
+    if (slot_records) *slot_records = h->geom.slot_records;
+    if (overflow_bits) *overflow_bits = h->outcome[0];
+    if (max_candidates) *max_candidates = h->outcome[1];
+    if (max_kept) *max_kept = h->outcome[2];
+    return L3D_OK;
+}
 
 int l3d_shard_chain_close(l3d_shard_chain* h)
 {

@@ -96,14 +96,6 @@ struct l3d_ctx {
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder;
-    // split chain (l3d_chain_split.hip): bins + overflow lists (whole run), per-view counters, ring-slot products of part A and of
-    // the chain kernel
-    l3d::DevBuf sp_bin_cnt, sp_bin_id, sp_bin_depth, sp_ovf_cnt, sp_ovf_key, sp_ovf_depth, sp_vflags, sp_confA, sp_maxA, sp_rev_meta, sp_rev_depth,
-        sp_rev_conf, sp_rev_max, sp_rev_tmp_meta, sp_rev_tmp_depth, sp_rev_seg, sp_kept_cnt, sp_segorder;
-    hipStream_t ahead_stream = nullptr;      // part A of the split chain (stage-1 hypotheses x stage-1 witnesses) runs ahead here
-    int chain_split = 0;            // 1: split chain (experiment, L3D_CHAIN_SPLIT=1), 0: resident chain
-    int bin_cap = 8;                // records per hand-over bin (L3D_BIN_CAP; the rest goes to the view's overflow list)
-    size_t test_ovf_cap = 0, test_rev_cap = 0;      // tests: initial overflow-list / reverse-store capacities (0 = estimate)
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     l3d::PinArena pin_arena;                 // kept lists of the running / last chain (valid until the next chain starts)
     std::vector<int> h_cnt;
@@ -170,7 +162,6 @@ inline void prof_resolve(l3d_ctx* c)
 {
     (void)hipStreamSynchronize(c->stream);
     if (c->stage1_stream) (void)hipStreamSynchronize(c->stage1_stream);
-    if (c->ahead_stream) (void)hipStreamSynchronize(c->ahead_stream);
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {
             float ms = 0.f;

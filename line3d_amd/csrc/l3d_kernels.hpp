@@ -89,59 +89,7 @@ struct VerifyArgs {
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
-    // split chain (l3d_chain_split.hip), part A: the launch sees the stage-1 candidates of the view only; besides the sum over the
-    // cameras (cand_conf) it stores the per-camera maxima of the n_tbm cameras to be matched (max_out[cand * max_stride + j] for camera
-    // tbm[j]) so that the chain kernel can insert the reverse-match cameras at their place in the ascending-camera sum.
-    float* max_out = nullptr;       // rows of max_stride floats, written only for hypotheses whose sum is not zero
-    const int* tbm = nullptr;
-    int n_tbm = 0, max_stride = 0;
 };
-
-// ---- split chain (l3d_chain_split.hip) -------------------------------------------------------------------------------------
-// Bins: the hand-over of kept matches between views.  One bin per (view, camera to be matched, target segment) in ONE global bin
-// space (view k owns bins [bin_first, bin_first + sum of its target segment counts)); a bin holds up to B records (id of the
-// source segment in the earlier view, the four depths already swapped to the later view's perspective, line3D.cc:847-856); the
-// rare record beyond B goes to the earlier view's overflow list, keyed by the global bin index.
-struct SplitSource {                // one source (earlier, mutually neighbouring view) of a chain view
-    int bin_first;                  // global index of the source's bin for (this view, segment 0); -1: the source hands nothing over
-    int n_bins;                     // = this view's segment count as the source sees it
-    int view;                       // chain index of the source view (its overflow list)
-    int cam;                        // the source's LOCAL camera index in this view
-};
-
-constexpr int kSplitInlineSrc = 16;          // sources whose table entries travel in the kernel arguments
-constexpr int kSplitMaxSrc = 64;             // neighbours of one view the split chain handles
-
-struct ChainSplitArgs {
-    const float4* src_segs; const float4* tgt_segs; const int2* offsets; const float* P; const float* RtKinv_src; const float* C_src;
-    const int* tbm; const unsigned* local2global;
-    int n_tbm, N, S;
-    float sigma_p, sigma_a, spatial_k;
-    // part A products of the view (ring slot): stage-1 candidates in (segment, camera, target) order, their part-A confidences
-    // (replaced by the final ones) and per-camera maxima
-    const int* rowA; const uint2* metaA; const float4* depthsA; float* confA; const float* maxA; int cand_cap;
-    int max_stride;                 // floats per row of maxA (n_tbm rounded up to 4); a row is only stored when its sum is not zero
-    // sources and bins
-    const SplitSource* sources; int n_src;
-    SplitSource src_inl[kSplitInlineSrc];         // = sources[0 .. min(n_src, kSplitInlineSrc))
-    int* bin_cnt; unsigned* bin_id; float4* bin_depth; int B;
-    int bin_first; const int* bin_slot_off;       // this view's bins: slot j (camera tbm[j]) starts at bin_first + bin_slot_off[j]
-    int* ovf_cnt_all; int2* ovf_key_all; float4* ovf_depth_all; int ovf_cap; int view_index;
-    // the view's reverse matches, gathered by k_chain_verify (per segment in first-depth order) for k_chain_kept: (id, camera),
-    // depths, confidence; rev_seg[y] = (first, count) of segment y; rev_tmp_*: staging for segments with more than fit in LDS
-    uint2* rev_meta; float4* rev_depth; float* rev_conf; uint2* rev_tmp_meta; float4* rev_tmp_depth; int rev_cap; int* rev_total; int2* rev_seg;
-    float* rev_max;                 // [rev_cap][N]: per-(reverse hypothesis, camera) maxima of segments whose reverse matches outgrow LDS
-    int rev_stride;                 // segment y owns entries [y * rev_stride, (y+1) * rev_stride) of the store; a segment with more takes a
-                                    // piece of the tail behind S * rev_stride (cursor rev_total)
-    const int* seg_order;           // workgroup i takes segment seg_order[i] (longest first); null = i
-    int* flags;                     // overflow bits of the view: 1 candidates, 4 overflow list, 8 reverse store
-    int* kept_cnt; float2* best_depths;
-    int debug;                      // timing-only ablations (L3D_SPLIT_DEBUG), 0 in production
-};
-void launch_chain_verify(const ChainSplitArgs& a, hipStream_t st);
-void launch_chain_kept(const ChainSplitArgs& a, const ChainResult* prev, int arena_cap, ChainResult* res, ChainResult* res_host, Match* arena, hipStream_t st);
-size_t chain_split_lds_bytes(int N, int n_src);
-bool chain_split_supported(int N);
 
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);

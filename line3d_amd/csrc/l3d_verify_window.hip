@@ -154,8 +154,6 @@ void k_verify_window(VerifyArgs a)
     int* sOff = reinterpret_cast<int*>(sP + a.N * 12);
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
-    __shared__ int s_tbm[64];                                                // part A of the split chain: cameras whose maxima are stored
-    if (a.max_out) for (int i = tid; i < 64; i += NT) s_tbm[i] = i < a.n_tbm ? a.tbm[i] : 0;
     float* smax_wave = smax + wave * 64 * a.N;
 
     // ---- one coalesced pass over the segment's candidates (kept in registers), counting sort on the depth bucket
@@ -327,17 +325,6 @@ void k_verify_window(VerifyArgs a)
         for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[c * 64 + lane];   // ascending camera order; +0.0f is exact
         if (hv) {
             a.cand_conf[start + idx_h] = conf_sum;
-            if (a.max_out && conf_sum != 0.0f) {                    // (a zero sum of non-negative terms: every maximum is zero, nothing to store)
-                float4* mo = reinterpret_cast<float4*>(a.max_out + (size_t)(start + (int)idx_h) * a.max_stride);
-                for (int j = 0; j < a.max_stride; j += 4) {
-                    float4 v;
-                    v.x = smax_wave[s_tbm[j] * 64 + lane];
-                    v.y = j + 1 < a.n_tbm ? smax_wave[s_tbm[j + 1] * 64 + lane] : 0.0f;
-                    v.z = j + 2 < a.n_tbm ? smax_wave[s_tbm[j + 2] * 64 + lane] : 0.0f;
-                    v.w = j + 3 < a.n_tbm ? smax_wave[s_tbm[j + 3] * 64 + lane] : 0.0f;
-                    mo[j >> 2] = v;
-                }
-            }
             kept_l += conf_sum > 1.0f;
             if (conf_sum > best_l || (conf_sum == best_l && (int)idx_h < besti_l)) { best_l = conf_sum; besti_l = (int)idx_h; }
         }

@@ -1891,22 +1891,38 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed)
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out)
 {
-    int n_views = 0;
-    size_t slot_bytes = 0;
-    const double t0 = now_s();
-    int rc = l3d_line3d_shard_open(h, rank, world, slot_records, &n_views, &slot_bytes);
-    if (rc) return rc;
-    const double t1 = now_s();
-    ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
-    rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, commit ? chain_callback : nullptr, commit ? &P->user : nullptr);
-    if (rc) h->fail(rc, std::string("shard_chain_run: ") + l3d_last_error(h->ctx));
-    if (gathered_out) *gathered_out = l3d_shard_chain_gathered(P->shard);
-    if (slot_bytes_out) *slot_bytes_out = slot_bytes;
-    const double t2 = now_s();
-    const int rc2 = l3d_line3d_shard_close(h, commit != 0 && rc == L3D_OK);
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
-                                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
-    return rc ? rc : rc2;
+    if (!h) return L3D_ERR_INVALID;
+    // A capacity failure is a verdict all ranks share (l3d_shard_chain_info): every rank reopens with the same, larger
+    // capacities and runs again -- the bookkeeping of the failed attempt is dropped by the reopen (match_begin).
+    size_t cand_cap_next = 0;
+    int rc = L3D_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        int n_views = 0;
+        size_t slot_bytes = 0;
+        const double t0 = now_s();
+        if (cand_cap_next) l3d_set_chain_capacities(h->ctx, cand_cap_next, 0);
+        rc = l3d_line3d_shard_open(h, rank, world, slot_records, &n_views, &slot_bytes);
+        if (cand_cap_next) l3d_set_chain_capacities(h->ctx, 0, 0);
+        if (rc) return rc;
+        const double t1 = now_s();
+        ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
+        rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, commit ? chain_callback : nullptr, commit ? &P->user : nullptr);
+        std::string msg = rc ? std::string("shard_chain_run: ") + l3d_last_error(h->ctx) : std::string();
+        size_t cand_cap = 0; int bits = 0, max_cand = 0, max_kept = 0, recs = slot_records;
+        l3d_shard_chain_info(P->shard, &cand_cap, &recs, &bits, &max_cand, &max_kept);
+        if (gathered_out) *gathered_out = l3d_shard_chain_gathered(P->shard);
+        if (slot_bytes_out) *slot_bytes_out = slot_bytes;
+        const double t2 = now_s();
+        const int rc2 = l3d_line3d_shard_close(h, commit != 0 && rc == L3D_OK);
+        if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
+                                          (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
+        if (rc == L3D_OK) return rc2;
+        h->fail(rc, msg);
+        if (rc != L3D_ERR_NOMEM || (bits & 4 && !(bits & 3)) || !(bits & 3)) return rc;      // not a capacity verdict: nothing a retry would change
+        if (bits & 1) cand_cap_next = std::max(cand_cap * 2, (size_t)max_cand + (size_t)max_cand / 4 + 65536);
+        if (bits & 2) slot_records = std::max(slot_records * 2, max_kept + max_kept / 4 + 1024);
+    }
+    return rc;
 }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 

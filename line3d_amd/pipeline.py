@@ -189,7 +189,11 @@ class Line3D:
         """The whole sharded chain as one native call (l3d_shard_chain_run).  exchange: "rccl" (exchange_user = a ctypes
         l3d_rccl_link), "local" (world 1) or "replay" (exchange_user = device address of recorded gathered blocks).
         Returns (device address of the gathered blocks, slot_bytes)."""
-        fn = {"rccl": self.lib.l3d_exchange_rccl, "local": self.lib.l3d_exchange_local, "replay": self.lib.l3d_exchange_replay}[exchange]
+        if callable(exchange):       # tests: a Python exchange (called on this thread by the enqueue loop), e.g. to inject a failure
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+            fn = self._exchange_keepalive = proto(exchange)
+        else:
+            fn = {"rccl": self.lib.l3d_exchange_rccl, "local": self.lib.l3d_exchange_local, "replay": self.lib.l3d_exchange_replay}[exchange]
         user = C.c_void_p(exchange_user) if isinstance(exchange_user, int) else (C.c_void_p(C.addressof(exchange_user)) if exchange_user is not None else None)
         g = C.c_void_p(0)
         sb = C.c_size_t(0)

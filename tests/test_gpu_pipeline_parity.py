@@ -312,6 +312,92 @@ def test_native_sharded_run_replayed_ranks(small_scene, small_oracle):
         l.close()
 
 
+def test_native_sharded_run_grows_capacities(small_scene, small_oracle):
+    """Slots or candidate buffers that are too small are a verdict every rank reads out of the gathered slot headers; the
+    facade reopens with more room and runs again (here: world 1, far too small slots, then far too small candidate buffers)."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    for slot_records, cand_cap in ((8, 0), (4096, 1500), (8, 1500)):
+        l = Line3D("", matchingNeighbors=6)
+        l.keep_view_matches(True)
+        load_scene(l, small_scene)
+        l.prepare()
+        if cand_cap:
+            l.context().set_chain_capacities(cand_cap, 0)
+        l.shard_run(0, 1, slot_records, "local", None, commit=True)
+        _check_against_oracle(l, small_oracle)
+        l.close()
+
+
+def test_native_sharded_run_failures_end_the_run_on_every_rank(small_scene, small_oracle):
+    """A rank that fails keeps exchanging "gave up" slots instead of leaving the others in a collective, and every rank ends
+    with an error: (a) an exchange that breaks mid-run, (b) a recorded world-3 run in which ANOTHER rank gave up at view 2 --
+    replayed on the committing rank 0 and on the bystander rank 2.  The pipeline object works again afterwards."""
+    import ctypes as C
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.prepare()
+    lib = l.lib
+    calls = []
+
+    def breaking_exchange(user, view, send, recv, slot_bytes, world, stream):
+        calls.append(view)
+        if len(calls) > 3:
+            return 1
+        return lib.l3d_exchange_local(None, C.c_int(view), C.c_void_p(send), C.c_void_p(recv), C.c_size_t(slot_bytes), C.c_int(world), C.c_void_p(stream))
+
+    with pytest.raises(RuntimeError):
+        l.shard_run(0, 1, 4096, breaking_exchange, None, commit=True)
+    assert len(calls) == 4
+    l.shard_run(0, 1, 4096, "local", None, commit=True)
+    _check_against_oracle(l, small_oracle)
+    l.close()
+
+    W, SLOT = 3, 4096
+    dev = torch.device("cuda", 0)
+    ls = []
+    for r in range(W):
+        x = Line3D("", matchingNeighbors=6)
+        x.keep_view_matches(True)
+        load_scene(x, small_scene)
+        x.prepare()
+        ls.append(x)
+    n_views, slot_bytes = [x.shard_open(r, W, SLOT) for r, x in enumerate(ls)][0]
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, x in enumerate(ls):
+            x.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for x in ls:
+            x.shard_mark(k)
+    for x in ls:
+        x.shard_close(False)
+    recorded = gathered.clone()
+    hdr = recorded[(2 * W + 1) * slot_bytes:(2 * W + 1) * slot_bytes + 32].view(torch.int32)     # view 2, rank 1: {n_kept, R, overflow, ...}
+    hdr[0] = 0
+    hdr[2] = 4                                                                                     # "gave up"
+    torch.cuda.synchronize()
+    for r in (0, 2):
+        with pytest.raises(RuntimeError, match="gave up"):
+            ls[r].shard_run(r, W, SLOT, "replay", recorded.data_ptr(), commit=(r == 0))
+        torch.cuda.synchronize()
+    # the same objects, the intact recording: everything is fine again
+    for r, x in enumerate(ls):
+        x.shard_run(r, W, SLOT, "replay", gathered.data_ptr(), commit=(r == 0))
+        torch.cuda.synchronize()
+    _check_against_oracle(ls[0], small_oracle)
+    for x in ls:
+        x.close()
+
+
 def test_result_writers_match_oracle(small_scene, small_oracle, tmp_path):
     """save3DLinesAsTXT / save3DLinesAsSTL (line3D.cc:384-473) through the C ABI against the oracle's writers: same
     lines, same ids, same 6-digit numbers (up to the 1e-4 endpoint tolerance), readable by line3d_amd.io.load_txt."""
