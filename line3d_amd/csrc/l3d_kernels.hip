@@ -69,16 +69,20 @@ constexpr float kWedgeTau = 1.0e-4f;
 constexpr float kIouCond = 1.0e-2f;           // error of t = a/(a-b) in units of (1+|t|)/|a-b| (a, b in margin units)
 constexpr float kIouSlack = 1.0e-3f;
 
-struct SrcBlockInv {                          // 35 words: odd stride, gathers by segment index spread over the LDS banks
+// LDS images of the block's source segments and the tile's target segments: odd strides (gathers by segment index spread over
+// the banks) and as small as possible -- with the 25-word target image the workgroup stays under 40 KB, i.e. FOUR workgroups
+// per CU instead of three (the scaled lines of level 2 are re-formed from the exact line and its inverse margin: the same
+// product, the same bits).
+struct SrcBlockInv {                          // 31 words
     SrcPairInv s;                             // exact invariants of the pair test
-    f3 e1s, e2s;                              // epipolar lines of p1 / p2 divided by their wedge margins
+    float im1, im2;                           // 1 / wedge margin of the epipolar lines of p1 / p2
     f3 ray1, ray2;                            // normalize(RtKinv_src * p1), (* p2): the reference's float sequence
-    f3 e1w, e2w;                              // the same two lines for the level-1 sector test, or zero where e_d = e1 - e2 may cross the tile
-    float pad;                                // (35 words)
+    f3 e1w, e2w;                              // the two lines over their margins for the level-1 sector test, or zero where e_d = e1 - e2 may cross the tile
+    float pad;
 };
-struct TgtBlockInv {                          // 29 words
+struct TgtBlockInv {                          // 25 words
     TgtPairInv t;
-    f3 e1s, e2s;                              // epipolar lines of q1 / q2 (in the source image) divided by their margins
+    float im1, im2;                           // 1 / margin of the epipolar lines of q1 / q2 (in the source image)
     f3 ray1, ray2;                            // normalize(RtKinv_tgt * q1), (* q2)
     float pad;
 };
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         const float m2 = kWedgeTau * (__builtin_fabsf(si.epi_p2.x) * ext0 + __builtin_fabsf(si.epi_p2.y) * ext1 + __builtin_fabsf(si.epi_p2.z));
         const float i1 = 1.0f / m1, i2 = 1.0f / m2;
         b.s = si;
-        b.e1s = i1 * si.epi_p1; b.e2s = i2 * si.epi_p2;
+        b.im1 = i1; b.im2 = i2;
+        const f3 e1s = i1 * si.epi_p1, e2s = i2 * si.epi_p2;
         b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2));
         // e_d = e1 - e2 against the bounding box of the tile's target endpoints (e_d cancels: its margin is the sum of the two
         // lines' margins, not 1e-4 of its own small terms).  Where it may cross the box the sector test of this source segment
@@ -201,15 +206,16 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         const float lo = ed.z + __builtin_fminf(ed.x * box[0], ed.x * box[1]) + __builtin_fminf(ed.y * box[2], ed.y * box[3]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[0], ed.x * box[1]) + __builtin_fmaxf(ed.y * box[2], ed.y * box[3]);
         const bool dsafe = lo > md || hi < -md;                // (NaN/inf: comparisons fail -> not safe)
-        b.e1w = dsafe ? b.e1s : mk3(0.0f, 0.0f, 0.0f);
-        b.e2w = dsafe ? b.e2s : mk3(0.0f, 0.0f, 0.0f);
+        b.e1w = dsafe ? e1s : mk3(0.0f, 0.0f, 0.0f);
+        b.e2w = dsafe ? e2s : mk3(0.0f, 0.0f, 0.0f);
     }
     f3 eq1s, eq2s;                           // this lane's epipolar lines (in the source image) over their margins, for level 1
     {
         const float mq1 = kWedgeTau * (__builtin_fabsf(t.epi_q1.x) * ext2 + __builtin_fabsf(t.epi_q1.y) * ext3 + __builtin_fabsf(t.epi_q1.z));
         const float mq2 = kWedgeTau * (__builtin_fabsf(t.epi_q2.x) * ext2 + __builtin_fabsf(t.epi_q2.y) * ext3 + __builtin_fabsf(t.epi_q2.z));
-        eq1s = (1.0f / mq1) * t.epi_q1; eq2s = (1.0f / mq2) * t.epi_q2;
-        s_tgt[tid].e1s = eq1s; s_tgt[tid].e2s = eq2s;                              // (level 2 reads the real lines from LDS)
+        const float iq1 = 1.0f / mq1, iq2 = 1.0f / mq2;
+        eq1s = iq1 * t.epi_q1; eq2s = iq2 * t.epi_q2;
+        s_tgt[tid].im1 = iq1; s_tgt[tid].im2 = iq2;                                // (level 2 re-forms the real lines from LDS)
         const f3 ed = t.epi_q1 - t.epi_q2;
         const float md = mq1 + mq2;
         const float lo = ed.z + __builtin_fminf(ed.x * box[4], ed.x * box[5]) + __builtin_fminf(ed.y * box[6], ed.y * box[7]);
@@ -287,10 +293,11 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
                     const TgtBlockInv& tb = tw[origin];
                     const f3 p1 = sb.s.p1, p2 = sb.s.p2, q1 = tb.t.q1, q2 = tb.t.q2;
                     // interval of the epipolar lines of q1/q2 on the source segment, of p1/p2 on the target segment
-                    const float b1 = fline(tb.e1s, p1.x, p1.y), b2 = fline(tb.e1s, p2.x, p2.y);
-                    const float b3 = fline(tb.e2s, p1.x, p1.y), b4 = fline(tb.e2s, p2.x, p2.y);
-                    const float a1 = fline(sb.e1s, q1.x, q1.y), a2 = fline(sb.e1s, q2.x, q2.y);
-                    const float a3 = fline(sb.e2s, q1.x, q1.y), a4 = fline(sb.e2s, q2.x, q2.y);
+                    const f3 te1 = tb.im1 * tb.t.epi_q1, te2 = tb.im2 * tb.t.epi_q2, se1 = sb.im1 * sb.s.epi_p1, se2 = sb.im2 * sb.s.epi_p2;
+                    const float b1 = fline(te1, p1.x, p1.y), b2 = fline(te1, p2.x, p2.y);
+                    const float b3 = fline(te2, p1.x, p1.y), b4 = fline(te2, p2.x, p2.y);
+                    const float a1 = fline(se1, q1.x, q1.y), a2 = fline(se1, q2.x, q2.y);
+                    const float a3 = fline(se2, q1.x, q1.y), a4 = fline(se2, q2.x, q2.y);
                     const float rb1 = __builtin_amdgcn_rcpf(b1 - b2), rb2 = __builtin_amdgcn_rcpf(b3 - b4);
                     const float ra1 = __builtin_amdgcn_rcpf(a1 - a2), ra2 = __builtin_amdgcn_rcpf(a3 - a4);
                     const float ls = sb.s.len, lt = tb.t.len;
