@@ -55,11 +55,13 @@ struct VWLds {
 // (cudawrapper.cu:388-401), then projection validity (:690-693) and the 2-D/angle confidence (:404-426); the
 // per-camera maximum goes to LDS with an integer atomic max (confidences are positive floats).
 __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, const int* sOff, const unsigned* q, int head, int n, int lane,
-                                         f3 C, f3 ray1, f3 ray2, f3 X1, f3 X2, f3 v1, float T1, float T2, bool gate,
+                                         f3 C, f3 ray1, f3 ray2, float d1y, float d2y, bool gate,
                                          float* smax_wave, float two_sig_d, float two_sig_a)
 {
     // a ring entry carries everything the witness contributes (camera, target id, both depths): the only global access of
-    // the evaluation is the gather of the target segment, issued straight after the ring read
+    // the evaluation is the gather of the target segment, issued straight after the ring read.  The hypothesis is rebuilt here
+    // from its two depths (3-D endpoints, direction, gate thresholds; the reference's operations, cudawrapper.cu:644-645,390-394):
+    // only the few pairs that pass the 1-D tests need it, the window walk itself works on depths alone.
     unsigned key = 0, tgt = 0;
     float wd1 = 0.0f, wd2 = 0.0f;
     if (lane < n) {
@@ -69,11 +71,16 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
     const int origin = key & 63, cam = (int)(key >> 8);
     float4 tq = make_float4(0.f, 0.f, 1.f, 1.f);
     if (lane < n) tq = a.tgt_segs[sOff[cam] + tgt];
-    const f3 hX1 = mk3(__shfl(X1.x, origin), __shfl(X1.y, origin), __shfl(X1.z, origin));
-    const f3 hX2 = mk3(__shfl(X2.x, origin), __shfl(X2.y, origin), __shfl(X2.z, origin));
-    const f3 hv = mk3(__shfl(v1.x, origin), __shfl(v1.y, origin), __shfl(v1.z, origin));
-    const float hT1 = __shfl(T1, origin), hT2 = __shfl(T2, origin);
+    const float hd1 = __shfl(d1y, origin), hd2 = __shfl(d2y, origin);
     if (lane >= n) return;
+    const f3 hX1 = C + hd1 * ray1;                                       // D_unproject_point_src, cudawrapper.cu:644-645
+    const f3 hX2 = C + hd2 * ray2;
+    const f3 hv = normalize(hX1 - hX2);
+    float hT1 = 0.0f, hT2 = 0.0f;
+    if (gate) {
+        hT1 = sq_threshold(a.spatial_k * length(C - hX1));              // cudawrapper.cu:390-394
+        hT2 = sq_threshold(a.spatial_k * length(C - hX2));
+    }
     const float conf = witness_conf(C, ray1, ray2, hX1, hX2, hv, hT1, hT2, gate, wd1, wd2, sP + cam * 12, tq, two_sig_d, two_sig_a);
     if (conf > 0.5f)                                                     // :699-704 (max over the camera's witnesses)
         atomicMax(reinterpret_cast<int*>(&smax_wave[cam * 64 + origin]), __float_as_int(conf));
@@ -248,22 +255,17 @@ void k_verify_window(VerifyArgs a)
     for (int h0 = 0; h0 < m; h0 += NT) {
         const int h = h0 + tid;
         const bool hv = h < m;
-        f3 X1 = mk3(0, 0, 0), X2 = mk3(0, 0, 0), v1 = mk3(0, 0, 0);
-        float d1y = 0.0f, d2y = 0.0f, T1 = 0.0f, T2 = 0.0f, w1 = 0.0f, w2 = 0.0f;
+        float d1y = 0.0f, d2y = 0.0f, w1 = 0.0f, w2 = 0.0f;
         unsigned cam_h = 0xffu, idx_h = 0;
         if (hv) {
             d1y = L.sd1[h]; d2y = L.sd2[h];
             cam_h = L.sci[h] >> 24; idx_h = L.sci[h] & 0xffffffu;
-            X1 = C + d1y * ray1;                                       // D_unproject_point_src, cudawrapper.cu:644-645
-            X2 = C + d2y * ray2;
-            v1 = normalize(X1 - X2);
             if (gate) {
-                const float unc1 = a.spatial_k * length(C - X1);      // cudawrapper.cu:390-394
-                const float unc2 = a.spatial_k * length(C - X2);
-                T1 = sq_threshold(unc1);
-                T2 = sq_threshold(unc2);
-                w1 = window_margin(unc1, __builtin_fabsf(d1y), dabs_max, c_inf);
-                w2 = window_margin(unc2, __builtin_fabsf(d2y), dabs_max, c_inf);
+                // the gate's uncertainty spatial_k * |C - X| (cudawrapper.cu:390-394) is at most spatial_k * |d| * (1 + 1e-5): |ray| = 1 +- 3u
+                // and X = C + d*ray carries a few ulps of |C| + |d| -- far inside the margin window_margin adds.  The walk needs nothing else
+                // of the hypothesis; its 3-D endpoints and thresholds are formed in vw_drain for the pairs that get that far.
+                w1 = window_margin(a.spatial_k * __builtin_fabsf(d1y) * 1.00001f, __builtin_fabsf(d1y), dabs_max, c_inf);
+                w2 = window_margin(a.spatial_k * __builtin_fabsf(d2y) * 1.00001f, __builtin_fabsf(d2y), dabs_max, c_inf);
             } else {
                 w1 = w2 = __builtin_inff();
             }
@@ -306,7 +308,7 @@ void k_verify_window(VerifyArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     if (count >= 64) {
                         VW_STAMP(2);
-                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
+                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, two_sig_d, two_sig_a);
                         head = (head + 64) & (kVQ - 1);
                         count -= 64;
                         VW_STAMP(3);
@@ -318,7 +320,7 @@ void k_verify_window(VerifyArgs a)
             for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; ct[g] = nt[g]; }
         }
         VW_STAMP(2);
-        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, X1, X2, v1, T1, T2, gate, smax_wave, two_sig_d, two_sig_a);
+        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, two_sig_d, two_sig_a);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         VW_STAMP(3);
         float conf_sum = 0.0f;
@@ -388,7 +390,7 @@ size_t verify_window_max_lds()
     // Measured on MI355X (config 2): the kernel is latency bound and gains more from resident workgroups than from a
     // large LDS image -- 24 KB of dynamic LDS (+8 KB static -> 5 workgroups per CU, the VGPR limit) beats 48 KB by 8 %,
     // and segments that outgrow the image lose nothing on the global-scratch (L2) variant.  So the budget is small.
-    size_t want = 24 * 1024;
+    size_t want = 24000;            // (+ 16.4 KB static: just under 40 KB, four workgroups per CU now that the kernel needs 121 VGPRs)
     limit = want;
     return limit;
 }
