@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __res
         const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (row >= S * n_tbm) return;
         const int y = row / n_tbm, cam = tbm[row % n_tbm];
-        const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
+        const int a = rowA[y * N + cam], b = row_start[y * N + cam], n = row_start[y * N + cam + 1] - b;   // (rowA may have been laid out for an upper bound of the row)
         for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
         return;
     }
@@ -345,6 +345,10 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
         }
     }
+    // the four depths of a stage-1 pair are triangulated once, by k_pair_fill (ring scheme only: the fill runs ahead, its true row counts
+    // are in place before the chain counts the view's reverse matches on top); L3D_DEPTH_IN_FILL=0: A/B, k_pair_mask triangulates too
+    static const bool depth_in_fill_env = !(getenv("L3D_DEPTH_IN_FILL") && atoi(getenv("L3D_DEPTH_IN_FILL")) == 0);
+    const bool depth_in_fill = depth_in_fill_env && c->chain_ring != 0;
     auto pair_args = [&](int k) {
         const l3d_chain_view& v = views[k];
         const ViewDev& d = vd[(size_t)k];
@@ -360,6 +364,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         pa.mask = d.mask;
         pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
         pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
+        pa.depth_in_fill = depth_in_fill ? 1 : 0;
         return pa;
     };
 
@@ -430,6 +435,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         const ViewDev& d = vd[(size_t)k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
+        pa.rowcnt = d.rowcnt;
         { ProfScope p(c, "pair_fill", s); launch_pair_fill(pa, d.rowA, ringA_meta(k), ringA_depths(k), s); }
     };
     auto enqueue_stage1 = [&](int k) -> int {
@@ -658,7 +664,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             --k;
             continue;
         }
-        raw_sum += hstats[2 * k];           // counted when the view is final (a restart enqueues views a second time)
+        raw_sum += r.R;                     // candidates verified (stage-1 + existing), counted when the view is final (a restart enqueues views twice)
         hand_over(k, 1, r);
     }
     { std::lock_guard<std::mutex> lk(mu); done = true; }

@@ -111,6 +111,7 @@ __device__ __forceinline__ float iou_upper(float t1, float r1, float t2, float r
     return inter * __builtin_amdgcn_rcpf(uni) * (1.0f + 1.0e-5f);
 }
 
+template <bool kDepth>
 __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
 {
     __shared__ SrcBlockInv s_src[kSrcPerBlock];
@@ -148,8 +149,10 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     const float4 tseg = valid ? a.tgt_segs[toff + x] : make_float4(0.f, 0.f, 1.f, 1.f);
     const TgtPairInv t = make_tgt_inv(tseg, s_cam);
     s_tgt[tid].t = t;
-    s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
-    s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
+    if (kDepth) {
+        s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
+        s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
+    }
     const int ny = min(a.src_per_block, a.seg_end - y0);
     {   // bounding boxes of this tile's target endpoints and this block's source endpoints: wave reductions, combined by every
         // thread after the barrier (the source segments sit in the first waves only)
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         b.s = si;
         b.im1 = i1; b.im2 = i2;
         const f3 e1s = i1 * si.epi_p1, e2s = i2 * si.epi_p2;
-        b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2));
+        if (kDepth) { b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2)); }
         // e_d = e1 - e2 against the bounding box of the tile's target endpoints (e_d cancels: its margin is the sum of the two
         // lines' margins, not 1e-4 of its own small terms).  Where it may cross the box the sector test of this source segment
         // is switched off (zero lines: all four values 0, never > 1 or < -1); level 2 decides those pairs.
@@ -273,9 +276,13 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
                     const TgtBlockInv& tb = tw[origin];
                     f3 l2_p1, l2_p2, l1_q1, l1_q2;
                     if (pair_overlap_test(sb.s, tb.t, l2_p1, l2_p2, l1_q1, l1_q2)) {
-                        const float4 d = pair_depths_pre(sb.ray1, sb.ray2, tb.ray1, tb.ray2, l2_p1, l2_p2, l1_q1, l1_q2, Rs, Rt, C_src, C_tgt);
-                        if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)         // cudawrapper.cu:931
-                            atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
+                        if (kDepth) {
+                            const float4 d = pair_depths_pre(sb.ray1, sb.ray2, tb.ray1, tb.ray2, l2_p1, l2_p2, l1_q1, l1_q2, Rs, Rt, C_src, C_tgt);
+                            if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)     // cudawrapper.cu:931
+                                atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
+                        } else {
+                            atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);               // (the depths and their sign test: k_pair_fill)
+                        }
                     }
                 }
                 hb = (hb + n) & (kPairQueue - 1);
@@ -434,19 +441,39 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
     const f3 ray_p1 = normalize(mat3_apply(a.RtKinv_src, s.p1)), ray_p2 = normalize(mat3_apply(a.RtKinv_src, s.p2));   // row invariants
     const int slot0 = row_start[y * a.N + cam];
 
-    for (int k = lane; k < total; k += 64) {
-        int lo = 0, hi = nw;               // largest w with pref[w] <= k
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[wave][mid] <= k) lo = mid; else hi = mid; }
-        const int x = lo * 64 + select_bit(s_words[wave][lo], k - s_pref[wave][lo]);
-        const TgtPairInv t = make_tgt_inv(a.tgt_segs[toff + x], a.F + cam * 9);
-        // the bit is set, so the overlap test passed: only its intersection points are needed again
-        f3 l2_p1, l2_p2, l1_q1, l1_q2;
-        pair_intersections(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
-        const float4 d = pair_depths_pre(ray_p1, ray_p2, normalize(mat3_apply(a.RtKinv + cam * 9, t.q1)), normalize(mat3_apply(a.RtKinv + cam * 9, t.q2)),
-                                         l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
-        cand_meta[slot0 + k] = make_uint2((unsigned)x, (unsigned)cam);
-        cand_depths[slot0 + k] = d;
+    int written = 0;                       // depth_in_fill: records of the row so far (wave-uniform)
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        const bool kv = k < total;
+        int x = 0;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kv) {
+            int lo = 0, hi = nw;               // largest w with pref[w] <= k
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[wave][mid] <= k) lo = mid; else hi = mid; }
+            x = lo * 64 + select_bit(s_words[wave][lo], k - s_pref[wave][lo]);
+            const TgtPairInv t = make_tgt_inv(a.tgt_segs[toff + x], a.F + cam * 9);
+            // the bit is set, so the overlap test passed: only its intersection points are needed again
+            f3 l2_p1, l2_p2, l1_q1, l1_q2;
+            pair_intersections(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
+            d = pair_depths_pre(ray_p1, ray_p2, normalize(mat3_apply(a.RtKinv + cam * 9, t.q1)), normalize(mat3_apply(a.RtKinv + cam * 9, t.q2)),
+                                l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
+        }
+        if (a.depth_in_fill) {
+            // the bit only says "overlap test passed": a candidate needs four positive depths (cudawrapper.cu:931); the row is packed
+            const bool ok = kv && d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f;
+            const unsigned long long om = __ballot(ok);
+            if (ok) {
+                const int pos = slot0 + written + __popcll(om & ((1ull << lane) - 1ull));
+                cand_meta[pos] = make_uint2((unsigned)x, (unsigned)cam);
+                cand_depths[pos] = d;
+            }
+            written += __popcll(om);
+        } else if (kv) {
+            cand_meta[slot0 + k] = make_uint2((unsigned)x, (unsigned)cam);
+            cand_depths[slot0 + k] = d;
+        }
     }
+    if (a.depth_in_fill && lane == 0) a.rowcnt[y * a.N + cam] = written;           // the row's true count replaces the upper bound
 }
 
 __global__ void k_exist_place(const ExistRec* __restrict__ ex, int n, int N, const int* __restrict__ row_start,
@@ -844,7 +871,8 @@ void launch_pair_mask(const PairArgs& a0, int maxW, hipStream_t st)
     PairArgs a = a0;
     a.src_per_block = pair_mask_src_per_block(a.seg_end - a.seg_begin, maxW, a.n_tbm);
     dim3 grid((maxW + 255) / 256, (a.seg_end - a.seg_begin + a.src_per_block - 1) / a.src_per_block, a.n_tbm);
-    hipLaunchKernelGGL(k_pair_mask, grid, dim3(256), 0, st, a);
+    if (a.depth_in_fill) hipLaunchKernelGGL(k_pair_mask<false>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_pair_mask<true>, grid, dim3(256), 0, st, a);
 }
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st)
 {

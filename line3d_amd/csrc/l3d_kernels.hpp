@@ -57,6 +57,10 @@ struct PairArgs {
     int* rowcnt;                    // chains: the per-(segment, camera) candidate counts are added here by k_pair_mask itself (rows zeroed at
                                     // chain start); null: a separate k_row_count launch (per-view seam call, chain restarts)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test (default 3)
+    int depth_in_fill = 0;          // resident chain: k_pair_mask stops after the exact overlap test (its bits and row counts are then an UPPER
+                                    // bound), the four depths are triangulated ONCE, in k_pair_fill, which drops the pairs without four positive
+                                    // depths (cudawrapper.cu:931), packs the row and writes its true count back into rowcnt; 0: the bit already
+                                    // says "four positive depths" (per-view seam call, sharded chain)
 };
 
 struct VerifyArgs {
