@@ -257,11 +257,11 @@ def main():
             avg_ms = ms / max(1, launches)
             achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic.json") for r in ("r2", "r1")) if os.path.exists(q)), "")
             if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/README.md)
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             valu = None
-            vpath = os.path.join(ROOT, "profiles", "r1_valu.json")
+            vpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_valu.json") for r in ("r2", "r1")) if os.path.exists(q)), "")
             if os.path.exists(vpath) and avg_ms > 0:   # wave-level VALU instructions per launch (PMC pass of this same command)
                 vi = json.load(open(vpath)).get(name, {}).get("valu_wave_insts_per_launch")
                 if vi:
