@@ -472,6 +472,42 @@ def test_ragged_scene_all_paths_equal_oracle():
         l.close()
 
 
+def test_opposing_and_forward_cameras_all_paths_equal_oracle():
+    """Cameras facing each other, forward motion (epipole inside the image), a side view: geometries in which the epipolar
+    transfer of a segment wraps through infinity and 3-D endpoints fall behind a camera.  Every view neighbours every other;
+    the resident chain, the per-view path and the native sharded run must reproduce the oracle's matches bit for bit and its lines."""
+    from line3d_amd.pipeline import Line3D
+    from line3d_amd.synth import make_scene_from_poses
+    from line3d_amd import distributed as l3dist
+    O = (0.0, 0.0, 0.0)
+    centers = [(0, 0, -4), (0.3, 0.1, 4), (-0.4, 0.2, 4.2), (0.1, 0.05, -3.0), (0.0, -0.1, -5.0), (4, 0.2, 0.3), (0.5, 0.3, -4.1), (-3.9, 0.1, 0.2)]
+    sc = make_scene_from_poses(centers, [O] * len(centers), 220, seed=92)
+    N = len(centers) - 1
+    o = op.OracleLine3D(matching_neighbors=N)
+    for v in sc.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    o.compute3Dmodel(False)
+    assert sum(len(t["matches"]) for t in o.trace.values()) > 300
+    for mode in ("chain", "sync", "native"):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        l.set_sync_matching(mode == "sync")
+        for v in sc.views:
+            assert l.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        if mode == "native":
+            l.prepare()
+            l3dist.match_views_chain_native(l, 0, 1, None, commit=True, n_segments=220, n_neighbors=N)
+            l.finish(False)
+        else:
+            l.compute3Dmodel(False)
+        for vid in sorted(o.trace):
+            got, med = l.view_matches(vid)
+            assert got.tobytes() == o.trace[vid]["matches"].tobytes(), "%s view %d" % (mode, vid)
+            assert np.float32(med) == np.float32(o.trace[vid]["median"]), "%s view %d" % (mode, vid)
+        assert_lines_equal(l.getResult(), o.result, 1e-4)
+        l.close()
+
+
 @pytest.mark.parametrize("n_views,S,N", [(27, 180, 24), (64, 48, 60)])
 def test_many_neighbours_parity(n_views, S, N):
     """BASELINE config 5's neighbourhood size (N = 24) and one beyond the window kernel's LDS limit (N = 60: the chain
