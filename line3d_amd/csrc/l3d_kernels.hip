@@ -73,17 +73,31 @@ constexpr float kIouSlack = 1.0e-3f;
 // the banks) and as small as possible -- with the 25-word target image the workgroup stays under 40 KB, i.e. FOUR workgroups
 // per CU instead of three (the scaled lines of level 2 are re-formed from the exact line and its inverse margin: the same
 // product, the same bits).
-struct SrcBlockInv {                          // 31 words
+template <bool kDepth> struct SrcBlockInvT {  // 25 words
     SrcPairInv s;                             // exact invariants of the pair test
     float im1, im2;                           // 1 / wedge margin of the epipolar lines of p1 / p2
     f3 ray1, ray2;                            // normalize(RtKinv_src * p1), (* p2): the reference's float sequence
-    f3 e1w, e2w;                              // the two lines over their margins for the level-1 sector test, or zero where e_d = e1 - e2 may cross the tile
     float pad;
 };
-struct TgtBlockInv {                          // 25 words
+template <> struct SrcBlockInvT<false> {      // 19 words: without the rays when the triangulation happens in k_pair_fill
+    SrcPairInv s;
+    float im1, im2;
+    float pad;
+};
+struct __attribute__((aligned(16))) SrcLevel1 {   // what the level-1 loop reads per source segment, as three aligned 16-byte broadcasts
+    float e1x, e1y, e1z, p1x;                 // the line of p1 over its margin for the sector test (zero where e_d = e1 - e2 may cross the tile) | p1
+    float e2x, e2y, e2z, p1y;                 // the line of p2 likewise
+    float p2x, p2y, pad0, pad1;
+};
+template <bool kDepth> struct TgtBlockInvT {  // 25 words
     TgtPairInv t;
     float im1, im2;                           // 1 / margin of the epipolar lines of q1 / q2 (in the source image)
     f3 ray1, ray2;                            // normalize(RtKinv_tgt * q1), (* q2)
+    float pad;
+};
+template <> struct TgtBlockInvT<false> {      // 19 words: 32 KB per workgroup, five per CU
+    TgtPairInv t;
+    float im1, im2;
     float pad;
 };
 
@@ -114,7 +128,10 @@ __device__ __forceinline__ float iou_upper(float t1, float r1, float t2, float r
 template <bool kDepth>
 __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
 {
+    typedef SrcBlockInvT<kDepth> SrcBlockInv;
+    typedef TgtBlockInvT<kDepth> TgtBlockInv;
     __shared__ SrcBlockInv s_src[kSrcPerBlock];
+    __shared__ SrcLevel1 s_l1[kSrcPerBlock];
     __shared__ TgtBlockInv s_tgt[256];
     __shared__ float s_cam[9 + 9 + 3 + 9];   // F, RtKinv_tgt, C_tgt of this camera, RtKinv_src
     __shared__ float s_boxw[4][8];       // per wave: {min x, max x, min y, max y} of its target endpoints, of its source endpoints
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     const float4 tseg = valid ? a.tgt_segs[toff + x] : make_float4(0.f, 0.f, 1.f, 1.f);
     const TgtPairInv t = make_tgt_inv(tseg, s_cam);
     s_tgt[tid].t = t;
-    if (kDepth) {
+    if constexpr (kDepth) {
         s_tgt[tid].ray1 = normalize(mat3_apply(Rt, t.q1));
         s_tgt[tid].ray2 = normalize(mat3_apply(Rt, t.q2));
     }
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         b.s = si;
         b.im1 = i1; b.im2 = i2;
         const f3 e1s = i1 * si.epi_p1, e2s = i2 * si.epi_p2;
-        if (kDepth) { b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2)); }
+        if constexpr (kDepth) { b.ray1 = normalize(mat3_apply(Rs, si.p1)); b.ray2 = normalize(mat3_apply(Rs, si.p2)); }
         // e_d = e1 - e2 against the bounding box of the tile's target endpoints (e_d cancels: its margin is the sum of the two
         // lines' margins, not 1e-4 of its own small terms).  Where it may cross the box the sector test of this source segment
         // is switched off (zero lines: all four values 0, never > 1 or < -1); level 2 decides those pairs.
@@ -209,8 +226,12 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         const float lo = ed.z + __builtin_fminf(ed.x * box[0], ed.x * box[1]) + __builtin_fminf(ed.y * box[2], ed.y * box[3]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[0], ed.x * box[1]) + __builtin_fmaxf(ed.y * box[2], ed.y * box[3]);
         const bool dsafe = lo > md || hi < -md;                // (NaN/inf: comparisons fail -> not safe)
-        b.e1w = dsafe ? e1s : mk3(0.0f, 0.0f, 0.0f);
-        b.e2w = dsafe ? e2s : mk3(0.0f, 0.0f, 0.0f);
+        const f3 e1w = dsafe ? e1s : mk3(0.0f, 0.0f, 0.0f), e2w = dsafe ? e2s : mk3(0.0f, 0.0f, 0.0f);
+        SrcLevel1 l1;
+        l1.e1x = e1w.x; l1.e1y = e1w.y; l1.e1z = e1w.z; l1.p1x = si.p1.x;
+        l1.e2x = e2w.x; l1.e2y = e2w.y; l1.e2z = e2w.z; l1.p1y = si.p1.y;
+        l1.p2x = si.p2.x; l1.p2y = si.p2.y; l1.pad0 = 0.0f; l1.pad1 = 0.0f;
+        s_l1[tid] = l1;
     }
     f3 eq1s, eq2s;                           // this lane's epipolar lines (in the source image) over their margins, for level 1
     {
@@ -241,16 +262,16 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
         const bool last = k == ny;
         if (!last) {
             // level 1: wedge test (broadcast reads of the source invariants)
-            const SrcBlockInv& sb = s_src[k];
+            const SrcLevel1 sl = s_l1[k];
             bool cand = valid;
             if (use_wedge) {
                 // both endpoints against one line at once: packed FP32 FMAs (v_pk_fma_f32), two lanes of work per instruction
                 const v2f qx = { t.q1.x, t.q2.x }, qy = { t.q1.y, t.q2.y };
-                const v2f a12 = pk_line(sb.e1w, qx, qy), a34 = pk_line(sb.e2w, qx, qy);
+                const v2f a12 = pk_line(mk3(sl.e1x, sl.e1y, sl.e1z), qx, qy), a34 = pk_line(mk3(sl.e2x, sl.e2y, sl.e2z), qx, qy);
                 const float lo2 = __builtin_fminf(__builtin_fminf(a12.x, a12.y), __builtin_fminf(a34.x, a34.y));
                 const float hi2 = __builtin_fmaxf(__builtin_fmaxf(a12.x, a12.y), __builtin_fmaxf(a34.x, a34.y));
                 const bool out2 = lo2 > 1.0f || hi2 < -1.0f;        // target segment strictly inside one same-sign sector of e1, e2 (and off e_d)
-                const v2f px = { sb.s.p1.x, sb.s.p2.x }, py = { sb.s.p1.y, sb.s.p2.y };
+                const v2f px = { sl.p1x, sl.p2x }, py = { sl.p1y, sl.p2y };
                 const v2f b12 = pk_line(eq1s, px, py), b34 = pk_line(eq2s, px, py);
                 const float lo1 = __builtin_fminf(__builtin_fminf(b12.x, b12.y), __builtin_fminf(b34.x, b34.y));
                 const float hi1 = __builtin_fmaxf(__builtin_fmaxf(b12.x, b12.y), __builtin_fmaxf(b34.x, b34.y));
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
                     const TgtBlockInv& tb = tw[origin];
                     f3 l2_p1, l2_p2, l1_q1, l1_q2;
                     if (pair_overlap_test(sb.s, tb.t, l2_p1, l2_p2, l1_q1, l1_q2)) {
-                        if (kDepth) {
+                        if constexpr (kDepth) {
                             const float4 d = pair_depths_pre(sb.ray1, sb.ray2, tb.ray1, tb.ray2, l2_p1, l2_p2, l1_q1, l1_q2, Rs, Rt, C_src, C_tgt);
                             if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f)     // cudawrapper.cu:931
                                 atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
