@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int*
         const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (row >= (s1 - s0) * n_tbm) return;
         const int y = s0 + row / n_tbm, cam = tbm[row % n_tbm];
-        const int a = rowA[y * N + cam], n = rowA[y * N + cam + 1] - a, b = row_start[y * N + cam];
+        const int a = rowA[y * N + cam], b = row_start[y * N + cam], n = row_start[y * N + cam + 1] - b;   // (rowA may have been laid out for an upper bound of the row)
         for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
         return;
     }
@@ -405,6 +405,7 @@ static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
     pa.mask = d.mask;
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
     pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg; pa.rowcnt = nullptr;
+    pa.depth_in_fill = 1;               // the depths of a stage-1 pair are triangulated once, by k_pair_fill (as in l3d_match_chain)
     return pa;
 }
 
@@ -430,6 +431,7 @@ static int shard_stage1(l3d_shard_chain* h, int k)
         if (k - l3d_shard_chain::kRingA >= 0) HIPCHK(c, hipStreamWaitEvent(s1, h->ev2[(size_t)(k - l3d_shard_chain::kRingA)], 0));
         PairArgs pf = pa;
         pf.cand_cap = (int)h->cand_cap;
+        pf.rowcnt = d.rowcnt;           // (the row's true count replaces k_pair_mask's upper bound)
         { ProfScope p(c, "pair_fill", s1); launch_pair_fill(pf, d.rowA, c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                                              c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap, s1); }
     }
