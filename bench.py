@@ -313,7 +313,7 @@ def main():
                 ctx.replicator_dynamics_diffusion(A, n_nodes)
                 t_rdd = time.perf_counter() - t1
                 ex["rdd"] = dict(seconds=t_rdd, entries=int(len(A)), iterations=10, iterations_per_s=10.0 / t_rdd,
-                                 entry_updates_per_s=10.0 * len(A) / t_rdd, note="host sorts + upload + 21 launches + download")
+                                 entry_updates_per_s=10.0 * len(A) / t_rdd, note="upload + device radix sorts + sparse build + 21 launches + download")
             except Exception as e:     # noqa: BLE001
                 ex["rdd"] = dict(error=str(e))
             out["rest_of_compute3Dmodel"] = ex

@@ -457,78 +457,7 @@ int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float col
 
 }  // extern "C"
 
-namespace {
-struct HostSparse { std::unique_ptr<float4[]> entries; std::unique_ptr<int[]> start; };   // sparsematrix.cc:99-131
-}  // namespace
-
 extern "C" {
-
-int l3d_replicator_dynamics_diffusion(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int iters, l3d_edge* out)
-{
-    if (!c) return L3D_ERR_INVALID;
-    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && (!A || !out))) return fail(c, L3D_ERR_INVALID, "bad argument");
-    if (nnz == 0 || n == 0) return L3D_OK;      // sparsematrix.cc:77-78: empty matrix, nothing to do
-    for (int k = 0; k < nnz; ++k)
-        if (A[k].i < 0 || A[k].i >= n || A[k].j < 0 || A[k].j >= n) return fail(c, L3D_ERR_INVALID, "edge index out of range");
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    const bool timing = getenv("L3D_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_last = now();
-    auto lap = [&](const char* what) { if (timing) { const double t = now(); fprintf(stderr, "[l3d rdd] %-24s %8.2f ms\n", what, (t - t_last) * 1e3); t_last = t; } };
-    // W: column-sorted (line3D.cc:1258 -> sparsematrix.cc:81-86, stable list sort by (j,i)); P: the column-sorted entries
-    // re-sorted by row (cudawrapper.cu:1145 -> sparsematrix.cc:157-167).  Entries and first-entry tables as sparsematrix.cc:99-131.
-    const unsigned nt = host_threads();
-    std::vector<uint32_t> ordW, ordP, startW, startP;
-    parallel_stable_order((size_t)nnz, (size_t)n, (size_t)n, [&](size_t k) { return A[k].j; }, [&](size_t k) { return A[k].i; }, nt, ordW, &startW);
-    parallel_stable_order((size_t)nnz, (size_t)n, (size_t)n, [&](size_t k) { return A[ordW[k]].i; }, [&](size_t k) { return A[ordW[k]].j; }, nt, ordP, &startP);
-    HostSparse W, Pm;
-    W.entries.reset(new float4[(size_t)nnz]); Pm.entries.reset(new float4[(size_t)nnz]);
-    W.start.reset(new int[(size_t)n]); Pm.start.reset(new int[(size_t)n]);
-    on_threads(nt, [&](unsigned t) {
-        for (size_t k = (size_t)nnz * t / nt; k < (size_t)nnz * (t + 1) / nt; ++k) {
-            const l3d_edge& w = A[ordW[k]];
-            W.entries[k] = make_float4((float)w.i, (float)w.j, w.w, 0.0f);
-            const l3d_edge& q = A[ordW[ordP[k]]];
-            Pm.entries[k] = make_float4((float)q.i, (float)q.j, q.w, 0.0f);
-        }
-        for (size_t r = (size_t)n * t / nt; r < (size_t)n * (t + 1) / nt; ++r) {
-            W.start[r] = startW[r + 1] > startW[r] ? (int)startW[r] : -1;
-            Pm.start[r] = startP[r + 1] > startP[r] ? (int)startP[r] : -1;
-        }
-    });
-    lap("sort + sparse build");
-
-    const size_t eb = (size_t)nnz * 16, sb = (size_t)n * 4;
-    HIPCHK(c, c->g0.reserve(eb)); HIPCHK(c, c->g1.reserve(eb)); HIPCHK(c, c->g2.reserve(eb));
-    HIPCHK(c, c->g3.reserve(sb)); HIPCHK(c, c->g4.reserve(sb)); HIPCHK(c, c->g5.reserve(sb));
-    float4 *dW = c->g0.as<float4>(), *dP = c->g1.as<float4>(), *dPp = c->g2.as<float4>();
-    int *dWc = c->g3.as<int>(), *dPr = c->g4.as<int>(), *dPpr = c->g5.as<int>();
-    HIPCHK(c, hipMemcpyAsync(dW, W.entries.get(), eb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dP, Pm.entries.get(), eb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dPp, Pm.entries.get(), eb, hipMemcpyHostToDevice, st));   // P' = copy of P (1148)
-    HIPCHK(c, hipMemcpyAsync(dWc, W.start.get(), sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dPr, Pm.start.get(), sb, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dPpr, Pm.start.get(), sb, hipMemcpyHostToDevice, st));
-    { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
-    for (int it = 0; it < iters; ++it) {
-        { ProfScope p(c, "diffusion_step"); launch_diffusion_step(dP, dW, dPr, dWc, dPp, dPpr, nnz, st); }
-        std::swap(dP, dPp);
-        std::swap(dPr, dPpr);
-        if (it < iters - 1) { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
-    }
-    if (timing) { HIPCHK(c, hipStreamSynchronize(st)); lap("upload + kernels"); }
-    std::unique_ptr<float4[]> res(new float4[(size_t)nnz]);
-    HIPCHK(c, hipMemcpyAsync(res.get(), dP, eb, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    lap("download");
-    on_threads(nt, [&](unsigned t) {
-        for (size_t k = (size_t)nnz * t / nt; k < (size_t)nnz * (t + 1) / nt; ++k) { out[k].i = (int)res[k].x; out[k].j = (int)res[k].y; out[k].w = res[k].z; }
-    });
-    lap("convert");
-    return L3D_OK;
-}
 
 // -------------------------------------------------------------------------------------------------
 int l3d_similarity_coll3D_batch(l3d_ctx* c, const l3d_hypothesis* hyp, int n_hyp, const int32_t* pairs, int n_pairs,
