@@ -268,7 +268,17 @@ def main():
                     peak_issue = 256 * 4 * 2.4e9 / 4.0      # one wave64 VALU instruction per SIMD every 4 cycles
                     valu = dict(wave_insts_per_launch=vi, issue_frac=vi / (avg_ms * 1e-3) / peak_issue,
                                 note="SQ_INSTS_VALU per launch / launch duration / (256 CUs x 4 SIMDs x 2.4 GHz / 4)")
-            roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+            # the meaningful fraction for this path is FP32 VALU.  Reference-formulation flops of the dominant kernel per launch
+            # (370 per stage-1 pair, 280 per verify inner iteration of the all-pairs loop) over its measured duration against the 157.3
+            # TFLOP/s vector peak: an EQUIVALENT rate -- the kernels do the reference's arithmetic only on the pairs their conservative
+            # filters / depth windows cannot exclude, so it may exceed what the VALUs actually execute (see `valu` for that)
+            ref_flops = {"pair_mask": 370.0 * pairs_per_launch, "pair_fill": 360.0 * R_per_launch}.get(name)
+            flops = None
+            if ref_flops and avg_ms > 0:
+                tf = ref_flops / (avg_ms * 1e-3) / 1e12
+                flops = dict(reference_formulation_flops_per_launch=ref_flops, equivalent_tflops=tf, peak_tflops=157.3, frac=tf / 157.3,
+                             note="reference-formulation flops / measured launch duration; not a count of executed instructions")
+            roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, fp32_equivalent=flops,
                         traffic=traffic, valu=valu, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
                         note="the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
                              "view and stay in L2/LDS; kernels_ms = per-kernel time of one untimed pass with every kernel bracketed; "
