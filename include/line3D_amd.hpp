@@ -56,14 +56,13 @@ private:
 
 class Line3D {
 public:
-    // line3D.h:61-66 (data_directory is accepted and unused: nothing is cached on disk)
+    // line3D.h:61-66 (data_directory: where the segment caches of an earlier run are looked up, addImageFromCache; nothing is written)
     Line3D(const std::string data_directory, const int matchingNeighbors = 10,
            const float uncertainty_t_upper_2D = 5.0f, const float uncertainty_t_lower_2D = 1.0f,
            const float sigma_p = 3.5f, const float sigma_a = 10.0f, const float min_baseline = 0.25f,
            bool useCollinearity = true, bool verbose = false, int device = 0)
-        : h_(nullptr), prefix_("[L3D] ")
+        : h_(nullptr), prefix_("[L3D] "), data_directory_(data_directory), use_collinearity_(useCollinearity)
     {
-        (void)data_directory;
         int rc = l3d_line3d_create(device, matchingNeighbors, uncertainty_t_upper_2D, uncertainty_t_lower_2D, sigma_p, sigma_a,
                                    min_baseline, useCollinearity ? 1 : 0, verbose ? 1 : 0, &h_);
         if (rc != L3D_OK) std::cerr << prefix_ << "no usable HIP device (code " << rc << "); this build has no CPU fallback" << std::endl;
@@ -81,6 +80,23 @@ public:
         std::vector<uint32_t> wps(worldpointIDs.begin(), worldpointIDs.end());
         report(l3d_line3d_add_image(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x, (int)segments.size(),
                                     K, R, t, wps.data(), (int)wps.size()));
+    }
+    // addImage when "<data_directory>/segments_<id>_<w>x<h>_coll<0|1>.bin" of an earlier run exists (line3D.cc:143-168):
+    // the file's segments and collinearities stand in for the image (the detector is not part of this library).
+    // false: no such file, or it is not a segment cache (message printed)
+    bool addImageFromCache(const unsigned int imageID, const unsigned int width, const unsigned int height,
+                           const double K[9], const double R[9], const double t[3], std::list<unsigned int>& worldpointIDs)
+    {
+        char name[128];
+        if (l3d_segment_cache_filename(imageID, width, height, use_collinearity_ ? 1 : 0, name, sizeof(name)) != L3D_OK) return false;
+        l3d_segment_cache* cache = nullptr;
+        int rc = l3d_segment_cache_read((data_directory_ + name).c_str(), &cache);
+        if (rc != L3D_OK) { std::cerr << prefix_ << l3d_segment_cache_last_error(cache) << std::endl; l3d_segment_cache_free(cache); return false; }
+        std::vector<uint32_t> wps(worldpointIDs.begin(), worldpointIDs.end());
+        rc = l3d_line3d_add_image_cached(h_, imageID, width, height, cache, K, R, t, wps.data(), (int)wps.size());
+        l3d_segment_cache_free(cache);
+        report(rc);
+        return rc == L3D_OK;
     }
     // line3D.h:75-79
     void addImage_fixed_sim(const unsigned int imageID, const unsigned int width, const unsigned int height,
@@ -174,7 +190,8 @@ public:
 private:
     void report(int rc) { if (rc != L3D_OK) std::cerr << prefix_ << l3d_line3d_last_error(h_) << std::endl; }
     l3d_line3d* h_;
-    std::string prefix_;
+    std::string prefix_, data_directory_;
+    bool use_collinearity_;
 };
 
 }  // namespace L3D

@@ -330,6 +330,30 @@ int l3d_sfm_camera_worldpoints(const l3d_sfm_scene* scene, int i, uint32_t* ids)
 /* the drivers' K from a focal length and the image size (main_vsfm.cpp:232-241): [[f,0,w/2],[0,f,h/2],[0,0,1]] */
 void l3d_sfm_intrinsics(double focal, unsigned int width, unsigned int height, double K[9]);
 
+/* =================================================================================================
+ * Segment cache of Line3D::addImage: "<data dir>/segments_<id>_<w>x<h>_coll<0|1>.bin" (line3D.cc:143-150),
+ * a boost binary archive of one L3DSegments -- the collinearity map, then the DataArray<float>* of padded rows
+ * (serialization.h:49-69, segments.h:124-131, dataArray.h:296-318) -- read and written without boost
+ * (layout and its pin status: line3d_amd/csrc/l3d_segcache.cpp).  A failed read still returns an object carrying the
+ * message (l3d_segment_cache_last_error); free it with l3d_segment_cache_free.
+ * Collinearities are the DIRECTED entries of segment2collinearities_ (i -> j and j -> i), ascending (i, j).
+ * ================================================================================================= */
+typedef struct l3d_segment_cache l3d_segment_cache;
+int l3d_segment_cache_filename(uint32_t image_id, unsigned int width, unsigned int height, int use_collinearity, char* out, size_t out_size);
+int l3d_segment_cache_read(const char* path, l3d_segment_cache** out);
+void l3d_segment_cache_free(l3d_segment_cache* cache);
+const char* l3d_segment_cache_last_error(const l3d_segment_cache* cache);
+int l3d_segment_cache_num_segments(const l3d_segment_cache* cache);
+int l3d_segment_cache_num_collinearities(const l3d_segment_cache* cache);
+int l3d_segment_cache_library_version(const l3d_segment_cache* cache);
+int l3d_segment_cache_get(const l3d_segment_cache* cache, float* segments, int32_t* ci, int32_t* cj, float* cw);
+int l3d_segment_cache_write(const char* path, const float* segments, int n_segments, const int32_t* ci, const int32_t* cj, const float* cw,
+                            int n_collinearities, int library_version);
+/* Line3D::addImage when the cache file exists (line3D.cc:160-168): the segments AND the collinearities of the file are
+ * used as they are (nothing is recomputed); world points as in l3d_line3d_add_image */
+int l3d_line3d_add_image_cached(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height, const l3d_segment_cache* cache,
+                                const double* K, const double* R, const double* t, const uint32_t* worldpoint_ids, int n_worldpoints);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,8 +215,11 @@ namespace {
 typedef l3d_line3d L;
 
 // ------------------------------------------------------------------------------------------------
+// coll_i/coll_j/coll_w (optional): the directed entries of a cached segment2collinearities_ map, ascending (i, j) -- used as
+// they are instead of computing the relation (Line3D::addImage with an existing segment cache, line3D.cc:160-168)
 int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
-              const double* K, const double* R, const double* t)
+              const double* K, const double* R, const double* t,
+              const int32_t* coll_i = nullptr, const int32_t* coll_j = nullptr, const float* coll_w = nullptr, int n_coll = -1)
 {
     View v;
     v.id = id;
@@ -229,7 +232,16 @@ int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* s
     v.unc_upper_px = h->unc_upper; v.unc_lower_px = h->unc_lower;
     v.segs.assign(segs, segs + (size_t)n * 4);
     v.coll_start.assign((size_t)n + 1, 0);
-    if (h->use_collinearity && n > 1) {             // L3DSegments ctor, segments.h:73-101
+    if (h->use_collinearity && n_coll >= 0) {       // the map of the cache file: iteration order of the nested std::map = ascending (i, j)
+        for (int k = 0; k < n_coll; ++k) {
+            if (coll_i[k] < 0 || coll_i[k] >= n || coll_j[k] < 0 || coll_j[k] >= n) return h->fail(L3D_ERR_INVALID, "cached collinearity names a segment that does not exist");
+            if (k && (coll_i[k] < coll_i[k - 1] || (coll_i[k] == coll_i[k - 1] && coll_j[k] <= coll_j[k - 1]))) return h->fail(L3D_ERR_INVALID, "cached collinearities are not in ascending (i, j) order");
+            v.coll_start[(size_t)coll_i[k] + 1]++;
+        }
+        for (int s = 0; s < n; ++s) v.coll_start[(size_t)s + 1] += v.coll_start[(size_t)s];
+        v.coll_other.assign(coll_j, coll_j + n_coll);
+        v.coll_w.assign(coll_w, coll_w + n_coll);
+    } else if (h->use_collinearity && n > 1) {      // L3DSegments ctor, segments.h:73-101
         int32_t *ci = nullptr, *cj = nullptr; float* cw = nullptr; int cn = 0;
         int rc = l3d_compute_collinearity(h->ctx, v.segs.data(), n, L3D_DEF_COLLINEARITY_S, &ci, &cj, &cw, &cn);
         if (rc) return h->fail(rc, std::string("collinearity: ") + l3d_last_error(h->ctx));
@@ -1744,6 +1756,27 @@ int l3d_line3d_add_image(l3d_line3d* h, uint32_t id, unsigned width, unsigned he
                          const double* K, const double* R, const double* t, const uint32_t* worldpoints, int n_wps)
 {
     int rc = add_common(h, id, width, height, segs, n, K, R, t, n_wps);
+    if (rc) return rc;
+    process_worldpoints(h, id, worldpoints, n_wps);
+    return L3D_OK;
+}
+
+// addImage when the segment cache exists, line3D.cc:160-168: segments and collinearities come from the file
+int l3d_line3d_add_image_cached(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const l3d_segment_cache* cache,
+                                const double* K, const double* R, const double* t, const uint32_t* worldpoints, int n_wps)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (!cache) return h->fail(L3D_ERR_INVALID, "null segment cache");
+    const int n = l3d_segment_cache_num_segments(cache), nc = l3d_segment_cache_num_collinearities(cache);
+    std::vector<float> segs((size_t)n * 4 + 1), cw((size_t)nc + 1);
+    std::vector<int32_t> ci((size_t)nc + 1), cj((size_t)nc + 1);
+    l3d_segment_cache_get(cache, segs.data(), ci.data(), cj.data(), cw.data());
+    if (h->computation) return h->fail(L3D_ERR_INVALID, "reconstruction already performed! cannot add more images (try reset first)");
+    if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
+    if (n_wps == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
+    if (width == 0 || height == 0) return h->fail(L3D_ERR_INVALID, "image is empty!");
+    if (n <= 0 || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "no segments");
+    int rc = make_view(h, id, width, height, segs.data(), n, K, R, t, ci.data(), cj.data(), cw.data(), nc);
     if (rc) return rc;
     process_worldpoints(h, id, worldpoints, n_wps);
     return L3D_OK;

@@ -64,6 +64,19 @@ class Line3D:
                                            C.c_int(len(segs)), _p(K), _p(R), _p(t), _p(wps), C.c_int(len(wps)))
         return rc == 0          # the reference prints to cerr and returns (line3D.cc:101-127)
 
+    def addImage_cached(self, imageID, width, height, cache_path, K, R, t, worldpointIDs):
+        """addImage when the segment cache file exists (line3D.cc:160-168): segments and collinearities from the file."""
+        from .io import open_segment_cache, close_segment_cache
+        K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))
+        wps = np.ascontiguousarray(list(worldpointIDs), dtype=np.uint32)
+        cache = open_segment_cache(cache_path)
+        try:
+            rc = self.lib.l3d_line3d_add_image_cached(self.h, C.c_uint32(imageID), C.c_uint(width), C.c_uint(height), cache,
+                                                      _p(K), _p(R), _p(t), _p(wps), C.c_int(len(wps)))
+        finally:
+            close_segment_cache(cache)
+        return rc == 0
+
     def addImage_fixed_sim(self, imageID, width, height, segments, K, R, t, viewSimilarity):
         segs = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
         K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))

@@ -77,14 +77,23 @@ def result_basename(max_width=-1, neighbors=10, min_uncertainty=1.0, max_uncerta
 def reconstruct(scene: SfmScene, segments, image_sizes, out_dir=None, neighbors=10, diffusion=False, device=0, **line3d_kwargs):
     """The drivers' flow (main_vsfm.cpp:226-325) with detected segments in place of images: K from focal and image size,
     addImage with the world point lists, compute3Dmodel, optional STL + TXT output under the drivers' file name.
-    segments[i]: (S,4) float32 of camera i (undistorted image coordinates); image_sizes[i]: (width, height)."""
+    segments[i]: (S,4) float32 of camera i (undistorted image coordinates); image_sizes[i]: (width, height).
+    segments may also be a DIRECTORY: the reference's data directory (main_vsfm.cpp:108-116, "<image folder>/L3D_data"),
+    whose segment caches "segments_<id>_<w>x<h>_coll<0|1>.bin" of an earlier run are replayed (line3D.cc:143-168)."""
     import os
     from .pipeline import Line3D
+    from .io import segment_cache_filename
     l3d = Line3D("", matchingNeighbors=neighbors, device=device, **line3d_kwargs)
     for i, cam in enumerate(scene.cameras):
         if np.any(np.abs(cam["dist"]) > 1e-12):
             raise RuntimeError("camera %d has lens distortion: undistort the image before detecting segments (out of scope here)" % i)
         w, h = image_sizes[i]
+        if isinstance(segments, (str, os.PathLike)):
+            path = os.fspath(segments) + segment_cache_filename(i, w, h, line3d_kwargs.get("useCollinearity", True))
+            if not os.path.exists(path):
+                raise RuntimeError("no segment cache %s (the detector is out of scope: segments must come from a cache or the caller)" % path)
+            l3d.addImage_cached(i, w, h, path, intrinsics(cam["focal"], w, h), cam["R"], cam["t"], cam["worldpoints"])
+            continue
         l3d.addImage(i, w, h, segments[i], intrinsics(cam["focal"], w, h), cam["R"], cam["t"], cam["worldpoints"])
     l3d.compute3Dmodel(diffusion)
     if out_dir is not None:

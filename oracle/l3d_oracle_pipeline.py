@@ -241,10 +241,12 @@ class OracleLine3D:
         self.trace = {}                                         # per-view kept matches etc. for tests
 
     # -- addImage (segments supplied: the detector is out of scope) ---------------------------
-    def _make_view(self, vid, width, height, segments, K, R, t):
+    def _make_view(self, vid, width, height, segments, K, R, t, cached_collin=None):
         segments = np.ascontiguousarray(segments, dtype=np.float32)
         collin = {}
-        if self.use_collinearity and len(segments):             # segments.h:73-101
+        if self.use_collinearity and cached_collin is not None:  # line3D.cc:160-168: the L3DSegments of the cache file as it is
+            collin = {k: OrderedDict(sorted(v.items())) for k, v in cached_collin.items()}
+        elif self.use_collinearity and len(segments):           # segments.h:73-101
             rel = collinearity(self.lib, segments, 2.0)
             S = len(segments)
             ii, jj = np.nonzero(np.triu(rel > 0.0, 1))
@@ -269,6 +271,17 @@ class OracleLine3D:
         if self.computation or vid in self.views or len(worldpoint_ids) == 0:
             return False
         self.views[vid] = self._make_view(vid, width, height, segments, K, R, t)
+        self._process_worldpoints(vid, worldpoint_ids)
+        return True
+
+    def add_image_cached(self, vid, width, height, cache_path, K, R, t, worldpoint_ids):   # line3D.cc:95-217 with :160-168
+        from l3d_oracle_sfm import read_segment_cache
+        if self.computation or vid in self.views or len(worldpoint_ids) == 0:
+            return False
+        segments, collin, _ = read_segment_cache(cache_path)
+        if len(segments) == 0:
+            return False
+        self.views[vid] = self._make_view(vid, width, height, segments, K, R, t, cached_collin=collin)
         self._process_worldpoints(vid, worldpoint_ids)
         return True
 

@@ -95,3 +95,47 @@ def test_driver_flow_from_nvm_matches_oracle(sfm_scene, tmp_path):
     txt = os.path.join(str(tmp_path / "out"), sfm.result_basename(neighbors=6) + ".txt")
     assert len(load_txt(txt)) == len(o.result) and os.path.exists(txt[:-4] + ".stl")
     l3d.close()
+
+
+@pytest.mark.gpu
+def test_driver_flow_replays_segment_caches(sfm_scene, tmp_path):
+    """main_vsfm's flow when the data directory already holds the segment caches of an earlier run (line3D.cc:143-168):
+    segments AND collinearities come from the files -- here thinned out, so that they differ from what would be computed --
+    against the oracle replaying the same files through its own reader."""
+    import l3d_oracle_pipeline as op
+    from line3d_amd import sfm
+    from line3d_amd.io import segment_cache_filename
+    sc, pts = sfm_scene
+    path = str(tmp_path / "scene.nvm")
+    write_nvm(path, sc, pts)
+    scene = sfm.read_nvm(path)
+    sizes = [(v["width"], v["height"]) for v in sc.views]
+    data_dir = str(tmp_path / "L3D_data")
+    os.makedirs(data_dir)
+    olib = op.load_lib()
+    n_entries = n_kept = 0
+    for i, v in enumerate(sc.views):
+        rel = op.collinearity(olib, v["segments"], 2.0)
+        coll = {}
+        ii, jj = np.nonzero(np.triu(rel > 0.0, 1))
+        for a, b in zip(ii.tolist(), jj.tolist()):
+            n_entries += 1
+            if (a * 7 + b * 3 + i) % 4 == 0:                    # the earlier run "saw" fewer collinear pairs
+                continue
+            n_kept += 1
+            coll.setdefault(a, {})[b] = rel[b, a]
+            coll.setdefault(b, {})[a] = rel[b, a]
+        osfm.write_segment_cache(data_dir + segment_cache_filename(i, sizes[i][0], sizes[i][1], True), v["segments"], coll)
+    assert 0 < n_kept < n_entries
+    l3d = sfm.reconstruct(scene, data_dir, sizes, neighbors=6)
+    cams, _ = osfm.read_nvm(path)
+    o = op.OracleLine3D(matching_neighbors=6)
+    for i, c in enumerate(cams):
+        assert o.add_image_cached(i, sizes[i][0], sizes[i][1], data_dir + osfm.filename_segment_cache(i, sizes[i][0], sizes[i][1], True),
+                                  osfm.intrinsics(c["focal"], *sizes[i]), c["R"], c["t"], list(c["worldpoints"]))
+    o.compute3Dmodel(False)
+    assert len(o.result) > 0
+    assert_lines_equal(l3d.getResult(), o.result, 1e-4)
+    l3d.close()
+    with pytest.raises(RuntimeError, match="no segment cache"):
+        sfm.reconstruct(scene, str(tmp_path / "nothing_here"), sizes, neighbors=6)
