@@ -120,6 +120,39 @@ int l3d_replicator_dynamics_diffusion(l3d_ctx* ctx, const l3d_edge* A, int nnz, 
 int l3d_similarity_coll3D_batch(l3d_ctx* ctx, const l3d_hypothesis* hyp, int n_hyp,
                                 const int32_t* pairs, int n_pairs, float sigma_a, float* sim);
 
+/* The affinity fill of Line3D::clusterSegments2D (line3D.cc:968-1221) on the device: candidate enumeration with the
+ * reference's `used` bookkeeping (three edge families: potential correspondence / collinear with it / collinear with the
+ * source), similarity_coll3D, the thresholds (L3D_MIN_AFFINITY 0.25 / 0.01), first-touch node numbering and the symmetric
+ * edge list A -- from flat tables.  Segments are numbered densely view by view (views in ascending camera id):
+ * dense id = seg_base[view] + segment.  Hypotheses (greedySelection, line3D.cc:899-965) are numbered in dense order.
+ *   seg_base        n_views + 1
+ *   view_hyp_begin  n_views + 1: the hypotheses of a view are [view_hyp_begin[v], view_hyp_begin[v+1])
+ *   hyp, score, hyp_dense   n_hyp: 3-D hypothesis, min(confidence, 1), dense id of its segment
+ *   best            per dense id: its hypothesis or -1
+ *   pot_start/pot_tgt   potential_correspondences_ (line3D.cc:861-865) per dense id as CSR, targets as dense ids, ascending
+ *                       (entries whose camera names no view, or whose segment does not exist, left out)
+ *   coll_start/coll_other/coll_w   segment2collinearities_ (segments.h:89-93) per dense id as CSR, ascending dense ids
+ * Outputs (callee-allocated, l3d_free): edges (n_edges = 2 x kept candidates, (a,b,w) then (b,a,w), in the reference's
+ * order), node_hyp[node] = hypothesis (local2global), the number of enumerated candidate pairs. */
+typedef struct l3d_affinity_input {
+    int32_t n_views;
+    const int32_t* seg_base;
+    const int32_t* view_hyp_begin;
+    int32_t n_hyp;
+    const l3d_hypothesis* hyp;
+    const float* score;
+    const int32_t* hyp_dense;
+    const int32_t* best;
+    const int64_t* pot_start;
+    const int32_t* pot_tgt;
+    const int64_t* coll_start;
+    const int32_t* coll_other;
+    const float* coll_w;
+    float sigma_a;
+} l3d_affinity_input;
+int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes,
+                      int* n_candidates);
+
 
 /* ---- Line3D::matchViews as one device-resident chain --------------------------------------------------------
  * The schedule of matchViews (line3D.cc:620-648) is static: which neighbours a view still has to match and

@@ -1,0 +1,579 @@
+// l3d_affinity.hip -- the affinity fill of Line3D::clusterSegments2D (line3D.cc:968-1221) on the device: candidate
+// enumeration with the reference's `used` bookkeeping, similarity_coll3D, thresholds, first-touch node numbering and the
+// symmetric edge list, from flat per-segment tables (l3d_affinity_input).
+//
+// What the reference does.  For every source segment s with a 3-D hypothesis, in (view, segment) order: walk its
+// potential correspondences t (other views, ascending key); skip t if it is `used` -- met earlier in this iteration, or
+// s was met while t was the source (an earlier iteration); otherwise mark it, and if t has a hypothesis: one candidate
+// edge (family 0), then the same for every segment c collinear with t (family 1).  Finally the segments collinear with s
+// itself (family 2).  `used` is a map of maps updated as the loops go.
+//
+// The same result without the sequential maps.  Within one source, targets of different views never interact (a mark is a
+// segment of the target's view), so the walk decomposes into GROUPS = the targets of one view, ascending.  In a group
+//   * target t_k is marked as a target  <=>  no EXPANDED earlier target t_i (i < k) lists it as collinear, and it is
+//     not m-used;  t_k is expanded  <=>  marked as a target and it has a hypothesis;
+//   * a collinear entry c of an expanded t_k is marked  <=>  c is none of t_j (j < k), no expanded t_i (i < k) lists c,
+//     and c is not m-used;
+//   * x is m-used  <=>  x has a hypothesis xb EARLIER than the source's and xb's iteration marked the source segment d
+//     <=>  d is one of xb's targets, or an expanded target of xb (in d's view) lists d as collinear
+// (an earlier source can never find a later one m-used, so nothing else can have stopped it from marking d).  Hence the
+// only state that flows from source to source is one bit per (source, target): "expanded".  It is computed view by view
+// (k_aff_groups: a target's bit only needs the bits of EARLIER views), with the few targets of a group resolved in
+// lane-parallel rounds; everything else is data parallel over all sources of all views at once:
+//   k_aff_words   how many 64-entry words the flattened (expanded target, collinear entry) sequence of a source takes
+//   k_aff_items<0> decides every entry (one ballot = one word), counts the candidates of the source
+//   k_aff_items<1> replays the words: similarity, weight, threshold -> candidate arrays in the reference's order
+//   k_aff_first / k_aff_nodes / k_aff_edges   first-touch numbering (line3D.cc:1020-1048 etc.) and the edge list
+// The family-2 entries need no state at all: x collinear with s is skipped  <=>  x's hypothesis is earlier and x lists s.
+//
+// Potential correspondences are recorded in both directions (line3D.cc:861-865), so "d is one of t's targets" holds for
+// nearly every target t of d: k_aff_sym looks that up for all sources at once (bit 2), and a target with that bit is m-used
+// as soon as its hypothesis is earlier -- no bit of another source is read.  Only views holding an entry WITHOUT the
+// reverse record (early-return views, cudawrapper.cu:877-878) have to wait for the bits of the views before them: the
+// launches of k_aff_groups are cut there; everywhere else consecutive views share one launch.
+#include <hipcub/hipcub.hpp>
+
+#include "l3d_ctx.hpp"
+#include "l3d_similarity.hpp"
+
+using namespace l3d;
+
+namespace l3d {
+
+struct AffIn {
+    int n_views, n_hyp, n_dense, chunk;             // chunk: targets handled per wave pass (64; smaller only in tests)
+    const int* seg_base;                            // n_views + 1
+    const int* dview;                               // n_dense: view index of a dense segment id
+    const Hypothesis* hyp;
+    const float* score;
+    const int* hyp_dense;                           // n_hyp: dense id of the hypothesis' segment
+    const int* best;                                // n_dense: hypothesis index or -1
+    const long long* pot_start;                     // n_dense + 1
+    const int* pot_tgt;                             // dense ids, ascending per segment
+    const long long* coll_start;                    // n_dense + 1
+    const int* coll_other;                          // dense ids (same view), ascending per segment
+    const float* coll_w;
+    unsigned char* flags;                           // per potential correspondence: bit 0 marked as a target, bit 1 expanded
+};
+
+// d in C(t)?
+__device__ __forceinline__ bool coll_has(const AffIn& a, int t, int d)
+{
+    long long lo = a.coll_start[t], hi = a.coll_start[t + 1];
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        const int x = a.coll_other[mid];
+        if (x == d) return true;
+        if (x < d) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// first potential correspondence of segment x (entries [pb, pe)) whose target is >= id
+__device__ __forceinline__ long long pot_lower(const AffIn& a, long long pb, long long pe, int id)
+{
+    while (pb < pe) {
+        const long long mid = (pb + pe) >> 1;
+        if (a.pot_tgt[mid] < id) pb = mid + 1; else pe = mid;
+    }
+    return pb;
+}
+
+__device__ __forceinline__ unsigned char load_flag(const AffIn& a, long long e)
+{
+    return __hip_atomic_load(a.flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// is d one of the targets of segment x?
+__device__ __forceinline__ bool pot_has(const AffIn& a, int x, int d)
+{
+    const long long pe = a.pot_start[x + 1];
+    const long long p = pot_lower(a, a.pot_start[x], pe, d);
+    return p < pe && a.pot_tgt[p] == d;
+}
+
+// did the iteration of the EARLIER hypothesis xb mark segment d (of view vd)?
+__device__ __forceinline__ bool met_by(const AffIn& a, int xb, int d, int vd)
+{
+    const int x = a.hyp_dense[xb];
+    const long long pe = a.pot_start[x + 1];
+    const int hi_id = a.seg_base[vd + 1];
+    for (long long e = pot_lower(a, a.pot_start[x], pe, a.seg_base[vd]); e < pe; ++e) {
+        const int t = a.pot_tgt[e];
+        if (t >= hi_id) break;
+        if (t == d) return true;
+        if ((load_flag(a, e) & 2) && coll_has(a, t, d)) return true;
+    }
+    return false;
+}
+
+__global__ void k_aff_dview(const int* __restrict__ seg_base, int n_views, int* __restrict__ dview)
+{
+    const int v = blockIdx.y;
+    const int i = seg_base[v] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_views && i < seg_base[v + 1]) dview[i] = v;
+}
+
+// bit 2 of a source's entry: the target has an earlier hypothesis and records the source among its own targets (=> m-used).
+// needs_prev[view] is raised when a target with an earlier hypothesis lacks the reverse record: its m-used test reads bits of
+// earlier views.
+__global__ __launch_bounds__(256) void k_aff_sym(AffIn a, int* __restrict__ needs_prev)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int si = blockIdx.x * 4 + wave;
+    if (si >= a.n_hyp) return;
+    const int d = a.hyp_dense[si];
+    const long long pe = a.pot_start[d + 1];
+    bool need = false;
+    for (long long e = a.pot_start[d] + lane; e < pe; e += 64) {
+        const int t = a.pot_tgt[e];
+        const int hb = a.best[t];
+        if (hb >= 0 && hb < si) {
+            if (pot_has(a, t, d)) a.flags[e] = 4; else need = true;
+        }
+    }
+    if (__ballot(need) && lane == 0) needs_prev[a.dview[d]] = 1;
+}
+
+// The "expanded" bits of the sources [h0, h1) (one view, or several that need no bits of each other).  One wave per source, one lane per target (passes of a.chunk
+// targets); a target waits for the earlier targets of its group: round r resolves the r-th target of every group.
+__global__ __launch_bounds__(256) void k_aff_groups(AffIn a, int h0, int h1)
+{
+    __shared__ int s_t[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int si = h0 + blockIdx.x * 4 + wave;
+    if (si >= h1) return;
+    const int d = a.hyp_dense[si];
+    const int vi = a.dview[d];
+    const long long pb = a.pot_start[d], pe = a.pot_start[d + 1];
+    int carry_view = -1;                                                       // view and start of the group the previous pass ended in
+    long long carry_gs = pb;
+    for (long long c0 = pb; c0 < pe; c0 += a.chunk) {
+        const long long e = c0 + lane;
+        const bool valid = lane < a.chunk && e < pe;
+        int t = -1, hb = -1, tv = -2;
+        bool mused = false;
+        if (valid) {
+            t = a.pot_tgt[e];
+            const unsigned char f0 = a.flags[e];                               // (bit 2 only: written by k_aff_sym, an earlier launch)
+            hb = a.best[t];
+            tv = a.dview[t];
+            mused = hb >= 0 && hb < si && ((f0 & 4) || met_by(a, hb, d, vi));
+        }
+        // first target of the lane's group: the targets ascend, a group is a run of one view
+        const int tv_prev = __shfl_up(tv, 1);
+        const unsigned long long starts = __ballot(valid && (lane == 0 ? tv != carry_view : tv != tv_prev));
+        const unsigned long long below = starts & ((lane == 63 ? 0ull : (1ull << (lane + 1))) - 1ull);
+        long long gs = below ? c0 + (63 - __clzll((long long)below)) : carry_gs;
+        {   // hand the last group over to the next pass
+            const int last = (int)(pe - c0 < (long long)a.chunk ? pe - c0 : (long long)a.chunk) - 1;
+            carry_view = __shfl(tv, last);
+            carry_gs = __shfl(gs, last);
+        }
+        s_t[wave][lane] = t;
+        const long long g0 = gs > c0 ? gs : c0;                                // the group's part inside this pass starts here
+        const int my_round = valid ? (int)(e - g0) : -1;
+        int rounds = my_round;
+        for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o));
+        unsigned long long exp_mask = 0ull;                                    // expanded targets of this pass (wave-uniform)
+        bool marked = false, expanded = false;
+        for (int r = 0; r <= rounds; ++r) {
+            if (my_round == r) {
+                bool hit = false;
+                for (long long e2 = gs; e2 < c0 && !hit; ++e2)                 // the group began in an earlier pass of this wave
+                    if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], t)) hit = true;
+                unsigned long long m = exp_mask & ((1ull << lane) - 1ull) & ~((1ull << (int)(g0 - c0)) - 1ull);
+                while (m && !hit) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    if (coll_has(a, s_t[wave][j], t)) hit = true;
+                }
+                marked = !hit && !mused;
+                expanded = marked && hb >= 0;
+            }
+            exp_mask |= __ballot(my_round == r && expanded);
+        }
+        if (valid) __hip_atomic_store(a.flags + e, (unsigned char)((marked ? 1 : 0) | (expanded ? 2 : 0) | (mused ? 4 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                 // (the next pass of this wave may read them back)
+    }
+}
+
+// Flattened entries of one pass of targets: every EXPANDED target contributes itself (family 0) and its collinear list
+// (family 1).  pre = exclusive prefix of the contributions over the lanes; returns the total.
+__device__ __forceinline__ int pass_layout(const AffIn& a, long long e, bool valid, int& t, long long& cs, int& len, int& pre)
+{
+    const int lane = threadIdx.x & 63;
+    t = -1; cs = 0; len = 0;
+    if (valid && (load_flag(a, e) & 2)) {
+        t = a.pot_tgt[e];
+        cs = a.coll_start[t];
+        len = 1 + (int)(a.coll_start[t + 1] - cs);
+    }
+    int incl = len;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    pre = incl - len;
+    return __shfl(incl, 63);
+}
+
+__global__ __launch_bounds__(256) void k_aff_words(AffIn a, int* __restrict__ nwords)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int si = blockIdx.x * 4 + wave;
+    if (si >= a.n_hyp) return;
+    const int d = a.hyp_dense[si];
+    const long long pb = a.pot_start[d], pe = a.pot_start[d + 1];
+    int words = 0;
+    for (long long c0 = pb; c0 < pe; c0 += a.chunk) {
+        int t, len, pre; long long cs;
+        const int T = pass_layout(a, c0 + lane, lane < a.chunk && c0 + lane < pe, t, cs, len, pre);
+        words += (T + 63) >> 6;
+    }
+    words += (int)((a.coll_start[d + 1] - a.coll_start[d] + 63) >> 6);
+    if (lane == 0) nwords[si] = words;
+}
+
+// kEmit = false: decide every flattened entry of every source; the ballots are stored (words), the candidates counted.
+// kEmit = true:  replay the words: candidate k of the source gets its pair, its weight (similarity * mean score
+//                [* collinearity weight]) or -1 when the weight does not pass the family's threshold.
+template <bool kEmit>
+__global__ __launch_bounds__(256) void k_aff_items(AffIn a, const int* __restrict__ word_off, unsigned long long* __restrict__ words,
+                                                   int* __restrict__ cnt, const int* __restrict__ item_off, int2* __restrict__ pairs,
+                                                   float* __restrict__ wgt, float sigma_a, float two_log)
+{
+    __shared__ int s_pre[4][64];
+    __shared__ int s_t[4][64];
+    __shared__ long long s_cs[4][64];
+    __shared__ long long s_e[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int si = blockIdx.x * 4 + wave;
+    if (si >= a.n_hyp) return;
+    const int d = a.hyp_dense[si];
+    const int vi = a.dview[d];
+    const long long pb = a.pot_start[d], pe = a.pot_start[d + 1];
+    long long w = word_off[si];
+    int written = 0;
+    const int out0 = kEmit ? item_off[si] : 0;
+    const float s_src = kEmit ? a.score[si] : 0.0f;
+
+    auto emit = [&](bool on, int b, int family, float cw) {
+        // (all lanes call; `on` lanes hold a candidate (si, b))
+        const unsigned long long bal = __ballot(on);
+        if (on) {
+            const int k = out0 + written + __popcll(bal & ((1ull << lane) - 1ull));
+            const float sim = similarity_coll3D(a.hyp[si], a.hyp[b], sigma_a, two_log);
+            float wv = 0.5f * (s_src + a.score[b]) * sim;                      // line3D.cc:1014, :1085
+            if (family == 2) wv = cw * 0.5f * (s_src + a.score[b]) * sim;      // :1163
+            const float thr = family == 0 ? 0.25f : 0.01f;                     // L3D_MIN_AFFINITY / 0.01f
+            pairs[k] = make_int2(si, b);
+            wgt[k] = wv > thr ? wv : -1.0f;
+        }
+        written += __popcll(bal);
+    };
+
+    for (long long c0 = pb; c0 < pe; c0 += a.chunk) {
+        const long long e = c0 + lane;
+        int t, len, pre; long long cs;
+        const int T = pass_layout(a, e, lane < a.chunk && e < pe, t, cs, len, pre);
+        s_pre[wave][lane] = pre;
+        s_t[wave][lane] = t; s_cs[wave][lane] = cs; s_e[wave][lane] = e;
+        for (int q0 = 0; q0 < T; q0 += 64, ++w) {
+            const int q = q0 + lane;
+            bool on = false;
+            int b = -1, family = 0;
+            // the target this entry belongs to: the last contributing lane with pre <= q
+            int k = -1;
+            const unsigned long long contrib = __ballot(len != 0);
+            if (q < T) {
+                unsigned long long m = contrib;
+                while (m) {                                                    // (few expanded targets per pass)
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    if (s_pre[wave][j] <= q) k = j; else break;
+                }
+            }
+            if (!kEmit) {
+                if (k >= 0) {
+                    const int pos = q - s_pre[wave][k] - 1;
+                    const int tk = s_t[wave][k];
+                    if (pos < 0) {                                             // the expanded target itself
+                        on = true;
+                    } else {
+                        const int c = a.coll_other[s_cs[wave][k] + pos];
+                        const long long ek = s_e[wave][k];
+                        const long long gs = pot_lower(a, pb, ek, a.seg_base[a.dview[tk]]);
+                        bool skip = false;
+                        {   // c is an earlier target of the group?
+                            const long long p = pot_lower(a, gs, ek, c);
+                            skip = p < ek && a.pot_tgt[p] == c;
+                        }
+                        for (long long e2 = gs; e2 < ek && !skip; ++e2)         // an earlier expanded target lists c?
+                            if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], c)) skip = true;
+                        if (!skip) {
+                            const int hb = a.best[c];
+                            if (hb >= 0 && !(hb < si && met_by(a, hb, d, vi))) on = true;   // marked; a candidate when it has a hypothesis
+                        }
+                    }
+                }
+                const unsigned long long bal = __ballot(on);
+                if (lane == 0) words[w] = bal;
+                written += __popcll(bal);
+            } else {
+                const unsigned long long bal = words[w];
+                on = (bal >> lane) & 1ull;
+                if (on) {
+                    const int pos = q - s_pre[wave][k] - 1;
+                    if (pos < 0) { b = a.best[s_t[wave][k]]; family = 0; }
+                    else { b = a.best[a.coll_other[s_cs[wave][k] + pos]]; family = 1; }
+                }
+                emit(on, b, family, 0.0f);
+            }
+        }
+    }
+    // family 2: the segments collinear with the source itself (line3D.cc:1141-1214)
+    const long long cb = a.coll_start[d], ce = a.coll_start[d + 1];
+    for (long long q0 = cb; q0 < ce; q0 += 64, ++w) {
+        const long long q = q0 + lane;
+        if (!kEmit) {
+            bool on = false;
+            if (q < ce) {
+                const int x = a.coll_other[q];
+                const int hb = a.best[x];
+                on = hb >= 0 && !(hb < si && coll_has(a, x, d));
+            }
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) words[w] = bal;
+            written += __popcll(bal);
+        } else {
+            const unsigned long long bal = words[w];
+            const bool on = (bal >> lane) & 1ull;
+            emit(on, on ? a.best[a.coll_other[q]] : -1, 2, on ? a.coll_w[q] : 0.0f);
+        }
+    }
+    if (!kEmit && lane == 0) cnt[si] = written;
+}
+
+// first-touch numbering: a node is created the first time a hypothesis appears in a candidate that passed its threshold,
+// source before target (line3D.cc:1020-1048 and the two other families)
+__global__ void k_aff_first(const int2* __restrict__ pairs, const float* __restrict__ wgt, int n, int* __restrict__ first, int* __restrict__ kept)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const bool on = wgt[k] > 0.0f;
+    kept[k] = on ? 1 : 0;
+    if (on) { atomicMin(&first[pairs[k].x], 2 * k); atomicMin(&first[pairs[k].y], 2 * k + 1); }
+}
+__global__ void k_aff_posflag(const int* __restrict__ first, int n_hyp, int* __restrict__ posflag)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n_hyp && first[h] != 0x7fffffff) posflag[first[h]] = 1;
+}
+__global__ void k_aff_nodes(const int* __restrict__ first, const int* __restrict__ posrank, int n_hyp, int* __restrict__ node, int* __restrict__ node_hyp)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hyp) return;
+    const int f = first[h];
+    const int nd = f != 0x7fffffff ? posrank[f] : -1;
+    node[h] = nd;
+    if (nd >= 0) node_hyp[nd] = h;
+}
+__global__ void k_aff_edges(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ erank, const int* __restrict__ node,
+                            int n, l3d_edge* __restrict__ A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || !(wgt[k] > 0.0f)) return;
+    const int r = erank[k];
+    const int na = node[pairs[k].x], nb = node[pairs[k].y];
+    A[2 * (size_t)r] = { na, nb, wgt[k] };
+    A[2 * (size_t)r + 1] = { nb, na, wgt[k] };
+}
+__global__ void k_aff_fill(int* p, int n, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace l3d
+
+namespace {
+
+// exclusive sum of n ints into out[0..n] (out[n] = total); tmp: the context's scratch
+int scan_excl(l3d_ctx* c, const int* in, int* out, int n, hipStream_t st)
+{
+    size_t bytes = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n + 1, st));
+    HIPCHK(c, c->g7.reserve(bytes + 256));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->g7.p, bytes, in, out, n + 1, st));
+    return L3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out,
+                      int* n_candidates_out)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!in || !edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    if (n_candidates_out) *n_candidates_out = 0;
+    const int V = in->n_views, nh = in->n_hyp;
+    if (V < 0 || nh < 0 || (V > 0 && (!in->seg_base || !in->view_hyp_begin))) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (nh == 0) return L3D_OK;
+    const int nd = in->seg_base[V];
+    if (nd <= 0 || !in->hyp || !in->score || !in->hyp_dense || !in->best || !in->pot_start || !in->coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    const long long n_pot = in->pot_start[nd], n_coll = in->coll_start[nd];
+    if (n_pot < 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_pot > 0 && !in->pot_tgt) || (n_coll > 0 && (!in->coll_other || !in->coll_w)))
+        return fail(c, L3D_ERR_INVALID, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool timing = getenv("L3D_TIMING") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = now_s(); fprintf(stderr, "[l3d affinity] %-34s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
+
+    // ---- inputs to the device (one arena, 256-byte aligned slices)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_base = 0;
+    const size_t o_dview = o_base + al((size_t)(V + 1) * 4);
+    const size_t o_hyp = o_dview + al((size_t)nd * 4);
+    const size_t o_score = o_hyp + al((size_t)nh * sizeof(Hypothesis));
+    const size_t o_hd = o_score + al((size_t)nh * 4);
+    const size_t o_best = o_hd + al((size_t)nh * 4);
+    const size_t o_ps = o_best + al((size_t)nd * 4);
+    const size_t o_pt = o_ps + al((size_t)(nd + 1) * 8);
+    const size_t o_cs = o_pt + al((size_t)n_pot * 4 + 4);
+    const size_t o_co = o_cs + al((size_t)(nd + 1) * 8);
+    const size_t o_cw = o_co + al((size_t)n_coll * 4 + 4);
+    const size_t o_fl = o_cw + al((size_t)n_coll * 4 + 4);
+    const size_t total = o_fl + al((size_t)n_pot + 4);
+    HIPCHK(c, c->g0.reserve(total));
+    char* base = c->g0.as<char>();
+    auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+    HIPCHK(c, up(o_base, in->seg_base, (size_t)(V + 1) * 4));
+    HIPCHK(c, up(o_hyp, in->hyp, (size_t)nh * sizeof(Hypothesis)));
+    HIPCHK(c, up(o_score, in->score, (size_t)nh * 4));
+    HIPCHK(c, up(o_hd, in->hyp_dense, (size_t)nh * 4));
+    HIPCHK(c, up(o_best, in->best, (size_t)nd * 4));
+    HIPCHK(c, up(o_ps, in->pot_start, (size_t)(nd + 1) * 8));
+    HIPCHK(c, up(o_pt, in->pot_tgt, (size_t)n_pot * 4));
+    HIPCHK(c, up(o_cs, in->coll_start, (size_t)(nd + 1) * 8));
+    HIPCHK(c, up(o_co, in->coll_other, (size_t)n_coll * 4));
+    HIPCHK(c, up(o_cw, in->coll_w, (size_t)n_coll * 4));
+    HIPCHK(c, hipMemsetAsync(base + o_fl, 0, (size_t)n_pot + 4, st));
+    AffIn a;
+    a.n_views = V; a.n_hyp = nh; a.n_dense = nd;
+    a.chunk = 64;
+    if (const char* e = getenv("L3D_AFF_CHUNK")) a.chunk = std::max(1, std::min(64, atoi(e)));       // tests: forces multi-pass groups on small scenes
+    a.seg_base = reinterpret_cast<const int*>(base + o_base);
+    a.dview = reinterpret_cast<const int*>(base + o_dview);
+    a.hyp = reinterpret_cast<const Hypothesis*>(base + o_hyp);
+    a.score = reinterpret_cast<const float*>(base + o_score);
+    a.hyp_dense = reinterpret_cast<const int*>(base + o_hd);
+    a.best = reinterpret_cast<const int*>(base + o_best);
+    a.pot_start = reinterpret_cast<const long long*>(base + o_ps);
+    a.pot_tgt = reinterpret_cast<const int*>(base + o_pt);
+    a.coll_start = reinterpret_cast<const long long*>(base + o_cs);
+    a.coll_other = reinterpret_cast<const int*>(base + o_co);
+    a.coll_w = reinterpret_cast<const float*>(base + o_cw);
+    a.flags = reinterpret_cast<unsigned char*>(base + o_fl);
+    int maxS = 1;
+    for (int v = 0; v < V; ++v) maxS = std::max(maxS, in->seg_base[v + 1] - in->seg_base[v]);
+    hipLaunchKernelGGL(k_aff_dview, dim3((maxS + 255) / 256, V), dim3(256), 0, st, a.seg_base, V, reinterpret_cast<int*>(base + o_dview));
+    lap("upload");
+
+    // ---- expanded bits: consecutive views share a launch unless one of them reads bits of the views before it
+    const dim3 gsrc((nh + 3) / 4);
+    HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
+    int* needs_prev = c->g1.as<int>() + ((size_t)nh + 2) * 4;
+    HIPCHK(c, hipMemsetAsync(needs_prev, 0, (size_t)V * 4, st));
+    { ProfScope p(c, "aff_sym", st); hipLaunchKernelGGL(k_aff_sym, gsrc, dim3(256), 0, st, a, needs_prev); }
+    std::vector<int> cut((size_t)V, 0);
+    HIPCHK(c, hipMemcpyAsync(cut.data(), needs_prev, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    static const bool per_view = getenv("L3D_AFF_PER_VIEW") && atoi(getenv("L3D_AFF_PER_VIEW")) != 0;   // tests: the general schedule everywhere
+    int n_launches = 0;
+    for (int v0 = 0; v0 < V;) {
+        int v1 = v0 + 1;
+        while (v1 < V && !cut[(size_t)v1] && !per_view) ++v1;
+        const int h0 = in->view_hyp_begin[v0], h1 = in->view_hyp_begin[v1];
+        if (h1 > h0) { ProfScope p(c, "aff_groups", st); hipLaunchKernelGGL(k_aff_groups, dim3((h1 - h0 + 3) / 4), dim3(256), 0, st, a, h0, h1); ++n_launches; }
+        v0 = v1;
+    }
+    if (timing) fprintf(stderr, "[l3d affinity] %d launch(es) of k_aff_groups for %d views\n", n_launches, V);
+    lap("reverse records + groups");
+
+    // ---- words, decisions, candidate offsets
+    int* nwords = c->g1.as<int>();
+    int* word_off = nwords + (nh + 2);
+    int* cnt = word_off + (nh + 2);
+    int* item_off = cnt + (nh + 2);
+    HIPCHK(c, hipMemsetAsync(nwords, 0, ((size_t)nh + 2) * 4 * 4, st));
+    { ProfScope p(c, "aff_words", st); hipLaunchKernelGGL(k_aff_words, gsrc, dim3(256), 0, st, a, nwords); }
+    if (int rc = scan_excl(c, nwords, word_off, nh, st)) return rc;
+    int n_words = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_words, word_off + nh, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, c->g2.reserve(((size_t)n_words + 1) * 8));
+    const float two_log = 2.0f * logf(0.01f);      // view.cc:376
+    { ProfScope p(c, "aff_decide", st);
+      hipLaunchKernelGGL(k_aff_items<false>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, in->sigma_a, two_log); }
+    if (int rc = scan_excl(c, cnt, item_off, nh, st)) return rc;
+    int n_items = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_items, item_off + nh, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    lap("words + decisions");
+    if (n_candidates_out) *n_candidates_out = n_items;
+    if (n_items == 0) return L3D_OK;
+    if (n_items > 0x3fffffff) return fail(c, L3D_ERR_NOMEM, "affinity fill: more than 2^30 candidate pairs");
+
+    // ---- candidates (similarity, thresholds), numbering, edges
+    HIPCHK(c, c->g3.reserve((size_t)n_items * 8 + 256));
+    HIPCHK(c, c->g4.reserve((size_t)n_items * 4 + 256));
+    int2* pairs = c->g3.as<int2>();
+    float* wgt = c->g4.as<float>();
+    { ProfScope p(c, "aff_emit", st);
+      hipLaunchKernelGGL(k_aff_items<true>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), (int*)nullptr, item_off, pairs, wgt, in->sigma_a, two_log); }
+    // first[] n_hyp | node[] n_hyp | kept[] n_items+1 | erank[] n_items+1 | posflag[] 2 n_items+1 | posrank[] 2 n_items+1
+    const size_t ni = (size_t)n_items;
+    HIPCHK(c, c->g5.reserve(((size_t)nh * 2 + (ni + 1) * 2 + (2 * ni + 1) * 2) * 4 + 1024));
+    int* first = c->g5.as<int>();
+    int* node = first + nh;
+    int* kept = node + nh;
+    int* erank = kept + (ni + 1);
+    int* posflag = erank + (ni + 1);
+    int* posrank = posflag + (2 * ni + 1);
+    hipLaunchKernelGGL(k_aff_fill, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, 0x7fffffff);
+    HIPCHK(c, hipMemsetAsync(kept, 0, ((ni + 1) * 2 + (2 * ni + 1) * 2) * 4, st));
+    hipLaunchKernelGGL(k_aff_first, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, n_items, first, kept);
+    hipLaunchKernelGGL(k_aff_posflag, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, posflag);
+    if (int rc = scan_excl(c, kept, erank, n_items, st)) return rc;
+    if (int rc = scan_excl(c, posflag, posrank, 2 * n_items, st)) return rc;
+    int totals[2] = { 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(&totals[0], erank + ni, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&totals[1], posrank + 2 * ni, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int n_kept = totals[0], n_nodes = totals[1];
+    lap("candidates + numbering");
+    if (n_kept == 0) return L3D_OK;
+    HIPCHK(c, c->g6.reserve((size_t)n_kept * 2 * sizeof(l3d_edge) + (size_t)n_nodes * 4 + 512));
+    l3d_edge* dA = c->g6.as<l3d_edge>();
+    int* d_node_hyp = reinterpret_cast<int*>(c->g6.as<char>() + al((size_t)n_kept * 2 * sizeof(l3d_edge)));
+    hipLaunchKernelGGL(k_aff_nodes, dim3((nh + 255) / 256), dim3(256), 0, st, first, posrank, nh, node, d_node_hyp);
+    hipLaunchKernelGGL(k_aff_edges, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, node, n_items, dA);
+    l3d_edge* A = static_cast<l3d_edge*>(malloc((size_t)n_kept * 2 * sizeof(l3d_edge)));
+    int32_t* nh_out = static_cast<int32_t*>(malloc((size_t)n_nodes * 4 + 4));
+    if (!A || !nh_out) { free(A); free(nh_out); return fail(c, L3D_ERR_NOMEM, "affinity fill: host allocation failed"); }
+    hipError_t e1 = hipMemcpyAsync(A, dA, (size_t)n_kept * 2 * sizeof(l3d_edge), hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(nh_out, d_node_hyp, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e3 = hipStreamSynchronize(st);
+    hipError_t e4 = hipGetLastError();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        free(A); free(nh_out);
+        return fail(c, L3D_ERR_HIP, std::string("affinity fill: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4));
+    }
+    lap("edges + download");
+    *edges_out = A; *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
+    return L3D_OK;
+}
+
+}  // extern "C"

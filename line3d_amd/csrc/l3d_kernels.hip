@@ -21,6 +21,7 @@
 #include "l3d_kernels.hpp"
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
+#include "l3d_similarity.hpp"
 
 namespace l3d {
 
@@ -808,54 +809,14 @@ __global__ void k_diffusion_step(const float4* __restrict__ P, const float4* __r
 }
 
 // =================================================================================================
-// similarity_coll3D (line3D.cc:1600-1681): double geometry, float Gaussians.
+// batched similarity_coll3D (l3d_similarity.hpp)
 // =================================================================================================
-__device__ __forceinline__ float p2l_3D(const double* P1, const double* dir, const double* X)   // :1684-1691
-{
-    const double v0 = X[0] - P1[0], v1 = X[1] - P1[1], v2 = X[2] - P1[2];
-    const double s = v0 * dir[0] + v1 * dir[1] + v2 * dir[2];
-    const double d0 = (P1[0] + dir[0] * s) - X[0];
-    const double d1 = (P1[1] + dir[1] * s) - X[1];
-    const double d2 = (P1[2] + dir[2] * s) - X[2];
-    return (float)__builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-}
-__device__ __forceinline__ float lower_unc(const Hypothesis& h, float depth)   // view.cc:353-359
-{
-    return depth < h.median_depth ? h.k_lower * depth : h.k_lower * h.median_depth;
-}
-__device__ __forceinline__ float upper_unc(const Hypothesis& h, float depth)
-{
-    return depth < h.median_depth ? h.k_upper * depth : h.k_upper * h.median_depth;
-}
-__device__ __forceinline__ float gauss_term(const Hypothesis& h, float depth, float d, float two_log)
-{
-    const float lo = lower_unc(h, depth);
-    if (d < lo) return 1.0f;
-    const float up = upper_unc(h, depth);
-    const float sig = -(up - lo) * (up - lo) / two_log;         // view.cc:371-377
-    return c_expf(-(d - lo) * (d - lo) / (2.0f * sig));
-}
-
 __global__ void k_similarity(const Hypothesis* __restrict__ hyp, const int2* __restrict__ pairs, int n,
                              float sigma_a, float two_log, float* __restrict__ sim)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const Hypothesis& a = hyp[pairs[k].x];
-    const Hypothesis& b = hyp[pairs[k].y];
-    const float d1 = p2l_3D(b.P1, b.dir, a.P1);
-    const float d2 = p2l_3D(b.P1, b.dir, a.P2);
-    const float w12 = __builtin_fminf(gauss_term(a, a.depth_p1, d1, two_log), gauss_term(a, a.depth_p2, d2, two_log));
-    const float d3 = p2l_3D(a.P1, a.dir, b.P1);
-    const float d4 = p2l_3D(a.P1, a.dir, b.P2);
-    const float w34 = __builtin_fminf(gauss_term(b, b.depth_p1, d3, two_log), gauss_term(b, b.depth_p2, d4, two_log));
-    const float w_d = __builtin_fminf(w12, w34);
-    const double dd = a.dir[0] * b.dir[0] + a.dir[1] * b.dir[1] + a.dir[2] * b.dir[2];
-    float angle = (float)(c_acos(__builtin_fmax(__builtin_fmin(dd, 1.0), -1.0)) / 3.14159265358979323846 * (double)180.0f);
-    if (angle > 90.0f) angle = 180.0f - angle;
-    const float w_a = c_expf(-angle * angle / (2.0f * sigma_a * sigma_a));
-    const float s = __builtin_fminf(w_d, w_a);
-    sim[k] = s <= 0.01f ? 0.0f : s;
+    sim[k] = similarity_coll3D(hyp[pairs[k].x], hyp[pairs[k].y], sigma_a, two_log);
 }
 
 __global__ void k_test_sqthr(const float* __restrict__ u, int n, float* __restrict__ walk, float* __restrict__ fast)

@@ -1424,6 +1424,106 @@ int cluster_segments_2D(L* h, bool perform_diff)
         for (size_t i = 0; i < nv; ++i) { hyp_begin[i] = run; run += cnt[i]; }
     }
 
+    if (!getenv("L3D_AFFINITY_HOST")) {
+        // ---- the whole fill on the device (l3d_affinity.hip): flat tables in, edge list and node numbering out
+        const unsigned nt = finish_threads();
+        if (voff.back() > 0x7fffffffu || nh > 0x3fffffffu) return h->fail(L3D_ERR_INVALID, "affinity fill: too many segments");
+        const size_t ndense = voff.back();
+        std::vector<int32_t> seg_base(nv + 1), vhb(nv + 1);
+        for (size_t i = 0; i <= nv; ++i) { seg_base[i] = (int32_t)voff[i]; vhb[i] = (int32_t)hyp_begin[i]; }
+        vhb[nv] = (int32_t)nh;
+        std::unique_ptr<l3d_hypothesis[]> hy(new l3d_hypothesis[nh]);
+        std::unique_ptr<float[]> score(new float[nh]);
+        std::unique_ptr<int32_t[]> hyp_dense(new int32_t[nh]), best(new int32_t[ndense + 1]);
+        parallel_slices(nh, nt, [&](size_t b0, size_t b1, unsigned) {
+            for (size_t i = b0; i < b1; ++i) {
+                const Hyp& sh = h->hyps[i];
+                const size_t vi = (size_t)view_of(kcam(sh.src));
+                const View& v = *h->vlist[vi];
+                l3d_hypothesis& o = hy[i];
+                o.P1[0] = sh.P1.x; o.P1[1] = sh.P1.y; o.P1[2] = sh.P1.z;
+                o.P2[0] = sh.P2.x; o.P2[1] = sh.P2.y; o.P2[2] = sh.P2.z;
+                o.dir[0] = sh.dir.x; o.dir[1] = sh.dir.y; o.dir[2] = sh.dir.z;
+                o.depth_p1 = sh.depth_p1; o.depth_p2 = sh.depth_p2;
+                o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
+                score[i] = sh.score;
+                hyp_dense[i] = (int32_t)(voff[vi] + kseg(sh.src));
+            }
+        });
+        // potential correspondences and collinearities as CSR over dense ids (a view's rows are written by one thread)
+        std::unique_ptr<int64_t[]> pot_start(new int64_t[ndense + 1]), coll_start(new int64_t[ndense + 1]);
+        std::vector<std::vector<int32_t>> vt(nv);
+        pot_start[0] = 0; coll_start[0] = 0;
+        {
+            std::atomic<size_t> next{ 0 };
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t vi = next.fetch_add(1, std::memory_order_relaxed);
+                    if (vi >= nv) break;
+                    const View& sv = *h->vlist[vi];
+                    const size_t S = (size_t)sv.S();
+                    for (size_t sg = 0; sg < S; ++sg) { pot_start[voff[vi] + sg + 1] = 0; best[voff[vi] + sg] = h->best_idx[vi][sg];
+                                                        coll_start[voff[vi] + sg + 1] = sv.coll_start[sg + 1] - sv.coll_start[sg]; }
+                    std::vector<int32_t>& out = vt[vi];
+                    out.clear();
+                    out.reserve(h->pot[vi].size());
+                    for (const auto& e : h->pot[vi]) {
+                        // keys whose camera is not a view (early-return quirk) or whose segment does not exist never have a
+                        // hypothesis or collinear segments: they take no part in the fill
+                        const int tvi = view_of(kcam(e.second));
+                        if (tvi < 0 || e.first >= S) continue;
+                        const uint32_t tseg = kseg(e.second);
+                        if (tseg >= (uint32_t)h->vlist[(size_t)tvi]->S()) continue;
+                        out.push_back((int32_t)(voff[(size_t)tvi] + tseg));
+                        ++pot_start[voff[vi] + e.first + 1];
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < std::min<unsigned>(nt, (unsigned)nv); ++t) th.emplace_back(worker);
+            worker();
+            for (auto& x : th) x.join();
+        }
+        for (size_t dd = 0; dd < ndense; ++dd) { pot_start[dd + 1] += pot_start[dd]; coll_start[dd + 1] += coll_start[dd]; }
+        const size_t n_pot = (size_t)pot_start[ndense], n_coll = (size_t)coll_start[ndense];
+        std::unique_ptr<int32_t[]> pot_tgt(new int32_t[n_pot + 1]), coll_other(new int32_t[n_coll + 1]);
+        std::unique_ptr<float[]> coll_w(new float[n_coll + 1]);
+        {
+            std::atomic<size_t> next{ 0 };
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t vi = next.fetch_add(1, std::memory_order_relaxed);
+                    if (vi >= nv) break;
+                    const View& sv = *h->vlist[vi];
+                    if (!vt[vi].empty()) memcpy(pot_tgt.get() + pot_start[voff[vi]], vt[vi].data(), vt[vi].size() * 4);
+                    const size_t cb = (size_t)coll_start[voff[vi]], cn = sv.coll_other.size();
+                    for (size_t q = 0; q < cn; ++q) { coll_other[cb + q] = (int32_t)(voff[vi] + (size_t)sv.coll_other[q]); coll_w[cb + q] = sv.coll_w[q]; }
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < std::min<unsigned>(nt, (unsigned)nv); ++t) th.emplace_back(worker);
+            worker();
+            for (auto& x : th) x.join();
+        }
+        lap("pack tables");
+        l3d_affinity_input in;
+        in.n_views = (int32_t)nv; in.seg_base = seg_base.data(); in.view_hyp_begin = vhb.data();
+        in.n_hyp = (int32_t)nh; in.hyp = hy.get(); in.score = score.get(); in.hyp_dense = hyp_dense.get(); in.best = best.get();
+        in.pot_start = pot_start.get(); in.pot_tgt = pot_tgt.get();
+        in.coll_start = coll_start.get(); in.coll_other = coll_other.get(); in.coll_w = coll_w.get();
+        in.sigma_a = h->sigma_a;
+        l3d_edge* edges = nullptr; int32_t* node_hyp = nullptr; int n_edges = 0, n_nodes = 0, n_cand = 0;
+        int rc = l3d_affinity_fill(h->ctx, &in, &edges, &n_edges, &node_hyp, &n_nodes, &n_cand);
+        if (rc) return h->fail(rc, std::string("affinity fill: ") + l3d_last_error(h->ctx));
+        lap("affinity fill (device)");
+        h->A.resize((size_t)n_edges);
+        parallel_slices((size_t)n_edges, nt, [&](size_t k0, size_t k1, unsigned) { if (k1 > k0) memcpy(&h->A[k0], edges + k0, (k1 - k0) * sizeof(l3d_edge)); });
+        h->local2global.resize((size_t)n_nodes);
+        for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
+        l3d_free(edges); l3d_free(node_hyp);
+        if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges, %u threads\n", nh, n_cand, h->A.size(), nt);
+        lap("edge list to host");
+    } else {
     // Candidate enumeration in the reference's order.  used[src][x] <=> x met earlier in this iteration, or src met while x was
     // the source (an earlier iteration).  The iterations of ONE view are independent of each other: a source only asks what
     // sources of EARLIER views met (potential correspondences and their collinear segments live in other views), except for
@@ -1608,13 +1708,14 @@ int cluster_segments_2D(L* h, bool perform_diff)
     });
     if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %zu candidate pairs, %zu edges, %u threads\n", nh, n_items, h->A.size(), nt);
     lap("thresholds / numbering");
+    }
     h->t_affinity = now_s() - t0;
     if (h->A.empty()) return L3D_OK;                                            // :1232-1233
 
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
     EdgeVec diffused;
-    if (perform_diff) { rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
+    if (perform_diff) { const int rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
     const EdgeVec& edges = perform_diff ? diffused : h->A;
     std::vector<int> labels;
     perform_clustering(edges.data(), edges.size(), n_nodes, 1.0f, labels);      // :1245
@@ -1661,7 +1762,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                 }
             }
         };
-        const unsigned ntf = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, groups.size() / 64 + 1));
+        const unsigned ntf = (unsigned)std::max<size_t>(1, std::min<size_t>(finish_threads(), groups.size() / 64 + 1));
         std::vector<std::thread> th;
         for (unsigned t = 1; t < ntf; ++t) th.emplace_back(worker);
         worker();
