@@ -193,6 +193,32 @@ class Context:
                                                        C.c_float(sigma_a), _p(sim)))
         return sim
 
+    def affinity_fill(self, seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, sigma_a):
+        """l3d_affinity_fill: flat tables -> (edges EDGE_DTYPE, node_hyp int32, number of enumerated candidate pairs)."""
+        class In(C.Structure):
+            _fields_ = [("n_views", C.c_int32), ("seg_base", C.c_void_p), ("view_hyp_begin", C.c_void_p), ("n_hyp", C.c_int32),
+                        ("hyp", C.c_void_p), ("score", C.c_void_p), ("hyp_dense", C.c_void_p), ("best", C.c_void_p),
+                        ("pot_start", C.c_void_p), ("pot_tgt", C.c_void_p), ("coll_start", C.c_void_p), ("coll_other", C.c_void_p),
+                        ("coll_w", C.c_void_p), ("sigma_a", C.c_float)]
+        arrs = [np.ascontiguousarray(seg_base, np.int32), np.ascontiguousarray(view_hyp_begin, np.int32), np.ascontiguousarray(hyp, HYP_DTYPE),
+                np.ascontiguousarray(score, np.float32), np.ascontiguousarray(hyp_dense, np.int32), np.ascontiguousarray(best, np.int32),
+                np.ascontiguousarray(pot_start, np.int64), np.ascontiguousarray(pot_tgt, np.int32), np.ascontiguousarray(coll_start, np.int64),
+                np.ascontiguousarray(coll_other, np.int32), np.ascontiguousarray(coll_w, np.float32)]
+        ptr = [a.ctypes.data_as(C.c_void_p) for a in arrs]
+        inp = In(len(arrs[0]) - 1, ptr[0], ptr[1], len(arrs[2]), ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], ptr[8], ptr[9], ptr[10], float(sigma_a))
+        edges, nodes = C.c_void_p(), C.c_void_p()
+        ne, nn, nc = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.l3d_affinity_fill(self.h, C.byref(inp), C.byref(edges), C.byref(ne), C.byref(nodes), C.byref(nn), C.byref(nc)))
+        A = np.zeros(ne.value, dtype=EDGE_DTYPE)
+        node_hyp = np.zeros(nn.value, dtype=np.int32)
+        if ne.value:
+            C.memmove(A.ctypes.data, edges, ne.value * 12)
+        if nn.value:
+            C.memmove(node_hyp.ctypes.data, nodes, nn.value * 4)
+        self.lib.l3d_free(edges)
+        self.lib.l3d_free(nodes)
+        return A, node_hyp, nc.value
+
     def test_contract_math(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         e = np.zeros(len(x), np.float32)

@@ -160,13 +160,22 @@ def test_full_size_diffusion_equals_oracle(chain_run, oracle_lib):
     ctx.close()
 
 
-def test_full_size_finish_threads_do_not_change_results(chain_run, monkeypatch):
-    """The finishing stages (candidate enumeration of clusterSegments2D, edge ordering, line fit) run on worker threads;
-    on one thread the enumeration applies the reference's `used` rule literally.  Same affinity list, same lines."""
+def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, monkeypatch):
+    """The affinity fill runs on the device (l3d_affinity_fill: per-target "expanded" bits instead of the reference's `used`
+    maps).  Cross-check at full size against the host enumeration kept for this purpose (L3D_AFFINITY_HOST=1), which on one
+    thread applies the reference's `used` rule literally -- and against the device path with 5-target passes (groups and
+    flattened entries straddling passes) and with one launch per view (the schedule of scenes with one-way records).
+    The other finishing stages (edge ordering, line fit) run on worker threads: 1, 5 and 16 threads.  Same list, same lines."""
     l, _ = chain_run
     out = {}
-    for threads in ("1", "16", "5"):
-        monkeypatch.setenv("L3D_HOST_THREADS", threads)
+    variants = {"device": {}, "device, 5-target passes": {"L3D_AFF_CHUNK": "5"}, "device, 5 threads": {"L3D_HOST_THREADS": "5"},
+                "host, literal rule (1 thread)": {"L3D_AFFINITY_HOST": "1", "L3D_HOST_THREADS": "1"},
+                "host, 16 threads": {"L3D_AFFINITY_HOST": "1", "L3D_HOST_THREADS": "16"}}
+    for name, env in variants.items():
+        for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFFINITY_HOST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         for diffusion in (False, True):
             l.finish(diffusion)
             A, n_nodes = l.affinity()[:2]
@@ -175,10 +184,11 @@ def test_full_size_finish_threads_do_not_change_results(chain_run, monkeypatch):
             for seg2, seg3 in lines:
                 sig.update(np.asarray(seg2, dtype=np.int64).tobytes())
                 sig.update(np.asarray([np.concatenate(p) for p in seg3], dtype=np.float64).tobytes())
-            out[(threads, diffusion)] = (len(A), n_nodes, len(lines), sig.hexdigest())
+            out[(name, diffusion)] = (len(A), n_nodes, len(lines), sig.hexdigest())
     for diffusion in (False, True):
-        assert out[("1", diffusion)][0] > 100000 and out[("1", diffusion)][2] > 100
-        assert out[("1", diffusion)] == out[("16", diffusion)] == out[("5", diffusion)], diffusion
+        assert out[("device", diffusion)][0] > 100000 and out[("device", diffusion)][2] > 100
+        for name in variants:
+            assert out[(name, diffusion)] == out[("device", diffusion)], (name, diffusion)
 
 
 def test_near_maximum_segments_per_view():

@@ -315,3 +315,134 @@ def test_sq_threshold_closed_form_equals_walk(gpu_ctx):
     T = closed[sel]
     assert np.all(np.sqrt(T) <= u[sel])
     assert np.all(np.sqrt(np.nextafter(T, np.float32(np.inf))) > u[sel])
+
+
+def _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, coll, sigma_a):
+    """clusterSegments2D's three loops with the `used` set, literally (line3D.cc:996-1214), over dense segment ids."""
+    import ctypes as C
+    half = np.float32(0.5)
+
+    def sim(a, b):
+        def parts(h):
+            return (np.concatenate([h["P1"], h["P2"], h["dir"]]).astype(np.float64), np.array([h["depth_p1"], h["depth_p2"]], np.float32),
+                    np.array([h["k_lower"], h["k_upper"], h["median_depth"]], np.float32))
+        s1, d1, c1 = parts(hyp[a])
+        s2, d2, c2 = parts(hyp[b])
+        return np.float32(oracle_lib.l3do_similarity_coll3D(s1.ctypes.data_as(C.POINTER(C.c_double)), d1.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            c1.ctypes.data_as(C.POINTER(C.c_float)), s2.ctypes.data_as(C.POINTER(C.c_double)),
+                                                            d2.ctypes.data_as(C.POINTER(C.c_float)), c2.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(sigma_a)))
+
+    used, node_of, node_hyp, A, n_cand = set(), {}, [], [], 0
+
+    def node(h):
+        if h not in node_of:
+            node_of[h] = len(node_hyp)
+            node_hyp.append(h)
+        return node_of[h]
+
+    def edge(a, b, w):
+        na = node(a)
+        nb = node(b)
+        A.append((na, nb, w))
+        A.append((nb, na, w))
+
+    for si in range(len(hyp)):
+        src = int(hyp_dense[si])
+        for t in pot[src]:
+            if (src, t) in used:
+                continue
+            used.add((src, t)); used.add((t, src))
+            if best[t] >= 0:
+                n_cand += 1
+                w = np.float32(half * np.float32(score[si] + score[best[t]])) * sim(si, best[t])
+                if w > np.float32(0.25):
+                    edge(si, int(best[t]), w)
+                for c, _ in coll[t]:
+                    if (src, c) in used:
+                        continue
+                    used.add((src, c)); used.add((c, src))
+                    if best[c] >= 0:
+                        n_cand += 1
+                        w = np.float32(half * np.float32(score[si] + score[best[c]])) * sim(si, best[c])
+                        if w > np.float32(0.01):
+                            edge(si, int(best[c]), w)
+        for x, cw in coll[src]:
+            if (src, x) in used:
+                continue
+            used.add((src, x)); used.add((x, src))
+            if best[x] >= 0:
+                n_cand += 1
+                w = np.float32(np.float32(np.float32(cw) * half) * np.float32(score[si] + score[best[x]])) * sim(si, best[x])
+                if w > np.float32(0.01):
+                    edge(si, int(best[x]), w)
+    return A, node_hyp, n_cand
+
+
+@pytest.mark.parametrize("seed,one_way,chunk", [(1, 0.0, None), (2, 0.15, None), (3, 0.15, "3"), (4, 0.5, "1"), (5, 0.0, "2")])
+def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib, monkeypatch, seed, one_way, chunk):
+    """l3d_affinity_fill on random flat tables -- clustered hypotheses so that many similarities pass, long target groups,
+    targets without a hypothesis, collinearity lists that are NOT symmetric, potential correspondences recorded one way only
+    (`one_way`: the schedule then waits for earlier views) -- against the reference's loops with a literal `used` set.
+    Small passes (`chunk` targets) make groups and flattened entries straddle passes."""
+    from line3d_amd.capi import HYP_DTYPE
+    if chunk:
+        monkeypatch.setenv("L3D_AFF_CHUNK", chunk)
+    rng = np.random.default_rng(seed)
+    V, S = 7, 40
+    seg_base = np.arange(V + 1, dtype=np.int32) * S
+    nd = V * S
+    has_hyp = rng.random(nd) < 0.8
+    best = np.full(nd, -1, np.int32)
+    best[has_hyp] = np.arange(int(has_hyp.sum()), dtype=np.int32)
+    hyp_dense = np.nonzero(has_hyp)[0].astype(np.int32)
+    nh = len(hyp_dense)
+    view_hyp_begin = np.searchsorted(hyp_dense, seg_base).astype(np.int32)
+    # hypotheses: a few 3-D lines, every hypothesis a noisy piece of one of them
+    lines_p = rng.normal(size=(12, 3)); lines_d = rng.normal(size=(12, 3)); lines_d /= np.linalg.norm(lines_d, axis=1, keepdims=True)
+    which = rng.integers(0, 12, nh)
+    hyp = np.zeros(nh, HYP_DTYPE)
+    for i in range(nh):
+        a, b = np.sort(rng.uniform(-1, 1, 2))
+        P1 = lines_p[which[i]] + a * lines_d[which[i]] + rng.normal(scale=0.002, size=3)
+        P2 = lines_p[which[i]] + (b + 0.1) * lines_d[which[i]] + rng.normal(scale=0.002, size=3)
+        dd = P2 - P1
+        hyp[i]["P1"], hyp[i]["P2"], hyp[i]["dir"] = P1, P2, dd / np.linalg.norm(dd)
+        hyp[i]["depth_p1"], hyp[i]["depth_p2"] = rng.uniform(2, 6, 2)
+        hyp[i]["k_lower"], hyp[i]["k_upper"], hyp[i]["median_depth"] = 0.002, 0.01, 4.0
+    score = rng.uniform(0.3, 1.0, nh).astype(np.float32)
+    # potential correspondences: dense, both directions unless dropped one way
+    pot = [set() for _ in range(nd)]
+    for d in range(nd):
+        for _ in range(rng.integers(0, 9)):
+            tv = int(rng.integers(0, V))
+            if tv == d // S:
+                continue
+            base = int(rng.integers(0, S - 6))
+            for t in range(base, base + int(rng.integers(1, 6))):       # runs: long groups in one view
+                pot[d].add(tv * S + t)
+                if rng.random() >= one_way:
+                    pot[tv * S + t].add(d)
+    pot = [sorted(p) for p in pot]
+    coll = [dict() for _ in range(nd)]
+    for d in range(nd):
+        v = d // S
+        for _ in range(rng.integers(0, 5)):
+            x = v * S + int(rng.integers(0, S))
+            if x == d:
+                continue
+            w = np.float32(rng.uniform(0.05, 1.0))
+            coll[d][x] = w
+            if rng.random() < 0.8:                                       # mostly, not always, symmetric
+                coll[x][d] = w
+    coll = [sorted(c.items()) for c in coll]
+    pot_start = np.zeros(nd + 1, np.int64); pot_start[1:] = np.cumsum([len(p) for p in pot])
+    coll_start = np.zeros(nd + 1, np.int64); coll_start[1:] = np.cumsum([len(c) for c in coll])
+    pot_tgt = np.array([t for p in pot for t in p], np.int32)
+    coll_other = np.array([x for c in coll for x, _ in c], np.int32)
+    coll_w = np.array([w for c in coll for _, w in c], np.float32)
+    A, node_hyp, n_cand = gpu_ctx.affinity_fill(seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, 10.0)
+    eA, e_nodes, e_cand = _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, coll, 10.0)
+    assert n_cand == e_cand and len(eA) > 200
+    assert node_hyp.tolist() == e_nodes
+    assert A["i"].tolist() == [e[0] for e in eA] and A["j"].tolist() == [e[1] for e in eA]
+    assert np.array_equal(A["w"].view(np.uint32), np.array([e[2] for e in eA], np.float32).view(np.uint32))
