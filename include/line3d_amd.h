@@ -29,6 +29,7 @@ extern "C" {
 #define L3D_ERR_HIP 2
 #define L3D_ERR_NOMEM 3
 #define L3D_ERR_NODEVICE 4
+#define L3D_ERR_UNSUPPORTED 5
 
 /* cudawrapper.h:35,43-46 / commons.h:42-66 */
 #define L3D_RDD_MAX_ITER 10
@@ -152,6 +153,14 @@ typedef struct l3d_affinity_input {
 } l3d_affinity_input;
 int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes,
                       int* n_candidates);
+
+/* The edge list Line3D::performClustering walks (clustering.cc:14-40; the union-find itself stays on the host), prepared on
+ * the device: optionally performDiffusion (line3D.cc:1255-1303: replicator_dynamics_diffusion, then A(i,j) = A(j,i) =
+ * min(W(i,j), W(j,i)), rebuilt in (i,j) order), then the STABLE ascending order by weight of clustering.cc:14.
+ * A == NULL: the list the last l3d_affinity_fill returned, still resident on the device (nnz must match; it is consumed).
+ * L3D_ERR_UNSUPPORTED: the diffused list is not a symmetric pattern of unique entries (never the case for the list of
+ * l3d_affinity_fill) -- take l3d_replicator_dynamics_diffusion and the reference's map arithmetic instead. */
+int l3d_clustering_edges(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, l3d_edge* sorted_out);
 
 
 /* ---- Line3D::matchViews as one device-resident chain --------------------------------------------------------

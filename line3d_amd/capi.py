@@ -219,6 +219,14 @@ class Context:
         self.lib.l3d_free(nodes)
         return A, node_hyp, nc.value
 
+    def clustering_edges(self, edges, n_nodes, perform_diffusion=False, iters=10):
+        """l3d_clustering_edges: (diffused, symmetrised) edge list in performClustering's stable ascending weight order."""
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        out = np.zeros(len(edges), dtype=EDGE_DTYPE)
+        self._chk(self.lib.l3d_clustering_edges(self.h, _p(edges), C.c_int(len(edges)), C.c_int(n_nodes), C.c_int(int(perform_diffusion)),
+                                                C.c_int(iters), _p(out)))
+        return out
+
     def test_contract_math(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         e = np.zeros(len(x), np.float32)

@@ -416,6 +416,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     if (!c) return L3D_ERR_INVALID;
     if (!in || !edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out) return fail(c, L3D_ERR_INVALID, "bad argument");
     *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    c->resident_edges = 0;
     if (n_candidates_out) *n_candidates_out = 0;
     const int V = in->n_views, nh = in->n_hyp;
     if (V < 0 || nh < 0 || (V > 0 && (!in->seg_base || !in->view_hyp_begin))) return fail(c, L3D_ERR_INVALID, "bad argument");
@@ -573,6 +574,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     }
     lap("edges + download");
     *edges_out = A; *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
+    c->resident_edges = 2 * n_kept;                                            // (the list stays in g6 for l3d_clustering_edges)
     return L3D_OK;
 }
 

@@ -1238,20 +1238,27 @@ int best_of(const L* h, Key k)
 }
 
 // Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115 (stays on the host)
-void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, float c, std::vector<int>& labels)
+// presorted: edges_in already is in the stable ascending weight order (l3d_clustering_edges)
+void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, float c, std::vector<int>& labels, bool presorted = false)
 {
     // stable ascending order of the weights (clustering.cc:14: std::stable_sort over CLEdge::operator<)
-    std::vector<uint32_t> order;
-    const double t_sort = now_s();
-    {
-        const l3d_edge* e = edges_in;
-        l3d::parallel_stable_order(n_edges, (size_t)65536, (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
-                                   [e](size_t i) { return l3d::float_order_key(e[i].w) & 0xffffu; }, finish_threads(), order);
+    std::unique_ptr<l3d_edge[]> gathered;
+    const l3d_edge* sorted = edges_in;
+    if (!presorted) {
+        std::vector<uint32_t> order;
+        const double t_sort = now_s();
+        {
+            const l3d_edge* e = edges_in;
+            l3d::parallel_stable_order(n_edges, (size_t)65536, (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
+                                       [e](size_t i) { return l3d::float_order_key(e[i].w) & 0xffffu; }, finish_threads(), order);
+        }
+        // the edges in that order, gathered by the worker threads (the merge loop below then reads them sequentially)
+        gathered.reset(new l3d_edge[n_edges + 1]);
+        l3d_edge* g = gathered.get();
+        parallel_slices(n_edges, finish_threads(), [&](size_t k0, size_t k1, unsigned) { for (size_t k = k0; k < k1; ++k) g[k] = edges_in[order[k]]; });
+        sorted = g;
+        if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
     }
-    // the edges in that order, gathered by the worker threads (the merge loop below then reads them sequentially)
-    std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[n_edges + 1]);
-    parallel_slices(n_edges, finish_threads(), [&](size_t k0, size_t k1, unsigned) { for (size_t k = k0; k < k1; ++k) sorted[k] = edges_in[order[k]]; });
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
     std::vector<int> rank((size_t)numNodes, 0), cid((size_t)numNodes), size((size_t)numNodes, 1);
     std::vector<float> thr((size_t)numNodes, c);
     for (int i = 0; i < numNodes; ++i) cid[i] = i;
@@ -1424,7 +1431,9 @@ int cluster_segments_2D(L* h, bool perform_diff)
         for (size_t i = 0; i < nv; ++i) { hyp_begin[i] = run; run += cnt[i]; }
     }
 
+    bool resident_list = false;                     // the affinity list is still on the device (l3d_affinity_fill ran last)
     if (!getenv("L3D_AFFINITY_HOST")) {
+        resident_list = true;
         // ---- the whole fill on the device (l3d_affinity.hip): flat tables in, edge list and node numbering out
         const unsigned nt = finish_threads();
         if (voff.back() > 0x7fffffffu || nh > 0x3fffffffu) return h->fail(L3D_ERR_INVALID, "affinity fill: too many segments");
@@ -1714,11 +1723,24 @@ int cluster_segments_2D(L* h, bool perform_diff)
 
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
-    EdgeVec diffused;
-    if (perform_diff) { const int rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
-    const EdgeVec& edges = perform_diff ? diffused : h->A;
     std::vector<int> labels;
-    perform_clustering(edges.data(), edges.size(), n_nodes, 1.0f, labels);      // :1245
+    {
+        // the list clustering walks -- diffused and symmetrised when asked for, in stable ascending weight order -- comes from
+        // the device, where the affinity list still is (l3d_clustering_edges); a list the device path does not take
+        // (L3D_ERR_UNSUPPORTED) goes through the reference's map arithmetic on the host
+        std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[h->A.size() + 1]);
+        int rc = resident_list ? l3d_clustering_edges(h->ctx, nullptr, (int)h->A.size(), n_nodes, perform_diff ? 1 : 0, L3D_RDD_MAX_ITER, sorted.get())
+                               : L3D_ERR_UNSUPPORTED;
+        if (rc == L3D_OK) {
+            lap(perform_diff ? "diffusion + edge order (device)" : "edge order (device)");
+            perform_clustering(sorted.get(), h->A.size(), n_nodes, 1.0f, labels, true);   // :1245
+        } else if (rc == L3D_ERR_UNSUPPORTED) {
+            EdgeVec diffused;
+            if (perform_diff) { rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
+            const EdgeVec& edges = perform_diff ? diffused : h->A;
+            perform_clustering(edges.data(), edges.size(), n_nodes, 1.0f, labels);
+        } else return h->fail(rc, std::string("clustering edges: ") + l3d_last_error(h->ctx));
+    }
     lap("clustering");
 
     // processClusteredSegments, line3D.cc:1306-1368: clusters in ascending label order (the reference's std::map), their

@@ -446,3 +446,44 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     assert node_hyp.tolist() == e_nodes
     assert A["i"].tolist() == [e[0] for e in eA] and A["j"].tolist() == [e[1] for e in eA]
     assert np.array_equal(A["w"].view(np.uint32), np.array([e[2] for e in eA], np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("diffusion", [False, True])
+def test_clustering_edges_order_and_diffusion_match_oracle(gpu_ctx, oracle_lib, diffusion):
+    """l3d_clustering_edges: the list performClustering walks.  A random symmetric list with MANY tied weights (the stable
+    order decides the segmentation), signed zeros included: without diffusion the stable ascending order of the input; with
+    diffusion the oracle's replicator dynamics + the reference's map symmetrisation (line3D.cc:1275-1301), then the order."""
+    rng = np.random.default_rng(11)
+    n = 300
+    pairs = set()
+    while len(pairs) < 2500:
+        a, b = (int(x) for x in rng.integers(0, n, 2))
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    levels = np.array([0.0, -0.0, 0.011, 0.25, 0.2500001, 0.5, 0.75, 1.0], np.float32)
+    A = []
+    for a, b in sorted(pairs, key=lambda p: (p[0] * 7919 + p[1] * 104729) % 1000003):
+        w = levels[rng.integers(0, len(levels))] if rng.random() < 0.6 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    A = np.array(A, dtype=op.EDGE_DTYPE)
+    got = gpu_ctx.clustering_edges(A, n, perform_diffusion=diffusion)
+    if diffusion:
+        W = op.rdd(oracle_lib, A, n, 10)
+        entries = {}
+        for e in W:
+            s1, s2, w12 = int(e["i"]), int(e["j"]), np.float32(e["w"])
+            w21 = entries.get(s2, {}).get(s1, w12)
+            w = min(w12, w21)
+            entries.setdefault(s1, {})[s2] = w
+            entries.setdefault(s2, {})[s1] = w
+        exp = np.array([(a, b, entries[a][b]) for a in sorted(entries) for b in sorted(entries[a])], dtype=op.EDGE_DTYPE)
+    else:
+        exp = A
+    exp = exp[np.argsort(exp["w"], kind="stable")]                      # (-0.0 == 0.0 for the comparison, as for CLEdge::operator<)
+    assert got.tobytes() == exp.tobytes()
+    assert len(np.unique(exp["w"])) <= len(exp) // 2                    # (every weight at least twice: the stable order matters)
+    # a list without the transposed entries is refused by the device path, not guessed
+    if diffusion:
+        from line3d_amd.capi import L3DError
+        with pytest.raises(L3DError):
+            gpu_ctx.clustering_edges(A[::2], n, perform_diffusion=True)
