@@ -172,26 +172,28 @@ __global__ __launch_bounds__(256) void k_aff_groups(AffIn a, int h0, int h1)
         }
         s_t[wave][lane] = t;
         const long long g0 = gs > c0 ? gs : c0;                                // the group's part inside this pass starts here
-        const int my_round = valid ? (int)(e - g0) : -1;
-        int rounds = my_round;
-        for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o));
-        unsigned long long exp_mask = 0ull;                                    // expanded targets of this pass (wave-uniform)
+        // Resolution.  A target is decided once every earlier target of its group is: the first undecided target of a group
+        // (its head) has by then been tested against every expanded target before it.  When a head turns out expanded, ALL
+        // undecided targets behind it test its collinear list at once -- the usual group (fragments of one line) is done
+        // after two iterations however long it is.
         bool marked = false, expanded = false;
-        for (int r = 0; r <= rounds; ++r) {
-            if (my_round == r) {
-                bool hit = false;
-                for (long long e2 = gs; e2 < c0 && !hit; ++e2)                 // the group began in an earlier pass of this wave
-                    if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], t)) hit = true;
-                unsigned long long m = exp_mask & ((1ull << lane) - 1ull) & ~((1ull << (int)(g0 - c0)) - 1ull);
-                while (m && !hit) {
-                    const int j = __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    if (coll_has(a, s_t[wave][j], t)) hit = true;
-                }
-                marked = !hit && !mused;
-                expanded = marked && hb >= 0;
+        bool resolved = !valid;
+        if (valid) {
+            bool hit = false;
+            for (long long e2 = gs; e2 < c0 && !hit; ++e2)                     // the group began in an earlier pass of this wave
+                if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], t)) hit = true;
+            resolved = hit;                                                    // listed by an expanded target: not marked
+        }
+        const unsigned long long group_below = ((1ull << lane) - 1ull) & ~((1ull << (int)(g0 - c0)) - 1ull);   // earlier lanes of my group
+        for (;;) {
+            const unsigned long long undecided = __ballot(!resolved);
+            if (!undecided) break;
+            const bool head = !resolved && (undecided & group_below) == 0ull;
+            if (head) { marked = !mused; expanded = marked && hb >= 0; resolved = true; }
+            const unsigned long long fresh = __ballot(head && expanded) & group_below;   // (at most one bit: my group's head)
+            if (!resolved && fresh) {
+                if (coll_has(a, s_t[wave][__ffsll((long long)fresh) - 1], t)) resolved = true;
             }
-            exp_mask |= __ballot(my_round == r && expanded);
         }
         if (valid) __hip_atomic_store(a.flags + e, (unsigned char)((marked ? 1 : 0) | (expanded ? 2 : 0) | (mused ? 4 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                 // (the next pass of this wave may read them back)

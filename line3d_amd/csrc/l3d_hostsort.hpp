@@ -9,7 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -42,13 +45,71 @@ inline unsigned host_threads()         // worker threads of the host-side stages
     return std::max(1u, std::min(16u, usable_cpus()));
 }
 
+// Worker threads of the host-side stages, kept alive between parallel regions (a finish of compute3Dmodel has a dozen regions of
+// a millisecond or two each; creating and joining 15 threads per region cost as much as the regions' work).  One region at a
+// time: a region started while another one runs (nested, or from another thread) gets plain threads of its own.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    void run(unsigned nt, const std::function<void(unsigned)>& fn)
+    {
+        if (nt <= 1) { fn(0u); return; }
+        std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
+        if (!region.owns_lock()) {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
+            fn(0u);
+            for (auto& x : th) x.join();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (threads_.size() + 1 < nt) { const unsigned idx = (unsigned)threads_.size() + 1; threads_.emplace_back([this, idx] { loop(idx); }); }
+            job_ = &fn; job_threads_ = nt; remaining_ = nt - 1; ++gen_;
+        }
+        cv_work_.notify_all();
+        fn(0u);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this] { return remaining_ == 0; });
+        job_ = nullptr;
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_work_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+private:
+    void loop(unsigned idx)
+    {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (idx >= job_threads_) continue;
+            const std::function<void(unsigned)>* job = job_;
+            lk.unlock();
+            (*job)(idx);
+            lk.lock();
+            if (--remaining_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::mutex region_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(unsigned)>* job_ = nullptr;
+    unsigned job_threads_ = 0, remaining_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
 template <class F>
 inline void on_threads(unsigned nt, F fn)   // fn(thread) on nt threads, the caller being thread 0
 {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
-    fn(0u);
-    for (auto& x : th) x.join();
+    const std::function<void(unsigned)> f = [&fn](unsigned t) { fn(t); };
+    HostPool::get().run(nt, f);
 }
 
 // Order of n records by (major(i), minor(i), i), major in [0, n_major), minor in [0, n_minor), on nt threads: a counting sort on the major key

@@ -1192,41 +1192,59 @@ void parallel_slices(size_t n, unsigned nt, F fn)
 {
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n));
     if (nt == 1) { fn((size_t)0, n, 0u); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, t); });
-    fn((size_t)0, n / nt, 0u);
-    for (auto& x : th) x.join();
+    l3d::on_threads(nt, [&](unsigned t) { fn(n * t / nt, n * (t + 1) / nt, t); });
 }
 
-// Line3D::greedySelection, line3D.cc:899-965: the stored list holds one (best) match per segment
+// Line3D::greedySelection, line3D.cc:899-965: the stored list holds one (best) match per segment.  The views are independent:
+// worker threads pick the best match of every segment of their views, the hypotheses are numbered view by view afterwards
+// (a prefix over the views' counts) and unprojected in parallel.
 void greedy_selection(L* h)
 {
-    h->hyps.clear();
-    h->best_idx.assign(h->vlist.size(), {});
-    std::vector<int> best;
-    for (View* v : h->vlist) {
-        std::vector<int>& bi = h->best_idx[(size_t)v->index];
+    const size_t nv = h->vlist.size();
+    h->best_idx.resize(nv);
+    std::vector<std::vector<int>> best(nv);                  // per view: index into the store of the segment's best match, or -1
+    std::vector<size_t> count(nv + 1, 0);
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(finish_threads(), nv));
+    auto for_views = [&](auto fn) {
+        std::atomic<size_t> next{ 0 };
+        auto worker = [&]() { for (;;) { const size_t vi = next.fetch_add(1, std::memory_order_relaxed); if (vi >= nv) break; fn(vi); } };
+        l3d::on_threads(nt, [&](unsigned) { worker(); });
+    };
+    for_views([&](size_t vi) {
+        View* v = h->vlist[vi];
         const uint32_t S = (uint32_t)v->S();
-        bi.assign((size_t)S, -1);
-        if (!v->store_exists) continue;
+        std::vector<int>& b = best[vi];
+        b.assign((size_t)S, -1);
+        h->best_idx[(size_t)v->index].assign((size_t)S, -1);
+        if (!v->store_exists) return;
         // group by segment (ascending), first of the highest confidence
-        best.assign((size_t)S, -1);
         for (size_t i = 0; i < v->store.size(); ++i) {
             const uint32_t sg = v->store[i].segID1;
             if (sg >= S) continue;
-            if (best[sg] < 0 || v->store[i].confidence > v->store[(size_t)best[sg]].confidence) best[sg] = (int)i;
+            if (b[sg] < 0 || v->store[i].confidence > v->store[(size_t)b[sg]].confidence) b[sg] = (int)i;
         }
-        for (uint32_t sg = 0; sg < S; ++sg) {
-            if (best[sg] < 0) continue;
-            const l3d_match& mp = v->store[(size_t)best[sg]];
+        size_t n = 0;
+        for (uint32_t sg = 0; sg < S; ++sg) n += b[sg] >= 0;
+        count[vi + 1] = n;
+    });
+    for (size_t vi = 0; vi < nv; ++vi) count[vi + 1] += count[vi];
+    h->hyps.resize(count[nv]);
+    for_views([&](size_t vi) {
+        View* v = h->vlist[vi];
+        std::vector<int>& bi = h->best_idx[(size_t)v->index];
+        const std::vector<int>& b = best[vi];
+        size_t k = count[vi];
+        for (uint32_t sg = 0; sg < (uint32_t)b.size(); ++sg) {
+            if (b[sg] < 0) continue;
+            const l3d_match& mp = v->store[(size_t)b[sg]];
             Hyp hy;
             hy.src = mk(v->id, sg);
             hy.score = fminf(mp.confidence, 1.0f);
             unproject_segment(*v, sg, mp.depths[0], mp.depths[1], hy);
-            bi[sg] = (int)h->hyps.size();
-            h->hyps.push_back(hy);
+            bi[sg] = (int)k;
+            h->hyps[k++] = hy;
         }
-    }
+    });
 }
 
 int best_of(const L* h, Key k)
@@ -1459,6 +1477,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                 hyp_dense[i] = (int32_t)(voff[vi] + kseg(sh.src));
             }
         });
+        lap("  pack: hypotheses");
         // potential correspondences and collinearities as CSR over dense ids (a view's rows are written by one thread)
         std::unique_ptr<int64_t[]> pot_start(new int64_t[ndense + 1]), coll_start(new int64_t[ndense + 1]);
         std::vector<std::vector<int32_t>> vt(nv);
@@ -1488,11 +1507,9 @@ int cluster_segments_2D(L* h, bool perform_diff)
                     }
                 }
             };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < std::min<unsigned>(nt, (unsigned)nv); ++t) th.emplace_back(worker);
-            worker();
-            for (auto& x : th) x.join();
+            l3d::on_threads(std::min<unsigned>(nt, (unsigned)nv), [&](unsigned) { worker(); });
         }
+        lap("  pack: count + targets per view");
         for (size_t dd = 0; dd < ndense; ++dd) { pot_start[dd + 1] += pot_start[dd]; coll_start[dd + 1] += coll_start[dd]; }
         const size_t n_pot = (size_t)pot_start[ndense], n_coll = (size_t)coll_start[ndense];
         std::unique_ptr<int32_t[]> pot_tgt(new int32_t[n_pot + 1]), coll_other(new int32_t[n_coll + 1]);
@@ -1509,10 +1526,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                     for (size_t q = 0; q < cn; ++q) { coll_other[cb + q] = (int32_t)(voff[vi] + (size_t)sv.coll_other[q]); coll_w[cb + q] = sv.coll_w[q]; }
                 }
             };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < std::min<unsigned>(nt, (unsigned)nv); ++t) th.emplace_back(worker);
-            worker();
-            for (auto& x : th) x.join();
+            l3d::on_threads(std::min<unsigned>(nt, (unsigned)nv), [&](unsigned) { worker(); });
         }
         lap("pack tables");
         l3d_affinity_input in;
@@ -1639,10 +1653,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                 }
             }
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(worker, t);
-        worker(0);
-        for (auto& x : th) x.join();
+        l3d::on_threads(nt, [&](unsigned t) { worker(t); });
     }
     std::vector<size_t> chunk_off(chunks.size() + 1, 0);
     for (size_t c = 0; c < chunks.size(); ++c) chunk_off[c + 1] = chunk_off[c] + chunks[c].items.size();
@@ -1785,10 +1796,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
             }
         };
         const unsigned ntf = (unsigned)std::max<size_t>(1, std::min<size_t>(finish_threads(), groups.size() / 64 + 1));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < ntf; ++t) th.emplace_back(worker);
-        worker();
-        for (auto& x : th) x.join();
+        l3d::on_threads(ntf, [&](unsigned) { worker(); });
     }
     for (FinalLine& fl : fitted) if (!fl.segs3D.empty()) h->result.push_back(std::move(fl));
     lap("line fit");
