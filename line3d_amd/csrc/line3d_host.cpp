@@ -195,6 +195,18 @@ struct l3d_line3d {
     EdgeVec A;
     std::vector<Key> local2global;
     std::vector<FinalLine> result;
+    std::vector<size_t> hyp_begin;                             // per view index: first hypothesis (greedy_selection)
+
+    // flat tables of the device affinity fill (l3d_affinity_input): kept between calls (no allocation, no page faults); the
+    // collinearity part only changes with the set of views (drop_plan)
+    struct AffTables {
+        std::vector<l3d_hypothesis, NoInitAlloc<l3d_hypothesis>> hyp;
+        std::vector<float, NoInitAlloc<float>> score, coll_w;
+        std::vector<int32_t, NoInitAlloc<int32_t>> hyp_dense, best, pot_tgt, coll_other;
+        std::vector<int64_t, NoInitAlloc<int64_t>> pot_start, coll_start;
+        bool coll_valid = false;
+    } aff;
+    std::vector<std::vector<int32_t>> aff_vt;                  // per view: its targets as dense ids (scratch of the table flattening)
 
     // statistics
     double stat_pairs = 0, stat_raw = 0, stat_kept = 0;
@@ -259,6 +271,7 @@ int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* s
     }
     v.derive();
     h->views[id] = std::move(v);
+    h->aff.coll_valid = false;
     return L3D_OK;
 }
 
@@ -1052,6 +1065,7 @@ ChainPlan* get_plan(L* h)
 }
 void drop_plan(L* h)
 {
+    h->aff.coll_valid = false;
     delete static_cast<ChainPlan*>(h->plan_cache);
     h->plan_cache = nullptr;
 }
@@ -1229,6 +1243,7 @@ void greedy_selection(L* h)
     });
     for (size_t vi = 0; vi < nv; ++vi) count[vi + 1] += count[vi];
     h->hyps.resize(count[nv]);
+    h->hyp_begin = count;                                    // the hypotheses of view index vi are [hyp_begin[vi], hyp_begin[vi + 1])
     for_views([&](size_t vi) {
         View* v = h->vlist[vi];
         std::vector<int>& bi = h->best_idx[(size_t)v->index];
@@ -1292,6 +1307,10 @@ void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, 
             a = find(a);
             thr[a] = ed.w + c / (float)size[a];
         }
+        // the affinity list holds every edge in both directions, and the stable order keeps the two together: whatever the
+        // first one did (merged its components, found them merged, or failed a threshold), the reversed twin right behind it
+        // meets the very same state and changes nothing
+        if (q + 1 < n_edges && sorted[q + 1].i == ed.j && sorted[q + 1].j == ed.i && sorted[q + 1].w == ed.w) ++q;
     }
     labels.resize((size_t)numNodes);
     for (int k = 0; k < numNodes; ++k) labels[k] = find(k);
@@ -1440,14 +1459,9 @@ int cluster_segments_2D(L* h, bool perform_diff)
         auto it = std::lower_bound(cam_ids.begin(), cam_ids.end(), cam);
         return it != cam_ids.end() && *it == cam ? (int)(it - cam_ids.begin()) : -1;
     };
-    // hypotheses are in (view, segment) order: the range of each view
-    std::vector<size_t> hyp_begin(nv + 1, nh);
-    {
-        std::vector<size_t> cnt(nv, 0);
-        for (const Hyp& hy : h->hyps) ++cnt[(size_t)view_of(kcam(hy.src))];
-        size_t run = 0;
-        for (size_t i = 0; i < nv; ++i) { hyp_begin[i] = run; run += cnt[i]; }
-    }
+    // hypotheses are in (view, segment) order: the range of each view (greedy_selection)
+    const std::vector<size_t>& hyp_begin = h->hyp_begin;
+    if (hyp_begin.size() != nv + 1 || hyp_begin[nv] != nh) return h->fail(L3D_ERR_INVALID, "hypothesis ranges do not match the views");
 
     bool resident_list = false;                     // the affinity list is still on the device (l3d_affinity_fill ran last)
     if (!getenv("L3D_AFFINITY_HOST")) {
@@ -1459,9 +1473,11 @@ int cluster_segments_2D(L* h, bool perform_diff)
         std::vector<int32_t> seg_base(nv + 1), vhb(nv + 1);
         for (size_t i = 0; i <= nv; ++i) { seg_base[i] = (int32_t)voff[i]; vhb[i] = (int32_t)hyp_begin[i]; }
         vhb[nv] = (int32_t)nh;
-        std::unique_ptr<l3d_hypothesis[]> hy(new l3d_hypothesis[nh]);
-        std::unique_ptr<float[]> score(new float[nh]);
-        std::unique_ptr<int32_t[]> hyp_dense(new int32_t[nh]), best(new int32_t[ndense + 1]);
+        L::AffTables& T = h->aff;
+        T.hyp.resize(nh); T.score.resize(nh); T.hyp_dense.resize(nh); T.best.resize(ndense + 1);
+        l3d_hypothesis* hy = T.hyp.data();
+        float* score = T.score.data();
+        int32_t *hyp_dense = T.hyp_dense.data(), *best = T.best.data();
         parallel_slices(nh, nt, [&](size_t b0, size_t b1, unsigned) {
             for (size_t i = b0; i < b1; ++i) {
                 const Hyp& sh = h->hyps[i];
@@ -1479,9 +1495,15 @@ int cluster_segments_2D(L* h, bool perform_diff)
         });
         lap("  pack: hypotheses");
         // potential correspondences and collinearities as CSR over dense ids (a view's rows are written by one thread)
-        std::unique_ptr<int64_t[]> pot_start(new int64_t[ndense + 1]), coll_start(new int64_t[ndense + 1]);
-        std::vector<std::vector<int32_t>> vt(nv);
-        pot_start[0] = 0; coll_start[0] = 0;
+        T.pot_start.resize(ndense + 1);
+        int64_t* pot_start = T.pot_start.data();
+        const bool pack_coll = !T.coll_valid || T.coll_start.size() != ndense + 1;
+        if (pack_coll) T.coll_start.resize(ndense + 1);
+        int64_t* coll_start = T.coll_start.data();
+        std::vector<std::vector<int32_t>>& vt = h->aff_vt;
+        vt.resize(nv);
+        pot_start[0] = 0;
+        if (pack_coll) coll_start[0] = 0;
         {
             std::atomic<size_t> next{ 0 };
             auto worker = [&]() {
@@ -1490,8 +1512,8 @@ int cluster_segments_2D(L* h, bool perform_diff)
                     if (vi >= nv) break;
                     const View& sv = *h->vlist[vi];
                     const size_t S = (size_t)sv.S();
-                    for (size_t sg = 0; sg < S; ++sg) { pot_start[voff[vi] + sg + 1] = 0; best[voff[vi] + sg] = h->best_idx[vi][sg];
-                                                        coll_start[voff[vi] + sg + 1] = sv.coll_start[sg + 1] - sv.coll_start[sg]; }
+                    for (size_t sg = 0; sg < S; ++sg) { pot_start[voff[vi] + sg + 1] = 0; best[voff[vi] + sg] = h->best_idx[vi][sg]; }
+                    if (pack_coll) for (size_t sg = 0; sg < S; ++sg) coll_start[voff[vi] + sg + 1] = sv.coll_start[sg + 1] - sv.coll_start[sg];
                     std::vector<int32_t>& out = vt[vi];
                     out.clear();
                     out.reserve(h->pot[vi].size());
@@ -1501,7 +1523,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
                         const int tvi = view_of(kcam(e.second));
                         if (tvi < 0 || e.first >= S) continue;
                         const uint32_t tseg = kseg(e.second);
-                        if (tseg >= (uint32_t)h->vlist[(size_t)tvi]->S()) continue;
+                        if (tseg >= (uint32_t)(voff[(size_t)tvi + 1] - voff[(size_t)tvi])) continue;
                         out.push_back((int32_t)(voff[(size_t)tvi] + tseg));
                         ++pot_start[voff[vi] + e.first + 1];
                     }
@@ -1510,10 +1532,13 @@ int cluster_segments_2D(L* h, bool perform_diff)
             l3d::on_threads(std::min<unsigned>(nt, (unsigned)nv), [&](unsigned) { worker(); });
         }
         lap("  pack: count + targets per view");
-        for (size_t dd = 0; dd < ndense; ++dd) { pot_start[dd + 1] += pot_start[dd]; coll_start[dd + 1] += coll_start[dd]; }
+        for (size_t dd = 0; dd < ndense; ++dd) pot_start[dd + 1] += pot_start[dd];
+        if (pack_coll) for (size_t dd = 0; dd < ndense; ++dd) coll_start[dd + 1] += coll_start[dd];
         const size_t n_pot = (size_t)pot_start[ndense], n_coll = (size_t)coll_start[ndense];
-        std::unique_ptr<int32_t[]> pot_tgt(new int32_t[n_pot + 1]), coll_other(new int32_t[n_coll + 1]);
-        std::unique_ptr<float[]> coll_w(new float[n_coll + 1]);
+        T.pot_tgt.resize(n_pot + 1);
+        if (pack_coll) { T.coll_other.resize(n_coll + 1); T.coll_w.resize(n_coll + 1); }
+        int32_t *pot_tgt = T.pot_tgt.data(), *coll_other = T.coll_other.data();
+        float* coll_w = T.coll_w.data();
         {
             std::atomic<size_t> next{ 0 };
             auto worker = [&]() {
@@ -1521,19 +1546,21 @@ int cluster_segments_2D(L* h, bool perform_diff)
                     const size_t vi = next.fetch_add(1, std::memory_order_relaxed);
                     if (vi >= nv) break;
                     const View& sv = *h->vlist[vi];
-                    if (!vt[vi].empty()) memcpy(pot_tgt.get() + pot_start[voff[vi]], vt[vi].data(), vt[vi].size() * 4);
+                    if (!vt[vi].empty()) memcpy(pot_tgt + pot_start[voff[vi]], vt[vi].data(), vt[vi].size() * 4);
+                    if (!pack_coll) continue;
                     const size_t cb = (size_t)coll_start[voff[vi]], cn = sv.coll_other.size();
                     for (size_t q = 0; q < cn; ++q) { coll_other[cb + q] = (int32_t)(voff[vi] + (size_t)sv.coll_other[q]); coll_w[cb + q] = sv.coll_w[q]; }
                 }
             };
             l3d::on_threads(std::min<unsigned>(nt, (unsigned)nv), [&](unsigned) { worker(); });
         }
+        T.coll_valid = true;
         lap("pack tables");
         l3d_affinity_input in;
         in.n_views = (int32_t)nv; in.seg_base = seg_base.data(); in.view_hyp_begin = vhb.data();
-        in.n_hyp = (int32_t)nh; in.hyp = hy.get(); in.score = score.get(); in.hyp_dense = hyp_dense.get(); in.best = best.get();
-        in.pot_start = pot_start.get(); in.pot_tgt = pot_tgt.get();
-        in.coll_start = coll_start.get(); in.coll_other = coll_other.get(); in.coll_w = coll_w.get();
+        in.n_hyp = (int32_t)nh; in.hyp = hy; in.score = score; in.hyp_dense = hyp_dense; in.best = best;
+        in.pot_start = pot_start; in.pot_tgt = pot_tgt;
+        in.coll_start = coll_start; in.coll_other = coll_other; in.coll_w = coll_w;
         in.sigma_a = h->sigma_a;
         l3d_edge* edges = nullptr; int32_t* node_hyp = nullptr; int n_edges = 0, n_nodes = 0, n_cand = 0;
         int rc = l3d_affinity_fill(h->ctx, &in, &edges, &n_edges, &node_hyp, &n_nodes, &n_cand);
