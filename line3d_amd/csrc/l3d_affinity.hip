@@ -114,6 +114,33 @@ __global__ void k_aff_dview(const int* __restrict__ seg_base, int n_views, int* 
     if (v < n_views && i < seg_base[v + 1]) dview[i] = v;
 }
 
+// The tables come from the caller: every id in range, lists strictly ascending, targets in OTHER views, collinear segments in
+// the SAME view, hypotheses numbered in dense order and consistent with `best` -- checked once, in parallel, so that a bad
+// table is an error message and not a fault inside the later kernels.
+__global__ void k_aff_validate(AffIn a, long long n_pot, long long n_coll, int* __restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n_dense) {
+        const long long pb = a.pot_start[i], pe = a.pot_start[i + 1], cb = a.coll_start[i], ce = a.coll_start[i + 1];
+        if (pb < 0 || pe < pb || pe > n_pot || cb < 0 || ce < cb || ce > n_coll) { *bad = 1; return; }
+        const int v = a.dview[i];
+        for (long long e = pb; e < pe; ++e) {
+            const int t = a.pot_tgt[e];
+            if (t < 0 || t >= a.n_dense || a.dview[t] == v || (e > pb && a.pot_tgt[e - 1] >= t)) { *bad = 2; return; }
+        }
+        for (long long q = cb; q < ce; ++q) {
+            const int x = a.coll_other[q];
+            if (x < 0 || x >= a.n_dense || a.dview[x] != v || x == (int)i || (q > cb && a.coll_other[q - 1] >= x)) { *bad = 3; return; }
+        }
+        const int hb = a.best[i];
+        if (hb < -1 || hb >= a.n_hyp || (hb >= 0 && a.hyp_dense[hb] != (int)i)) *bad = 4;
+    }
+    if (i < a.n_hyp) {
+        const int d = a.hyp_dense[i];
+        if (d < 0 || d >= a.n_dense || a.best[d] != (int)i || (i > 0 && a.hyp_dense[i - 1] >= d)) *bad = 5;
+    }
+}
+
 // bit 2 of a source's entry: the target has an earlier hypothesis and records the source among its own targets (=> m-used).
 // needs_prev[view] is raised when a target with an earlier hypothesis lacks the reverse record: its m-used test reads bits of
 // earlier views.
@@ -482,7 +509,25 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     int maxS = 1;
     for (int v = 0; v < V; ++v) maxS = std::max(maxS, in->seg_base[v + 1] - in->seg_base[v]);
     hipLaunchKernelGGL(k_aff_dview, dim3((maxS + 255) / 256, V), dim3(256), 0, st, a.seg_base, V, reinterpret_cast<int*>(base + o_dview));
-    lap("upload");
+    {
+        if (in->pot_start[0] != 0 || in->coll_start[0] != 0) return fail(c, L3D_ERR_INVALID, "affinity fill: CSR tables must start at 0");
+        for (int v = 0; v < V; ++v)
+            if (in->seg_base[v + 1] < in->seg_base[v] || in->view_hyp_begin[v + 1] < in->view_hyp_begin[v]) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables must ascend");
+        if (in->seg_base[0] != 0 || in->view_hyp_begin[0] != 0 || in->view_hyp_begin[V] != nh) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables do not cover the hypotheses");
+        HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
+        int* bad = c->g1.as<int>();
+        HIPCHK(c, hipMemsetAsync(bad, 0, 4, st));
+        const int nmax = std::max(nd, nh);
+        hipLaunchKernelGGL(k_aff_validate, dim3((nmax + 255) / 256), dim3(256), 0, st, a, n_pot, n_coll, bad);
+        int h_bad = 0;
+        HIPCHK(c, hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        static const char* what[] = { "", "a CSR range is out of bounds", "a potential correspondence is out of range, in the source's own view, or out of order",
+                                      "a collinearity entry is out of range, in another view, a self entry, or out of order", "best[] and hyp_dense[] disagree",
+                                      "hypotheses are not numbered in dense order" };
+        if (h_bad) return fail(c, L3D_ERR_INVALID, std::string("affinity fill: ") + what[std::min(h_bad, 5)]);
+    }
+    lap("upload + table check");
 
     // ---- expanded bits: consecutive views share a launch unless one of them reads bits of the views before it
     const dim3 gsrc((nh + 3) / 4);

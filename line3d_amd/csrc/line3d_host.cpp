@@ -248,6 +248,7 @@ int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* s
         for (int k = 0; k < n_coll; ++k) {
             if (coll_i[k] < 0 || coll_i[k] >= n || coll_j[k] < 0 || coll_j[k] >= n) return h->fail(L3D_ERR_INVALID, "cached collinearity names a segment that does not exist");
             if (k && (coll_i[k] < coll_i[k - 1] || (coll_i[k] == coll_i[k - 1] && coll_j[k] <= coll_j[k - 1]))) return h->fail(L3D_ERR_INVALID, "cached collinearities are not in ascending (i, j) order");
+            if (coll_i[k] == coll_j[k]) return h->fail(L3D_ERR_INVALID, "cached collinearity of a segment with itself");
             v.coll_start[(size_t)coll_i[k] + 1]++;
         }
         for (int s = 0; s < n; ++s) v.coll_start[(size_t)s + 1] += v.coll_start[(size_t)s];

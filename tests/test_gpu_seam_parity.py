@@ -446,6 +446,22 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     assert node_hyp.tolist() == e_nodes
     assert A["i"].tolist() == [e[0] for e in eA] and A["j"].tolist() == [e[1] for e in eA]
     assert np.array_equal(A["w"].view(np.uint32), np.array([e[2] for e in eA], np.float32).view(np.uint32))
+    if seed == 1:
+        # tables that break the contract are refused with a message instead of being walked
+        from line3d_amd.capi import L3DError
+        args = [seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, 10.0]
+
+        def broken(idx, mutate):
+            b = list(args)
+            b[idx] = np.array(b[idx], copy=True)
+            mutate(b[idx])
+            with pytest.raises(L3DError, match="affinity fill"):
+                gpu_ctx.affinity_fill(*b)
+        broken(7, lambda x: x.__setitem__(0, nd))                          # target out of range
+        broken(7, lambda x: x.__setitem__(slice(0, 2), x[1::-1].copy()) if pot_start[1] >= 2 else x.__setitem__(0, -1))   # out of order
+        broken(9, lambda x: x.__setitem__(0, (int(x[0]) + S) % nd))        # collinear segment in another view
+        broken(5, lambda x: x.__setitem__(int(hyp_dense[0]), 1))           # best[] disagrees with hyp_dense[]
+        broken(6, lambda x: x.__setitem__(3, x[4] + 1))                    # CSR starts that do not ascend
 
 
 @pytest.mark.parametrize("diffusion", [False, True])
