@@ -38,8 +38,8 @@ def usable_cpus():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views-per-gpu", type=int, default=64)
     ap.add_argument("--segments", type=int, default=2000)
     ap.add_argument("--neighbors", type=int, default=12)

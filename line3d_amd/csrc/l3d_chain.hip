@@ -220,6 +220,7 @@ struct ViewDev {            // device addresses of one view's static tables and 
     int* rowA;              // row starts of the stage-1 candidates alone (S*N + 1)
     int* stats;             // {raw total, raw max per segment}
     float2* best;
+    float4* rays;           // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
     int W64, maxW;
     bool verified;
 };
@@ -318,6 +319,34 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
     HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
+    {   // the viewing rays of every view's target endpoints, once per chain (they only depend on the neighbour's camera and segment)
+        static const bool rays_env = !(getenv("L3D_TGT_RAYS") && atoi(getenv("L3D_TGT_RAYS")) == 0);      // (0: k_pair_fill normalises per candidate, A/B)
+        size_t n_ray = 0;
+        int max_n_tgt = 0;
+        std::vector<RayJob>& jobs = c->ray_jobs;             // (lives in the context: the upload below is asynchronous)
+        jobs.clear();
+        for (int k = 0; k < n_views; ++k) {
+            vd[(size_t)k].rays = nullptr;
+            if (!vd[(size_t)k].verified || !rays_env || views[k].n_tbm == 0) continue;
+            n_ray += (size_t)views[k].n_tgt;
+        }
+        HIPCHK(c, c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
+        float4* rbase = c->ch_rays.as<float4>();
+        RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
+        size_t ro = 0;
+        for (int k = 0; k < n_views; ++k) {
+            ViewDev& d = vd[(size_t)k];
+            if (!d.verified || !rays_env || views[k].n_tbm == 0) continue;
+            d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
+            jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(dtab + d.o_off), reinterpret_cast<const float*>(dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
+            max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
+        }
+        if (!jobs.empty()) {
+            HIPCHK(c, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
+            ProfScope p(c, "tgt_rays", st);
+            launch_tgt_rays(djobs, (int)jobs.size(), max_n_tgt, st);
+        }
+    }
     {   // stage 1 starts after the tables and the zeroed row counts are in place
         hipEvent_t ready = get_event(c);
         HIPCHK(c, hipEventRecord(ready, st));
@@ -365,6 +394,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
         pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
         pa.depth_in_fill = depth_in_fill ? 1 : 0;
+        pa.tgt_rays = d.rays;
         return pa;
     };
 

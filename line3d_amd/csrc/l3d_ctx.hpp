@@ -95,8 +95,9 @@ struct l3d_ctx {
     l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
-    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder;
+    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    std::vector<l3d::RayJob> ray_jobs;       // job list of k_tgt_rays of the running chain
     l3d::PinArena pin_arena;                 // kept lists of the running / last chain (valid until the next chain starts)
     std::vector<int> h_cnt;
     int mmax_seen = 0;

@@ -422,6 +422,25 @@ __device__ __forceinline__ int select_bit(unsigned long long m, int r)
     return pos;
 }
 
+// Unit viewing rays of the target endpoints, normalize(RtKinv_cam * (x, y, 1)) -- what K_pairwise_matches recomputes for every pair
+// (cudawrapper.cu:590-601 through D_get_ray_tgt:288) depends on the neighbour's camera and segment only: once per chain for every
+// entry of every view's target array, read (2 x 16 bytes) by k_pair_fill instead of two mat-vecs, two square roots and six
+// correctly rounded divisions per candidate.  Same operations, same bits.
+__global__ __launch_bounds__(256) void k_tgt_rays(const RayJob* __restrict__ jobs)
+{
+    const RayJob jb = jobs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jb.n_tgt) return;
+    int cam = -1;
+    for (int c = 0; c < jb.N; ++c) { const int2 o = jb.offsets[c]; if (i >= o.x && i < o.x + o.y) cam = c; }
+    if (cam < 0) return;
+    const float4 t = jb.tgt[i];
+    const f3 r1 = normalize(mat3_apply(jb.RtKinv + cam * 9, mk3(t.x, t.y, 1.0f)));
+    const f3 r2 = normalize(mat3_apply(jb.RtKinv + cam * 9, mk3(t.z, t.w, 1.0f)));
+    jb.out[2 * (size_t)i] = make_float4(r1.x, r1.y, r1.z, 0.0f);
+    jb.out[2 * (size_t)i + 1] = make_float4(r2.x, r2.y, r2.z, 0.0f);
+}
+
 // Stage 1c.  One wave per (src segment, tbm camera) row: the row's set bits are enumerated in
 // ascending target order, 64 at a time with all lanes busy, and the depth record of each is written
 // to slot row_start + rank -> candidates come out sorted (seg, cam, tgt) with no sort pass.
@@ -477,8 +496,14 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
             // the bit is set, so the overlap test passed: only its intersection points are needed again
             f3 l2_p1, l2_p2, l1_q1, l1_q2;
             pair_intersections(s, t, l2_p1, l2_p2, l1_q1, l1_q2);
-            d = pair_depths_pre(ray_p1, ray_p2, normalize(mat3_apply(a.RtKinv + cam * 9, t.q1)), normalize(mat3_apply(a.RtKinv + cam * 9, t.q2)),
-                                l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
+            f3 ray_q1, ray_q2;
+            if (a.tgt_rays) {
+                const float4 r1 = a.tgt_rays[2 * (size_t)(toff + x)], r2 = a.tgt_rays[2 * (size_t)(toff + x) + 1];
+                ray_q1 = mk3(r1.x, r1.y, r1.z); ray_q2 = mk3(r2.x, r2.y, r2.z);
+            } else {
+                ray_q1 = normalize(mat3_apply(a.RtKinv + cam * 9, t.q1)); ray_q2 = normalize(mat3_apply(a.RtKinv + cam * 9, t.q2));
+            }
+            d = pair_depths_pre(ray_p1, ray_p2, ray_q1, ray_q2, l2_p1, l2_p2, l1_q1, l1_q2, a.RtKinv_src, a.RtKinv + cam * 9, C_src, C_tgt);
         }
         if (a.depth_in_fill) {
             // the bit only says "overlap test passed": a candidate needs four positive depths (cudawrapper.cu:931); the row is packed
@@ -900,6 +925,10 @@ void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st)
 {
     if (a.seg_end > a.seg_begin) hipLaunchKernelGGL(k_kept_write, dim3(a.seg_end - a.seg_begin), dim3(256), 0, st, a, kept_start, l2g, out);
+}
+void launch_tgt_rays(const RayJob* jobs, int n_jobs, int max_n_tgt, hipStream_t st)
+{
+    if (n_jobs > 0 && max_n_tgt > 0) hipLaunchKernelGGL(k_tgt_rays, dim3((max_n_tgt + 255) / 256, n_jobs), dim3(256), 0, st, jobs);
 }
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st)
 {

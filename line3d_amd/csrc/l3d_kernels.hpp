@@ -57,6 +57,8 @@ struct PairArgs {
     int* rowcnt;                    // chains: the per-(segment, camera) candidate counts are added here by k_pair_mask itself (rows zeroed at
                                     // chain start); null: a separate k_row_count launch (per-view seam call, chain restarts)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test (default 3)
+    const float4* tgt_rays = nullptr;   // resident chain: unit viewing rays of the target endpoints, 2 per entry of tgt_segs (k_tgt_rays); null: k_pair_fill
+                                    // normalises them itself, per candidate, with the same operations
     int depth_in_fill = 0;          // resident chain: k_pair_mask stops after the exact overlap test (its bits and row counts are then an UPPER
                                     // bound), the four depths are triangulated ONCE, in k_pair_fill, which drops the pairs without four positive
                                     // depths (cudawrapper.cu:931), packs the row and writes its true count back into rowcnt; 0: the bit already
@@ -98,6 +100,10 @@ struct VerifyArgs {
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
+struct RayJob {                     // one view of k_tgt_rays
+    const float4* tgt; const int2* offsets; const float* RtKinv; float4* out; int n_tgt, N;
+};
+void launch_tgt_rays(const RayJob* jobs, int n_jobs, int max_n_tgt, hipStream_t st);
 void launch_scan(const int* in, int* out, int n, int* zero, hipStream_t st, int* seg_order = nullptr, int N = 0, int seg_begin = 0, int seg_end = 0,
                  int* stats_out = nullptr);
 void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, int seg_end, int nrow_total, int* zero, int* seg_order, hipStream_t st,
