@@ -73,6 +73,10 @@ void l3d_free(void* p);
  * segments: n_segments x 4 (p1x,p1y,p2x,p2y).  Outputs callee-allocated. */
 int l3d_compute_collinearity(l3d_ctx* ctx, const float* segments, int n_segments, float collin_s,
                              int32_t** out_i, int32_t** out_j, float** out_w, int* out_n);
+/* The same for several segment sets at once (all views of a scene): no host round trip per set.  The triplets of set v are
+ * entries [set_start[v], set_start[v+1]) of the concatenated outputs (callee-allocated; set_start: n_sets + 1, caller's). */
+int l3d_compute_collinearity_batch(l3d_ctx* ctx, const float* const* segments, const int* n_segments, int n_sets, float collin_s,
+                                   int32_t** out_i, int32_t** out_j, float** out_w, int* set_start);
 
 /* Replaces compute_pairwise_matches (cudawrapper.h:54-70, cudawrapper.cu:858-1128):
  * K_pairwise_matches for every neighbour in to_be_matched, selection of pairs with four

@@ -456,6 +456,108 @@ int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float col
     return L3D_OK;
 }
 
+namespace l3d {
+__global__ void k_gather_ints(const int* __restrict__ base, const long long* __restrict__ idx, int n, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base[idx[i]];
+}
+}  // namespace l3d
+
+// The collinearity relations of several segment sets (the views of a scene) without a host round trip per set: all bit-row and
+// counting launches, ONE read-back of the totals, all fill launches, ONE read-back of the triplets.
+int l3d_compute_collinearity_batch(l3d_ctx* c, const float* const* segments, const int* n_segments, int n_sets, float collin_s,
+                                   int32_t** out_i, int32_t** out_j, float** out_w, int* set_start)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!out_i || !out_j || !out_w || !set_start || n_sets < 0 || (n_sets > 0 && (!segments || !n_segments))) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *out_i = nullptr; *out_j = nullptr; *out_w = nullptr;
+    for (int v = 0; v <= n_sets; ++v) set_start[v] = 0;
+    if (n_sets == 0) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    struct Set { const float4* d; int S, W64; size_t o_mask, o_cnt, o_start; };
+    std::vector<Set> sets((size_t)n_sets);
+    size_t up_bytes = 0, mask_bytes = 0, cnt_ints = 0, start_ints = 0;
+    for (int v = 0; v < n_sets; ++v) {
+        Set& q = sets[(size_t)v];
+        q.S = n_segments[v];
+        if (q.S < 0 || (q.S > 0 && !segments[v])) return fail(c, L3D_ERR_INVALID, "bad argument");
+        q.W64 = 4 * ((q.S + 255) / 256);
+        q.d = q.S >= 2 ? static_cast<const float4*>(resident_ptr(c, segments[v], (size_t)q.S * 16)) : nullptr;
+        if (q.S >= 2 && !q.d) up_bytes += (size_t)q.S * 16;
+        q.o_mask = mask_bytes; q.o_cnt = cnt_ints; q.o_start = start_ints;
+        if (q.S >= 2) { mask_bytes += (size_t)q.S * q.W64 * 8; cnt_ints += (size_t)q.S; start_ints += (size_t)q.S + 1; }
+    }
+    if (start_ints == 0) return L3D_OK;
+    HIPCHK(c, c->g0.reserve(up_bytes + 16));
+    HIPCHK(c, c->g1.reserve(mask_bytes + 16));
+    HIPCHK(c, c->g2.reserve(cnt_ints * 4 + 16));
+    HIPCHK(c, c->g3.reserve(start_ints * 4 + (size_t)n_sets * 12 + 64));
+    HIPCHK(c, hipMemsetAsync(c->g1.p, 0, mask_bytes, st));
+    HIPCHK(c, hipMemsetAsync(c->g2.p, 0, cnt_ints * 4, st));
+    const float sigma_sqr = collin_s * collin_s;   // cudawrapper.cu:850
+    {
+        size_t uo = 0;
+        for (int v = 0; v < n_sets; ++v) {
+            Set& q = sets[(size_t)v];
+            if (q.S < 2) continue;
+            if (!q.d) {
+                HIPCHK(c, hipMemcpyAsync(c->g0.as<unsigned char>() + uo, segments[v], (size_t)q.S * 16, hipMemcpyHostToDevice, st));
+                q.d = reinterpret_cast<const float4*>(c->g0.as<unsigned char>() + uo);
+                uo += (size_t)q.S * 16;
+            }
+            unsigned long long* mask = reinterpret_cast<unsigned long long*>(c->g1.as<unsigned char>() + q.o_mask);
+            { ProfScope p(c, "collinearity"); launch_collinearity(q.d, q.S, sigma_sqr, mask, q.W64, c->g2.as<int>() + q.o_cnt, st); }
+            { ProfScope p(c, "scan"); launch_scan(c->g2.as<int>() + q.o_cnt, c->g3.as<int>() + q.o_start, q.S, nullptr, st); }
+        }
+    }
+    // totals of all sets in one read-back
+    std::vector<long long> idx((size_t)n_sets, 0);
+    std::vector<int> totals((size_t)n_sets, 0);
+    int n_live = 0;
+    for (int v = 0; v < n_sets; ++v) if (sets[(size_t)v].S >= 2) idx[(size_t)n_live++] = (long long)(sets[(size_t)v].o_start + (size_t)sets[(size_t)v].S);
+    long long* d_idx = reinterpret_cast<long long*>(c->g3.as<unsigned char>() + ((start_ints * 4 + 15) & ~(size_t)15));
+    int* d_tot = reinterpret_cast<int*>(d_idx + n_sets);
+    HIPCHK(c, hipMemcpyAsync(d_idx, idx.data(), (size_t)n_live * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_ints, dim3((n_live + 255) / 256), dim3(256), 0, st, c->g3.as<int>(), d_idx, n_live, d_tot);
+    HIPCHK(c, hipMemcpyAsync(totals.data(), d_tot, (size_t)n_live * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    long long total = 0;
+    for (int v = 0, k = 0; v < n_sets; ++v) {
+        set_start[v] = (int)total;
+        if (sets[(size_t)v].S >= 2) total += totals[(size_t)k++];
+        if (total > 0x7fffffffll) return fail(c, L3D_ERR_NOMEM, "more than 2^31 collinear pairs");
+    }
+    set_start[n_sets] = (int)total;
+    if (total == 0) return L3D_OK;
+    const size_t n = (size_t)total;
+    HIPCHK(c, c->g4.reserve(n * 4));
+    HIPCHK(c, c->g5.reserve(n * 4));
+    c->resident_edges = 0;                          // (g6 is reused)
+    HIPCHK(c, c->g6.reserve(n * 4));
+    for (int v = 0; v < n_sets; ++v) {
+        const Set& q = sets[(size_t)v];
+        if (q.S < 2 || set_start[v + 1] == set_start[v]) continue;
+        const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(c->g1.as<unsigned char>() + q.o_mask);
+        ProfScope p(c, "collinearity_fill");
+        launch_collinearity_fill(q.d, q.S, sigma_sqr, mask, q.W64, c->g3.as<int>() + q.o_start, c->g4.as<int>() + set_start[v], c->g5.as<int>() + set_start[v],
+                                 c->g6.as<float>() + set_start[v], st);
+    }
+    int32_t* oi = (int32_t*)malloc(n * 4);
+    int32_t* oj = (int32_t*)malloc(n * 4);
+    float* ow = (float*)malloc(n * 4);
+    if (!oi || !oj || !ow) { free(oi); free(oj); free(ow); return fail(c, L3D_ERR_NOMEM, "malloc"); }
+    hipError_t e1 = hipMemcpyAsync(oi, c->g4.p, n * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(oj, c->g5.p, n * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e3 = hipMemcpyAsync(ow, c->g6.p, n * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e4 = hipStreamSynchronize(st);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { free(oi); free(oj); free(ow); return fail(c, L3D_ERR_HIP, "collinearity batch: read-back failed"); }
+    *out_i = oi; *out_j = oj; *out_w = ow;
+    return L3D_OK;
+}
+
 }  // extern "C"
 
 extern "C" {

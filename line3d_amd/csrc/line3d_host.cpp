@@ -51,6 +51,7 @@ struct View {                                   // L3DView, view.h:40-153
     double pp[2];
     float unc_upper_px = 0, unc_lower_px = 0, k_upper = 0, k_lower = 0, median_depth = 1.0f;
     std::vector<float> segs;                    // S x 4
+    bool coll_pending = false;                  // the relation is still to be computed (prepare: all views in one batch)
     std::vector<int> coll_start;                // CSR of segment2collinearities_ (segments.h:84-97)
     std::vector<int> coll_other;
     std::vector<float> coll_w;
@@ -227,6 +228,51 @@ namespace {
 typedef l3d_line3d L;
 
 // ------------------------------------------------------------------------------------------------
+// segment2collinearities_ of a view from the relation's upper-triangle triplets (i < j, ascending (i, j)): both directions
+// (segments.h:89-93), per segment in ascending order of the other segment
+void set_collinearities(View& v, const int32_t* ci, const int32_t* cj, const float* cw, int cn)
+{
+    const int n = v.S();
+    v.coll_start.assign((size_t)n + 1, 0);
+    std::vector<int> cnt((size_t)n, 0);
+    for (int k = 0; k < cn; ++k) { cnt[ci[k]]++; cnt[cj[k]]++; }
+    for (int s = 0; s < n; ++s) v.coll_start[s + 1] = v.coll_start[s] + cnt[s];
+    v.coll_other.resize((size_t)v.coll_start[n]);
+    v.coll_w.resize((size_t)v.coll_start[n]);
+    std::vector<int> cur(v.coll_start.begin(), v.coll_start.end() - 1);
+    // triplets come sorted by (i,j), i<j: for a segment s its partners j>s arrive ascending, and its
+    // partners i<s arrive ascending (ascending i) and before them in index order -> fill lower part first
+    for (int k = 0; k < cn; ++k) { const int s = cj[k]; v.coll_other[cur[s]] = ci[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
+    for (int k = 0; k < cn; ++k) { const int s = ci[k]; v.coll_other[cur[s]] = cj[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
+}
+
+// The collinearity relations the L3DSegments constructor computes per image (segments.h:73-101, one kernel launch and one dense
+// S x S download each) for all views added since the last call, in one batch (l3d_compute_collinearity_batch)
+int compute_pending_collinearities(L* h)
+{
+    std::vector<View*> pend;
+    for (auto& kv : h->views) if (kv.second.coll_pending) pend.push_back(&kv.second);
+    if (pend.empty()) return L3D_OK;
+    std::vector<const float*> segs(pend.size());
+    std::vector<int> ns(pend.size()), start(pend.size() + 1, 0);
+    for (size_t i = 0; i < pend.size(); ++i) { segs[i] = pend[i]->segs.data(); ns[i] = pend[i]->S(); }
+    int32_t *ci = nullptr, *cj = nullptr; float* cw = nullptr;
+    int rc = l3d_compute_collinearity_batch(h->ctx, segs.data(), ns.data(), (int)pend.size(), L3D_DEF_COLLINEARITY_S, &ci, &cj, &cw, start.data());
+    if (rc) return h->fail(rc, std::string("collinearity: ") + l3d_last_error(h->ctx));
+    std::atomic<size_t> next{ 0 };
+    l3d::on_threads((unsigned)std::max<size_t>(1, std::min<size_t>(l3d::host_threads(), pend.size())), [&](unsigned) {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pend.size()) break;
+            set_collinearities(*pend[i], ci + start[i], cj + start[i], cw + start[i], start[i + 1] - start[i]);
+            pend[i]->coll_pending = false;
+        }
+    });
+    l3d_free(ci); l3d_free(cj); l3d_free(cw);
+    h->aff.coll_valid = false;
+    return L3D_OK;
+}
+
 // coll_i/coll_j/coll_w (optional): the directed entries of a cached segment2collinearities_ map, ascending (i, j) -- used as
 // they are instead of computing the relation (Line3D::addImage with an existing segment cache, line3D.cc:160-168)
 int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n,
@@ -254,21 +300,8 @@ int make_view(L* h, uint32_t id, unsigned width, unsigned height, const float* s
         for (int s = 0; s < n; ++s) v.coll_start[(size_t)s + 1] += v.coll_start[(size_t)s];
         v.coll_other.assign(coll_j, coll_j + n_coll);
         v.coll_w.assign(coll_w, coll_w + n_coll);
-    } else if (h->use_collinearity && n > 1) {      // L3DSegments ctor, segments.h:73-101
-        int32_t *ci = nullptr, *cj = nullptr; float* cw = nullptr; int cn = 0;
-        int rc = l3d_compute_collinearity(h->ctx, v.segs.data(), n, L3D_DEF_COLLINEARITY_S, &ci, &cj, &cw, &cn);
-        if (rc) return h->fail(rc, std::string("collinearity: ") + l3d_last_error(h->ctx));
-        std::vector<int> cnt((size_t)n, 0);
-        for (int k = 0; k < cn; ++k) { cnt[ci[k]]++; cnt[cj[k]]++; }
-        for (int s = 0; s < n; ++s) v.coll_start[s + 1] = v.coll_start[s] + cnt[s];
-        v.coll_other.resize((size_t)v.coll_start[n]);
-        v.coll_w.resize((size_t)v.coll_start[n]);
-        std::vector<int> cur(v.coll_start.begin(), v.coll_start.end() - 1);
-        // triplets come sorted by (i,j), i<j: for a segment s its partners j>s arrive ascending, and its
-        // partners i<s arrive ascending (ascending i) and before them in index order -> fill lower part first
-        for (int k = 0; k < cn; ++k) { const int s = cj[k]; v.coll_other[cur[s]] = ci[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
-        for (int k = 0; k < cn; ++k) { const int s = ci[k]; v.coll_other[cur[s]] = cj[k]; v.coll_w[cur[s]] = cw[k]; cur[s]++; }
-        l3d_free(ci); l3d_free(cj); l3d_free(cw);
+    } else if (h->use_collinearity && n > 1) {      // L3DSegments ctor, segments.h:73-101: computed for all new views together, in prepare()
+        v.coll_pending = true;
     }
     v.derive();
     h->views[id] = std::move(v);
@@ -696,6 +729,8 @@ int prepare(L* h)
         if (!rc) rc = l3d_register_segments(h->ctx, v->nb_segs.data(), (int)(v->nb_segs.size() / 4));
         if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
     }
+    rc = compute_pending_collinearities(h);             // (the segments are resident now: nothing is uploaded again)
+    if (rc) return rc;
     h->prepared = true;
     return L3D_OK;
 }
