@@ -202,6 +202,7 @@ struct SViewDev {
     int* rowA;                               // row starts of the stage-1 candidates alone
     int* stats;
     float2* best;
+    float4* rays;                            // unit viewing rays of the target endpoints (k_tgt_rays), as in l3d_match_chain
     int W64, maxW, s0, s1;
     bool verified;
 };
@@ -328,6 +329,28 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     }
     OCHK(hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
     h->dtab = c->ch_tables.as<unsigned char>();
+    {   // the viewing rays of every view's target endpoints, once per chain (l3d_chain.hip)
+        size_t n_ray = 0;
+        int max_n_tgt = 0;
+        std::vector<RayJob>& jobs = c->ray_jobs;
+        jobs.clear();
+        for (int k = 0; k < n_views; ++k) { h->vd[(size_t)k].rays = nullptr; if (h->vd[(size_t)k].verified && views[k].n_tbm != 0) n_ray += (size_t)views[k].n_tgt; }
+        OCHK(c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
+        float4* rbase = c->ch_rays.as<float4>();
+        RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
+        size_t ro = 0;
+        for (int k = 0; k < n_views; ++k) {
+            SViewDev& d = h->vd[(size_t)k];
+            if (!d.verified || views[k].n_tbm == 0) continue;
+            d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
+            jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(h->dtab + d.o_off), reinterpret_cast<const float*>(h->dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
+            max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
+        }
+        if (!jobs.empty()) {
+            OCHK(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
+            launch_tgt_rays(djobs, (int)jobs.size(), max_n_tgt, st);
+        }
+    }
     OCHK(c->ch_mask.reserve(mask_bytes + 16));
     OCHK(c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
     OCHK(c->ch_rowA.reserve((rowcnt_ints + 4 * (size_t)n_views) * 4 + 64));
@@ -406,6 +429,7 @@ static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
     pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg; pa.rowcnt = nullptr;
     pa.depth_in_fill = 1;               // the depths of a stage-1 pair are triangulated once, by k_pair_fill (as in l3d_match_chain)
+    pa.tgt_rays = d.rays;
     return pa;
 }
 
