@@ -5,6 +5,7 @@
 
 #include <stdint.h>
 #include <sched.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,7 +51,8 @@ inline unsigned host_threads()         // worker threads of the host-side stages
 // time: a region started while another one runs (nested, or from another thread) gets plain threads of its own.
 class HostPool {
 public:
-    static HostPool& get() { static HostPool p; return p; }
+    // never destroyed: the (detached) workers may still be parked on its condition variable when the process exits
+    static HostPool& get() { static HostPool* p = new HostPool(); return *p; }
     void run(unsigned nt, const std::function<void(unsigned)>& fn)
     {
         if (nt <= 1) { fn(0u); return; }
@@ -64,7 +66,8 @@ public:
         }
         {
             std::lock_guard<std::mutex> lk(mu_);
-            while (threads_.size() + 1 < nt) { const unsigned idx = (unsigned)threads_.size() + 1; threads_.emplace_back([this, idx] { loop(idx); }); }
+            if (pid_ != getpid()) { pid_ = getpid(); n_threads_ = 0; }   // a forked child has none of the parent's threads
+            while (n_threads_ + 1 < nt) { const unsigned idx = ++n_threads_; const unsigned long long g = gen_; std::thread([this, idx, g] { loop(idx, g); }).detach(); }
             job_ = &fn; job_threads_ = nt; remaining_ = nt - 1; ++gen_;
         }
         cv_work_.notify_all();
@@ -73,20 +76,13 @@ public:
         cv_done_.wait(lk, [this] { return remaining_ == 0; });
         job_ = nullptr;
     }
-    ~HostPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-        cv_work_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
 private:
-    void loop(unsigned idx)
+    HostPool() {}
+    void loop(unsigned idx, unsigned long long seen)     // seen: the generation current when the thread was created
     {
-        unsigned long long seen = 0;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
-            if (stop_) return;
+            cv_work_.wait(lk, [&] { return gen_ != seen; });
             seen = gen_;
             if (idx >= job_threads_) continue;
             const std::function<void(unsigned)>* job = job_;
@@ -98,11 +94,11 @@ private:
     }
     std::mutex region_mu_, mu_;
     std::condition_variable cv_work_, cv_done_;
-    std::vector<std::thread> threads_;
+    unsigned n_threads_ = 0;
+    pid_t pid_ = 0;
     const std::function<void(unsigned)>* job_ = nullptr;
     unsigned job_threads_ = 0, remaining_ = 0;
     unsigned long long gen_ = 0;
-    bool stop_ = false;
 };
 
 template <class F>
