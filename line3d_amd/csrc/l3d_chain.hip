@@ -218,6 +218,8 @@ struct ViewDev {            // device addresses of one view's static tables and 
     unsigned long long* mask;
     int* rowcnt;
     int* rowA;              // row starts of the stage-1 candidates alone (S*N + 1)
+    int* rowub;             // fused row starts: k_pair_mask's (upper-bound) counts, S*N, and their 256-row block sums (never rewritten)
+    int* rowblk;
     int* stats;             // {raw total, raw max per segment}
     float2* best;
     float4* rays;           // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
@@ -311,7 +313,10 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // ---- per-view arenas: bit rows, row counts, statistics, best depths, results
     HIPCHK(c, c->ch_mask.reserve(mask_bytes + 16));
     HIPCHK(c, c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
-    HIPCHK(c, c->ch_rowA.reserve((rowcnt_ints + 4 * (size_t)n_views) * 4 + 64));
+    // (row starts | upper-bound counts | their block sums: the last two zeroed, k_pair_mask adds into them)
+    const size_t rowA_ints = rowcnt_ints + 4 * (size_t)n_views, rowub_ints = rowcnt_ints + 4 * (size_t)n_views, rowblk_ints = rowcnt_ints / 256 + 8 * (size_t)n_views;
+    HIPCHK(c, c->ch_rowA.reserve((rowA_ints + rowub_ints + rowblk_ints) * 4 + 64));
+    HIPCHK(c, hipMemsetAsync(c->ch_rowA.as<int>() + rowA_ints, 0, (rowub_ints + rowblk_ints) * 4, st));
     HIPCHK(c, c->ch_best.reserve(best_elems * 8 + 16));
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
     HIPCHK(c, c->ch_flags.reserve(64));
@@ -360,7 +365,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&hres_dev), hres, 0));
     int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
     {
-        size_t mo = 0, ro = 0, bo = 0, ao = 0;
+        size_t mo = 0, ro = 0, bo = 0, ao = 0, ko = 0;
         int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
         for (int k = 0; k < n_views; ++k) {
             ViewDev& d = vd[(size_t)k];
@@ -370,7 +375,11 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
             mo += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
             d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
-            d.rowA = c->ch_rowA.as<int>() + ao; ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
+            d.rowA = c->ch_rowA.as<int>() + ao;
+            d.rowub = c->ch_rowA.as<int>() + rowA_ints + ao;
+            d.rowblk = c->ch_rowA.as<int>() + rowA_ints + rowub_ints + ko;
+            ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
+            ko += (((size_t)v.S_src * v.N + 255) / 256 + 4) & ~(size_t)3;
             d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
         }
     }
@@ -460,12 +469,17 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // stage-1 candidates in place instead of copying them (k_place) -- 20 % SLOWER: the copy is a streaming pass that
     // leaves the candidates cache-hot for the latency-bound kernels that follow.)
     const bool use_ring = c->chain_ring != 0;
+    // the row starts of the stage-1 candidates are formed inside k_pair_fill from k_pair_mask's counters and their block sums: no
+    // scan launch on the stage-1 stream (the longer of the two), no statistics for the host to wait for.  L3D_FUSED_ROWS=0: A/B.
+    static const bool fused_rows_env = !(getenv("L3D_FUSED_ROWS") && atoi(getenv("L3D_FUSED_ROWS")) == 0);
+    const bool fused_rows = fused_rows_env && use_ring && depth_in_fill;
     auto enqueue_fillA = [&](int k, hipStream_t s) {
         if (!use_ring) return;
         const ViewDev& d = vd[(size_t)k];
         PairArgs pa = pair_args(k);
         pa.cand_cap = (int)cand_cap;
         pa.rowcnt = d.rowcnt;
+        if (fused_rows) { pa.rowub = d.rowub; pa.rowblk = d.rowblk; pa.rowstart_out = d.rowA; }
         { ProfScope p(c, "pair_fill", s); launch_pair_fill(pa, d.rowA, ringA_meta(k), ringA_depths(k), s); }
     };
     auto enqueue_stage1 = [&](int k) -> int {
@@ -475,12 +489,14 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             const PairArgs pa = pair_args(k);
             {   // bit rows + row counts (added into the rows zeroed at chain start) in one launch
                 PairArgs pm = pa;
-                pm.rowcnt = vd[(size_t)k].rowcnt;
+                pm.rowcnt = fused_rows ? vd[(size_t)k].rowub : vd[(size_t)k].rowcnt;
+                if (fused_rows) pm.rowblk = vd[(size_t)k].rowblk;
                 ProfScope p(c, "pair_mask", s1);
                 launch_pair_mask(pm, vd[(size_t)k].maxW, s1);
             }
             // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch)
-            if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
+            if (fused_rows) {}
+            else if (use_ring) { ProfScope p(c, "scan", s1); launch_scan(vd[(size_t)k].rowcnt, vd[(size_t)k].rowA, views[k].S_src * views[k].N, nullptr, s1, nullptr, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k); }
             else launch_raw_stats(vd[(size_t)k].rowcnt, views[k].N, 0, views[k].S_src, hstats_dev + 2 * k, s1);
             // the ring slot was last used by view k - kRing: wait until its chain has consumed it
             for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(s1, ev[(size_t)j], 0)); break; }
@@ -498,7 +514,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         while (k_p1 < n_views && k_p1 <= k + kStage1Ahead) { int rc = enqueue_stage1(k_p1); if (rc) return rc; ++k_p1; }
         if (!d.verified) return L3D_OK;
         const double te0 = now_s();
-        HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
+        if (!fused_rows) HIPCHK(c, hipEventSynchronize(ev1[(size_t)k]));          // its stage-1 statistics (enqueued a window earlier)
         t_ev1 += now_s() - te0;
         HIPCHK(c, hipStreamWaitEvent(st, ev1[(size_t)k], 0));
         PairArgs pa = pair_args(k);
@@ -543,7 +559,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
         va.seg_order = c->ch_segorder.as<int>();
         // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
-        int mmax = hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
+        // (fused row starts: no statistics -- the largest image the budget allows; the budget, not the image, sets the occupancy)
+        int mmax = fused_rows ? 16384 : hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
         while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
         va.mmax = mmax;
         if (c->verify_mode == 0 && verify_window_supported(N)) {
@@ -685,7 +702,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
                 if (!vd[(size_t)j].verified || views[j].S_src == 0) continue;
                 if (j < k_enq) {
                     if (!hip_ok(hipMemsetAsync(vd[(size_t)j].rowcnt, 0, (size_t)views[j].S_src * views[j].N * 4, st), "hipMemsetAsync")) break;
-                    launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);
+                    if (!fused_rows) launch_row_count(pair_args(j), vd[(size_t)j].rowcnt, st);      // (fused: the upper bounds live in rowub, untouched)
                 }
                 enqueue_fillA(j, st);
             }

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     __shared__ unsigned short s_qa[4][kPairQueue];
     __shared__ unsigned short s_qb[4][kPairQueue];
     __shared__ unsigned long long s_bits[kSrcPerBlock * 4];
+    __shared__ int s_blk[32];            // block sums of this workgroup's rows (fused row starts)
 
     const int j = blockIdx.z;
     const int cam = a.tbm[j];
@@ -358,6 +359,21 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
             const int cnt = __popcll(s_bits[tid * 4]) + __popcll(s_bits[tid * 4 + 1]) + __popcll(s_bits[tid * 4 + 2]) + __popcll(s_bits[tid * 4 + 3]);
             if (cnt) atomicAdd(&a.rowcnt[(y0 + tid) * a.N + cam], cnt);
         }
+        if (a.rowblk && wave == 0) {
+            // block sums (256 rows): this workgroup's rows lie N apart, i.e. in a handful of consecutive blocks -- summed in LDS
+            // first, one global atomic per block and workgroup (one per row made every workgroup of the launch queue up on the
+            // same ~100 counters: k_pair_mask 6.8 -> 18.7 ms)
+            const int b0 = (y0 * a.N + cam) >> 8;
+            const int nb = (((y0 + ny - 1) * a.N + cam) >> 8) - b0 + 1;        // <= 64 * N / 256 + 2 <= 18
+            if (lane < nb) s_blk[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (tid < ny) {
+                const int cnt = __popcll(s_bits[tid * 4]) + __popcll(s_bits[tid * 4 + 1]) + __popcll(s_bits[tid * 4 + 2]) + __popcll(s_bits[tid * 4 + 3]);
+                if (cnt) atomicAdd(&s_blk[(((y0 + tid) * a.N + cam) >> 8) - b0], cnt);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (lane < nb) { const int v = s_blk[lane]; if (v) atomicAdd(&a.rowblk[b0 + lane], v); }
+        }
     }
     if (a.dbg) {
         int nbits = 0;
@@ -474,13 +490,30 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
     const int total = base;
     if (lane == 0) s_pref[wave][nw] = total;
     if (total == 0) return;
-    if (a.cand_cap && row_start[(size_t)a.S_src * a.N] > a.cand_cap) return;   // overflow: the chain is re-run with more room
+    int slot0;
+    if (a.rowub) {
+        // the row's start from k_pair_mask's counters: 256-row block sums in front of the row's block + the rows in front of it
+        // inside the block (about 350 ints per wave, L2 resident) -- no scan launch between k_pair_mask and this kernel
+        const int idx = y * a.N + cam, blk = idx >> 8, nblk = (a.S_src * a.N + 255) >> 8;
+        int before = 0, all = 0;
+        for (int b = lane; b < nblk; b += 64) { const int v = a.rowblk[b]; all += v; if (b < blk) before += v; }
+        for (int i = (blk << 8) + lane; i < idx; i += 64) before += a.rowub[i];
+        for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+        if (a.cand_cap && all > a.cand_cap) {                                  // overflow: the chain is re-run with more room -- it finds out
+            if (lane == 0) a.rowcnt[idx] = total;                              // from the final counts, which then carry the upper bounds
+            return;
+        }
+        slot0 = before;
+        if (lane == 0) a.rowstart_out[idx] = before;
+    } else {
+        if (a.cand_cap && row_start[(size_t)a.S_src * a.N] > a.cand_cap) return;   // overflow: the chain is re-run with more room
+        slot0 = row_start[y * a.N + cam];
+    }
 
     const SrcPairInv s = make_src_inv(a.src_segs[y], a.F + cam * 9);
     const f3 C_tgt = mk3(a.centers[cam * 3], a.centers[cam * 3 + 1], a.centers[cam * 3 + 2]);
     const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     const f3 ray_p1 = normalize(mat3_apply(a.RtKinv_src, s.p1)), ray_p2 = normalize(mat3_apply(a.RtKinv_src, s.p2));   // row invariants
-    const int slot0 = row_start[y * a.N + cam];
 
     int written = 0;                       // depth_in_fill: records of the row so far (wave-uniform)
     for (int k0 = 0; k0 < total; k0 += 64) {

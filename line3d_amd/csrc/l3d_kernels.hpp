@@ -57,6 +57,13 @@ struct PairArgs {
     int* rowcnt;                    // chains: the per-(segment, camera) candidate counts are added here by k_pair_mask itself (rows zeroed at
                                     // chain start); null: a separate k_row_count launch (per-view seam call, chain restarts)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test (default 3)
+    // resident chain, row starts without a scan launch: k_pair_mask also adds its counts to rowblk[(row) >> 8] (sums of 256 rows; row =
+    // segment * N + camera).  k_pair_fill then reads the (upper-bound) counts from rowub -- the array k_pair_mask filled, never
+    // written again -- and forms a row's start itself: the block sums in front of its block + the counts in front of it inside the
+    // block; it writes the start to rowstart_out and the row's true count to rowcnt (a different array: the chain's final counts).
+    int* rowblk = nullptr;
+    const int* rowub = nullptr;
+    int* rowstart_out = nullptr;
     const float4* tgt_rays = nullptr;   // resident chain: unit viewing rays of the target endpoints, 2 per entry of tgt_segs (k_tgt_rays); null: k_pair_fill
                                     // normalises them itself, per candidate, with the same operations
     int depth_in_fill = 0;          // resident chain: k_pair_mask stops after the exact overlap test (its bits and row counts are then an UPPER
