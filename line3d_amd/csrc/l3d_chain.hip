@@ -472,7 +472,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // the row starts of the stage-1 candidates are formed inside k_pair_fill from k_pair_mask's counters and their block sums: no
     // scan launch on the stage-1 stream (the longer of the two), no statistics for the host to wait for.  L3D_FUSED_ROWS=0: A/B.
     static const bool fused_rows_env = !(getenv("L3D_FUSED_ROWS") && atoi(getenv("L3D_FUSED_ROWS")) == 0);
-    const bool fused_rows = fused_rows_env && use_ring && depth_in_fill;
+    const bool fused_rows = fused_rows_env && use_ring && depth_in_fill && maxN <= 96;      // (k_pair_mask's LDS block sums: 64 rows N apart span <= 32 blocks)
     auto enqueue_fillA = [&](int k, hipStream_t s) {
         if (!use_ring) return;
         const ViewDev& d = vd[(size_t)k];
