@@ -143,6 +143,24 @@ class Context:
             self.lib.l3d_free(p)
         return i, j, w
 
+    def compute_collinearity_batch(self, seg_sets, collin_s=2.0):
+        """l3d_compute_collinearity_batch: list of (S_v, 4) arrays -> list of (i, j, w) triplet arrays, one per set."""
+        sets = [np.ascontiguousarray(s, dtype=np.float32).reshape(-1, 4) for s in seg_sets]
+        n = len(sets)
+        ptrs = (C.c_void_p * max(n, 1))(*[s.ctypes.data for s in sets])
+        ns = np.array([len(s) for s in sets], np.int32)
+        start = np.zeros(n + 1, np.int32)
+        oi, oj, ow = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+        self._chk(self.lib.l3d_compute_collinearity_batch(self.h, ptrs, _p(ns), C.c_int(n), C.c_float(collin_s),
+                                                          C.byref(oi), C.byref(oj), C.byref(ow), _p(start)))
+        total = int(start[n])
+        i = np.ctypeslib.as_array(oi, (total,)).copy() if total else np.zeros(0, np.int32)
+        j = np.ctypeslib.as_array(oj, (total,)).copy() if total else np.zeros(0, np.int32)
+        w = np.ctypeslib.as_array(ow, (total,)).copy() if total else np.zeros(0, np.float32)
+        for p in (oi, oj, ow):
+            self.lib.l3d_free(p)
+        return [(i[start[v]:start[v + 1]], j[start[v]:start[v + 1]], w[start[v]:start[v + 1]]) for v in range(n)]
+
     def compute_pairwise_matches(self, src_segs, RtKinv_src, C_src, tgt_segs, offsets, F, RtKinv, centers, P,
                                  to_be_matched, in_matches, local2global, k_upper, k_lower, sigma_p, sigma_a,
                                  spatial_k, median_depth=1.0, seg_range=None, want_best=False):

@@ -48,6 +48,25 @@ def test_collinearity_structured(gpu_ctx, oracle_lib):
     assert np.array_equal(gw.view(np.uint32), rel[jj, ii].view(np.uint32))
 
 
+def test_collinearity_batch_equals_per_set_calls(gpu_ctx, oracle_lib, small_scene):
+    """l3d_compute_collinearity_batch (what prepare() uses for all views at once): sets of different sizes, including an empty one
+    and a single segment, against the per-set call and the oracle."""
+    sets = [v["segments"] for v in small_scene.views[:4]]
+    sets = [sets[0], sets[1][:1], np.zeros((0, 4), np.float32), sets[2][:77], sets[3]]
+    got = gpu_ctx.compute_collinearity_batch(sets, 2.0)
+    assert len(got) == len(sets)
+    for segs, (gi, gj, gw) in zip(sets, got):
+        if len(segs) < 2:
+            assert len(gi) == 0
+            continue
+        si, sj, sw = gpu_ctx.compute_collinearity(segs, 2.0)
+        assert np.array_equal(gi, si) and np.array_equal(gj, sj) and np.array_equal(gw.view(np.uint32), sw.view(np.uint32))
+        rel = op.collinearity(oracle_lib, segs, 2.0)
+        ii, jj = np.nonzero(np.triu(rel > 0, 1))
+        assert np.array_equal(gi, ii.astype(np.int32)) and np.array_equal(gj, jj.astype(np.int32))
+        assert np.array_equal(gw.view(np.uint32), rel[jj, ii].view(np.uint32))
+
+
 def _run_view(ctx, tr, seg_range=None):
     mv = tr["marshal"]
     return ctx.compute_pairwise_matches(mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"],
