@@ -1280,6 +1280,10 @@ void greedy_selection(L* h)
     for (size_t vi = 0; vi < nv; ++vi) count[vi + 1] += count[vi];
     h->hyps.resize(count[nv]);
     h->hyp_begin = count;                                    // the hypotheses of view index vi are [hyp_begin[vi], hyp_begin[vi + 1])
+    // (the flat copies the device affinity fill takes -- hypothesis, score, dense segment id -- are written in the same pass)
+    std::vector<size_t> voff(nv + 1, 0);
+    for (size_t vi = 0; vi < nv; ++vi) voff[vi + 1] = voff[vi] + (size_t)h->vlist[vi]->S();
+    h->aff.hyp.resize(count[nv]); h->aff.score.resize(count[nv]); h->aff.hyp_dense.resize(count[nv]);
     for_views([&](size_t vi) {
         View* v = h->vlist[vi];
         std::vector<int>& bi = h->best_idx[(size_t)v->index];
@@ -1293,6 +1297,14 @@ void greedy_selection(L* h)
             hy.score = fminf(mp.confidence, 1.0f);
             unproject_segment(*v, sg, mp.depths[0], mp.depths[1], hy);
             bi[sg] = (int)k;
+            l3d_hypothesis& o = h->aff.hyp[k];
+            o.P1[0] = hy.P1.x; o.P1[1] = hy.P1.y; o.P1[2] = hy.P1.z;
+            o.P2[0] = hy.P2.x; o.P2[1] = hy.P2.y; o.P2[2] = hy.P2.z;
+            o.dir[0] = hy.dir.x; o.dir[1] = hy.dir.y; o.dir[2] = hy.dir.z;
+            o.depth_p1 = hy.depth_p1; o.depth_p2 = hy.depth_p2;
+            o.k_lower = v->k_lower; o.k_upper = v->k_upper; o.median_depth = v->median_depth; o.pad = 0;
+            h->aff.score[k] = hy.score;
+            h->aff.hyp_dense[k] = (int32_t)(voff[vi] + sg);
             h->hyps[k++] = hy;
         }
     });
@@ -1510,25 +1522,11 @@ int cluster_segments_2D(L* h, bool perform_diff)
         for (size_t i = 0; i <= nv; ++i) { seg_base[i] = (int32_t)voff[i]; vhb[i] = (int32_t)hyp_begin[i]; }
         vhb[nv] = (int32_t)nh;
         L::AffTables& T = h->aff;
-        T.hyp.resize(nh); T.score.resize(nh); T.hyp_dense.resize(nh); T.best.resize(ndense + 1);
+        if (T.hyp.size() != nh || T.score.size() != nh || T.hyp_dense.size() != nh) return h->fail(L3D_ERR_INVALID, "hypothesis tables do not match the hypotheses");
+        T.best.resize(ndense + 1);                      // (hypothesis, score, dense id: written by greedy_selection)
         l3d_hypothesis* hy = T.hyp.data();
         float* score = T.score.data();
         int32_t *hyp_dense = T.hyp_dense.data(), *best = T.best.data();
-        parallel_slices(nh, nt, [&](size_t b0, size_t b1, unsigned) {
-            for (size_t i = b0; i < b1; ++i) {
-                const Hyp& sh = h->hyps[i];
-                const size_t vi = (size_t)view_of(kcam(sh.src));
-                const View& v = *h->vlist[vi];
-                l3d_hypothesis& o = hy[i];
-                o.P1[0] = sh.P1.x; o.P1[1] = sh.P1.y; o.P1[2] = sh.P1.z;
-                o.P2[0] = sh.P2.x; o.P2[1] = sh.P2.y; o.P2[2] = sh.P2.z;
-                o.dir[0] = sh.dir.x; o.dir[1] = sh.dir.y; o.dir[2] = sh.dir.z;
-                o.depth_p1 = sh.depth_p1; o.depth_p2 = sh.depth_p2;
-                o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
-                score[i] = sh.score;
-                hyp_dense[i] = (int32_t)(voff[vi] + kseg(sh.src));
-            }
-        });
         lap("  pack: hypotheses");
         // potential correspondences and collinearities as CSR over dense ids (a view's rows are written by one thread)
         T.pot_start.resize(ndense + 1);
