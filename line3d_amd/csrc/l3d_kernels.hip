@@ -821,16 +821,22 @@ __global__ __launch_bounds__(256) void k_rownorm(float4* __restrict__ data, cons
     if (y >= num_rows) return;
     const int s = start[y];
     if (s < 0) return;
-    int e = s;
+    // row length: rows are contiguous runs of entries with .x == y.  The first 64 entries are loaded by the lanes at once (one
+    // memory round trip instead of one per entry); the sum still runs over them in entry order, one addition after the other
+    const float4 d = s + lane < nnz ? data[s + lane] : make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+    const unsigned long long in_row = __ballot(s + lane < nnz && (int)d.x == y);
+    const int run = in_row == ~0ull ? 64 : __ffsll((long long)~in_row) - 1;      // leading lanes of the row
     float sum = 0.0f;
-    // row length: rows are contiguous runs of entries with .x == y
-    if (lane == 0) {
-        while (e < nnz && (int)data[e].x == y) { sum += data[e].z; ++e; }
-        if (sum < kEpsG) sum = kEpsG;
+    for (int k = 0; k < run; ++k) sum += __shfl(d.z, k);
+    int e = s + run;
+    if (run == 64) {                                                            // a longer row: the rest one by one
+        if (lane == 0) while (e < nnz && (int)data[e].x == y) { sum += data[e].z; ++e; }
+        e = __shfl(e, 0);
+        sum = __shfl(sum, 0);
     }
-    e = __shfl(e, 0);
-    sum = __shfl(sum, 0);
-    for (int i = s + lane; i < e; i += 64) data[i].z = data[i].z / sum;
+    if (sum < kEpsG) sum = kEpsG;
+    if (lane < run) data[s + lane].z = d.z / sum;
+    for (int i = s + 64 + lane; i < e; i += 64) data[i].z = data[i].z / sum;
 }
 
 // K_sparseMat_diffusion_step (cudawrapper.cu:765-829): one thread per entry; positional lock-step
