@@ -12,7 +12,7 @@
 //   k_seg_post       per segment: best hypothesis depths, number of kept matches
 //   k_kept_write     ordered compaction of the kept matches
 //   k_collinearity   per-view 2-D collinearity relation (upper triangle, bit + value)
-//   k_rownorm / k_diffusion_step   replicator dynamics diffusion
+//   (replicator dynamics diffusion: l3d_rdd.hip)
 //   k_similarity     batched similarity_coll3D for the affinity fill
 #include <algorithm>
 #include <cstdlib>
@@ -809,70 +809,6 @@ __global__ __launch_bounds__(256) void k_collinearity_fill(const float4* __restr
 }
 
 // =================================================================================================
-// Replicator dynamics diffusion.  Entries are float4 (row, col, val, 0) like the reference's
-// SparseMatrix (sparsematrix.cc:99-131); start[] = first entry of a row/col or -1.
-// =================================================================================================
-// K_sparseMat_row_normalization (cudawrapper.cu:717-762): one wave per row, serial-order sum kept
-// (the sum order is part of the result): lane 0 accumulates in entry order, all lanes divide.
-__global__ __launch_bounds__(256) void k_rownorm(float4* __restrict__ data, const int* __restrict__ start, int num_rows, int nnz)
-{
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (y >= num_rows) return;
-    const int s = start[y];
-    if (s < 0) return;
-    // row length: rows are contiguous runs of entries with .x == y.  The first 64 entries are loaded by the lanes at once (one
-    // memory round trip instead of one per entry); the sum still runs over them in entry order, one addition after the other
-    const float4 d = s + lane < nnz ? data[s + lane] : make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
-    const unsigned long long in_row = __ballot(s + lane < nnz && (int)d.x == y);
-    const int run = in_row == ~0ull ? 64 : __ffsll((long long)~in_row) - 1;      // leading lanes of the row
-    float sum = 0.0f;
-    for (int k = 0; k < run; ++k) sum += __shfl(d.z, k);
-    int e = s + run;
-    if (run == 64) {                                                            // a longer row: the rest one by one
-        if (lane == 0) while (e < nnz && (int)data[e].x == y) { sum += data[e].z; ++e; }
-        e = __shfl(e, 0);
-        sum = __shfl(sum, 0);
-    }
-    if (sum < kEpsG) sum = kEpsG;
-    if (lane < run) data[s + lane].z = d.z / sum;
-    for (int i = s + 64 + lane; i < e; i += 64) data[i].z = data[i].z / sum;
-}
-
-// K_sparseMat_diffusion_step (cudawrapper.cu:765-829): one thread per entry; positional lock-step
-// product of row r of P with column c of W; result stored at (r,c) of P'.
-__global__ void k_diffusion_step(const float4* __restrict__ P, const float4* __restrict__ W,
-                                 const int* __restrict__ P_rows, const int* __restrict__ W_cols,
-                                 float4* __restrict__ Pp, const int* __restrict__ Pp_rows, int nnz)
-{
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= nnz) return;
-    const float4 data = P[y];
-    const int r = (int)data.y;
-    const int c = (int)data.x;
-    float mul = 0.0f;
-    int sp = P_rows[r], sw = W_cols[c];
-    if (sp >= 0 && sw >= 0) {
-        while (sp < nnz && sw < nnz) {
-            const float4 d1 = P[sp];
-            const float4 d2 = W[sw];
-            if ((int)d1.x != r || (int)d2.y != c) break;
-            mul += (d1.z * d2.z);
-            ++sp; ++sw;
-        }
-    }
-    mul *= data.z;
-    if (mul < kEpsG) mul = kEpsG;
-    int s = Pp_rows[r];
-    while (s >= 0 && s < nnz) {
-        const float4 dat = Pp[s];
-        if ((int)dat.x != r) break;
-        if ((int)dat.y == c) { Pp[s].z = mul; break; }
-        ++s;
-    }
-}
-
-// =================================================================================================
 // batched similarity_coll3D (l3d_similarity.hpp)
 // =================================================================================================
 __global__ void k_similarity(const Hypothesis* __restrict__ hyp, const int2* __restrict__ pairs, int n,
@@ -977,15 +913,6 @@ void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const 
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st)
 {
     hipLaunchKernelGGL(k_collinearity_fill, dim3((S + 3) / 4), dim3(256), 0, st, segs, S, sigma_sqr, mask, W64, row_start, oi, oj, ow);
-}
-void launch_rownorm(float4* data, const int* start, int n, int nnz, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_rownorm, dim3((n + 3) / 4), dim3(256), 0, st, data, start, n, nnz);
-}
-void launch_diffusion_step(const float4* P, const float4* W, const int* P_rows, const int* W_cols, float4* Pp,
-                           const int* Pp_rows, int nnz, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_diffusion_step, dim3((nnz + 255) / 256), dim3(256), 0, st, P, W, P_rows, W_cols, Pp, Pp_rows, nnz);
 }
 void launch_similarity(const Hypothesis* hyp, const int2* pairs, int n, float sigma_a, float two_log, float* sim, hipStream_t st)
 {

@@ -142,9 +142,6 @@ void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow,
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);
-void launch_rownorm(float4* data, const int* start, int n, int nnz, hipStream_t st);
-void launch_diffusion_step(const float4* P, const float4* W, const int* P_rows, const int* W_cols, float4* Pp,
-                           const int* Pp_rows, int nnz, hipStream_t st);
 void launch_similarity(const Hypothesis* hyp, const int2* pairs, int n, float sigma_a, float two_log, float* sim, hipStream_t st);
 void launch_test_sqthr(const float* u, int n, float* walk, float* fast, hipStream_t st);
 void launch_test_math(const float* x, int n, float* e, float* ac, double* acd, hipStream_t st);

@@ -10,6 +10,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "l3d_ctx.hpp"
+#include "l3d_geometry.hpp"
 
 using namespace l3d;
 
@@ -28,25 +29,97 @@ __global__ void k_rdd_keys_p(const l3d_edge* __restrict__ A, const unsigned* __r
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nnz) { const l3d_edge e = A[ordW[k]]; key[k] = ((unsigned long long)(unsigned)e.i << shift) | (unsigned)e.j; val[k] = (unsigned)k; }
 }
-// entries (row, col, val, 0) as floats like the reference's SparseMatrix, in both orders (+ P' = copy of P, cudawrapper.cu:1148), and
-// the first entry of every column of W / row of P (tables preset to -1)
+// The reference keeps three copies of the entries as float4 (row, col, val, 0) -- W by column, P and P' by row (cudawrapper.cu:1148)
+// -- and every thread of every iteration walks them entry by entry: index tests to find the end of a row / column run, a
+// search for the slot of the result.  The pattern never changes during the iteration, so here it is resolved ONCE: first entry and
+// LENGTH of every row of P and column of W, the slot each entry's result goes to (tpos), and the values alone (4 bytes per entry
+// instead of 16) in arrays of their own.  The arithmetic -- which products, in which order, into which slot -- is the reference's.
 __global__ void k_rdd_build(const l3d_edge* __restrict__ A, const unsigned* __restrict__ ordW, const unsigned* __restrict__ ordP, int nnz,
-                            float4* __restrict__ W, float4* __restrict__ P, float4* __restrict__ Pp, int* __restrict__ startW, int* __restrict__ startP)
+                            float* __restrict__ Wval, int* __restrict__ Wcol, int2* __restrict__ Pij, float* __restrict__ Pval, float* __restrict__ Pval2,
+                            int* __restrict__ startW, int* __restrict__ startP)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnz) return;
     const l3d_edge w = A[ordW[k]];
-    W[k] = make_float4((float)w.i, (float)w.j, w.w, 0.0f);
+    Wval[k] = w.w; Wcol[k] = w.j;
     if (k == 0 || A[ordW[k - 1]].j != w.j) startW[w.j] = k;
     const l3d_edge q = A[ordW[ordP[k]]];
-    const float4 e = make_float4((float)q.i, (float)q.j, q.w, 0.0f);
-    P[k] = e; Pp[k] = e;
+    Pij[k] = make_int2(q.i, q.j); Pval[k] = q.w; Pval2[k] = q.w;
     if (k == 0 || A[ordW[ordP[k - 1]]].i != q.i) startP[q.i] = k;
 }
-__global__ void k_rdd_result(const float4* __restrict__ P, int nnz, l3d_edge* __restrict__ out)
+// run lengths: the entry that ends a run knows where it started
+__global__ void k_rdd_lens(const int* __restrict__ Wcol, const int2* __restrict__ Pij, int nnz, const int* __restrict__ startW, const int* __restrict__ startP,
+                           int* __restrict__ lenW, int* __restrict__ lenP)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nnz) { const float4 e = P[k]; l3d_edge r; r.i = (int)e.x; r.j = (int)e.y; r.w = e.z; out[k] = r; }
+    if (k >= nnz) return;
+    const int c = Wcol[k];
+    if (k == nnz - 1 || Wcol[k + 1] != c) lenW[c] = k + 1 - startW[c];
+    const int r = Pij[k].x;
+    if (k == nnz - 1 || Pij[k + 1].x != r) lenP[r] = k + 1 - startP[r];
+}
+// K_sparseMat_diffusion_step stores the product of entry (x, y) in the FIRST entry of row y with column x (cudawrapper.cu:809-826): its slot
+__global__ void k_rdd_tpos(const int2* __restrict__ Pij, int nnz, const int* __restrict__ startP, const int* __restrict__ lenP, int* __restrict__ tpos)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nnz) return;
+    const int r = Pij[y].y, c = Pij[y].x;
+    int t = -1;
+    const int s0 = startP[r];
+    if (s0 >= 0) {
+        int lo = s0, hi = s0 + lenP[r];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (Pij[mid].y < c) lo = mid + 1; else hi = mid; }
+        if (lo < s0 + lenP[r] && Pij[lo].y == c) t = lo;
+    }
+    tpos[y] = t;
+}
+// K_sparseMat_row_normalization (cudawrapper.cu:717-762): one wave per row; the first 64 values are loaded by the lanes at once, the
+// sum runs over them in entry order, one addition after the other (the order is part of the result)
+__global__ __launch_bounds__(256) void k_rdd_rownorm(float* __restrict__ val, const int* __restrict__ start, const int* __restrict__ len, int num_rows)
+{
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= num_rows) return;
+    const int s = start[y];
+    if (s < 0) return;
+    const int n = len[y];
+    const float v = lane < n ? val[s + lane] : 0.0f;
+    float sum = 0.0f;
+    const int head = n < 64 ? n : 64;
+    for (int k = 0; k < head; ++k) sum += __shfl(v, k);
+    if (n > 64) {
+        if (lane == 0) for (int i = s + 64; i < s + n; ++i) sum += val[i];
+        sum = __shfl(sum, 0);
+    }
+    if (sum < kEpsG) sum = kEpsG;
+    if (lane < n) val[s + lane] = v / sum;
+    for (int i = s + 64 + lane; i < s + n; i += 64) val[i] = val[i] / sum;
+}
+// K_sparseMat_diffusion_step (cudawrapper.cu:765-829): one thread per entry (x, y): positional lock-step product of row y of P with
+// column x of W -- as many terms as the shorter of the two runs --, times the entry's own value, stored in slot (y, x) of P'
+__global__ void k_rdd_step(const int2* __restrict__ Pij, const float* __restrict__ Pval, const float* __restrict__ Wval, const int* __restrict__ startP,
+                           const int* __restrict__ lenP, const int* __restrict__ startW, const int* __restrict__ lenW, const int* __restrict__ tpos,
+                           float* __restrict__ Pout, int nnz)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nnz) return;
+    const int2 ij = Pij[y];
+    const int r = ij.y, c = ij.x;
+    float mul = 0.0f;
+    const int sp = startP[r], sw = startW[c];
+    if (sp >= 0 && sw >= 0) {
+        const int n = min(lenP[r], lenW[c]);
+        for (int k = 0; k < n; ++k) mul += (Pval[sp + k] * Wval[sw + k]);
+    }
+    mul *= Pval[y];
+    if (mul < kEpsG) mul = kEpsG;
+    const int t = tpos[y];
+    if (t >= 0) Pout[t] = mul;
+}
+__global__ void k_rdd_result(const int2* __restrict__ Pij, const float* __restrict__ Pval, int nnz, l3d_edge* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) { l3d_edge r; r.i = Pij[k].x; r.j = Pij[k].y; r.w = Pval[k]; out[k] = r; }
 }
 
 // after the diffusion (line3D.cc:1275-1301): A(i,j) = A(j,i) = min(W(i,j), W(j,i)); W sorted by (row, column), entries unique.
@@ -126,9 +199,9 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
 
     int shift = 1;
     while ((1ll << shift) < (long long)n) ++shift;                       // index bits: keys are (major << shift) | minor
-    const size_t eb = (size_t)nnz * 16, sb = (size_t)n * 4;
-    HIPCHK(c, c->g0.reserve(eb)); HIPCHK(c, c->g1.reserve(eb)); HIPCHK(c, c->g2.reserve(eb));
-    HIPCHK(c, c->g3.reserve(sb)); HIPCHK(c, c->g4.reserve(sb)); HIPCHK(c, c->g5.reserve(sb));
+    const size_t vb4 = ((size_t)nnz * 4 + 255) & ~(size_t)255, sb = ((size_t)n * 4 + 255) & ~(size_t)255;
+    HIPCHK(c, c->g0.reserve(3 * vb4)); HIPCHK(c, c->g1.reserve(2 * vb4)); HIPCHK(c, c->g2.reserve(2 * vb4));
+    HIPCHK(c, c->g3.reserve(2 * sb)); HIPCHK(c, c->g4.reserve(2 * sb));
     // sort scratch: two key arrays, four index arrays, hipCUB's temporary storage
     size_t temp_bytes = 0;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
@@ -144,8 +217,14 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
     unsigned* ordP = reinterpret_cast<unsigned*>(sc + 2 * kb + 3 * vb);
     void* temp = sc + 2 * kb + 4 * vb;
 
-    float4 *dW = c->g0.as<float4>(), *dP = c->g1.as<float4>(), *dPp = c->g2.as<float4>();
-    int *dWc = c->g3.as<int>(), *dPr = c->g4.as<int>(), *dPpr = c->g5.as<int>();
+    float* Wval = c->g0.as<float>();
+    int* Wcol = reinterpret_cast<int*>(c->g0.as<unsigned char>() + vb4);
+    int* tpos = reinterpret_cast<int*>(c->g0.as<unsigned char>() + 2 * vb4);
+    int2* Pij = c->g1.as<int2>();
+    float* Pval = c->g2.as<float>();
+    float* Pval2 = reinterpret_cast<float*>(c->g2.as<unsigned char>() + vb4);
+    int *startW = c->g3.as<int>(), *lenW = reinterpret_cast<int*>(c->g3.as<unsigned char>() + sb);
+    int *startP = c->g4.as<int>(), *lenP = reinterpret_cast<int*>(c->g4.as<unsigned char>() + sb);
     l3d_edge* dA = c->g6.as<l3d_edge>();
     const dim3 grid((nnz + 255) / 256), block(256);
     // W: column-sorted (line3D.cc:1258 -> sparsematrix.cc:81-86, stable list sort by (j,i)); P: the column-sorted entries
@@ -154,21 +233,25 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, val_in, ordW, nnz, 0, 2 * shift, st));
     hipLaunchKernelGGL(k_rdd_keys_p, grid, block, 0, st, dA, ordW, nnz, shift, key_in, val_in2);
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, val_in2, ordP, nnz, 0, 2 * shift, st));
-    HIPCHK(c, hipMemsetAsync(dWc, 0xff, sb, st));                       // -1: no entry in that column / row
-    HIPCHK(c, hipMemsetAsync(dPr, 0xff, sb, st));
-    hipLaunchKernelGGL(k_rdd_build, grid, block, 0, st, dA, ordW, ordP, nnz, dW, dP, dPp, dWc, dPr);
-    HIPCHK(c, hipMemcpyAsync(dPpr, dPr, sb, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemsetAsync(startW, 0xff, (size_t)n * 4, st));           // -1: no entry in that column / row
+    HIPCHK(c, hipMemsetAsync(startP, 0xff, (size_t)n * 4, st));
+    HIPCHK(c, hipMemsetAsync(lenW, 0, (size_t)n * 4, st));
+    HIPCHK(c, hipMemsetAsync(lenP, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(k_rdd_build, grid, block, 0, st, dA, ordW, ordP, nnz, Wval, Wcol, Pij, Pval, Pval2, startW, startP);
+    hipLaunchKernelGGL(k_rdd_lens, grid, block, 0, st, Wcol, Pij, nnz, startW, startP, lenW, lenP);
+    hipLaunchKernelGGL(k_rdd_tpos, grid, block, 0, st, Pij, nnz, startP, lenP, tpos);
     lap("sort + sparse build (device)");
 
-    { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
+    float *cur = Pval, *nxt = Pval2;                                     // P and P' (cudawrapper.cu:1148: P' starts as a copy of P)
+    const dim3 rgrid((n + 3) / 4);
+    { ProfScope p(c, "rownorm"); hipLaunchKernelGGL(k_rdd_rownorm, rgrid, block, 0, st, cur, startP, lenP, n); }
     for (int it = 0; it < iters; ++it) {
-        { ProfScope p(c, "diffusion_step"); launch_diffusion_step(dP, dW, dPr, dWc, dPp, dPpr, nnz, st); }
-        std::swap(dP, dPp);
-        std::swap(dPr, dPpr);
-        if (it < iters - 1) { ProfScope p(c, "rownorm"); launch_rownorm(dP, dPr, n, nnz, st); }
+        { ProfScope p(c, "diffusion_step"); hipLaunchKernelGGL(k_rdd_step, grid, block, 0, st, Pij, cur, Wval, startP, lenP, startW, lenW, tpos, nxt, nnz); }
+        std::swap(cur, nxt);
+        if (it < iters - 1) { ProfScope p(c, "rownorm"); hipLaunchKernelGGL(k_rdd_rownorm, rgrid, block, 0, st, cur, startP, lenP, n); }
     }
     lap("kernels");
-    hipLaunchKernelGGL(k_rdd_result, grid, block, 0, st, dP, nnz, dA);   // (the input copy is no longer needed)
+    hipLaunchKernelGGL(k_rdd_result, grid, block, 0, st, Pij, cur, nnz, dA);   // (the input copy is no longer needed)
     return L3D_OK;
 }
 
