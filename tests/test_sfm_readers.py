@@ -139,3 +139,50 @@ def test_driver_flow_replays_segment_caches(sfm_scene, tmp_path):
     l3d.close()
     with pytest.raises(RuntimeError, match="no segment cache"):
         sfm.reconstruct(scene, str(tmp_path / "nothing_here"), sizes, neighbors=6)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_over_segment_caches_matches_oracle(sfm_scene, tmp_path):
+    """examples/main_vsfm_amd.cpp -- the reference driver's flow in C++ over the facade, the NVM reader and the segment caches
+    (image sizes read off the cache file names) -- built with plain g++, run as a program, its TXT result against the oracle."""
+    import subprocess
+    import l3d_oracle_pipeline as op
+    from line3d_amd import sfm
+    from line3d_amd.io import load_txt, segment_cache_filename
+    sc, pts = sfm_scene
+    nvm = str(tmp_path / "scene.nvm")
+    write_nvm(nvm, sc, pts)
+    sizes = [(v["width"], v["height"]) for v in sc.views]
+    data_dir = str(tmp_path / "L3D_data")
+    os.makedirs(data_dir)
+    olib = op.load_lib()
+    for i, v in enumerate(sc.views):
+        rel = op.collinearity(olib, v["segments"], 2.0)
+        coll = {}
+        ii, jj = np.nonzero(np.triu(rel > 0.0, 1))
+        for a, b in zip(ii.tolist(), jj.tolist()):
+            coll.setdefault(a, {})[b] = rel[b, a]
+            coll.setdefault(b, {})[a] = rel[b, a]
+        osfm.write_segment_cache(data_dir + segment_cache_filename(i, sizes[i][0], sizes[i][1], True), v["segments"], coll)
+    exe = str(tmp_path / "main_vsfm_amd")
+    lib = os.path.join(ROOT, "line3d_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "main_vsfm_amd.cpp"),
+                           "-L" + lib, "-lline3d_amd", "-Wl,-rpath," + lib, "-o", exe])
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    r = subprocess.run([exe, nvm, data_dir, "6", "0", out_dir], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = os.path.join(out_dir, sfm.result_basename(neighbors=6) + ".txt")
+    got = load_txt(txt)
+    assert os.path.exists(txt[:-4] + ".stl")
+    cams, _ = osfm.read_nvm(nvm)
+    o = op.OracleLine3D(matching_neighbors=6)
+    for i, c in enumerate(cams):
+        assert o.add_image(i, sizes[i][0], sizes[i][1], sc.views[i]["segments"], osfm.intrinsics(c["focal"], *sizes[i]), c["R"], c["t"], list(c["worldpoints"]))
+    o.compute3Dmodel(False)
+    assert len(got) == len(o.result) > 0
+    for (g2, g3), (o2, o3) in zip(got, o.result):
+        assert [(c, s) for c, s, _ in g2] == [tuple(k) for k in o2]
+        assert len(g3) == len(o3)
+        for (gp, gq), (p, q) in zip(g3, o3):
+            assert np.allclose(gp, p, rtol=0, atol=1e-4) and np.allclose(gq, q, rtol=0, atol=1e-4)
