@@ -1,7 +1,7 @@
 // main_vsfm_amd.cpp -- the flow of the reference's VisualSfM driver (main_vsfm.cpp:34-329) over this library, with the
 // segment caches of an earlier Line3D run standing in for the images (no OpenCV, no tclap, no boost):
 //
-//   main_vsfm_amd <scene.nvm> <data directory> [neighbors=10] [diffusion=0] [output folder=<data directory>]
+//   main_vsfm_amd <scene.nvm | bundle.rd.out> <data directory> [neighbors=10] [diffusion=0] [output folder=<data directory>]
 //
 // For every camera of the NVM file the data directory ("<image folder>/L3D_data" of the reference, main_vsfm.cpp:108-116)
 // must hold "segments_<id>_<w>x<h>_coll1.bin" (line3D.cc:143-150) -- the image size is read off the file name, K is built
@@ -44,14 +44,16 @@ bool find_cache(const std::string& dir, unsigned id, unsigned& w, unsigned& h)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s <scene.nvm> <data directory> [neighbors=10] [diffusion=0] [output folder]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <scene.nvm | bundle.rd.out> <data directory> [neighbors=10] [diffusion=0] [output folder]\n", argv[0]); return 2; }
     const std::string nvm = argv[1], data_dir = argv[2];
     const int neighbors = argc > 3 ? atoi(argv[3]) : 10;
     const bool diffusion = argc > 4 && atoi(argv[4]) != 0;
     const std::string out_dir = argc > 5 ? argv[5] : data_dir;
 
     l3d_sfm_scene* scene = nullptr;
-    if (l3d_sfm_read_nvm(nvm.c_str(), &scene) != L3D_OK) {
+    // a bundler file (bundle.rd.out, main_bundler.cpp:110-204) is read just as well: the rest of the two drivers is the same flow
+    const bool is_nvm = nvm.size() >= 4 && nvm.compare(nvm.size() - 4, 4, ".nvm") == 0;
+    if ((is_nvm ? l3d_sfm_read_nvm(nvm.c_str(), &scene) : l3d_sfm_read_bundler(nvm.c_str(), &scene)) != L3D_OK) {
         fprintf(stderr, "%s\n", l3d_sfm_last_error(scene));
         l3d_sfm_free(scene);
         return 1;
