@@ -240,8 +240,7 @@ def main():
         value = pairs_total * args.steps / dt
         # dominant kernel = the one with the largest summed duration on this rank
         roof = None
-        if prof:
-            name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
+        def kernel_roof(name, launches, ms):
             # algorithmic HBM bytes per launch: one launch = one view
             nv = max(1, len(scene.views))
             R_per_launch = raw_local / nv
@@ -278,12 +277,23 @@ def main():
                 tf = ref_flops / (avg_ms * 1e-3) / 1e12
                 flops = dict(reference_formulation_flops_per_launch=ref_flops, equivalent_tflops=tf, peak_tflops=157.3, frac=tf / 157.3,
                              note="reference-formulation flops / measured launch duration; not a count of executed instructions")
-            roof = dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, fp32_equivalent=flops,
-                        traffic=traffic, valu=valu, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg,
-                        note="the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
-                             "view and stay in L2/LDS; kernels_ms = per-kernel time of one untimed pass with every kernel bracketed; "
-                             "in the timed region only the dominant kernel carries HIP events",
-                        kernels_ms={k: round(v[1], 3) for k, v in prof_all.items()})
+            return dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, fp32_equivalent=flops,
+                        traffic=traffic, valu=valu, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg)
+
+        if prof:
+            name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
+            roof = kernel_roof(name, launches, ms)
+            roof["note"] = ("the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
+                            "view and stay in L2/LDS; kernels_ms = per-kernel time of one untimed pass with every kernel bracketed; "
+                            "in the timed region only the dominant kernel carries HIP events")
+            roof["kernels_ms"] = {k: round(v[1], 3) for k, v in prof_all.items()}
+            # k_pair_mask and k_verify_window take about the same time per pass: which one is named dominant changes from run to run.
+            # The other one, from the untimed bracketed pass (one launch per view), so that both are always in the line
+            others = sorted(((k, v) for k, v in prof_all.items() if k != name), key=lambda kv: -kv[1][1])
+            if others:
+                k2, (l2, m2) = others[0]
+                roof["runner_up"] = kernel_roof(k2, l2, m2)
+                roof["runner_up"]["note"] = "second kernel by time, from the untimed pass with every kernel bracketed"
         out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
