@@ -1447,7 +1447,10 @@ void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std
         if (c < 0) dir = dir * -1.0;
     }
     struct SP { V3 P; unsigned seg3D, cam; float dist; };
-    std::vector<SP> sortable;
+    static thread_local std::vector<SP> sortable;           // (per-thread buffers: a fit is a few microseconds, allocations were a third of it)
+    static thread_local std::vector<char> line_open;
+    static thread_local std::vector<std::pair<unsigned, unsigned>> cam_open;
+    sortable.clear();
     V3 min_point;
     double min_length = 0.0, max_length = 0.0;
     const double dn2 = norm(dir) * norm(dir);
@@ -1468,21 +1471,27 @@ void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std
     }
     for (SP& s : sortable) s.dist = (float)norm(s.P - min_point);
     std::stable_sort(sortable.begin(), sortable.end(), [](const SP& a, const SP& b) { return a.dist < b.dist; });
-    std::map<unsigned, unsigned> open;
-    std::set<unsigned> open_lines;
+    // the sweep of projectToLine (line3D.cc:1543-1594): a 3-D segment opens at its first end point and closes at its second; the
+    // reference's std::map<camera, open segments> / std::set<open segment> are a flag per segment and a short (camera, count) list here
+    line_open.assign(segID, 0);
+    cam_open.clear();
+    size_t n_open_cams = 0;                                 // cameras with at least one open segment (= open.size())
     bool opened = false;
     V3 start;
     for (const SP& pt : sortable) {
-        if (!open_lines.count(pt.seg3D)) { open_lines.insert(pt.seg3D); ++open[pt.cam]; }
-        else { open_lines.erase(pt.seg3D); if (--open[pt.cam] == 0) open.erase(pt.cam); }
-        if (opened && open.size() < 3) { aligned.emplace_back(start, pt.P); opened = false; }
-        else if (!opened && open.size() >= 3) { start = pt.P; opened = true; }
+        size_t ci = 0;
+        while (ci < cam_open.size() && cam_open[ci].first != pt.cam) ++ci;
+        if (ci == cam_open.size()) cam_open.emplace_back(pt.cam, 0u);
+        if (!line_open[pt.seg3D]) { line_open[pt.seg3D] = 1; if (cam_open[ci].second++ == 0) ++n_open_cams; }
+        else { line_open[pt.seg3D] = 0; if (--cam_open[ci].second == 0) --n_open_cams; }
+        if (opened && n_open_cams < 3) { aligned.emplace_back(start, pt.P); opened = false; }
+        else if (!opened && n_open_cams >= 3) { start = pt.P; opened = true; }
     }
 }
 
-// Line3D::clusterSegments2D, line3D.cc:968-1252: candidate enumeration in the reference's order on the
-// host, all similarity_coll3D evaluations in one batched HIP launch, thresholds / first-touch node
-// numbering replayed sequentially.
+// Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
+// (l3d_affinity_fill, l3d_clustering_edges), union-find and line fit here; the round-1 host stages remain as the cross-check
+// (L3D_AFFINITY_HOST=1) and for edge lists the device path refuses.
 int cluster_segments_2D(L* h, bool perform_diff)
 {
     const double t0 = now_s();
