@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -51,8 +52,22 @@ inline unsigned host_threads()         // worker threads of the host-side stages
 // time: a region started while another one runs (nested, or from another thread) gets plain threads of its own.
 class HostPool {
 public:
-    // never destroyed: the (detached) workers may still be parked on its condition variable when the process exits
-    static HostPool& get() { static HostPool* p = new HostPool(); return *p; }
+    // Never destroyed: the (detached) workers may still be parked on its condition variable when the process exits.  A forked
+    // child has none of the parent's workers, and the parent's condition variables still count them as waiters (a notify can
+    // block on them for ever): the child gets a pool of its own, the inherited one is left alone.
+    static HostPool& get()
+    {
+        static std::atomic<HostPool*> inst{ nullptr };
+        HostPool* p = inst.load(std::memory_order_acquire);
+        if (!p || p->pid_ != getpid()) {
+            static std::atomic_flag busy = ATOMIC_FLAG_INIT;              // (not a mutex: its owner may not exist in a forked child)
+            while (busy.test_and_set(std::memory_order_acquire)) std::this_thread::yield();
+            p = inst.load(std::memory_order_relaxed);
+            if (!p || p->pid_ != getpid()) { p = new HostPool(); p->pid_ = getpid(); inst.store(p, std::memory_order_release); }
+            busy.clear(std::memory_order_release);
+        }
+        return *p;
+    }
     void run(unsigned nt, const std::function<void(unsigned)>& fn)
     {
         if (nt <= 1) { fn(0u); return; }
@@ -66,7 +81,6 @@ public:
         }
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (pid_ != getpid()) { pid_ = getpid(); n_threads_ = 0; }   // a forked child has none of the parent's threads
             while (n_threads_ + 1 < nt) { const unsigned idx = ++n_threads_; const unsigned long long g = gen_; std::thread([this, idx, g] { loop(idx, g); }).detach(); }
             job_ = &fn; job_threads_ = nt; remaining_ = nt - 1; ++gen_;
         }
