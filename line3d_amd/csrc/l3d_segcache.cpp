@@ -172,8 +172,9 @@ int l3d_segment_cache_read(const char* path, l3d_segment_cache** out)
         // DataArray<float>(4, n) (segments.h:70, dataArray.h:66-95): rows padded to a multiple of 32 bytes
         if (width != 4 || real_width < width || stride_cpu != real_width || pitch_cpu != (uint64_t)real_width * 4)
             return fail(s, "segment cache: segment array is not a 4-column float array (width " + std::to_string(width) + ", row " + std::to_string(real_width) + ")", out);
-        const uint64_t payload = (uint64_t)real_width * height * 4;
-        if (bytes.size() - r.pos != payload)
+        const uint64_t left = bytes.size() - r.pos, row_bytes = (uint64_t)real_width * 4;
+        const uint64_t payload = height <= left / row_bytes ? row_bytes * height : ~(uint64_t)0;      // (no overflow: rows that cannot be there)
+        if (left != payload)
             return fail(s, "segment cache: " + std::to_string(bytes.size() - r.pos) + " bytes left for " + std::to_string(height) + " rows of " + std::to_string(real_width) + " floats", out);
         n_seg = height;
         s->segs.resize(n_seg * 4);

@@ -130,3 +130,47 @@ def test_malformed_files_are_refused_with_a_message(tmp_path):
         lio.write_segment_cache(str(tmp_path / "dup.bin"), segs, [0, 0], [1, 1], [0.5, 0.5])
     with pytest.raises(RuntimeError):
         lio.write_segment_cache(str(tmp_path / "range.bin"), segs, [0], [12], [0.5])
+
+
+def test_reader_survives_random_corruption(tmp_path):
+    """Byte flips, truncations and spliced garbage: the reader either parses the file or refuses it with a message -- it never
+    crashes and never trusts a count or a size the file cannot back (e.g. 2^31 rows of 2^31 floats, whose byte count wraps)."""
+    segs, coll = _scene(30, 9, 0.25)
+    good = str(tmp_path / "good.bin")
+    osfm.write_segment_cache(good, segs, coll)
+    data = bytearray(open(good, "rb").read())
+    rng = np.random.default_rng(123)
+    p = str(tmp_path / "fuzz.bin")
+    outcomes = {"parsed": 0, "refused": 0}
+    for trial in range(400):
+        blob = bytearray(data)
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                blob[int(rng.integers(0, len(blob)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            blob = blob[:int(rng.integers(0, len(blob)))]
+        elif kind == 2:
+            pos = int(rng.integers(0, len(blob)))
+            blob[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        else:
+            pos = int(rng.integers(30, len(blob) - 8))
+            blob[pos:pos + 8] = bytes(rng.choice([0x00, 0x7f, 0x80, 0xff], 8).astype(np.uint8))
+        open(p, "wb").write(bytes(blob))
+        try:
+            got = lio.read_segment_cache(p)
+            assert got.segments.shape[1] == 4 and len(got.ci) == len(got.cj) == len(got.cw)
+            outcomes["parsed"] += 1
+        except RuntimeError as e:
+            assert str(e)
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 200
+    # the row count that wraps a 64-bit byte count
+    hdr = data.find(struct.pack("<III", 4, 30, 8))
+    assert hdr > 0
+    blob = bytearray(data[:hdr + 44])
+    blob[hdr + 4:hdr + 12] = struct.pack("<II", 0x80000000, 0x80000000)
+    blob[hdr + 12:hdr + 28] = struct.pack("<QQ", 0x80000000 * 4, 0x80000000)
+    open(p, "wb").write(bytes(blob))
+    with pytest.raises(RuntimeError):
+        lio.read_segment_cache(p)
