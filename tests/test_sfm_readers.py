@@ -186,3 +186,42 @@ def test_cpp_driver_over_segment_caches_matches_oracle(sfm_scene, tmp_path):
         assert len(g3) == len(o3)
         for (gp, gq), (p, q) in zip(g3, o3):
             assert np.allclose(gp, p, rtol=0, atol=1e-4) and np.allclose(gq, q, rtol=0, atol=1e-4)
+
+
+def test_sfm_readers_survive_corrupted_files(sfm_scene, tmp_path):
+    """Truncated and garbled NVM / bundler files: the readers return cameras or raise with a message; they never crash and never
+    trust a count the file cannot back."""
+    from line3d_amd import sfm
+    sc, pts = sfm_scene
+    rng = np.random.default_rng(7)
+    for writer, reader, name in ((write_nvm, sfm.read_nvm, "scene.nvm"), (write_bundler, sfm.read_bundler, "bundle.rd.out")):
+        good = str(tmp_path / name)
+        writer(good, sc, pts)
+        text = open(good).read()
+        p = str(tmp_path / ("fuzz_" + name))
+        outcomes = {"read": 0, "refused": 0}
+        for trial in range(120):
+            kind = trial % 4
+            if kind == 0:
+                t = text[:int(rng.integers(0, len(text)))]
+            elif kind == 1:
+                toks = text.split(" ")
+                for _ in range(int(rng.integers(1, 8))):
+                    toks[int(rng.integers(0, len(toks)))] = str(rng.choice(["-1", "999999999", "nan", "x", "1e400", "", "4294967296", "-2147483649"]))
+                t = " ".join(toks)
+            elif kind == 2:
+                lines = text.split("\\n")
+                del lines[int(rng.integers(0, len(lines)))]
+                t = "\\n".join(lines)
+            else:
+                pos = int(rng.integers(0, len(text)))
+                t = text[:pos] + "".join(chr(int(c)) for c in rng.integers(32, 127, int(rng.integers(1, 30)))) + text[pos:]
+            open(p, "w").write(t)
+            try:
+                got = reader(p)
+                assert len(got.cameras) >= 0
+                outcomes["read"] += 1
+            except RuntimeError as e:
+                assert str(e)
+                outcomes["refused"] += 1
+        assert outcomes["read"] + outcomes["refused"] == 120
