@@ -590,3 +590,36 @@ def test_random_small_scenes_full_parity(seed):
         assert np.float32(med) == np.float32(o.trace[v]["median"])
     assert_lines_equal(l.getResult(), o.result, 1e-4)
     l.close()
+
+
+def test_degenerate_segments_through_the_whole_pipeline():
+    """Zero-length segments, exact duplicates, a segment repeated in reverse, coordinates far outside the image and one segment per
+    view with the same endpoints in every view: the whole pipeline (chain, affinity fill, diffusion, clustering, line fit) runs to
+    the end, and kept lists and edge lists equal the oracle's bit for bit."""
+    from line3d_amd.synth import make_scene
+    sc = make_scene(9, 220, 6, seed=909)
+    rng = np.random.default_rng(5)
+    for v in sc.views:
+        s = v["segments"]
+        n = len(s)
+        for k in rng.choice(n, 12, replace=False):
+            s[k, 2:] = s[k, :2]                                    # zero length
+        for k in rng.choice(n, 10, replace=False):
+            s[k] = s[(k + 7) % n]                                  # exact duplicate of another segment
+        for k in rng.choice(n, 10, replace=False):
+            s[k] = s[(k + 3) % n][[2, 3, 0, 1]]                    # another segment, reversed
+        for k in rng.choice(n, 6, replace=False):
+            s[k] += np.float32(1e5)                                # far outside the image
+        s[0] = np.array([960.0, 540.0, 1000.0, 560.0], np.float32)  # the same segment in every view
+        v["segments"] = np.ascontiguousarray(s)
+    for diffusion in (False, True):
+        o = op.run_scene(sc, 6, perform_diffusion=diffusion)
+        l = _run_gpu(sc, 6, diffusion=diffusion)
+        for v in sorted(o.trace):
+            got, med = l.view_matches(v)
+            assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
+            assert np.float32(med) == np.float32(o.trace[v]["median"])
+        A, n_nodes = l.affinity()
+        assert A.tobytes() == o.affinity.tobytes()
+        assert_lines_equal(l.getResult(), o.result, 1e-4)
+        l.close()
