@@ -397,7 +397,7 @@ def _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, co
     return A, node_hyp, n_cand
 
 
-@pytest.mark.parametrize("seed,one_way,chunk", [(1, 0.0, None), (2, 0.15, None), (3, 0.15, "3"), (4, 0.5, "1"), (5, 0.0, "2")])
+@pytest.mark.parametrize("seed,one_way,chunk", [(1, 0.0, None), (2, 0.15, None), (3, 0.15, "3"), (4, 0.5, "1"), (5, 0.0, "2"), (6, 0.1, None)])
 def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib, monkeypatch, seed, one_way, chunk):
     """l3d_affinity_fill on random flat tables -- clustered hypotheses so that many similarities pass, long target groups,
     targets without a hypothesis, collinearity lists that are NOT symmetric, potential correspondences recorded one way only
@@ -408,6 +408,9 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
         monkeypatch.setenv("L3D_AFF_CHUNK", chunk)
     rng = np.random.default_rng(seed)
     V, S = 7, 40
+    dense = seed == 6                    # groups of more than 64 targets and collinearity lists of more than 64 entries (64-lane passes)
+    if dense:
+        V, S = 4, 260
     seg_base = np.arange(V + 1, dtype=np.int32) * S
     nd = V * S
     has_hyp = rng.random(nd) < 0.8
@@ -436,8 +439,9 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
             tv = int(rng.integers(0, V))
             if tv == d // S:
                 continue
-            base = int(rng.integers(0, S - 6))
-            for t in range(base, base + int(rng.integers(1, 6))):       # runs: long groups in one view
+            run = int(rng.integers(1, 6)) if not dense or rng.random() < 0.9 else int(rng.integers(70, 200))
+            base = int(rng.integers(0, S - run))
+            for t in range(base, base + run):                           # runs: long groups in one view
                 pot[d].add(tv * S + t)
                 if rng.random() >= one_way:
                     pot[tv * S + t].add(d)
@@ -445,7 +449,7 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     coll = [dict() for _ in range(nd)]
     for d in range(nd):
         v = d // S
-        for _ in range(rng.integers(0, 5)):
+        for _ in range(rng.integers(0, 5) if not dense or rng.random() < 0.9 else rng.integers(70, 150)):
             x = v * S + int(rng.integers(0, S))
             if x == d:
                 continue
