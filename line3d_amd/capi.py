@@ -53,6 +53,14 @@ def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t)
 
 
+class AffinityInput(C.Structure):
+    """l3d_affinity_input (include/line3d_amd.h)"""
+    _fields_ = [("n_views", C.c_int32), ("seg_base", C.c_void_p), ("view_hyp_begin", C.c_void_p), ("n_hyp", C.c_int32),
+                ("hyp", C.c_void_p), ("score", C.c_void_p), ("hyp_dense", C.c_void_p), ("best", C.c_void_p),
+                ("pot_start", C.c_void_p), ("pot_tgt", C.c_void_p), ("coll_start", C.c_void_p), ("coll_other", C.c_void_p),
+                ("coll_w", C.c_void_p), ("sigma_a", C.c_float)]
+
+
 class Context:
     """One GPU, one stream, grow-only device arenas (l3d_ctx)."""
 
@@ -213,11 +221,7 @@ class Context:
 
     def affinity_fill(self, seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, sigma_a):
         """l3d_affinity_fill: flat tables -> (edges EDGE_DTYPE, node_hyp int32, number of enumerated candidate pairs)."""
-        class In(C.Structure):
-            _fields_ = [("n_views", C.c_int32), ("seg_base", C.c_void_p), ("view_hyp_begin", C.c_void_p), ("n_hyp", C.c_int32),
-                        ("hyp", C.c_void_p), ("score", C.c_void_p), ("hyp_dense", C.c_void_p), ("best", C.c_void_p),
-                        ("pot_start", C.c_void_p), ("pot_tgt", C.c_void_p), ("coll_start", C.c_void_p), ("coll_other", C.c_void_p),
-                        ("coll_w", C.c_void_p), ("sigma_a", C.c_float)]
+        In = AffinityInput
         arrs = [np.ascontiguousarray(seg_base, np.int32), np.ascontiguousarray(view_hyp_begin, np.int32), np.ascontiguousarray(hyp, HYP_DTYPE),
                 np.ascontiguousarray(score, np.float32), np.ascontiguousarray(hyp_dense, np.int32), np.ascontiguousarray(best, np.int32),
                 np.ascontiguousarray(pot_start, np.int64), np.ascontiguousarray(pot_tgt, np.int32), np.ascontiguousarray(coll_start, np.int64),

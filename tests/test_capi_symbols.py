@@ -28,9 +28,23 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
-def test_struct_layouts():
+def test_struct_layouts(tmp_path):
+    """The Python mirrors of the C structs against the header itself: sizes and member offsets printed by a C program."""
+    import ctypes
+    import subprocess
     from line3d_amd import capi
     assert capi.MATCH_DTYPE.itemsize == 32 and capi.EDGE_DTYPE.itemsize == 12 and capi.HYP_DTYPE.itemsize == 96
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "line3d_amd.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(l3d_match), sizeof(l3d_edge), sizeof(l3d_hypothesis),\n'
+                   '  sizeof(l3d_affinity_input), offsetof(l3d_affinity_input, seg_base), offsetof(l3d_affinity_input, n_hyp), offsetof(l3d_affinity_input, hyp),\n'
+                   '  offsetof(l3d_affinity_input, coll_w), offsetof(l3d_affinity_input, sigma_a)); return 0; }\n')
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    A = capi.AffinityInput
+    assert got == [capi.MATCH_DTYPE.itemsize, capi.EDGE_DTYPE.itemsize, capi.HYP_DTYPE.itemsize, ctypes.sizeof(A), A.seg_base.offset, A.n_hyp.offset,
+                   A.hyp.offset, A.coll_w.offset, A.sigma_a.offset], got
 
 
 def test_no_gpu_fails_loudly():
