@@ -710,10 +710,14 @@ int prepare(L* h)
 {
     drop_plan(h);
     if (h->views.size() < 4) return h->fail(L3D_ERR_INVALID, "not enough images! can't compute 3D model...");   // line3D.cc:347-351
+    const bool timing = getenv("L3D_TIMING") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d prepare] %-28s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
     h->computation = true;
     find_visual_neighbors(h);
     int rc = transform_geometry(h);
     if (rc) return rc;
+    lap("neighbours + normalisation");
     h->vlist.clear();
     int idx = 0;
     for (auto& kv : h->views) { kv.second.index = idx++; h->vlist.push_back(&kv.second); }
@@ -729,8 +733,10 @@ int prepare(L* h)
         if (!rc) rc = l3d_register_segments(h->ctx, v->nb_segs.data(), (int)(v->nb_segs.size() / 4));
         if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
     }
+    lap("neighbour tiles + residency");
     rc = compute_pending_collinearities(h);             // (the segments are resident now: nothing is uploaded again)
     if (rc) return rc;
+    lap("collinearity (all views)");
     h->prepared = true;
     return L3D_OK;
 }
