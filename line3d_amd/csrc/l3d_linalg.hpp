@@ -5,45 +5,52 @@
 #include <cmath>
 #include <cstring>
 
+// (the line fit runs these on the device too: l3d_linefit.hip)
+#if defined(__HIPCC__)
+#define L3D_LA_HD __host__ __device__
+#else
+#define L3D_LA_HD
+#endif
+
 namespace l3d {
 namespace la {
 
 struct V3 { double x = 0, y = 0, z = 0; };
-inline V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
-inline V3 operator-(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
-inline V3 operator*(V3 a, double s) { return { a.x * s, a.y * s, a.z * s }; }
-inline V3 operator*(double s, V3 a) { return { a.x * s, a.y * s, a.z * s }; }
-inline V3 operator/(V3 a, double s) { return { a.x / s, a.y / s, a.z / s }; }
-inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
-inline V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+L3D_LA_HD inline V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+L3D_LA_HD inline V3 operator-(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+L3D_LA_HD inline V3 operator*(V3 a, double s) { return { a.x * s, a.y * s, a.z * s }; }
+L3D_LA_HD inline V3 operator*(double s, V3 a) { return { a.x * s, a.y * s, a.z * s }; }
+L3D_LA_HD inline V3 operator/(V3 a, double s) { return { a.x / s, a.y / s, a.z / s }; }
+L3D_LA_HD inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+L3D_LA_HD inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+L3D_LA_HD inline V3 cross(V3 a, V3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
 
 struct M3 {
     double m[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    double& operator()(int r, int c) { return m[r * 3 + c]; }
-    double operator()(int r, int c) const { return m[r * 3 + c]; }
+    L3D_LA_HD double& operator()(int r, int c) { return m[r * 3 + c]; }
+    L3D_LA_HD double operator()(int r, int c) const { return m[r * 3 + c]; }
 };
-inline M3 identity3() { M3 r; r(0, 0) = r(1, 1) = r(2, 2) = 1.0; return r; }
-inline M3 transpose(const M3& a) { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = a(j, i); return r; }
-inline M3 mul(const M3& a, const M3& b)
+L3D_LA_HD inline M3 identity3() { M3 r; r(0, 0) = r(1, 1) = r(2, 2) = 1.0; return r; }
+L3D_LA_HD inline M3 transpose(const M3& a) { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = a(j, i); return r; }
+L3D_LA_HD inline M3 mul(const M3& a, const M3& b)
 {
     M3 r;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) r(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
     return r;
 }
-inline V3 mul(const M3& a, V3 v)
+L3D_LA_HD inline V3 mul(const M3& a, V3 v)
 {
     return { a(0, 0) * v.x + a(0, 1) * v.y + a(0, 2) * v.z, a(1, 0) * v.x + a(1, 1) * v.y + a(1, 2) * v.z,
              a(2, 0) * v.x + a(2, 1) * v.y + a(2, 2) * v.z };
 }
-inline double det(const M3& a)
+L3D_LA_HD inline double det(const M3& a)
 {
     return a(0, 0) * (a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) + a(0, 1) * (a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2)) +
            a(0, 2) * (a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0));
 }
 // cofactor inverse (what a fixed-size 3x3 inverse does)
-inline M3 inverse(const M3& a)
+L3D_LA_HD inline M3 inverse(const M3& a)
 {
     const double c00 = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
     const double c01 = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
@@ -63,7 +70,7 @@ inline M3 inverse(const M3& a)
 }
 
 // Cyclic Jacobi eigen-decomposition of a symmetric 3x3: A = V diag(w) V^T (columns of V).
-inline void eig_sym3(const M3& A, double w[3], M3& V)
+L3D_LA_HD inline void eig_sym3(const M3& A, double w[3], M3& V)
 {
     M3 a = A;
     V = identity3();

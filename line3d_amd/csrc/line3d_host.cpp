@@ -25,6 +25,7 @@
 
 #include "../../include/line3d_amd.h"
 #include "l3d_linalg.hpp"
+#include "l3d_linefit.hpp"
 #include "l3d_hostsort.hpp"
 
 using namespace l3d::la;
@@ -1423,76 +1424,24 @@ int perform_diffusion(L* h, const EdgeVec& A, int n, EdgeVec& out)
     return L3D_OK;
 }
 
-// getLineEquation3D + projectToLine, line3D.cc:1392-1597
+// getLineEquation3D + projectToLine, line3D.cc:1392-1597 (the arithmetic lives in l3d_linefit.hpp, shared with the device kernel)
 void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std::vector<std::pair<V3, V3>>& aligned)
 {
     aligned.clear();
     if (t3.empty()) return;
-    const double n = (double)t3.size() * 2.0;
-    V3 Pc;
-    for (auto& e : t3) { Pc = Pc + e.second.first; Pc = Pc + e.second.second; }
-    Pc = Pc / n;
-    M3 Sc;
-    auto acc = [&](V3 p) {
-        const V3 d = p - Pc;
-        const double dv[3] = { d.x, d.y, d.z };
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sc(r, c) += dv[r] * dv[c];
-    };
-    for (auto& e : t3) { acc(e.second.first); acc(e.second.second); }
-    double w[3]; M3 V;
-    l3d::la::eig_sym3(Sc, w, V);
-    int mx = 0;
-    for (int k = 1; k < 3; ++k) if (w[k] > w[mx]) mx = k;
-    V3 dir = { V(0, mx), V(1, mx), V(2, mx) };
-    dir = dir / norm(dir);
-    // sign convention (Eigen's is unpinned): the largest |component| is positive
-    {
-        const double a[3] = { std::fabs(dir.x), std::fabs(dir.y), std::fabs(dir.z) };
-        int k = 0; if (a[1] > a[k]) k = 1; if (a[2] > a[k]) k = 2;
-        const double c = k == 0 ? dir.x : (k == 1 ? dir.y : dir.z);
-        if (c < 0) dir = dir * -1.0;
-    }
-    struct SP { V3 P; unsigned seg3D, cam; float dist; };
-    static thread_local std::vector<SP> sortable;           // (per-thread buffers: a fit is a few microseconds, allocations were a third of it)
-    static thread_local std::vector<char> line_open;
-    static thread_local std::vector<std::pair<unsigned, unsigned>> cam_open;
-    sortable.clear();
-    V3 min_point;
-    double min_length = 0.0, max_length = 0.0;
-    const double dn2 = norm(dir) * norm(dir);
-    unsigned segID = 0;
-    for (auto& e : t3) {
-        const V3 P1 = e.second.first, P2 = e.second.second;
-        const V3 proj1 = Pc + (dot(dir, P1 - Pc) / dn2) * dir;
-        const V3 proj2 = Pc + (dot(dir, P2 - Pc) / dn2) * dir;
-        const double loc1 = dot(dir, Pc - proj1);
-        if (loc1 <= min_length) { min_length = loc1; min_point = proj1; }
-        if (loc1 >= max_length) max_length = loc1;
-        const double loc2 = dot(dir, Pc - proj2);
-        if (loc2 <= min_length) { min_length = loc2; min_point = proj2; }
-        if (loc2 >= max_length) max_length = loc2;
-        sortable.push_back({ P1, segID, kcam(e.first), 0.0f });
-        sortable.push_back({ P2, segID, kcam(e.first), 0.0f });
-        ++segID;
-    }
-    for (SP& s : sortable) s.dist = (float)norm(s.P - min_point);
-    std::stable_sort(sortable.begin(), sortable.end(), [](const SP& a, const SP& b) { return a.dist < b.dist; });
-    // the sweep of projectToLine (line3D.cc:1543-1594): a 3-D segment opens at its first end point and closes at its second; the
-    // reference's std::map<camera, open segments> / std::set<open segment> are a flag per segment and a short (camera, count) list here
-    line_open.assign(segID, 0);
-    cam_open.clear();
-    size_t n_open_cams = 0;                                 // cameras with at least one open segment (= open.size())
-    bool opened = false;
-    V3 start;
-    for (const SP& pt : sortable) {
-        size_t ci = 0;
-        while (ci < cam_open.size() && cam_open[ci].first != pt.cam) ++ci;
-        if (ci == cam_open.size()) cam_open.emplace_back(pt.cam, 0u);
-        if (!line_open[pt.seg3D]) { line_open[pt.seg3D] = 1; if (cam_open[ci].second++ == 0) ++n_open_cams; }
-        else { line_open[pt.seg3D] = 0; if (--cam_open[ci].second == 0) --n_open_cams; }
-        if (opened && n_open_cams < 3) { aligned.emplace_back(start, pt.P); opened = false; }
-        else if (!opened && n_open_cams >= 3) { start = pt.P; opened = true; }
-    }
+    const int n2 = (int)t3.size() * 2;
+    auto get = [&](int i) { return (i & 1) ? t3[(size_t)(i >> 1)].second.second : t3[(size_t)(i >> 1)].second.first; };
+    V3 Pc, dir, min_point;
+    l3d::fit::line_of_points(get, n2, Pc, dir, min_point);
+    static thread_local std::vector<float> dist;             // (per-thread buffers: a fit is a few microseconds, allocations were a third of it)
+    static thread_local std::vector<int> order;
+    static thread_local std::vector<unsigned char> line_open;
+    static thread_local std::vector<unsigned> cam_ids, cam_cnt;
+    dist.resize((size_t)n2); order.resize((size_t)n2); line_open.resize(t3.size()); cam_ids.resize(t3.size()); cam_cnt.resize(t3.size());
+    for (int i = 0; i < n2; ++i) { dist[(size_t)i] = l3d::fit::point_dist(get(i), min_point); order[(size_t)i] = i; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dist[(size_t)a] < dist[(size_t)b]; });
+    l3d::fit::sweep_line(order.data(), n2, get, [&](int member) { return kcam(t3[(size_t)member].first); }, line_open.data(), cam_ids.data(), cam_cnt.data(),
+                         [&](V3 s0, V3 e0) { aligned.emplace_back(s0, e0); });
 }
 
 // Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
