@@ -166,6 +166,17 @@ int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edg
  * l3d_affinity_fill) -- take l3d_replicator_dynamics_diffusion and the reference's map arithmetic instead. */
 int l3d_clustering_edges(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, l3d_edge* sorted_out);
 
+/* The line fit of Line3D::processClusteredSegments (line3D.cc:1306-1597: getLineEquation3D, projectToLine) for many clusters at
+ * once, on the device.  A cluster = its members' hypothesis indices in key order (camera, segment):
+ * group_start (n_groups + 1) into member_hyp.  hyp / hyp_cam: all hypotheses (3-D end points in the normalised scene) and their
+ * camera ids; hyp == NULL: the table of the last l3d_affinity_fill, still on the device (n_hyp must match).
+ * Rinv (3x3 row-major), scale_inv, tneg: Line3D::inverseTransform (line3D.cc:1782-1786), applied to every end point.
+ * Outputs (callee-allocated, l3d_free): seg_count[g] = 3-D segments of cluster g (the stretches seen by at least three cameras,
+ * in sweep order), segs = 6 doubles (start, end) per segment, the clusters back to back. */
+int l3d_fit_clusters(l3d_ctx* ctx, const int32_t* group_start, int n_groups, const int32_t* member_hyp, const l3d_hypothesis* hyp,
+                     const uint32_t* hyp_cam, int n_hyp, const double* Rinv, double scale_inv, const double* tneg,
+                     int32_t** seg_count, double** segs, int* n_segs);
+
 
 /* ---- Line3D::matchViews as one device-resident chain --------------------------------------------------------
  * The schedule of matchViews (line3D.cc:620-648) is static: which neighbours a view still has to match and

@@ -249,6 +249,29 @@ class Context:
                                                 C.c_int(iters), _p(out)))
         return out
 
+    def fit_clusters(self, group_start, member_hyp, hyp, hyp_cam, Rinv, scale_inv, tneg):
+        """l3d_fit_clusters: -> list (one per cluster) of lists of (start (3,), end (3,)) float64."""
+        gs = np.ascontiguousarray(group_start, np.int32)
+        mh = np.ascontiguousarray(member_hyp, np.int32)
+        hy = np.ascontiguousarray(hyp, HYP_DTYPE)
+        hc = np.ascontiguousarray(hyp_cam, np.uint32)
+        R = np.ascontiguousarray(Rinv, np.float64).reshape(9)
+        t = np.ascontiguousarray(tneg, np.float64).reshape(3)
+        cnt, segs = C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        n = C.c_int(0)
+        ng = len(gs) - 1
+        self._chk(self.lib.l3d_fit_clusters(self.h, _p(gs), C.c_int(ng), _p(mh), _p(hy), _p(hc), C.c_int(len(hy)), _p(R), C.c_double(scale_inv), _p(t),
+                                            C.byref(cnt), C.byref(segs), C.byref(n)))
+        counts = np.ctypeslib.as_array(cnt, (ng,)).copy() if ng else np.zeros(0, np.int32)
+        flat = np.ctypeslib.as_array(segs, (n.value * 6,)).copy().reshape(-1, 6) if n.value else np.zeros((0, 6))
+        self.lib.l3d_free(cnt)
+        self.lib.l3d_free(segs)
+        out, k = [], 0
+        for c in counts:
+            out.append([(flat[k + i, :3].copy(), flat[k + i, 3:].copy()) for i in range(c)])
+            k += int(c)
+        return out
+
     def test_contract_math(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         e = np.zeros(len(x), np.float32)

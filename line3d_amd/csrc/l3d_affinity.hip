@@ -465,8 +465,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_base = 0;
     const size_t o_dview = o_base + al((size_t)(V + 1) * 4);
-    const size_t o_hyp = o_dview + al((size_t)nd * 4);
-    const size_t o_score = o_hyp + al((size_t)nh * sizeof(Hypothesis));
+    const size_t o_score = o_dview + al((size_t)nd * 4);
     const size_t o_hd = o_score + al((size_t)nh * 4);
     const size_t o_best = o_hd + al((size_t)nh * 4);
     const size_t o_ps = o_best + al((size_t)nd * 4);
@@ -480,7 +479,10 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     char* base = c->g0.as<char>();
     auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
     HIPCHK(c, up(o_base, in->seg_base, (size_t)(V + 1) * 4));
-    HIPCHK(c, up(o_hyp, in->hyp, (size_t)nh * sizeof(Hypothesis)));
+    // (the hypothesis table gets a buffer of its own: the line fit of the same finish reads it again, l3d_fit_clusters)
+    c->resident_hyp = 0;
+    HIPCHK(c, c->aff_hyp.reserve((size_t)nh * sizeof(Hypothesis) + 64));
+    HIPCHK(c, hipMemcpyAsync(c->aff_hyp.p, in->hyp, (size_t)nh * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
     HIPCHK(c, up(o_score, in->score, (size_t)nh * 4));
     HIPCHK(c, up(o_hd, in->hyp_dense, (size_t)nh * 4));
     HIPCHK(c, up(o_best, in->best, (size_t)nd * 4));
@@ -496,7 +498,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     if (const char* e = getenv("L3D_AFF_CHUNK")) a.chunk = std::max(1, std::min(64, atoi(e)));       // tests: forces multi-pass groups on small scenes
     a.seg_base = reinterpret_cast<const int*>(base + o_base);
     a.dview = reinterpret_cast<const int*>(base + o_dview);
-    a.hyp = reinterpret_cast<const Hypothesis*>(base + o_hyp);
+    a.hyp = c->aff_hyp.as<Hypothesis>();
     a.score = reinterpret_cast<const float*>(base + o_score);
     a.hyp_dense = reinterpret_cast<const int*>(base + o_hd);
     a.best = reinterpret_cast<const int*>(base + o_best);
@@ -622,6 +624,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     lap("edges + download");
     *edges_out = A; *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
     c->resident_edges = 2 * n_kept;                                            // (the list stays in g6 for l3d_clustering_edges)
+    c->resident_hyp = nh;
     return L3D_OK;
 }
 

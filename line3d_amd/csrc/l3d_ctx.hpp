@@ -108,6 +108,8 @@ struct l3d_ctx {
     int verify_mode = 0;            // 0: depth-window search (all-pairs kernel only beyond ~50 neighbours), 1: all-pairs
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
+    l3d::DevBuf aff_hyp;            // hypothesis table of the last l3d_affinity_fill (kept for l3d_fit_clusters)
+    int resident_hyp = 0;           // its number of hypotheses (0: none)
     int resident_edges = 0;         // entries of the edge list l3d_affinity_fill left in g6 (0: none); consumed by l3d_clustering_edges
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;
     bool prof_on = false;

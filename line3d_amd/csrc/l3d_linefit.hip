@@ -1,0 +1,152 @@
+// l3d_linefit.hip -- the line fit of processClusteredSegments (line3D.cc:1306-1597: getLineEquation3D, projectToLine) on the device
+// (SURVEY.md 8f4): one wave per cluster, the arithmetic of l3d_linefit.hpp -- the very functions the host fit calls.
+//
+// A cluster is a list of hypothesis indices in key order (= ascending index: hypotheses are numbered by (camera, segment)).  The wave
+// takes the members' 3-D end points back to the caller's coordinates, fits the line (every lane runs the same short sequential
+// sums: the order of the additions is part of the result), gives every point its float distance along the line, ranks the points
+// (all-to-all comparison: the rank IS the stable order), and one lane sweeps them, emitting the stretches seen by >= 3 cameras.
+#include <hipcub/hipcub.hpp>
+
+#include "l3d_ctx.hpp"
+#include "l3d_linefit.hpp"
+
+using namespace l3d;
+
+namespace l3d {
+
+struct FitArgs {
+    int n_groups;
+    const int* group_start;             // n_groups + 1 (members)
+    const int* member_hyp;              // hypothesis indices, ascending per group
+    const Hypothesis* hyp;
+    const unsigned* hyp_cam;            // camera id per hypothesis
+    la::M3 Rinv; double scale_inv; la::V3 tneg;
+    la::V3* pts;                        // 2 per member
+    float* dist;                        // 2 per member
+    int* order;                         // 2 per member
+    unsigned char* line_open;           // 1 per member
+    unsigned* cam_ids; unsigned* cam_cnt;   // 1 per member
+    double* out;                        // 12 doubles... 6 per emitted segment, at most one per member
+    int* out_cnt;                       // per group
+};
+
+__global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= a.n_groups) return;
+    const int m0 = a.group_start[g], members = a.group_start[g + 1] - m0, n2 = 2 * members;
+    la::V3* pts = a.pts + 2 * (size_t)m0;
+    for (int i = lane; i < n2; i += 64) {
+        const Hypothesis& h = a.hyp[a.member_hyp[m0 + (i >> 1)]];
+        const la::V3 P = (i & 1) ? la::V3{ h.P2[0], h.P2[1], h.P2[2] } : la::V3{ h.P1[0], h.P1[1], h.P1[2] };
+        pts[i] = fit::inverse_transform(a.Rinv, a.scale_inv, a.tneg, P);
+    }
+    __threadfence_block();
+    auto get = [&](int i) { return pts[i]; };
+    la::V3 Pc, dir, min_point;
+    fit::line_of_points(get, n2, Pc, dir, min_point);                     // (every lane: the same sums in the same order)
+    float* dist = a.dist + 2 * (size_t)m0;
+    int* order = a.order + 2 * (size_t)m0;
+    for (int i = lane; i < n2; i += 64) dist[i] = fit::point_dist(pts[i], min_point);
+    __threadfence_block();
+    for (int i = lane; i < n2; i += 64) {                                 // stable order = rank by (distance, point index)
+        const float d = dist[i];
+        int r = 0;
+        for (int j = 0; j < n2; ++j) { const float e = dist[j]; r += (e < d) || (e == d && j < i); }
+        order[r] = i;
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        double* out = a.out + 6 * (size_t)m0;
+        int n_out = 0;
+        const int* mh = a.member_hyp + m0;
+        fit::sweep_line(order, n2, get, [&](int member) { return a.hyp_cam[mh[member]]; }, a.line_open + m0, a.cam_ids + m0, a.cam_cnt + m0,
+                        [&](la::V3 s0, la::V3 e0) { double* o = out + 6 * (size_t)n_out++; o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = e0.x; o[4] = e0.y; o[5] = e0.z; });
+        a.out_cnt[g] = n_out;
+    }
+}
+
+// the emitted segments of all groups, back to back
+__global__ void k_fit_gather(const int* __restrict__ group_start, const int* __restrict__ out_off, const double* __restrict__ out, int n_groups,
+                             double* __restrict__ packed)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= n_groups) return;
+    const int n = (out_off[g + 1] - out_off[g]) * 6;
+    const double* src = out + 6 * (size_t)group_start[g];
+    double* dst = packed + 6 * (size_t)out_off[g];
+    for (int i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+}  // namespace l3d
+
+// clusters: group_start (n_groups + 1) into member_hyp (hypothesis indices in key order); hyp / hyp_cam: all hypotheses (3-D end
+// points in the normalised scene) and their camera ids; Rinv (3x3 row-major), scale_inv, tneg: Line3D::inverseTransform.
+// Out (callee-allocated, l3d_free): seg_count[g] = 3-D segments of cluster g, segs = 6 doubles per segment, groups back to back.
+extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_groups, const int32_t* member_hyp, const l3d_hypothesis* hyp, const uint32_t* hyp_cam,
+                                int n_hyp, const double* Rinv, double scale_inv, const double* tneg, int32_t** seg_count, double** segs, int* n_segs)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!seg_count || !segs || !n_segs || n_groups < 0 || n_hyp < 0 || (n_groups > 0 && (!group_start || !member_hyp || !hyp_cam || !Rinv || !tneg)))
+        return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (n_groups > 0 && !hyp && c->resident_hyp != n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: no resident hypothesis table of that size (l3d_affinity_fill)");
+    *seg_count = nullptr; *segs = nullptr; *n_segs = 0;
+    if (n_groups == 0) return L3D_OK;
+    const int n_members = group_start[n_groups];
+    if (group_start[0] != 0 || n_members < 0) return fail(c, L3D_ERR_INVALID, "line fit: group table must start at 0");
+    for (int g = 0; g < n_groups; ++g) if (group_start[g + 1] < group_start[g]) return fail(c, L3D_ERR_INVALID, "line fit: group table must ascend");
+    for (int i = 0; i < n_members; ++i) if (member_hyp[i] < 0 || member_hyp[i] >= n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: member out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nm = (size_t)n_members, ng = (size_t)n_groups;
+    // inputs
+    const size_t o_gs = 0, o_mh = al((ng + 1) * 4), o_hyp = o_mh + al(nm * 4 + 4), o_cam = o_hyp + (hyp ? al((size_t)n_hyp * sizeof(Hypothesis)) : 0),
+                 in_bytes = o_cam + al((size_t)n_hyp * 4 + 4);
+    HIPCHK(c, c->g0.reserve(in_bytes));
+    char* ib = c->g0.as<char>();
+    HIPCHK(c, hipMemcpyAsync(ib + o_gs, group_start, (ng + 1) * 4, hipMemcpyHostToDevice, st));
+    if (nm) HIPCHK(c, hipMemcpyAsync(ib + o_mh, member_hyp, nm * 4, hipMemcpyHostToDevice, st));
+    if (n_hyp && hyp) HIPCHK(c, hipMemcpyAsync(ib + o_hyp, hyp, (size_t)n_hyp * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
+    if (n_hyp) HIPCHK(c, hipMemcpyAsync(ib + o_cam, hyp_cam, (size_t)n_hyp * 4, hipMemcpyHostToDevice, st));
+    // scratch + outputs
+    const size_t o_pts = 0, o_dist = al(2 * nm * sizeof(la::V3) + 64), o_ord = o_dist + al(2 * nm * 4 + 4), o_open = o_ord + al(2 * nm * 4 + 4), o_ci = o_open + al(nm + 4),
+                 o_cc = o_ci + al(nm * 4 + 4), o_out = o_cc + al(nm * 4 + 4), o_cnt = o_out + al(6 * nm * 8 + 8), o_off = o_cnt + al((ng + 1) * 4), sc_bytes = o_off + al((ng + 2) * 4);
+    HIPCHK(c, c->g1.reserve(sc_bytes));
+    char* sb = c->g1.as<char>();
+    FitArgs a;
+    a.n_groups = n_groups;
+    a.group_start = reinterpret_cast<const int*>(ib + o_gs); a.member_hyp = reinterpret_cast<const int*>(ib + o_mh);
+    a.hyp = hyp ? reinterpret_cast<const Hypothesis*>(ib + o_hyp) : c->aff_hyp.as<Hypothesis>(); a.hyp_cam = reinterpret_cast<const unsigned*>(ib + o_cam);
+    for (int i = 0; i < 9; ++i) a.Rinv.m[i] = Rinv[i];
+    a.scale_inv = scale_inv; a.tneg = la::V3{ tneg[0], tneg[1], tneg[2] };
+    a.pts = reinterpret_cast<la::V3*>(sb + o_pts); a.dist = reinterpret_cast<float*>(sb + o_dist); a.order = reinterpret_cast<int*>(sb + o_ord);
+    a.line_open = reinterpret_cast<unsigned char*>(sb + o_open); a.cam_ids = reinterpret_cast<unsigned*>(sb + o_ci); a.cam_cnt = reinterpret_cast<unsigned*>(sb + o_cc);
+    a.out = reinterpret_cast<double*>(sb + o_out); a.out_cnt = reinterpret_cast<int*>(sb + o_cnt);
+    int* out_off = reinterpret_cast<int*>(sb + o_off);
+    HIPCHK(c, hipMemsetAsync(a.out_cnt, 0, (ng + 1) * 4, st));
+    { ProfScope p(c, "fit_clusters", st); hipLaunchKernelGGL(k_fit_clusters, dim3((n_groups + 3) / 4), dim3(256), 0, st, a); }
+    size_t tb = 0;
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.out_cnt, out_off, n_groups + 1, st));
+    HIPCHK(c, c->g7.reserve(tb + 256));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->g7.p, tb, a.out_cnt, out_off, n_groups + 1, st));
+    int32_t* cnt = static_cast<int32_t*>(malloc((ng + 1) * 4));
+    if (!cnt) return fail(c, L3D_ERR_NOMEM, "malloc");
+    int total = 0;
+    hipError_t e1 = hipMemcpyAsync(cnt, a.out_cnt, ng * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(&total, out_off + n_groups, 4, hipMemcpyDeviceToHost, st);
+    hipError_t e3 = hipStreamSynchronize(st);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free(cnt); return fail(c, L3D_ERR_HIP, "line fit: read-back failed"); }
+    double* packed_host = static_cast<double*>(malloc(((size_t)total * 6 + 1) * 8));
+    if (!packed_host) { free(cnt); return fail(c, L3D_ERR_NOMEM, "malloc"); }
+    if (total > 0) {
+        HIPCHK(c, c->g2.reserve((size_t)total * 48 + 64));
+        hipLaunchKernelGGL(k_fit_gather, dim3((n_groups + 3) / 4), dim3(256), 0, st, a.group_start, out_off, a.out, n_groups, c->g2.as<double>());
+        e1 = hipMemcpyAsync(packed_host, c->g2.p, (size_t)total * 48, hipMemcpyDeviceToHost, st);
+        e2 = hipStreamSynchronize(st);
+        e3 = hipGetLastError();
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free(cnt); free(packed_host); return fail(c, L3D_ERR_HIP, "line fit: read-back failed"); }
+    }
+    *seg_count = cnt; *segs = packed_host; *n_segs = total;
+    return L3D_OK;
+}

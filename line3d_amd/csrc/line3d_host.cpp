@@ -206,8 +206,10 @@ struct l3d_line3d {
         std::vector<float, NoInitAlloc<float>> score, coll_w;
         std::vector<int32_t, NoInitAlloc<int32_t>> hyp_dense, best, pot_tgt, coll_other;
         std::vector<int64_t, NoInitAlloc<int64_t>> pot_start, coll_start;
+        std::vector<uint32_t, NoInitAlloc<uint32_t>> hyp_cam;                  // camera id per hypothesis (device line fit)
         bool coll_valid = false;
     } aff;
+    std::vector<int32_t> node_hyp;                             // hypothesis of every node of the affinity graph (device fill)
     std::vector<std::vector<int32_t>> aff_vt;                  // per view: its targets as dense ids (scratch of the table flattening)
 
     // statistics
@@ -1290,7 +1292,7 @@ void greedy_selection(L* h)
     // (the flat copies the device affinity fill takes -- hypothesis, score, dense segment id -- are written in the same pass)
     std::vector<size_t> voff(nv + 1, 0);
     for (size_t vi = 0; vi < nv; ++vi) voff[vi + 1] = voff[vi] + (size_t)h->vlist[vi]->S();
-    h->aff.hyp.resize(count[nv]); h->aff.score.resize(count[nv]); h->aff.hyp_dense.resize(count[nv]);
+    h->aff.hyp.resize(count[nv]); h->aff.score.resize(count[nv]); h->aff.hyp_dense.resize(count[nv]); h->aff.hyp_cam.resize(count[nv]);
     for_views([&](size_t vi) {
         View* v = h->vlist[vi];
         std::vector<int>& bi = h->best_idx[(size_t)v->index];
@@ -1312,6 +1314,7 @@ void greedy_selection(L* h)
             o.k_lower = v->k_lower; o.k_upper = v->k_upper; o.median_depth = v->median_depth; o.pad = 0;
             h->aff.score[k] = hy.score;
             h->aff.hyp_dense[k] = (int32_t)(voff[vi] + sg);
+            h->aff.hyp_cam[k] = v->id;
             h->hyps[k++] = hy;
         }
     });
@@ -1568,6 +1571,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
         parallel_slices((size_t)n_edges, nt, [&](size_t k0, size_t k1, unsigned) { if (k1 > k0) memcpy(&h->A[k0], edges + k0, (k1 - k0) * sizeof(l3d_edge)); });
         h->local2global.resize((size_t)n_nodes);
         for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
+        h->node_hyp.assign(node_hyp, node_hyp + n_nodes);
         l3d_free(edges); l3d_free(node_hyp);
         if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges, %u threads\n", nh, n_cand, h->A.size(), nt);
         lap("edge list to host");
@@ -1791,7 +1795,56 @@ int cluster_segments_2D(L* h, bool perform_diff)
     std::vector<int> groups;                                                    // labels with >= 4 members (>= 4 cameras needs that)
     for (int l = 0; l < n_nodes; ++l) if (lstart[(size_t)l + 1] - lstart[(size_t)l] >= 4) groups.push_back(l);
     std::vector<FinalLine> fitted(groups.size());
-    {
+    lap("  fit: clusters by label");
+    if (resident_list && (int)h->node_hyp.size() == n_nodes) {
+        // ---- the fits on the device (l3d_fit_clusters): members as hypothesis indices in key order (= ascending index)
+        std::vector<int32_t> memb_tmp((size_t)n_nodes);
+        std::vector<char> valid(groups.size(), 0);
+        parallel_slices(groups.size(), finish_threads(), [&](size_t g0, size_t g1, unsigned) {
+            for (size_t g = g0; g < g1; ++g) {
+                const int l = groups[g];
+                int32_t* mb = memb_tmp.data() + lstart[(size_t)l];
+                const int n = lstart[(size_t)l + 1] - lstart[(size_t)l];
+                for (int q = 0; q < n; ++q) mb[q] = h->node_hyp[(size_t)lnodes[(size_t)(lstart[(size_t)l] + q)]];
+                std::sort(mb, mb + n);
+                int ncam = 1;
+                for (int q = 1; q < n; ++q) ncam += h->aff.hyp_cam[(size_t)mb[q]] != h->aff.hyp_cam[(size_t)mb[q - 1]];
+                valid[g] = ncam >= 4;
+            }
+        });
+        std::vector<int32_t> gstart(1, 0), memb;
+        std::vector<size_t> gof;                                                // fitted[] slot of every cluster handed to the device
+        memb.reserve((size_t)n_nodes);
+        for (size_t g = 0; g < groups.size(); ++g) {
+            if (!valid[g]) continue;
+            const int l = groups[g];
+            memb.insert(memb.end(), memb_tmp.begin() + lstart[(size_t)l], memb_tmp.begin() + lstart[(size_t)l + 1]);
+            gstart.push_back((int32_t)memb.size());
+            gof.push_back(g);
+        }
+        lap("  fit: member lists");
+        int32_t* cnt = nullptr; double* segs = nullptr; int n_segs = 0;
+        const double tneg[3] = { h->transf_tneg.x, h->transf_tneg.y, h->transf_tneg.z };
+        // (hyp = null: the table l3d_affinity_fill uploaded in this finish is still on the device)
+        const int rc = l3d_fit_clusters(h->ctx, gstart.data(), (int)gof.size(), memb.data(), nullptr, h->aff.hyp_cam.data(), (int)h->aff.hyp.size(),
+                                        h->transf_Rinv.m, h->transf_scale_inv, tneg, &cnt, &segs, &n_segs);
+        if (rc) return h->fail(rc, std::string("line fit: ") + l3d_last_error(h->ctx));
+        lap("  fit: device");
+        std::vector<size_t> soff(gof.size() + 1, 0);
+        for (size_t v = 0; v < gof.size(); ++v) soff[v + 1] = soff[v] + (size_t)cnt[v];
+        parallel_slices(gof.size(), finish_threads(), [&](size_t v0, size_t v1, unsigned) {
+            for (size_t v = v0; v < v1; ++v) {
+                if (cnt[v] == 0) continue;
+                FinalLine& fl = fitted[gof[v]];
+                for (size_t k = soff[v]; k < soff[v + 1]; ++k) {
+                    const double* q = segs + 6 * k;
+                    fl.segs3D.emplace_back(V3{ q[0], q[1], q[2] }, V3{ q[3], q[4], q[5] });
+                }
+                for (int32_t i = gstart[v]; i < gstart[v + 1]; ++i) fl.segs2D.push_back(h->hyps[(size_t)memb[(size_t)i]].src);
+            }
+        });
+        l3d_free(cnt); l3d_free(segs);
+    } else {
         std::atomic<size_t> next{ 0 };
         auto worker = [&]() {
             std::vector<Key> keys;

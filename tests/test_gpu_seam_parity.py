@@ -526,3 +526,62 @@ def test_clustering_edges_order_and_diffusion_match_oracle(gpu_ctx, oracle_lib, 
         from line3d_amd.capi import L3DError
         with pytest.raises(L3DError):
             gpu_ctx.clustering_edges(A[::2], n, perform_diffusion=True)
+
+
+def test_fit_clusters_against_the_oracle_line_fit(gpu_ctx):
+    """l3d_fit_clusters (the line fit of processClusteredSegments on the device) against the oracle's align(): clusters of
+    noisy pieces of 3-D lines seen from 4-9 cameras, a cluster of 300 members, one seen by two cameras only (no segment), one
+    whose members are all the same segment, and a non-trivial inverse transformation.  End points within 1e-9 (the oracle takes
+    the direction from numpy's SVD, the product from its own Jacobi iteration), segment counts and sweep structure identical."""
+    from collections import OrderedDict
+    from line3d_amd.capi import HYP_DTYPE
+    rng = np.random.default_rng(17)
+    th = 0.4
+    Rinv = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]]) @ np.array([[1.0, 0, 0], [0, 0.8, -0.6], [0, 0.6, 0.8]])
+    scale_inv, tneg = 2.5, np.array([0.3, -1.2, 0.7])
+    hyps, cams, groups = [], [], []
+
+    def piece(p0, d, a, b, cam, noise=0.002):
+        hyps.append((p0 + a * d + rng.normal(scale=noise, size=3), p0 + b * d + rng.normal(scale=noise, size=3)))
+        cams.append(cam)
+        return len(hyps) - 1
+
+    for g in range(40):
+        p0, d = rng.normal(size=3), rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        ncam = int(rng.integers(4, 10)) if g != 5 else 2
+        m = int(rng.integers(4, 20)) if g != 7 else 300
+        members = []
+        for _ in range(m):
+            a = rng.uniform(-1, 1)
+            members.append(piece(p0, d, a, a + rng.uniform(0.2, 1.0), int(rng.integers(0, ncam)) + 10 * g))
+        if g == 9:                                                       # every member the very same segment
+            for k in members:
+                hyps[k] = hyps[members[0]]
+        groups.append(members)
+    # hypotheses are numbered by (camera, segment): sort all of them by camera and renumber
+    order = sorted(range(len(hyps)), key=lambda k: (cams[k], k))
+    new_of = {old: new for new, old in enumerate(order)}
+    hyp = np.zeros(len(hyps), HYP_DTYPE)
+    hyp_cam = np.zeros(len(hyps), np.uint32)
+    for new, old in enumerate(order):
+        hyp[new]["P1"], hyp[new]["P2"] = hyps[old]
+        hyp_cam[new] = cams[old]
+    group_start, member_hyp = [0], []
+    for members in groups:
+        member_hyp += sorted(new_of[k] for k in members)
+        group_start.append(len(member_hyp))
+    got = gpu_ctx.fit_clusters(group_start, member_hyp, hyp, hyp_cam, Rinv, scale_inv, tneg)
+    o = op.OracleLine3D(matching_neighbors=4)
+    o.transf_Rinv, o.transf_scale_inv, o.transf_tneg = Rinv, scale_inv, tneg
+    n_lines = 0
+    for g, members in enumerate(groups):
+        t3 = OrderedDict()
+        for k in sorted(new_of[q] for q in members):
+            t3[(int(hyp_cam[k]), k)] = (o.inverse_transform(hyp[k]["P1"]), o.inverse_transform(hyp[k]["P2"]))
+        exp = o.align(t3)
+        assert len(got[g]) == len(exp), g
+        n_lines += len(exp)
+        for (gs, ge), (es, ee) in zip(got[g], exp):
+            assert np.allclose(gs, es, rtol=0, atol=1e-9) and np.allclose(ge, ee, rtol=0, atol=1e-9), g
+    assert len(got[5]) == 0 and n_lines > 30
