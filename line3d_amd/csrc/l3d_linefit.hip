@@ -30,24 +30,34 @@ struct FitArgs {
     int* out_cnt;                       // per group
 };
 
+constexpr int kFitLds = 128;            // members of a cluster whose sweep state fits the per-wave LDS arrays
+
 __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
 {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= a.n_groups) return;
     const int m0 = a.group_start[g], members = a.group_start[g + 1] - m0, n2 = 2 * members;
-    la::V3* pts = a.pts + 2 * (size_t)m0;
+    // points, order and sweep state in LDS for clusters of up to kFitLds members (nearly all): with everything in global memory the
+    // sequential sums and the sweep are chains of dependent L2 round trips (0.86 ms per launch at config 2); bigger clusters keep
+    // the global scratch
+    __shared__ double s_pts[4][2 * kFitLds][3];
+    const int wv = threadIdx.x >> 6;
+    const bool small = members <= kFitLds;
+    la::V3* gpts = a.pts + 2 * (size_t)m0;
     for (int i = lane; i < n2; i += 64) {
         const Hypothesis& h = a.hyp[a.member_hyp[m0 + (i >> 1)]];
         const la::V3 P = (i & 1) ? la::V3{ h.P2[0], h.P2[1], h.P2[2] } : la::V3{ h.P1[0], h.P1[1], h.P1[2] };
-        pts[i] = fit::inverse_transform(a.Rinv, a.scale_inv, a.tneg, P);
+        const la::V3 Q = fit::inverse_transform(a.Rinv, a.scale_inv, a.tneg, P);
+        if (small) { s_pts[wv][i][0] = Q.x; s_pts[wv][i][1] = Q.y; s_pts[wv][i][2] = Q.z; }
+        else gpts[i] = Q;
     }
     __threadfence_block();
-    auto get = [&](int i) { return pts[i]; };
+    auto get = [&](int i) { return small ? la::V3{ s_pts[wv][i][0], s_pts[wv][i][1], s_pts[wv][i][2] } : gpts[i]; };
     la::V3 Pc, dir, min_point;
     fit::line_of_points(get, n2, Pc, dir, min_point);                     // (every lane: the same sums in the same order)
     float* dist = a.dist + 2 * (size_t)m0;
     int* order = a.order + 2 * (size_t)m0;
-    for (int i = lane; i < n2; i += 64) dist[i] = fit::point_dist(pts[i], min_point);
+    for (int i = lane; i < n2; i += 64) dist[i] = fit::point_dist(get(i), min_point);
     __threadfence_block();
     for (int i = lane; i < n2; i += 64) {                                 // stable order = rank by (distance, point index)
         const float d = dist[i];
@@ -56,12 +66,21 @@ __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
         order[r] = i;
     }
     __threadfence_block();
+    __shared__ int s_order[4][2 * kFitLds];
+    __shared__ unsigned s_cam[4][kFitLds], s_cid[4][kFitLds], s_ccnt[4][kFitLds];
+    __shared__ unsigned char s_open[4][kFitLds];
+    const int* mh = a.member_hyp + m0;
+    if (small) {
+        for (int i = lane; i < n2; i += 64) s_order[wv][i] = order[i];
+        for (int i = lane; i < members; i += 64) s_cam[wv][i] = a.hyp_cam[mh[i]];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
     if (lane == 0) {
         double* out = a.out + 6 * (size_t)m0;
         int n_out = 0;
-        const int* mh = a.member_hyp + m0;
-        fit::sweep_line(order, n2, get, [&](int member) { return a.hyp_cam[mh[member]]; }, a.line_open + m0, a.cam_ids + m0, a.cam_cnt + m0,
-                        [&](la::V3 s0, la::V3 e0) { double* o = out + 6 * (size_t)n_out++; o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = e0.x; o[4] = e0.y; o[5] = e0.z; });
+        auto emit = [&](la::V3 s0, la::V3 e0) { double* o = out + 6 * (size_t)n_out++; o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = e0.x; o[4] = e0.y; o[5] = e0.z; };
+        if (small) fit::sweep_line(s_order[wv], n2, get, [&](int member) { return s_cam[wv][member]; }, s_open[wv], s_cid[wv], s_ccnt[wv], emit);
+        else fit::sweep_line(order, n2, get, [&](int member) { return a.hyp_cam[mh[member]]; }, a.line_open + m0, a.cam_ids + m0, a.cam_cnt + m0, emit);
         a.out_cnt[g] = n_out;
     }
 }
