@@ -78,22 +78,28 @@ L3D_LA_HD inline void eig_sym3(const M3& A, double w[3], M3& V)
         const double off = a(0, 1) * a(0, 1) + a(0, 2) * a(0, 2) + a(1, 2) * a(1, 2);
         const double diag = a(0, 0) * a(0, 0) + a(1, 1) * a(1, 1) + a(2, 2) * a(2, 2);
         if (off <= 1e-300 || off <= 1e-32 * diag) break;
+        // (fixed trip counts, unrolled: on the device the matrices then live in registers instead of indexed scratch memory)
+#pragma unroll
         for (int p = 0; p < 2; ++p)
+#pragma unroll
             for (int q = p + 1; q < 3; ++q) {
                 if (a(p, q) == 0.0) continue;
                 const double theta = (a(q, q) - a(p, p)) / (2.0 * a(p, q));
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {   // A <- A J
                     const double akp = a(k, p), akq = a(k, q);
                     a(k, p) = c * akp - s * akq;
                     a(k, q) = s * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {   // A <- J^T A
                     const double apk = a(p, k), aqk = a(q, k);
                     a(p, k) = c * apk - s * aqk;
                     a(q, k) = s * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const double vkp = V(k, p), vkq = V(k, q);
                     V(k, p) = c * vkp - s * vkq;

@@ -28,13 +28,18 @@ L3D_LA_HD inline void line_of_points(Get get, int n2, V3& Pc, V3& dir, V3& min_p
     for (int i = 0; i < n2; ++i) {
         const V3 d = get(i) - Pc;
         const double dv[3] = { d.x, d.y, d.z };
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sc(r, c) += dv[r] * dv[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Sc(r, c) += dv[r] * dv[c];
+        }
     }
     double w[3]; M3 V;
     la::eig_sym3(Sc, w, V);
     int mx = 0;
-    for (int k = 1; k < 3; ++k) if (w[k] > w[mx]) mx = k;
-    dir = V3{ V(0, mx), V(1, mx), V(2, mx) };
+    if (w[1] > w[mx]) mx = 1;
+    if (w[2] > (mx == 1 ? w[1] : w[0])) mx = 2;
+    dir = mx == 0 ? V3{ V(0, 0), V(1, 0), V(2, 0) } : (mx == 1 ? V3{ V(0, 1), V(1, 1), V(2, 1) } : V3{ V(0, 2), V(1, 2), V(2, 2) });
     dir = dir / la::norm(dir);
     {
         const double a[3] = { fabs(dir.x), fabs(dir.y), fabs(dir.z) };
