@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
     auto get = [&](int i) { return small ? la::V3{ s_pts[wv][i][0], s_pts[wv][i][1], s_pts[wv][i][2] } : gpts[i]; };
     la::V3 Pc, dir, min_point;
     fit::line_of_points(get, n2, Pc, dir, min_point);                     // (every lane: the same sums in the same order)
-    float* dist = a.dist + 2 * (size_t)m0;
-    int* order = a.order + 2 * (size_t)m0;
+    __shared__ float s_dist[4][2 * kFitLds];
+    __shared__ int s_order[4][2 * kFitLds];
+    float* dist = small ? s_dist[wv] : a.dist + 2 * (size_t)m0;
+    int* order = small ? s_order[wv] : a.order + 2 * (size_t)m0;
     for (int i = lane; i < n2; i += 64) dist[i] = fit::point_dist(get(i), min_point);
     __threadfence_block();
     for (int i = lane; i < n2; i += 64) {                                 // stable order = rank by (distance, point index)
@@ -66,12 +68,10 @@ __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
         order[r] = i;
     }
     __threadfence_block();
-    __shared__ int s_order[4][2 * kFitLds];
     __shared__ unsigned s_cam[4][kFitLds], s_cid[4][kFitLds], s_ccnt[4][kFitLds];
     __shared__ unsigned char s_open[4][kFitLds];
     const int* mh = a.member_hyp + m0;
     if (small) {
-        for (int i = lane; i < n2; i += 64) s_order[wv][i] = order[i];
         for (int i = lane; i < members; i += 64) s_cam[wv][i] = a.hyp_cam[mh[i]];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
