@@ -26,7 +26,7 @@ struct FitArgs {
     int* order;                         // 2 per member
     unsigned char* line_open;           // 1 per member
     unsigned* cam_ids; unsigned* cam_cnt;   // 1 per member
-    double* out;                        // 12 doubles... 6 per emitted segment, at most one per member
+    double* out;                        // 6 doubles per emitted segment, at most one per member
     int* out_cnt;                       // per group
 };
 
@@ -75,14 +75,43 @@ __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
         for (int i = lane; i < members; i += 64) s_cam[wv][i] = a.hyp_cam[mh[i]];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    if (lane == 0) {
-        double* out = a.out + 6 * (size_t)m0;
-        int n_out = 0;
-        auto emit = [&](la::V3 s0, la::V3 e0) { double* o = out + 6 * (size_t)n_out++; o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = e0.x; o[4] = e0.y; o[5] = e0.z; };
+    double* out = a.out + 6 * (size_t)m0;
+    int n_out = 0;
+    auto emit = [&](la::V3 s0, la::V3 e0) { double* o = out + 6 * (size_t)n_out++; o[0] = s0.x; o[1] = s0.y; o[2] = s0.z; o[3] = e0.x; o[4] = e0.y; o[5] = e0.z; };
+    bool swept = false;
+    if (small) {
+        // The sweep of fit::sweep_line with its state in registers: lane c owns camera slot c (id, open segments), the members' open
+        // flags are two wave-uniform 64-bit masks, the walk is wave-uniform.  (One lane walking LDS arrays spent 0.55 ms of the launch
+        // on dependent LDS round trips.)  Pure bookkeeping -- the same decisions as the sequential version; a cluster with more
+        // than 64 cameras takes that one.
+        unsigned my_cam = 0xffffffffu, my_cnt = 0;
+        int n_cams = 0;
+        unsigned long long open_lo = 0ull, open_hi = 0ull;
+        bool opened = false, overflow = false;
+        la::V3 start;
+        for (int k = 0; k < n2 && !overflow; ++k) {
+            const int p = s_order[wv][k], member = p >> 1;
+            const unsigned cam = s_cam[wv][member];
+            const unsigned long long hit = __ballot(lane < n_cams && my_cam == cam);
+            int ci = hit ? __ffsll((long long)hit) - 1 : n_cams;
+            if (!hit) { if (n_cams == 64) { overflow = true; break; } if (lane == n_cams) { my_cam = cam; my_cnt = 0; } ++n_cams; }
+            unsigned long long& om = member < 64 ? open_lo : open_hi;
+            const unsigned long long bit = 1ull << (member & 63);
+            if (!(om & bit)) { om |= bit; if (lane == ci) ++my_cnt; }
+            else { om &= ~bit; if (lane == ci) --my_cnt; }
+            const int n_open_cams = __popcll(__ballot(lane < n_cams && my_cnt > 0));
+            if (opened && n_open_cams < 3) { if (lane == 0) emit(start, get(p)); else ++n_out; opened = false; }
+            else if (!opened && n_open_cams >= 3) { start = get(p); opened = true; }
+        }
+        swept = !overflow;
+        if (overflow) n_out = 0;
+    }
+    if (!swept && lane == 0) {
+        n_out = 0;
         if (small) fit::sweep_line(s_order[wv], n2, get, [&](int member) { return s_cam[wv][member]; }, s_open[wv], s_cid[wv], s_ccnt[wv], emit);
         else fit::sweep_line(order, n2, get, [&](int member) { return a.hyp_cam[mh[member]]; }, a.line_open + m0, a.cam_ids + m0, a.cam_cnt + m0, emit);
-        a.out_cnt[g] = n_out;
     }
+    if (lane == 0) a.out_cnt[g] = n_out;
 }
 
 // the emitted segments of all groups, back to back
