@@ -165,6 +165,12 @@ int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edg
  * L3D_ERR_UNSUPPORTED: the diffused list is not a symmetric pattern of unique entries (never the case for the list of
  * l3d_affinity_fill) -- take l3d_replicator_dynamics_diffusion and the reference's map arithmetic instead. */
 int l3d_clustering_edges(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, l3d_edge* sorted_out);
+/* The same list grouped by CONNECTED COMPONENT of the (diffused) graph -- labels by hooking + pointer jumping on the device --, in
+ * stable ascending weight order inside every group: the merge loop of performClustering never relates nodes of different
+ * components, so the groups can be walked independently, in parallel, with the result of the sequential walk.
+ * group_start (callee-allocated, l3d_free): n_groups + 1 offsets into sorted_out. */
+int l3d_clustering_edges_grouped(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, l3d_edge* sorted_out,
+                                 int32_t** group_start, int* n_groups);
 
 /* The line fit of Line3D::processClusteredSegments (line3D.cc:1306-1597: getLineEquation3D, projectToLine) for many clusters at
  * once, on the device.  A cluster = its members' hypothesis indices in key order (camera, segment):

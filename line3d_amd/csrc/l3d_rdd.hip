@@ -154,6 +154,56 @@ __global__ void k_edge_weight_keys(const l3d_edge* __restrict__ E, int nnz, unsi
     key[k] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     val[k] = (unsigned)k;
 }
+// ---- connected components of the edge list (labels = smallest node id of the component): Felzenszwalb-Huttenlocher never looks
+// across components, so each one can be segmented on its own (l3d_clustering_edges_grouped).  Hooking by atomicMin on the roots +
+// full path compression, repeated until a hooking round changes nothing.
+__global__ void k_cc_init(int* __restrict__ comp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) comp[i] = i;
+}
+__global__ void k_cc_hook(const l3d_edge* __restrict__ E, int nnz, int* __restrict__ comp, int* __restrict__ changed)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    int a = E[k].i, b = E[k].j;
+    // roots (the labels only ever decrease: a stale read costs another round, nothing else)
+    int ra = __hip_atomic_load(comp + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (ra != a) { a = ra; ra = __hip_atomic_load(comp + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    int rb = __hip_atomic_load(comp + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (rb != b) { b = rb; rb = __hip_atomic_load(comp + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (a != b) { atomicMin(&comp[max(a, b)], min(a, b)); *changed = 1; }
+}
+__global__ void k_cc_compress(int* __restrict__ comp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = comp[i];
+    while (true) { const int q = comp[r]; if (q == r) break; r = q; }
+    comp[i] = r;
+}
+// keys of the grouped order: (component, weight key); values: the entry's position
+__global__ void k_edge_group_keys(const l3d_edge* __restrict__ E, const int* __restrict__ comp, int nnz, unsigned long long* __restrict__ key, unsigned* __restrict__ val)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    float w = E[k].w;
+    if (w == 0.0f) w = 0.0f;
+    const unsigned u = __float_as_uint(w);
+    key[k] = ((unsigned long long)(unsigned)comp[E[k].i] << 32) | ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    val[k] = (unsigned)k;
+}
+// first entry of every group in the sorted key array
+__global__ void k_group_flags(const unsigned long long* __restrict__ key, int nnz, int* __restrict__ flag)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) flag[k] = (k == 0 || (key[k] >> 32) != (key[k - 1] >> 32)) ? 1 : 0;
+}
+__global__ void k_group_starts(const int* __restrict__ flag, const int* __restrict__ rank, int nnz, int* __restrict__ start)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz && flag[k]) start[rank[k]] = k;
+}
 __global__ void k_edge_gather(const l3d_edge* __restrict__ E, const unsigned* __restrict__ order, int nnz, l3d_edge* __restrict__ out)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,10 +309,12 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
 
 // The edge list performClustering walks (clustering.cc:14-40), prepared on the device: optional performDiffusion
 // (line3D.cc:1255-1303: replicator dynamics, symmetrise by the minimum, (i,j) order) and the stable ascending weight order.
-extern "C" int l3d_clustering_edges(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out)
+static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out,
+                                 int32_t** group_start_out, int* n_groups_out)
 {
     if (!c) return L3D_ERR_INVALID;
     if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && !sorted_out)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (group_start_out) { *group_start_out = nullptr; *n_groups_out = 0; }
     if (nnz == 0) return L3D_OK;
     if (!A && c->resident_edges != nnz) return fail(c, L3D_ERR_INVALID, "no resident edge list of that size (l3d_affinity_fill)");
     if (A) for (int k = 0; k < nnz; ++k)
@@ -295,6 +347,67 @@ extern "C" int l3d_clustering_edges(l3d_ctx* c, const l3d_edge* A, int nnz, int 
         E = c->g0.as<l3d_edge>();
         lap("diffusion + symmetrise");
     }
+    if (group_start_out) {
+        // ---- grouped by connected component: labels, then ONE stable sort by (component, weight key)
+        HIPCHK(c, c->g3.reserve((size_t)n * 4 + 256));
+        int* comp = c->g3.as<int>();
+        int* changed = comp + n;                                           // (n * 4 + 256 reserved)
+        const dim3 ngrid((n + 255) / 256);
+        hipLaunchKernelGGL(k_cc_init, ngrid, block, 0, st, comp, n);
+        for (int round = 0; round < 64; ++round) {
+            HIPCHK(c, hipMemsetAsync(changed, 0, 4, st));
+            for (int r = 0; r < 3; ++r) {                                  // a few hooking rounds per look at the flag
+                hipLaunchKernelGGL(k_cc_hook, grid, block, 0, st, E, nnz, comp, changed + (r == 2 ? 0 : 1));
+                hipLaunchKernelGGL(k_cc_compress, ngrid, block, 0, st, comp, n);
+            }
+            int h_changed = 0;
+            HIPCHK(c, hipMemcpyAsync(&h_changed, changed, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (!h_changed) break;
+            if (round == 63) return fail(c, L3D_ERR_HIP, "connected components did not converge");
+        }
+        lap("connected components");
+        int shift = 1;
+        while ((1ll << shift) < (long long)n) ++shift;
+        size_t tb = 0;
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32 + shift, st));
+        size_t tb2 = 0;
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (const int*)nullptr, (int*)nullptr, nnz + 1, st));
+        tb = std::max(tb, tb2);
+        const size_t kb = ((size_t)nnz * 8 + 255) & ~(size_t)255, vb4 = ((size_t)nnz * 4 + 255 + 4) & ~(size_t)255;
+        HIPCHK(c, c->g7.reserve(2 * kb + 5 * vb4 + tb + 256));
+        unsigned char* sc = c->g7.as<unsigned char>();
+        unsigned long long* key_in = reinterpret_cast<unsigned long long*>(sc);
+        unsigned long long* key_out = reinterpret_cast<unsigned long long*>(sc + kb);
+        unsigned* val_in = reinterpret_cast<unsigned*>(sc + 2 * kb);
+        unsigned* order = reinterpret_cast<unsigned*>(sc + 2 * kb + vb4);
+        int* flag = reinterpret_cast<int*>(sc + 2 * kb + 2 * vb4);
+        int* frank = reinterpret_cast<int*>(sc + 2 * kb + 3 * vb4);
+        int* gstart = reinterpret_cast<int*>(sc + 2 * kb + 4 * vb4);
+        void* temp = sc + 2 * kb + 5 * vb4;
+        hipLaunchKernelGGL(k_edge_group_keys, grid, block, 0, st, E, comp, nnz, key_in, val_in);
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, tb, key_in, key_out, val_in, order, nnz, 0, 32 + shift, st));
+        HIPCHK(c, c->g1.reserve(ab + 64));
+        hipLaunchKernelGGL(k_edge_gather, grid, block, 0, st, E, order, nnz, c->g1.as<l3d_edge>());
+        HIPCHK(c, hipMemcpyAsync(sorted_out, c->g1.p, ab, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemsetAsync(flag + nnz, 0, 4, st));
+        hipLaunchKernelGGL(k_group_flags, grid, block, 0, st, key_out, nnz, flag);
+        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, frank, nnz + 1, st));
+        hipLaunchKernelGGL(k_group_starts, grid, block, 0, st, flag, frank, nnz, gstart);
+        int n_groups = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_groups, frank + nnz, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        int32_t* gs = static_cast<int32_t*>(malloc(((size_t)n_groups + 1) * 4));
+        if (!gs) return fail(c, L3D_ERR_NOMEM, "malloc");
+        hipError_t e1 = hipMemcpyAsync(gs, gstart, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st);
+        hipError_t e2 = hipStreamSynchronize(st);
+        hipError_t e3 = hipGetLastError();
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free(gs); return fail(c, L3D_ERR_HIP, "clustering edges: read-back failed"); }
+        gs[n_groups] = nnz;
+        *group_start_out = gs; *n_groups_out = n_groups;
+        lap("grouped weight order + download");
+        return L3D_OK;
+    }
     // stable radix sort by the weight key, then gather
     size_t temp_bytes = 0;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32, st));
@@ -314,4 +427,18 @@ extern "C" int l3d_clustering_edges(l3d_ctx* c, const l3d_edge* A, int nnz, int 
     HIPCHK(c, hipGetLastError());
     lap("weight order + download");
     return L3D_OK;
+}
+
+extern "C" int l3d_clustering_edges(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out)
+{
+    return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, sorted_out, nullptr, nullptr);
+}
+
+// The same list GROUPED BY CONNECTED COMPONENT of the (diffused) graph, ascending weight (stable) inside every group: the merge loop of
+// performClustering never relates nodes of different components, so the groups can be walked independently -- and in parallel.
+extern "C" int l3d_clustering_edges_grouped(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out,
+                                            int32_t** group_start, int* n_groups)
+{
+    if (!group_start || !n_groups) return c ? fail(c, L3D_ERR_INVALID, "bad argument") : L3D_ERR_INVALID;
+    return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, sorted_out, group_start, n_groups);
 }
