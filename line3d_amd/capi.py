@@ -249,6 +249,18 @@ class Context:
                                                 C.c_int(iters), _p(out)))
         return out
 
+    def clustering_edges_grouped(self, edges, n_nodes, perform_diffusion=False, iters=10):
+        """l3d_clustering_edges_grouped: -> (edges grouped by connected component, stable ascending weight inside a group; group_start)."""
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        out = np.zeros(len(edges), dtype=EDGE_DTYPE)
+        gs = C.POINTER(C.c_int32)()
+        ng = C.c_int(0)
+        self._chk(self.lib.l3d_clustering_edges_grouped(self.h, _p(edges), C.c_int(len(edges)), C.c_int(n_nodes), C.c_int(int(perform_diffusion)),
+                                                        C.c_int(iters), _p(out), C.byref(gs), C.byref(ng)))
+        start = np.ctypeslib.as_array(gs, (ng.value + 1,)).copy() if ng.value else np.zeros(1, np.int32)
+        self.lib.l3d_free(gs)
+        return out, start
+
     def fit_clusters(self, group_start, member_hyp, hyp, hyp_cam, Rinv, scale_inv, tneg):
         """l3d_fit_clusters: -> list (one per cluster) of lists of (start (3,), end (3,)) float64."""
         gs = np.ascontiguousarray(group_start, np.int32)

@@ -585,3 +585,50 @@ def test_fit_clusters_against_the_oracle_line_fit(gpu_ctx):
         for (gs, ge), (es, ee) in zip(got[g], exp):
             assert np.allclose(gs, es, rtol=0, atol=1e-9) and np.allclose(ge, ee, rtol=0, atol=1e-9), g
     assert len(got[5]) == 0 and n_lines > 30
+
+
+@pytest.mark.parametrize("diffusion", [False, True])
+def test_clustering_edges_grouped_by_component(gpu_ctx, oracle_lib, diffusion):
+    """l3d_clustering_edges_grouped: every group is one connected component of the list (scipy's labels), its edges in the stable
+    ascending weight order of l3d_clustering_edges, the groups ascend by their smallest node id -- and the Felzenszwalb-Huttenlocher
+    walk over the groups one after the other gives the partition of the oracle's walk over the whole sorted list."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    rng = np.random.default_rng(23)
+    n = 600
+    comp_of = rng.integers(0, 40, n)                                       # 40 planted components (some may split)
+    pairs = set()
+    while len(pairs) < 3000:
+        a = int(rng.integers(0, n))
+        same = np.nonzero(comp_of == comp_of[a])[0]
+        b = int(rng.choice(same))
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    levels = np.array([0.011, 0.25, 0.2500001, 0.5, 0.75, 1.0], np.float32)
+    A = []
+    for a, b in sorted(pairs, key=lambda p: (p[0] * 7919 + p[1] * 104729) % 1000003):
+        w = levels[rng.integers(0, len(levels))] if rng.random() < 0.5 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    A = np.array(A, dtype=op.EDGE_DTYPE)
+    flat = gpu_ctx.clustering_edges(A, n, perform_diffusion=diffusion)
+    grouped, start = gpu_ctx.clustering_edges_grouped(A, n, perform_diffusion=diffusion)
+    assert start[0] == 0 and start[-1] == len(A) and np.all(np.diff(start) > 0)
+    nc, lab = connected_components(coo_matrix((np.ones(len(A)), (A["i"], A["j"])), shape=(n, n)).tocsr(), directed=False)
+    touched = np.unique(A["i"])
+    assert len(start) - 1 == len(np.unique(lab[touched]))
+    firsts = []
+    for g in range(len(start) - 1):
+        e = grouped[start[g]:start[g + 1]]
+        assert len(np.unique(lab[e["i"]])) == 1 and np.array_equal(lab[e["i"]], lab[e["j"]])
+        members = np.nonzero(lab == lab[e["i"][0]])[0]
+        firsts.append(int(members.min()))
+        sel = flat[np.isin(flat["i"], members)]                             # the flat stable order, restricted to the component
+        assert e.tobytes() == sel.tobytes(), g
+    assert firsts == sorted(firsts)
+    labels_flat = op.clustering(oracle_lib, flat, n, 1.0)
+    labels_grp = op.clustering(oracle_lib, grouped, n, 1.0)
+    # same partition (the oracle's walk over the concatenated groups is the per-group walk)
+    def canon(l):
+        first = {}
+        return [first.setdefault(int(x), k) for k, x in enumerate(l)]
+    assert canon(labels_flat) == canon(labels_grp)
