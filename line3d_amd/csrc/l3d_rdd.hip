@@ -347,7 +347,8 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         E = c->g0.as<l3d_edge>();
         lap("diffusion + symmetrise");
     }
-    if (group_start_out) {
+    bool grouped = group_start_out != nullptr;
+    if (grouped) {
         // ---- grouped by connected component: labels, then ONE stable sort by (component, weight key)
         HIPCHK(c, c->g3.reserve((size_t)n * 4 + 256));
         int* comp = c->g3.as<int>();
@@ -364,9 +365,12 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
             HIPCHK(c, hipMemcpyAsync(&h_changed, changed, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (!h_changed) break;
-            if (round == 63) return fail(c, L3D_ERR_HIP, "connected components did not converge");
+            if (round == 63) grouped = false;                              // (not converged: one group, the plain order below)
         }
         lap("connected components");
+    }
+    if (grouped) {
+        const int* comp = c->g3.as<int>();
         int shift = 1;
         while ((1ll << shift) < (long long)n) ++shift;
         size_t tb = 0;
@@ -426,6 +430,12 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     lap("weight order + download");
+    if (group_start_out) {                                                 // (components not available: the whole list is one group)
+        int32_t* gs = static_cast<int32_t*>(malloc(2 * sizeof(int32_t)));
+        if (!gs) return fail(c, L3D_ERR_NOMEM, "malloc");
+        gs[0] = 0; gs[1] = nnz;
+        *group_start_out = gs; *n_groups_out = 1;
+    }
     return L3D_OK;
 }
 

@@ -632,3 +632,34 @@ def test_clustering_edges_grouped_by_component(gpu_ctx, oracle_lib, diffusion):
         first = {}
         return [first.setdefault(int(x), k) for k, x in enumerate(l)]
     assert canon(labels_flat) == canon(labels_grp)
+
+
+def test_clustering_edges_grouped_long_chains(gpu_ctx):
+    """Connected components on graphs that are hard for label propagation: one path of 60 000 nodes in scrambled numbering, 500
+    paths of 100 nodes, isolated pairs -- every group one component, the order inside the groups the stable weight order."""
+    rng = np.random.default_rng(31)
+    n = 60000 + 500 * 100 + 2000
+    perm = rng.permutation(n)
+    edges = []
+    chain = perm[:60000]
+    edges += [(int(chain[k]), int(chain[k + 1])) for k in range(len(chain) - 1)]
+    for p in range(500):
+        c = perm[60000 + p * 100: 60000 + (p + 1) * 100]
+        edges += [(int(c[k]), int(c[k + 1])) for k in range(99)]
+    iso = perm[60000 + 50000:]
+    edges += [(int(iso[2 * k]), int(iso[2 * k + 1])) for k in range(1000)]
+    A = []
+    for a, b in edges:
+        w = np.float32(rng.choice([0.1, 0.5, 0.9])) if rng.random() < 0.7 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    A = np.array(A, dtype=op.EDGE_DTYPE)
+    grouped, start = gpu_ctx.clustering_edges_grouped(A, n)
+    assert len(start) - 1 == 1 + 500 + 1000 and start[-1] == len(A)
+    sizes = np.diff(start)
+    assert sorted(sizes.tolist())[-1] == 2 * 59999 and sorted(sizes.tolist())[0] == 2
+    flat = gpu_ctx.clustering_edges(A, n)
+    for g in (0, 1, len(start) - 2, int(np.argmax(sizes))):
+        e = grouped[start[g]:start[g + 1]]
+        members = np.unique(np.concatenate([e["i"], e["j"]]))
+        sel = flat[np.isin(flat["i"], members)]
+        assert e.tobytes() == sel.tobytes()
