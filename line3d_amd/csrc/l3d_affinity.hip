@@ -452,6 +452,12 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     if (nh == 0) return L3D_OK;
     const int nd = in->seg_base[V];
     if (nd <= 0 || !in->hyp || !in->score || !in->hyp_dense || !in->best || !in->pot_start || !in->coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    // the view tables decide where k_aff_dview writes and how the arena is laid out: checked on the host before anything is launched
+    // (ascending from 0 up to seg_base[V] = nd, so no view's range leaves the dense ids)
+    if (in->pot_start[0] != 0 || in->coll_start[0] != 0) return fail(c, L3D_ERR_INVALID, "affinity fill: CSR tables must start at 0");
+    for (int v = 0; v < V; ++v)
+        if (in->seg_base[v + 1] < in->seg_base[v] || in->view_hyp_begin[v + 1] < in->view_hyp_begin[v]) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables must ascend");
+    if (in->seg_base[0] != 0 || in->view_hyp_begin[0] != 0 || in->view_hyp_begin[V] != nh) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables do not cover the hypotheses");
     const long long n_pot = in->pot_start[nd], n_coll = in->coll_start[nd];
     if (n_pot < 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_pot > 0 && !in->pot_tgt) || (n_coll > 0 && (!in->coll_other || !in->coll_w)))
         return fail(c, L3D_ERR_INVALID, "bad argument");
@@ -512,10 +518,6 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     for (int v = 0; v < V; ++v) maxS = std::max(maxS, in->seg_base[v + 1] - in->seg_base[v]);
     hipLaunchKernelGGL(k_aff_dview, dim3((maxS + 255) / 256, V), dim3(256), 0, st, a.seg_base, V, reinterpret_cast<int*>(base + o_dview));
     {
-        if (in->pot_start[0] != 0 || in->coll_start[0] != 0) return fail(c, L3D_ERR_INVALID, "affinity fill: CSR tables must start at 0");
-        for (int v = 0; v < V; ++v)
-            if (in->seg_base[v + 1] < in->seg_base[v] || in->view_hyp_begin[v + 1] < in->view_hyp_begin[v]) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables must ascend");
-        if (in->seg_base[0] != 0 || in->view_hyp_begin[0] != 0 || in->view_hyp_begin[V] != nh) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables do not cover the hypotheses");
         HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
         int* bad = c->g1.as<int>();
         HIPCHK(c, hipMemsetAsync(bad, 0, 4, st));

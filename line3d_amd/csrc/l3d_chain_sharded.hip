@@ -661,6 +661,16 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     for (int k = 0; k < h->n_views; ++k)
         if (!h->vd[(size_t)k].verified) HIPCHK(c, hipMemsetAsync(gathered + (size_t)k * block, 0, block, c->stream));
 
+    // the "gave up" header of the failure protocol below -- allocated BEFORE any helper thread exists: an early return with
+    // joinable threads would terminate the process and leave the peers waiting in their collectives
+    SlotHeader* abort_hdr = nullptr;
+    {
+        hipError_t ae = hipSuccess;
+        abort_hdr = static_cast<SlotHeader*>(c->pin_arena.alloc(sizeof(SlotHeader), &ae));
+        HIPCHK(c, ae);
+        memset(abort_hdr, 0, sizeof(SlotHeader));
+        abort_hdr->overflow = 4;
+    }
     std::mutex mu;
     std::condition_variable cv;
     int marked = 0;                         // views [0, marked) carry their "complete" event
@@ -708,14 +718,6 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     // overflowed -- must NOT stop calling the exchange: the other ranks keep enqueueing one collective per verified view and would
     // wait for it forever.  From the failure on it sends a header that says "gave up" for every remaining view (no kernels) and
     // keeps exchanging; k_check_slots then gives every rank the same verdict.  Only a failing exchange call itself ends the loop.
-    SlotHeader* abort_hdr = nullptr;
-    {
-        hipError_t ae = hipSuccess;
-        abort_hdr = static_cast<SlotHeader*>(c->pin_arena.alloc(sizeof(SlotHeader), &ae));
-        HIPCHK(c, ae);
-        memset(abort_hdr, 0, sizeof(SlotHeader));
-        abort_hdr->overflow = 4;
-    }
     bool draining = false, exchange_broken = false;
     for (int k = 0; k < h->n_views; ++k) {
         if (!draining) {

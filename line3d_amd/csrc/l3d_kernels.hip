@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
     __shared__ unsigned short s_qa[4][kPairQueue];
     __shared__ unsigned short s_qb[4][kPairQueue];
     __shared__ unsigned long long s_bits[kSrcPerBlock * 4];
-    __shared__ int s_blk[32];            // block sums of this workgroup's rows (fused row starts)
+    __shared__ int s_blk[kSrcPerBlock * 96 / 256 + 2];   // block sums of this workgroup's rows (fused row starts: N <= 96, rows N apart)
 
     const int j = blockIdx.z;
     const int cam = a.tbm[j];
@@ -364,15 +364,15 @@ __global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
             // first, one global atomic per block and workgroup (one per row made every workgroup of the launch queue up on the
             // same ~100 counters: k_pair_mask 6.8 -> 18.7 ms)
             const int b0 = (y0 * a.N + cam) >> 8;
-            const int nb = (((y0 + ny - 1) * a.N + cam) >> 8) - b0 + 1;        // <= 64 * N / 256 + 2 <= 18
-            if (lane < nb) s_blk[lane] = 0;
+            const int nb = (((y0 + ny - 1) * a.N + cam) >> 8) - b0 + 1;        // <= kSrcPerBlock * N / 256 + 2
+            for (int l = lane; l < nb; l += 64) s_blk[l] = 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (tid < ny) {
-                const int cnt = __popcll(s_bits[tid * 4]) + __popcll(s_bits[tid * 4 + 1]) + __popcll(s_bits[tid * 4 + 2]) + __popcll(s_bits[tid * 4 + 3]);
-                if (cnt) atomicAdd(&s_blk[(((y0 + tid) * a.N + cam) >> 8) - b0], cnt);
+            for (int r = lane; r < ny; r += 64) {                             // (every row of the workgroup, whatever kSrcPerBlock is)
+                const int cnt = __popcll(s_bits[r * 4]) + __popcll(s_bits[r * 4 + 1]) + __popcll(s_bits[r * 4 + 2]) + __popcll(s_bits[r * 4 + 3]);
+                if (cnt) atomicAdd(&s_blk[(((y0 + r) * a.N + cam) >> 8) - b0], cnt);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (lane < nb) { const int v = s_blk[lane]; if (v) atomicAdd(&a.rowblk[b0 + lane], v); }
+            for (int l = lane; l < nb; l += 64) { const int v = s_blk[l]; if (v) atomicAdd(&a.rowblk[b0 + l], v); }
         }
     }
     if (a.dbg) {

@@ -9,6 +9,7 @@ namespace l3d {
 #ifndef L3D_SRC_PER_BLOCK
 #define L3D_SRC_PER_BLOCK 64
 #endif
+static_assert(L3D_SRC_PER_BLOCK >= 1 && L3D_SRC_PER_BLOCK <= 256, "k_pair_mask: ring keys hold the source row in 8 bits, one thread stages one source segment");
 constexpr int kSrcPerBlock = L3D_SRC_PER_BLOCK;    // source segments walked by one k_pair_mask workgroup (A/B, ms per config-2 pass: 32 -> +0.3, 48 -> +0.9, 64 best, 96 -> +0.4, 128 -> +0.8)
 constexpr int kMaxW64 = 256;        // bit-row words per camera: up to 16384 segments per view
 constexpr int kVerifyTile = 256;

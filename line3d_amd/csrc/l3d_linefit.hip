@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_fit_clusters(FitArgs a)
     __shared__ int s_order[4][2 * kFitLds];
     float* dist = small ? s_dist[wv] : a.dist + 2 * (size_t)m0;
     int* order = small ? s_order[wv] : a.order + 2 * (size_t)m0;
-    for (int i = lane; i < n2; i += 64) dist[i] = fit::point_dist(get(i), min_point);
+    for (int i = lane; i < n2; i += 64) { dist[i] = fit::point_dist(get(i), min_point); order[i] = i; }   // (order: every slot valid even when NaN distances make ranks collide)
     __threadfence_block();
     for (int i = lane; i < n2; i += 64) {                                 // stable order = rank by (distance, point index)
         const float d = dist[i];
@@ -188,7 +188,7 @@ extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_gr
     double* packed_host = static_cast<double*>(malloc(((size_t)total * 6 + 1) * 8));
     if (!packed_host) { free(cnt); return fail(c, L3D_ERR_NOMEM, "malloc"); }
     if (total > 0) {
-        HIPCHK(c, c->g2.reserve((size_t)total * 48 + 64));
+        if (c->g2.reserve((size_t)total * 48 + 64) != hipSuccess) { free(cnt); free(packed_host); return fail(c, L3D_ERR_NOMEM, "line fit: device buffer for the packed segments"); }
         hipLaunchKernelGGL(k_fit_gather, dim3((n_groups + 3) / 4), dim3(256), 0, st, a.group_start, out_off, a.out, n_groups, c->g2.as<double>());
         e1 = hipMemcpyAsync(packed_host, c->g2.p, (size_t)total * 48, hipMemcpyDeviceToHost, st);
         e2 = hipStreamSynchronize(st);

@@ -32,6 +32,8 @@
 #include <cstring>
 #include <algorithm>
 #include <fstream>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -100,10 +102,25 @@ int l3d_segment_cache_filename(uint32_t image_id, unsigned int width, unsigned i
 }
 
 // serializeFromFile<L3DSegments> (serialization.h:58-69)
+static int segment_cache_read_into(const char* path, l3d_segment_cache* s, l3d_segment_cache** out);
 int l3d_segment_cache_read(const char* path, l3d_segment_cache** out)
 {
     if (!out) return L3D_ERR_INVALID;
-    l3d_segment_cache* s = new l3d_segment_cache();
+    *out = nullptr;
+    l3d_segment_cache* s = new (std::nothrow) l3d_segment_cache();
+    if (!s) return L3D_ERR_NOMEM;
+    // no exception leaves an extern "C" function: a file whose size (or whose counts) cannot be allocated is refused with a message
+    try {
+        return segment_cache_read_into(path, s, out);
+    } catch (const std::exception&) {           // (std::bad_alloc / std::length_error of a resize)
+        s->segs.clear(); s->ci.clear(); s->cj.clear(); s->cw.clear();
+        try { s->err = "segment cache: out of memory while reading the file"; } catch (...) {}
+        *out = s;
+        return L3D_ERR_NOMEM;
+    }
+}
+static int segment_cache_read_into(const char* path, l3d_segment_cache* s, l3d_segment_cache** out)
+{
     if (!path) return fail(s, "null path", out);
     std::vector<unsigned char> bytes;
     {

@@ -80,3 +80,69 @@ def write_bundler(path, scene, points):
             f.write("%.17g %.17g %.17g\n" % tuple(t))
         for X, obs in points:
             f.write("%.17g %.17g %.17g\n128 128 128\n%d " % (X[0], X[1], X[2], len(obs)) + " ".join("%d %d %.3f %.3f" % o for o in obs) + "\n")
+
+
+# ---- oracle on a slice of one full-size view (mid-chain: with the reverse matches its earlier neighbours handed it) -------
+def digest_lists(lists):
+    import hashlib
+    h = hashlib.sha256()
+    for vid in sorted(lists):
+        h.update(lists[vid][0].tobytes())
+        h.update(np.float32(lists[vid][1]).tobytes())
+    return h.hexdigest()
+
+
+def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None):
+    """compute_pairwise_matches of the oracle for source segments [seg_lo, seg_hi) of view `vid` in the state matchViews has
+    when it reaches that view (line3D.cc:620-648): matched_ after views 0..vid-1 (:875-881) and, as the existing matches
+    (view.cc:200-224), the kept matches of the earlier views towards `vid` taken from `lists` (view id -> (matches, median);
+    view ids are 0..V-1 in processing order).  The range is cut into one piece per host thread (the C oracle releases the
+    GIL; a source segment's verification only reads that segment's candidates, so the pieces concatenate)."""
+    import os
+    import threading
+    import l3d_oracle_pipeline as op
+    o = op.OracleLine3D(matching_neighbors=N, use_collinearity=False)
+    for v in scene.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    o.computation = True
+    o.matched, o.potential = {}, {}
+    o.find_visual_neighbors()
+    o.transform_geometry()
+    for n in o.visual_neighbors[vid]:
+        o._fundamental(vid, n)
+    for a in range(vid):
+        for nb in o.visual_neighbors[a]:
+            o.matched.setdefault(a, {})[nb] = True
+            if a in o.visual_neighbors.get(nb, []):
+                o.matched.setdefault(nb, {})[a] = True
+    mv = o.marshal_view(vid)
+    ex = []
+    for a in range(vid):
+        m, _ = lists[a]
+        sel = m[m["camID2"] == vid]
+        if len(sel) and a in mv["g2l"]:
+            r = np.zeros(len(sel), dtype=op.MATCH_DTYPE)
+            r["segID1"], r["segID2"], r["camID2"] = sel["segID2"], sel["segID1"], mv["g2l"][a]
+            r["depths"] = sel["depths"][:, [2, 3, 0, 1]]
+            ex.append(r)
+    existing = np.concatenate(ex) if ex else np.zeros(0, dtype=op.MATCH_DTYPE)
+    if threads is None:
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        threads = max(1, min(threads, 64, seg_hi - seg_lo))
+    cuts = [seg_lo + (seg_hi - seg_lo) * i // threads for i in range(threads + 1)]
+    parts = [None] * threads
+
+    def work(i):
+        parts[i] = op.compute_pairwise_matches(
+            o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
+            mv["centers"], mv["P"], mv["tbm"], existing, mv["l2g"], mv["k_upper"], mv["k_lower"], 3.5, 10.0, mv["spatial_k"],
+            seg_range=(cuts[i], cuts[i + 1]))[0]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return np.concatenate(parts), mv, existing

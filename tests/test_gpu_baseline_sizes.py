@@ -1,0 +1,229 @@
+"""Parity at the literal sizes BASELINE.json states (the workload bench.py times and the shapes of configs[2] and configs[4]).
+
+The oracle needs ~25 s for one whole 2000-segment view, so whole scenes are covered by properties -- every matching path
+(resident chain, per-view seam calls, native sharded run, virtual ranks) gives the same bytes, a second pass is idempotent,
+the conservative stage-1 filters and the depth-window search change nothing against the exact sequence / the all-pairs loop
+on EVERY pair of the scene -- and the oracle pins slices of early, mid-chain, late and early-return views bit for bit
+(reference: line3D.cc:620-648, cudawrapper.cu:858-1128)."""
+import numpy as np
+import pytest
+
+from helpers import digest_lists, oracle_view_slice
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(scene, N, sync=False, pretest=None, verify_mode=None, native=False, S=2000):
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    l = Line3D("", matchingNeighbors=N)
+    l.keep_view_matches(True)
+    l.set_sync_matching(sync)
+    if pretest is not None:
+        l.context().set_pair_pretest(pretest)
+    if verify_mode is not None:
+        l.context().set_verify_mode(verify_mode)
+    load_scene(l, scene)
+    l.prepare()
+    if native:
+        l3dist.match_views_chain_native(l, 0, 1, None, commit=True, n_segments=S, n_neighbors=N)
+    else:
+        l.match_views()
+    lists = {v["id"]: l.view_matches(v["id"]) for v in scene.views}
+    return l, lists
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[1] / configs[3]: 64 views x 2000 segments x 12 neighbours, the scene bench.py times (seed 20260)
+# ---------------------------------------------------------------------------------------------------------------------
+V2, S2, N2 = 64, 2000, 12
+
+
+@pytest.fixture(scope="module")
+def cfg2_scene():
+    from line3d_amd.synth import make_scene
+    return make_scene(V2, S2, N2, seed=20260)
+
+
+@pytest.fixture(scope="module")
+def cfg2_chain(cfg2_scene):
+    l, lists = _run(cfg2_scene, N2)
+    yield l, lists
+    l.close()
+
+
+def test_config2_all_paths_agree_and_a_second_pass_is_idempotent(cfg2_scene, cfg2_chain):
+    """63 chained views: the stage-1 ring (15 slots) wraps four times, the kept arena holds every view's list."""
+    l, lists = cfg2_chain
+    ref = digest_lists(lists)
+    assert sum(len(m) for m, _ in lists.values()) > 1500000
+    assert l.stats()["pairs"] == pytest.approx(1.452e9, rel=0.01)         # the workload of the bench line
+    l.match_views()
+    assert digest_lists({v["id"]: l.view_matches(v["id"]) for v in cfg2_scene.views}) == ref, "second pass"
+    for name, kw in (("per-view seam calls", dict(sync=True)), ("native sharded run, world 1", dict(native=True))):
+        l2, lists2 = _run(cfg2_scene, N2, **kw)
+        l2.close()
+        assert digest_lists(lists2) == ref, name
+
+
+def test_config2_filters_and_window_search_change_nothing_on_the_whole_scene(cfg2_scene, cfg2_chain):
+    """1.45e9 segment pairs through the conservative stage-1 filters (margins 1e-4 / 1e-2, l3d_kernels.hip) against the
+    exact sequence alone, and every candidate through the depth-window search against the all-pairs loop of
+    K_verify_matches (cudawrapper.cu:614-714): identical kept lists."""
+    _l, lists = cfg2_chain
+    ref = digest_lists(lists)
+    for name, kw in (("no stage-1 filters", dict(pretest=0)), ("wedge test only", dict(pretest=1)), ("overlap bound only", dict(pretest=2)),
+                     ("all-pairs verification", dict(verify_mode=1))):
+        l2, lists2 = _run(cfg2_scene, N2, **kw)
+        l2.close()
+        assert digest_lists(lists2) == ref, name
+
+
+@pytest.mark.parametrize("vid,lo,hi", [(7, 0, 256), (20, 400, 656), (33, 900, 1156), (48, 1300, 1556), (62, 1744, 2000), (63, 0, 2000)])
+def test_config2_view_slices_against_the_oracle(cfg2_scene, cfg2_chain, vid, lo, hi):
+    """256 source segments of an early view, a mid-chain view (6 cameras to match, 6 sources of reverse matches), the last
+    computed view (1 camera to match, 11 sources) -- and the whole last view, which has nothing left to match: the
+    reference returns its existing list untouched, LOCAL camera ids, confidence 0 (cudawrapper.cu:877-878)."""
+    _l, lists = cfg2_chain
+    exp, mv, existing = oracle_view_slice(cfg2_scene, lists, vid, lo, hi, N2)
+    got = lists[vid][0]
+    got = got[(got["segID1"] >= lo) & (got["segID1"] < hi)]
+    if vid == 63:
+        assert len(mv["tbm"]) == 0 and len(existing) > 10000
+    else:
+        assert len(mv["tbm"]) == min(6, 63 - vid) and (vid < 12 or len(existing) > 10000)
+    assert len(exp) > 500 and got.tobytes() == exp.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[2]: 512 views x 2000 x 12, sharded over 8 ranks -- on one GPU: the unsharded chain against rank 0's committed lists
+# of a recorded 8-virtual-rank run replayed through the native loop
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config3_512_views_chain_equals_eight_virtual_ranks():
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from line3d_amd.distributed import default_slot_records
+    V, S, N, W = 512, 2000, 12, 8
+    scene = make_scene(V, S, N, seed=20263)
+    l, lists = _run(scene, N)
+    ref = digest_lists(lists)
+    kept = sum(len(m) for m, _ in lists.values())
+    assert kept > 12000000
+    l.match_views()
+    assert digest_lists({v["id"]: l.view_matches(v["id"]) for v in scene.views}) == ref, "second pass"
+    l.close()
+    del lists
+    slot = default_slot_records(S, N, W)
+    dev = torch.device("cuda", 0)
+    ls = []
+    for r in range(W):
+        lr = Line3D("", matchingNeighbors=N, useCollinearity=False)
+        lr.keep_view_matches(r == 0)
+        load_scene(lr, scene)
+        lr.prepare()
+        ls.append(lr)
+    n_views, slot_bytes = [lr.shard_open(r, W, slot) for r, lr in enumerate(ls)][0]
+    assert n_views == V
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, lr in enumerate(ls):
+            lr.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for lr in ls:
+            lr.shard_mark(k)
+    for lr in ls:
+        lr.shard_close(False)
+    del send
+    # every rank replays its part through the native loop (l3d_shard_chain_run) against the recorded blocks; rank 0 commits
+    for r in (W - 1, 3, 0):
+        ls[r].shard_run(r, W, slot, "replay", gathered.data_ptr(), commit=(r == 0))
+        torch.cuda.synchronize()
+    assert digest_lists({v["id"]: ls[0].view_matches(v["id"]) for v in scene.views}) == ref
+    for lr in ls:
+        lr.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[4] per-view shape: 4000 segments x 24 neighbours.  26 views: view 13 has 12 cameras to match and 12 sources of
+# reverse matches.  The scene keeps ~10^3 matches per segment (a quarter of the candidates), so lists are digested view by
+# view and only what the oracle slice needs is kept.
+# ---------------------------------------------------------------------------------------------------------------------
+V5, S5, N5, VID5 = 26, 4000, 24, 13
+
+
+def _digest_stream(l, scene, keep_towards=None):
+    import hashlib
+    h = hashlib.sha256()
+    kept, towards, own = 0, {}, None
+    for v in scene.views:
+        m, med = l.view_matches(v["id"])
+        h.update(m.tobytes())
+        h.update(np.float32(med).tobytes())
+        kept += len(m)
+        if keep_towards is not None and v["id"] < keep_towards:
+            towards[v["id"]] = (m[m["camID2"] == keep_towards].copy(), med)
+        if keep_towards is not None and v["id"] == keep_towards:
+            own = m
+    return h.hexdigest(), kept, towards, own
+
+
+def _run5(scene, **kw):
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    l = Line3D("", matchingNeighbors=N5, useCollinearity=False)
+    l.keep_view_matches(True)
+    l.set_sync_matching(bool(kw.get("sync")))
+    if kw.get("pretest") is not None:
+        l.context().set_pair_pretest(kw["pretest"])
+    load_scene(l, scene)
+    l.prepare()
+    if kw.get("native"):
+        l3dist.match_views_chain_native(l, 0, 1, None, commit=True, n_segments=S5, n_neighbors=N5)
+    else:
+        l.match_views()
+    return l
+
+
+@pytest.fixture(scope="module")
+def cfg5_scene():
+    from line3d_amd.synth import make_scene
+    return make_scene(V5, S5, N5, seed=20265)
+
+
+@pytest.fixture(scope="module")
+def cfg5_chain(cfg5_scene):
+    l = _run5(cfg5_scene)
+    out = _digest_stream(l, cfg5_scene, keep_towards=VID5)
+    yield l, out
+    l.close()
+
+
+def test_config5_shape_paths_agree(cfg5_scene, cfg5_chain):
+    l, (ref, kept, _t, _o) = cfg5_chain
+    assert kept > 10000000
+    l.match_views()
+    assert _digest_stream(l, cfg5_scene)[0] == ref, "second pass"
+    for name, kw in (("per-view seam calls", dict(sync=True)), ("native sharded run, world 1", dict(native=True)),
+                     ("no stage-1 filters", dict(pretest=0))):
+        l2 = _run5(cfg5_scene, **kw)
+        d = _digest_stream(l2, cfg5_scene)[0]
+        l2.close()
+        assert d == ref, name
+
+
+def test_config5_shape_mid_chain_slice_against_the_oracle(cfg5_scene, cfg5_chain):
+    """128 source segments of view 13 (12 cameras to match, 12 sources): several thousand candidates per segment, the
+    all-pairs loop of the oracle runs ~2e9 iterations (about half a minute on 16 host threads)."""
+    _l, (_ref, _kept, towards, own) = cfg5_chain
+    lo, hi = 2000, 2128
+    exp, mv, existing = oracle_view_slice(cfg5_scene, towards, VID5, lo, hi, N5)
+    assert len(mv["tbm"]) == 12 and len(mv["l2g"]) == 24 and len(existing) > 100000
+    got = own[(own["segID1"] >= lo) & (own["segID1"] < hi)]
+    assert len(exp) > 500 and got.tobytes() == exp.tobytes()
