@@ -741,8 +741,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         }
         if (verified) {
             const double te1 = now_s();
-            if (exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream)) {
-                if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed"; }
+            if (const int exr = exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream)) {
+                if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed (code " + std::to_string(exr) + ", last HIP error: " + hipGetErrorString(hipGetLastError()) + ")"; }
                 exchange_broken = true;
                 break;
             }
@@ -808,13 +808,15 @@ int l3d_exchange_rccl(void* user, int, const void* send_slot, void* recv_block, 
 int l3d_exchange_local(void*, int, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream)
 {
     if (world != 1) return 1;
-    return hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+    return (int)hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 // replay of a recorded run (user = device address of its gathered blocks): one rank of a world-W job measured on one GPU
 int l3d_exchange_replay(void* user, int view, const void*, void* recv_block, size_t slot_bytes, int world, void* stream)
 {
     const size_t block = slot_bytes * (size_t)world;
-    return hipMemcpyAsync(recv_block, static_cast<const unsigned char*>(user) + (size_t)view * block, block, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess;
+    const hipError_t e = hipMemcpyAsync(recv_block, static_cast<const unsigned char*>(user) + (size_t)view * block, block, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) fprintf(stderr, "[l3d exchange_replay] view %d: hipMemcpyAsync(dst %p, src %p + %zu, %zu bytes): %s\n", view, recv_block, user, (size_t)view * block, block, hipGetErrorString(e));
+    return (int)e;
 }
 const void* l3d_shard_chain_gathered(l3d_shard_chain* h) { return h ? h->c->ch_gathered.p : nullptr; }
 int l3d_shard_chain_info(l3d_shard_chain* h, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept)

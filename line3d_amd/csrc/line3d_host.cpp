@@ -190,6 +190,8 @@ struct l3d_line3d {
     void* plan_cache = nullptr;                                // ChainPlan of the current set of views (the schedule is static)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
+    int shard_world_seen = 0, shard_slot_records_seen = 0;     // sharded native run: slot / candidate sizes a capacity verdict made necessary
+    size_t shard_cand_cap_seen = 0;
 
     // final hypotheses
     std::vector<Hyp> hyps;                                     // best_match_ in key order
@@ -2178,6 +2180,9 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
     // capacities and runs again -- the bookkeeping of the failed attempt is dropped by the reopen (match_begin).
     size_t cand_cap_next = 0;
     int rc = L3D_OK;
+    // sizes a capacity verdict of an earlier pass of this job taught us (identical on every rank: the verdict is shared)
+    if (h->shard_world_seen == world) { slot_records = std::max(slot_records, h->shard_slot_records_seen); cand_cap_next = h->shard_cand_cap_seen; }
+    else { h->shard_world_seen = world; h->shard_slot_records_seen = 0; h->shard_cand_cap_seen = 0; }
     for (int attempt = 0; attempt < 4; ++attempt) {
         int n_views = 0;
         size_t slot_bytes = 0;
@@ -2201,8 +2206,9 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         if (rc == L3D_OK) return rc2;
         h->fail(rc, msg);
         if (rc != L3D_ERR_NOMEM || (bits & 4 && !(bits & 3)) || !(bits & 3)) return rc;      // not a capacity verdict: nothing a retry would change
-        if (bits & 1) cand_cap_next = std::max(cand_cap * 2, (size_t)max_cand + (size_t)max_cand / 4 + 65536);
-        if (bits & 2) slot_records = std::max(slot_records * 2, max_kept + max_kept / 4 + 1024);
+        if ((bits & 2) && exchange == l3d_exchange_replay) return rc;                        // recorded blocks have the recorded slot size: the caller records again with more room
+        if (bits & 1) cand_cap_next = h->shard_cand_cap_seen = std::max(cand_cap * 2, (size_t)max_cand + (size_t)max_cand / 4 + 65536);
+        if (bits & 2) slot_records = h->shard_slot_records_seen = std::max(slot_records * 2, max_kept + max_kept / 4 + 1024);
     }
     return rc;
 }

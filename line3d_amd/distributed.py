@@ -73,9 +73,12 @@ def match_views_sharded(l3d, rank: int, world: int, dist, compute=None, device=N
 
 
 def default_slot_records(n_segments: int, n_neighbors: int, world: int) -> int:
-    """Kept matches one rank may produce for one view: about 1.5 per (source segment, neighbour) on the synthetic
-    scenes; 6x that leaves ample room (an overflow is reported by the fetch, never silent)."""
-    return max(1024, (6 * n_segments * n_neighbors) // (2 * world) + 1024)
+    """Kept matches one rank may produce for one view.  The synthetic scenes keep 1.7 (64 views) to 3.5 (512 views: the later
+    turns of the helix keep more) matches per (source segment, neighbour) on average, the densest view of the 512-view scene
+    5.8, and a rank's segment range up to 6.5 (19 344 records at 8 ranks): 10 per (segment, neighbour) leaves room.  An
+    overflow is a verdict every rank reads out of the slot headers, never silent: the native run reopens with larger slots
+    and remembers the size for later passes."""
+    return max(1024, (10 * n_segments * n_neighbors) // world + 1024)
 
 
 def match_views_chain_sharded(l3d, rank: int, world: int, dist, commit: bool = True, slot_records: int | None = None,

@@ -1,0 +1,186 @@
+"""Inputs for the device-function pins (tests/test_oracle_pins.py, tests/golden/make_golden_devfn.py): the same seeded random
+and adversarial cases are fired through the reference's own functions (oracle/_ref/libdevfn_ref.so, prefix l3dref_) and the
+oracle's restatements (oracle/libl3d_oracle.so, prefix l3do_devfn_).  Points are float32 xyz triples."""
+import ctypes as C
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _pts2d(rng, n, scale=2000.0):
+    p = np.empty((n, 3), F32)
+    p[:, :2] = (rng.random((n, 2)) * scale - scale * 0.1).astype(F32)
+    p[:, 2] = 1.0
+    return p
+
+
+def overlap_cases(rng, n):
+    """Four points per case (src_p1, src_p2, q1, q2) as D_segment_overlap_2D meets them -- the q's are intersections of epipolar
+    lines with the source line, i.e. (nearly) collinear with it -- plus the hard spots: exactly collinear lattice points, points
+    ON endpoints (dot = 0 against EPS_G), zero-length and sub-pixel segments (the `< 1.0f` tests), reversed and nested
+    intervals, huge and tiny coordinates."""
+    out = [np.empty((n, 3), F32) for _ in range(4)]
+    kinds = rng.integers(0, 8, n)
+    o = (rng.random((n, 2)) * 1500).astype(F32)
+    ang = rng.random(n) * 2 * np.pi
+    u = np.stack([np.cos(ang), np.sin(ang)], 1)
+    lattice_dirs = np.array([[1, 0], [0, 1], [1, 1], [1, -1], [3, 4], [-5, 12], [2, 1], [7, -24]], np.float64)
+    specials = np.array([0.0, 1.0, 0.5, 0.25, 2.0, -1.0, 1.0 - 2.0 ** -24, 1.0 + 2.0 ** -23, 0.999999, 1.000001, 3.0, 100.0])
+    for i in range(n):
+        k = kinds[i]
+        if k <= 1:        # generic: random parameters along a random line, small perpendicular noise (float rounding scale)
+            t = rng.normal(0, 80, 4)
+            noise = rng.normal(0, 1e-3 if k == 0 else 0.0, (4, 2))
+            P = o[i] + t[:, None] * u[i] + noise
+        elif k == 2:      # integer lattice, exactly collinear: dots and lengths are exact in float
+            d = lattice_dirs[rng.integers(0, len(lattice_dirs))]
+            t = rng.integers(-40, 41, 4).astype(np.float64)
+            P = np.round(o[i]) + t[:, None] * d
+        elif k == 3:      # shared endpoints / duplicates
+            d = lattice_dirs[rng.integers(0, len(lattice_dirs))]
+            t = rng.integers(-10, 11, 2).astype(np.float64)
+            t = np.array([t[0], t[1], t[rng.integers(0, 2)], rng.integers(-10, 11)], np.float64)
+            if rng.random() < 0.3:
+                t[3] = t[rng.integers(0, 3)]
+            P = np.round(o[i]) + t[:, None] * d
+        elif k == 4:      # lengths around the 1-pixel threshold, axis aligned (exact) or not
+            L = specials[rng.integers(0, len(specials), 2)]
+            a = rng.integers(-5, 6, 2).astype(np.float64)
+            t = np.array([a[0], a[0] + L[0], a[1], a[1] + L[1]])
+            d = np.array([1.0, 0.0]) if rng.random() < 0.5 else u[i]
+            P = np.round(o[i]) + t[:, None] * d
+        elif k == 5:      # nested / containing / disjoint intervals with a random scale
+            s = 10.0 ** rng.uniform(-2, 4)
+            t = np.sort(rng.random(4)) * s
+            perm = [[0, 3, 1, 2], [1, 2, 0, 3], [0, 1, 2, 3], [0, 2, 1, 3], [3, 0, 2, 1], [2, 1, 3, 0]][rng.integers(0, 6)]
+            P = o[i] + t[perm][:, None] * u[i]
+        elif k == 6:      # not collinear at all (the function is still deterministic there)
+            P = rng.random((4, 2)) * 1000
+        else:             # degenerate / extreme magnitudes
+            s = 10.0 ** rng.uniform(-20, 15)
+            P = (rng.random((4, 2)) - 0.5) * s
+            if rng.random() < 0.3:
+                P[:] = P[0]
+        for j in range(4):
+            out[j][i, :2] = P[j].astype(F32)
+            out[j][i, 2] = 1.0
+    return out
+
+
+def point_on_segment_cases(rng, n):
+    sp1, sp2, q1, _ = overlap_cases(rng, n)
+    return sp1, sp2, q1
+
+
+def lines_and_points(rng, n):
+    line = rng.normal(0, 1, (n, 3)).astype(F32)
+    line[:, 2] *= 500
+    k = rng.integers(0, 10, n)
+    line[k == 0, 0] = 0.0                      # horizontal / vertical / degenerate lines
+    line[k == 1, 1] = 0.0
+    line[k == 2, :2] = 0.0                     # 0/0 and x/0: NaN / inf must come out alike
+    line[k == 3] *= F32(1e-20)
+    p = _pts2d(rng, n)
+    return line, p
+
+
+def hom_points(rng, n):
+    p = rng.normal(0, 100, (n, 3)).astype(F32)
+    k = rng.integers(0, 8, n)
+    p[k == 0, 2] = 0.0
+    p[k == 1, 2] = F32(1e-12)                  # |z| > EPS_G is false at exactly EPS_G (as float)
+    p[k == 2, 2] = np.nextafter(F32(1e-12), F32(1))
+    p[k == 3, 2] = F32(-1e-12)
+    p[k == 4, 2] = F32(1e-30)
+    return p
+
+
+def points3d(rng, n, scale=3.0):
+    return rng.normal(0, scale, (n, 3)).astype(F32)
+
+
+def angle_cases(rng, n):
+    P1, P2, Q1, Q2 = (points3d(rng, n) for _ in range(4))
+    k = rng.integers(0, 8, n)
+    par = k == 0                               # parallel / antiparallel / nearly parallel: dot at and around +-1 (the clamp)
+    s = rng.choice([1.0, -1.0, 2.5, -0.3], n).astype(F32)
+    Q2[par] = Q1[par] + (P2[par] - P1[par]) * s[par, None]
+    near = k == 1
+    Q2[near] = Q1[near] + (P2[near] - P1[near]) + rng.normal(0, 1e-4, (int(near.sum()), 3)).astype(F32)
+    perp = k == 2                              # right angles: the 90-degree fold
+    d = P2[perp] - P1[perp]
+    r = rng.normal(0, 1, d.shape).astype(F32)
+    Q2[perp] = Q1[perp] + np.cross(d, r).astype(F32)
+    zero = k == 3                              # zero-length direction: NaN from normalize
+    Q2[zero] = Q1[zero]
+    return P1, P2, Q1, Q2
+
+
+def matrices(rng, n, stride):
+    M = np.zeros((n, 3, stride), F32)
+    M[:, :, :3] = rng.normal(0, 1, (n, 3, 3)).astype(F32)
+    M[:, :, 3:] = F32(7777.0)                  # padding must never be read
+    return M
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_inputs(seed, n):
+    """The seeded cases of every pinned function: {name: (inputs tuple, output dtype/shape, extra int args)}."""
+    rng = np.random.default_rng(seed)
+    c = {}
+    c["segment_overlap_2D"] = (overlap_cases(rng, n), (np.float32, (n,)), "segment_overlap_2D", None)
+    c["point_on_segment_2D"] = (point_on_segment_cases(rng, n), (np.int32, (n,)), "point_on_segment_2D", None)
+    p1, p2, _, _ = overlap_cases(rng, n)
+    c["segment_length_2D"] = ((p1, p2), (F32, (n,)), "segment_length_2D", None)
+    c["distance_p2l_2D"] = (lines_and_points(rng, n), (F32, (n,)), "distance_p2l_2D", None)
+    c["angle_between_lines_deg_3D"] = (angle_cases(rng, n), (F32, (n,)), "angle_between_lines_deg_3D", None)
+    c["normalize_hom_coords_2D"] = ((hom_points(rng, n),), (F32, (n, 3)), "normalize_hom_coords_2D", None)
+    for stride in (3, 8):                      # the reference's host stride for RtKinv is 8 floats
+        p = _pts2d(rng, n)
+        M = matrices(rng, n, stride)
+        c["get_ray_src_stride%d" % stride] = ((p, M), (F32, (n, 3)), "get_ray_src", stride)
+        Cc, depth = points3d(rng, n), (rng.random(n) * 10).astype(F32)
+        c["unproject_point_src_stride%d" % stride] = ((p, Cc, depth, M), (F32, (n, 3)), "unproject_point_src", stride)
+    v = points3d(rng, n)
+    v[rng.integers(0, 10, n) == 0] = 0.0
+    c["normalize3"] = ((v,), (F32, (n, 3)), "normalize3", None)
+    c["cross3"] = ((points3d(rng, n), points3d(rng, n)), (F32, (n, 3)), "cross3", None)
+    c["length3"] = ((points3d(rng, n, 1e3),), (F32, (n,)), "length3", None)
+    c["dot3"] = ((points3d(rng, n), points3d(rng, n)), (F32, (n,)), "dot3", None)
+    return {k: (tuple(np.ascontiguousarray(a) for a in ins), o, fn, st) for k, (ins, o, fn, st) in c.items()}
+
+
+def run(lib, prefix, cases):
+    """Every pinned function of `lib` on `cases` (make_inputs).  Returns {name: (inputs tuple, output)}."""
+    res = {}
+    for name, (ins, (dt, shape), fname, stride) in cases.items():
+        fn = getattr(lib, prefix + fname)
+        fn.restype = None
+        out = np.zeros(shape, dt)
+        extra = () if stride is None else (C.c_int(stride),)
+        fn(C.c_int(shape[0]), *[_fp(a) for a in ins], *extra, _fp(out))
+        res[name] = (ins, out)
+    consts = []
+    for nm in ("eps_g", "min_overlap_lower", "min_overlap_upper", "collin_aff_t"):
+        fn = getattr(lib, prefix + nm)
+        fn.restype = C.c_float
+        consts.append(fn())
+    res["constants"] = ((), np.asarray(consts, F32))
+    return res
+
+
+def run_all(lib, prefix, seed, n):
+    return run(lib, prefix, make_inputs(seed, n))
+
+
+def same_bits(a, b):
+    """bit-equal, NaNs of any payload counted equal (0/0 has no defined payload across compilers)"""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.dtype.kind != "f":
+        return np.array_equal(a, b)
+    ai, bi = a.view(np.uint32), b.view(np.uint32)
+    return bool(np.all((ai == bi) | (np.isnan(a) & np.isnan(b))))

@@ -216,3 +216,58 @@ def test_txt_result_format_round_trip(tmp_path):
     op.save_result_stl(o, stl)
     lines = open(stl).read().splitlines()
     assert lines[0] == "solid lineModel" and lines[3] == "   vertex 1.234567e-01 -2.000000e+00 3.000000e-07" and lines[-1] == "endsolid lineModel"
+
+
+# ---- the texture-free device functions of cudawrapper.cu, pinned to the reference's own code ------------------------------
+# oracle/_ref/libdevfn_ref.so is the reference's text (line ranges of cudawrapper.cu / cudawrapper.h, helper_math.h unmodified)
+# compiled against the genuine NVIDIA runtime headers (oracle/make_ref_devfn.py).  Everything must be bit-equal except the
+# angle function: the reference calls acosf of the platform's libm (glibc here, CUDA's on a GPU: both unpinned, <= 2 ulp), the
+# numeric contract its own acosf -- bit-equal with the libm build of the oracle, <= 3e-5 degrees with the
+# contract build.  A host compiler resolves `acos(fmax(fmin(float, 1.0f), -1.0f))` (cudawrapper.cu:124) to the FLOAT overloads,
+# like nvcc: the contract's reading.
+_ANGLE = "angle_between_lines_deg_3D"
+
+
+def _check_devfn(got, exp_out, name, libm):
+    import devfn_cases as dc
+    if name == _ANGLE and not libm:
+        a, b = np.asarray(got), np.asarray(exp_out)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), name
+        assert np.nanmax(np.abs(a - b)) <= 3e-5, name
+    else:
+        assert dc.same_bits(got, exp_out), name
+
+
+@pytest.mark.parametrize("libm", [False, True])
+def test_device_functions_match_reference_golden(libm):
+    import devfn_cases as dc
+    g = np.load(os.path.join(HERE, "golden", "devfn_ref.npz"))
+    assert int(g["sizeof_angle_acos"]) == 4
+    lib = op.load_lib(libm=libm)
+    res = dc.run_all(lib, "l3do_devfn_", int(g["seed"]), int(g["n"]))
+    names = sorted({k.split("__")[0] for k in g.files if "__" in k})
+    assert len(names) == 15 and set(names) == set(res)
+    for name in names:
+        ins, out = res[name]
+        for i, a in enumerate(ins):                                 # the committed inputs are the ones the generator makes
+            assert a.tobytes() == g["%s__in%d" % (name, i)].tobytes(), (name, i)
+        _check_devfn(out, g[name + "__out"], name, libm)
+    ov = g["segment_overlap_2D__out"]
+    assert (ov != 0).sum() > 1000 and len(np.unique(ov)) > 500 and g["point_on_segment_2D__out"].sum() > 1000   # every branch is exercised
+
+
+def test_device_functions_match_reference_live():
+    """10^6 seeded random and adversarial inputs per function through the reference's own code and the oracle."""
+    import devfn_cases as dc
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    assert ref.l3dref_sizeof_angle_acos() == 4
+    for seed in (1, 2, 3, 4):
+        cases = dc.make_inputs(seed, 250000)
+        exp = dc.run(ref, "l3dref_", cases)
+        for libm in (False, True):
+            got = dc.run(op.load_lib(libm=libm), "l3do_devfn_", cases)
+            for name in exp:
+                _check_devfn(got[name][1], exp[name][1], name, libm)
