@@ -444,6 +444,10 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     // overflow ALL of them are refilled before any of their chains runs again
     const int kAhead = L3D_AHEAD, kStage1Ahead = L3D_S1AHEAD, kRing = kAhead + kStage1Ahead + 3;
     int rc_final = L3D_OK;
+    // a pass over the same scene (same number of views, same pair count) starts with what the previous one ended up needing: no
+    // overflow, no restart, no allocation after the first pass
+    const bool same_scene = c->chain_seen_views == n_views && c->chain_seen_pairs == pairs;
+    if (same_scene) { cand_cap = std::max(cand_cap, c->chain_seen_cand_cap); arena_cap = std::max(arena_cap, c->chain_seen_arena_cap); }
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;
 
@@ -687,7 +691,9 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             if (r.overflow & 2) {
                 // the arena cannot be reallocated without losing earlier lists that later views still read:
                 // copy it over
-                const size_t new_cap = arena_cap * 2;
+                // (projected from the views done so far when there are enough of them: dense scenes keep 10x the first guess)
+                size_t new_cap = arena_cap * 2;
+                if (k >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / k * n_views * 1.3) + 1048576);
                 void* np = nullptr;
                 if (!hip_ok(hipMalloc(&np, new_cap * sizeof(Match)), "hipMalloc")) break;
                 if (!hip_ok(hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice), "hipMemcpy")) break;
@@ -727,5 +733,8 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
     c->stats[1] = raw_sum;
     c->stats[3] = kept_total;
+    if (rc_final == L3D_OK && !c->test_cand_cap && !c->test_arena_cap) {
+        c->chain_seen_views = n_views; c->chain_seen_pairs = pairs; c->chain_seen_cand_cap = cand_cap; c->chain_seen_arena_cap = arena_cap;
+    }
     return rc_final;
 }

@@ -103,6 +103,7 @@ struct l3d_ctx {
     int mmax_seen = 0;
     int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_place (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
+    int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0;   // what the last chain over this scene needed
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
     int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing)
     int verify_mode = 0;            // 0: depth-window search (all-pairs kernel only beyond ~50 neighbours), 1: all-pairs
