@@ -217,6 +217,62 @@ typedef int (*l3d_chain_callback)(void* user, int index, int verified, const l3d
                                   const float* best_depths, int n_best, int n_candidates);
 int l3d_match_chain(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user);
 
+/* ---- Line3D::matchViews with its products kept in HBM ------------------------------------------------------------
+ * l3d_match_chain_resident runs the chain of l3d_match_chain WITHOUT handing any kept list to the host, and builds what
+ * performMatching leaves behind (line3D.cc:834-884) on the device, from the kept arena that never left HBM:
+ *   - potential_correspondences_ (line3D.cc:861-865): for every kept match both directions, as a CSR over DENSE segment
+ *     ids -- sorted, duplicates dropped (the reference's nested std::map: set semantics, ascending iteration);
+ *   - the match file of every view after its own only-best overwrite (line3D.cc:884, view.cc:165-183): per segment the
+ *     first kept match with the highest confidence;
+ *   - the median depth of every view (cudawrapper.cu:1058-1076).
+ * Views with nothing left to match (cudawrapper.cu:877-878) hand back their existing list with LOCAL camera ids and
+ * confidence 0; their entries are formed with those numbers read as view ids, as the reference does.
+ * Dense ids: the segments of ALL views of the scene, view by view in ascending camera id: dense = seg_base[i] + segment.
+ * summary (caller's, n_views entries): per chain view its kept / candidate counts and median depth (1.0 where the
+ * reference leaves it untouched).  n_pot: entries of the CSR.  The products stay valid until the next chain runs on ctx. */
+typedef struct l3d_dense_map {
+    int32_t n_views;               /* all views of the scene */
+    const uint32_t* view_ids;      /* ascending */
+    const int32_t* seg_base;       /* n_views + 1 */
+} l3d_dense_map;
+typedef struct l3d_chain_summary {
+    int32_t verified;              /* 0: nothing left to match (early return) */
+    int32_t n_kept;                /* length of the view's list (early return: the localized existing list) */
+    int64_t n_candidates;
+    float median_depth;
+    int32_t pad;
+} l3d_chain_summary;
+int l3d_match_chain_resident(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map,
+                             l3d_chain_summary* summary, int64_t* n_pot);
+/* copies of the resident products (inspection, tests, host fallbacks).  l3d_chain_kept_list: the kept list of chain view
+ * `index` as l3d_match_chain's callback would have received it (callee-allocated, l3d_free; 0 records for a view that was
+ * not verified).  l3d_chain_products_get: pot_start (n_dense + 1), pot_tgt (n_pot), best_match (n_dense records; segID1 ==
+ * 0xffffffff where a segment has none; camera ids as in the kept lists: GLOBAL, LOCAL for early-return views) -- any
+ * pointer may be NULL. */
+int l3d_chain_kept_list(l3d_ctx* ctx, int index, l3d_match** out, int* n);
+int l3d_chain_products_get(l3d_ctx* ctx, int64_t* pot_start, int32_t* pot_tgt, l3d_match* best_match);
+
+/* Line3D::greedySelection (line3D.cc:899-965) on the resident products: one 3-D hypothesis per segment that has a best
+ * match (L3DView::unprojectSegment, view.cc:302-342, in double), numbered in dense order, left on the device for
+ * l3d_affinity_fill_resident and l3d_fit_clusters.  geometry: one entry per view of the dense map.
+ * Outputs: view_hyp_begin (caller's, n_views + 1), hyp_dense (callee-allocated, l3d_free: dense id per hypothesis). */
+typedef struct l3d_view_geometry {
+    double RtKinv[9];              /* R^T K^-1, row-major */
+    double C[3];
+    float k_lower, k_upper;        /* view.cc:90-121 */
+    float median_depth;
+    int32_t n_segments;
+    const float* segments;         /* host pointer of the view's segments (registered: l3d_register_segments) */
+} l3d_view_geometry;
+int l3d_products_hypotheses(l3d_ctx* ctx, const l3d_view_geometry* geometry, int n_views, int32_t* view_hyp_begin, int32_t** hyp_dense, int* n_hyp);
+/* l3d_affinity_fill on the resident tables: hypotheses of l3d_products_hypotheses, potential correspondences and best
+ * matches of l3d_match_chain_resident; only the collinearity CSR (segment2collinearities_, static per scene) comes from the
+ * host -- uploaded when coll_changed != 0, otherwise the copy of the previous call is used.  Outputs as l3d_affinity_fill. */
+int l3d_affinity_fill_resident(l3d_ctx* ctx, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed,
+                               float sigma_a, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes, int* n_candidates);
+/* the resident hypothesis table (n_hyp entries of l3d_products_hypotheses) copied to the host */
+int l3d_products_hypotheses_get(l3d_ctx* ctx, l3d_hypothesis* hyp, float* score);
+
 /* ---- the resident chain with every view's source segments sharded over the GPUs of one node ---------------------
  * One process per GPU.  Each rank opens the chain with (rank, world) and per view k: l3d_shard_chain_enqueue writes
  * this rank's kept records for its source-segment range [S*rank/world, S*(rank+1)/world) into `send_slot`

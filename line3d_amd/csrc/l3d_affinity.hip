@@ -437,86 +437,32 @@ int scan_excl(l3d_ctx* c, const int* in, int* out, int n, hipStream_t st)
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out,
-                      int* n_candidates_out)
+// The fill proper, on tables that are already on the device (`a`: everything but dview / flags, which live in the context's scratch).
+// seg_base_h / vhb_h: host copies of the view tables (launch geometry).
+int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int32_t* vhb_h, long long n_pot, long long n_coll, float sigma_a,
+                       l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
 {
-    if (!c) return L3D_ERR_INVALID;
-    if (!in || !edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out) return fail(c, L3D_ERR_INVALID, "bad argument");
-    *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
-    c->resident_edges = 0;
-    if (n_candidates_out) *n_candidates_out = 0;
-    const int V = in->n_views, nh = in->n_hyp;
-    if (V < 0 || nh < 0 || (V > 0 && (!in->seg_base || !in->view_hyp_begin))) return fail(c, L3D_ERR_INVALID, "bad argument");
-    if (nh == 0) return L3D_OK;
-    const int nd = in->seg_base[V];
-    if (nd <= 0 || !in->hyp || !in->score || !in->hyp_dense || !in->best || !in->pot_start || !in->coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
-    // the view tables decide where k_aff_dview writes and how the arena is laid out: checked on the host before anything is launched
-    // (ascending from 0 up to seg_base[V] = nd, so no view's range leaves the dense ids)
-    if (in->pot_start[0] != 0 || in->coll_start[0] != 0) return fail(c, L3D_ERR_INVALID, "affinity fill: CSR tables must start at 0");
-    for (int v = 0; v < V; ++v)
-        if (in->seg_base[v + 1] < in->seg_base[v] || in->view_hyp_begin[v + 1] < in->view_hyp_begin[v]) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables must ascend");
-    if (in->seg_base[0] != 0 || in->view_hyp_begin[0] != 0 || in->view_hyp_begin[V] != nh) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables do not cover the hypotheses");
-    const long long n_pot = in->pot_start[nd], n_coll = in->coll_start[nd];
-    if (n_pot < 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_pot > 0 && !in->pot_tgt) || (n_coll > 0 && (!in->coll_other || !in->coll_w)))
-        return fail(c, L3D_ERR_INVALID, "bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    const int V = a.n_views, nh = a.n_hyp, nd = a.n_dense;
     hipStream_t st = c->stream;
     const bool timing = getenv("L3D_TIMING") != nullptr;
     double tl = now_s();
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = now_s(); fprintf(stderr, "[l3d affinity] %-34s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
-
-    // ---- inputs to the device (one arena, 256-byte aligned slices)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_base = 0;
-    const size_t o_dview = o_base + al((size_t)(V + 1) * 4);
-    const size_t o_score = o_dview + al((size_t)nd * 4);
-    const size_t o_hd = o_score + al((size_t)nh * 4);
-    const size_t o_best = o_hd + al((size_t)nh * 4);
-    const size_t o_ps = o_best + al((size_t)nd * 4);
-    const size_t o_pt = o_ps + al((size_t)(nd + 1) * 8);
-    const size_t o_cs = o_pt + al((size_t)n_pot * 4 + 4);
-    const size_t o_co = o_cs + al((size_t)(nd + 1) * 8);
-    const size_t o_cw = o_co + al((size_t)n_coll * 4 + 4);
-    const size_t o_fl = o_cw + al((size_t)n_coll * 4 + 4);
-    const size_t total = o_fl + al((size_t)n_pot + 4);
-    HIPCHK(c, c->g0.reserve(total));
-    char* base = c->g0.as<char>();
-    auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
-    HIPCHK(c, up(o_base, in->seg_base, (size_t)(V + 1) * 4));
-    // (the hypothesis table gets a buffer of its own: the line fit of the same finish reads it again, l3d_fit_clusters)
-    c->resident_hyp = 0;
-    HIPCHK(c, c->aff_hyp.reserve((size_t)nh * sizeof(Hypothesis) + 64));
-    HIPCHK(c, hipMemcpyAsync(c->aff_hyp.p, in->hyp, (size_t)nh * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
-    HIPCHK(c, up(o_score, in->score, (size_t)nh * 4));
-    HIPCHK(c, up(o_hd, in->hyp_dense, (size_t)nh * 4));
-    HIPCHK(c, up(o_best, in->best, (size_t)nd * 4));
-    HIPCHK(c, up(o_ps, in->pot_start, (size_t)(nd + 1) * 8));
-    HIPCHK(c, up(o_pt, in->pot_tgt, (size_t)n_pot * 4));
-    HIPCHK(c, up(o_cs, in->coll_start, (size_t)(nd + 1) * 8));
-    HIPCHK(c, up(o_co, in->coll_other, (size_t)n_coll * 4));
-    HIPCHK(c, up(o_cw, in->coll_w, (size_t)n_coll * 4));
-    HIPCHK(c, hipMemsetAsync(base + o_fl, 0, (size_t)n_pot + 4, st));
-    AffIn a;
-    a.n_views = V; a.n_hyp = nh; a.n_dense = nd;
+    {   // dview + per-entry flags
+        const size_t o_fl = al((size_t)nd * 4);
+        HIPCHK(c, c->products.aux.reserve(o_fl + al((size_t)n_pot + 4)));
+        a.dview = c->products.aux.as<int>();
+        a.flags = reinterpret_cast<unsigned char*>(c->products.aux.as<char>() + o_fl);
+        HIPCHK(c, hipMemsetAsync(a.flags, 0, (size_t)n_pot + 4, st));
+    }
     a.chunk = 64;
     if (const char* e = getenv("L3D_AFF_CHUNK")) a.chunk = std::max(1, std::min(64, atoi(e)));       // tests: forces multi-pass groups on small scenes
-    a.seg_base = reinterpret_cast<const int*>(base + o_base);
-    a.dview = reinterpret_cast<const int*>(base + o_dview);
-    a.hyp = c->aff_hyp.as<Hypothesis>();
-    a.score = reinterpret_cast<const float*>(base + o_score);
-    a.hyp_dense = reinterpret_cast<const int*>(base + o_hd);
-    a.best = reinterpret_cast<const int*>(base + o_best);
-    a.pot_start = reinterpret_cast<const long long*>(base + o_ps);
-    a.pot_tgt = reinterpret_cast<const int*>(base + o_pt);
-    a.coll_start = reinterpret_cast<const long long*>(base + o_cs);
-    a.coll_other = reinterpret_cast<const int*>(base + o_co);
-    a.coll_w = reinterpret_cast<const float*>(base + o_cw);
-    a.flags = reinterpret_cast<unsigned char*>(base + o_fl);
+    char* const base = nullptr; (void)base;
     int maxS = 1;
-    for (int v = 0; v < V; ++v) maxS = std::max(maxS, in->seg_base[v + 1] - in->seg_base[v]);
-    hipLaunchKernelGGL(k_aff_dview, dim3((maxS + 255) / 256, V), dim3(256), 0, st, a.seg_base, V, reinterpret_cast<int*>(base + o_dview));
+    for (int v = 0; v < V; ++v) maxS = std::max(maxS, seg_base_h[v + 1] - seg_base_h[v]);
+    hipLaunchKernelGGL(k_aff_dview, dim3((maxS + 255) / 256, V), dim3(256), 0, st, a.seg_base, V, const_cast<int*>(a.dview));
     {
         HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
         int* bad = c->g1.as<int>();
@@ -547,7 +493,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     for (int v0 = 0; v0 < V;) {
         int v1 = v0 + 1;
         while (v1 < V && !cut[(size_t)v1] && !per_view) ++v1;
-        const int h0 = in->view_hyp_begin[v0], h1 = in->view_hyp_begin[v1];
+        const int h0 = vhb_h[v0], h1 = vhb_h[v1];
         if (h1 > h0) { ProfScope p(c, "aff_groups", st); hipLaunchKernelGGL(k_aff_groups, dim3((h1 - h0 + 3) / 4), dim3(256), 0, st, a, h0, h1); ++n_launches; }
         v0 = v1;
     }
@@ -568,7 +514,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     HIPCHK(c, c->g2.reserve(((size_t)n_words + 1) * 8));
     const float two_log = 2.0f * logf(0.01f);      // view.cc:376
     { ProfScope p(c, "aff_decide", st);
-      hipLaunchKernelGGL(k_aff_items<false>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, in->sigma_a, two_log); }
+      hipLaunchKernelGGL(k_aff_items<false>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, sigma_a, two_log); }
     if (int rc = scan_excl(c, cnt, item_off, nh, st)) return rc;
     int n_items = 0;
     HIPCHK(c, hipMemcpyAsync(&n_items, item_off + nh, 4, hipMemcpyDeviceToHost, st));
@@ -584,7 +530,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     int2* pairs = c->g3.as<int2>();
     float* wgt = c->g4.as<float>();
     { ProfScope p(c, "aff_emit", st);
-      hipLaunchKernelGGL(k_aff_items<true>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), (int*)nullptr, item_off, pairs, wgt, in->sigma_a, two_log); }
+      hipLaunchKernelGGL(k_aff_items<true>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), (int*)nullptr, item_off, pairs, wgt, sigma_a, two_log); }
     // first[] n_hyp | node[] n_hyp | kept[] n_items+1 | erank[] n_items+1 | posflag[] 2 n_items+1 | posrank[] 2 n_items+1
     const size_t ni = (size_t)n_items;
     HIPCHK(c, c->g5.reserve(((size_t)nh * 2 + (ni + 1) * 2 + (2 * ni + 1) * 2) * 4 + 1024));
@@ -628,6 +574,127 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     c->resident_edges = 2 * n_kept;                                            // (the list stays in g6 for l3d_clustering_edges)
     c->resident_hyp = nh;
     return L3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out,
+                      int* n_candidates_out)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!in || !edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    c->resident_edges = 0;
+    if (n_candidates_out) *n_candidates_out = 0;
+    const int V = in->n_views, nh = in->n_hyp;
+    if (V < 0 || nh < 0 || (V > 0 && (!in->seg_base || !in->view_hyp_begin))) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (nh == 0) return L3D_OK;
+    const int nd = in->seg_base[V];
+    if (nd <= 0 || !in->hyp || !in->score || !in->hyp_dense || !in->best || !in->pot_start || !in->coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    // the view tables decide where k_aff_dview writes and how the arena is laid out: checked on the host before anything is launched
+    // (ascending from 0 up to seg_base[V] = nd, so no view's range leaves the dense ids)
+    if (in->pot_start[0] != 0 || in->coll_start[0] != 0) return fail(c, L3D_ERR_INVALID, "affinity fill: CSR tables must start at 0");
+    for (int v = 0; v < V; ++v)
+        if (in->seg_base[v + 1] < in->seg_base[v] || in->view_hyp_begin[v + 1] < in->view_hyp_begin[v]) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables must ascend");
+    if (in->seg_base[0] != 0 || in->view_hyp_begin[0] != 0 || in->view_hyp_begin[V] != nh) return fail(c, L3D_ERR_INVALID, "affinity fill: view tables do not cover the hypotheses");
+    const long long n_pot = in->pot_start[nd], n_coll = in->coll_start[nd];
+    if (n_pot < 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_pot > 0 && !in->pot_tgt) || (n_coll > 0 && (!in->coll_other || !in->coll_w)))
+        return fail(c, L3D_ERR_INVALID, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    // ---- inputs to the device (one arena, 256-byte aligned slices)
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_base = 0;
+    const size_t o_score = o_base + al((size_t)(V + 1) * 4);
+    const size_t o_hd = o_score + al((size_t)nh * 4);
+    const size_t o_best = o_hd + al((size_t)nh * 4);
+    const size_t o_ps = o_best + al((size_t)nd * 4);
+    const size_t o_pt = o_ps + al((size_t)(nd + 1) * 8);
+    const size_t o_cs = o_pt + al((size_t)n_pot * 4 + 4);
+    const size_t o_co = o_cs + al((size_t)(nd + 1) * 8);
+    const size_t o_cw = o_co + al((size_t)n_coll * 4 + 4);
+    const size_t total = o_cw + al((size_t)n_coll * 4 + 4);
+    HIPCHK(c, c->g0.reserve(total));
+    char* base = c->g0.as<char>();
+    auto up = [&](size_t off, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+    HIPCHK(c, up(o_base, in->seg_base, (size_t)(V + 1) * 4));
+    // (the hypothesis table gets a buffer of its own: the line fit of the same finish reads it again, l3d_fit_clusters)
+    c->resident_hyp = 0;
+    HIPCHK(c, c->aff_hyp.reserve((size_t)nh * sizeof(Hypothesis) + 64));
+    HIPCHK(c, hipMemcpyAsync(c->aff_hyp.p, in->hyp, (size_t)nh * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
+    HIPCHK(c, up(o_score, in->score, (size_t)nh * 4));
+    HIPCHK(c, up(o_hd, in->hyp_dense, (size_t)nh * 4));
+    HIPCHK(c, up(o_best, in->best, (size_t)nd * 4));
+    HIPCHK(c, up(o_ps, in->pot_start, (size_t)(nd + 1) * 8));
+    HIPCHK(c, up(o_pt, in->pot_tgt, (size_t)n_pot * 4));
+    HIPCHK(c, up(o_cs, in->coll_start, (size_t)(nd + 1) * 8));
+    HIPCHK(c, up(o_co, in->coll_other, (size_t)n_coll * 4));
+    HIPCHK(c, up(o_cw, in->coll_w, (size_t)n_coll * 4));
+    AffIn a;
+    a.n_views = V; a.n_hyp = nh; a.n_dense = nd;
+    a.seg_base = reinterpret_cast<const int*>(base + o_base);
+    a.hyp = c->aff_hyp.as<Hypothesis>();
+    a.score = reinterpret_cast<const float*>(base + o_score);
+    a.hyp_dense = reinterpret_cast<const int*>(base + o_hd);
+    a.best = reinterpret_cast<const int*>(base + o_best);
+    a.pot_start = reinterpret_cast<const long long*>(base + o_ps);
+    a.pot_tgt = reinterpret_cast<const int*>(base + o_pt);
+    a.coll_start = reinterpret_cast<const long long*>(base + o_cs);
+    a.coll_other = reinterpret_cast<const int*>(base + o_co);
+    a.coll_w = reinterpret_cast<const float*>(base + o_cw);
+    return affinity_fill_core(c, a, in->seg_base, in->view_hyp_begin, n_pot, n_coll, in->sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out);
+}
+
+// The same fill on the resident tables: hypotheses (l3d_products_hypotheses), potential correspondences and best matches
+// (l3d_match_chain_resident) never left the device; the collinearity CSR is uploaded when it changed.
+int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, float sigma_a,
+                               l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    c->resident_edges = 0;
+    if (n_candidates_out) *n_candidates_out = 0;
+    Products& P = c->products;
+    if (!P.valid || !P.hyp_valid) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: no resident products / hypotheses");
+    const int nd = P.n_dense, nh = P.n_hyp, V = P.n_views_all;
+    if (nh == 0) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const long long n_coll = coll_start[nd];
+    if (coll_start[0] != 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_coll > 0 && (!coll_other || !coll_w))) return fail(c, L3D_ERR_INVALID, "affinity fill: bad collinearity table");
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_cs = 0, o_co = al((size_t)(nd + 1) * 8), o_cw = o_co + al((size_t)n_coll * 4 + 4), o_sb = o_cw + al((size_t)n_coll * 4 + 4);
+    if (coll_changed || P.coll_n != n_coll || P.coll.cap < o_sb + al((size_t)(V + 1) * 4)) {
+        HIPCHK(c, P.coll.reserve(o_sb + al((size_t)(V + 1) * 4)));
+        char* cb = P.coll.as<char>();
+        HIPCHK(c, hipMemcpyAsync(cb + o_cs, coll_start, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, st));
+        if (n_coll) {
+            HIPCHK(c, hipMemcpyAsync(cb + o_co, coll_other, (size_t)n_coll * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(cb + o_cw, coll_w, (size_t)n_coll * 4, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(c, hipMemcpyAsync(cb + o_sb, P.seg_base.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, st));
+        P.coll_n = n_coll;
+    }
+    char* cb = P.coll.as<char>();
+    AffIn a;
+    a.n_views = V; a.n_hyp = nh; a.n_dense = nd; a.chunk = 64;
+    a.seg_base = reinterpret_cast<const int*>(cb + o_sb);
+    a.dview = nullptr; a.flags = nullptr;
+    a.hyp = c->aff_hyp.as<Hypothesis>();
+    a.score = P.score.as<float>();
+    a.hyp_dense = P.hyp_dense.as<int>();
+    a.best = P.best_hyp.as<int>();
+    a.pot_start = P.pot_start.as<long long>();
+    a.pot_tgt = P.pot_tgt.as<int>();
+    a.coll_start = reinterpret_cast<const long long*>(cb + o_cs);
+    a.coll_other = reinterpret_cast<const int*>(cb + o_co);
+    a.coll_w = reinterpret_cast<const float*>(cb + o_cw);
+    if ((int)P.view_hyp_begin.size() != V + 1) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: hypothesis ranges missing");
+    return affinity_fill_core(c, a, P.seg_base.data(), P.view_hyp_begin.data(), P.n_pot, n_coll, sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out);
 }
 
 }  // extern "C"

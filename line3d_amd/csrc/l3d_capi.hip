@@ -90,6 +90,8 @@ void l3d_ctx_destroy(l3d_ctx* c)
                        &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
                        &c->ch_rays, &c->aff_hyp, &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
+    c->ch_bestpos.release();
+    c->products.release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
     for (auto& kv : c->resident) (void)hipFree(kv.second.first);

@@ -25,6 +25,7 @@
 #include "l3d_ctx.hpp"
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
+#include "l3d_products.hpp"
 
 using namespace l3d;
 
@@ -146,10 +147,11 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
 // Workgroup 0 also writes the view's result record (device copy for later views, host-mapped copy for the host).
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, const ChainResult* __restrict__ prev,
                                                           int arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
-                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena)
+                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos)
 {
     __shared__ int s_red[8];
     __shared__ int s_cnt[32];
+    __shared__ unsigned long long s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
     const int yl = blockIdx.x;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
     if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
     if (blockIdx.x == 0 && tid == 0) { *res = r; *res_host = r; }
     if (yl >= nseg || r.overflow) return;
-    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt);
+    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
@@ -202,9 +204,9 @@ void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int*
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
-                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st)
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos)
 {
-    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena);
+    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos);
 }
 
 }  // namespace l3d
@@ -222,6 +224,7 @@ struct ViewDev {            // device addresses of one view's static tables and 
     int* rowblk;
     int* stats;             // {raw total, raw max per segment}
     float2* best;
+    int* bestpos;           // per segment: position (in the view's kept slice) of its best kept match or -1 (k_kept_write_chain)
     float4* rays;           // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
     int W64, maxW;
     bool verified;
@@ -231,10 +234,14 @@ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace
 
-extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user)
+// cb: per-view delivery of the kept lists to the host (l3d_match_chain); map: products built on the device at the end of the chain
+// (l3d_match_chain_resident) -- either or both
+static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user, const l3d_dense_map* map,
+                     l3d_chain_summary* summary, int64_t* n_pot)
 {
     if (!c) return L3D_ERR_INVALID;
-    if (n_views < 0 || (n_views > 0 && (!views || !cb))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
+    if (n_views < 0 || (n_views > 0 && (!views || (!cb && !map)))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
+    c->products.valid = false;
     if (n_views == 0) return L3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const double t_setup0 = now_s();
@@ -318,6 +325,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     HIPCHK(c, c->ch_rowA.reserve((rowA_ints + rowub_ints + rowblk_ints) * 4 + 64));
     HIPCHK(c, hipMemsetAsync(c->ch_rowA.as<int>() + rowA_ints, 0, (rowub_ints + rowblk_ints) * 4, st));
     HIPCHK(c, c->ch_best.reserve(best_elems * 8 + 16));
+    HIPCHK(c, c->ch_bestpos.reserve(best_elems * 4 + 16));
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
     HIPCHK(c, c->ch_flags.reserve(64));
     HIPCHK(c, c->ch_pin_res.reserve((size_t)n_views * (sizeof(ChainResult) + 8) + 64));
@@ -380,7 +388,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             d.rowblk = c->ch_rowA.as<int>() + rowA_ints + rowub_ints + ko;
             ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
             ko += (((size_t)v.S_src * v.N + 255) / 256 + 4) & ~(size_t)3;
-            d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
+            d.best = c->ch_best.as<float2>() + bo; d.bestpos = c->ch_bestpos.as<int>() + bo; bo += (size_t)v.S_src;
         }
     }
     // the four depths of a stage-1 pair are triangulated once, by k_pair_fill (ring scheme only: the fill runs ahead, its true row counts
@@ -586,7 +594,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
             int pv = k - 1;
             while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
             launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (int)arena_cap, dres + k, hres_dev + k,
-                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st);
+                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, map ? d.bestpos : nullptr);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
@@ -608,6 +616,7 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     int deliver_rc = L3D_OK;
     std::string deliver_err;
     std::thread deliverer([&]() {
+        if (!cb) return;                                // resident run: nothing is handed to the host
         (void)hipSetDevice(c->device);
         for (;;) {
             Item it;
@@ -660,10 +669,12 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         }
     });
     auto hand_over = [&](int k, int verified, const ChainResult& r) {
+        if (!cb) { if (verified) kept_total += r.n_kept; return; }
         { std::lock_guard<std::mutex> lk(mu); work.push_back(Item{ k, verified, r }); }
         cv_work.notify_one();
     };
     auto wait_delivered = [&]() {                       // every handed-over view has left the device arena
+        if (!cb) return;
         std::unique_lock<std::mutex> lk(mu);
         cv_idle.wait(lk, [&]() { return work.empty() && !busy; });
     };
@@ -727,6 +738,12 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
     if (getenv("L3D_TIMING"))
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
                 (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
+    if (rc_final == L3D_OK && map) {
+        // ---- the products of matchViews, on the device, from the arena (l3d_products.hip); enqueued behind the last view
+        std::vector<ProdChainView> pv((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0 };
+        rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot);
+    }
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
@@ -737,4 +754,18 @@ extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_vi
         c->chain_seen_views = n_views; c->chain_seen_pairs = pairs; c->chain_seen_cand_cap = cand_cap; c->chain_seen_arena_cap = arena_cap;
     }
     return rc_final;
+}
+
+extern "C" int l3d_match_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user)
+{
+    if (c && n_views > 0 && !cb) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
+    return run_chain(c, views, n_views, cb, user, nullptr, nullptr, nullptr);
+}
+
+extern "C" int l3d_match_chain_resident(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!map || !map->view_ids || !map->seg_base || map->n_views < 0 || (n_views > 0 && !summary)) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_resident: bad argument");
+    if (n_pot) *n_pot = 0;
+    return run_chain(c, views, n_views, nullptr, nullptr, map, summary, n_pot);
 }

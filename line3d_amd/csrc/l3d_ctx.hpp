@@ -75,6 +75,30 @@ struct PinArena {
     void release() { for (auto& b : chunks) b.release(); chunks.clear(); reset(); }
 };
 
+// Device-resident products of the last resident chain (l3d_products.hip) and the hypothesis table built from them
+struct Products {
+    bool valid = false, hyp_valid = false;
+    int n_dense = 0, n_views_all = 0, n_chain = 0, n_hyp = 0;
+    long long n_pot = 0, total_kept = 0;
+    DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables;
+    DevBuf geo, hyp_of, score, hyp_dense, best_hyp, coll, aux;       // greedy selection / affinity fill on the resident tables
+    long long coll_n = 0;           // entries of the collinearity CSR resident in `coll` (with n_dense + 1 starts in front)
+    std::vector<int> seg_base;      // host copies: the dense map, the chain's result records, what the early-return views need
+    std::vector<unsigned> view_ids;
+    std::vector<l3d::ChainResult> res;
+    std::vector<int> chain_view;    // per chain index: index of its view in the dense map
+    std::vector<char> chain_verified;
+    std::vector<int> view_hyp_begin; // per view of the dense map: first hypothesis (l3d_products_hypotheses)
+    std::vector<std::vector<int>> early_src_index, early_src_cam;    // per chain index (early-return views only): its sources
+    std::vector<unsigned> chain_view_id;
+    void release()
+    {
+        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
+        for (DevBuf* x : b) x->release();
+        valid = hyp_valid = false; coll_n = 0;
+    }
+};
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -97,6 +121,8 @@ struct l3d_ctx {
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    l3d::DevBuf ch_bestpos;                  // per segment of every view: position of its best kept match in the view's slice (resident runs)
+    l3d::Products products;
     std::vector<l3d::RayJob> ray_jobs;       // job list of k_tgt_rays of the running chain
     l3d::PinArena pin_arena;                 // kept lists of the running / last chain (valid until the next chain starts)
     std::vector<int> h_cnt;

@@ -12,12 +12,17 @@ namespace l3d {
 // (2048 candidates) whose confidences are all loaded at once; the chunks' kept counts go through LDS, every wave then knows
 // the output offset of its chunks.  A segment of config 2 (about 1500 candidates) is one round of loads instead of a chain of
 // dependent ones.  s_cnt: 32 ints of LDS.  All 256 threads must call.
+// best_pos (optional, with s_best = 4 x 64 bits of LDS): *best_pos = position in `out` of the segment's first kept match with the
+// highest confidence, or -1 -- what L3DView::addMatches(only_best) leaves of the list (view.cc:165-183: stable sort by confidence,
+// front of every segment's group), found where the confidences already are in registers.
 __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y, int o, const unsigned* __restrict__ local2global,
-                                                      Match* __restrict__ out, int* s_cnt)
+                                                      Match* __restrict__ out, int* s_cnt, int* __restrict__ best_pos = nullptr,
+                                                      unsigned long long* s_best = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
+    unsigned long long bk = 0ull;            // (confidence bits, ~position): the maximum is the first strict maximum in list order
     for (int base = 0; base < m; base += 2048) {
         float c[8];
 #pragma unroll
@@ -43,11 +48,28 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
                 rec.segID1 = (unsigned)y; rec.camID2 = local2global[meta.y]; rec.segID2 = meta.x;
                 rec.depths[0] = d.x; rec.depths[1] = d.y; rec.depths[2] = d.z; rec.depths[3] = d.w;
                 rec.confidence = c[r] / 2.0f;                    // confidence_norm, cudawrapper.cu:1089,1098
-                out[o + off + __popcll(b[r] & ((1ull << lane) - 1ull))] = rec;
+                const int pos = o + off + __popcll(b[r] & ((1ull << lane) - 1ull));
+                out[pos] = rec;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(c[r]) << 32) | (0xffffffffu - (unsigned)pos);   // (c > 1: the bits order like the value)
+                bk = key > bk ? key : bk;
             }
         }
         o += total;
         __syncthreads();                                       // s_cnt is rewritten by the next round
+    }
+    if (best_pos) {
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned lo = __shfl_down((unsigned)bk, d), hi = __shfl_down((unsigned)(bk >> 32), d);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            bk = other > bk ? other : bk;
+        }
+        if (lane == 0) s_best[wave] = bk;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long mx = s_best[0];
+            for (int w = 1; w < 4; ++w) mx = s_best[w] > mx ? s_best[w] : mx;
+            *best_pos = mx ? (int)(0xffffffffu - (unsigned)mx) : -1;
+        }
     }
 }
 

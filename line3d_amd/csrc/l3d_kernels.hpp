@@ -139,7 +139,7 @@ void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, cons
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
-                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st);
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);

@@ -1,0 +1,26 @@
+// l3d_products.hpp -- what Line3D::performMatching leaves behind (line3D.cc:834-884), kept on the device: shared by the resident
+// chain (l3d_chain.hip), the builder (l3d_products.hip) and the affinity fill on resident tables (l3d_affinity.hip).
+#pragma once
+
+#include "l3d_ctx.hpp"
+
+namespace l3d {
+
+// one view of a finished chain, as the builder needs it
+struct ProdChainView {
+    const float2* best;     // depths of the best hypothesis per segment (k_verify_window epilogue), null for views that were not verified
+    const int* bestpos;     // position (in the view's kept slice) of every segment's best kept match or -1
+    int verified;
+};
+
+// Enqueued on the context's stream behind the last view of the chain; returns after the few scalars the host needs (entries of the
+// CSR, medians) have arrived.  hres: the chain's per-view result records (host copies).
+int build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pv, const ChainResult* hres,
+                   const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot);
+
+// references into the kept arena (best_ref): record index, bit 62 = "read it reversed" (the record of an earlier view that an
+// early-return view got back, cudawrapper.cu:877-878: segments and depth pairs swap, confidence 0), -1 = the segment has no match
+constexpr long long kBestReversed = 1ll << 62;
+constexpr long long kBestIndexMask = (1ll << 40) - 1;
+
+}  // namespace l3d

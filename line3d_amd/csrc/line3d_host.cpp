@@ -26,6 +26,7 @@
 #include "../../include/line3d_amd.h"
 #include "l3d_linalg.hpp"
 #include "l3d_linefit.hpp"
+#include "l3d_unproject.hpp"
 #include "l3d_hostsort.hpp"
 
 using namespace l3d::la;
@@ -190,6 +191,10 @@ struct l3d_line3d {
     void* plan_cache = nullptr;                                // ChainPlan of the current set of views (the schedule is static)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
+    bool host_bookkeeping = false;                             // chain with per-view delivery + host lists (L3D_HOST_BOOKKEEPING=1 / L3D_AFFINITY_HOST=1: A/B, cross-checks)
+    bool resident_products = false;                            // the last matchViews left its products on the device: no host lists exist
+    std::vector<l3d_chain_summary> chain_summary;
+    int64_t resident_n_pot = 0;
     int shard_world_seen = 0, shard_slot_records_seen = 0;     // sharded native run: slot / candidate sizes a capacity verdict made necessary
     size_t shard_cand_cap_seen = 0;
 
@@ -749,6 +754,7 @@ int prepare(L* h)
 // reset of everything matchViews produces (line3D.cc:355-358 + the views' match files)
 void match_begin(L* h)
 {
+    h->resident_products = false;
     h->matched.clear();
     h->pot.resize(h->vlist.size());                     // (capacities survive from an earlier pass)
     for (auto& pv : h->pot) pv.clear();
@@ -1201,6 +1207,123 @@ void finish_chain_host(L* h, ChainPlan& P, bool ok)
     }
 }
 
+// the dense numbering of all segments: views in ascending id, dense id = base + segment
+void dense_map(L* h, std::vector<uint32_t>& ids, std::vector<int32_t>& base)
+{
+    const size_t nv = h->vlist.size();
+    ids.resize(nv); base.assign(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) { ids[i] = h->vlist[i]->id; base[i + 1] = base[i] + (int32_t)h->vlist[i]->S(); }
+}
+
+// L3D_CHECK_POT (tests): the device products against the plain host construction from the kept lists -- potential
+// correspondences as the normal form (sort + unique) of all entries (line3D.cc:861-865), the only-best store of every view
+// (view.cc:165-183: first match of the highest confidence per segment)
+int check_resident_products(L* h, ChainPlan& P)
+{
+    std::vector<uint32_t> ids; std::vector<int32_t> base;
+    dense_map(h, ids, base);
+    const size_t nd = (size_t)base.back();
+    std::vector<int64_t> pot_start(nd + 1);
+    std::vector<int32_t> pot_tgt((size_t)h->resident_n_pot + 1);
+    std::vector<l3d_match> best(nd + 1);
+    int rc = l3d_chain_products_get(h->ctx, pot_start.data(), pot_tgt.data(), best.data());
+    if (rc) return h->fail(rc, std::string("products_get: ") + l3d_last_error(h->ctx));
+    std::vector<std::vector<std::pair<uint32_t, Key>>> ref(h->vlist.size());
+    std::vector<std::vector<l3d_match>> lists(P.n);
+    for (size_t k = 0; k < P.n; ++k) {
+        l3d_match* m = nullptr; int n = 0;
+        rc = l3d_chain_kept_list(h->ctx, (int)k, &m, &n);
+        if (rc) return h->fail(rc, std::string("kept_list: ") + l3d_last_error(h->ctx));
+        lists[k].assign(m, m + n);
+        l3d_free(m);
+        const View& v = h->views[h->order[k]];
+        for (const l3d_match& mm : lists[k]) {
+            ref[(size_t)v.index].emplace_back(mm.segID1, mk(mm.camID2, mm.segID2));
+            View* o = h->find_view(mm.camID2);
+            if (o) ref[(size_t)o->index].emplace_back(mm.segID2, mk(v.id, mm.segID1));
+        }
+    }
+    bool ok = true;
+    for (size_t vi = 0; vi < ref.size() && ok; ++vi) {
+        std::sort(ref[vi].begin(), ref[vi].end());
+        ref[vi].erase(std::unique(ref[vi].begin(), ref[vi].end()), ref[vi].end());
+        const size_t S = (size_t)h->vlist[vi]->S();
+        std::vector<std::vector<int32_t>> exp(S);
+        for (auto& e : ref[vi]) {
+            View* o = h->find_view(kcam(e.second));
+            if (!o || e.first >= S || kseg(e.second) >= (uint32_t)o->S()) continue;       // (takes no part in the fill)
+            exp[e.first].push_back(base[(size_t)o->index] + (int32_t)kseg(e.second));
+        }
+        for (size_t sg = 0; sg < S && ok; ++sg) {
+            const size_t d = (size_t)base[vi] + sg;
+            std::sort(exp[sg].begin(), exp[sg].end());
+            const int64_t b = pot_start[d], e = pot_start[d + 1];
+            if (e - b != (int64_t)exp[sg].size() || b < 0 || e > h->resident_n_pot || !std::equal(exp[sg].begin(), exp[sg].end(), pot_tgt.begin() + b)) {
+                ok = false;
+                fprintf(stderr, "[l3d] device potential correspondences of view index %zu segment %zu differ from the host construction (%lld vs %zu entries)\n", vi, sg, (long long)(e - b), exp[sg].size());
+            }
+        }
+    }
+    for (size_t k = 0; k < P.n && ok; ++k) {
+        const View& v = h->views[h->order[k]];
+        std::vector<int> bi((size_t)v.S(), -1);
+        for (size_t i = 0; i < lists[k].size(); ++i) {
+            const uint32_t sg = lists[k][i].segID1;
+            if (sg >= (uint32_t)v.S()) continue;
+            if (bi[sg] < 0 || lists[k][i].confidence > lists[k][(size_t)bi[sg]].confidence) bi[sg] = (int)i;
+        }
+        for (int sg = 0; sg < v.S() && ok; ++sg) {
+            const l3d_match& got = best[(size_t)base[(size_t)v.index] + (size_t)sg];
+            if (bi[(size_t)sg] < 0) { if (got.segID1 != 0xffffffffu) ok = false; }
+            else if (memcmp(&got, &lists[k][(size_t)bi[(size_t)sg]], sizeof(l3d_match)) != 0) ok = false;
+            if (!ok) fprintf(stderr, "[l3d] device best match of view %u segment %d differs from the host rule\n", v.id, sg);
+        }
+    }
+    if (!ok) { h->pot_check_failed = true; return h->fail(L3D_ERR_INVALID, "L3D_CHECK_POT: the device products differ from the host construction"); }
+    return L3D_OK;
+}
+
+// Line3D::matchViews with nothing but a few scalars per view coming back: the chain runs resident, the products of
+// performMatching (potential_correspondences_, only-best stores, medians) are built on the device (l3d_products.hip)
+int match_views_resident(L* h, ChainPlan& P, double t0)
+{
+    std::vector<uint32_t> ids; std::vector<int32_t> base;
+    dense_map(h, ids, base);
+    l3d_dense_map map;
+    map.n_views = (int32_t)ids.size(); map.view_ids = ids.data(); map.seg_base = base.data();
+    h->chain_summary.assign(P.n, l3d_chain_summary());
+    h->resident_products = false;
+    const double t1 = now_s();
+    int rc = l3d_match_chain_resident(h->ctx, P.cv.data(), (int)P.n, &map, h->chain_summary.data(), &h->resident_n_pot);
+    h->t_gpu_call += now_s() - t1;
+    if (rc == L3D_ERR_UNSUPPORTED) return rc;
+    if (rc) return h->fail(rc, std::string("match_chain_resident: ") + l3d_last_error(h->ctx));
+    for (size_t k = 0; k < P.n; ++k) {
+        View& v = h->views[h->order[k]];
+        v.median_depth = h->chain_summary[k].median_depth;      // line3D.cc:835
+        h->stat_kept += h->chain_summary[k].n_kept;
+        mark_matched(h, v);                                     // line3D.cc:875-881
+    }
+    h->resident_products = true;
+    if (h->keep_view_matches) {
+        for (size_t k = 0; k < P.n; ++k) {
+            l3d_match* m = nullptr; int n = 0;
+            rc = l3d_chain_kept_list(h->ctx, (int)k, &m, &n);
+            if (rc) return h->fail(rc, std::string("kept_list: ") + l3d_last_error(h->ctx));
+            h->view_matches[h->order[k]].assign(m, m + n);
+            l3d_free(m);
+        }
+    }
+    if (getenv("L3D_CHECK_POT")) { rc = check_resident_products(h, P); if (rc) return rc; }
+    double st[4];
+    l3d_last_stats(h->ctx, st);
+    h->stat_pairs += st[0];
+    h->stat_raw += st[1];
+    h->t_match = now_s() - t0;
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d match_views] resident chain + device products %.2f ms\n", (now_s() - t1) * 1e3);
+    return L3D_OK;
+}
+
 int match_views(L* h)
 {
     if (h->force_sync) return match_views_sync(h);
@@ -1211,6 +1334,10 @@ int match_views(L* h)
     if (!Pp) return match_views_sync(h);
     ChainPlan& P = *Pp;
     const double tb = now_s();
+    if (!(h->host_bookkeeping || getenv("L3D_HOST_BOOKKEEPING") || getenv("L3D_AFFINITY_HOST"))) {
+        const int rr = match_views_resident(h, P, t0);
+        if (rr != L3D_ERR_UNSUPPORTED) return rr;           // (more kept matches than the device builder takes: host lists)
+    }
     start_finalizer(h, P);
     const double t1 = now_s();
     int rc = l3d_match_chain(h->ctx, P.cv.data(), (int)P.n, chain_callback, &P.user);
@@ -1229,18 +1356,11 @@ int match_views(L* h)
     return L3D_OK;
 }
 
-// L3DView::unprojectSegment, view.cc:302-342
+// L3DView::unprojectSegment, view.cc:302-342 (the arithmetic is shared with the device: l3d_unproject.hpp)
 void unproject_segment(const View& v, uint32_t id, float d1, float d2, Hyp& o)
 {
     const float* s = &v.segs[(size_t)id * 4];
-    V3 r1 = mul(v.RtKinv, V3{ s[0], s[1], 1.0 });
-    r1 = r1 / norm(r1);
-    V3 r2 = mul(v.RtKinv, V3{ s[2], s[3], 1.0 });
-    r2 = r2 / norm(r2);
-    o.P1 = v.C + r1 * (double)d1;
-    o.P2 = v.C + r2 * (double)d2;
-    o.dir = o.P2 - o.P1;
-    o.dir = o.dir / norm(o.dir);
+    l3d::unproject_segment_f64(v.RtKinv, v.C, s[0], s[1], s[2], s[3], d1, d2, o.P1, o.P2, o.dir);
     o.depth_p1 = d1; o.depth_p2 = d2;
 }
 
@@ -1485,6 +1605,96 @@ void align_cluster(const std::vector<std::pair<Key, std::pair<V3, V3>>>& t3, std
                          [&](V3 s0, V3 e0) { aligned.emplace_back(s0, e0); });
 }
 
+// segment2collinearities_ of all views as one CSR over dense ids (static per scene: kept between calls)
+void pack_collinearities(L* h, const std::vector<size_t>& voff)
+{
+    L::AffTables& T = h->aff;
+    const size_t nv = h->vlist.size(), ndense = voff.back();
+    if (T.coll_valid && T.coll_start.size() == ndense + 1) return;
+    T.coll_start.resize(ndense + 1);
+    int64_t* coll_start = T.coll_start.data();
+    coll_start[0] = 0;
+    for (size_t vi = 0; vi < nv; ++vi) {
+        const View& sv = *h->vlist[vi];
+        for (size_t sg = 0; sg < (size_t)sv.S(); ++sg) coll_start[voff[vi] + sg + 1] = coll_start[voff[vi] + sg] + (sv.coll_start[sg + 1] - sv.coll_start[sg]);
+    }
+    const size_t n_coll = (size_t)coll_start[ndense];
+    T.coll_other.resize(n_coll + 1); T.coll_w.resize(n_coll + 1);
+    int32_t* coll_other = T.coll_other.data();
+    float* coll_w = T.coll_w.data();
+    std::atomic<size_t> next{ 0 };
+    l3d::on_threads(std::min<unsigned>(finish_threads(), (unsigned)std::max<size_t>(1, nv)), [&](unsigned) {
+        for (;;) {
+            const size_t vi = next.fetch_add(1, std::memory_order_relaxed);
+            if (vi >= nv) break;
+            const View& sv = *h->vlist[vi];
+            const size_t cb = (size_t)coll_start[voff[vi]], cn = sv.coll_other.size();
+            for (size_t q = 0; q < cn; ++q) { coll_other[cb + q] = (int32_t)(voff[vi] + (size_t)sv.coll_other[q]); coll_w[cb + q] = sv.coll_w[q]; }
+        }
+    });
+    T.coll_valid = false;           // (the caller uploads, then marks it valid)
+}
+
+// Line3D::greedySelection (line3D.cc:899-965) on the device-resident products of matchViews (l3d_products_hypotheses): the host
+// keeps only what the result needs -- which 2-D segment every hypothesis belongs to
+int greedy_selection_resident(L* h)
+{
+    const size_t nv = h->vlist.size();
+    std::vector<l3d_view_geometry> geo(nv);
+    for (size_t i = 0; i < nv; ++i) {
+        const View& v = *h->vlist[i];
+        l3d_view_geometry& g = geo[i];
+        memcpy(g.RtKinv, v.RtKinv.m, 72);
+        g.C[0] = v.C.x; g.C[1] = v.C.y; g.C[2] = v.C.z;
+        g.k_lower = v.k_lower; g.k_upper = v.k_upper; g.median_depth = v.median_depth;
+        g.n_segments = v.S(); g.segments = v.segs.data();
+    }
+    std::vector<int32_t> vhb(nv + 1, 0);
+    int32_t* hyp_dense = nullptr; int nh = 0;
+    int rc = l3d_products_hypotheses(h->ctx, geo.data(), (int)nv, vhb.data(), &hyp_dense, &nh);
+    if (rc) return h->fail(rc, std::string("hypotheses: ") + l3d_last_error(h->ctx));
+    h->hyp_begin.assign(nv + 1, 0);
+    for (size_t i = 0; i <= nv; ++i) h->hyp_begin[i] = (size_t)vhb[i];
+    h->hyps.resize((size_t)nh);
+    h->aff.hyp_cam.resize((size_t)nh);
+    h->best_idx.clear();
+    std::vector<size_t> voff(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
+    parallel_slices(nv, finish_threads(), [&](size_t v0, size_t v1, unsigned) {
+        for (size_t vi = v0; vi < v1; ++vi)
+            for (size_t k = h->hyp_begin[vi]; k < h->hyp_begin[vi + 1]; ++k) {
+                h->hyps[k].src = mk(h->vlist[vi]->id, (uint32_t)((size_t)hyp_dense[k] - voff[vi]));
+                h->aff.hyp_cam[k] = h->vlist[vi]->id;
+            }
+    });
+    l3d_free(hyp_dense);
+    return L3D_OK;
+}
+
+// the affinity fill on the resident tables (l3d_affinity_fill_resident): only the collinearity CSR comes from the host, once per scene
+int fill_affinity_resident(L* h)
+{
+    const size_t nv = h->vlist.size();
+    std::vector<size_t> voff(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
+    L::AffTables& T = h->aff;
+    const bool changed = !T.coll_valid || T.coll_start.size() != voff.back() + 1;
+    if (changed) pack_collinearities(h, voff);
+    l3d_edge* edges = nullptr; int32_t* node_hyp = nullptr; int n_edges = 0, n_nodes = 0, n_cand = 0;
+    int rc = l3d_affinity_fill_resident(h->ctx, T.coll_start.data(), T.coll_other.data(), T.coll_w.data(), changed ? 1 : 0, h->sigma_a, &edges, &n_edges, &node_hyp, &n_nodes, &n_cand);
+    if (rc) return h->fail(rc, std::string("affinity fill: ") + l3d_last_error(h->ctx));
+    T.coll_valid = true;
+    const unsigned nt = finish_threads();
+    h->A.resize((size_t)n_edges);
+    parallel_slices((size_t)n_edges, nt, [&](size_t k0, size_t k1, unsigned) { if (k1 > k0) memcpy(&h->A[k0], edges + k0, (k1 - k0) * sizeof(l3d_edge)); });
+    h->local2global.resize((size_t)n_nodes);
+    for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
+    h->node_hyp.assign(node_hyp, node_hyp + n_nodes);
+    l3d_free(edges); l3d_free(node_hyp);
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges (resident tables)\n", h->hyps.size(), n_cand, h->A.size());
+    return L3D_OK;
+}
+
 // Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
 // (l3d_affinity_fill, l3d_clustering_edges), union-find and line fit here; the round-1 host stages remain as the cross-check
 // (L3D_AFFINITY_HOST=1) and for edge lists the device path refuses.
@@ -1517,7 +1727,12 @@ int cluster_segments_2D(L* h, bool perform_diff)
     if (hyp_begin.size() != nv + 1 || hyp_begin[nv] != nh) return h->fail(L3D_ERR_INVALID, "hypothesis ranges do not match the views");
 
     bool resident_list = false;                     // the affinity list is still on the device (l3d_affinity_fill ran last)
-    if (!getenv("L3D_AFFINITY_HOST")) {
+    if (h->resident_products) {
+        const int rc = fill_affinity_resident(h);
+        if (rc) return rc;
+        resident_list = true;
+        lap("affinity fill (resident tables)");
+    } else if (!getenv("L3D_AFFINITY_HOST")) {
         resident_list = true;
         // ---- the whole fill on the device (l3d_affinity.hip): flat tables in, edge list and node numbering out
         const unsigned nt = finish_threads();
@@ -1868,7 +2083,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
         int32_t* cnt = nullptr; double* segs = nullptr; int n_segs = 0;
         const double tneg[3] = { h->transf_tneg.x, h->transf_tneg.y, h->transf_tneg.z };
         // (hyp = null: the table l3d_affinity_fill uploaded in this finish is still on the device)
-        const int rc = l3d_fit_clusters(h->ctx, gstart.data(), (int)gof.size(), memb.data(), nullptr, h->aff.hyp_cam.data(), (int)h->aff.hyp.size(),
+        const int rc = l3d_fit_clusters(h->ctx, gstart.data(), (int)gof.size(), memb.data(), nullptr, h->aff.hyp_cam.data(), (int)h->hyps.size(),
                                         h->transf_Rinv.m, h->transf_scale_inv, tneg, &cnt, &segs, &n_segs);
         if (rc) return h->fail(rc, std::string("line fit: ") + l3d_last_error(h->ctx));
         lap("  fit: device");
@@ -1948,6 +2163,7 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
     h->sigma_p = sigma_p; h->sigma_a = sigma_a; h->min_baseline = min_baseline;
     h->use_collinearity = use_collinearity != 0;
     h->force_sync = getenv("L3D_MATCH_SYNC") != nullptr;
+    h->host_bookkeeping = getenv("L3D_HOST_BOOKKEEPING") != nullptr || getenv("L3D_AFFINITY_HOST") != nullptr;
     *out = h;
     return L3D_OK;
 }
@@ -2044,8 +2260,13 @@ int l3d_line3d_match_views(l3d_line3d* h)
 int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    if (h->resident_products && getenv("L3D_AFFINITY_HOST")) {     // the host cross-check works on host lists: match again with them
+        const int rm = match_views(h);
+        if (rm) return rm;
+    }
     const double t0 = now_s();
-    greedy_selection(h);                                   // optimizeLocalMatches, :888-896
+    if (h->resident_products) { const int rg = greedy_selection_resident(h); if (rg) return rg; }
+    else greedy_selection(h);                              // optimizeLocalMatches, :888-896
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
     const int rc = cluster_segments_2D(h, perform_diffusion != 0);
     if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "total", (now_s() - t0) * 1e3);
