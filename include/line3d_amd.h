@@ -428,6 +428,12 @@ int l3d_line3d_set_sync_matching(l3d_line3d* h, int on);
 int l3d_line3d_keep_view_matches(l3d_line3d* h, int on);
 int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median);
 int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes);
+/* the device-resident products of the last matchViews (l3d_match_chain_resident) and, after finish, the hypothesis table of
+ * greedySelection, copied to the host for inspection: sizes first (0 views: no resident products -- sync / host-bookkeeping /
+ * sharded matching), then the arrays (any pointer may be NULL): seg_base n_views + 1, pot_start n_dense + 1, pot_tgt n_pot,
+ * best n_dense (segID1 == 0xffffffff: none), hyp / score n_hyp */
+int l3d_line3d_products_sizes(const l3d_line3d* h, int* n_views, int* n_dense, int64_t* n_pot, int* n_hyp);
+int l3d_line3d_products_get(l3d_line3d* h, int32_t* seg_base, int64_t* pot_start, int32_t* pot_tgt, l3d_match* best, l3d_hypothesis* hyp, float* score);
 int l3d_line3d_stats(const l3d_line3d* h, double* stats12);
 
 /* =================================================================================================

@@ -24,7 +24,7 @@ static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
 static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
 
 namespace {
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity;tgt_rays;prod_keys;prod_sort;hypotheses";
 }  // namespace
 
 extern "C" {

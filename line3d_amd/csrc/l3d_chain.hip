@@ -735,15 +735,17 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     cv_work.notify_one();
     deliverer.join();
     if (rc_final == L3D_OK && deliver_rc) rc_final = fail(c, deliver_rc, deliver_err);
-    if (getenv("L3D_TIMING"))
-        fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
-                (t_loop0 - t_setup0) * 1e3, (now_s() - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
+    const double t_prod0 = now_s();
     if (rc_final == L3D_OK && map) {
         // ---- the products of matchViews, on the device, from the arena (l3d_products.hip); enqueued behind the last view
         std::vector<ProdChainView> pv((size_t)n_views);
         for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0 };
         rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot);
     }
+    if (getenv("L3D_TIMING"))
+        fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
+                (t_loop0 - t_setup0) * 1e3, (t_prod0 - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
+    if (getenv("L3D_TIMING") && map) fprintf(stderr, "[l3d match_chain] products on the device %.2f ms\n", (now_s() - t_prod0) * 1e3);
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);

@@ -2538,6 +2538,27 @@ int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* 
     if (n_nodes) *n_nodes = (int)h->local2global.size();
     return L3D_OK;
 }
+int l3d_line3d_products_sizes(const l3d_line3d* h, int* n_views, int* n_dense, int64_t* n_pot, int* n_hyp)
+{
+    if (!h) return L3D_ERR_INVALID;
+    const bool on = h->resident_products;
+    int nd = 0;
+    for (const View* v : h->vlist) nd += v->S();
+    if (n_views) *n_views = on ? (int)h->vlist.size() : 0;
+    if (n_dense) *n_dense = on ? nd : 0;
+    if (n_pot) *n_pot = on ? h->resident_n_pot : 0;
+    if (n_hyp) *n_hyp = on ? (int)h->hyps.size() : 0;
+    return L3D_OK;
+}
+int l3d_line3d_products_get(l3d_line3d* h, int32_t* seg_base, int64_t* pot_start, int32_t* pot_tgt, l3d_match* best, l3d_hypothesis* hyp, float* score)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (!h->resident_products) return h->fail(L3D_ERR_INVALID, "no resident products");
+    if (seg_base) { int b = 0; size_t i = 0; for (const View* v : h->vlist) { seg_base[i++] = b; b += v->S(); } seg_base[i] = b; }
+    int rc = l3d_chain_products_get(h->ctx, pot_start, pot_tgt, best);
+    if (!rc && (hyp || score) && !h->hyps.empty()) rc = l3d_products_hypotheses_get(h->ctx, hyp, score);
+    return rc ? h->fail(rc, std::string("products_get: ") + l3d_last_error(h->ctx)) : L3D_OK;
+}
 /* stats[12]: pairs, raw candidates, kept, #hypotheses, t_match, t_gpu_call, t_commit, t_finalize, t_affinity, t_cluster, #edges, #lines */
 int l3d_line3d_stats(const l3d_line3d* h, double* s)
 {

@@ -246,6 +246,24 @@ class Line3D:
             C.memmove(res.ctypes.data, p, nnz.value * 12)
         return res, nn.value
 
+    def resident_products(self):
+        """The device-resident products of the last match_views (and, after finish, the hypothesis table), copied to the host:
+        None when matchViews ran with host bookkeeping.  dict(seg_base, pot_start, pot_tgt, best, hyp, score)."""
+        nv, nd, nh = C.c_int(0), C.c_int(0), C.c_int(0)
+        npot = C.c_int64(0)
+        self._chk(self.lib.l3d_line3d_products_sizes(self.h, C.byref(nv), C.byref(nd), C.byref(npot), C.byref(nh)))
+        if nv.value == 0:
+            return None
+        seg_base = np.zeros(nv.value + 1, np.int32)
+        pot_start = np.zeros(nd.value + 1, np.int64)
+        pot_tgt = np.zeros(max(1, npot.value), np.int32)
+        best = np.zeros(nd.value, MATCH_DTYPE)
+        hyp = np.zeros(max(1, nh.value), capi.HYP_DTYPE)
+        score = np.zeros(max(1, nh.value), np.float32)
+        self._chk(self.lib.l3d_line3d_products_get(self.h, _p(seg_base), _p(pot_start), _p(pot_tgt), _p(best), _p(hyp) if nh.value else None,
+                                                   _p(score) if nh.value else None))
+        return dict(seg_base=seg_base, pot_start=pot_start, pot_tgt=pot_tgt[:npot.value], best=best, hyp=hyp[:nh.value], score=score[:nh.value])
+
     def stats(self):
         s = (C.c_double * 12)()
         self._chk(self.lib.l3d_line3d_stats(self.h, s))
