@@ -48,31 +48,52 @@ def parse():
     ap.add_argument("--cpu-sample-segments", type=int, default=1500)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) rest of compute3Dmodel after the timed passes")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold measurement (first matchViews + first finish of the fresh object)")
     return ap.parse_args()
 
 
-def cpu_baseline(scene, n_neighbors, sample_segments):
-    """The oracle (scalar C restatement of the reference formulation, 1 thread) on a bounded sample of the same
-    workload: view 0 of the scene, the first `sample_segments` source segments against all its neighbours,
-    stage 1 + sort + stage 2 + filter.  Reported, never the target."""
+def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
+    """The oracle (scalar C restatement of the reference formulation, 1 thread) on a bounded sample of the same workload: a
+    MID-CHAIN view of the scene (half of its neighbours still to be matched, the other half already matched: their kept
+    matches towards it -- taken from `lists`, the GPU run's kept lists -- come back as existing matches, line3D.cc:806,838-872),
+    the first `sample_segments` source segments, stage 1 + sort + stage 2 + filter.  Reported, never the target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import l3d_oracle_pipeline as op
+    V = len(scene.views)
+    vid = scene.views[V // 2]["id"] if lists is not None else scene.views[0]["id"]
     o = op.OracleLine3D(matching_neighbors=n_neighbors, use_collinearity=False)
-    for v in scene.views[: n_neighbors + 1]:
-        sims = {k: s for k, s in v["sims"].items() if k <= n_neighbors}
-        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], sims)
+    for v in scene.views:
+        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
     o.computation = True
     o.matched, o.potential = {}, {}
     o.find_visual_neighbors()
     o.transform_geometry()
-    vid = scene.views[0]["id"]
     for n in o.visual_neighbors[vid]:
         o._fundamental(vid, n)
+    existing = np.zeros(0, dtype=op.MATCH_DTYPE)
+    if lists is not None:
+        for a in range(vid):                              # matched_ after the earlier views (line3D.cc:875-881; ids are 0..V-1 in order)
+            for nb in o.visual_neighbors[a]:
+                o.matched.setdefault(a, {})[nb] = True
+                if a in o.visual_neighbors.get(nb, []):
+                    o.matched.setdefault(nb, {})[a] = True
     mv = o.marshal_view(vid)
+    if lists is not None:
+        ex = []
+        for a in range(vid):
+            m = lists[a]
+            sel = m[m["camID2"] == vid]
+            if len(sel) and a in mv["g2l"]:
+                r = np.zeros(len(sel), dtype=op.MATCH_DTYPE)
+                r["segID1"], r["segID2"], r["camID2"] = sel["segID2"], sel["segID1"], mv["g2l"][a]
+                r["depths"] = sel["depths"][:, [2, 3, 0, 1]]
+                ex.append(r)
+        if ex:
+            existing = np.concatenate(ex)
     t0 = time.time()
     m, med, stats = op.compute_pairwise_matches(
         o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
-        mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"],
+        mv["centers"], mv["P"], mv["tbm"], existing, mv["l2g"], mv["k_upper"], mv["k_lower"],
         3.5, 10.0, mv["spatial_k"], seg_range=(0, sample_segments), want_stats=True)
     dt = time.time() - t0
     # the same formulation on all host threads: one source-segment range of the same view per thread (the C oracle releases
@@ -87,7 +108,7 @@ def cpu_baseline(scene, n_neighbors, sample_segments):
         s0 = (i * per) % max(1, S - per + 1)
         _m, _med, st = op.compute_pairwise_matches(
             o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
-            mv["centers"], mv["P"], mv["tbm"], np.zeros(0, dtype=op.MATCH_DTYPE), mv["l2g"], mv["k_upper"], mv["k_lower"],
+            mv["centers"], mv["P"], mv["tbm"], existing, mv["l2g"], mv["k_upper"], mv["k_lower"],
             3.5, 10.0, mv["spatial_k"], seg_range=(s0, s0 + per), want_stats=True)
         res[i] = st[3]
 
@@ -101,11 +122,13 @@ def cpu_baseline(scene, n_neighbors, sample_segments):
             t.join()
         dta = time.time() - t1
         all_threads = dict(value=float(sum(r for r in res if r)) / dta, cores=nthreads, seconds=dta,
-                           sample="%d threads (usable CPUs of this container) x %d source segments of view 0" % (nthreads, per))
+                           sample="%d threads (usable CPUs of this container) x %d source segments of view %d" % (nthreads, per, vid))
     return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
-                sample="view 0 of the bench scene, first %d of %d source segments x %d neighbours: %d pairs, %d raw candidates, "
-                       "%.3g verify inner iterations, %.1f s on 1 thread (oracle/l3d_oracle.c, reference formulation)"
-                       % (sample_segments, len(mv["src_segs"]), len(mv["tbm"]), int(stats[3]), int(stats[0]), stats[2], dt),
+                sample="view %d of %d of the bench scene (mid-chain: %d cameras still to match, %d existing reverse matches from the %d already "
+                       "matched), first %d of %d source segments: %d pairs, %d raw candidates, %.3g verify inner iterations, %.1f s on 1 thread "
+                       "(oracle/l3d_oracle.c, reference formulation)"
+                       % (vid, V, len(mv["tbm"]), len(existing), len(mv["l2g"]) - len(mv["tbm"]), sample_segments, len(mv["src_segs"]), int(stats[3]),
+                          int(stats[0]), stats[2], dt),
                 seconds=dt, verify_iterations_per_s=stats[2] / dt)
 
 
@@ -131,12 +154,31 @@ def main():
 
     V = args.views_per_gpu * n_gpus
     scene = make_scene(V, args.segments, args.neighbors, seed=args.seed)
+    t0 = time.perf_counter()
     l3d = Line3D("", matchingNeighbors=args.neighbors, device=local_rank)
-    t0 = time.time()
-    load_scene(l3d, scene)               # uploads segments, per-view collinearity (HIP)
-    l3d.prepare()                        # neighbours, scene normalisation; inputs become HBM-resident
-    t_setup = time.time() - t0
+    t_create = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    load_scene(l3d, scene)               # addImage_fixed_sim per view (host only: the segments go to HBM in prepare)
+    t_add = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    l3d.prepare()                        # neighbours, scene normalisation, residency of all segment arrays, collinearity of all views
+    t_prepare = time.perf_counter() - t0
+    t_setup = t_add + t_prepare
     ctx = l3d.context()
+    cold = None
+    if dist is None and not args.no_cold:
+        # what ONE compute3Dmodel of a fresh object costs (line3D.cc:345-374): the first matchViews and the first finish of the process,
+        # before any warm-up (the timed passes below are passes 2.. of the same object)
+        t0 = time.perf_counter()
+        l3d.match_views()
+        t_m = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        l3d.finish(False)
+        t_f = time.perf_counter() - t0
+        cold = dict(create_s=t_create, add_images_s=t_add, prepare_s=t_prepare, first_match_views_s=t_m, first_finish_s=t_f,
+                    compute3Dmodel_total_s=t_prepare + t_m + t_f,
+                    note="fresh process, fresh object, no warm-up: compute3Dmodel = prepare + matchViews + finish (no diffusion); create = context, "
+                         "streams and the start of the code-object loading that overlaps add_images")
 
     def sync():
         if dist is not None:
@@ -240,6 +282,20 @@ def main():
         value = pairs_total * args.steps / dt
         # dominant kernel = the one with the largest summed duration on this rank
         roof = None
+        def prof_json(kind):
+            """profiles/<round>_<kind>.json of the newest round that has one: per-kernel PMC figures of this same command (scripts/measure_round.sh),
+            stamped with the commit they were measured on -- NOT measured in this run."""
+            for r in ("r3", "r2", "r1"):
+                q = os.path.join(ROOT, "profiles", "%s_%s.json" % (r, kind))
+                if os.path.exists(q):
+                    d = json.load(open(q))
+                    return d, "profiles/%s_%s.json @%s" % (r, kind, d.get("_commit", "unstamped"))
+            return {}, None
+
+        traffic_json, traffic_src = prof_json("traffic")
+        valu_json, valu_src = prof_json("valu")
+        PEAK_ISSUE = 256 * 4 * 2.4e9 / 4.0      # wave64 VALU instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, one instruction per SIMD every 4 cycles
+
         def kernel_roof(name, launches, ms):
             # algorithmic HBM bytes per launch (DESIGN.md section 4): one launch = one view
             nv = max(1, len(scene.views))
@@ -254,39 +310,52 @@ def main():
                 "exist": 2 * 32.0 * st["kept"] / nv * n_tbm,  # the sources' kept lists are read twice (count, scatter)
             }.get(name, 0.0)
             avg_ms = ms / max(1, launches)
-            achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic = None
-            tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic.json") for r in ("r2", "r1")) if os.path.exists(q)), "")
-            if os.path.exists(tpath):     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/README.md)
-                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
-            valu = None
-            vpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_valu.json") for r in ("r2", "r1")) if os.path.exists(q)), "")
-            if os.path.exists(vpath) and avg_ms > 0:   # wave-level VALU instructions per launch (PMC pass of this same command)
-                vi = json.load(open(vpath)).get(name, {}).get("valu_wave_insts_per_launch")
-                if vi:
-                    peak_issue = 256 * 4 * 2.4e9 / 4.0      # one wave64 VALU instruction per SIMD every 4 cycles
-                    valu = dict(wave_insts_per_launch=vi, issue_frac=vi / (avg_ms * 1e-3) / peak_issue,
-                                note="SQ_INSTS_VALU per launch / launch duration / (256 CUs x 4 SIMDs x 2.4 GHz / 4)")
-            # the meaningful fraction for this path is FP32 VALU.  Reference-formulation flops of the dominant kernel per launch
-            # (370 per stage-1 pair, 280 per verify inner iteration of the all-pairs loop) over its measured duration against the 157.3
-            # TFLOP/s vector peak: an EQUIVALENT rate -- the kernels do the reference's arithmetic only on the pairs their conservative
-            # filters / depth windows cannot exclude, so it may exceed what the VALUs actually execute (see `valu` for that)
+            hbm_achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic = traffic_json.get(name, {}).get("hbm_bytes_per_launch")
+            hbm = dict(bound="hbm", achieved=hbm_achieved, peak=8000.0, unit="GB/s", frac=hbm_achieved / 8000.0, algorithmic_bytes_per_launch=alg, traffic=traffic,
+                       traffic_source=traffic_src, note="SURVEY 8d's 4.5 B per pair x the pairs of one launch / its measured duration: the path's inputs are a few "
+                                                        "hundred KB per view and stay in L2 / LDS, so this fraction is tiny by nature")
+            # the bound of this path is FP32 VALU issue.  achieved = wave-level VALU instructions per launch (PMC, committed profile) /
+            # the launch duration measured live in THIS run; peak = the chip's issue rate
+            vi = valu_json.get(name, {}).get("valu_wave_insts_per_launch")
+            out = dict(bound="valu", kernel=name, launches=launches, avg_launch_ms=avg_ms, hbm=hbm, traffic=traffic)
+            if vi and avg_ms > 0:
+                ach = vi / (avg_ms * 1e-3)
+                out.update(achieved=ach / 1e9, peak=PEAK_ISSUE / 1e9, unit="G wave-instructions/s", frac=ach / PEAK_ISSUE, valu_wave_insts_per_launch=vi, source=valu_src,
+                           note="issue fraction: SQ_INSTS_VALU per launch (rocprofv3 --pmc pass of this command, committed under profiles/ at the commit "
+                                "named in `source`) / launch duration by HIP events in this run / (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)")
+            else:
+                out.update(achieved=hbm_achieved, peak=8000.0, unit="GB/s", frac=hbm_achieved / 8000.0, bound="hbm",
+                           note="no committed VALU profile found: the HBM figure stands in (the path is VALU bound, SURVEY 8d)")
+            # reference-formulation flops over the measured duration against the 157.3 TFLOP/s vector peak: an EQUIVALENT rate (the kernels run the
+            # reference's arithmetic only on the pairs their conservative filters / depth windows cannot exclude)
             ref_flops = {"pair_mask": 370.0 * pairs_per_launch, "pair_fill": 360.0 * R_per_launch}.get(name)
-            flops = None
             if ref_flops and avg_ms > 0:
                 tf = ref_flops / (avg_ms * 1e-3) / 1e12
-                flops = dict(reference_formulation_flops_per_launch=ref_flops, equivalent_tflops=tf, peak_tflops=157.3, frac=tf / 157.3,
-                             note="reference-formulation flops / measured launch duration; not a count of executed instructions")
-            return dict(bound="hbm", kernel=name, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, fp32_equivalent=flops,
-                        traffic=traffic, valu=valu, launches=launches, avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=alg)
+                out["fp32_equivalent"] = dict(reference_formulation_flops_per_launch=ref_flops, equivalent_tflops=tf, peak_tflops=157.3, frac=tf / 157.3,
+                                              note="reference-formulation flops / measured launch duration; not a count of executed instructions")
+            return out
 
         if prof:
             name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
             roof = kernel_roof(name, launches, ms)
-            roof["note"] = ("the path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d): inputs are a few hundred KB per "
-                            "view and stay in L2/LDS; kernels_ms = per-kernel time of one untimed pass with every kernel bracketed; "
-                            "in the timed region only the dominant kernel carries HIP events")
             roof["kernels_ms"] = {k: round(v[1], 3) for k, v in prof_all.items()}
+            roof["kernels_note"] = ("kernels_ms = per-kernel time of one untimed pass with every kernel bracketed (two streams: the times overlap); in the timed "
+                                    "region only the dominant kernel carries HIP events")
+            # the whole pass against the issue peak: summed VALU instructions of all kernels of one pass (committed PMC profile) over the wall time of a
+            # pass (this run) and over the time the GPU is busy (the longer of the two streams' kernel sums of the bracketed pass: an upper bound of busy)
+            tot_vi = 0.0
+            for kname, (kl, _kms) in prof_all.items():
+                tot_vi += valu_json.get(kname, {}).get("valu_wave_insts_per_launch", 0.0) * kl
+            if tot_vi > 0:
+                km = roof["kernels_ms"]
+                s1 = sum(km.get(k, 0.0) for k in ("pair_mask", "row_count", "pair_fill", "tgt_rays"))
+                s2 = sum(km.get(k, 0.0) for k in ("scan", "cand_move", "exist", "verify_window", "verify", "seg_post", "kept_write", "prod_keys", "prod_sort"))
+                busy_ms = max(s1, s2)
+                roof["pass"] = dict(valu_wave_insts=tot_vi, issue_frac_of_wall=tot_vi / (ms_per_step * 1e-3) / PEAK_ISSUE,
+                                    issue_frac_of_gpu_busy=(tot_vi / (busy_ms * 1e-3) / PEAK_ISSUE) if busy_ms > 0 else None, gpu_busy_ms=busy_ms,
+                                    source=valu_src, note="sum over kernels of (VALU wave instructions per launch x launches of one pass) / (wall time of a pass | the longer "
+                                                          "stream's kernel time of the bracketed pass) / issue peak")
             # k_pair_mask and k_verify_window take about the same time per pass: which one is named dominant changes from run to run.
             # The other one, from the untimed bracketed pass (one launch per view), so that both are always in the line
             others = sorted(((k, v) for k, v in prof_all.items() if k != name), key=lambda kv: -kv[1][1])
@@ -303,7 +372,7 @@ def main():
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
                                parallelism=("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU"),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
-                   kept_per_step=st["kept"], setup_s=t_setup,
+                   kept_per_step=st["kept"], setup_s=t_setup, cold=cold,
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))
         if roof:
             out["roofline"] = roof
@@ -323,6 +392,8 @@ def main():
                 t1 = time.perf_counter()
                 l3d.finish(diff)
                 t_first = time.perf_counter() - t1
+                if not diff and cold:
+                    t_first = cold["first_finish_s"]       # (the real first call was the cold one)
                 t1 = time.perf_counter()
                 l3d.finish(diff)
                 st2 = l3d.stats()
@@ -342,7 +413,12 @@ def main():
                 ex["rdd"] = dict(error=str(e))
             out["rest_of_compute3Dmodel"] = ex
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments)
+            lists = None
+            if dist is None:                       # the kept lists of the earlier views feed the oracle's mid-chain sample (checker input, untimed)
+                l3d.keep_view_matches(True)
+                l3d.match_views()
+                lists = {v["id"]: l3d.view_matches(v["id"])[0] for v in scene.views[: len(scene.views) // 2]}
+            out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments, lists)
         print(json.dumps(out))
     l3d.close()
     if dist is not None:

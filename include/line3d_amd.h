@@ -321,6 +321,8 @@ int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_rec
  * host pointers that were registered (same pointer, same size) and skips the upload. */
 int l3d_register_segments(l3d_ctx* ctx, const float* segments, int n_segments);
 int l3d_unregister_segments(l3d_ctx* ctx, const float* segments);
+/* the same for many arrays at once (all views of a scene): one device allocation, one wait */
+int l3d_register_segments_batch(l3d_ctx* ctx, const float* const* arrays, const int* n_segments, int n_arrays);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the context's stream;
@@ -340,6 +342,12 @@ int l3d_set_verify_lds_budget(size_t bytes);
 /* testing: initial candidate / kept-arena capacities (records) of the resident chain, 0 = the built-in estimate; small
  * values force the overflow -> grow -> restart-at-that-view path */
 int l3d_set_chain_capacities(l3d_ctx* ctx, size_t cand_cap, size_t arena_cap);
+/* loads the code objects of every kernel of the library now (in parallel) instead of at their first launch: takes the
+ * ~10 x 3 ms of lazy loading out of the first matchViews / finish of a process */
+int l3d_warm_up(l3d_ctx* ctx);
+/* reserves the device arenas of the finishing stages (greedy selection, affinity fill, edge order, line fit) ahead of their
+ * first use, from the size of the scene: a hint, the arenas still grow on demand */
+int l3d_reserve_hint(l3d_ctx* ctx, int n_dense, int n_views, int n_neighbors);
 int l3d_profile_enable(l3d_ctx* ctx, int on);
 /* bracket only the named kernel with HIP events (NULL or "": all kernels) -- keeps a timed region nearly undisturbed */
 int l3d_profile_only(l3d_ctx* ctx, const char* kernel);

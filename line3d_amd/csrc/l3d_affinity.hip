@@ -698,3 +698,5 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
 }
 
 }  // extern "C"
+
+void l3d::warm_affinity() { touch_kernel(reinterpret_cast<const void*>(&k_aff_fill)); }

@@ -14,6 +14,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <thread>
+
 #include "l3d_ctx.hpp"
 #include "l3d_hostsort.hpp"
 
@@ -94,7 +96,8 @@ void l3d_ctx_destroy(l3d_ctx* c)
     c->products.release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
-    for (auto& kv : c->resident) (void)hipFree(kv.second.first);
+    for (auto& kv : c->resident) if (!c->resident_arena_of.count(kv.first)) (void)hipFree(kv.second.first);
+    for (auto& a : c->resident_arenas) if (a.first) (void)hipFree(a.first);
     (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
@@ -117,11 +120,54 @@ int l3d_register_segments(l3d_ctx* c, const float* segments, int n_segments)
     return L3D_OK;
 }
 
+// Many arrays at once (all views of a scene): ONE device allocation, the copies queued back to back, one wait -- 128 separate
+// hipMalloc + synchronous hipMemcpy pairs were 20 ms of a 24 ms prepare() at config 2.
+int l3d_register_segments_batch(l3d_ctx* c, const float* const* arrays, const int* counts, int n)
+{
+    if (!c || n < 0 || (n > 0 && (!arrays || !counts))) return fail(c, L3D_ERR_INVALID, "l3d_register_segments_batch: bad argument");
+    if (n == 0) return L3D_OK;
+    (void)hipSetDevice(c->device);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!arrays[i] || counts[i] < 0) return fail(c, L3D_ERR_INVALID, "l3d_register_segments_batch: bad argument");
+        total += ((size_t)counts[i] * 16 + 255) & ~(size_t)255;
+    }
+    for (int i = 0; i < n; ++i) l3d_unregister_segments(c, arrays[i]);
+    char* base = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&base), total ? total : 256));
+    const int arena = (int)c->resident_arenas.size();
+    c->resident_arenas.push_back({ base, 0 });
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (c->resident.count(arrays[i])) continue;                          // (the same array twice in one batch)
+        const size_t bytes = (size_t)counts[i] * 16;
+        if (bytes) {
+            hipError_t e = hipMemcpyAsync(base + off, arrays[i], bytes, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); return fail(c, L3D_ERR_HIP, std::string("l3d_register_segments_batch: ") + hipGetErrorString(e)); }
+        }
+        c->resident[arrays[i]] = { base + off, bytes };
+        c->resident_arena_of[arrays[i]] = arena;
+        c->resident_arenas[(size_t)arena].second += 1;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->resident_arenas[(size_t)arena].second == 0) { (void)hipFree(base); c->resident_arenas[(size_t)arena].first = nullptr; }
+    return L3D_OK;
+}
+
 int l3d_unregister_segments(l3d_ctx* c, const float* segments)
 {
     if (!c) return L3D_ERR_INVALID;
     auto it = c->resident.find(segments);
-    if (it != c->resident.end()) { (void)hipFree(it->second.first); c->resident.erase(it); }
+    if (it == c->resident.end()) return L3D_OK;
+    auto ia = c->resident_arena_of.find(segments);
+    if (ia == c->resident_arena_of.end()) (void)hipFree(it->second.first);
+    else {                                                                    // a slice of a batch allocation: freed with its last slice
+        auto& a = c->resident_arenas[(size_t)ia->second];
+        if (--a.second == 0 && a.first) { (void)hipFree(a.first); a.first = nullptr; }
+        c->resident_arena_of.erase(ia);
+    }
+    c->resident.erase(it);
     return L3D_OK;
 }
 
@@ -148,6 +194,55 @@ int l3d_profile_get(l3d_ctx* c, const char* kernel, int64_t* launches, double* t
     return L3D_OK;
 }
 const char* l3d_profile_names(void) { return kProfNames; }
+// Device arenas of the finishing stages (greedy selection, affinity fill, edge order, line fit) reserved ahead of their first use from
+// the scene's size: n_dense segments in all views, about n_neighbors per view.  Grow-only arenas make this a hint: a stage that
+// needs more still gets it.  (The first finish of a process spent most of its time in hipMalloc.)
+int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
+{
+    if (!c || n_dense < 0 || n_views < 0 || n_neighbors < 0) return L3D_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    const size_t nd = (size_t)n_dense, N = (size_t)std::max(1, n_neighbors);
+    const size_t n_pot = 3 * N * nd + 1024, n_items = (3 * N * nd) / 2 + 1024, n_edges = N * nd + 1024, slots = 2 * n_pot;
+    Products& P = c->products;
+    struct R { DevBuf* b; size_t bytes; } rs[] = {
+        { &P.keys, slots * 8 }, { &P.keys2, slots * 8 }, { &P.flag, slots * 4 }, { &P.pos, slots * 4 }, { &P.tmp, slots * 4 + (64u << 10) }, { &P.pot_start, (nd + 2) * 8 },
+        { &P.pot_tgt, slots * 4 }, { &P.best_ref, nd * 8 }, { &P.hyp_of, (nd + 2) * 8 }, { &P.score, nd * 4 }, { &P.hyp_dense, nd * 4 }, { &P.best_hyp, nd * 4 },
+        { &P.aux, nd * 4 + n_pot + 1024 }, { &c->aff_hyp, nd * sizeof(Hypothesis) },
+        { &c->g1, (nd + 2) * 16 + (size_t)n_views * 4 + 1024 }, { &c->g2, n_items * 8 }, { &c->g3, n_items * 8 }, { &c->g4, n_items * 4 },
+        { &c->g5, (nd * 2 + n_items * 6 + 8) * 4 }, { &c->g6, n_edges * 2 * sizeof(l3d_edge) + nd * 4 }, { &c->g7, n_edges * 16 + (1u << 20) }, { &c->g0, n_edges * 2 * sizeof(l3d_edge) * 2 },
+    };
+    for (const R& r : rs) HIPCHK(c, r.b->reserve(r.bytes + 256));
+    return L3D_OK;
+}
+
+// The first launch out of a translation unit loads its code object (a few milliseconds each, and the first matchViews / finish of a
+// process touch all of them): loaded here, in parallel, so that a caller can do it while it still reads its input.
+int l3d_warm_up(l3d_ctx* c)
+{
+    if (!c) return L3D_ERR_INVALID;
+    void (*fns[])() = { warm_kernels, warm_verify_window, warm_rdd, warm_affinity, warm_linefit, warm_chain, warm_chain_sharded, warm_products };
+    std::vector<std::thread> th;
+    const int dev = c->device;
+    for (auto f : fns) th.emplace_back([f, dev]() { (void)hipSetDevice(dev); f(); });
+    // the runtime builds its staging for copies between device and pageable host memory at the first such copy of a size class
+    // (20 ms at the first 12 MB read-back of an edge list): here instead
+    {
+        (void)hipSetDevice(dev);
+        const size_t bytes = 16u << 20;
+        void* d = nullptr;
+        std::vector<char> host(bytes);
+        if (hipMalloc(&d, bytes) == hipSuccess) {
+            (void)hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(host.data(), d, bytes, hipMemcpyDeviceToHost, c->stream);
+            (void)hipMemcpyAsync(host.data(), d, 4, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(d);
+        }
+    }
+    for (auto& t : th) t.join();
+    (void)hipGetLastError();
+    return L3D_OK;
+}
 int l3d_last_stats(l3d_ctx* c, double stats[4])
 {
     if (!c || !stats) return L3D_ERR_INVALID;

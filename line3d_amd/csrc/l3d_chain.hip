@@ -771,3 +771,5 @@ extern "C" int l3d_match_chain_resident(l3d_ctx* c, const l3d_chain_view* views,
     if (n_pot) *n_pot = 0;
     return run_chain(c, views, n_views, nullptr, nullptr, map, summary, n_pot);
 }
+
+void l3d::warm_chain() { touch_kernel(reinterpret_cast<const void*>(&k_exist_count)); }

@@ -849,3 +849,5 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
 }
 
 }  // extern "C"
+
+void l3d::warm_chain_sharded() { touch_kernel(reinterpret_cast<const void*>(&l3d::k_exist_count_slots)); }

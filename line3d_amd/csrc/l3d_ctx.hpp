@@ -139,6 +139,8 @@ struct l3d_ctx {
     int resident_hyp = 0;           // its number of hypotheses (0: none)
     int resident_edges = 0;         // entries of the edge list l3d_affinity_fill left in g6 (0: none); consumed by l3d_clustering_edges
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;
+    std::vector<std::pair<char*, int>> resident_arenas;                  // batch registrations: (one allocation, slices still registered)
+    std::unordered_map<const void*, int> resident_arena_of;             // host pointer -> its batch allocation
     bool prof_on = false;
     std::string prof_only;          // bracket only this kernel (keeps the timed region of bench.py nearly undisturbed)
     std::map<std::string, l3d::ProfEntry> prof;

@@ -928,3 +928,6 @@ void launch_test_math(const float* x, int n, float* e, float* ac, double* acd, h
 }
 
 }  // namespace l3d
+
+// first use of a kernel loads its translation unit's code object (milliseconds): l3d_warm_up does that ahead of the first matchViews
+void l3d::warm_kernels() { touch_kernel(reinterpret_cast<const void*>(&k_pair_mask<false>)); }

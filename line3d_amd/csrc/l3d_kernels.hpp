@@ -105,6 +105,10 @@ struct VerifyArgs {
     float sigma_p, sigma_a, spatial_k;
 };
 
+// code-object warm-up, one function per translation unit (l3d_warm_up)
+void warm_kernels(); void warm_verify_window(); void warm_rdd(); void warm_affinity(); void warm_linefit(); void warm_chain(); void warm_chain_sharded(); void warm_products();
+inline void touch_kernel(const void* f) { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, f); }
+
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);

@@ -198,3 +198,5 @@ extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_gr
     *seg_count = cnt; *segs = packed_host; *n_segs = total;
     return L3D_OK;
 }
+
+void l3d::warm_linefit() { touch_kernel(reinterpret_cast<const void*>(&l3d::k_fit_gather)); }

@@ -569,3 +569,5 @@ int l3d_chain_products_get(l3d_ctx* c, int64_t* pot_start, int32_t* pot_tgt, l3d
 }
 
 }  // extern "C"
+
+void l3d::warm_products() { touch_kernel(reinterpret_cast<const void*>(&k_prod_flags)); }

@@ -452,3 +452,5 @@ extern "C" int l3d_clustering_edges_grouped(l3d_ctx* c, const l3d_edge* A, int n
     if (!group_start || !n_groups) return c ? fail(c, L3D_ERR_INVALID, "bad argument") : L3D_ERR_INVALID;
     return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, sorted_out, group_start, n_groups);
 }
+
+void l3d::warm_rdd() { touch_kernel(reinterpret_cast<const void*>(&k_cc_init)); }

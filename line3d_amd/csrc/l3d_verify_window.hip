@@ -438,3 +438,5 @@ void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, in
 }
 
 }  // namespace l3d
+
+void l3d::warm_verify_window() { touch_kernel(reinterpret_cast<const void*>(&k_seg_mmax)); }

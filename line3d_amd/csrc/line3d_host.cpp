@@ -191,6 +191,7 @@ struct l3d_line3d {
     void* plan_cache = nullptr;                                // ChainPlan of the current set of views (the schedule is static)
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
+    std::thread warm_thread;                                   // l3d_warm_up, started with the object: the code objects load while the caller adds its images
     bool host_bookkeeping = false;                             // chain with per-view delivery + host lists (L3D_HOST_BOOKKEEPING=1 / L3D_AFFINITY_HOST=1: A/B, cross-checks)
     bool resident_products = false;                            // the last matchViews left its products on the device: no host lists exist
     std::vector<l3d_chain_summary> chain_summary;
@@ -733,14 +734,32 @@ int prepare(L* h)
     for (auto& kv : h->views) { kv.second.index = idx++; h->vlist.push_back(&kv.second); }
     // residency: every view's neighbour tile (concatenated neighbour segments) and its own segments stay
     // in HBM for the whole run (the reference re-uploads them per view, line3D.cc:793-800)
-    for (View* v : h->vlist) {
-        v->nb_segs.clear();
-        auto it = h->visual_neighbors.find(v->id);
-        if (it != h->visual_neighbors.end())
-            for (uint32_t nb : it->second) { const View& o = h->views[nb]; v->nb_segs.insert(v->nb_segs.end(), o.segs.begin(), o.segs.end()); }
-        if (v->nb_segs.empty()) v->nb_segs.resize(4, 0.0f);
-        rc = l3d_register_segments(h->ctx, v->segs.data(), v->S());
-        if (!rc) rc = l3d_register_segments(h->ctx, v->nb_segs.data(), (int)(v->nb_segs.size() / 4));
+    {
+        int nd_all = 0;
+        for (View* v : h->vlist) nd_all += v->S();
+        const int nv_all = (int)h->vlist.size(), nn = h->matching_neighbors;
+        std::thread warm([h, nd_all, nv_all, nn]() {                // the finishing stages' arenas are reserved while the tiles are built and copied
+            if (h->warm_thread.joinable()) h->warm_thread.join();   // (the code objects: loading since the object was created)
+            (void)l3d_reserve_hint(h->ctx, nd_all, nv_all, nn);
+        });
+        std::atomic<size_t> next{ 0 };
+        l3d::on_threads((unsigned)std::max<size_t>(1, std::min<size_t>(l3d::host_threads(), h->vlist.size())), [&](unsigned) {
+            for (;;) {
+                const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= h->vlist.size()) break;
+                View* v = h->vlist[i];
+                v->nb_segs.clear();
+                auto it = h->visual_neighbors.find(v->id);
+                if (it != h->visual_neighbors.end())
+                    for (uint32_t nb : it->second) { const View& o = h->views.find(nb)->second; v->nb_segs.insert(v->nb_segs.end(), o.segs.begin(), o.segs.end()); }
+                if (v->nb_segs.empty()) v->nb_segs.resize(4, 0.0f);
+            }
+        });
+        std::vector<const float*> arrs;
+        std::vector<int> cnts;
+        for (View* v : h->vlist) { arrs.push_back(v->segs.data()); cnts.push_back(v->S()); arrs.push_back(v->nb_segs.data()); cnts.push_back((int)(v->nb_segs.size() / 4)); }
+        rc = l3d_register_segments_batch(h->ctx, arrs.data(), cnts.data(), (int)arrs.size());
+        warm.join();
         if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
     }
     lap("neighbour tiles + residency");
@@ -2163,6 +2182,7 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
     h->sigma_p = sigma_p; h->sigma_a = sigma_a; h->min_baseline = min_baseline;
     h->use_collinearity = use_collinearity != 0;
     h->force_sync = getenv("L3D_MATCH_SYNC") != nullptr;
+    h->warm_thread = std::thread([ctx]() { (void)l3d_warm_up(ctx); });
     h->host_bookkeeping = getenv("L3D_HOST_BOOKKEEPING") != nullptr || getenv("L3D_AFFINITY_HOST") != nullptr;
     *out = h;
     return L3D_OK;
@@ -2171,6 +2191,7 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
 void l3d_line3d_destroy(l3d_line3d* h)
 {
     if (!h) return;
+    if (h->warm_thread.joinable()) h->warm_thread.join();
     delete static_cast<ChainFinalizer*>(h->finalizer);      // joins the worker threads
     drop_plan(h);
     l3d_ctx_destroy(h->ctx);

@@ -39,4 +39,5 @@ if __name__ == "__main__":
         wk, n2 = w.get(k, (0.0, 0))
         out[k] = dict(FETCH_SIZE_KB_per_launch=fk, WRITE_SIZE_KB_per_launch=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, launches=max(n, n2),
                       note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, per-launch average")
+    out["_commit"] = __import__("os").environ.get("L3D_COMMIT", "unstamped")      # (the GPU box has no .git: the caller passes the commit it sent)
     json.dump(out, sys.stdout, indent=1)

@@ -20,4 +20,5 @@ out = {k: dict(valu_wave_insts_per_launch=tot[k].get("SQ_INSTS_VALU", 0.0) / max
                waves_per_launch=tot[k].get("SQ_WAVES", 0.0) / max(1, len(launches[k])), launches=len(launches[k]),
                note="SQ_INSTS_VALU / SQ_WAVES summed over all shader engines, per-launch average")
        for k in sorted(tot)}
+out["_commit"] = __import__("os").environ.get("L3D_COMMIT", "unstamped")      # (the GPU box has no .git: the caller passes the commit it sent)
 json.dump(out, sys.stdout, indent=1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One measurement set of the bench command on the GPU box (run through gpurun from the repo root):
-#   scripts/measure_round.sh r2_v1
+#   L3D_COMMIT=$(git rev-parse --short HEAD) gpurun -- 'L3D_COMMIT=<sha> scripts/measure_round.sh r3_v1'
 # writes gpurun_out/<tag>/: bench.json (plain run), bench_under_rocprof.json + kernel_stats.csv (rocprofv3 --kernel-trace --stats),
 # fetch/ write/ valu/ (separate --pmc passes).  Copy the summaries into profiles/ afterwards (scripts/make_traffic.py, make_valu.py).
 set -u
