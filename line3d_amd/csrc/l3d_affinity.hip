@@ -488,7 +488,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     std::vector<int> cut((size_t)V, 0);
     HIPCHK(c, hipMemcpyAsync(cut.data(), needs_prev, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    static const bool per_view = getenv("L3D_AFF_PER_VIEW") && atoi(getenv("L3D_AFF_PER_VIEW")) != 0;   // tests: the general schedule everywhere
+    const bool per_view = getenv("L3D_AFF_PER_VIEW") && atoi(getenv("L3D_AFF_PER_VIEW")) != 0;   // tests: the general schedule everywhere
     int n_launches = 0;
     for (int v0 = 0; v0 < V;) {
         int v1 = v0 + 1;

@@ -192,7 +192,7 @@ struct l3d_line3d {
     void* shard_plan_ = nullptr;                               // open sharded chain (ChainPlan*, l3d_line3d_shard_*)
     bool force_sync = false;                                   // matchViews through the per-view seam call (A/B, L3D_MATCH_SYNC=1)
     std::thread warm_thread;                                   // l3d_warm_up, started with the object: the code objects load while the caller adds its images
-    bool host_bookkeeping = false;                             // chain with per-view delivery + host lists (L3D_HOST_BOOKKEEPING=1 / L3D_AFFINITY_HOST=1: A/B, cross-checks)
+    bool host_bookkeeping = false;                             // chain with per-view delivery + host lists (L3D_HOST_BOOKKEEPING=1: A/B, cross-check of the device products)
     bool resident_products = false;                            // the last matchViews left its products on the device: no host lists exist
     std::vector<l3d_chain_summary> chain_summary;
     int64_t resident_n_pot = 0;
@@ -1353,7 +1353,7 @@ int match_views(L* h)
     if (!Pp) return match_views_sync(h);
     ChainPlan& P = *Pp;
     const double tb = now_s();
-    if (!(h->host_bookkeeping || getenv("L3D_HOST_BOOKKEEPING") || getenv("L3D_AFFINITY_HOST"))) {
+    if (!(h->host_bookkeeping || getenv("L3D_HOST_BOOKKEEPING"))) {
         const int rr = match_views_resident(h, P, t0);
         if (rr != L3D_ERR_UNSUPPORTED) return rr;           // (more kept matches than the device builder takes: host lists)
     }
@@ -1715,8 +1715,9 @@ int fill_affinity_resident(L* h)
 }
 
 // Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
-// (l3d_affinity_fill, l3d_clustering_edges), union-find and line fit here; the round-1 host stages remain as the cross-check
-// (L3D_AFFINITY_HOST=1) and for edge lists the device path refuses.
+// (l3d_affinity_fill / l3d_affinity_fill_resident, l3d_clustering_edges), union-find and line fit here; host symmetrisation and
+// edge order remain for edge lists the device path refuses.  (The literal `used` enumeration of round 1 lives on as a test helper:
+// tests/cpp/literal_used_rule.c.)
 int cluster_segments_2D(L* h, bool perform_diff)
 {
     const double t0 = now_s();
@@ -1751,7 +1752,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
         if (rc) return rc;
         resident_list = true;
         lap("affinity fill (resident tables)");
-    } else if (!getenv("L3D_AFFINITY_HOST")) {
+    } else {
         resident_list = true;
         // ---- the whole fill on the device (l3d_affinity.hip): flat tables in, edge list and node numbering out
         const unsigned nt = finish_threads();
@@ -1847,188 +1848,6 @@ int cluster_segments_2D(L* h, bool perform_diff)
         l3d_free(edges); l3d_free(node_hyp);
         if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges, %u threads\n", nh, n_cand, h->A.size(), nt);
         lap("edge list to host");
-    } else {
-    // Candidate enumeration in the reference's order.  used[src][x] <=> x met earlier in this iteration, or src met while x was
-    // the source (an earlier iteration).  The iterations of ONE view are independent of each other: a source only asks what
-    // sources of EARLIER views met (potential correspondences and their collinear segments live in other views), except for
-    // its own view's collinear segments (:1141-1214), where "x met src" is simply "src is in x's collinear list" (x's iteration
-    // walks that whole list and marks what it has not marked yet).  So the sources are handed out in order, in chunks of one
-    // view's segments, to the worker threads; a lookup into an earlier view's chunk waits for that chunk (the oldest unfinished
-    // chunk never waits, so there is always progress); the chunks' item lists are concatenated in order afterwards.
-    struct Item { int a, b; int kind; float cw; };
-    constexpr size_t kChunk = 32;
-    struct Chunk { size_t begin, end; std::vector<Item> items; std::vector<uint32_t> met; };   // met: the sources' sorted lists, back to back
-    std::vector<Chunk> chunks;
-    std::vector<size_t> view_chunk_begin(nv + 1, 0);
-    for (size_t vi = 0; vi < nv; ++vi) {
-        view_chunk_begin[vi] = chunks.size();
-        for (size_t bgn = hyp_begin[vi]; bgn < hyp_begin[vi + 1]; bgn += kChunk) chunks.push_back({ bgn, std::min(hyp_begin[vi + 1], bgn + kChunk), {}, {} });
-    }
-    view_chunk_begin[nv] = chunks.size();
-    // per processed src (hyp index): sorted dense ids met = chunks[enc_chunk].met[enc_off .. enc_off + enc_len)
-    std::unique_ptr<uint32_t[]> enc_chunk(new uint32_t[nh]), enc_off(new uint32_t[nh]), enc_len(new uint32_t[nh]);
-    std::vector<uint32_t> chunk_view(chunks.size());
-    for (size_t vi = 0; vi < nv; ++vi) for (size_t c = view_chunk_begin[vi]; c < view_chunk_begin[vi + 1]; ++c) chunk_view[c] = (uint32_t)vi;
-    for (size_t c = 0; c < chunks.size(); ++c) for (size_t si = chunks[c].begin; si < chunks[c].end; ++si) enc_chunk[si] = (uint32_t)c;   // (static)
-    std::vector<std::atomic<int>> chunk_done(chunks.size());
-    for (auto& f : chunk_done) f.store(0, std::memory_order_relaxed);
-    // was dense id d met while hypothesis xb was the source?  (cur: the caller's own chunk -- only a single thread ever asks
-    // about its own, still growing, chunk)
-    auto met_has = [&](size_t xb, uint32_t d, size_t cur) {
-        const size_t cx = enc_chunk[xb];
-        if (cx != cur) { int spins = 0; while (!chunk_done[cx].load(std::memory_order_acquire)) if (++spins > 200) std::this_thread::yield(); }
-        const uint32_t* p = chunks[cx].met.data() + enc_off[xb];
-        return std::binary_search(p, p + enc_len[xb], d);
-    };
-    const unsigned nt = finish_threads();
-    {
-        std::atomic<size_t> next{ 0 };
-        auto worker = [&](unsigned) {
-            std::vector<uint32_t> stamp(voff.back(), 0), met;
-            uint32_t st = 0;
-            {
-                for (;;) {
-                    const size_t ci = next.fetch_add(1, std::memory_order_relaxed);
-                    if (ci >= chunks.size()) break;
-                    const size_t vi = chunk_view[ci];
-                    const View& sv = *h->vlist[vi];
-                    const auto& pot = h->pot[vi];
-                    const std::vector<int>& sbi = h->best_idx[vi];
-                    Chunk& ch = chunks[ci];
-                    for (size_t si = ch.begin; si < ch.end; ++si) {
-                        const uint32_t sseg = kseg(h->hyps[si].src);
-                        const uint32_t dsrc = (uint32_t)(voff[vi] + sseg);
-                        ++st;
-                        met.clear();
-                        auto lo = std::lower_bound(pot.begin(), pot.end(), std::make_pair(sseg, (Key)0));
-                        for (; lo != pot.end() && lo->first == sseg; ++lo) {                     // :996-1138
-                            const Key tgt = lo->second;
-                            // keys whose camera is not a view (early-return quirk) sort among the others, never have a best
-                            // match and appear at most once per source: they only need to be skipped
-                            const int tvi = view_of(kcam(tgt));
-                            if (tvi < 0) continue;
-                            const View& tv = *h->vlist[(size_t)tvi];
-                            const uint32_t tseg = kseg(tgt);
-                            if (tseg >= (uint32_t)tv.S()) continue;
-                            const std::vector<int>& tbi = h->best_idx[(size_t)tvi];
-                            auto used = [&](uint32_t xs) -> bool {
-                                if (stamp[voff[(size_t)tvi] + xs] == st) return true;
-                                const int xb = tbi[xs];
-                                return xb >= 0 && (size_t)xb < si && met_has((size_t)xb, dsrc, ci);
-                            };
-                            auto mark = [&](uint32_t xs) { const uint32_t d = (uint32_t)(voff[(size_t)tvi] + xs); stamp[d] = st; met.push_back(d); };
-                            if (used(tseg)) continue;
-                            mark(tseg);
-                            const int tb = tbi[tseg];
-                            if (tb < 0) continue;
-                            ch.items.push_back({ (int)si, tb, 0, 0.0f });
-                            for (int c = tv.coll_start[tseg]; c < tv.coll_start[tseg + 1]; ++c) {  // :1065-1136
-                                const uint32_t cs = (uint32_t)tv.coll_other[(size_t)c];
-                                if (used(cs)) continue;
-                                mark(cs);
-                                const int cb = tbi[cs];
-                                if (cb >= 0) ch.items.push_back({ (int)si, cb, 1, 0.0f });
-                            }
-                        }
-                        for (int c = sv.coll_start[sseg]; c < sv.coll_start[sseg + 1]; ++c) {     // :1141-1214
-                            const uint32_t xs = (uint32_t)sv.coll_other[(size_t)c];
-                            const uint32_t dx = (uint32_t)(voff[vi] + xs);
-                            bool u = stamp[dx] == st;
-                            if (!u) {
-                                const int xb = sbi[xs];
-                                if (xb >= 0 && (size_t)xb < si) {
-                                    if (nt == 1) u = met_has((size_t)xb, dsrc, ci);   // the literal rule (single thread: L3D_HOST_THREADS=1, tests)
-                                    else for (int q = sv.coll_start[xs]; q < sv.coll_start[xs + 1] && !u; ++q) u = (uint32_t)sv.coll_other[(size_t)q] == sseg;
-                                }
-                            }
-                            if (u) continue;
-                            stamp[dx] = st; met.push_back(dx);
-                            const int tb = sbi[xs];
-                            if (tb >= 0) ch.items.push_back({ (int)si, tb, 2, sv.coll_w[(size_t)c] });
-                        }
-                        std::sort(met.begin(), met.end());
-                        enc_off[si] = (uint32_t)ch.met.size(); enc_len[si] = (uint32_t)met.size();
-                        ch.met.insert(ch.met.end(), met.begin(), met.end());
-                    }
-                    chunk_done[ci].store(1, std::memory_order_release);
-                }
-            }
-        };
-        l3d::on_threads(nt, [&](unsigned t) { worker(t); });
-    }
-    std::vector<size_t> chunk_off(chunks.size() + 1, 0);
-    for (size_t c = 0; c < chunks.size(); ++c) chunk_off[c + 1] = chunk_off[c] + chunks[c].items.size();
-    const size_t n_items = chunk_off.back();
-    lap("enumerate candidates");
-
-    // batched similarity on the GPU
-    // (plain arrays: first touched -- and paged in -- by the worker threads, not zero-filled by this one)
-    std::unique_ptr<l3d_hypothesis[]> hy(new l3d_hypothesis[nh]);
-    std::unique_ptr<int32_t[]> pairs(new int32_t[n_items * 2 + 1]);
-    std::unique_ptr<Item[]> items(new Item[n_items + 1]);
-    parallel_slices(nh, nt, [&](size_t b0, size_t b1, unsigned) {
-        for (size_t i = b0; i < b1; ++i) {
-            const Hyp& sh = h->hyps[i];
-            const View& v = *h->vlist[(size_t)view_of(kcam(sh.src))];
-            l3d_hypothesis& o = hy[i];
-            o.P1[0] = sh.P1.x; o.P1[1] = sh.P1.y; o.P1[2] = sh.P1.z;
-            o.P2[0] = sh.P2.x; o.P2[1] = sh.P2.y; o.P2[2] = sh.P2.z;
-            o.dir[0] = sh.dir.x; o.dir[1] = sh.dir.y; o.dir[2] = sh.dir.z;
-            o.depth_p1 = sh.depth_p1; o.depth_p2 = sh.depth_p2;
-            o.k_lower = v.k_lower; o.k_upper = v.k_upper; o.median_depth = v.median_depth; o.pad = 0;
-        }
-    });
-    parallel_slices(chunks.size(), nt, [&](size_t c0, size_t c1, unsigned) {
-        for (size_t c = c0; c < c1; ++c) {
-            size_t k = chunk_off[c];
-            for (const Item& it : chunks[c].items) { items[k] = it; pairs[2 * k] = it.a; pairs[2 * k + 1] = it.b; ++k; }
-            std::vector<Item>().swap(chunks[c].items);
-        }
-    });
-    std::unique_ptr<float[]> sim(new float[n_items + 1]), wgt(new float[n_items + 1]);
-    lap("pack hypotheses / pairs");
-    int rc = l3d_similarity_coll3D_batch(h->ctx, hy.get(), (int)nh, pairs.get(), (int)n_items, h->sigma_a, sim.get());
-    if (rc) return h->fail(rc, std::string("similarity: ") + l3d_last_error(h->ctx));
-    lap("similarity (GPU call)");
-
-    // thresholds (parallel), first-touch node numbering in enumeration order (sequential, integers only), edge list (parallel)
-    std::vector<size_t> slice_edges((size_t)nt + 1, 0);
-    const unsigned nts = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n_items));
-    parallel_slices(n_items, nts, [&](size_t k0, size_t k1, unsigned t) {
-        size_t cnt = 0;
-        for (size_t k = k0; k < k1; ++k) {
-            const Item& it = items[k];
-            const float s1 = h->hyps[(size_t)it.a].score, s2 = h->hyps[(size_t)it.b].score;
-            float w;
-            if (it.kind == 2) w = it.cw * 0.5f * (s1 + s2) * sim[k];                // :1163
-            else w = 0.5f * (s1 + s2) * sim[k];                                     // :1014,:1085
-            const float thr = it.kind == 0 ? 0.25f : 0.01f;                         // L3D_MIN_AFFINITY / 0.01f
-            wgt[k] = w > thr ? w : -1.0f;
-            cnt += w > thr;
-        }
-        slice_edges[(size_t)t + 1] = cnt;
-    });
-    for (unsigned t = 0; t < nts; ++t) slice_edges[(size_t)t + 1] += slice_edges[t];
-    std::vector<int> node(nh, -1);
-    h->local2global.reserve(nh);
-    for (size_t k = 0; k < n_items; ++k) {
-        if (!(wgt[k] > 0.0f)) continue;
-        for (const int hidx : { items[k].a, items[k].b })
-            if (node[(size_t)hidx] < 0) { node[(size_t)hidx] = (int)h->local2global.size(); h->local2global.push_back(h->hyps[(size_t)hidx].src); }
-    }
-    h->A.resize(2 * slice_edges[nts]);
-    parallel_slices(n_items, nts, [&](size_t k0, size_t k1, unsigned t) {
-        size_t r = slice_edges[t];
-        for (size_t k = k0; k < k1; ++k) {
-            if (!(wgt[k] > 0.0f)) continue;
-            const int a = node[(size_t)items[k].a], b = node[(size_t)items[k].b];
-            h->A[2 * r] = { a, b, wgt[k] };
-            h->A[2 * r + 1] = { b, a, wgt[k] };
-            ++r;
-        }
-    });
-    if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %zu candidate pairs, %zu edges, %u threads\n", nh, n_items, h->A.size(), nt);
-    lap("thresholds / numbering");
     }
     h->t_affinity = now_s() - t0;
     if (h->A.empty()) return L3D_OK;                                            // :1232-1233
@@ -2183,7 +2002,7 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
     h->use_collinearity = use_collinearity != 0;
     h->force_sync = getenv("L3D_MATCH_SYNC") != nullptr;
     h->warm_thread = std::thread([ctx]() { (void)l3d_warm_up(ctx); });
-    h->host_bookkeeping = getenv("L3D_HOST_BOOKKEEPING") != nullptr || getenv("L3D_AFFINITY_HOST") != nullptr;
+    h->host_bookkeeping = getenv("L3D_HOST_BOOKKEEPING") != nullptr;
     *out = h;
     return L3D_OK;
 }
@@ -2281,10 +2100,6 @@ int l3d_line3d_match_views(l3d_line3d* h)
 int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
-    if (h->resident_products && getenv("L3D_AFFINITY_HOST")) {     // the host cross-check works on host lists: match again with them
-        const int rm = match_views(h);
-        if (rm) return rm;
-    }
     const double t0 = now_s();
     if (h->resident_products) { const int rg = greedy_selection_resident(h); if (rg) return rg; }
     else greedy_selection(h);                              // optimizeLocalMatches, :888-896

@@ -160,19 +160,37 @@ def test_full_size_diffusion_equals_oracle(chain_run, oracle_lib):
     ctx.close()
 
 
-def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, monkeypatch):
-    """The affinity fill runs on the device (l3d_affinity_fill: per-target "expanded" bits instead of the reference's `used`
-    maps).  Cross-check at full size against the host enumeration kept for this purpose (L3D_AFFINITY_HOST=1), which on one
-    thread applies the reference's `used` rule literally -- and against the device path with 5-target passes (groups and
-    flattened entries straddling passes) and with one launch per view (the schedule of scenes with one-way records).
-    The other finishing stages (edge ordering, line fit) run on worker threads: 1, 5 and 16 threads.  Same list, same lines."""
+def _literal_rule_lib():
+    """tests/cpp/literal_used_rule.c (the reference's `used` bookkeeping applied literally on one thread), built on demand"""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libliteral_used_rule.so")
+    src = os.path.join(here, "cpp", "literal_used_rule.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.literal_used_rule.restype = C.c_int64
+    return lib
+
+
+def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, full_scene, gpu_ctx, monkeypatch):
+    """The affinity fill runs on the device (l3d_affinity_fill: per-target "expanded" bits instead of the reference's `used` maps),
+    on tables that never left it.  Cross-check at full size: (i) the device path with 5-target passes (groups and flattened entries
+    straddling passes), one launch per view (the schedule of scenes with one-way records), other thread counts of the host stages,
+    and matchViews with host bookkeeping (host-built tables uploaded to the same fill) give the same list and the same lines;
+    (ii) the candidate enumeration with the reference's `used` rule applied LITERALLY on one thread (tests/cpp/literal_used_rule.c)
+    over the resident tables, weighted through the similarity seam call, gives the same edge list bit for bit."""
+    import ctypes as C
     l, _ = chain_run
     out = {}
-    variants = {"device": {}, "device, 5-target passes": {"L3D_AFF_CHUNK": "5"}, "device, 5 threads": {"L3D_HOST_THREADS": "5"},
-                "host, literal rule (1 thread)": {"L3D_AFFINITY_HOST": "1", "L3D_HOST_THREADS": "1"},
-                "host, 16 threads": {"L3D_AFFINITY_HOST": "1", "L3D_HOST_THREADS": "16"}}
+    variants = {"device": {}, "device, 5-target passes": {"L3D_AFF_CHUNK": "5"}, "device, one launch per view": {"L3D_AFF_PER_VIEW": "1"},
+                "device, 5 host threads": {"L3D_HOST_THREADS": "5"}}
     for name, env in variants.items():
-        for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFFINITY_HOST"):
+        for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFF_PER_VIEW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -185,10 +203,72 @@ def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, monk
                 sig.update(np.asarray(seg2, dtype=np.int64).tobytes())
                 sig.update(np.asarray([np.concatenate(p) for p in seg3], dtype=np.float64).tobytes())
             out[(name, diffusion)] = (len(A), n_nodes, len(lines), sig.hexdigest())
+    for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFF_PER_VIEW"):
+        monkeypatch.delenv(k, raising=False)
     for diffusion in (False, True):
         assert out[("device", diffusion)][0] > 100000 and out[("device", diffusion)][2] > 100
         for name in variants:
             assert out[(name, diffusion)] == out[("device", diffusion)], (name, diffusion)
+    # host bookkeeping (per-view delivery, host lists, host-packed tables): the same list
+    from line3d_amd.pipeline import Line3D, load_scene
+    monkeypatch.setenv("L3D_HOST_BOOKKEEPING", "1")
+    l2 = Line3D("", matchingNeighbors=N)
+    load_scene(l2, full_scene)
+    l2.compute3Dmodel(False)
+    assert l2.resident_products() is None
+    A2 = l2.affinity()[0]
+    monkeypatch.delenv("L3D_HOST_BOOKKEEPING")
+    l.finish(False)
+    A, n_nodes = l.affinity()[:2]
+    assert A2.tobytes() == A.tobytes()
+    l2.close()
+
+    # ---- the literal rule over the resident tables
+    pr = l.resident_products()
+    seg_base, nd = pr["seg_base"], int(pr["seg_base"][-1])
+    has = pr["best"]["segID1"] != 0xffffffff
+    best = np.where(has, np.cumsum(has) - 1, -1).astype(np.int32)                # hypotheses are numbered in dense order
+    hyp_dense = np.nonzero(has)[0].astype(np.int32)
+    nh = len(hyp_dense)
+    assert nh == len(pr["hyp"]) > 10000
+    coll = gpu_ctx.compute_collinearity_batch([v["segments"] for v in full_scene.views])     # (the call prepare() makes)
+    ci, cj, cw = [], [], []
+    for vi, (i, j, w) in enumerate(coll):
+        b = int(seg_base[vi])
+        ci += [b + i, b + j]; cj += [b + j, b + i]; cw += [w, w]
+    ci, cj, cw = np.concatenate(ci), np.concatenate(cj), np.concatenate(cw)
+    order = np.lexsort((cj, ci))
+    ci, cj, cw = ci[order], cj[order].astype(np.int32), cw[order].astype(np.float32)
+    coll_start = np.zeros(nd + 1, np.int64)
+    np.add.at(coll_start, ci + 1, 1)
+    coll_start = np.cumsum(coll_start)
+    lib = _literal_rule_lib()
+    item_t = np.dtype([("a", "<i4"), ("b", "<i4"), ("kind", "<i4"), ("cw", "<f4")])
+    pot_start, pot_tgt = np.ascontiguousarray(pr["pot_start"]), np.ascontiguousarray(pr["pot_tgt"])
+    args = [C.c_int32(nd), C.c_int32(nh), hyp_dense.ctypes.data_as(C.c_void_p), best.ctypes.data_as(C.c_void_p), pot_start.ctypes.data_as(C.c_void_p),
+            pot_tgt.ctypes.data_as(C.c_void_p), coll_start.ctypes.data_as(C.c_void_p), cj.ctypes.data_as(C.c_void_p), cw.ctypes.data_as(C.c_void_p)]
+    n_items = lib.literal_used_rule(*args, None, C.c_int64(0))
+    items = np.zeros(n_items, item_t)
+    assert lib.literal_used_rule(*args, items.ctypes.data_as(C.c_void_p), C.c_int64(n_items)) == n_items > 100000
+    pairs = np.stack([items["a"], items["b"]], 1).astype(np.int32)
+    sim = gpu_ctx.similarity_coll3D_batch(pr["hyp"], pairs, 10.0)                 # line3D.cc:1600-1681 (seam call, pinned to the oracle elsewhere)
+    sc = pr["score"].astype(np.float32)
+    ssum = (sc[items["a"]] + sc[items["b"]]).astype(np.float32)
+    half = np.float32(0.5)
+    w01 = ((half * ssum).astype(np.float32) * sim).astype(np.float32)            # :1014, :1085
+    w2 = (((items["cw"] * half).astype(np.float32) * ssum).astype(np.float32) * sim).astype(np.float32)   # :1163
+    w = np.where(items["kind"] == 2, w2, w01)
+    keep = w > np.where(items["kind"] == 0, np.float32(0.25), np.float32(0.01))
+    ka, kb, kw = items["a"][keep], items["b"][keep], w[keep]
+    touch = np.stack([ka, kb], 1).ravel()                                         # first-touch node numbering: source before target, in order
+    _, first = np.unique(touch, return_index=True)
+    node_of = np.full(nh, -1, np.int64)
+    node_of[touch[np.sort(first)]] = np.arange(len(first))
+    exp = np.zeros(2 * len(ka), dtype=A.dtype)
+    exp["i"][0::2], exp["j"][0::2], exp["w"][0::2] = node_of[ka], node_of[kb], kw
+    exp["i"][1::2], exp["j"][1::2], exp["w"][1::2] = node_of[kb], node_of[ka], kw
+    assert len(first) == n_nodes
+    assert exp.tobytes() == A.tobytes()
 
 
 def test_near_maximum_segments_per_view():
