@@ -26,6 +26,7 @@
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
 #include "l3d_products.hpp"
+#include "l3d_chain_common.hpp"
 
 using namespace l3d;
 
@@ -213,22 +214,7 @@ void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow,
 
 namespace {
 
-struct ViewDev {            // device addresses of one view's static tables and per-view arenas
-    const float4 *src, *tgt;
-    const unsigned char* tab;
-    size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
-    unsigned long long* mask;
-    int* rowcnt;
-    int* rowA;              // row starts of the stage-1 candidates alone (S*N + 1)
-    int* rowub;             // fused row starts: k_pair_mask's (upper-bound) counts, S*N, and their 256-row block sums (never rewritten)
-    int* rowblk;
-    int* stats;             // {raw total, raw max per segment}
-    float2* best;
-    int* bestpos;           // per segment: position (in the view's kept slice) of its best kept match or -1 (k_kept_write_chain)
-    float4* rays;           // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
-    int W64, maxW;
-    bool verified;
-};
+typedef l3d::ChainViewDev ViewDev;
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -252,114 +238,20 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (serial) s1 = st;
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
 
-    // ---- validation, table layout
-    std::vector<ViewDev> vd((size_t)n_views);
-    size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
-    int maxS = 0, maxN = 0;
-    for (int k = 0; k < n_views; ++k) {
-        const l3d_chain_view& v = views[k];
-        if (v.S_src < 0 || v.N < 0 || v.n_tbm < 0 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0)
-            return fail(c, L3D_ERR_INVALID, "l3d_match_chain: inconsistent sizes");
-        ViewDev& d = vd[(size_t)k];
-        d.verified = v.n_tbm > 0;
-        if (!d.verified) continue;
-        if (!v.src_segs || !v.tgt_segs || !v.offsets || !v.F || !v.RtKinv || !v.centers || !v.P || !v.RtKinv_src || !v.C_src ||
-            !v.to_be_matched || !v.local2global || (v.n_sources && (!v.source_cam || !v.source_index)))
-            return fail(c, L3D_ERR_INVALID, "l3d_match_chain: null input pointer");
-        if (v.N > 255) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: more than 255 neighbours");
-        for (int s = 0; s < v.n_sources; ++s)
-            if (v.source_index[s] < 0 || v.source_index[s] >= k || v.source_cam[s] < 0 || v.source_cam[s] >= v.N)
-                return fail(c, L3D_ERR_INVALID, "l3d_match_chain: a source must be an earlier view of the chain");
-        int maxW = 0;
-        for (int j = 0; j < v.n_tbm; ++j) {
-            const int cam = v.to_be_matched[j];
-            if (cam < 0 || cam >= v.N) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: to_be_matched out of range");
-            maxW = std::max(maxW, v.offsets[2 * cam + 1]);
-        }
-        for (int i = 0; i < v.N; ++i)
-            if (v.offsets[2 * i] < 0 || v.offsets[2 * i + 1] < 0 || v.offsets[2 * i] + v.offsets[2 * i + 1] > v.n_tgt)
-                return fail(c, L3D_ERR_INVALID, "l3d_match_chain: offsets outside the target tile");
-        d.maxW = maxW;
-        d.W64 = 4 * ((maxW + 255) / 256);
-        if (d.W64 > kMaxW64) return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments");
-        // residency: segments stay in HBM; arrays not registered yet are registered now
-        if (!resident_ptr(c, v.src_segs, (size_t)v.S_src * 16)) { int rc = l3d_register_segments(c, v.src_segs, v.S_src); if (rc) return rc; }
-        if (!resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16)) { int rc = l3d_register_segments(c, v.tgt_segs, v.n_tgt); if (rc) return rc; }
-        d.src = reinterpret_cast<const float4*>(resident_ptr(c, v.src_segs, (size_t)v.S_src * 16));
-        d.tgt = reinterpret_cast<const float4*>(resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16));
-        const size_t N = (size_t)v.N;
-        size_t o = tab_bytes;
-        d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
-        d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
-        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
-        tab_bytes = align16(o);
-        mask_bytes += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
-        rowcnt_ints += (size_t)v.S_src * v.N;
-        best_elems += (size_t)v.S_src;
-        maxS = std::max(maxS, v.S_src); maxN = std::max(maxN, v.N);
-    }
-
-    // ---- upload all static tables in one block
-    HIPCHK(c, c->ch_pin_tables.reserve(tab_bytes + 16));
-    HIPCHK(c, c->ch_tables.reserve(tab_bytes + 16));
-    unsigned char* tab = c->ch_pin_tables.as<unsigned char>();
-    for (int k = 0; k < n_views; ++k) {
-        const l3d_chain_view& v = views[k];
-        const ViewDev& d = vd[(size_t)k];
-        if (!d.verified) continue;
-        const size_t N = (size_t)v.N;
-        memcpy(tab + d.o_off, v.offsets, N * 8); memcpy(tab + d.o_F, v.F, N * 36); memcpy(tab + d.o_R, v.RtKinv, N * 36);
-        memcpy(tab + d.o_C, v.centers, N * 12); memcpy(tab + d.o_P, v.P, N * 48); memcpy(tab + d.o_Rs, v.RtKinv_src, 36);
-        memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
-        memcpy(tab + d.o_l2g, v.local2global, N * 4);
-        if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
-    }
-    HIPCHK(c, hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
-    const unsigned char* dtab = c->ch_tables.as<unsigned char>();
-
-    // ---- per-view arenas: bit rows, row counts, statistics, best depths, results
-    HIPCHK(c, c->ch_mask.reserve(mask_bytes + 16));
-    HIPCHK(c, c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
-    // (row starts | upper-bound counts | their block sums: the last two zeroed, k_pair_mask adds into them)
-    const size_t rowA_ints = rowcnt_ints + 4 * (size_t)n_views, rowub_ints = rowcnt_ints + 4 * (size_t)n_views, rowblk_ints = rowcnt_ints / 256 + 8 * (size_t)n_views;
-    HIPCHK(c, c->ch_rowA.reserve((rowA_ints + rowub_ints + rowblk_ints) * 4 + 64));
-    HIPCHK(c, hipMemsetAsync(c->ch_rowA.as<int>() + rowA_ints, 0, (rowub_ints + rowblk_ints) * 4, st));
-    HIPCHK(c, c->ch_best.reserve(best_elems * 8 + 16));
-    HIPCHK(c, c->ch_bestpos.reserve(best_elems * 4 + 16));
+    // ---- validation, table layout and upload, per-view slices of the whole-run arenas (l3d_chain_common.hip: shared with the sharded chain)
+    std::vector<ViewDev> vd;
+    ChainLayout L;
+    if (int rc = chain_plan_views(c, views, n_views, 0, 1, vd, L, "l3d_match_chain")) return rc;
+    static const bool rays_env = !(getenv("L3D_TGT_RAYS") && atoi(getenv("L3D_TGT_RAYS")) == 0);      // (0: k_pair_fill normalises per candidate, A/B)
+    if (int rc = chain_upload_tables(c, views, n_views, vd, L, rays_env, st)) return rc;
+    if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, st)) return rc;
+    const unsigned char* dtab = L.dtab;
+    const int maxN = L.maxN;
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
     HIPCHK(c, c->ch_flags.reserve(64));
     HIPCHK(c, c->ch_pin_res.reserve((size_t)n_views * (sizeof(ChainResult) + 8) + 64));
-    HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
     HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
     HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
-    {   // the viewing rays of every view's target endpoints, once per chain (they only depend on the neighbour's camera and segment)
-        static const bool rays_env = !(getenv("L3D_TGT_RAYS") && atoi(getenv("L3D_TGT_RAYS")) == 0);      // (0: k_pair_fill normalises per candidate, A/B)
-        size_t n_ray = 0;
-        int max_n_tgt = 0;
-        std::vector<RayJob>& jobs = c->ray_jobs;             // (lives in the context: the upload below is asynchronous)
-        jobs.clear();
-        for (int k = 0; k < n_views; ++k) {
-            vd[(size_t)k].rays = nullptr;
-            if (!vd[(size_t)k].verified || !rays_env || views[k].n_tbm == 0) continue;
-            n_ray += (size_t)views[k].n_tgt;
-        }
-        HIPCHK(c, c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
-        float4* rbase = c->ch_rays.as<float4>();
-        RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
-        size_t ro = 0;
-        for (int k = 0; k < n_views; ++k) {
-            ViewDev& d = vd[(size_t)k];
-            if (!d.verified || !rays_env || views[k].n_tbm == 0) continue;
-            d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
-            jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(dtab + d.o_off), reinterpret_cast<const float*>(dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
-            max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
-        }
-        if (!jobs.empty()) {
-            HIPCHK(c, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
-            ProfScope p(c, "tgt_rays", st);
-            launch_tgt_rays(djobs, (int)jobs.size(), max_n_tgt, st);
-        }
-    }
     {   // stage 1 starts after the tables and the zeroed row counts are in place
         hipEvent_t ready = get_event(c);
         HIPCHK(c, hipEventRecord(ready, st));
@@ -372,59 +264,20 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     ChainResult* hres_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&hres_dev), hres, 0));
     int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
-    {
-        size_t mo = 0, ro = 0, bo = 0, ao = 0, ko = 0;
-        int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
-        for (int k = 0; k < n_views; ++k) {
-            ViewDev& d = vd[(size_t)k];
-            d.stats = stats_base + 2 * k;
-            if (!d.verified) continue;
-            const l3d_chain_view& v = views[k];
-            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
-            mo += align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
-            d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
-            d.rowA = c->ch_rowA.as<int>() + ao;
-            d.rowub = c->ch_rowA.as<int>() + rowA_ints + ao;
-            d.rowblk = c->ch_rowA.as<int>() + rowA_ints + rowub_ints + ko;
-            ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
-            ko += (((size_t)v.S_src * v.N + 255) / 256 + 4) & ~(size_t)3;
-            d.best = c->ch_best.as<float2>() + bo; d.bestpos = c->ch_bestpos.as<int>() + bo; bo += (size_t)v.S_src;
-        }
-    }
     // the four depths of a stage-1 pair are triangulated once, by k_pair_fill (ring scheme only: the fill runs ahead, its true row counts
     // are in place before the chain counts the view's reverse matches on top); L3D_DEPTH_IN_FILL=0: A/B, k_pair_mask triangulates too
     static const bool depth_in_fill_env = !(getenv("L3D_DEPTH_IN_FILL") && atoi(getenv("L3D_DEPTH_IN_FILL")) == 0);
     const bool depth_in_fill = depth_in_fill_env && c->chain_ring != 0;
     auto pair_args = [&](int k) {
-        const l3d_chain_view& v = views[k];
-        const ViewDev& d = vd[(size_t)k];
-        PairArgs pa;
-        pa.src_segs = d.src; pa.tgt_segs = d.tgt;
-        pa.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
-        pa.F = reinterpret_cast<const float*>(dtab + d.o_F);
-        pa.RtKinv = reinterpret_cast<const float*>(dtab + d.o_R);
-        pa.centers = reinterpret_cast<const float*>(dtab + d.o_C);
-        pa.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
-        pa.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
-        pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
-        pa.mask = d.mask;
-        pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-        pa.seg_begin = 0; pa.seg_end = v.S_src; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
+        PairArgs pa = chain_pair_args(c, views[k], vd[(size_t)k], dtab);
         pa.depth_in_fill = depth_in_fill ? 1 : 0;
-        pa.tgt_rays = d.rays;
         return pa;
     };
 
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain setup: ") + hipGetErrorString(e_)); }
     // ---- phase 1 (stage 1 of a view: pair test -> bit rows -> row counts -> statistics) is independent of the
     // chain; it is enqueued a window ahead of phase 2 so that the GPU always has work while the host trails behind
-    double pairs = 0, max_pairs = 0;
-    for (int k = 0; k < n_views; ++k) {
-        if (!vd[(size_t)k].verified) continue;
-        double p = 0;
-        for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
-        pairs += p; max_pairs = std::max(max_pairs, p);
-    }
+    const double pairs = L.pairs, max_pairs = L.max_pairs;
     std::vector<hipEvent_t> ev1((size_t)n_views, nullptr);
     int k_p1 = 0;                       // next view whose stage 1 is enqueued
     c->stats[0] = pairs;
@@ -432,15 +285,9 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
 
     // ---- capacities (guarded on the device; an overflow restarts the chain at that view with more room)
     // first guess from the pair counts (raw density ~6 %, kept ~0.2 % of the pairs on the synthetic scenes)
-    size_t cand_cap = (size_t)(max_pairs * 0.10) + 65536;
+    size_t cand_cap = chain_first_cand_cap(max_pairs);
     size_t arena_cap = (size_t)(pairs * 0.004) + 1048576;
     std::vector<hipEvent_t> ev((size_t)n_views, nullptr);
-    const size_t nrow_max = (size_t)maxS * maxN;
-    HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));
-    HIPCHK(c, c->ch_cursor.reserve(nrow_max * 4 + 16));
-    HIPCHK(c, c->kept_cnt.reserve((size_t)maxS * 4 + 4));
-    HIPCHK(c, c->ch_segorder.reserve((size_t)maxS * 4 + 16));
-    HIPCHK(c, c->kept_start.reserve((size_t)maxS * 4 + 8));
     int k_enq = 0;                      // next view whose phase 2 is enqueued
     // run-ahead depths, A/B measured on one box (ms per config-2 pass): (12, 24) 19.1, (6, 12) 18.7, (4, 8) 18.4, (2, 4) 18.3,
     // (24, 40) 20.0 -- a shallow queue keeps the stage-1 candidates of a view cache-warm until its chain consumes them
@@ -460,16 +307,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;
 
     auto reserve_caps = [&]() -> int {
-        HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
-        HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
-        HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
-        HIPCHK(c, c->vw_scratch.reserve((cand_cap + kVWSlack) * 16));
+        if (int rc = chain_reserve_candidates(c, L, cand_cap, c->chain_ring ? kRing : 0)) return rc;
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
-        // ring of stage-1 candidate buffers: stage 1 (incl. the triangulation of its candidates) runs kStage1Ahead views ahead
-        if (c->chain_ring) {
-            HIPCHK(c, c->ch_ringA_meta.reserve((size_t)kRing * cand_cap * 8));
-            HIPCHK(c, c->ch_ringA_depths.reserve((size_t)kRing * cand_cap * 16));
-        }
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
@@ -559,36 +398,10 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N)))
                 launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
         }
-        VerifyArgs va;
-        va.exist_cams = nullptr; va.n_exist_cams = 0;
-        va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
-        va.P = reinterpret_cast<const float*>(dtab + d.o_P);
-        va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
-        va.row_start = c->row_start.as<int>();
-        va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
-        va.N = N; va.seg_begin = 0; va.seg_end = S; va.nrow_total = (int)nrow;
-        va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
-        va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = dres + k;
-        va.seg_order = c->ch_segorder.as<int>();
-        // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
-        // (fused row starts: no statistics -- the largest image the budget allows; the budget, not the image, sets the occupancy)
-        int mmax = fused_rows ? 16384 : hstats[2 * k + 1] + hstats[2 * k + 1] / 4 + 64;
-        while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
-        va.mmax = mmax;
-        if (c->verify_mode == 0 && verify_window_supported(N)) {
-            // one launch: segments that fit the LDS image, the ones that outgrow it (reverse matches are not in the estimate)
-            // on a global scratch, and the per-segment epilogue (best hypothesis, kept count)
-            va.skip_above = 1; va.only_above = -1; va.big = 2;
-            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + kVWSlack;
-            va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
-            va.exist_cams = d_sc; va.n_exist_cams = v.n_sources;            // reverse-match runs are ordered by the segment's workgroup
-            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-        } else {
-            va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
-            va.kept_cnt = nullptr; va.best_depths = nullptr;
-            { ProfScope p(c, "verify"); launch_verify(va, st); }
-            { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
-        }
+        VerifyArgs va = chain_verify_args(c, v, d, dtab, cand_cap);
+        va.res = dres + k;
+        // (fused row starts: no statistics -- the largest LDS image the budget allows)
+        chain_launch_verify(c, va, d, d_sc, v.n_sources, fused_rows ? -1 : hstats[2 * k + 1], cand_cap, st);
         {
             ProfScope p(c, "kept_write");
             int pv = k - 1;

@@ -1,0 +1,230 @@
+// l3d_chain_common.hip -- see l3d_chain_common.hpp
+#include <algorithm>
+#include <string>
+
+#include "l3d_chain_common.hpp"
+
+namespace l3d {
+
+int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int rank, int world, std::vector<ChainViewDev>& vd, ChainLayout& L, const char* what)
+{
+    const std::string w(what);
+    vd.assign((size_t)n_views, ChainViewDev());
+    L = ChainLayout();
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        if (v.S_src < 0 || v.N < 0 || v.n_tbm < 0 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0) return fail(c, L3D_ERR_INVALID, w + ": inconsistent sizes");
+        ChainViewDev& d = vd[(size_t)k];
+        d.verified = v.n_tbm > 0;
+        d.s0 = (int)(((long long)v.S_src * rank) / world);
+        d.s1 = (int)(((long long)v.S_src * (rank + 1)) / world);
+        L.maxS = std::max(L.maxS, v.S_src); L.maxN = std::max(L.maxN, v.N);
+        if (!d.verified) continue;
+        if (!v.src_segs || !v.tgt_segs || !v.offsets || !v.F || !v.RtKinv || !v.centers || !v.P || !v.RtKinv_src || !v.C_src ||
+            !v.to_be_matched || !v.local2global || (v.n_sources && (!v.source_cam || !v.source_index)))
+            return fail(c, L3D_ERR_INVALID, w + ": null input pointer");
+        if (v.N > 255) return fail(c, L3D_ERR_INVALID, w + ": more than 255 neighbours");
+        for (int s = 0; s < v.n_sources; ++s)
+            if (v.source_index[s] < 0 || v.source_index[s] >= k || v.source_cam[s] < 0 || v.source_cam[s] >= v.N)
+                return fail(c, L3D_ERR_INVALID, w + ": a source must be an earlier view of the chain");
+        int maxW = 0;
+        double p = 0;
+        for (int j = 0; j < v.n_tbm; ++j) {
+            const int cam = v.to_be_matched[j];
+            if (cam < 0 || cam >= v.N) return fail(c, L3D_ERR_INVALID, w + ": to_be_matched out of range");
+            maxW = std::max(maxW, v.offsets[2 * cam + 1]);
+            p += (double)(d.s1 - d.s0) * v.offsets[2 * cam + 1];
+        }
+        for (int i = 0; i < v.N; ++i)
+            if (v.offsets[2 * i] < 0 || v.offsets[2 * i + 1] < 0 || v.offsets[2 * i] + v.offsets[2 * i + 1] > v.n_tgt)
+                return fail(c, L3D_ERR_INVALID, w + ": offsets outside the target tile");
+        L.pairs += p; L.max_pairs = std::max(L.max_pairs, p);
+        d.maxW = maxW;
+        d.W64 = 4 * ((maxW + 255) / 256);
+        if (d.W64 > kMaxW64) return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments");
+        // residency: segments stay in HBM; arrays not registered yet are registered now
+        if (!resident_ptr(c, v.src_segs, (size_t)v.S_src * 16)) { int rc = l3d_register_segments(c, v.src_segs, v.S_src); if (rc) return rc; }
+        if (!resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16)) { int rc = l3d_register_segments(c, v.tgt_segs, v.n_tgt); if (rc) return rc; }
+        d.src = reinterpret_cast<const float4*>(resident_ptr(c, v.src_segs, (size_t)v.S_src * 16));
+        d.tgt = reinterpret_cast<const float4*>(resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16));
+        const size_t N = (size_t)v.N;
+        size_t o = L.tab_bytes;
+        d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
+        d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
+        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
+        L.tab_bytes = chain_align16(o);
+        L.mask_bytes += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        L.rowcnt_ints += (size_t)v.S_src * v.N;
+        L.best_elems += (size_t)v.S_src;
+    }
+    return L3D_OK;
+}
+
+int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool with_rays, hipStream_t st)
+{
+    HIPCHK(c, c->ch_pin_tables.reserve(L.tab_bytes + 16));
+    HIPCHK(c, c->ch_tables.reserve(L.tab_bytes + 16));
+    unsigned char* tab = c->ch_pin_tables.as<unsigned char>();
+    for (int k = 0; k < n_views; ++k) {
+        const l3d_chain_view& v = views[k];
+        const ChainViewDev& d = vd[(size_t)k];
+        if (!d.verified) continue;
+        const size_t N = (size_t)v.N;
+        memcpy(tab + d.o_off, v.offsets, N * 8); memcpy(tab + d.o_F, v.F, N * 36); memcpy(tab + d.o_R, v.RtKinv, N * 36);
+        memcpy(tab + d.o_C, v.centers, N * 12); memcpy(tab + d.o_P, v.P, N * 48); memcpy(tab + d.o_Rs, v.RtKinv_src, 36);
+        memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
+        memcpy(tab + d.o_l2g, v.local2global, N * 4);
+        if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
+    }
+    if (L.tab_bytes) HIPCHK(c, hipMemcpyAsync(c->ch_tables.p, tab, L.tab_bytes, hipMemcpyHostToDevice, st));
+    L.dtab = c->ch_tables.as<unsigned char>();
+    // the viewing rays of every view's target endpoints, once per chain (they only depend on the neighbour's camera and segment)
+    size_t n_ray = 0;
+    int max_n_tgt = 0;
+    std::vector<RayJob>& jobs = c->ray_jobs;             // (lives in the context: the upload below is asynchronous)
+    jobs.clear();
+    for (int k = 0; k < n_views; ++k) {
+        vd[(size_t)k].rays = nullptr;
+        if (with_rays && vd[(size_t)k].verified && views[k].n_tbm != 0) n_ray += (size_t)views[k].n_tgt;
+    }
+    HIPCHK(c, c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
+    float4* rbase = c->ch_rays.as<float4>();
+    RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
+    size_t ro = 0;
+    for (int k = 0; k < n_views; ++k) {
+        ChainViewDev& d = vd[(size_t)k];
+        if (!with_rays || !d.verified || views[k].n_tbm == 0) continue;
+        d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
+        jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(L.dtab + d.o_off), reinterpret_cast<const float*>(L.dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
+        max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
+    }
+    if (!jobs.empty()) {
+        HIPCHK(c, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
+        ProfScope p(c, "tgt_rays", st);
+        launch_tgt_rays(djobs, (int)jobs.size(), max_n_tgt, st);
+    }
+    return L3D_OK;
+}
+
+int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, hipStream_t st)
+{
+    const size_t nv = (size_t)n_views;
+    HIPCHK(c, c->ch_mask.reserve(L.mask_bytes + 16));
+    HIPCHK(c, c->ch_rowcnt.reserve((L.rowcnt_ints + 2 * nv) * 4 + 16));
+    // (row starts | upper-bound counts | their block sums: the last two zeroed, k_pair_mask adds into them)
+    L.rowA_ints = L.rowcnt_ints + 4 * nv;
+    L.rowub_ints = fused_rows ? L.rowcnt_ints + 4 * nv : 0;
+    L.rowblk_ints = fused_rows ? L.rowcnt_ints / 256 + 8 * nv : 0;
+    HIPCHK(c, c->ch_rowA.reserve((L.rowA_ints + L.rowub_ints + L.rowblk_ints) * 4 + 64));
+    if (fused_rows) HIPCHK(c, hipMemsetAsync(c->ch_rowA.as<int>() + L.rowA_ints, 0, (L.rowub_ints + L.rowblk_ints) * 4, st));
+    HIPCHK(c, c->ch_best.reserve(L.best_elems * 8 + 16));
+    if (best_positions) HIPCHK(c, c->ch_bestpos.reserve(L.best_elems * 4 + 16));
+    HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (L.rowcnt_ints + 2 * nv) * 4, st));
+    size_t mo = 0, ro = 0, bo = 0, ao = 0, ko = 0;
+    int* stats_base = c->ch_rowcnt.as<int>() + L.rowcnt_ints;
+    for (int k = 0; k < n_views; ++k) {
+        ChainViewDev& d = vd[(size_t)k];
+        d.stats = stats_base + 2 * k;
+        if (!d.verified) continue;
+        const l3d_chain_view& v = views[k];
+        d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
+        mo += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
+        d.rowA = c->ch_rowA.as<int>() + ao;
+        if (fused_rows) {
+            d.rowub = c->ch_rowA.as<int>() + L.rowA_ints + ao;
+            d.rowblk = c->ch_rowA.as<int>() + L.rowA_ints + L.rowub_ints + ko;
+        }
+        ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;     // 16-byte aligned slices
+        ko += (((size_t)v.S_src * v.N + 255) / 256 + 4) & ~(size_t)3;
+        d.best = c->ch_best.as<float2>() + bo;
+        d.bestpos = best_positions ? c->ch_bestpos.as<int>() + bo : nullptr;
+        bo += (size_t)v.S_src;
+    }
+    const size_t nrow_max = (size_t)L.maxS * L.maxN;
+    HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));
+    HIPCHK(c, c->ch_cursor.reserve(nrow_max * 4 + 16));
+    HIPCHK(c, c->kept_cnt.reserve((size_t)L.maxS * 4 + 4));
+    HIPCHK(c, c->ch_segorder.reserve((size_t)L.maxS * 4 + 16));
+    HIPCHK(c, c->kept_start.reserve((size_t)L.maxS * 4 + 8));
+    return L3D_OK;
+}
+
+int chain_reserve_candidates(l3d_ctx* c, const ChainLayout&, size_t cand_cap, int ring)
+{
+    HIPCHK(c, c->cand_meta.reserve(cand_cap * 8));
+    HIPCHK(c, c->cand_depths.reserve(cand_cap * 16));
+    HIPCHK(c, c->cand_conf.reserve(cand_cap * 4));
+    HIPCHK(c, c->vw_scratch.reserve((cand_cap + kVWSlack) * 16));
+    if (ring > 0) {     // ring of stage-1 candidate buffers: stage 1 (incl. the triangulation of its candidates) runs views ahead of the chain
+        HIPCHK(c, c->ch_ringA_meta.reserve((size_t)ring * cand_cap * 8));
+        HIPCHK(c, c->ch_ringA_depths.reserve((size_t)ring * cand_cap * 16));
+    }
+    return L3D_OK;
+}
+
+PairArgs chain_pair_args(const l3d_ctx* c, const l3d_chain_view& v, const ChainViewDev& d, const unsigned char* dtab)
+{
+    PairArgs pa;
+    pa.src_segs = d.src; pa.tgt_segs = d.tgt;
+    pa.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
+    pa.F = reinterpret_cast<const float*>(dtab + d.o_F);
+    pa.RtKinv = reinterpret_cast<const float*>(dtab + d.o_R);
+    pa.centers = reinterpret_cast<const float*>(dtab + d.o_C);
+    pa.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
+    pa.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
+    pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
+    pa.mask = d.mask;
+    pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
+    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
+    pa.depth_in_fill = 1;               // the four depths of a stage-1 pair are triangulated once, by k_pair_fill
+    pa.tgt_rays = d.rays;
+    return pa;
+}
+
+VerifyArgs chain_verify_args(l3d_ctx* c, const l3d_chain_view& v, const ChainViewDev& d, const unsigned char* dtab, size_t cand_cap)
+{
+    VerifyArgs va;
+    va.exist_cams = nullptr; va.n_exist_cams = 0;
+    va.src_segs = d.src; va.tgt_segs = d.tgt;
+    va.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
+    va.P = reinterpret_cast<const float*>(dtab + d.o_P);
+    va.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
+    va.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
+    va.row_start = c->row_start.as<int>();
+    va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
+    va.N = v.N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = v.S_src * v.N;
+    va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
+    va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = nullptr;
+    va.seg_order = c->ch_segorder.as<int>();
+    va.mmax = 0; va.only_above = -1; va.skip_above = 0; va.big = 0;
+    va.kept_cnt = nullptr; va.best_depths = nullptr; va.scratch = nullptr; va.scratch_stride = 0;
+    return va;
+}
+
+void chain_launch_verify(l3d_ctx* c, VerifyArgs& va, const ChainViewDev& d, const int* exist_cams, int n_exist_cams, int raw_max_per_segment, size_t cand_cap, hipStream_t st)
+{
+    // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
+    // (raw_max_per_segment < 0: no statistics -- the largest image the budget allows; the budget, not the image, sets the occupancy)
+    int mmax = raw_max_per_segment < 0 ? 16384 : raw_max_per_segment + raw_max_per_segment / 4 + 64;
+    while (mmax > 64 && verify_window_lds_bytes(mmax, va.N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
+    va.mmax = mmax;
+    if (va.seg_end <= va.seg_begin) return;
+    if (c->verify_mode == 0 && verify_window_supported(va.N)) {
+        // one launch: segments that fit the LDS image, the ones that outgrow it (reverse matches are not in the estimate) on a global
+        // scratch, and the per-segment epilogue (best hypothesis, kept count)
+        va.skip_above = 1; va.only_above = -1; va.big = 2;
+        va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)cand_cap + kVWSlack;
+        va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
+        va.exist_cams = exist_cams; va.n_exist_cams = n_exist_cams;            // reverse-match runs are ordered by the segment's workgroup
+        ProfScope p(c, "verify_window", st);
+        launch_verify_window(va, st);
+    } else {
+        va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
+        va.kept_cnt = nullptr; va.best_depths = nullptr;
+        { ProfScope p(c, "verify", st); launch_verify(va, st); }
+        { ProfScope p(c, "seg_post", st); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
+    }
+}
+
+}  // namespace l3d

@@ -22,6 +22,7 @@
 #include "l3d_ctx.hpp"
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
+#include "l3d_chain_common.hpp"
 
 using namespace l3d;
 
@@ -194,18 +195,7 @@ __global__ void k_check_slots(const unsigned char* __restrict__ G, SlotGeom g, c
 
 namespace {
 
-struct SViewDev {
-    const float4 *src, *tgt;
-    size_t o_off, o_F, o_R, o_C, o_P, o_Rs, o_Cs, o_tbm, o_l2g, o_sc, o_si;
-    unsigned long long* mask;
-    int* rowcnt;
-    int* rowA;                               // row starts of the stage-1 candidates alone
-    int* stats;
-    float2* best;
-    float4* rays;                            // unit viewing rays of the target endpoints (k_tgt_rays), as in l3d_match_chain
-    int W64, maxW, s0, s1;
-    bool verified;
-};
+typedef l3d::ChainViewDev SViewDev;           // (s0, s1: this rank's source-segment range)
 
 size_t salign(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -262,47 +252,10 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     (void)hipGetLastError();
     l3d_shard_chain* h = new l3d_shard_chain();
     h->c = c; h->views = views; h->n_views = n_views; h->rank = rank; h->world = world;
-    h->vd.resize((size_t)n_views);
-    size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
-    double max_pairs = 0;
-    for (int k = 0; k < n_views; ++k) {
-        const l3d_chain_view& v = views[k];
-        SViewDev& d = h->vd[(size_t)k];
-        d.verified = v.n_tbm > 0;
-        d.s0 = (int)(((long long)v.S_src * rank) / world);
-        d.s1 = (int)(((long long)v.S_src * (rank + 1)) / world);
-        h->maxS = std::max(h->maxS, v.S_src); h->maxN = std::max(h->maxN, v.N);
-        if (!d.verified) continue;
-        if (v.S_src < 0 || v.N < 0 || v.N > 255 || v.n_tbm > v.N || v.n_sources < 0 || v.n_tgt < 0 || !v.src_segs || !v.tgt_segs || !v.offsets ||
-            !v.F || !v.RtKinv || !v.centers || !v.P || !v.RtKinv_src || !v.C_src || !v.to_be_matched || !v.local2global ||
-            (v.n_sources && (!v.source_cam || !v.source_index))) { delete h; return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_open: bad view"); }
-        for (int s = 0; s < v.n_sources; ++s)
-            if (v.source_index[s] < 0 || v.source_index[s] >= k || v.source_cam[s] < 0 || v.source_cam[s] >= v.N) { delete h; return fail(c, L3D_ERR_INVALID, "a source must be an earlier view"); }
-        int maxW = 0;
-        double p = 0;
-        for (int j = 0; j < v.n_tbm; ++j) {
-            const int cam = v.to_be_matched[j];
-            if (cam < 0 || cam >= v.N) { delete h; return fail(c, L3D_ERR_INVALID, "to_be_matched out of range"); }
-            maxW = std::max(maxW, v.offsets[2 * cam + 1]);
-            p += (double)(d.s1 - d.s0) * v.offsets[2 * cam + 1];
-        }
-        h->pairs += p; max_pairs = std::max(max_pairs, p);
-        d.maxW = maxW; d.W64 = 4 * ((maxW + 255) / 256);
-        if (d.W64 > kMaxW64) { delete h; return fail(c, L3D_ERR_INVALID, "a neighbour has more than 16384 segments"); }
-        if (!resident_ptr(c, v.src_segs, (size_t)v.S_src * 16)) { int rc = l3d_register_segments(c, v.src_segs, v.S_src); if (rc) { delete h; return rc; } }
-        if (!resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16)) { int rc = l3d_register_segments(c, v.tgt_segs, v.n_tgt); if (rc) { delete h; return rc; } }
-        d.src = reinterpret_cast<const float4*>(resident_ptr(c, v.src_segs, (size_t)v.S_src * 16));
-        d.tgt = reinterpret_cast<const float4*>(resident_ptr(c, v.tgt_segs, (size_t)v.n_tgt * 16));
-        const size_t N = (size_t)v.N;
-        size_t o = tab_bytes;
-        d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
-        d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
-        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
-        tab_bytes = salign(o, 16);
-        mask_bytes += salign((size_t)v.n_tbm * v.S_src * d.W64 * 8, 16);
-        rowcnt_ints += (size_t)v.S_src * v.N;
-        best_elems += (size_t)v.S_src;
-    }
+    ChainLayout L;
+    { int rc = chain_plan_views(c, views, n_views, rank, world, h->vd, L, "l3d_shard_chain_open"); if (rc) { delete h; return rc; } }
+    h->maxS = L.maxS; h->maxN = L.maxN; h->pairs = L.pairs;
+    const double max_pairs = L.max_pairs;
     h->geom.world = world;
     h->geom.seg_cap = (h->maxS + world - 1) / world + 1;
     h->geom.slot_records = slot_records;
@@ -313,65 +266,11 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
 
     auto bail = [&](int rc) { delete h; return rc; };
 #define OCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(L3D_ERR_HIP); } } while (0)
-    OCHK(c->ch_pin_tables.reserve(tab_bytes + 16));
-    OCHK(c->ch_tables.reserve(tab_bytes + 16));
-    unsigned char* tab = c->ch_pin_tables.as<unsigned char>();
-    for (int k = 0; k < n_views; ++k) {
-        const l3d_chain_view& v = views[k];
-        const SViewDev& d = h->vd[(size_t)k];
-        if (!d.verified) continue;
-        const size_t N = (size_t)v.N;
-        memcpy(tab + d.o_off, v.offsets, N * 8); memcpy(tab + d.o_F, v.F, N * 36); memcpy(tab + d.o_R, v.RtKinv, N * 36);
-        memcpy(tab + d.o_C, v.centers, N * 12); memcpy(tab + d.o_P, v.P, N * 48); memcpy(tab + d.o_Rs, v.RtKinv_src, 36);
-        memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
-        memcpy(tab + d.o_l2g, v.local2global, N * 4);
-        if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
-    }
-    OCHK(hipMemcpyAsync(c->ch_tables.p, tab, tab_bytes, hipMemcpyHostToDevice, st));
-    h->dtab = c->ch_tables.as<unsigned char>();
-    {   // the viewing rays of every view's target endpoints, once per chain (l3d_chain.hip)
-        size_t n_ray = 0;
-        int max_n_tgt = 0;
-        std::vector<RayJob>& jobs = c->ray_jobs;
-        jobs.clear();
-        for (int k = 0; k < n_views; ++k) { h->vd[(size_t)k].rays = nullptr; if (h->vd[(size_t)k].verified && views[k].n_tbm != 0) n_ray += (size_t)views[k].n_tgt; }
-        OCHK(c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
-        float4* rbase = c->ch_rays.as<float4>();
-        RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
-        size_t ro = 0;
-        for (int k = 0; k < n_views; ++k) {
-            SViewDev& d = h->vd[(size_t)k];
-            if (!d.verified || views[k].n_tbm == 0) continue;
-            d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
-            jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(h->dtab + d.o_off), reinterpret_cast<const float*>(h->dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
-            max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
-        }
-        if (!jobs.empty()) {
-            OCHK(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
-            launch_tgt_rays(djobs, (int)jobs.size(), max_n_tgt, st);
-        }
-    }
-    OCHK(c->ch_mask.reserve(mask_bytes + 16));
-    OCHK(c->ch_rowcnt.reserve((rowcnt_ints + 2 * (size_t)n_views) * 4 + 16));
-    OCHK(c->ch_rowA.reserve((rowcnt_ints + 4 * (size_t)n_views) * 4 + 64));
-    OCHK(c->ch_best.reserve(best_elems * 8 + 16));
+    // tables, target rays, per-view slices of the whole-run arenas (l3d_chain_common.hip: shared with the single-GPU chain)
+    { int rc = chain_upload_tables(c, views, n_views, h->vd, L, true, st); if (rc) return bail(rc); }
+    { int rc = chain_assign_arenas(c, views, n_views, h->vd, L, false, false, st); if (rc) return bail(rc); }
+    h->dtab = L.dtab;
     OCHK(c->ch_pin_res.reserve((size_t)n_views * 8 + 64));
-    OCHK(hipMemsetAsync(c->ch_rowcnt.p, 0, (rowcnt_ints + 2 * (size_t)n_views) * 4, st));
-    {
-        size_t mo = 0, ro = 0, bo = 0, ao = 0;
-        int* stats_base = c->ch_rowcnt.as<int>() + rowcnt_ints;
-        for (int k = 0; k < n_views; ++k) {
-            SViewDev& d = h->vd[(size_t)k];
-            d.stats = stats_base + 2 * k;
-            if (!d.verified) continue;
-            const l3d_chain_view& v = views[k];
-            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
-            mo += salign((size_t)v.n_tbm * v.S_src * d.W64 * 8, 16);
-            d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
-            d.rowA = c->ch_rowA.as<int>() + ao; ao += ((size_t)v.S_src * v.N + 4) & ~(size_t)3;
-            d.best = c->ch_best.as<float2>() + bo; bo += (size_t)v.S_src;
-        }
-    }
     h->hstats = c->ch_pin_res.as<int>();
     OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hstats_dev), h->hstats, 0));
     {   // stage 1 (own stream) starts after the tables and the zeroed row counts are in place
@@ -380,19 +279,8 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
         OCHK(hipStreamWaitEvent(c->stage1_stream, ready, 0));
         c->event_pool.push_back(ready);
     }
-    h->cand_cap = c->test_cand_cap ? c->test_cand_cap : (size_t)(max_pairs * 0.12) + 65536;     // (l3d_set_chain_capacities: tests, retries with more room)
-    const size_t nrow_max = (size_t)h->maxS * h->maxN;
-    OCHK(c->row_start.reserve((nrow_max + 1) * 4));
-    OCHK(c->ch_cursor.reserve(nrow_max * 4 + 16));
-    OCHK(c->kept_cnt.reserve((size_t)h->maxS * 4 + 4));
-    OCHK(c->ch_segorder.reserve((size_t)h->maxS * 4 + 16));
-    OCHK(c->kept_start.reserve((size_t)h->maxS * 4 + 8));
-    OCHK(c->cand_meta.reserve(h->cand_cap * 8));
-    OCHK(c->cand_depths.reserve(h->cand_cap * 16));
-    OCHK(c->cand_conf.reserve(h->cand_cap * 4));
-    OCHK(c->vw_scratch.reserve((h->cand_cap + kVWSlack) * 16));
-    OCHK(c->ch_ringA_meta.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 8));
-    OCHK(c->ch_ringA_depths.reserve((size_t)l3d_shard_chain::kRingA * h->cand_cap * 16));
+    h->cand_cap = c->test_cand_cap ? c->test_cand_cap : chain_first_cand_cap(max_pairs);     // (l3d_set_chain_capacities: tests, retries with more room)
+    { int rc = chain_reserve_candidates(c, L, h->cand_cap, l3d_shard_chain::kRingA); if (rc) return bail(rc); }
     h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
     OCHK(c->ch_pin_kept.reserve(2 * ((size_t)world * (size_t)h->geom.seg_cap * 8 + 64) + 64));
     c->pin_arena.reset();
@@ -411,27 +299,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     return L3D_OK;
 }
 
-static PairArgs shard_pair_args(l3d_shard_chain* h, int k)
-{
-    const l3d_chain_view& v = h->views[k];
-    const SViewDev& d = h->vd[(size_t)k];
-    const unsigned char* dtab = h->dtab;
-    PairArgs pa;
-    pa.src_segs = d.src; pa.tgt_segs = d.tgt;
-    pa.offsets = reinterpret_cast<const int2*>(dtab + d.o_off);
-    pa.F = reinterpret_cast<const float*>(dtab + d.o_F);
-    pa.RtKinv = reinterpret_cast<const float*>(dtab + d.o_R);
-    pa.centers = reinterpret_cast<const float*>(dtab + d.o_C);
-    pa.RtKinv_src = reinterpret_cast<const float*>(dtab + d.o_Rs);
-    pa.C_src = reinterpret_cast<const float*>(dtab + d.o_Cs);
-    pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
-    pa.mask = d.mask;
-    pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = h->c->wedge_pretest; pa.dbg = h->c->pair_dbg; pa.rowcnt = nullptr;
-    pa.depth_in_fill = 1;               // the depths of a stage-1 pair are triangulated once, by k_pair_fill (as in l3d_match_chain)
-    pa.tgt_rays = d.rays;
-    return pa;
-}
+static PairArgs shard_pair_args(l3d_shard_chain* h, int k) { return chain_pair_args(h->c, h->views[k], h->vd[(size_t)k], h->dtab); }
 
 static int shard_stage1(l3d_shard_chain* h, int k)
 {
@@ -513,35 +381,9 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         ProfScope p(c, "exist");
         launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
     }
-    VerifyArgs va;
-    va.exist_cams = nullptr; va.n_exist_cams = 0;
-    va.src_segs = d.src; va.tgt_segs = d.tgt; va.offsets = pa.offsets;
-    va.P = reinterpret_cast<const float*>(dtab + d.o_P);
-    va.RtKinv_src = pa.RtKinv_src; va.C_src = pa.C_src;
-    va.row_start = c->row_start.as<int>();
-    va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
-    va.N = N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = (int)nrow;
-    va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
-    va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)h->cand_cap; va.res = nullptr;
-    va.seg_order = c->ch_segorder.as<int>();
-    int mmax = h->hstats[2 * k + 1] + h->hstats[2 * k + 1] / 4 + 64;
-    while (mmax > 64 && verify_window_lds_bytes(mmax, N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
-    va.mmax = mmax;
-    if (d.s1 > d.s0) {
-        if (c->verify_mode == 0 && verify_window_supported(N)) {
-            // one launch: LDS blocks, global-scratch blocks for segments that outgrow the LDS image, per-segment epilogue
-            va.skip_above = 1; va.only_above = -1; va.big = 2;
-            va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)h->cand_cap + kVWSlack;
-            va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
-            va.exist_cams = d_sc; va.n_exist_cams = v.n_sources;            // reverse-match runs are ordered by the segment's workgroup
-            { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
-        } else {
-            va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
-            va.kept_cnt = nullptr; va.best_depths = nullptr;
-            { ProfScope p(c, "verify"); launch_verify(va, st); }
-            { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), d.best, st); }
-        }
-    }
+    VerifyArgs va = chain_verify_args(c, v, d, dtab, h->cand_cap);
+    chain_launch_verify(c, va, d, d_sc, v.n_sources, h->hstats[2 * k + 1], h->cand_cap, st);
+    const int mmax = va.mmax;
     {
         ProfScope p(c, "kept_write");
         hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, d.s1 - d.s0)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
