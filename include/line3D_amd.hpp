@@ -2,8 +2,8 @@
 // over the C ABI of include/line3d_amd.h.  Same method names, argument order and defaults (commons.h:42-61).
 // Differences forced by the scope: `cv::Mat image` is replaced by the segments the detector would have produced
 // (std::vector<float4>, the side door the reference itself has in L3DSegments(list<float4>&, bool), segments.h:60)
-// plus the image size; Eigen types are replaced by plain row-major double arrays.  When Eigen is available,
-// define L3D_AMD_WITH_EIGEN before including this header to get the Eigen-typed overloads the drivers use.
+// plus the image size; cameras are plain row-major double arrays or any matrix type with K(i, j) / t(i) access (Eigen's, as the
+// reference's drivers pass them) -- Eigen itself is not needed to compile this header.
 #pragma once
 
 #include <array>
@@ -16,10 +16,6 @@
 #include <vector>
 
 #include "line3d_amd.h"
-
-#ifdef L3D_AMD_WITH_EIGEN
-#include <Eigen/Core>
-#endif
 
 namespace L3D {
 
@@ -56,7 +52,7 @@ private:
 
 class Line3D {
 public:
-    // line3D.h:61-66 (data_directory: where the segment caches of an earlier run are looked up, addImageFromCache; nothing is written)
+    // line3D.h:61-66 (data_directory: where addImage keeps its segment caches, line3D.cc:143-150)
     Line3D(const std::string data_directory, const int matchingNeighbors = 10,
            const float uncertainty_t_upper_2D = 5.0f, const float uncertainty_t_lower_2D = 1.0f,
            const float sigma_p = 3.5f, const float sigma_a = 10.0f, const float min_baseline = 0.25f,
@@ -72,14 +68,16 @@ public:
     Line3D& operator=(const Line3D&) = delete;
     bool valid() const { return h_ != nullptr; }
 
-    // line3D.h:69-73; errors are printed and the call returns, like the reference (line3D.cc:101-127)
+    // line3D.h:69-73; errors are printed and the call returns, like the reference (line3D.cc:101-127).  `image` is replaced by its size
+    // and the segments the detector would have produced; maxImgWidth / loadAndStoreSegments keep their meaning: the segment cache
+    // "<data_directory>/segments_<id>_<w'>x<h'>_coll<0|1>.bin" is removed, read INSTEAD of `segments`, or written (line3D.cc:128-199)
     void addImage(const unsigned int imageID, const unsigned int width, const unsigned int height,
                   const std::vector<float4>& segments, const double K[9], const double R[9], const double t[3],
-                  std::list<unsigned int>& worldpointIDs)
+                  std::list<unsigned int>& worldpointIDs, const int maxImgWidth = 1920, const bool loadAndStoreSegments = true)
     {
         std::vector<uint32_t> wps(worldpointIDs.begin(), worldpointIDs.end());
-        report(l3d_line3d_add_image(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x, (int)segments.size(),
-                                    K, R, t, wps.data(), (int)wps.size()));
+        report(l3d_line3d_add_image_ex(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x, (int)segments.size(),
+                                       K, R, t, wps.data(), (int)wps.size(), data_directory_.c_str(), maxImgWidth, loadAndStoreSegments ? 1 : 0));
     }
     // addImage when "<data_directory>/segments_<id>_<w>x<h>_coll<0|1>.bin" of an earlier run exists (line3D.cc:143-168):
     // the file's segments and collinearities stand in for the image (the detector is not part of this library).
@@ -101,23 +99,34 @@ public:
     // line3D.h:75-79
     void addImage_fixed_sim(const unsigned int imageID, const unsigned int width, const unsigned int height,
                             const std::vector<float4>& segments, const double K[9], const double R[9], const double t[3],
-                            std::map<unsigned int, float>& viewSimilarity)
+                            std::map<unsigned int, float>& viewSimilarity, const int maxImgWidth = 1920, const bool loadAndStoreSegments = true)
     {
         std::vector<uint32_t> ids;
         std::vector<float> sims;
         for (auto& kv : viewSimilarity) { ids.push_back(kv.first); sims.push_back(kv.second); }
-        report(l3d_line3d_add_image_fixed_sim(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x,
-                                              (int)segments.size(), K, R, t, ids.data(), sims.data(), (int)ids.size()));
+        report(l3d_line3d_add_image_fixed_sim_ex(h_, imageID, width, height, segments.empty() ? nullptr : &segments[0].x, (int)segments.size(), K, R, t,
+                                                 ids.data(), sims.data(), (int)ids.size(), data_directory_.c_str(), maxImgWidth, loadAndStoreSegments ? 1 : 0));
     }
-#ifdef L3D_AMD_WITH_EIGEN
+    // The same two calls with matrix-typed cameras, as the reference's drivers pass them (Eigen::Matrix3d K, R; Eigen::Vector3d t,
+    // main_vsfm.cpp:273-281): any type with K(i, j) / t(i) access -- Eigen is not a dependency of this header.
+    template <class M3, class V3, class = decltype(std::declval<const M3&>()(0, 0)), class = decltype(std::declval<const V3&>()(0))>
     void addImage(const unsigned int imageID, const unsigned int width, const unsigned int height, const std::vector<float4>& segments,
-                  const Eigen::Matrix3d K, const Eigen::Matrix3d R, const Eigen::Vector3d t, std::list<unsigned int>& worldpointIDs)
+                  const M3& K, const M3& R, const V3& t, std::list<unsigned int>& worldpointIDs, const int maxImgWidth = 1920,
+                  const bool loadAndStoreSegments = true)
     {
         double k[9], r[9], tt[3];
-        for (int i = 0; i < 3; ++i) { tt[i] = t(i); for (int j = 0; j < 3; ++j) { k[i * 3 + j] = K(i, j); r[i * 3 + j] = R(i, j); } }
-        addImage(imageID, width, height, segments, k, r, tt, worldpointIDs);
+        flatten(K, R, t, k, r, tt);
+        addImage(imageID, width, height, segments, k, r, tt, worldpointIDs, maxImgWidth, loadAndStoreSegments);
     }
-#endif
+    template <class M3, class V3, class = decltype(std::declval<const M3&>()(0, 0)), class = decltype(std::declval<const V3&>()(0))>
+    void addImage_fixed_sim(const unsigned int imageID, const unsigned int width, const unsigned int height, const std::vector<float4>& segments,
+                            const M3& K, const M3& R, const V3& t, std::map<unsigned int, float>& viewSimilarity, const int maxImgWidth = 1920,
+                            const bool loadAndStoreSegments = true)
+    {
+        double k[9], r[9], tt[3];
+        flatten(K, R, t, k, r, tt);
+        addImage_fixed_sim(imageID, width, height, segments, k, r, tt, viewSimilarity, maxImgWidth, loadAndStoreSegments);
+    }
     // line3D.h:82
     void compute3Dmodel(bool perform_diffusion = false) { report(l3d_line3d_compute3Dmodel(h_, perform_diffusion ? 1 : 0)); }
     // line3D.h:85
@@ -188,6 +197,10 @@ public:
     l3d_line3d* handle() { return h_; }
 
 private:
+    template <class M3, class V3> static void flatten(const M3& K, const M3& R, const V3& t, double* k, double* r, double* tt)
+    {
+        for (int i = 0; i < 3; ++i) { tt[i] = t(i); for (int j = 0; j < 3; ++j) { k[i * 3 + j] = K(i, j); r[i * 3 + j] = R(i, j); } }
+    }
     void report(int rc) { if (rc != L3D_OK) std::cerr << prefix_ << l3d_line3d_last_error(h_) << std::endl; }
     l3d_line3d* h_;
     std::string prefix_, data_directory_;

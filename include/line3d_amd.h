@@ -487,6 +487,22 @@ int l3d_segment_cache_write(const char* path, const float* segments, int n_segme
 int l3d_line3d_add_image_cached(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height, const l3d_segment_cache* cache,
                                 const double* K, const double* R, const double* t, const uint32_t* worldpoint_ids, int n_worldpoints);
 
+/* Line3D::addImage / addImage_fixed_sim with the reference's cache behaviour (line3D.cc:128-199, 253-324): the cache file of the
+ * view is "<data_directory>/segments_<id>_<w'>x<h'>_coll<0|1>.bin" with (w', h') the image size after the max_img_width
+ * down-scaling the detector would have worked at (line3D.cc:133-138; the view itself keeps the original size).
+ *   file exists, load_and_store == 0   the file is removed (line3D.cc:153-156), `segments` are used
+ *   file exists, load_and_store != 0   segments AND collinearities come from the file, `segments` are ignored (:159-168)
+ *   otherwise                          `segments` are used; with load_and_store != 0 the cache is written (:180-182) -- at
+ *                                      prepare(), when the collinearities of all new views have been computed in one batch
+ * `segments` is what detectLineSegments (line3D.cc:1789-1871: LSD, length filter, longest 3000) would have produced.
+ * links: observed world point ids (add_image_ex) or (view id, similarity) pairs (add_image_fixed_sim_ex). */
+int l3d_line3d_add_image_ex(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height, const float* segments, int n_segments,
+                            const double* K, const double* R, const double* t, const uint32_t* worldpoint_ids, int n_worldpoints,
+                            const char* data_directory, int max_img_width, int load_and_store);
+int l3d_line3d_add_image_fixed_sim_ex(l3d_line3d* h, uint32_t image_id, unsigned width, unsigned height, const float* segments, int n_segments,
+                                      const double* K, const double* R, const double* t, const uint32_t* sim_ids, const float* sims, int n_sims,
+                                      const char* data_directory, int max_img_width, int load_and_store);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ struct View {                                   // L3DView, view.h:40-153
     float unc_upper_px = 0, unc_lower_px = 0, k_upper = 0, k_lower = 0, median_depth = 1.0f;
     std::vector<float> segs;                    // S x 4
     bool coll_pending = false;                  // the relation is still to be computed (prepare: all views in one batch)
+    std::string cache_to_write;                 // addImage with loadAndStoreSegments: the segment cache to write once the relation is there (line3D.cc:180-182)
     std::vector<int> coll_start;                // CSR of segment2collinearities_ (segments.h:84-97)
     std::vector<int> coll_other;
     std::vector<float> coll_w;
@@ -715,6 +716,23 @@ void finalize_matching(L* h)
     h->t_finalize += now_s() - t0;
 }
 
+// serializeToFile of addImage with loadAndStoreSegments (line3D.cc:180-182), deferred to prepare(): the collinearity map of
+// segment2collinearities_ as directed entries, ascending (i, j)
+void write_pending_caches(L* h)
+{
+    for (auto& kv : h->views) {
+        View& v = kv.second;
+        if (v.cache_to_write.empty()) continue;
+        std::vector<int32_t> ci, cj;
+        std::vector<float> cw;
+        for (int s = 0; s < v.S(); ++s)
+            for (int q = v.coll_start[(size_t)s]; q < v.coll_start[(size_t)s + 1]; ++q) { ci.push_back(s); cj.push_back(v.coll_other[(size_t)q]); cw.push_back(v.coll_w[(size_t)q]); }
+        const int rc = l3d_segment_cache_write(v.cache_to_write.c_str(), v.segs.data(), v.S(), ci.data(), cj.data(), cw.data(), (int)ci.size(), 17);
+        if (rc && h->verbose) fprintf(stderr, "[L3D] could not write %s\n", v.cache_to_write.c_str());      // (the reference's ofstream fails silently)
+        v.cache_to_write.clear();
+    }
+}
+
 void drop_plan(L* h);           // the cached matchViews schedule depends on the set of views and their neighbours
 
 int prepare(L* h)
@@ -765,6 +783,7 @@ int prepare(L* h)
     lap("neighbour tiles + residency");
     rc = compute_pending_collinearities(h);             // (the segments are resident now: nothing is uploaded again)
     if (rc) return rc;
+    write_pending_caches(h);
     lap("collinearity (all views)");
     h->prepared = true;
     return L3D_OK;
@@ -2086,6 +2105,84 @@ int l3d_line3d_add_image_cached(l3d_line3d* h, uint32_t id, unsigned width, unsi
     int rc = make_view(h, id, width, height, segs.data(), n, K, R, t, ci.data(), cj.data(), cw.data(), nc);
     if (rc) return rc;
     process_worldpoints(h, id, worldpoints, n_wps);
+    return L3D_OK;
+}
+
+// the cache decisions of addImage / addImage_fixed_sim, line3D.cc:128-199: returns 1 when the view was added from the cache file,
+// 0 when the caller's segments are to be used (cache_path set when the file is to be written), < 0: error code negated
+static int add_from_cache_or_plan_write(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const double* K, const double* R, const double* t,
+                                        const char* data_directory, int max_img_width, int load_and_store, std::string& cache_path)
+{
+    unsigned new_w = width, new_h = height;
+    if (max_img_width > 0 && (int)std::max(width, height) > max_img_width) {                 // :133-138
+        const float scale = float(max_img_width) / fmaxf((float)height, (float)width);
+        new_w = (unsigned)roundf(float(width) * scale);
+        new_h = (unsigned)roundf(float(height) * scale);
+    }
+    char name[160];
+    if (l3d_segment_cache_filename(id, new_w, new_h, h->use_collinearity ? 1 : 0, name, sizeof(name)) != L3D_OK) return -L3D_ERR_INVALID;
+    const std::string file = std::string(data_directory ? data_directory : "") + name;
+    FILE* f = fopen(file.c_str(), "rb");
+    const bool exists = f != nullptr;
+    if (f) fclose(f);
+    cache_path.clear();
+    if (exists && !load_and_store) { remove(file.c_str()); return 0; }                        // :153-156
+    if (exists) {                                                                            // :159-168
+        l3d_segment_cache* cache = nullptr;
+        int rc = l3d_segment_cache_read(file.c_str(), &cache);
+        if (rc != L3D_OK) { h->fail(rc, l3d_segment_cache_last_error(cache)); l3d_segment_cache_free(cache); return -rc; }   // (the reference exits, serialization.h:63)
+        const int n = l3d_segment_cache_num_segments(cache), nc = l3d_segment_cache_num_collinearities(cache);
+        std::vector<float> segs((size_t)n * 4 + 1), cw((size_t)nc + 1);
+        std::vector<int32_t> ci((size_t)nc + 1), cj((size_t)nc + 1);
+        l3d_segment_cache_get(cache, segs.data(), ci.data(), cj.data(), cw.data());
+        l3d_segment_cache_free(cache);
+        if (n <= 0) return -h->fail(L3D_ERR_INVALID, "no segments");
+        rc = make_view(h, id, width, height, segs.data(), n, K, R, t, ci.data(), cj.data(), cw.data(), nc);
+        return rc ? -rc : 1;
+    }
+    if (load_and_store) cache_path = file;                                                   // :180-182
+    return 0;
+}
+
+int l3d_line3d_add_image_ex(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n, const double* K, const double* R,
+                            const double* t, const uint32_t* worldpoints, int n_wps, const char* data_directory, int max_img_width, int load_and_store)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (h->computation) return h->fail(L3D_ERR_INVALID, "reconstruction already performed! cannot add more images (try reset first)");
+    if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
+    if (n_wps == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
+    if (width == 0 || height == 0 || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "image is empty!");
+    std::string cache_path;
+    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path);
+    if (from_cache < 0) return -from_cache;
+    if (!from_cache) {
+        const int rc = add_common(h, id, width, height, segs, n, K, R, t, n_wps);
+        if (rc) return rc;
+        h->views[id].cache_to_write = cache_path;
+    }
+    process_worldpoints(h, id, worldpoints, n_wps);
+    return L3D_OK;
+}
+
+int l3d_line3d_add_image_fixed_sim_ex(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const float* segs, int n, const double* K, const double* R,
+                                      const double* t, const uint32_t* sim_ids, const float* sims, int n_sims, const char* data_directory, int max_img_width,
+                                      int load_and_store)
+{
+    if (!h) return L3D_ERR_INVALID;
+    if (h->computation) return h->fail(L3D_ERR_INVALID, "reconstruction already performed! cannot add more images (try reset first)");
+    if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
+    if (n_sims == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
+    if (width == 0 || height == 0 || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "image is empty!");
+    std::string cache_path;
+    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path);
+    if (from_cache < 0) return -from_cache;
+    if (!from_cache) {
+        const int rc = add_common(h, id, width, height, segs, n, K, R, t, n_sims);
+        if (rc) return rc;
+        h->views[id].cache_to_write = cache_path;
+    }
+    for (int i = 0; i < n_sims; ++i)                       // setViewSimilarity, :1938-1946
+        if (sims[i] > 0.01f) h->view_similarities[id][sim_ids[i]] = sims[i];
     return L3D_OK;
 }
 

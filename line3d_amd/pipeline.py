@@ -77,6 +77,25 @@ class Line3D:
             close_segment_cache(cache)
         return rc == 0
 
+    def addImage_ex(self, imageID, width, height, segments, K, R, t, links, maxImgWidth=1920, loadAndStoreSegments=True, fixed_sim=False):
+        """addImage / addImage_fixed_sim with the reference's segment-cache behaviour in `data_directory` (line3D.cc:128-199): the cache
+        file is removed, read instead of `segments`, or written.  links: world point ids, or {view id: similarity} with fixed_sim."""
+        segs = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
+        K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))
+        d = self.data_directory.encode()
+        if fixed_sim:
+            ids = np.ascontiguousarray(sorted(links), dtype=np.uint32)
+            sims = np.ascontiguousarray([links[int(i)] for i in ids], dtype=np.float32)
+            rc = self.lib.l3d_line3d_add_image_fixed_sim_ex(self.h, C.c_uint32(imageID), C.c_uint(width), C.c_uint(height), _p(segs), C.c_int(len(segs)),
+                                                            _p(K), _p(R), _p(t), _p(ids), _p(sims), C.c_int(len(ids)), C.c_char_p(d), C.c_int(maxImgWidth),
+                                                            C.c_int(int(loadAndStoreSegments)))
+        else:
+            wps = np.ascontiguousarray(list(links), dtype=np.uint32)
+            rc = self.lib.l3d_line3d_add_image_ex(self.h, C.c_uint32(imageID), C.c_uint(width), C.c_uint(height), _p(segs), C.c_int(len(segs)),
+                                                  _p(K), _p(R), _p(t), _p(wps), C.c_int(len(wps)), C.c_char_p(d), C.c_int(maxImgWidth),
+                                                  C.c_int(int(loadAndStoreSegments)))
+        return rc == 0
+
     def addImage_fixed_sim(self, imageID, width, height, segments, K, R, t, viewSimilarity):
         segs = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
         K, R, t = (np.ascontiguousarray(a, dtype=np.float64) for a in (K, R, t))

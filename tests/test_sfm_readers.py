@@ -225,3 +225,54 @@ def test_sfm_readers_survive_corrupted_files(sfm_scene, tmp_path):
                 assert str(e)
                 outcomes["refused"] += 1
         assert outcomes["read"] + outcomes["refused"] == 120
+
+
+@pytest.mark.gpu
+def test_add_image_writes_reads_and_removes_segment_caches(small_scene, small_oracle, tmp_path):
+    """Line3D::addImage's cache behaviour (line3D.cc:128-199, loadAndStoreSegments): a first run writes one cache per view
+    (segments + the collinearity relation, the bytes the oracle's writer produces), a second run reads them INSTEAD of the segments
+    it is handed (here: garbage) and reconstructs the same lines, a run with loadAndStoreSegments = false removes them, and
+    maxImgWidth decides the size in the file name (line3D.cc:133-150)."""
+    import l3d_oracle_pipeline as op
+    from line3d_amd.pipeline import Line3D
+    from line3d_amd.io import segment_cache_filename
+    d = str(tmp_path / "L3D_data")
+    os.makedirs(d)
+
+    def run(segments_of, load_and_store, max_w=1920):
+        l = Line3D(d, matchingNeighbors=6)
+        for v in small_scene.views:
+            assert l.addImage_ex(v["id"], v["width"], v["height"], segments_of(v), v["K"], v["R"], v["t"], v["sims"], max_w, load_and_store, fixed_sim=True)
+        l.compute3Dmodel(False)
+        return l
+
+    l1 = run(lambda v: v["segments"], True)
+    assert_lines_equal(l1.getResult(), small_oracle.result, 1e-4)
+    files = sorted(os.listdir(d))
+    assert files == sorted(segment_cache_filename(v["id"], v["width"], v["height"], True)[1:] for v in small_scene.views)
+    olib = op.load_lib()
+    for v in small_scene.views:                                   # the oracle's writer on the oracle's relation: the same bytes
+        rel = op.collinearity(olib, v["segments"], 2.0)
+        coll = {}
+        ii, jj = np.nonzero(np.triu(rel > 0.0, 1))
+        for a, b in zip(ii.tolist(), jj.tolist()):
+            coll.setdefault(a, {})[b] = rel[b, a]
+            coll.setdefault(b, {})[a] = rel[b, a]
+        ref = str(tmp_path / "ref.bin")
+        osfm.write_segment_cache(ref, v["segments"], coll, library_version=17)
+        got = open(d + segment_cache_filename(v["id"], v["width"], v["height"], True), "rb").read()
+        assert got == open(ref, "rb").read()
+    l1.close()
+    junk = np.array([[1.0, 2.0, 30.0, 40.0]] * 7, np.float32)
+    l2 = run(lambda v: junk, True)                               # the caches stand in for the segments
+    assert_lines_equal(l2.getResult(), small_oracle.result, 1e-4)
+    l2.close()
+    l3 = run(lambda v: v["segments"], False)                     # loadAndStoreSegments = false: the files are removed, nothing is written
+    assert os.listdir(d) == []
+    assert_lines_equal(l3.getResult(), small_oracle.result, 1e-4)
+    l3.close()
+    l4 = run(lambda v: v["segments"], True, max_w=960)           # the detector would have worked at half size: that size names the file
+    v0 = small_scene.views[0]
+    assert segment_cache_filename(v0["id"], 960, 540, True)[1:] in os.listdir(d)
+    assert_lines_equal(l4.getResult(), small_oracle.result, 1e-4)
+    l4.close()
