@@ -132,6 +132,19 @@ def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
                 seconds=dt, verify_iterations_per_s=stats[2] / dt)
 
 
+def workload_name(n_gpus, V, S, N):
+    """which BASELINE.json config the shape is"""
+    if (S, N) == (2000, 12):
+        if n_gpus == 1 and V == 64:
+            return "BASELINE configs[1]"
+        if V == 512:
+            return "BASELINE configs[2]" + ("" if n_gpus == 8 else " (its 512 views on %d GPU%s)" % (n_gpus, "" if n_gpus == 1 else "s"))
+        return "BASELINE configs[1] grown to %d views per GPU" % (V // max(1, n_gpus))
+    if (S, N) == (4000, 24):
+        return "BASELINE configs[4] per-view shape (4000 segments, 24 neighbours) at %d of its 2048 views" % V
+    return "custom shape"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -366,9 +379,8 @@ def main():
         out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="%s: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+bookkeeping)"
-                                        % ("BASELINE configs[1]" if n_gpus == 1 else ("BASELINE configs[2]" if V == 512 else "BASELINE configs[1] grown to 64 views per GPU"),
-                                           V, args.segments, args.neighbors),
+                   config=dict(workload="%s: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+products of performMatching)"
+                                        % (workload_name(n_gpus, V, args.segments, args.neighbors), V, args.segments, args.neighbors),
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
                                parallelism=("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU"),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
