@@ -431,10 +431,18 @@ def main():
                 l3d.match_views()
                 lists = {v["id"]: l3d.view_matches(v["id"])[0] for v in scene.views[: len(scene.views) // 2]}
             out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments, lists)
-        print(json.dumps(out))
     l3d.close()
+    if sharded_mode["link"] is not None:
+        sharded_mode["link"].close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)        # the ONE line
+    if dist is not None:
+        # RCCL prints a version banner to stdout from an exit handler: leave without running those (everything of ours is closed and flushed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
