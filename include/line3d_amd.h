@@ -171,6 +171,14 @@ int l3d_clustering_edges(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, 
  * group_start (callee-allocated, l3d_free): n_groups + 1 offsets into sorted_out. */
 int l3d_clustering_edges_grouped(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, l3d_edge* sorted_out,
                                  int32_t** group_start, int* n_groups);
+/* clusterSegments2D's tail in one call (line3D.cc:1239-1246 -> clustering.cc:6-47, universe.h:59-115): [performDiffusion,]
+ * the grouped order above and the MERGE LOOP of performClustering on the device, one wave per connected component (the loop is
+ * sequential only inside a component; each is walked in LDS with the unions, ranks and roots of the one sequential walk).
+ * labels (n_nodes, caller-allocated): labels[k] = CLUniverse::find(k), bit-equal to performClustering's.  c: the reference
+ * passes 1.0 (line3D.cc:1245).  n_components (may be NULL): connected components that hold an edge.
+ * A == NULL: the resident list of l3d_affinity_fill, as above.  L3D_ERR_UNSUPPORTED as for l3d_clustering_edges. */
+int l3d_perform_clustering_device(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, float c, int32_t* labels,
+                                  int* n_components);
 
 /* The line fit of Line3D::processClusteredSegments (line3D.cc:1306-1597: getLineEquation3D, projectToLine) for many clusters at
  * once, on the device.  A cluster = its members' hypothesis indices in key order (camera, segment):
@@ -270,6 +278,9 @@ int l3d_products_hypotheses(l3d_ctx* ctx, const l3d_view_geometry* geometry, int
  * host -- uploaded when coll_changed != 0, otherwise the copy of the previous call is used.  Outputs as l3d_affinity_fill. */
 int l3d_affinity_fill_resident(l3d_ctx* ctx, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed,
                                float sigma_a, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes, int* n_candidates);
+/* (edges == NULL: the list is not copied to the host -- it stays resident for l3d_perform_clustering_device / l3d_clustering_edges(A
+ * = NULL) and can be fetched later, also after the clustering consumed it: ) */
+int l3d_resident_edges_get(l3d_ctx* ctx, l3d_edge* out, int nnz);
 /* the resident hypothesis table (n_hyp entries of l3d_products_hypotheses) copied to the host */
 int l3d_products_hypotheses_get(l3d_ctx* ctx, l3d_hypothesis* hyp, float* score);
 

@@ -261,6 +261,15 @@ class Context:
         self.lib.l3d_free(gs)
         return out, start
 
+    def perform_clustering_device(self, edges, n_nodes, c=1.0, perform_diffusion=False, iters=10):
+        """l3d_perform_clustering_device: [diffusion +] performClustering's merge loop on the device -> (labels (n_nodes,), components with an edge)."""
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        labels = np.full(max(n_nodes, 1), -1, dtype=np.int32)
+        nc = C.c_int(0)
+        self._chk(self.lib.l3d_perform_clustering_device(self.h, _p(edges), C.c_int(len(edges)), C.c_int(n_nodes), C.c_int(int(perform_diffusion)),
+                                                         C.c_int(iters), C.c_float(c), _p(labels), C.byref(nc)))
+        return labels[:n_nodes], nc.value
+
     def fit_clusters(self, group_start, member_hyp, hyp, hyp_cam, Rinv, scale_inv, tneg):
         """l3d_fit_clusters: -> list (one per cluster) of lists of (start (3,), end (3,)) float64."""
         gs = np.ascontiguousarray(group_start, np.int32)

@@ -558,10 +558,11 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     int* d_node_hyp = reinterpret_cast<int*>(c->g6.as<char>() + al((size_t)n_kept * 2 * sizeof(l3d_edge)));
     hipLaunchKernelGGL(k_aff_nodes, dim3((nh + 255) / 256), dim3(256), 0, st, first, posrank, nh, node, d_node_hyp);
     hipLaunchKernelGGL(k_aff_edges, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, node, n_items, dA);
-    l3d_edge* A = static_cast<l3d_edge*>(malloc((size_t)n_kept * 2 * sizeof(l3d_edge)));
+    // (edges_out == nullptr: the list stays on the device only -- l3d_perform_clustering_device walks it there, l3d_resident_edges_get copies it)
+    l3d_edge* A = edges_out ? static_cast<l3d_edge*>(malloc((size_t)n_kept * 2 * sizeof(l3d_edge))) : nullptr;
     int32_t* nh_out = static_cast<int32_t*>(malloc((size_t)n_nodes * 4 + 4));
-    if (!A || !nh_out) { free(A); free(nh_out); return fail(c, L3D_ERR_NOMEM, "affinity fill: host allocation failed"); }
-    hipError_t e1 = hipMemcpyAsync(A, dA, (size_t)n_kept * 2 * sizeof(l3d_edge), hipMemcpyDeviceToHost, st);
+    if ((edges_out && !A) || !nh_out) { free(A); free(nh_out); return fail(c, L3D_ERR_NOMEM, "affinity fill: host allocation failed"); }
+    hipError_t e1 = A ? hipMemcpyAsync(A, dA, (size_t)n_kept * 2 * sizeof(l3d_edge), hipMemcpyDeviceToHost, st) : hipSuccess;
     hipError_t e2 = hipMemcpyAsync(nh_out, d_node_hyp, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, st);
     hipError_t e3 = hipStreamSynchronize(st);
     hipError_t e4 = hipGetLastError();
@@ -569,9 +570,11 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
         free(A); free(nh_out);
         return fail(c, L3D_ERR_HIP, std::string("affinity fill: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4));
     }
-    lap("edges + download");
-    *edges_out = A; *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
+    lap(A ? "edges + download" : "edges");
+    if (edges_out) *edges_out = A;
+    *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
     c->resident_edges = 2 * n_kept;                                            // (the list stays in g6 for l3d_clustering_edges)
+    c->kept_edges = 0;
     c->resident_hyp = nh;
     return L3D_OK;
 }
@@ -586,7 +589,7 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     if (!c) return L3D_ERR_INVALID;
     if (!in || !edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out) return fail(c, L3D_ERR_INVALID, "bad argument");
     *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
-    c->resident_edges = 0;
+    c->resident_edges = 0; c->kept_edges = 0;
     if (n_candidates_out) *n_candidates_out = 0;
     const int V = in->n_views, nh = in->n_hyp;
     if (V < 0 || nh < 0 || (V > 0 && (!in->seg_base || !in->view_hyp_begin))) return fail(c, L3D_ERR_INVALID, "bad argument");
@@ -654,9 +657,10 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
                                l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
 {
     if (!c) return L3D_ERR_INVALID;
-    if (!edges_out || !n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
-    *edges_out = nullptr; *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
-    c->resident_edges = 0;
+    if (!n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (edges_out) *edges_out = nullptr;
+    *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    c->resident_edges = 0; c->kept_edges = 0;
     if (n_candidates_out) *n_candidates_out = 0;
     Products& P = c->products;
     if (!P.valid || !P.hyp_valid) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: no resident products / hypotheses");

@@ -138,6 +138,8 @@ struct l3d_ctx {
     l3d::DevBuf aff_hyp;            // hypothesis table of the last l3d_affinity_fill (kept for l3d_fit_clusters)
     int resident_hyp = 0;           // its number of hypotheses (0: none)
     int resident_edges = 0;         // entries of the edge list l3d_affinity_fill left in g6 (0: none); consumed by l3d_clustering_edges
+    l3d::DevBuf edges_keep;         // copy of that list taken when the clustering consumes it (l3d_resident_edges_get)
+    int kept_edges = 0;
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;
     std::vector<std::pair<char*, int>> resident_arenas;                  // batch registrations: (one allocation, slices still registered)
     std::unordered_map<const void*, int> resident_arena_of;             // host pointer -> its batch allocation

@@ -210,6 +210,81 @@ __global__ void k_edge_gather(const l3d_edge* __restrict__ E, const unsigned* __
     if (k < nnz) out[k] = E[order[k]];
 }
 
+// ---- the merge loop of performClustering (clustering.cc:21-40, universe.h:59-115) on the device, one WAVE per connected component.
+// Felzenszwalb-Huttenlocher is sequential by definition -- every merge decision depends on the thresholds the earlier merges left --
+// but only INSIDE a component: each one is walked by lane 0 of its wave with the unions, ranks and roots of the one sequential walk,
+// its state (parent, rank, size, threshold per node) in LDS under LOCAL node numbers (the component's nodes sorted by id), the edges
+// prefetched 64 at a time by the whole wave.  All components run at once: the launch lasts as long as its largest component
+// (config 2: 1326 edges, 127 nodes).  Components beyond kUfLds nodes keep their state in global arrays (same code, slower).
+constexpr int kUfLds = 2048;
+__global__ void k_uf_node_keys(const int* __restrict__ comp, int n, unsigned* __restrict__ key, unsigned* __restrict__ val, int* __restrict__ labels)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) { key[v] = (unsigned)comp[v]; val[v] = (unsigned)v; labels[v] = v; }   // (a node without edges is its own cluster)
+}
+// position of every node in the (component, id) order, and the node count of every component under its label
+__global__ void k_uf_pos(const unsigned* __restrict__ key_sorted, const unsigned* __restrict__ node_sorted, int n, int* __restrict__ pos, int* __restrict__ ncnt)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) { pos[node_sorted[p]] = p; atomicAdd(&ncnt[key_sorted[p]], 1); }
+}
+// one component's walk; called once with the LDS arrays and once with global ones, so that either gets its own address space
+__device__ __forceinline__ void uf_component_walk(const l3d_edge* __restrict__ E, int e0, int e1, const unsigned* __restrict__ node_sorted,
+                                                  const int* __restrict__ pos, int n0, int k, float c, int* cid, int* rnk, int* size, float* thr,
+                                                  int* s_ei, int* s_ej, float* s_ew, int* __restrict__ labels)
+{
+    const int lane = threadIdx.x;
+    for (int t = lane; t < k; t += 64) { cid[t] = t; rnk[t] = 0; size[t] = 1; thr[t] = c; }
+    __threadfence_block();
+    for (int base = e0; base < e1; base += 64) {
+        const int q = base + lane;
+        if (q < e1) { const l3d_edge e = E[q]; s_ei[lane] = pos[e.i] - n0; s_ej[lane] = pos[e.j] - n0; s_ew[lane] = e.w; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            // clustering.cc:21-40 with universe.h's find (path halving finds the same root: unions go by rank, which no compression touches)
+            const int cnt = min(64, e1 - base);
+            for (int q2 = 0; q2 < cnt; ++q2) {
+                const float w = s_ew[q2];
+                int a = s_ei[q2], b = s_ej[q2];
+                while (a != cid[a]) { cid[a] = cid[cid[a]]; a = cid[a]; }
+                while (b != cid[b]) { cid[b] = cid[cid[b]]; b = cid[b]; }
+                if (a != b && w <= thr[a] && w <= thr[b]) {
+                    if (rnk[a] > rnk[b]) { cid[b] = a; size[a] += size[b]; }
+                    else { cid[a] = b; size[b] += size[a]; if (rnk[a] == rnk[b]) rnk[b]++; a = b; }
+                    thr[a] = w + c / (float)size[a];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence_block();
+    // labels: CLUniverse::find of every node, as global node ids (clustering.h:125 hands back find(k))
+    for (int t = lane; t < k; t += 64) {
+        int y = t;
+        while (y != cid[y]) y = cid[y];
+        labels[node_sorted[n0 + t]] = (int)node_sorted[n0 + y];
+    }
+}
+__global__ __launch_bounds__(64) void k_uf_component(const l3d_edge* __restrict__ E, const int* __restrict__ gstart, int n_groups, int nnz,
+                                                      const int* __restrict__ comp, const unsigned* __restrict__ node_sorted, const int* __restrict__ pos,
+                                                      const int* __restrict__ ncnt, int n, float c, int* __restrict__ g_state, int* __restrict__ labels)
+{
+    __shared__ int s_cid[kUfLds], s_rank[kUfLds], s_size[kUfLds];
+    __shared__ float s_thr[kUfLds];
+    __shared__ int s_ei[64], s_ej[64];
+    __shared__ float s_ew[64];
+    const int g = blockIdx.x;
+    const int e0 = gstart[g], e1 = g + 1 < n_groups ? gstart[g + 1] : nnz;
+    // the component's label is its smallest node id, and the node order inside a component is ascending: its first node is the label
+    const int label = comp[E[e0].i], n0 = pos[label], k = ncnt[label];
+    if (k <= kUfLds) uf_component_walk(E, e0, e1, node_sorted, pos, n0, k, c, s_cid, s_rank, s_size, s_thr, s_ei, s_ej, s_ew, labels);
+    // (a component too big for LDS: its slices of four global arrays, indexed by the same local numbers)
+    else uf_component_walk(E, e0, e1, node_sorted, pos, n0, k, c, g_state + n0, g_state + (size_t)n + n0, g_state + 2 * (size_t)n + n0,
+                           reinterpret_cast<float*>(g_state + 3 * (size_t)n) + n0, s_ei, s_ej, s_ew, labels);
+}
+
 }  // namespace l3d
 
 namespace {
@@ -309,11 +384,13 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
 
 // The edge list performClustering walks (clustering.cc:14-40), prepared on the device: optional performDiffusion
 // (line3D.cc:1255-1303: replicator dynamics, symmetrise by the minimum, (i,j) order) and the stable ascending weight order.
+// labels_out != nullptr: the merge loop runs on the device as well (k_uf_component) and only the n labels come back
 static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out,
-                                 int32_t** group_start_out, int* n_groups_out)
+                                 int32_t** group_start_out, int* n_groups_out, int32_t* labels_out = nullptr, float cl_c = 0.0f)
 {
     if (!c) return L3D_ERR_INVALID;
-    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && !sorted_out)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && !sorted_out && !labels_out)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (labels_out && nnz == 0) { for (int v = 0; v < n; ++v) labels_out[v] = v; return L3D_OK; }
     if (group_start_out) { *group_start_out = nullptr; *n_groups_out = 0; }
     if (nnz == 0) return L3D_OK;
     if (!A && c->resident_edges != nnz) return fail(c, L3D_ERR_INVALID, "no resident edge list of that size (l3d_affinity_fill)");
@@ -328,6 +405,11 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
     if (A) {
         HIPCHK(c, c->g6.reserve(ab + 64));
         HIPCHK(c, hipMemcpyAsync(c->g6.p, A, ab, hipMemcpyHostToDevice, st));
+    }
+    if (!A) {                                                            // (a device copy stays for l3d_resident_edges_get: 12 B per edge, microseconds)
+        HIPCHK(c, c->edges_keep.reserve(ab + 64));
+        HIPCHK(c, hipMemcpyAsync(c->edges_keep.p, c->g6.p, ab, hipMemcpyDeviceToDevice, st));
+        c->kept_edges = nnz;
     }
     c->resident_edges = 0;                                               // the list is consumed (diffusion overwrites it)
     const dim3 grid((nnz + 255) / 256), block(256);
@@ -347,7 +429,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         E = c->g0.as<l3d_edge>();
         lap("diffusion + symmetrise");
     }
-    bool grouped = group_start_out != nullptr;
+    bool grouped = group_start_out != nullptr || labels_out != nullptr;
     if (grouped) {
         // ---- grouped by connected component: labels, then ONE stable sort by (component, weight key)
         HIPCHK(c, c->g3.reserve((size_t)n * 4 + 256));
@@ -365,7 +447,10 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
             HIPCHK(c, hipMemcpyAsync(&h_changed, changed, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (!h_changed) break;
-            if (round == 63) grouped = false;                              // (not converged: one group, the plain order below)
+            if (round == 63) {                                             // not converged: one group, ...
+                if (labels_out) HIPCHK(c, hipMemsetAsync(comp, 0, (size_t)n * 4, st));   // ... here as the single component 0
+                else grouped = false;                                      // ... the plain order below
+            }
         }
         lap("connected components");
     }
@@ -393,7 +478,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, tb, key_in, key_out, val_in, order, nnz, 0, 32 + shift, st));
         HIPCHK(c, c->g1.reserve(ab + 64));
         hipLaunchKernelGGL(k_edge_gather, grid, block, 0, st, E, order, nnz, c->g1.as<l3d_edge>());
-        HIPCHK(c, hipMemcpyAsync(sorted_out, c->g1.p, ab, hipMemcpyDeviceToHost, st));
+        if (sorted_out) HIPCHK(c, hipMemcpyAsync(sorted_out, c->g1.p, ab, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemsetAsync(flag + nnz, 0, 4, st));
         hipLaunchKernelGGL(k_group_flags, grid, block, 0, st, key_out, nnz, flag);
         HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, frank, nnz + 1, st));
@@ -401,6 +486,31 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int n_groups = 0;
         HIPCHK(c, hipMemcpyAsync(&n_groups, frank + nnz, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        if (labels_out) {
+            // nodes in (component, id) order -> local numbers; then one wave per component
+            size_t tbn = 0;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tbn, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0, shift, st));
+            const size_t sb = ((size_t)n * 4 + 255) & ~(size_t)255;
+            HIPCHK(c, c->g4.reserve(11 * sb + tbn + 256));
+            unsigned char* ns = c->g4.as<unsigned char>();
+            unsigned *nkey_in = reinterpret_cast<unsigned*>(ns), *nkey = reinterpret_cast<unsigned*>(ns + sb);
+            unsigned *nval_in = reinterpret_cast<unsigned*>(ns + 2 * sb), *node_sorted = reinterpret_cast<unsigned*>(ns + 3 * sb);
+            int *pos = reinterpret_cast<int*>(ns + 4 * sb), *ncnt = reinterpret_cast<int*>(ns + 5 * sb), *labels = reinterpret_cast<int*>(ns + 6 * sb);
+            int* g_state = reinterpret_cast<int*>(ns + 7 * sb);
+            const dim3 ngrid((n + 255) / 256);
+            hipLaunchKernelGGL(k_uf_node_keys, ngrid, block, 0, st, comp, n, nkey_in, nval_in, labels);
+            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(ns + 11 * sb, tbn, nkey_in, nkey, nval_in, node_sorted, n, 0, shift, st));
+            HIPCHK(c, hipMemsetAsync(ncnt, 0, (size_t)n * 4, st));
+            hipLaunchKernelGGL(k_uf_pos, ngrid, block, 0, st, nkey, node_sorted, n, pos, ncnt);
+            { ProfScope p(c, "uf_components");
+              hipLaunchKernelGGL(k_uf_component, dim3(n_groups), dim3(64), 0, st, c->g1.as<l3d_edge>(), gstart, n_groups, nnz, comp, node_sorted, pos, ncnt, n, cl_c, g_state, labels); }
+            HIPCHK(c, hipMemcpyAsync(labels_out, labels, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipGetLastError());
+            lap("grouped order + merge loop (device)");
+            if (n_groups_out) *n_groups_out = n_groups;
+            return L3D_OK;
+        }
         int32_t* gs = static_cast<int32_t*>(malloc(((size_t)n_groups + 1) * 4));
         if (!gs) return fail(c, L3D_ERR_NOMEM, "malloc");
         hipError_t e1 = hipMemcpyAsync(gs, gstart, (size_t)n_groups * 4, hipMemcpyDeviceToHost, st);
@@ -451,6 +561,31 @@ extern "C" int l3d_clustering_edges_grouped(l3d_ctx* c, const l3d_edge* A, int n
 {
     if (!group_start || !n_groups) return c ? fail(c, L3D_ERR_INVALID, "bad argument") : L3D_ERR_INVALID;
     return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, sorted_out, group_start, n_groups);
+}
+
+// clusterSegments2D's tail in one call: [performDiffusion] + performClustering(A, n, c) with only the labels coming back
+// (line3D.cc:1239-1246 -> clustering.cc:6-47).  labels[k] = CLUniverse::find(k), the same roots as the host walk.
+extern "C" int l3d_perform_clustering_device(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, float cl_c, int32_t* labels,
+                                             int* n_components)
+{
+    if (!labels && n > 0) return c ? fail(c, L3D_ERR_INVALID, "bad argument") : L3D_ERR_INVALID;
+    if (n_components) *n_components = 0;
+    return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, nullptr, nullptr, n_components, labels, cl_c);
+}
+
+// the edge list of the last l3d_affinity_fill / l3d_affinity_fill_resident, copied to the host: from g6 while it is resident, from the
+// copy the clustering took when it consumed it afterwards
+extern "C" int l3d_resident_edges_get(l3d_ctx* c, l3d_edge* out, int nnz)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (nnz < 0 || (nnz > 0 && !out)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (nnz == 0) return L3D_OK;
+    const void* src = c->resident_edges == nnz ? c->g6.p : c->kept_edges == nnz ? c->edges_keep.p : nullptr;
+    if (!src) return fail(c, L3D_ERR_INVALID, "no resident edge list of that size (l3d_affinity_fill)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, src, (size_t)nnz * sizeof(l3d_edge), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return L3D_OK;
 }
 
 void l3d::warm_rdd() { touch_kernel(reinterpret_cast<const void*>(&k_cc_init)); }

@@ -203,7 +203,9 @@ struct l3d_line3d {
     // final hypotheses
     std::vector<Hyp> hyps;                                     // best_match_ in key order
     std::vector<std::vector<int>> best_idx;                    // per view index: seg -> hyp index or -1
-    EdgeVec A;
+    EdgeVec A;                     // the affinity list on the host -- filled on demand (ensure_edges) when it was left on the device
+    size_t n_edges = 0;
+    bool A_on_host = true;
     std::vector<Key> local2global;
     std::vector<FinalLine> result;
     std::vector<size_t> hyp_begin;                             // per view index: first hypothesis (greedy_selection)
@@ -1709,6 +1711,17 @@ int greedy_selection_resident(L* h)
     return L3D_OK;
 }
 
+// the affinity list on the host (the resident fill leaves it on the device: fetched on first use)
+int ensure_edges(L* h)
+{
+    if (h->A_on_host) return L3D_OK;
+    h->A.resize(h->n_edges);
+    int rc = l3d_resident_edges_get(h->ctx, h->A.data(), (int)h->n_edges);
+    if (rc) { h->A.clear(); return h->fail(rc, std::string("affinity list: ") + l3d_last_error(h->ctx)); }
+    h->A_on_host = true;
+    return L3D_OK;
+}
+
 // the affinity fill on the resident tables (l3d_affinity_fill_resident): only the collinearity CSR comes from the host, once per scene
 int fill_affinity_resident(L* h)
 {
@@ -1719,17 +1732,16 @@ int fill_affinity_resident(L* h)
     const bool changed = !T.coll_valid || T.coll_start.size() != voff.back() + 1;
     if (changed) pack_collinearities(h, voff);
     l3d_edge* edges = nullptr; int32_t* node_hyp = nullptr; int n_edges = 0, n_nodes = 0, n_cand = 0;
-    int rc = l3d_affinity_fill_resident(h->ctx, T.coll_start.data(), T.coll_other.data(), T.coll_w.data(), changed ? 1 : 0, h->sigma_a, &edges, &n_edges, &node_hyp, &n_nodes, &n_cand);
+    // (the list itself stays on the device, where the clustering walks it; l3d_line3d_affinity fetches it when somebody asks)
+    int rc = l3d_affinity_fill_resident(h->ctx, T.coll_start.data(), T.coll_other.data(), T.coll_w.data(), changed ? 1 : 0, h->sigma_a, nullptr, &n_edges, &node_hyp, &n_nodes, &n_cand);
     if (rc) return h->fail(rc, std::string("affinity fill: ") + l3d_last_error(h->ctx));
     T.coll_valid = true;
-    const unsigned nt = finish_threads();
-    h->A.resize((size_t)n_edges);
-    parallel_slices((size_t)n_edges, nt, [&](size_t k0, size_t k1, unsigned) { if (k1 > k0) memcpy(&h->A[k0], edges + k0, (k1 - k0) * sizeof(l3d_edge)); });
+    h->A.clear(); h->n_edges = (size_t)n_edges; h->A_on_host = n_edges == 0;
     h->local2global.resize((size_t)n_nodes);
     for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
     h->node_hyp.assign(node_hyp, node_hyp + n_nodes);
     l3d_free(edges); l3d_free(node_hyp);
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges (resident tables)\n", h->hyps.size(), n_cand, h->A.size());
+    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges (resident tables)\n", h->hyps.size(), n_cand, h->n_edges);
     return L3D_OK;
 }
 
@@ -1743,7 +1755,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
     const bool timing = getenv("L3D_TIMING") != nullptr;
     double tm_last = t0;
     auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", what, (t - tm_last) * 1e3); tm_last = t; } };
-    h->A.clear(); h->local2global.clear(); h->result.clear();
+    h->A.clear(); h->n_edges = 0; h->A_on_host = true; h->local2global.clear(); h->result.clear();
     const size_t nh = h->hyps.size();
     if (nh == 0) return L3D_OK;
 
@@ -1865,11 +1877,12 @@ int cluster_segments_2D(L* h, bool perform_diff)
         for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
         h->node_hyp.assign(node_hyp, node_hyp + n_nodes);
         l3d_free(edges); l3d_free(node_hyp);
+        h->n_edges = h->A.size(); h->A_on_host = true;
         if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges, %u threads\n", nh, n_cand, h->A.size(), nt);
         lap("edge list to host");
     }
     h->t_affinity = now_s() - t0;
-    if (h->A.empty()) return L3D_OK;                                            // :1232-1233
+    if (h->n_edges == 0) return L3D_OK;                                         // :1232-1233
 
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
@@ -1878,22 +1891,33 @@ int cluster_segments_2D(L* h, bool perform_diff)
         // the list clustering walks -- diffused and symmetrised when asked for, in stable ascending weight order -- comes from
         // the device, where the affinity list still is (l3d_clustering_edges); a list the device path does not take
         // (L3D_ERR_UNSUPPORTED) goes through the reference's map arithmetic on the host
-        std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[h->A.size() + 1]);
-        int32_t* group_start = nullptr;
-        int n_groups = 0;
-        int rc = resident_list ? l3d_clustering_edges_grouped(h->ctx, nullptr, (int)h->A.size(), n_nodes, perform_diff ? 1 : 0, L3D_RDD_MAX_ITER, sorted.get(),
-                                                              &group_start, &n_groups)
-                               : L3D_ERR_UNSUPPORTED;
-        if (rc == L3D_OK) {
-            lap(perform_diff ? "diffusion + grouped edge order (device)" : "grouped edge order (device)");
-            perform_clustering_grouped(sorted.get(), group_start, n_groups, n_nodes, 1.0f, labels);   // :1245
-            l3d_free(group_start);
-        } else if (rc == L3D_ERR_UNSUPPORTED) {
+        // ... and so does the merge loop itself, one wave per connected component (l3d_perform_clustering_device): only the labels
+        // come back.  L3D_HOST_CLUSTERING=1 keeps the merge loop on the worker threads (the seam tests compare the two).
+        static const bool host_loop = getenv("L3D_HOST_CLUSTERING") != nullptr;
+        const int nnz = (int)h->n_edges, diff = perform_diff ? 1 : 0;
+        int rc = L3D_ERR_UNSUPPORTED;
+        if (resident_list && !host_loop) {
+            labels.resize((size_t)n_nodes);
+            rc = l3d_perform_clustering_device(h->ctx, nullptr, nnz, n_nodes, diff, L3D_RDD_MAX_ITER, 1.0f, labels.data(), nullptr);   // :1245
+            if (rc == L3D_OK) lap(perform_diff ? "diffusion + clustering (device)" : "clustering (device)");
+        } else if (resident_list) {
+            std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[h->n_edges + 1]);
+            int32_t* group_start = nullptr;
+            int n_groups = 0;
+            rc = l3d_clustering_edges_grouped(h->ctx, nullptr, nnz, n_nodes, diff, L3D_RDD_MAX_ITER, sorted.get(), &group_start, &n_groups);
+            if (rc == L3D_OK) {
+                lap(perform_diff ? "diffusion + grouped edge order (device)" : "grouped edge order (device)");
+                perform_clustering_grouped(sorted.get(), group_start, n_groups, n_nodes, 1.0f, labels);   // :1245
+                l3d_free(group_start);
+            }
+        }
+        if (rc == L3D_ERR_UNSUPPORTED) {
+            if (int e = ensure_edges(h)) return e;
             EdgeVec diffused;
             if (perform_diff) { rc = perform_diffusion(h, h->A, n_nodes, diffused); if (rc) return rc; lap("diffusion"); }
             const EdgeVec& edges = perform_diff ? diffused : h->A;
             perform_clustering(edges.data(), edges.size(), n_nodes, 1.0f, labels);
-        } else return h->fail(rc, std::string("clustering edges: ") + l3d_last_error(h->ctx));
+        } else if (rc != L3D_OK) return h->fail(rc, std::string("clustering: ") + l3d_last_error(h->ctx));
     }
     lap("clustering");
 
@@ -2046,7 +2070,7 @@ int l3d_line3d_reset(l3d_line3d* h)
     for (auto& kv : h->views) { l3d_unregister_segments(h->ctx, kv.second.segs.data()); l3d_unregister_segments(h->ctx, kv.second.nb_segs.data()); }
     h->views.clear(); h->vlist.clear(); h->view_similarities.clear(); h->num_wps.clear(); h->common_wps.clear();
     h->worldpoints2views.clear(); h->visual_neighbors.clear(); h->fundamentals.clear(); h->matched.clear();
-    h->pot.clear(); h->pot_foreign.clear(); h->hyps.clear(); h->best_idx.clear(); h->A.clear(); h->local2global.clear(); h->result.clear();
+    h->pot.clear(); h->pot_foreign.clear(); h->hyps.clear(); h->best_idx.clear(); h->A.clear(); h->n_edges = 0; h->A_on_host = true; h->local2global.clear(); h->result.clear();
     h->computation = false; h->prepared = false;
     drop_plan(h);
     return L3D_OK;
@@ -2466,8 +2490,8 @@ int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_mat
 int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes)
 {
     if (!h) return L3D_ERR_INVALID;
-    if (A) *A = h->A.data();
-    if (nnz) *nnz = (int)h->A.size();
+    if (A) { if (int rc = ensure_edges(const_cast<l3d_line3d*>(h))) return rc; *A = h->A.data(); }
+    if (nnz) *nnz = (int)h->n_edges;
     if (n_nodes) *n_nodes = (int)h->local2global.size();
     return L3D_OK;
 }
@@ -2498,7 +2522,7 @@ int l3d_line3d_stats(const l3d_line3d* h, double* s)
     if (!h || !s) return L3D_ERR_INVALID;
     s[0] = h->stat_pairs; s[1] = h->stat_raw; s[2] = h->stat_kept; s[3] = (double)h->hyps.size();
     s[4] = h->t_match; s[5] = h->t_gpu_call; s[6] = h->t_commit; s[7] = h->t_finalize; s[8] = h->t_affinity; s[9] = h->t_cluster;
-    s[10] = (double)h->A.size(); s[11] = (double)h->result.size();
+    s[10] = (double)h->n_edges; s[11] = (double)h->result.size();
     return L3D_OK;
 }
 

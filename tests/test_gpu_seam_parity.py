@@ -1,5 +1,6 @@
 """GPU parity of the three seam functions (+ similarity batch) against the CPU oracle, through the C ABI.
 Bar: bit-exact (match ids, depths, confidences, median; collinearity weights; diffusion values)."""
+import os
 import numpy as np
 import pytest
 
@@ -663,3 +664,83 @@ def test_clustering_edges_grouped_long_chains(gpu_ctx):
         members = np.unique(np.concatenate([e["i"], e["j"]]))
         sel = flat[np.isin(flat["i"], members)]
         assert e.tobytes() == sel.tobytes()
+
+
+def _planted_graph(rng, n, n_comp, n_pairs):
+    comp_of = rng.integers(0, n_comp, n)
+    pairs = set()
+    while len(pairs) < n_pairs:
+        a = int(rng.integers(0, n))
+        b = int(rng.choice(np.nonzero(comp_of == comp_of[a])[0]))
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    levels = np.array([0.011, 0.25, 0.2500001, 0.5, 0.75, 1.0], np.float32)
+    A = []
+    for a, b in sorted(pairs, key=lambda p: (p[0] * 7919 + p[1] * 104729) % 1000003):
+        w = levels[rng.integers(0, len(levels))] if rng.random() < 0.5 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    return np.array(A, dtype=op.EDGE_DTYPE)
+
+
+@pytest.mark.parametrize("diffusion", [False, True])
+@pytest.mark.parametrize("c", [1.0, 0.3])
+def test_clustering_merge_loop_on_device(gpu_ctx, oracle_lib, diffusion, c):
+    """l3d_perform_clustering_device (the merge loop of clustering.cc:21-40, one wave per connected component, state in LDS under
+    local node numbers): labels BIT-EQUAL -- the same root ids -- to the oracle's sequential walk over the whole sorted list; nodes
+    without an edge are their own cluster."""
+    rng = np.random.default_rng(41)
+    n = 900                                                               # (nodes 800..899 never appear in an edge)
+    A = _planted_graph(rng, 800, 40, 4000)
+    flat = gpu_ctx.clustering_edges(A, n, perform_diffusion=diffusion)
+    want = op.clustering(oracle_lib, flat, n, c)
+    got, n_comp = gpu_ctx.perform_clustering_device(A, n, c=c, perform_diffusion=diffusion)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[800:], np.arange(800, 900))
+    assert n_comp == len(gpu_ctx.clustering_edges_grouped(A, n, perform_diffusion=diffusion)[1]) - 1
+    assert len(np.unique(got)) > n_comp                                    # (the thresholds did split components)
+
+
+def test_clustering_merge_loop_reference_vectors(gpu_ctx):
+    """... and equal to the labels the reference's own clustering.cc produced (tests/golden/clustering_ref.npz, made from
+    oracle/_ref/libclustering_ref.so)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "clustering_ref.npz"))
+    cases = sorted({k.rsplit("_", 1)[0] for k in g.files})
+    assert len(cases) == 8
+    for case in cases:
+        A = np.zeros(len(g[case + "_i"]), dtype=op.EDGE_DTYPE)
+        A["i"], A["j"], A["w"] = g[case + "_i"], g[case + "_j"], g[case + "_w"]
+        got, _ = gpu_ctx.perform_clustering_device(A, int(g[case + "_n"]), c=float(case.split("_")[1]))
+        assert np.array_equal(got, g[case + "_labels"]), case
+
+
+def test_clustering_merge_loop_big_components(gpu_ctx, oracle_lib):
+    """Components beyond the LDS state (2048 nodes) take the same walk with their state in HBM: one path of 60 000 nodes in scrambled
+    numbering, one dense blob of 3000 nodes, 500 paths of 100 nodes, 1000 pairs -- labels equal to the oracle's."""
+    rng = np.random.default_rng(43)
+    n = 60000 + 3000 + 500 * 100 + 2000 + 17
+    perm = rng.permutation(n - 17)
+    edges = []
+    chain = perm[:60000]
+    edges += [(int(chain[k]), int(chain[k + 1])) for k in range(len(chain) - 1)]
+    blob = perm[60000:63000]
+    for _ in range(20000):
+        a, b = rng.choice(blob, 2, replace=False)
+        edges.append((int(a), int(b)))
+    edges += [(int(blob[k]), int(blob[k + 1])) for k in range(len(blob) - 1)]
+    for p in range(500):
+        cc = perm[63000 + p * 100: 63000 + (p + 1) * 100]
+        edges += [(int(cc[k]), int(cc[k + 1])) for k in range(99)]
+    iso = perm[63000 + 50000:]
+    edges += [(int(iso[2 * k]), int(iso[2 * k + 1])) for k in range(1000)]
+    edges = sorted({(min(a, b), max(a, b)) for a, b in edges}, key=lambda p: (p[0] * 7919 + p[1] * 104729) % 1000003)
+    A = []
+    for a, b in edges:
+        w = np.float32(rng.choice([0.1, 0.5, 0.9])) if rng.random() < 0.7 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    A = np.array(A, dtype=op.EDGE_DTYPE)
+    flat = gpu_ctx.clustering_edges(A, n)
+    want = op.clustering(oracle_lib, flat, n, 1.0)
+    got, n_comp = gpu_ctx.perform_clustering_device(A, n, c=1.0)
+    assert n_comp == 1 + 1 + 500 + 1000
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[n - 17:], np.arange(n - 17, n))
