@@ -174,7 +174,8 @@ int l3d_clustering_edges_grouped(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n
 /* clusterSegments2D's tail in one call (line3D.cc:1239-1246 -> clustering.cc:6-47, universe.h:59-115): [performDiffusion,]
  * the grouped order above and the MERGE LOOP of performClustering on the device, one wave per connected component (the loop is
  * sequential only inside a component; each is walked in LDS with the unions, ranks and roots of the one sequential walk).
- * labels (n_nodes, caller-allocated): labels[k] = CLUniverse::find(k), bit-equal to performClustering's.  c: the reference
+ * labels (n_nodes, caller-allocated; NULL: they only stay on the device, for l3d_fit_labelled_clusters): labels[k] =
+ * CLUniverse::find(k), bit-equal to performClustering's.  c: the reference
  * passes 1.0 (line3D.cc:1245).  n_components (may be NULL): connected components that hold an edge.
  * A == NULL: the resident list of l3d_affinity_fill, as above.  L3D_ERR_UNSUPPORTED as for l3d_clustering_edges. */
 int l3d_perform_clustering_device(l3d_ctx* ctx, const l3d_edge* A, int nnz, int n_nodes, int perform_diffusion, int iters, float c, int32_t* labels,
@@ -190,6 +191,14 @@ int l3d_perform_clustering_device(l3d_ctx* ctx, const l3d_edge* A, int nnz, int 
 int l3d_fit_clusters(l3d_ctx* ctx, const int32_t* group_start, int n_groups, const int32_t* member_hyp, const l3d_hypothesis* hyp,
                      const uint32_t* hyp_cam, int n_hyp, const double* Rinv, double scale_inv, const double* tneg,
                      int32_t** seg_count, double** segs, int* n_segs);
+/* processClusteredSegments from the LABELS (line3D.cc:1306-1368): the grouping on the device too -- clusters in ascending label
+ * order (the reference's std::map), members in key order, those with >= 4 members seen from >= 4 cameras are fitted as above.
+ * labels / node_hyp (n_nodes each): cluster label and hypothesis index of every node of the affinity list; NULL: the arrays
+ * l3d_perform_clustering_device / l3d_affinity_fill* left on the device.  Out (callee-allocated, l3d_free): the fitted
+ * clusters -- group_start (n_groups + 1) into member_hyp -- and seg_count / segs as l3d_fit_clusters. */
+int l3d_fit_labelled_clusters(l3d_ctx* ctx, const int32_t* labels, const int32_t* node_hyp, int n_nodes, const l3d_hypothesis* hyp,
+                              const uint32_t* hyp_cam, int n_hyp, const double* Rinv, double scale_inv, const double* tneg,
+                              int32_t** group_start, int32_t** member_hyp, int* n_groups, int32_t** seg_count, double** segs, int* n_segs);
 
 
 /* ---- Line3D::matchViews as one device-resident chain --------------------------------------------------------

@@ -293,6 +293,31 @@ class Context:
             k += int(c)
         return out
 
+    def fit_labelled_clusters(self, labels, node_hyp, hyp, hyp_cam, Rinv, scale_inv, tneg):
+        """l3d_fit_labelled_clusters: -> (group_start, member_hyp, list per fitted cluster of (start, end))."""
+        lab = np.ascontiguousarray(labels, np.int32)
+        nh = np.ascontiguousarray(node_hyp, np.int32)
+        hy = np.ascontiguousarray(hyp, HYP_DTYPE)
+        hc = np.ascontiguousarray(hyp_cam, np.uint32)
+        R = np.ascontiguousarray(Rinv, np.float64).reshape(9)
+        t = np.ascontiguousarray(tneg, np.float64).reshape(3)
+        gs, mh, cnt, segs = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        ng, n = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.l3d_fit_labelled_clusters(self.h, _p(lab), _p(nh), C.c_int(len(lab)), _p(hy), _p(hc), C.c_int(len(hy)), _p(R), C.c_double(scale_inv), _p(t),
+                                                     C.byref(gs), C.byref(mh), C.byref(ng), C.byref(cnt), C.byref(segs), C.byref(n)))
+        g = ng.value
+        group_start = np.ctypeslib.as_array(gs, (g + 1,)).copy() if g else np.zeros(1, np.int32)
+        members = np.ctypeslib.as_array(mh, (int(group_start[-1]),)).copy() if g and group_start[-1] else np.zeros(0, np.int32)
+        counts = np.ctypeslib.as_array(cnt, (g,)).copy() if g else np.zeros(0, np.int32)
+        flat = np.ctypeslib.as_array(segs, (n.value * 6,)).copy().reshape(-1, 6) if n.value else np.zeros((0, 6))
+        for q in (gs, mh, cnt, segs):
+            self.lib.l3d_free(q)
+        out, k = [], 0
+        for c in counts:
+            out.append([(flat[k + i, :3].copy(), flat[k + i, 3:].copy()) for i in range(c)])
+            k += int(c)
+        return group_start, members, out
+
     def test_contract_math(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
         e = np.zeros(len(x), np.float32)

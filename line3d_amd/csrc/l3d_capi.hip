@@ -537,7 +537,7 @@ int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float col
     if (n == 0) return L3D_OK;
     HIPCHK(c, c->g4.reserve((size_t)n * 4));
     HIPCHK(c, c->g5.reserve((size_t)n * 4));
-    c->resident_edges = 0;                          // (g6 is reused)
+    c->resident_edges = 0; c->resident_nodes = 0;   // (g6 is reused)
     HIPCHK(c, c->g6.reserve((size_t)n * 4));
     { ProfScope p(c, "collinearity_fill");
       launch_collinearity_fill(d_segs, S, sigma_sqr, c->g1.as<unsigned long long>(), W64, c->g3.as<int>(), c->g4.as<int>(), c->g5.as<int>(), c->g6.as<float>(), st); }
@@ -632,7 +632,7 @@ int l3d_compute_collinearity_batch(l3d_ctx* c, const float* const* segments, con
     const size_t n = (size_t)total;
     HIPCHK(c, c->g4.reserve(n * 4));
     HIPCHK(c, c->g5.reserve(n * 4));
-    c->resident_edges = 0;                          // (g6 is reused)
+    c->resident_edges = 0; c->resident_nodes = 0;   // (g6 is reused)
     HIPCHK(c, c->g6.reserve(n * 4));
     for (int v = 0; v < n_sets; ++v) {
         const Set& q = sets[(size_t)v];

@@ -138,6 +138,10 @@ struct l3d_ctx {
     l3d::DevBuf aff_hyp;            // hypothesis table of the last l3d_affinity_fill (kept for l3d_fit_clusters)
     int resident_hyp = 0;           // its number of hypotheses (0: none)
     int resident_edges = 0;         // entries of the edge list l3d_affinity_fill left in g6 (0: none); consumed by l3d_clustering_edges
+    int resident_nodes = 0;         // nodes of that list; resident_nodes_p: their hypothesis indices (behind the edges in g6)
+    const int* resident_nodes_p = nullptr;
+    int resident_labels = 0;        // labels l3d_perform_clustering_device left on the device (in g4), for l3d_fit_labelled_clusters
+    const int* resident_labels_p = nullptr;
     l3d::DevBuf edges_keep;         // copy of that list taken when the clustering consumes it (l3d_resident_edges_get)
     int kept_edges = 0;
     std::unordered_map<const void*, std::pair<void*, size_t>> resident;

@@ -128,44 +128,74 @@ __global__ void k_fit_gather(const int* __restrict__ group_start, const int* __r
 
 }  // namespace l3d
 
-// clusters: group_start (n_groups + 1) into member_hyp (hypothesis indices in key order); hyp / hyp_cam: all hypotheses (3-D end
-// points in the normalised scene) and their camera ids; Rinv (3x3 row-major), scale_inv, tneg: Line3D::inverseTransform.
-// Out (callee-allocated, l3d_free): seg_count[g] = 3-D segments of cluster g, segs = 6 doubles per segment, groups back to back.
-extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_groups, const int32_t* member_hyp, const l3d_hypothesis* hyp, const uint32_t* hyp_cam,
-                                int n_hyp, const double* Rinv, double scale_inv, const double* tneg, int32_t** seg_count, double** segs, int* n_segs)
+namespace l3d {
+
+// ---- processClusteredSegments' grouping (line3D.cc:1306-1368) on the device: clusters in ascending label order, their members in key
+// order (= ascending hypothesis index), only those with >= 4 members seen from >= 4 cameras.
+__global__ void k_lab_keys(const int* __restrict__ labels, const int* __restrict__ node_hyp, int n, unsigned long long* __restrict__ key)
 {
-    if (!c) return L3D_ERR_INVALID;
-    if (!seg_count || !segs || !n_segs || n_groups < 0 || n_hyp < 0 || (n_groups > 0 && (!group_start || !member_hyp || !hyp_cam || !Rinv || !tneg)))
-        return fail(c, L3D_ERR_INVALID, "bad argument");
-    if (n_groups > 0 && !hyp && c->resident_hyp != n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: no resident hypothesis table of that size (l3d_affinity_fill)");
-    *seg_count = nullptr; *segs = nullptr; *n_segs = 0;
-    if (n_groups == 0) return L3D_OK;
-    const int n_members = group_start[n_groups];
-    if (group_start[0] != 0 || n_members < 0) return fail(c, L3D_ERR_INVALID, "line fit: group table must start at 0");
-    for (int g = 0; g < n_groups; ++g) if (group_start[g + 1] < group_start[g]) return fail(c, L3D_ERR_INVALID, "line fit: group table must ascend");
-    for (int i = 0; i < n_members; ++i) if (member_hyp[i] < 0 || member_hyp[i] >= n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: member out of range");
-    HIPCHK(c, hipSetDevice(c->device));
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) key[v] = ((unsigned long long)(unsigned)labels[v] << 32) | (unsigned)node_hyp[v];
+}
+__global__ void k_lab_flags(const unsigned long long* __restrict__ key, int n, int* __restrict__ flag)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flag[p] = (p == 0 || (key[p] >> 32) != (key[p - 1] >> 32)) ? 1 : 0;
+    if (p == n) flag[p] = 0;
+}
+__global__ void k_lab_starts(const int* __restrict__ flag, const int* __restrict__ rank, int n, int* __restrict__ start)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flag[p]) start[rank[p]] = p;
+    if (p == n) start[rank[n]] = n;                                        // (rank[n] = number of clusters)
+}
+// a thread per cluster: members (0 unless the cluster qualifies: >= 4 members, >= 4 cameras -- line3D.cc:1324-1340)
+__global__ void k_lab_valid(const unsigned long long* __restrict__ key, const int* __restrict__ start, const int* __restrict__ n_all, const unsigned* __restrict__ hyp_cam,
+                            int* __restrict__ vflag, int* __restrict__ vsize)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ng = *n_all;
+    if (g > ng) return;
+    if (g == ng) { vflag[g] = 0; vsize[g] = 0; return; }
+    const int p0 = start[g], p1 = start[g + 1];
+    int ncam = 1;
+    for (int p = p0 + 1; p < p1; ++p) ncam += hyp_cam[(unsigned)key[p]] != hyp_cam[(unsigned)key[p - 1]];
+    const bool ok = p1 - p0 >= 4 && ncam >= 4;
+    vflag[g] = ok ? 1 : 0; vsize[g] = ok ? p1 - p0 : 0;
+}
+__global__ void k_lab_compact(const unsigned long long* __restrict__ key, const int* __restrict__ start, const int* __restrict__ n_all, const int* __restrict__ vflag,
+                              const int* __restrict__ vrank, const int* __restrict__ voff, int* __restrict__ group_start, int* __restrict__ member_hyp)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng = *n_all;
+    if (g > ng) return;
+    if (g == ng) { if (lane == 0) group_start[vrank[ng]] = voff[ng]; return; }   // (the closing entry)
+    if (!vflag[g]) return;
+    const int p0 = start[g], n = start[g + 1] - p0, o = voff[g];
+    if (lane == 0) group_start[vrank[g]] = o;
+    for (int i = lane; i < n; i += 64) member_hyp[o + i] = (int)(unsigned)key[p0 + i];
+}
+
+}  // namespace l3d
+
+namespace {
+
+struct FitStage { const int* gs; const int* mh; const Hypothesis* hyp; const unsigned* cam; };
+
+// the fits of clusters whose tables are on the device already
+int fit_core(l3d_ctx* c, FitStage in, int n_groups, int n_members, const double* Rinv, double scale_inv, const double* tneg,
+             int32_t** seg_count, double** segs, int* n_segs)
+{
     hipStream_t st = c->stream;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t nm = (size_t)n_members, ng = (size_t)n_groups;
-    // inputs
-    const size_t o_gs = 0, o_mh = al((ng + 1) * 4), o_hyp = o_mh + al(nm * 4 + 4), o_cam = o_hyp + (hyp ? al((size_t)n_hyp * sizeof(Hypothesis)) : 0),
-                 in_bytes = o_cam + al((size_t)n_hyp * 4 + 4);
-    HIPCHK(c, c->g0.reserve(in_bytes));
-    char* ib = c->g0.as<char>();
-    HIPCHK(c, hipMemcpyAsync(ib + o_gs, group_start, (ng + 1) * 4, hipMemcpyHostToDevice, st));
-    if (nm) HIPCHK(c, hipMemcpyAsync(ib + o_mh, member_hyp, nm * 4, hipMemcpyHostToDevice, st));
-    if (n_hyp && hyp) HIPCHK(c, hipMemcpyAsync(ib + o_hyp, hyp, (size_t)n_hyp * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
-    if (n_hyp) HIPCHK(c, hipMemcpyAsync(ib + o_cam, hyp_cam, (size_t)n_hyp * 4, hipMemcpyHostToDevice, st));
-    // scratch + outputs
     const size_t o_pts = 0, o_dist = al(2 * nm * sizeof(la::V3) + 64), o_ord = o_dist + al(2 * nm * 4 + 4), o_open = o_ord + al(2 * nm * 4 + 4), o_ci = o_open + al(nm + 4),
                  o_cc = o_ci + al(nm * 4 + 4), o_out = o_cc + al(nm * 4 + 4), o_cnt = o_out + al(6 * nm * 8 + 8), o_off = o_cnt + al((ng + 1) * 4), sc_bytes = o_off + al((ng + 2) * 4);
     HIPCHK(c, c->g1.reserve(sc_bytes));
     char* sb = c->g1.as<char>();
     FitArgs a;
     a.n_groups = n_groups;
-    a.group_start = reinterpret_cast<const int*>(ib + o_gs); a.member_hyp = reinterpret_cast<const int*>(ib + o_mh);
-    a.hyp = hyp ? reinterpret_cast<const Hypothesis*>(ib + o_hyp) : c->aff_hyp.as<Hypothesis>(); a.hyp_cam = reinterpret_cast<const unsigned*>(ib + o_cam);
+    a.group_start = in.gs; a.member_hyp = in.mh; a.hyp = in.hyp; a.hyp_cam = in.cam;
     for (int i = 0; i < 9; ++i) a.Rinv.m[i] = Rinv[i];
     a.scale_inv = scale_inv; a.tneg = la::V3{ tneg[0], tneg[1], tneg[2] };
     a.pts = reinterpret_cast<la::V3*>(sb + o_pts); a.dist = reinterpret_cast<float*>(sb + o_dist); a.order = reinterpret_cast<int*>(sb + o_ord);
@@ -196,6 +226,131 @@ extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_gr
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { free(cnt); free(packed_host); return fail(c, L3D_ERR_HIP, "line fit: read-back failed"); }
     }
     *seg_count = cnt; *segs = packed_host; *n_segs = total;
+    return L3D_OK;
+}
+
+}  // namespace
+
+// clusters: group_start (n_groups + 1) into member_hyp (hypothesis indices in key order); hyp / hyp_cam: all hypotheses (3-D end
+// points in the normalised scene) and their camera ids; Rinv (3x3 row-major), scale_inv, tneg: Line3D::inverseTransform.
+// Out (callee-allocated, l3d_free): seg_count[g] = 3-D segments of cluster g, segs = 6 doubles per segment, groups back to back.
+extern "C" int l3d_fit_clusters(l3d_ctx* c, const int32_t* group_start, int n_groups, const int32_t* member_hyp, const l3d_hypothesis* hyp, const uint32_t* hyp_cam,
+                                int n_hyp, const double* Rinv, double scale_inv, const double* tneg, int32_t** seg_count, double** segs, int* n_segs)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!seg_count || !segs || !n_segs || n_groups < 0 || n_hyp < 0 || (n_groups > 0 && (!group_start || !member_hyp || !hyp_cam || !Rinv || !tneg)))
+        return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (n_groups > 0 && !hyp && c->resident_hyp != n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: no resident hypothesis table of that size (l3d_affinity_fill)");
+    *seg_count = nullptr; *segs = nullptr; *n_segs = 0;
+    if (n_groups == 0) return L3D_OK;
+    const int n_members = group_start[n_groups];
+    if (group_start[0] != 0 || n_members < 0) return fail(c, L3D_ERR_INVALID, "line fit: group table must start at 0");
+    for (int g = 0; g < n_groups; ++g) if (group_start[g + 1] < group_start[g]) return fail(c, L3D_ERR_INVALID, "line fit: group table must ascend");
+    for (int i = 0; i < n_members; ++i) if (member_hyp[i] < 0 || member_hyp[i] >= n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: member out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nm = (size_t)n_members, ng = (size_t)n_groups;
+    const size_t o_gs = 0, o_mh = al((ng + 1) * 4), o_hyp = o_mh + al(nm * 4 + 4), o_cam = o_hyp + (hyp ? al((size_t)n_hyp * sizeof(Hypothesis)) : 0),
+                 in_bytes = o_cam + al((size_t)n_hyp * 4 + 4);
+    HIPCHK(c, c->g0.reserve(in_bytes));
+    char* ib = c->g0.as<char>();
+    HIPCHK(c, hipMemcpyAsync(ib + o_gs, group_start, (ng + 1) * 4, hipMemcpyHostToDevice, st));
+    if (nm) HIPCHK(c, hipMemcpyAsync(ib + o_mh, member_hyp, nm * 4, hipMemcpyHostToDevice, st));
+    if (n_hyp && hyp) HIPCHK(c, hipMemcpyAsync(ib + o_hyp, hyp, (size_t)n_hyp * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
+    if (n_hyp) HIPCHK(c, hipMemcpyAsync(ib + o_cam, hyp_cam, (size_t)n_hyp * 4, hipMemcpyHostToDevice, st));
+    FitStage in{ reinterpret_cast<const int*>(ib + o_gs), reinterpret_cast<const int*>(ib + o_mh),
+                 hyp ? reinterpret_cast<const Hypothesis*>(ib + o_hyp) : c->aff_hyp.as<Hypothesis>(), reinterpret_cast<const unsigned*>(ib + o_cam) };
+    return fit_core(c, in, n_groups, n_members, Rinv, scale_inv, tneg, seg_count, segs, n_segs);
+}
+
+// processClusteredSegments from the LABELS (line3D.cc:1306-1368): the grouping on the device as well.  labels / node_hyp (n_nodes each: the
+// cluster label and the hypothesis index of every node) -- NULL: the arrays l3d_perform_clustering_device / l3d_affinity_fill* left on
+// the device.  Out: the clusters that were fitted, in ascending label order -- group_start (n_groups + 1), member_hyp -- and their segments.
+extern "C" int l3d_fit_labelled_clusters(l3d_ctx* c, const int32_t* labels, const int32_t* node_hyp, int n_nodes, const l3d_hypothesis* hyp, const uint32_t* hyp_cam, int n_hyp,
+                                         const double* Rinv, double scale_inv, const double* tneg, int32_t** group_start, int32_t** member_hyp, int* n_groups,
+                                         int32_t** seg_count, double** segs, int* n_segs)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!group_start || !member_hyp || !n_groups || !seg_count || !segs || !n_segs || n_nodes < 0 || n_hyp < 0 || (n_nodes > 0 && (!hyp_cam || !Rinv || !tneg)))
+        return fail(c, L3D_ERR_INVALID, "bad argument");
+    *group_start = nullptr; *member_hyp = nullptr; *n_groups = 0; *seg_count = nullptr; *segs = nullptr; *n_segs = 0;
+    if (n_nodes == 0) return L3D_OK;
+    if (!hyp && c->resident_hyp != n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: no resident hypothesis table of that size (l3d_affinity_fill)");
+    if (!labels && c->resident_labels != n_nodes) return fail(c, L3D_ERR_INVALID, "line fit: no resident labels of that size (l3d_perform_clustering_device)");
+    if (!node_hyp && c->resident_nodes != n_nodes) return fail(c, L3D_ERR_INVALID, "line fit: no resident node table of that size (l3d_affinity_fill)");
+    if (labels) for (int v = 0; v < n_nodes; ++v) if (labels[v] < 0 || labels[v] >= n_nodes) return fail(c, L3D_ERR_INVALID, "line fit: label out of range");
+    if (node_hyp) for (int v = 0; v < n_nodes; ++v) if (node_hyp[v] < 0 || node_hyp[v] >= n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: node hypothesis out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nn = (size_t)n_nodes;
+    // staging (g0): group table and members of the fitted clusters (upper bounds: n/4 clusters, n members), hypotheses, cameras, uploads
+    const size_t o_gs = 0, o_mh = al((nn / 4 + 2) * 4), o_hyp = o_mh + al(nn * 4 + 4), o_cam = o_hyp + (hyp ? al((size_t)n_hyp * sizeof(Hypothesis)) : 0),
+                 o_lab = o_cam + al((size_t)n_hyp * 4 + 4), o_nh = o_lab + (labels ? al(nn * 4) : 0), in_bytes = o_nh + (node_hyp ? al(nn * 4) : 0);
+    HIPCHK(c, c->g0.reserve(in_bytes));
+    char* ib = c->g0.as<char>();
+    if (hyp) HIPCHK(c, hipMemcpyAsync(ib + o_hyp, hyp, (size_t)n_hyp * sizeof(Hypothesis), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ib + o_cam, hyp_cam, (size_t)n_hyp * 4, hipMemcpyHostToDevice, st));
+    if (labels) HIPCHK(c, hipMemcpyAsync(ib + o_lab, labels, nn * 4, hipMemcpyHostToDevice, st));
+    if (node_hyp) HIPCHK(c, hipMemcpyAsync(ib + o_nh, node_hyp, nn * 4, hipMemcpyHostToDevice, st));
+    const int* d_lab = labels ? reinterpret_cast<const int*>(ib + o_lab) : c->resident_labels_p;
+    const int* d_nh = node_hyp ? reinterpret_cast<const int*>(ib + o_nh) : c->resident_nodes_p;
+    const unsigned* d_cam = reinterpret_cast<const unsigned*>(ib + o_cam);
+    int* d_gs = reinterpret_cast<int*>(ib + o_gs);
+    int* d_mh = reinterpret_cast<int*>(ib + o_mh);
+    // scratch (g5): two key arrays, flags / ranks / starts / valid / sizes and their scans, hipCUB's temporary storage
+    int bits = 1;
+    while ((1ll << bits) < (long long)n_nodes) ++bits;
+    size_t tb = 0, tb2 = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n_nodes, 0, 32 + bits, st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (const int*)nullptr, (int*)nullptr, n_nodes + 1, st));
+    tb = std::max(tb, tb2);
+    const size_t kb = al(nn * 8), ib4 = al((nn + 2) * 4);
+    HIPCHK(c, c->g5.reserve(2 * kb + 8 * ib4 + tb + 256));
+    char* sc = c->g5.as<char>();
+    unsigned long long *key_in = reinterpret_cast<unsigned long long*>(sc), *key = reinterpret_cast<unsigned long long*>(sc + kb);
+    int* flag = reinterpret_cast<int*>(sc + 2 * kb);
+    int* rank = reinterpret_cast<int*>(sc + 2 * kb + ib4);
+    int* start = reinterpret_cast<int*>(sc + 2 * kb + 2 * ib4);
+    int* vflag = reinterpret_cast<int*>(sc + 2 * kb + 3 * ib4);
+    int* vsize = reinterpret_cast<int*>(sc + 2 * kb + 4 * ib4);
+    int* vrank = reinterpret_cast<int*>(sc + 2 * kb + 5 * ib4);
+    int* voff = reinterpret_cast<int*>(sc + 2 * kb + 6 * ib4);
+    void* temp = sc + 2 * kb + 8 * ib4;
+    const dim3 block(256), grid((n_nodes + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_lab_keys, grid, block, 0, st, d_lab, d_nh, n_nodes, key_in);
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(temp, tb, key_in, key, n_nodes, 0, 32 + bits, st));
+    hipLaunchKernelGGL(k_lab_flags, grid, block, 0, st, key, n_nodes, flag);
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, rank, n_nodes + 1, st));
+    hipLaunchKernelGGL(k_lab_starts, grid, block, 0, st, flag, rank, n_nodes, start);
+    const int* n_all = rank + n_nodes;                                       // number of clusters (device)
+    hipLaunchKernelGGL(k_lab_valid, grid, block, 0, st, key, start, n_all, d_cam, vflag, vsize);
+    // (the scans run over n_nodes + 1 entries; beyond the clusters the flags are whatever k_lab_valid left -- it writes 0 at index n_all,
+    // and nothing behind it is read)
+    int h_all = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_all, n_all, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, vflag, vrank, h_all + 1, st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, vsize, voff, h_all + 1, st));
+    hipLaunchKernelGGL(k_lab_compact, dim3((h_all + 1 + 3) / 4), block, 0, st, key, start, n_all, vflag, vrank, voff, d_gs, d_mh);
+    int tot[2] = { 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(&tot[0], vrank + h_all, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&tot[1], voff + h_all, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    const int ng = tot[0], nm = tot[1];
+    if (ng == 0) return L3D_OK;
+    int32_t* gs_h = static_cast<int32_t*>(malloc(((size_t)ng + 1) * 4));
+    int32_t* mh_h = static_cast<int32_t*>(malloc(((size_t)nm + 1) * 4));
+    if (!gs_h || !mh_h) { free(gs_h); free(mh_h); return fail(c, L3D_ERR_NOMEM, "malloc"); }
+    hipError_t e1 = hipMemcpyAsync(gs_h, d_gs, ((size_t)ng + 1) * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(mh_h, d_mh, (size_t)nm * 4, hipMemcpyDeviceToHost, st);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipStreamSynchronize(st); free(gs_h); free(mh_h); return fail(c, L3D_ERR_HIP, "line fit: read-back failed"); }
+    FitStage in{ d_gs, d_mh, hyp ? reinterpret_cast<const Hypothesis*>(ib + o_hyp) : c->aff_hyp.as<Hypothesis>(), d_cam };
+    const int rc = fit_core(c, in, ng, nm, Rinv, scale_inv, tneg, seg_count, segs, n_segs);   // (synchronises: the two copies above are done)
+    if (rc) { (void)hipStreamSynchronize(st); free(gs_h); free(mh_h); return rc; }
+    *group_start = gs_h; *member_hyp = mh_h; *n_groups = ng;
     return L3D_OK;
 }
 

@@ -306,7 +306,7 @@ extern "C" int l3d_replicator_dynamics_diffusion(l3d_ctx* c, const l3d_edge* A, 
     const bool timing = getenv("L3D_TIMING") != nullptr;
     const size_t ab = (size_t)nnz * sizeof(l3d_edge);
     HIPCHK(c, c->g6.reserve(ab + 64));
-    c->resident_edges = 0;                                               // (whatever list was resident there is gone)
+    c->resident_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;   // (whatever list was resident there is gone; g4 is scratch)
     HIPCHK(c, hipMemcpyAsync(c->g6.p, A, ab, hipMemcpyHostToDevice, st));
     if (int rc = rdd_resident(c, nnz, n, iters, st, timing)) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->g6.p, ab, hipMemcpyDeviceToHost, st));
@@ -384,13 +384,17 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
 
 // The edge list performClustering walks (clustering.cc:14-40), prepared on the device: optional performDiffusion
 // (line3D.cc:1255-1303: replicator dynamics, symmetrise by the minimum, (i,j) order) and the stable ascending weight order.
-// labels_out != nullptr: the merge loop runs on the device as well (k_uf_component) and only the n labels come back
+// merge_loop: the merge loop runs on the device as well (k_uf_component); the n labels stay there and come back when labels_out != nullptr
 static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, l3d_edge* sorted_out,
-                                 int32_t** group_start_out, int* n_groups_out, int32_t* labels_out = nullptr, float cl_c = 0.0f)
+                                 int32_t** group_start_out, int* n_groups_out, bool merge_loop = false, int32_t* labels_out = nullptr, float cl_c = 0.0f)
 {
     if (!c) return L3D_ERR_INVALID;
-    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && !sorted_out && !labels_out)) return fail(c, L3D_ERR_INVALID, "bad argument");
-    if (labels_out && nnz == 0) { for (int v = 0; v < n; ++v) labels_out[v] = v; return L3D_OK; }
+    if (nnz < 0 || n < 0 || iters < 0 || (nnz > 0 && !sorted_out && !merge_loop)) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (merge_loop && nnz == 0) {
+        if (!labels_out && n > 0) return fail(c, L3D_ERR_INVALID, "clustering: no edges and no place for the labels");
+        for (int v = 0; v < n; ++v) labels_out[v] = v;
+        return L3D_OK;
+    }
     if (group_start_out) { *group_start_out = nullptr; *n_groups_out = 0; }
     if (nnz == 0) return L3D_OK;
     if (!A && c->resident_edges != nnz) return fail(c, L3D_ERR_INVALID, "no resident edge list of that size (l3d_affinity_fill)");
@@ -402,7 +406,9 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
     double t_last = now_s();
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = now_s(); fprintf(stderr, "[l3d edges] %-24s %8.2f ms\n", what, (t - t_last) * 1e3); t_last = t; } };
     const size_t ab = (size_t)nnz * sizeof(l3d_edge);
+    c->resident_labels = 0;                                              // (g4 is scratch of the diffusion and of the merge loop)
     if (A) {
+        c->resident_nodes = 0;                                           // (g6 is overwritten)
         HIPCHK(c, c->g6.reserve(ab + 64));
         HIPCHK(c, hipMemcpyAsync(c->g6.p, A, ab, hipMemcpyHostToDevice, st));
     }
@@ -429,7 +435,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         E = c->g0.as<l3d_edge>();
         lap("diffusion + symmetrise");
     }
-    bool grouped = group_start_out != nullptr || labels_out != nullptr;
+    bool grouped = group_start_out != nullptr || merge_loop;
     if (grouped) {
         // ---- grouped by connected component: labels, then ONE stable sort by (component, weight key)
         HIPCHK(c, c->g3.reserve((size_t)n * 4 + 256));
@@ -437,7 +443,9 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int* changed = comp + n;                                           // (n * 4 + 256 reserved)
         const dim3 ngrid((n + 255) / 256);
         hipLaunchKernelGGL(k_cc_init, ngrid, block, 0, st, comp, n);
-        for (int round = 0; round < 64; ++round) {
+        const char* mr = getenv("L3D_CC_MAX_ROUNDS");                      // (test hook: forces the not-converged path)
+        const int max_rounds = mr && atoi(mr) > 0 ? atoi(mr) : 64;
+        for (int round = 0; round < max_rounds; ++round) {
             HIPCHK(c, hipMemsetAsync(changed, 0, 4, st));
             for (int r = 0; r < 3; ++r) {                                  // a few hooking rounds per look at the flag
                 hipLaunchKernelGGL(k_cc_hook, grid, block, 0, st, E, nnz, comp, changed + (r == 2 ? 0 : 1));
@@ -447,8 +455,8 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
             HIPCHK(c, hipMemcpyAsync(&h_changed, changed, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             if (!h_changed) break;
-            if (round == 63) {                                             // not converged: one group, ...
-                if (labels_out) HIPCHK(c, hipMemsetAsync(comp, 0, (size_t)n * 4, st));   // ... here as the single component 0
+            if (round == max_rounds - 1) {                                 // not converged: one group, ...
+                if (merge_loop) HIPCHK(c, hipMemsetAsync(comp, 0, (size_t)n * 4, st));   // ... here as the single component 0
                 else grouped = false;                                      // ... the plain order below
             }
         }
@@ -486,7 +494,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int n_groups = 0;
         HIPCHK(c, hipMemcpyAsync(&n_groups, frank + nnz, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        if (labels_out) {
+        if (merge_loop) {
             // nodes in (component, id) order -> local numbers; then one wave per component
             size_t tbn = 0;
             HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tbn, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0, shift, st));
@@ -504,9 +512,10 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
             hipLaunchKernelGGL(k_uf_pos, ngrid, block, 0, st, nkey, node_sorted, n, pos, ncnt);
             { ProfScope p(c, "uf_components");
               hipLaunchKernelGGL(k_uf_component, dim3(n_groups), dim3(64), 0, st, c->g1.as<l3d_edge>(), gstart, n_groups, nnz, comp, node_sorted, pos, ncnt, n, cl_c, g_state, labels); }
-            HIPCHK(c, hipMemcpyAsync(labels_out, labels, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            if (labels_out) HIPCHK(c, hipMemcpyAsync(labels_out, labels, (size_t)n * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             HIPCHK(c, hipGetLastError());
+            c->resident_labels = n; c->resident_labels_p = labels;        // (for l3d_fit_labelled_clusters)
             lap("grouped order + merge loop (device)");
             if (n_groups_out) *n_groups_out = n_groups;
             return L3D_OK;
@@ -568,9 +577,8 @@ extern "C" int l3d_clustering_edges_grouped(l3d_ctx* c, const l3d_edge* A, int n
 extern "C" int l3d_perform_clustering_device(l3d_ctx* c, const l3d_edge* A, int nnz, int n, int perform_diffusion, int iters, float cl_c, int32_t* labels,
                                              int* n_components)
 {
-    if (!labels && n > 0) return c ? fail(c, L3D_ERR_INVALID, "bad argument") : L3D_ERR_INVALID;
     if (n_components) *n_components = 0;
-    return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, nullptr, nullptr, n_components, labels, cl_c);
+    return clustering_edges_impl(c, A, nnz, n, perform_diffusion, iters, nullptr, nullptr, n_components, true, labels, cl_c);
 }
 
 // the edge list of the last l3d_affinity_fill / l3d_affinity_fill_resident, copied to the host: from g6 while it is resident, from the

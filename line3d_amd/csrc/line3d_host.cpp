@@ -1887,19 +1887,20 @@ int cluster_segments_2D(L* h, bool perform_diff)
     const double t1 = now_s();
     const int n_nodes = (int)h->local2global.size();
     std::vector<int> labels;
+    bool labels_on_device = false;
     {
         // the list clustering walks -- diffused and symmetrised when asked for, in stable ascending weight order -- comes from
         // the device, where the affinity list still is (l3d_clustering_edges); a list the device path does not take
         // (L3D_ERR_UNSUPPORTED) goes through the reference's map arithmetic on the host
         // ... and so does the merge loop itself, one wave per connected component (l3d_perform_clustering_device): only the labels
         // come back.  L3D_HOST_CLUSTERING=1 keeps the merge loop on the worker threads (the seam tests compare the two).
-        static const bool host_loop = getenv("L3D_HOST_CLUSTERING") != nullptr;
+        const bool host_loop = getenv("L3D_HOST_CLUSTERING") != nullptr;
         const int nnz = (int)h->n_edges, diff = perform_diff ? 1 : 0;
         int rc = L3D_ERR_UNSUPPORTED;
         if (resident_list && !host_loop) {
-            labels.resize((size_t)n_nodes);
-            rc = l3d_perform_clustering_device(h->ctx, nullptr, nnz, n_nodes, diff, L3D_RDD_MAX_ITER, 1.0f, labels.data(), nullptr);   // :1245
-            if (rc == L3D_OK) lap(perform_diff ? "diffusion + clustering (device)" : "clustering (device)");
+            // (the labels stay on the device as well: the grouping and the fits follow there, l3d_fit_labelled_clusters)
+            rc = l3d_perform_clustering_device(h->ctx, nullptr, nnz, n_nodes, diff, L3D_RDD_MAX_ITER, 1.0f, nullptr, nullptr);   // :1245
+            if (rc == L3D_OK) { labels_on_device = true; lap(perform_diff ? "diffusion + clustering (device)" : "clustering (device)"); }
         } else if (resident_list) {
             std::unique_ptr<l3d_edge[]> sorted(new l3d_edge[h->n_edges + 1]);
             int32_t* group_start = nullptr;
@@ -1920,6 +1921,36 @@ int cluster_segments_2D(L* h, bool perform_diff)
         } else if (rc != L3D_OK) return h->fail(rc, std::string("clustering: ") + l3d_last_error(h->ctx));
     }
     lap("clustering");
+
+    if (labels_on_device) {
+        // processClusteredSegments, line3D.cc:1306-1368, from the labels on the device: grouping (ascending label, members in key order,
+        // >= 4 cameras) and the fits in one call; the host turns the answer into the result list
+        int32_t *gstart = nullptr, *memb = nullptr, *cnt = nullptr; double* segs = nullptr; int n_groups = 0, n_segs = 0;
+        const double tneg[3] = { h->transf_tneg.x, h->transf_tneg.y, h->transf_tneg.z };
+        const int rc = l3d_fit_labelled_clusters(h->ctx, nullptr, nullptr, n_nodes, nullptr, h->aff.hyp_cam.data(), (int)h->hyps.size(), h->transf_Rinv.m, h->transf_scale_inv,
+                                                 tneg, &gstart, &memb, &n_groups, &cnt, &segs, &n_segs);
+        if (rc) return h->fail(rc, std::string("line fit: ") + l3d_last_error(h->ctx));
+        lap("  fit: grouping + fits (device)");
+        std::vector<size_t> soff((size_t)n_groups + 1, 0);
+        for (int v = 0; v < n_groups; ++v) soff[(size_t)v + 1] = soff[(size_t)v] + (size_t)cnt[v];
+        std::vector<FinalLine> fitted((size_t)n_groups);
+        parallel_slices((size_t)n_groups, finish_threads(), [&](size_t v0, size_t v1, unsigned) {
+            for (size_t v = v0; v < v1; ++v) {
+                if (cnt[v] == 0) continue;
+                FinalLine& fl = fitted[v];
+                for (size_t k = soff[v]; k < soff[v + 1]; ++k) {
+                    const double* q = segs + 6 * k;
+                    fl.segs3D.emplace_back(V3{ q[0], q[1], q[2] }, V3{ q[3], q[4], q[5] });
+                }
+                for (int32_t i = gstart[v]; i < gstart[v + 1]; ++i) fl.segs2D.push_back(h->hyps[(size_t)memb[(size_t)i]].src);
+            }
+        });
+        l3d_free(gstart); l3d_free(memb); l3d_free(cnt); l3d_free(segs);
+        for (FinalLine& fl : fitted) if (!fl.segs3D.empty()) h->result.push_back(std::move(fl));
+        lap("line fit");
+        h->t_cluster = now_s() - t1;
+        return L3D_OK;
+    }
 
     // processClusteredSegments, line3D.cc:1306-1368: clusters in ascending label order (the reference's std::map), their
     // segments in key order; clusters seen from >= 4 cameras are fitted, independently of each other, by the worker threads

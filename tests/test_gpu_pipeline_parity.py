@@ -680,3 +680,25 @@ def test_resident_products_with_foreign_camera_ids_and_early_returns():
         _check_resident_products_against_oracle(l, o, sc)
         assert_lines_equal(l.getResult(), o.result, 1e-4)
         l.close()
+
+
+@pytest.mark.parametrize("diffusion", [False, True])
+def test_finish_on_the_device_and_on_the_host_agree(small_scene, small_oracle, monkeypatch, diffusion):
+    """compute3Dmodel's tail after the affinity fill -- [diffusion,] merge loop, grouping, fits -- on the device (default: the labels
+    and the edge list never leave it) and with the merge loop and the grouping on the host threads (L3D_HOST_CLUSTERING=1): the same
+    lines, bit for bit; the affinity list fetched afterwards is the same list."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    outs = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("L3D_HOST_CLUSTERING", "1")
+        l = Line3D("", matchingNeighbors=6)
+        load_scene(l, small_scene)
+        l.compute3Dmodel(diffusion)
+        res = l.getResult()
+        outs.append((l.affinity()[0].tobytes(), [(list(s2), np.asarray(s3).tobytes()) for s2, s3 in res]))
+        if not host and not diffusion:
+            assert_lines_equal(res, small_oracle.result, 1e-4)
+        l.close()
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 0
+    assert outs[0][1] == outs[1][1] and len(outs[0][1]) > 0

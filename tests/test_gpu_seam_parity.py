@@ -744,3 +744,67 @@ def test_clustering_merge_loop_big_components(gpu_ctx, oracle_lib):
     assert n_comp == 1 + 1 + 500 + 1000
     assert np.array_equal(got, want)
     assert np.array_equal(got[n - 17:], np.arange(n - 17, n))
+
+
+def test_clustering_merge_loop_without_components(gpu_ctx, oracle_lib, monkeypatch):
+    """When the component labels do not converge (forced here: one hooking round on long paths) the whole list is walked as ONE
+    component -- the plain sequential order, state in HBM: same labels."""
+    rng = np.random.default_rng(47)
+    n = 5000
+    perm = rng.permutation(n)
+    edges = [(int(perm[k]), int(perm[k + 1])) for k in range(n - 1) if k % 500 != 499]      # ten paths of 500 nodes
+    A = []
+    for a, b in edges:
+        w = np.float32(rng.choice([0.1, 0.5, 0.9])) if rng.random() < 0.7 else np.float32(rng.random())
+        A.append((a, b, w)); A.append((b, a, w))
+    A = np.array(A, dtype=op.EDGE_DTYPE)
+    want = op.clustering(oracle_lib, gpu_ctx.clustering_edges(A, n), n, 1.0)
+    got, n_comp = gpu_ctx.perform_clustering_device(A, n, c=1.0)
+    assert n_comp == 10 and np.array_equal(got, want)
+    monkeypatch.setenv("L3D_CC_MAX_ROUNDS", "1")
+    got1, n_comp1 = gpu_ctx.perform_clustering_device(A, n, c=1.0)
+    assert n_comp1 == 1 and np.array_equal(got1, want)
+
+
+def test_fit_labelled_clusters_groups_like_process_clustered_segments(gpu_ctx):
+    """l3d_fit_labelled_clusters: from (label, hypothesis) per node to the fitted clusters -- ascending label order, members in key
+    order, only clusters with >= 4 members seen from >= 4 cameras (line3D.cc:1306-1340); the fits bit-equal to l3d_fit_clusters on the
+    same tables."""
+    from line3d_amd.capi import HYP_DTYPE
+    rng = np.random.default_rng(19)
+    n_hyp = 6000
+    hyp = np.zeros(n_hyp, HYP_DTYPE)
+    hyp_cam = np.sort(rng.integers(0, 40, n_hyp)).astype(np.uint32)            # hypotheses are numbered by (camera, segment)
+    Rinv, scale_inv, tneg = np.eye(3), 1.0, np.zeros(3)
+    nodes = rng.permutation(n_hyp)[:4000]                                      # node -> hypothesis (first-touch numbering: any order)
+    n = len(nodes)
+    labels = np.arange(n, dtype=np.int32)                                      # everybody alone ...
+    free = list(rng.permutation(n))
+    expected = {}
+    for g in range(180):                                                       # ... except 180 planted clusters
+        size = int(rng.integers(2, 30)) if g else 400
+        members = [free.pop() for _ in range(size)]
+        p0, d = rng.normal(size=3), rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        for v in members:
+            a = rng.uniform(-1, 1)
+            hyp[nodes[v]]["P1"] = p0 + a * d + rng.normal(scale=0.002, size=3)
+            hyp[nodes[v]]["P2"] = p0 + (a + rng.uniform(0.2, 1.0)) * d + rng.normal(scale=0.002, size=3)
+        root = int(members[int(rng.integers(0, size))])                        # (a root is one of the cluster's nodes)
+        labels[members] = root
+        hs = sorted(int(nodes[v]) for v in members)
+        if size >= 4 and len({int(hyp_cam[k]) for k in hs}) >= 4:
+            expected[root] = hs
+    gs, mh, fits = gpu_ctx.fit_labelled_clusters(labels, nodes, hyp, hyp_cam, Rinv, scale_inv, tneg)
+    want_gs, want_mh = [0], []
+    for root in sorted(expected):
+        want_mh += expected[root]
+        want_gs.append(len(want_mh))
+    assert len(expected) > 100 and any(len(v) == 400 for v in expected.values())
+    assert gs.tolist() == want_gs and mh.tolist() == want_mh
+    ref = gpu_ctx.fit_clusters(want_gs, want_mh, hyp, hyp_cam, Rinv, scale_inv, tneg)
+    assert len(ref) == len(fits) and sum(len(f) for f in fits) > 100
+    for a, b in zip(fits, ref):
+        assert len(a) == len(b)
+        for (s1, e1), (s2, e2) in zip(a, b):
+            assert s1.tobytes() == s2.tobytes() and e1.tobytes() == e2.tobytes()
