@@ -158,7 +158,7 @@ typedef struct l3d_affinity_input {
 int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes,
                       int* n_candidates);
 
-/* The edge list Line3D::performClustering walks (clustering.cc:14-40; the union-find itself stays on the host), prepared on
+/* The edge list Line3D::performClustering walks (clustering.cc:14-40; the merge loop itself: l3d_perform_clustering_device below), prepared on
  * the device: optionally performDiffusion (line3D.cc:1255-1303: replicator_dynamics_diffusion, then A(i,j) = A(j,i) =
  * min(W(i,j), W(j,i)), rebuilt in (i,j) order), then the STABLE ascending order by weight of clustering.cc:14.
  * A == NULL: the list the last l3d_affinity_fill returned, still resident on the device (nnz must match; it is consumed).
@@ -438,7 +438,7 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
  * gathered_out (optional) receives the device address of the gathered blocks (valid until the next chain) */
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);
-/* performClustering (clustering.h:125, clustering.cc:6-47; stays on the host): labels[k] = CLUniverse::find(k) */
+/* performClustering (clustering.h:125, clustering.cc:6-47) on the host (fallback and cross-check of l3d_perform_clustering_device): labels[k] = CLUniverse::find(k) */
 int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */
 int l3d_line3d_result_sizes(const l3d_line3d* h, int* n_lines, int* n_seg3d, int* n_seg2d);

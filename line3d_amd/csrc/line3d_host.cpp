@@ -1490,7 +1490,8 @@ int best_of(const L* h, Key k)
     return kseg(k) < bi.size() ? bi[kseg(k)] : -1;
 }
 
-// Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115 (stays on the host)
+// Felzenszwalb-Huttenlocher segmentation, clustering.cc:6-47 + universe.h:59-115, on the host: the fallback for lists the device path
+// refuses and the cross-check of l3d_perform_clustering_device (L3D_HOST_CLUSTERING=1)
 // presorted: edges_in already is in the stable ascending weight order (l3d_clustering_edges)
 void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, float c, std::vector<int>& labels, bool presorted = false)
 {
@@ -1746,7 +1747,7 @@ int fill_affinity_resident(L* h)
 }
 
 // Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
-// (l3d_affinity_fill / l3d_affinity_fill_resident, l3d_clustering_edges), union-find and line fit here; host symmetrisation and
+// (l3d_affinity_fill / l3d_affinity_fill_resident, l3d_perform_clustering_device, l3d_fit_labelled_clusters); host union-find, symmetrisation and
 // edge order remain for edge lists the device path refuses.  (The literal `used` enumeration of round 1 lives on as a test helper:
 // tests/cpp/literal_used_rule.c.)
 int cluster_segments_2D(L* h, bool perform_diff)
