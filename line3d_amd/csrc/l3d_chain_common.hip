@@ -84,10 +84,10 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
     std::vector<RayJob>& jobs = c->ray_jobs;             // (lives in the context: the upload below is asynchronous)
     jobs.clear();
     for (int k = 0; k < n_views; ++k) {
-        vd[(size_t)k].rays = nullptr;
-        if (with_rays && vd[(size_t)k].verified && views[k].n_tbm != 0) n_ray += (size_t)views[k].n_tgt;
+        vd[(size_t)k].rays = nullptr; vd[(size_t)k].src_rays = nullptr;
+        if (with_rays && vd[(size_t)k].verified && views[k].n_tbm != 0) n_ray += (size_t)views[k].n_tgt + (size_t)views[k].S_src;
     }
-    HIPCHK(c, c->ch_rays.reserve(n_ray * 32 + (size_t)n_views * sizeof(RayJob) + 512));
+    HIPCHK(c, c->ch_rays.reserve(n_ray * 32 + 2 * (size_t)n_views * sizeof(RayJob) + 512));
     float4* rbase = c->ch_rays.as<float4>();
     RayJob* djobs = reinterpret_cast<RayJob*>(c->ch_rays.as<unsigned char>() + ((n_ray * 32 + 255) & ~(size_t)255));
     size_t ro = 0;
@@ -96,7 +96,10 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
         if (!with_rays || !d.verified || views[k].n_tbm == 0) continue;
         d.rays = rbase + 2 * ro; ro += (size_t)views[k].n_tgt;
         jobs.push_back(RayJob{ d.tgt, reinterpret_cast<const int2*>(L.dtab + d.o_off), reinterpret_cast<const float*>(L.dtab + d.o_R), d.rays, views[k].n_tgt, views[k].N });
-        max_n_tgt = std::max(max_n_tgt, views[k].n_tgt);
+        // (the view's own segments under its own camera: what k_pair_fill needs once per (segment, camera) row)
+        d.src_rays = rbase + 2 * ro; ro += (size_t)views[k].S_src;
+        jobs.push_back(RayJob{ d.src, nullptr, reinterpret_cast<const float*>(L.dtab + d.o_Rs), d.src_rays, views[k].S_src, 1 });
+        max_n_tgt = std::max(max_n_tgt, std::max(views[k].n_tgt, views[k].S_src));
     }
     if (!jobs.empty()) {
         HIPCHK(c, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(RayJob), hipMemcpyHostToDevice, st));
@@ -178,7 +181,8 @@ PairArgs chain_pair_args(const l3d_ctx* c, const l3d_chain_view& v, const ChainV
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
     pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
     pa.depth_in_fill = 1;               // the four depths of a stage-1 pair are triangulated once, by k_pair_fill
-    pa.tgt_rays = d.rays;
+    static const bool src_rays_env = !(getenv("L3D_SRC_RAYS") && atoi(getenv("L3D_SRC_RAYS")) == 0);   // (0: A/B, k_pair_fill normalises per row)
+    pa.tgt_rays = d.rays; pa.src_rays = src_rays_env ? d.src_rays : nullptr;
     return pa;
 }
 

@@ -22,6 +22,7 @@ struct ChainViewDev {               // device addresses of one view's static tab
     float2* best = nullptr;
     int* bestpos = nullptr;         // per segment: position (in the view's kept slice) of its best kept match or -1 (k_kept_write_chain)
     float4* rays = nullptr;         // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
+    float4* src_rays = nullptr;     // ... of the view's own end points (2 per source segment)
     int W64 = 0, maxW = 0;
     int s0 = 0, s1 = 0;             // this rank's source-segment range ([0, S) in the single-GPU chain)
     bool verified = false;

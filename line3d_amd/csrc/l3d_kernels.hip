@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256) void k_tgt_rays(const RayJob* __restrict__ job
     const RayJob jb = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= jb.n_tgt) return;
-    int cam = -1;
-    for (int c = 0; c < jb.N; ++c) { const int2 o = jb.offsets[c]; if (i >= o.x && i < o.x + o.y) cam = c; }
+    int cam = jb.offsets ? -1 : 0;                       // (no offsets: one camera for all entries -- a view's own segments under its own camera)
+    if (jb.offsets) for (int c = 0; c < jb.N; ++c) { const int2 o = jb.offsets[c]; if (i >= o.x && i < o.x + o.y) cam = c; }
     if (cam < 0) return;
     const float4 t = jb.tgt[i];
     const f3 r1 = normalize(mat3_apply(jb.RtKinv + cam * 9, mk3(t.x, t.y, 1.0f)));
@@ -513,7 +513,13 @@ __global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __rest
     const SrcPairInv s = make_src_inv(a.src_segs[y], a.F + cam * 9);
     const f3 C_tgt = mk3(a.centers[cam * 3], a.centers[cam * 3 + 1], a.centers[cam * 3 + 2]);
     const f3 C_src = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
-    const f3 ray_p1 = normalize(mat3_apply(a.RtKinv_src, s.p1)), ray_p2 = normalize(mat3_apply(a.RtKinv_src, s.p2));   // row invariants
+    f3 ray_p1, ray_p2;                                                                                                  // row invariants
+    if (a.src_rays) {                      // (the same table for the view's own segments: the same operations once per chain instead of once per row)
+        const float4 r1 = a.src_rays[2 * (size_t)y], r2 = a.src_rays[2 * (size_t)y + 1];
+        ray_p1 = mk3(r1.x, r1.y, r1.z); ray_p2 = mk3(r2.x, r2.y, r2.z);
+    } else {
+        ray_p1 = normalize(mat3_apply(a.RtKinv_src, s.p1)); ray_p2 = normalize(mat3_apply(a.RtKinv_src, s.p2));
+    }
 
     int written = 0;                       // depth_in_fill: records of the row so far (wave-uniform)
     for (int k0 = 0; k0 < total; k0 += 64) {

@@ -67,6 +67,7 @@ struct PairArgs {
     int* rowstart_out = nullptr;
     const float4* tgt_rays = nullptr;   // resident chain: unit viewing rays of the target endpoints, 2 per entry of tgt_segs (k_tgt_rays); null: k_pair_fill
                                     // normalises them itself, per candidate, with the same operations
+    const float4* src_rays = nullptr;   // ... and of the view's own end points (2 per source segment)
     int depth_in_fill = 0;          // resident chain: k_pair_mask stops after the exact overlap test (its bits and row counts are then an UPPER
                                     // bound), the four depths are triangulated ONCE, in k_pair_fill, which drops the pairs without four positive
                                     // depths (cudawrapper.cu:931), packs the row and writes its true count back into rowcnt; 0: the bit already
