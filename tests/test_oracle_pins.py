@@ -167,6 +167,31 @@ def test_contract_and_libm_oracles_agree_on_ids(small_scene, small_oracle):
         assert np.max(np.abs(a["confidence"] - b["confidence"]), initial=0) < 1e-6
 
 
+@pytest.mark.parametrize("family", ["helix14x400", "narrow10x600", "opposing6x250"])
+def test_contract_and_libm_oracles_agree_on_more_scenes(family):
+    """The same comparison on three more scene families (21 500 kept matches together): a wider helix, a narrow-baseline helix
+    (step 0.05 rad, 8 neighbours) and cameras that face each other / look along the baseline (epipoles inside the images).  Identical
+    id sets, confidences within 3e-7 (one float ulp at 1 -- what two correctly-rounded-to-2-ulp transcendentals can differ by),
+    the same number of 3-D lines."""
+    from line3d_amd.synth import make_scene_from_poses
+    if family == "helix14x400":
+        scene, N = make_scene(14, 400, 6, seed=3), 6
+    elif family == "narrow10x600":
+        scene, N = make_scene(10, 600, 8, seed=11, step=0.05), 8
+    else:
+        scene, N = make_scene_from_poses([(4, 0, 0), (-4, 0.2, 0.3), (0, 0.1, 4), (0.2, 0, -4), (3, 0.5, 3), (1.5, 0.2, 0.1)], [(0, 0, 0)] * 6, 250, seed=5), 5
+    a, b = op.run_scene(scene, N), op.run_scene(scene, N, libm=True)
+    n = 0
+    for v in sorted(a.trace):
+        ma, mb = a.trace[v]["matches"], b.trace[v]["matches"]
+        ka = list(zip(ma["segID1"].tolist(), ma["camID2"].tolist(), ma["segID2"].tolist()))
+        kb = list(zip(mb["segID1"].tolist(), mb["camID2"].tolist(), mb["segID2"].tolist()))
+        assert ka == kb, v
+        n += len(ka)
+        assert np.max(np.abs(ma["confidence"] - mb["confidence"]), initial=0) < 3e-7
+    assert n > 2500 and len(a.result) == len(b.result) > 40
+
+
 def test_synth_is_deterministic():
     a = make_scene(5, 40, 4, seed=9)
     b = make_scene(5, 40, 4, seed=9)
