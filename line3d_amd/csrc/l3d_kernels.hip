@@ -126,8 +126,15 @@ __device__ __forceinline__ float iou_upper(float t1, float r1, float t2, float r
     return inter * __builtin_amdgcn_rcpf(uni) * (1.0f + 1.0e-5f);
 }
 
+#ifndef L3D_PM_WAVES
+#define L3D_PM_WAVES 0
+#endif
 template <bool kDepth>
-__global__ __launch_bounds__(256) void k_pair_mask(PairArgs a)
+__global__ __launch_bounds__(256)
+#if L3D_PM_WAVES
+__attribute__((amdgpu_waves_per_eu(L3D_PM_WAVES, L3D_PM_WAVES)))
+#endif
+void k_pair_mask(PairArgs a)
 {
     typedef SrcBlockInvT<kDepth> SrcBlockInv;
     typedef TgtBlockInvT<kDepth> TgtBlockInv;
@@ -460,7 +467,14 @@ __global__ __launch_bounds__(256) void k_tgt_rays(const RayJob* __restrict__ job
 // Stage 1c.  One wave per (src segment, tbm camera) row: the row's set bits are enumerated in
 // ascending target order, 64 at a time with all lanes busy, and the depth record of each is written
 // to slot row_start + rank -> candidates come out sorted (seg, cam, tgt) with no sort pass.
-__global__ __launch_bounds__(256) void k_pair_fill(PairArgs a, const int* __restrict__ row_start,
+#ifndef L3D_PF_WAVES
+#define L3D_PF_WAVES 0
+#endif
+__global__ __launch_bounds__(256)
+#if L3D_PF_WAVES
+__attribute__((amdgpu_waves_per_eu(L3D_PF_WAVES, L3D_PF_WAVES)))
+#endif
+void k_pair_fill(PairArgs a, const int* __restrict__ row_start,
                                                    uint2* __restrict__ cand_meta, float4* __restrict__ cand_depths)
 {
     __shared__ unsigned long long s_words[4][kMaxW64];
