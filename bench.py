@@ -201,7 +201,8 @@ def main():
 
     # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
     # nobody is left waiting in a collective)
-    MODES = ["native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream",
+    MODES = ["native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream, "
+             "matchViews' products built on every rank's device from the gathered slots (no host bookkeeping)",
              "resident chain, source segments sharded, all-gather of per-view kept slots through torch.distributed on the library's stream",
              "per-view seam call, source segments sharded, all-gather of kept lists through the host"]
     sharded_mode = {"i": 0, "link": None}
@@ -219,8 +220,8 @@ def main():
             sharded_mode["i"] = max(sharded_mode["i"], int(os.environ["L3D_BENCH_MODE"]))
 
     def step_once(mode):
-        if mode == 0:       # rank 0 trails behind with the host bookkeeping; the other ranks only feed the collectives
-            l3dist.match_views_chain_native(l3d, rank, world, sharded_mode["link"], commit=(rank == 0),
+        if mode == 0:       # no rank hands lists to the host: every rank builds matchViews' products on its device from the gathered slots
+            l3dist.match_views_chain_native(l3d, rank, world, sharded_mode["link"], commit="device",
                                             n_segments=args.segments, n_neighbors=args.neighbors)
         elif mode == 1:
             l3dist.match_views_chain_sharded(l3d, rank, world, dist, commit=(rank == 0),

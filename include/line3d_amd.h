@@ -333,6 +333,11 @@ const void* l3d_shard_chain_gathered(l3d_shard_chain* chain);   /* device addres
  * overflow bits (1 candidate capacity, 2 slot_records, 4 a rank gave up) and the largest candidate / kept count one rank
  * reported for one view -- what a caller needs to reopen with more room (l3d_set_chain_capacities sets the candidate capacity
  * of the next chain); l3d_line3d_shard_run does exactly that, up to three times. */
+/* matchViews' products (as l3d_match_chain_resident leaves them: potential correspondences, best matches, medians; line3D.cc:834-884)
+ * built on THIS rank's device from the gathered slots of a finished l3d_shard_chain_run -- every rank holds every view's kept records,
+ * so no rank has to hand lists to the host (cb == NULL on all ranks).  The context then serves l3d_chain_kept_list,
+ * l3d_chain_products_get, l3d_products_hypotheses, l3d_affinity_fill_resident as after the single-GPU chain. */
+int l3d_shard_chain_products(l3d_shard_chain* chain, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot);
 int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept);
 
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
@@ -434,7 +439,10 @@ int l3d_line3d_shard_enqueue(l3d_line3d* h, int k, void* send_slot, const void* 
 int l3d_line3d_shard_mark(l3d_line3d* h, int k);
 int l3d_line3d_shard_fetch(l3d_line3d* h, int k);
 int l3d_line3d_shard_close(l3d_line3d* h, int committed);
-/* open -> run -> close in one call (l3d_shard_chain_run); commit != 0: this rank does the host bookkeeping.
+/* open -> run -> close in one call (l3d_shard_chain_run); commit: 0 = this rank only computes and exchanges; 1 = it also does the
+ * host bookkeeping (kept lists handed to the host view by view: the round-2 protocol, one rank of the job); 2 = it builds matchViews'
+ * products on its device from the gathered slots (l3d_shard_chain_products) -- any number of ranks, no list leaves the device, the
+ * rest of compute3Dmodel runs on the resident tables as after the single-GPU chain.
  * gathered_out (optional) receives the device address of the gathered blocks (valid until the next chain) */
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);

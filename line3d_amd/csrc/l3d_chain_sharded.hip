@@ -11,7 +11,8 @@
 // framework enqueues the collective on the same stream, the host trails behind on events (l3d_shard_chain_fetch).
 // The concatenation of the ranks' kept lists in rank order is the sorted list of the unsharded run, bit for bit.
 //
-// slot layout: [SlotHeader 32 B][best depth pairs float2 x seg_cap][kept records l3d_match x slot_records]
+// slot layout: [SlotHeader 32 B][best depth pairs float2 x seg_cap][position of every segment's best kept match int x seg_cap][kept records
+// l3d_match x slot_records]
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -23,6 +24,7 @@
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
 #include "l3d_chain_common.hpp"
+#include "l3d_products.hpp"
 
 using namespace l3d;
 
@@ -43,7 +45,7 @@ namespace l3d {
 struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
 static_assert(sizeof(SlotHeader) == 32, "slot header");
 
-struct SlotGeom { size_t slot_bytes, best_off, rec_off; int seg_cap, slot_records, world; };
+struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off; int seg_cap, slot_records, world; };
 
 // reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
 // (blockIdx.y = source * world + rank)
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
 {
     __shared__ int s_red[8];
     __shared__ int s_cnt[32];
+    __shared__ unsigned long long s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
     const int yl = blockIdx.x;
@@ -130,8 +133,9 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     if (yl >= nseg) return;                                  // (an empty range still launches workgroup 0 for the header)
     const int y = a.seg_begin + yl;
     if (tid == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
-    if (h.overflow) return;
-    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt);
+    int* bpos = reinterpret_cast<int*>(slot + g.bpos_off) + yl;              // (position in this slot's records; -1: the segment kept nothing)
+    if (h.overflow) { if (tid == 0) *bpos = -1; return; }
+    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best);
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -171,6 +175,49 @@ __global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restri
     const float4* src = reinterpret_cast<const float4*>(slot + g.rec_off);
     float4* dst = reinterpret_cast<float4*>(o_rec + (size_t)base * sizeof(Match));
     for (int i = tid; i < 2 * n; i += nt) dst[i] = src[i];
+}
+
+// ---- matchViews' products from the gathered slots (l3d_shard_chain_products): every rank holds every view's kept records, so every
+// rank can build what the single-GPU chain builds from its kept arena -- no rank hands lists to the host.
+// per view: kept matches and candidates summed over the ranks' slots
+__global__ void k_shard_totals(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int2* __restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_views) return;
+    int n = 0; long long R = 0;
+    if (verified[k])
+        for (int r = 0; r < g.world; ++r) {
+            const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(G + ((size_t)k * g.world + r) * g.slot_bytes);
+            n += hd->overflow ? 0 : hd->n_kept; R += hd->R;
+        }
+    out[k] = make_int2(n, (int)min(R, 0x7fffffffll));
+}
+// all views' slots -> ONE kept arena (views back to back, ranks in segment order: the sorted list of the unsharded run) + the whole
+// view's best depth pairs and best positions (relative to the view's slice).  grid (x, rank, view).
+__global__ __launch_bounds__(256) void k_shard_pack_all(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified,
+                                                        const int* __restrict__ kept_base, const long long* __restrict__ best_off, Match* __restrict__ arena,
+                                                        float2* __restrict__ best_all, int* __restrict__ bestpos_all)
+{
+    const int k = blockIdx.z, r = blockIdx.y;
+    if (!verified[k]) return;
+    const unsigned char* block = G + (size_t)k * g.world * g.slot_bytes;
+    int base = 0;
+    for (int q = 0; q < r; ++q) { const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(block + (size_t)q * g.slot_bytes); base += hq->overflow ? 0 : hq->n_kept; }
+    const unsigned char* slot = block + (size_t)r * g.slot_bytes;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    const int n = hd->overflow ? 0 : hd->n_kept;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const float4* src = reinterpret_cast<const float4*>(slot + g.rec_off);
+    float4* dst = reinterpret_cast<float4*>(arena + (size_t)kept_base[k] + base);
+    for (int i = tid; i < 2 * n; i += nt) dst[i] = src[i];
+    const float2* sb = reinterpret_cast<const float2*>(slot + g.best_off);
+    const int* sp = reinterpret_cast<const int*>(slot + g.bpos_off);
+    for (int i = tid; i < hd->s1 - hd->s0; i += nt) {
+        const long long o = best_off[k] + hd->s0 + i;
+        best_all[o] = sb[i];
+        const int p = sp[i];
+        bestpos_all[o] = p < 0 || n == 0 ? -1 : base + p;
+    }
 }
 
 // After the last exchange: the OR of the overflow bits of every gathered slot header (1 candidate capacity, 2 slot records,
@@ -260,7 +307,8 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     h->geom.seg_cap = (h->maxS + world - 1) / world + 1;
     h->geom.slot_records = slot_records;
     h->geom.best_off = sizeof(SlotHeader);
-    h->geom.rec_off = salign(h->geom.best_off + (size_t)h->geom.seg_cap * 8, 32);
+    h->geom.bpos_off = h->geom.best_off + (size_t)h->geom.seg_cap * 8;
+    h->geom.rec_off = salign(h->geom.bpos_off + (size_t)h->geom.seg_cap * 4, 32);
     h->geom.slot_bytes = salign(h->geom.rec_off + (size_t)slot_records * sizeof(Match), 256);
     *slot_bytes = h->geom.slot_bytes;
 
@@ -268,7 +316,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
 #define OCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(L3D_ERR_HIP); } } while (0)
     // tables, target rays, per-view slices of the whole-run arenas (l3d_chain_common.hip: shared with the single-GPU chain)
     { int rc = chain_upload_tables(c, views, n_views, h->vd, L, true, st); if (rc) return bail(rc); }
-    { int rc = chain_assign_arenas(c, views, n_views, h->vd, L, false, false, st); if (rc) return bail(rc); }
+    { int rc = chain_assign_arenas(c, views, n_views, h->vd, L, false, true, st); if (rc) return bail(rc); }   // (+ best positions: l3d_shard_chain_products)
     h->dtab = L.dtab;
     OCHK(c->ch_pin_res.reserve((size_t)n_views * 8 + 64));
     h->hstats = c->ch_pin_res.as<int>();
@@ -670,6 +718,61 @@ int l3d_shard_chain_info(l3d_shard_chain* h, size_t* cand_cap, int* slot_records
     if (max_candidates) *max_candidates = h->outcome[1];
     if (max_kept) *max_kept = h->outcome[2];
     return L3D_OK;
+}
+
+// What matchViews leaves behind (l3d_match_chain_resident's products: potential correspondences, best matches, medians), built on THIS
+// rank's device from the gathered slots of a finished, successful l3d_shard_chain_run: all views' kept records go into one arena in the
+// order of the unsharded run, then the very builder of the single-GPU chain runs on it.  Every rank may call it (each then holds the
+// full products and can run greedy selection / affinity fill / clustering); none hands a kept list to the host.
+int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot)
+{
+    if (!h) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    if (!map || !summary) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: bad argument");
+    if (!h->gathered || h->outcome[0]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: no finished run without overflow on this chain");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int nv = h->n_views;
+    const size_t nvs = (size_t)nv;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // scratch: verified flags | totals int2 | kept_base int | best_off i64
+    const size_t o_ver = 0, o_tot = al(nvs), o_kb = o_tot + al(nvs * 8), o_bo = o_kb + al(nvs * 4), bytes = o_bo + al(nvs * 8);
+    HIPCHK(c, c->g7.reserve(bytes + 64));
+    unsigned char* sc = c->g7.as<unsigned char>();
+    std::vector<unsigned char> ver(nvs);
+    for (int k = 0; k < nv; ++k) ver[(size_t)k] = h->vd[(size_t)k].verified ? 1 : 0;
+    HIPCHK(c, hipMemcpyAsync(sc + o_ver, ver.data(), nvs, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_shard_totals, dim3((nv + 255) / 256), dim3(256), 0, st, h->gathered, h->geom, sc + o_ver, nv, reinterpret_cast<int2*>(sc + o_tot));
+    std::vector<int2> tot(nvs);
+    HIPCHK(c, hipMemcpyAsync(tot.data(), sc + o_tot, nvs * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<ChainResult> hres(nvs);
+    std::vector<ProdChainView> pvh(nvs);
+    std::vector<int> kept_base(nvs, 0);
+    std::vector<long long> best_off(nvs, 0);
+    long long total = 0;
+    for (int k = 0; k < nv; ++k) {
+        const SViewDev& d = h->vd[(size_t)k];
+        ChainResult& r = hres[(size_t)k];
+        r.kept_base = (int)total; r.n_kept = d.verified ? tot[(size_t)k].x : 0; r.R = d.verified ? tot[(size_t)k].y : 0; r.overflow = 0;
+        kept_base[(size_t)k] = (int)total;
+        total += r.n_kept;
+        if (total > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_products: more than 2^31 kept matches");
+        best_off[(size_t)k] = d.verified ? (long long)(d.best - c->ch_best.as<float2>()) : 0;
+        pvh[(size_t)k].verified = d.verified ? 1 : 0;
+        pvh[(size_t)k].best = d.verified ? d.best : nullptr;
+        pvh[(size_t)k].bestpos = d.verified ? d.bestpos : nullptr;
+    }
+    HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
+    HIPCHK(c, hipMemcpyAsync(sc + o_kb, kept_base.data(), nvs * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(sc + o_bo, best_off.data(), nvs * 8, hipMemcpyHostToDevice, st));
+    if (nv > 0)
+        hipLaunchKernelGGL(k_shard_pack_all, dim3(8, h->world, nv), dim3(256), 0, st, h->gathered, h->geom, sc + o_ver, reinterpret_cast<const int*>(sc + o_kb),
+                           reinterpret_cast<const long long*>(sc + o_bo), c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>());
+    HIPCHK(c, hipStreamSynchronize(st));                                 // (the upload sources above are locals)
+    HIPCHK(c, hipGetLastError());
+    h->kept_total = (double)total;
+    return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot);
 }
 
 int l3d_shard_chain_close(l3d_shard_chain* h)

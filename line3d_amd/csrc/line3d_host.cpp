@@ -1325,6 +1325,30 @@ int check_resident_products(L* h, ChainPlan& P)
 
 // Line3D::matchViews with nothing but a few scalars per view coming back: the chain runs resident, the products of
 // performMatching (potential_correspondences_, only-best stores, medians) are built on the device (l3d_products.hip)
+// the facade's side of products that were built on the device (h->chain_summary filled by the builder): medians, matched marks,
+// optional copies of the kept lists, the self-check of the tests
+int adopt_resident_products(L* h, ChainPlan& P)
+{
+    for (size_t k = 0; k < P.n; ++k) {
+        View& v = h->views[h->order[k]];
+        v.median_depth = h->chain_summary[k].median_depth;      // line3D.cc:835
+        h->stat_kept += h->chain_summary[k].n_kept;
+        mark_matched(h, v);                                     // line3D.cc:875-881
+    }
+    h->resident_products = true;
+    if (h->keep_view_matches) {
+        for (size_t k = 0; k < P.n; ++k) {
+            l3d_match* m = nullptr; int n = 0;
+            int rc = l3d_chain_kept_list(h->ctx, (int)k, &m, &n);
+            if (rc) return h->fail(rc, std::string("kept_list: ") + l3d_last_error(h->ctx));
+            h->view_matches[h->order[k]].assign(m, m + n);
+            l3d_free(m);
+        }
+    }
+    if (getenv("L3D_CHECK_POT")) { int rc = check_resident_products(h, P); if (rc) return rc; }
+    return L3D_OK;
+}
+
 int match_views_resident(L* h, ChainPlan& P, double t0)
 {
     std::vector<uint32_t> ids; std::vector<int32_t> base;
@@ -1338,23 +1362,8 @@ int match_views_resident(L* h, ChainPlan& P, double t0)
     h->t_gpu_call += now_s() - t1;
     if (rc == L3D_ERR_UNSUPPORTED) return rc;
     if (rc) return h->fail(rc, std::string("match_chain_resident: ") + l3d_last_error(h->ctx));
-    for (size_t k = 0; k < P.n; ++k) {
-        View& v = h->views[h->order[k]];
-        v.median_depth = h->chain_summary[k].median_depth;      // line3D.cc:835
-        h->stat_kept += h->chain_summary[k].n_kept;
-        mark_matched(h, v);                                     // line3D.cc:875-881
-    }
-    h->resident_products = true;
-    if (h->keep_view_matches) {
-        for (size_t k = 0; k < P.n; ++k) {
-            l3d_match* m = nullptr; int n = 0;
-            rc = l3d_chain_kept_list(h->ctx, (int)k, &m, &n);
-            if (rc) return h->fail(rc, std::string("kept_list: ") + l3d_last_error(h->ctx));
-            h->view_matches[h->order[k]].assign(m, m + n);
-            l3d_free(m);
-        }
-    }
-    if (getenv("L3D_CHECK_POT")) { rc = check_resident_products(h, P); if (rc) return rc; }
+    rc = adopt_resident_products(h, P);
+    if (rc) return rc;
     double st[4];
     l3d_last_stats(h->ctx, st);
     h->stat_pairs += st[0];
@@ -2403,14 +2412,26 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         if (rc) return rc;
         const double t1 = now_s();
         ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
-        rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, commit ? chain_callback : nullptr, commit ? &P->user : nullptr);
+        const bool host_commit = commit == 1;
+        rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, host_commit ? chain_callback : nullptr, host_commit ? &P->user : nullptr);
         std::string msg = rc ? std::string("shard_chain_run: ") + l3d_last_error(h->ctx) : std::string();
+        if (rc == L3D_OK && commit == 2) {
+            // commit on the device: this rank builds matchViews' products from the gathered slots (every rank may), no list goes to the host
+            std::vector<uint32_t> ids; std::vector<int32_t> base;
+            dense_map(h, ids, base);
+            l3d_dense_map map;
+            map.n_views = (int32_t)ids.size(); map.view_ids = ids.data(); map.seg_base = base.data();
+            h->chain_summary.assign(P->n, l3d_chain_summary());
+            rc = l3d_shard_chain_products(P->shard, &map, h->chain_summary.data(), &h->resident_n_pot);
+            if (rc) msg = std::string("shard_chain_products: ") + l3d_last_error(h->ctx);
+            else { rc = adopt_resident_products(h, *P); if (rc) msg = h->err; }
+        }
         size_t cand_cap = 0; int bits = 0, max_cand = 0, max_kept = 0, recs = slot_records;
         l3d_shard_chain_info(P->shard, &cand_cap, &recs, &bits, &max_cand, &max_kept);
         if (gathered_out) *gathered_out = l3d_shard_chain_gathered(P->shard);
         if (slot_bytes_out) *slot_bytes_out = slot_bytes;
         const double t2 = now_s();
-        const int rc2 = l3d_line3d_shard_close(h, commit != 0 && rc == L3D_OK);
+        const int rc2 = l3d_line3d_shard_close(h, commit == 1 && rc == L3D_OK);
         if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
                                           (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
         if (rc == L3D_OK) return rc2;

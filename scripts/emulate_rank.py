@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ahead", type=int, default=12)
     ap.add_argument("--no-commit", action="store_true", help="rank 0 without the host hand-over (what a non-committing rank with this range would take)")
+    ap.add_argument("--device-commit", action="store_true", help="the replayed rank builds matchViews' products on its device from the gathered slots (no host hand-over)")
     args = ap.parse_args()
     import torch
     from line3d_amd.pipeline import Line3D, load_scene
@@ -72,7 +73,7 @@ def main():
     for rep in range(args.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(), commit=(R == 0 and not args.no_commit))
+        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(), commit=("device" if args.device_commit else (R == 0 and not args.no_commit)))
         dt = time.perf_counter() - t0
         if rep:
             print("world %d rank %d: %d views x %d segs: %.2f ms (%.1f us/view), kept %d (recorded %d), slot %d KB"

@@ -119,7 +119,7 @@ def test_config3_512_views_chain_equals_eight_virtual_ranks():
     ls = []
     for r in range(W):
         lr = Line3D("", matchingNeighbors=N, useCollinearity=False)
-        lr.keep_view_matches(r == 0)
+        lr.keep_view_matches(r in (0, 3))
         load_scene(lr, scene)
         lr.prepare()
         ls.append(lr)
@@ -141,11 +141,14 @@ def test_config3_512_views_chain_equals_eight_virtual_ranks():
     for lr in ls:
         lr.shard_close(False)
     del send
-    # every rank replays its part through the native loop (l3d_shard_chain_run) against the recorded blocks; rank 0 commits
+    # ranks replay their part through the native loop (l3d_shard_chain_run) against the recorded blocks; rank 0 commits on the host
+    # (kept lists handed over view by view), rank 3 on its device (matchViews' products built from the gathered slots)
     for r in (W - 1, 3, 0):
-        ls[r].shard_run(r, W, slot, "replay", gathered.data_ptr(), commit=(r == 0))
+        ls[r].shard_run(r, W, slot, "replay", gathered.data_ptr(), commit=("device" if r == 3 else r == 0))
         torch.cuda.synchronize()
     assert digest_lists({v["id"]: ls[0].view_matches(v["id"]) for v in scene.views}) == ref
+    assert digest_lists({v["id"]: ls[3].view_matches(v["id"]) for v in scene.views}) == ref
+    assert ls[3].resident_products() is not None and ls[0].resident_products() is None
     for lr in ls:
         lr.close()
 

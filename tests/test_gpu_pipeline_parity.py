@@ -702,3 +702,67 @@ def test_finish_on_the_device_and_on_the_host_agree(small_scene, small_oracle, m
         l.close()
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 0
     assert outs[0][1] == outs[1][1] and len(outs[0][1]) > 0
+
+
+def _products_digest(l):
+    p = l.resident_products()
+    assert p is not None
+    return {k: np.ascontiguousarray(p[k]).tobytes() for k in ("seg_base", "pot_start", "pot_tgt", "best", "hyp", "score")}
+
+
+def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, monkeypatch):
+    """commit="device": the sharded run hands no kept list to the host -- every rank builds matchViews' products on its device from the
+    gathered slots (l3d_shard_chain_products).  World 1 (local exchange) and every rank of a recorded world-3 job (replay): kept lists,
+    medians and lines equal to the oracle's, the products (potential correspondences, best matches, hypotheses) byte-equal to the
+    single-GPU chain's; the device products are also compared with the plain host construction (L3D_CHECK_POT)."""
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    monkeypatch.setenv("L3D_CHECK_POT", "1")
+    ref = Line3D("", matchingNeighbors=6)
+    load_scene(ref, small_scene)
+    ref.compute3Dmodel(False)
+    want = _products_digest(ref)
+    ref.close()
+    # world 1
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.prepare()
+    l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=300, n_neighbors=6)
+    _check_against_oracle(l, small_oracle)
+    assert _products_digest(l) == want
+    l.close()
+    # world 3: record with virtual ranks, then every rank replays its part and commits on its device
+    W, SLOT = 3, 4096
+    dev = torch.device("cuda", 0)
+    ls = []
+    for r in range(W):
+        q = Line3D("", matchingNeighbors=6)
+        q.keep_view_matches(True)
+        load_scene(q, small_scene)
+        q.prepare()
+        ls.append(q)
+    n_views, slot_bytes = [q.shard_open(r, W, SLOT) for r, q in enumerate(ls)][0]
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, q in enumerate(ls):
+            q.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for q in ls:
+            q.shard_mark(k)
+    for q in ls:
+        q.shard_close(False)
+    recorded = gathered.clone()
+    for r, q in enumerate(ls):
+        q.shard_run(r, W, SLOT, "replay", recorded.data_ptr(), commit="device")
+        torch.cuda.synchronize()
+        _check_against_oracle(q, small_oracle)
+        assert _products_digest(q) == want, "rank %d" % r
+        q.close()
