@@ -7,8 +7,9 @@ host bookkeeping) on synthetic helix scenes.
 
 A "step" is one full matchViews pass over the scene.  Workload: BASELINE.json configs[1] per GPU --
 64*N views x 2000 segments, 12 neighbours (N=1: config 2 itself; N=8: config 3) -> weak scaling.
-For N>1 every rank holds the whole (replicated) host state, computes a 1/N source-segment range of each
-view on its GPU and the per-view kept lists are all-gathered over RCCL before the (replicated) commit.
+For N>1 every rank holds the scene, computes a 1/N source-segment range of each view on its GPU, the per-view
+kept lists are all-gathered over RCCL, and every rank builds matchViews' products on its device from the gathered
+slots (no rank hands lists to the host).
 Prints ONE JSON line on rank 0.
 """
 import argparse
