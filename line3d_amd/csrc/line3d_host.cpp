@@ -1739,19 +1739,27 @@ int fill_affinity_resident(L* h)
     std::vector<size_t> voff(nv + 1, 0);
     for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
     L::AffTables& T = h->aff;
+    const bool timing = getenv("L3D_TIMING") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish]   fill: %-22s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
     const bool changed = !T.coll_valid || T.coll_start.size() != voff.back() + 1;
     if (changed) pack_collinearities(h, voff);
+    lap("collinearity tables");
     l3d_edge* edges = nullptr; int32_t* node_hyp = nullptr; int n_edges = 0, n_nodes = 0, n_cand = 0;
     // (the list itself stays on the device, where the clustering walks it; l3d_line3d_affinity fetches it when somebody asks)
     int rc = l3d_affinity_fill_resident(h->ctx, T.coll_start.data(), T.coll_other.data(), T.coll_w.data(), changed ? 1 : 0, h->sigma_a, nullptr, &n_edges, &node_hyp, &n_nodes, &n_cand);
     if (rc) return h->fail(rc, std::string("affinity fill: ") + l3d_last_error(h->ctx));
+    lap("device");
     T.coll_valid = true;
     h->A.clear(); h->n_edges = (size_t)n_edges; h->A_on_host = n_edges == 0;
     h->local2global.resize((size_t)n_nodes);
-    for (int k = 0; k < n_nodes; ++k) h->local2global[(size_t)k] = h->hyps[(size_t)node_hyp[k]].src;
-    h->node_hyp.assign(node_hyp, node_hyp + n_nodes);
+    h->node_hyp.resize((size_t)n_nodes);
+    parallel_slices((size_t)n_nodes, finish_threads(), [&](size_t k0, size_t k1, unsigned) {     // (a gather over the hypothesis table: 0.5 M nodes at 512 views)
+        for (size_t k = k0; k < k1; ++k) { h->node_hyp[k] = node_hyp[k]; h->local2global[k] = h->hyps[(size_t)node_hyp[k]].src; }
+    });
     l3d_free(edges); l3d_free(node_hyp);
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges (resident tables)\n", h->hyps.size(), n_cand, h->n_edges);
+    lap("node table");
+    if (timing) fprintf(stderr, "[l3d finish] %zu hypotheses, %d candidate pairs, %zu edges (resident tables)\n", h->hyps.size(), n_cand, h->n_edges);
     return L3D_OK;
 }
 
@@ -1955,7 +1963,10 @@ int cluster_segments_2D(L* h, bool perform_diff)
                 for (int32_t i = gstart[v]; i < gstart[v + 1]; ++i) fl.segs2D.push_back(h->hyps[(size_t)memb[(size_t)i]].src);
             }
         });
+        size_t n_lines = 0;
+        for (int v = 0; v < n_groups; ++v) n_lines += cnt[v] != 0;
         l3d_free(gstart); l3d_free(memb); l3d_free(cnt); l3d_free(segs);
+        h->result.reserve(n_lines);
         for (FinalLine& fl : fitted) if (!fl.segs3D.empty()) h->result.push_back(std::move(fl));
         lap("line fit");
         h->t_cluster = now_s() - t1;
