@@ -254,6 +254,9 @@ __device__ __forceinline__ void uf_component_walk(const l3d_edge* __restrict__ E
                     else { cid[a] = b; size[b] += size[a]; if (rnk[a] == rnk[b]) rnk[b]++; a = b; }
                     thr[a] = w + c / (float)size[a];
                 }
+                // the list holds every edge in both directions and the stable order keeps the two together: whatever the first one did
+                // (merged, found merged, failed a threshold), the reversed twin right behind it meets the same state and changes nothing
+                if (q2 + 1 < cnt && s_ei[q2 + 1] == s_ej[q2] && s_ej[q2 + 1] == s_ei[q2] && s_ew[q2 + 1] == w) ++q2;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
