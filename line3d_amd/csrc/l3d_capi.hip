@@ -211,6 +211,12 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
         { &c->g1, (nd + 2) * 16 + (size_t)n_views * 4 + 1024 }, { &c->g2, n_items * 8 }, { &c->g3, n_items * 8 }, { &c->g4, n_items * 4 },
         { &c->g5, (nd * 2 + n_items * 6 + 8) * 4 }, { &c->g6, n_edges * 2 * sizeof(l3d_edge) + nd * 4 }, { &c->g7, n_edges * 16 + (1u << 20) }, { &c->g0, n_edges * 2 * sizeof(l3d_edge) * 2 },
     };
+    bool grows = false;
+    for (const R& r : rs) grows = grows || r.b->cap < r.bytes + 256;
+    if (grows) {        // a growing arena is reallocated: whatever an earlier stage left resident in these buffers is gone
+        c->resident_edges = 0; c->resident_nodes = 0; c->resident_labels = 0; c->resident_hyp = 0;
+        P.valid = false; P.hyp_valid = false;
+    }
     for (const R& r : rs) HIPCHK(c, r.b->reserve(r.bytes + 256));
     return L3D_OK;
 }
@@ -537,7 +543,7 @@ int l3d_compute_collinearity(l3d_ctx* c, const float* segments, int S, float col
     if (n == 0) return L3D_OK;
     HIPCHK(c, c->g4.reserve((size_t)n * 4));
     HIPCHK(c, c->g5.reserve((size_t)n * 4));
-    c->resident_edges = 0; c->resident_nodes = 0;   // (g6 is reused)
+    c->resident_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;   // (g4 and g6 are reused)
     HIPCHK(c, c->g6.reserve((size_t)n * 4));
     { ProfScope p(c, "collinearity_fill");
       launch_collinearity_fill(d_segs, S, sigma_sqr, c->g1.as<unsigned long long>(), W64, c->g3.as<int>(), c->g4.as<int>(), c->g5.as<int>(), c->g6.as<float>(), st); }
@@ -632,7 +638,7 @@ int l3d_compute_collinearity_batch(l3d_ctx* c, const float* const* segments, con
     const size_t n = (size_t)total;
     HIPCHK(c, c->g4.reserve(n * 4));
     HIPCHK(c, c->g5.reserve(n * 4));
-    c->resident_edges = 0; c->resident_nodes = 0;   // (g6 is reused)
+    c->resident_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;   // (g4 and g6 are reused)
     HIPCHK(c, c->g6.reserve(n * 4));
     for (int v = 0; v < n_sets; ++v) {
         const Set& q = sets[(size_t)v];
