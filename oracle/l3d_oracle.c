@@ -15,10 +15,15 @@
  *     cudawrapper.h:43-46, against the genuine NVIDIA runtime headers of the triton wheel (target `ref_devfn`,
  *     oracle/make_ref_devfn.py): bit-equal on 10^6 random and adversarial inputs per function, live and as committed
  *     golden vectors (tests/test_oracle_pins.py, tests/golden/devfn_ref.npz); the angle function bit-equal in the libm
- *     build, within 3e-5 degrees in the contract build (acosf is the one transcendental in it).
+ *     build, within 3e-5 degrees in the contract build (acosf is the one transcendental in it);
+ *   - the two kernels of replicator_dynamics_diffusion, K_sparseMat_row_normalization and K_sparseMat_diffusion_step
+ *     (cudawrapper.cu:717-829; texture-free, every thread independent), compiled the same way (their launch variables, declared by
+ *     the genuine <device_launch_parameters.h>, get their storage from oracle/ref_devfn_launch.cc): l3do_rdd_hooked runs them
+ *     inside this file's restatement of the host loop -- bit-equal with l3do_rdd, live and as committed vectors
+ *     (tests/golden/rdd_ref.npz).
  * Still "parity unpinned" by the reference, pinned by restatement, analytic known-answer scenes and committed vectors
  * only: everything that reads textures (D_epipolar_line, D_get_ray_tgt, D_get_triangulation_depth, D_project_point_tgt,
- * D_hypothesis_confidence, the five kernels), the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc,
+ * D_hypothesis_confidence, the three matching kernels), the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc,
  * view.cc and line3D.cc -- they need CUDA texture references, boost, Eigen or OpenCV, which this image lacks; building
  * them would take stand-in headers, so they are treated as unbuildable.  The reference has no tests, golden vectors
  * or fixtures of its own.
@@ -729,8 +734,20 @@ static void diffusion_step(const f4* P, const f4* W, const int* P_rows, const in
  * performDiffusion (line3D.cc:1258: SparseMatrix(A, n) = column-sorted).  in: edges in the
  * order of the list A; out: entries of the returned W (= P after the last swap, row-sorted),
  * as (i,j,w), nnz of them.  iters = L3D_RDD_MAX_ITER in the reference. */
-void l3do_rdd(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out)
+/* The same with the two kernels handed in: tests/test_oracle_pins.py passes the reference's OWN K_sparseMat_row_normalization /
+ * K_sparseMat_diffusion_step (oracle/_ref/libdevfn_ref.so: compiled from cudawrapper.cu:717-829) and requires the result of
+ * l3do_rdd bit for bit.  NULL = the restatements above.  float4 records as plain floats. */
+typedef void (*l3do_norm_fn)(float* data, const int* start_indices, int num_rows, int num_entries);
+typedef void (*l3do_step_fn)(const float* P, const float* W, const int* P_rows, const int* W_cols, float* P_prime, const int* P_prime_rows, int num_entries);
+static void norm_default(float* data, const int* s, int nr, int ne) { row_normalization((f4*)data, s, nr, ne); }
+static void step_default(const float* P, const float* W, const int* Pr, const int* Wc, float* Pp, const int* Ppr, int ne)
+{ diffusion_step((const f4*)P, (const f4*)W, Pr, Wc, (f4*)Pp, Ppr, ne); }
+void l3do_rdd_hooked(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out, l3do_norm_fn norm, l3do_step_fn step);
+void l3do_rdd(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out) { l3do_rdd_hooked(A, nnz, n, iters, out, 0, 0); }
+void l3do_rdd_hooked(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out, l3do_norm_fn norm, l3do_step_fn step)
 {
+    if (!norm) norm = norm_default;
+    if (!step) step = step_default;
     l3do_edge* col = (l3do_edge*)malloc((size_t)nnz * sizeof(l3do_edge));
     memcpy(col, A, (size_t)nnz * sizeof(l3do_edge));
     stable_sort_edges(col, nnz, 0);
@@ -749,13 +766,13 @@ void l3do_rdd(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out)
     memcpy(Pp, P, (size_t)nnz * sizeof(f4));
     memcpy(Pp_rows, P_rows, (size_t)n * sizeof(int));
 
-    row_normalization(P, P_rows, n, nnz);
+    norm((float*)P, P_rows, n, nnz);
     for (int it = 0; it < iters; ++it) {
-        diffusion_step(P, W, P_rows, W_cols, Pp, Pp_rows, nnz);
+        step((const float*)P, (const float*)W, P_rows, W_cols, (float*)Pp, Pp_rows, nnz);
         f4* t = P; P = Pp; Pp = t;
         int* ti = P_rows; P_rows = Pp_rows; Pp_rows = ti;
         if (it < iters - 1)
-            row_normalization(P, P_rows, n, nnz);
+            norm((float*)P, P_rows, n, nnz);
     }
     for (int k = 0; k < nnz; ++k) {
         out[k].i = (int)P[k].x; out[k].j = (int)P[k].y; out[k].w = P[k].z;

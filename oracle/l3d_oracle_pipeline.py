@@ -143,6 +143,18 @@ def rdd(lib, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
     return out
 
 
+def rdd_hooked(lib, ref, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
+    """l3do_rdd_hooked with the two kernels of `ref` (oracle/_ref/libdevfn_ref.so: the reference's own K_sparseMat_row_normalization and
+    K_sparseMat_diffusion_step, cudawrapper.cu:717-829) in place of the oracle's restatements."""
+    edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    out = np.zeros(len(edges), dtype=EDGE_DTYPE)
+    norm = C.cast(ref.l3dref_sparse_row_normalization, C.c_void_p)
+    step = C.cast(ref.l3dref_sparse_diffusion_step, C.c_void_p)
+    lib.l3do_rdd_hooked(edges.ctypes.data_as(C.POINTER(Edge)), C.c_int(len(edges)), C.c_int(n), C.c_int(iters),
+                        out.ctypes.data_as(C.POINTER(Edge)), norm, step)
+    return out
+
+
 def clustering(lib, edges: np.ndarray, num_nodes: int, c: float = 1.0) -> np.ndarray:
     edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
     labels = np.zeros(num_nodes, dtype=np.int32)

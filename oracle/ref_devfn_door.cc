@@ -47,6 +47,26 @@ void l3dref_cross3(int n, const float* a, const float* b, float* out) { for (int
 void l3dref_length3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) out[i] = length(ld3(v, i)); }
 void l3dref_dot3(int n, const float* a, const float* b, float* out) { for (int i = 0; i < n; ++i) out[i] = dot(ld3(a, i), ld3(b, i)); }
 
+// cudawrapper.cu:717-762 and :765-829 -- the two kernels of replicator_dynamics_diffusion (texture-free; every thread is independent:
+// no shared memory, no barrier), run one "thread" at a time over the grid the reference launches (x = 0, y = row / entry; the launch
+// variables: ref_devfn_launch.cc).  data / P / W / P_prime: float4 records (row, column, value, unused) as SparseMatrix keeps them.
+void l3dref_set_launch(unsigned block_x, unsigned block_y, unsigned thread_x, unsigned thread_y, unsigned dim_x, unsigned dim_y);
+void l3dref_sparse_row_normalization(float* data, const int* start_indices, int num_rows, int num_entries)
+{
+    for (int y = 0; y < num_rows; ++y) {
+        l3dref_set_launch(0, (unsigned)(y / 256), 0, (unsigned)(y % 256), 1, 256);     // dimBlock = (1, 16 * 16), cudawrapper.cu:1139
+        L3D::K_sparseMat_row_normalization(reinterpret_cast<float4*>(data), start_indices, num_rows, num_entries);
+    }
+}
+void l3dref_sparse_diffusion_step(const float* P, const float* W, const int* P_rows, const int* W_cols, float* P_prime, const int* P_prime_rows, int num_entries)
+{
+    for (int y = 0; y < num_entries; ++y) {
+        l3dref_set_launch(0, (unsigned)(y / 256), 0, (unsigned)(y % 256), 1, 256);
+        L3D::K_sparseMat_diffusion_step(reinterpret_cast<const float4*>(P), reinterpret_cast<const float4*>(W), P_rows, W_cols,
+                                        reinterpret_cast<float4*>(P_prime), P_prime_rows, num_entries);
+    }
+}
+
 // Which overloads does a HOST compiler pick for `acos(fmax(fmin(float, 1.0f), -1.0f))` (cudawrapper.cu:124)?  4 = float
 // (acosf: what nvcc's device code uses as well), 8 = double.  The numeric contract follows the float reading.
 int l3dref_sizeof_angle_acos(void) { return (int)sizeof(decltype(acos(fmax(fmin(1.0f, 1.0f), -1.0f)))); }

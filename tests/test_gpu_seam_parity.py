@@ -808,3 +808,16 @@ def test_fit_labelled_clusters_groups_like_process_clustered_segments(gpu_ctx):
         assert len(a) == len(b)
         for (s1, e1), (s2, e2) in zip(a, b):
             assert s1.tobytes() == s2.tobytes() and e1.tobytes() == e2.tobytes()
+
+
+def test_diffusion_equals_the_reference_kernels(gpu_ctx):
+    """l3d_replicator_dynamics_diffusion against tests/golden/rdd_ref.npz: results of the REFERENCE's own K_sparseMat_row_normalization /
+    K_sparseMat_diffusion_step (compiled from cudawrapper.cu:717-829, tests/golden/make_golden_rdd.py) -- bit for bit, 1 and 10 iterations,
+    symmetric and asymmetric values, ties, values under L3D_EPS_G."""
+    import rdd_cases as rc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rdd_ref.npz"))
+    for k, case in enumerate(rc.CASES):
+        A = rc.make_list(**case)
+        assert A.tobytes() == g["c%d_in" % k].tobytes()
+        for iters in (1, 10):
+            assert gpu_ctx.replicator_dynamics_diffusion(A, case["n"], iters).tobytes() == g["c%d_it%d" % (k, iters)].tobytes(), (k, iters)

@@ -296,3 +296,39 @@ def test_device_functions_match_reference_live():
             got = dc.run(op.load_lib(libm=libm), "l3do_devfn_", cases)
             for name in exp:
                 _check_devfn(got[name][1], exp[name][1], name, libm)
+
+
+# ---- the two kernels of replicator_dynamics_diffusion, pinned to the reference's own code -----------------------------------------
+# K_sparseMat_row_normalization and K_sparseMat_diffusion_step (cudawrapper.cu:717-829) are texture-free and every thread is
+# independent: oracle/_ref/libdevfn_ref.so holds them compiled from the reference's text (their launch variables get storage from
+# oracle/ref_devfn_launch.cc); l3do_rdd_hooked runs the oracle's restatement of the host orchestration (sparsematrix.cc sort orders and
+# start indices, the loop of cudawrapper.cu:1131-1191) with those kernels in place of its own.
+def test_rdd_kernels_match_reference_golden(oracle_lib):
+    import rdd_cases as rc
+    g = np.load(os.path.join(HERE, "golden", "rdd_ref.npz"))
+    n_entries = 0
+    for k, case in enumerate(rc.CASES):
+        A = rc.make_list(**case)
+        assert A.tobytes() == g["c%d_in" % k].tobytes(), k              # the committed inputs are the ones the generator makes
+        for iters in (1, 10):
+            W = op.rdd(oracle_lib, A, case["n"], iters)
+            assert W.tobytes() == g["c%d_it%d" % (k, iters)].tobytes(), (k, iters)
+        n_entries += len(A)
+        assert len(np.unique(W["w"])) > len(A) // 8                      # (a real diffusion result, not a constant)
+    assert n_entries > 20000
+
+
+def test_rdd_kernels_match_reference_live(oracle_lib):
+    """... and live, on more lists (the reference's kernels inside the oracle's loop against the oracle's own), 1 to 10 iterations."""
+    import rdd_cases as rc
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_sparse_diffusion_step"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so predates the sparse-matrix kernels")
+    for seed in range(20, 32):
+        n = 20 + 37 * (seed - 20)
+        A = rc.make_list(seed, n, 6 * n, symmetric_values=seed % 3 != 0, tiny=seed % 4 == 0)
+        for iters in (1, 2, 10):
+            assert op.rdd(oracle_lib, A, n, iters).tobytes() == op.rdd_hooked(oracle_lib, ref, A, n, iters).tobytes(), (seed, iters)
