@@ -657,6 +657,9 @@ static void stable_sort_edges(l3do_edge* e, size_t n, int mode /*0 col,1 row,2 w
     free(tmp);
 }
 
+/* (door for tests/test_oracle_pins.py: the order against the reference's own std::list::sort with its comparators) */
+void l3do_sort_edges(l3do_edge* e, int n, int mode) { stable_sort_edges(e, (size_t)(n > 0 ? n : 0), mode); }
+
 /* entries as float4 (row, col, val, 0) + start index per row/col (-1 if empty), sparsematrix.cc:99-131 */
 static void build_sparse(const l3do_edge* sorted, int nnz, int n, int by_row, f4* entries, int* start)
 {

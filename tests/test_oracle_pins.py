@@ -332,3 +332,26 @@ def test_rdd_kernels_match_reference_live(oracle_lib):
         A = rc.make_list(seed, n, 6 * n, symmetric_values=seed % 3 != 0, tiny=seed % 4 == 0)
         for iters in (1, 2, 10):
             assert op.rdd(oracle_lib, A, n, iters).tobytes() == op.rdd_hooked(oracle_lib, ref, A, n, iters).tobytes(), (seed, iters)
+
+
+def test_sparse_matrix_orders_match_reference_live(oracle_lib):
+    """The two orders SparseMatrix gives its entries (sparsematrix.cc:78-84: std::list::sort with clustering.h's sortCLEdgesByRow / ByCol) by
+    the reference's own comparators (oracle/_ref/libclustering_ref.so) against the oracle's stable merge sort -- with duplicate (i, j)
+    keys of different weights, where only a STABLE sort agrees."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libclustering_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libclustering_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_sort_cledges"):
+        pytest.skip("oracle/_ref/libclustering_ref.so predates the sort door")
+    rng = np.random.default_rng(5)
+    for n, E in ((5, 60), (40, 3000), (1000, 20000)):
+        ei = rng.integers(0, n, E).astype(np.int32); ej = rng.integers(0, n, E).astype(np.int32); ew = rng.random(E).astype(np.float32)
+        for by_row in (0, 1):
+            a, b, w = ei.copy(), ej.copy(), ew.copy()
+            ref.l3dref_sort_cledges(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), C.c_int(E), C.c_int(by_row))
+            e = np.zeros(E, dtype=op.EDGE_DTYPE)
+            e["i"], e["j"], e["w"] = ei, ej, ew
+            oracle_lib.l3do_sort_edges(e.ctypes.data_as(C.c_void_p), C.c_int(E), C.c_int(by_row))
+            assert np.array_equal(e["i"], a) and np.array_equal(e["j"], b) and e["w"].tobytes() == w.tobytes(), (n, by_row)
+            assert len(np.unique(np.stack([ei, ej]), axis=1).T) < E          # (duplicates are present)
