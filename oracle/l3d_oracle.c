@@ -20,10 +20,16 @@
  *     (cudawrapper.cu:717-829; texture-free, every thread independent), compiled the same way (their launch variables, declared by
  *     the genuine <device_launch_parameters.h>, get their storage from oracle/ref_devfn_launch.cc): l3do_rdd_hooked runs them
  *     inside this file's restatement of the host loop -- bit-equal with l3do_rdd, live and as committed vectors
- *     (tests/golden/rdd_ref.npz).
+ *     (tests/golden/rdd_ref.npz);
+ *   - three bodies BEHIND their texture fetches -- the reference's own lines compiled inside a function of ours whose parameters stand
+ *     for the fetched values (make_ref_devfn.py marks which lines are whose): D_hypothesis_confidence (:380-427 without the fetch :407 --
+ *     the whole scoring of stage 2: gate, 2-D distances, 3-D angle, two expf), the middle of K_pairwise_matches (:569-588: intersection
+ *     points, validity, overlaps against the thresholds -- the stage-1 decision), K_collinearity's body for one pair (:492-529): bit-equal
+ *     on 10^6 cases each (the two with transcendentals in the libm build; contract build within a few 1e-6, no decision flips seen).
  * Still "parity unpinned" by the reference, pinned by restatement, analytic known-answer scenes and committed vectors
- * only: everything that reads textures (D_epipolar_line, D_get_ray_tgt, D_get_triangulation_depth, D_project_point_tgt,
- * D_hypothesis_confidence, the three matching kernels), the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc,
+ * only: the three matrix-vector products that accumulate straight out of textures (D_epipolar_line, D_get_ray_tgt and with it
+ * D_get_triangulation_depth, D_project_point_tgt), the control flow of the kernels around them (per-camera maxima of K_verify_matches),
+ * the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc's index tables,
  * view.cc and line3D.cc -- they need CUDA texture references, boost, Eigen or OpenCV, which this image lacks; building
  * them would take stand-in headers, so they are treated as unbuildable.  The reference has no tests, golden vectors
  * or fixtures of its own.
@@ -241,6 +247,27 @@ static float hypothesis_confidence(f3 p1, f3 p2, f3 P1, f3 P2, f3 Q1, f3 Q2, f3 
 /* ------------------------------------------------------------------------- */
 /* K_collinearity, cudawrapper.cu:476-535 (+ compute_collinearity :833-855:
  * sigma passed squared).  relation is dense S x S, row-major. */
+/* the kernel's body for one pair of segments, cudawrapper.cu:492-529 behind the four texture fetches (pinned to the reference's own
+ * lines: tests/test_oracle_pins.py, `collinearity_pair`) */
+static float collinearity_pair(f3 p1, f3 p2, f3 q1, f3 q2, float coll_sigma_sqr)
+{
+    float result = 0.0f;
+    f3 line1 = cross3(p1, p2);
+    f3 line2 = cross3(q1, q2);
+    float d1 = fmaxf(distance_p2l_2D(line2, p1), distance_p2l_2D(line2, p2));
+    float d2 = fmaxf(distance_p2l_2D(line1, q1), distance_p2l_2D(line1, q2));
+    float d = fmaxf(d1, d2);
+    float aff = l3do_expf(-d * d / (2.0f * coll_sigma_sqr));
+    if (aff > COLLIN_AFF_T_G) {
+        float pos1 = dot2(q1.x - p1.x, q1.y - p1.y, q2.x - p1.x, q2.y - p1.y);
+        float pos2 = dot2(q1.x - p2.x, q1.y - p2.y, q2.x - p2.x, q2.y - p2.y);
+        float pos3 = dot2(p1.x - q1.x, p1.y - q1.y, p2.x - q1.x, p2.y - q1.y);
+        float pos4 = dot2(p1.x - q2.x, p1.y - q2.y, p2.x - q2.x, p2.y - q2.y);
+        if (pos1 > -EPS_G && pos2 > -EPS_G && pos3 > -EPS_G && pos4 > -EPS_G)
+            result = aff;
+    }
+    return result;
+}
 void l3do_collinearity(const float* segs, int S, float collin_s, float* relation)
 {
     float coll_sigma_sqr = collin_s * collin_s;
@@ -249,25 +276,11 @@ void l3do_collinearity(const float* segs, int S, float collin_s, float* relation
             if (x == y) {
                 relation[(size_t)y * S + x] = 0.0f;
             } else if (x < y) {
-                float result = 0.0f;
                 f3 p1 = mk3(segs[x * 4 + 0], segs[x * 4 + 1], 1.0f);
                 f3 p2 = mk3(segs[x * 4 + 2], segs[x * 4 + 3], 1.0f);
-                f3 line1 = cross3(p1, p2);
                 f3 q1 = mk3(segs[y * 4 + 0], segs[y * 4 + 1], 1.0f);
                 f3 q2 = mk3(segs[y * 4 + 2], segs[y * 4 + 3], 1.0f);
-                f3 line2 = cross3(q1, q2);
-                float d1 = fmaxf(distance_p2l_2D(line2, p1), distance_p2l_2D(line2, p2));
-                float d2 = fmaxf(distance_p2l_2D(line1, q1), distance_p2l_2D(line1, q2));
-                float d = fmaxf(d1, d2);
-                float aff = l3do_expf(-d * d / (2.0f * coll_sigma_sqr));
-                if (aff > COLLIN_AFF_T_G) {
-                    float pos1 = dot2(q1.x - p1.x, q1.y - p1.y, q2.x - p1.x, q2.y - p1.y);
-                    float pos2 = dot2(q1.x - p2.x, q1.y - p2.y, q2.x - p2.x, q2.y - p2.y);
-                    float pos3 = dot2(p1.x - q1.x, p1.y - q1.y, p2.x - q1.x, p2.y - q1.y);
-                    float pos4 = dot2(p1.x - q2.x, p1.y - q2.y, p2.x - q2.x, p2.y - q2.y);
-                    if (pos1 > -EPS_G && pos2 > -EPS_G && pos3 > -EPS_G && pos4 > -EPS_G)
-                        result = aff;
-                }
+                float result = collinearity_pair(p1, p2, q1, q2, coll_sigma_sqr);
                 relation[(size_t)y * S + x] = result;
                 relation[(size_t)x * S + y] = result;
             }
@@ -278,6 +291,22 @@ void l3do_collinearity(const float* segs, int S, float collin_s, float* relation
 /* K_pairwise_matches for ONE thread (y = src segment, x = tgt segment of neighbour
  * `cam`), cudawrapper.cu:538-611.  tgt_segs is the concatenation of all neighbours'
  * segments (line3D.cc:770-781), offset = that neighbour's start. */
+/* the middle of the kernel, cudawrapper.cu:569-588: the four intersection points, their validity, the two overlaps against the
+ * thresholds (pinned to the reference's own lines: tests/test_oracle_pins.py, `pairwise_overlap`).  1 = potential match. */
+static int pairwise_overlap(f3 p1, f3 p2, f3 q1, f3 q2, f3 line1, f3 line2, f3 epi_p1, f3 epi_p2, f3 epi_q1, f3 epi_q2,
+                            f3* l2_p1, f3* l2_p2, f3* l1_q1, f3* l1_q2)
+{
+    *l2_p1 = normalize_hom_coords_2D(cross3(line2, epi_p1));
+    *l2_p2 = normalize_hom_coords_2D(cross3(line2, epi_p2));
+    *l1_q1 = normalize_hom_coords_2D(cross3(line1, epi_q1));
+    *l1_q2 = normalize_hom_coords_2D(cross3(line1, epi_q2));
+    if ((int)l2_p1->z == 0 || (int)l2_p2->z == 0 || (int)l1_q1->z == 0 || (int)l1_q2->z == 0)
+        return 0;
+    float overlap1 = segment_overlap_2D(p1, p2, *l1_q1, *l1_q2);
+    float overlap2 = segment_overlap_2D(q1, q2, *l2_p1, *l2_p2);
+    return fminf(overlap1, overlap2) > MIN_OVERLAP_LOWER_T_G && fmaxf(overlap1, overlap2) > MIN_OVERLAP_UPPER_T_G;
+}
+
 static f4 pairwise_one(const float* src_segs, int y, const float* RtKinv_src, f3 C_src,
                        const float* tgt_segs, int offset, int x, int cam,
                        const float* F, const float* RtKinv, const float* centers)
@@ -297,18 +326,8 @@ static f4 pairwise_one(const float* src_segs, int y, const float* RtKinv_src, f3
     f3 epi_q1 = epipolar_line(q1, F, cam, 1);
     f3 epi_q2 = epipolar_line(q2, F, cam, 1);
 
-    f3 l2_p1 = normalize_hom_coords_2D(cross3(line2, epi_p1));
-    f3 l2_p2 = normalize_hom_coords_2D(cross3(line2, epi_p2));
-    f3 l1_q1 = normalize_hom_coords_2D(cross3(line1, epi_q1));
-    f3 l1_q2 = normalize_hom_coords_2D(cross3(line1, epi_q2));
-
-    if ((int)l2_p1.z == 0 || (int)l2_p2.z == 0 || (int)l1_q1.z == 0 || (int)l1_q2.z == 0)
-        return result;
-
-    float overlap1 = segment_overlap_2D(p1, p2, l1_q1, l1_q2);
-    float overlap2 = segment_overlap_2D(q1, q2, l2_p1, l2_p2);
-
-    if (fminf(overlap1, overlap2) > MIN_OVERLAP_LOWER_T_G && fmaxf(overlap1, overlap2) > MIN_OVERLAP_UPPER_T_G) {
+    f3 l2_p1, l2_p2, l1_q1, l1_q2;
+    if (pairwise_overlap(p1, p2, q1, q2, line1, line2, epi_p1, epi_p2, epi_q1, epi_q2, &l2_p1, &l2_p2, &l1_q1, &l1_q2)) {
         f3 C_tgt = mk3(centers[cam * 3 + 0], centers[cam * 3 + 1], centers[cam * 3 + 2]);
         const float* Rk2 = RtKinv + cam * 9;
         result.x = triangulation_depth(p1, l2_p1, C_src, C_tgt, Rk2, 1, RtKinv_src);
@@ -1034,6 +1053,28 @@ void l3do_devfn_unproject_point_src(int n, const float* p, const float* C, const
         float M[9];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r * 3 + c] = RtKinv[(size_t)i * 3 * stride + r * stride + c];
         st3(out, i, unproject_point_src(ld3(p, i), ld3(C, i), depth[i], M));
+    }
+}
+void l3do_devfn_collinearity_pair(int n, const float* p1, const float* p2, const float* q1, const float* q2, const float* sigma_sqr, float* out)
+{ for (int i = 0; i < n; ++i) out[i] = collinearity_pair(ld3(p1, i), ld3(p2, i), ld3(q1, i), ld3(q2, i), sigma_sqr[i]); }
+void l3do_devfn_hypothesis_confidence(int n, const float* p1, const float* p2, const float* P1, const float* P2, const float* Q1, const float* Q2, const float* Cc,
+                                      const float* tgt, const float* par, float* out)
+{
+    for (int i = 0; i < n; ++i)
+        out[i] = hypothesis_confidence(ld3(p1, i), ld3(p2, i), ld3(P1, i), ld3(P2, i), ld3(Q1, i), ld3(Q2, i), ld3(Cc, i), tgt + 4 * i, par[3 * i], par[3 * i + 1], par[3 * i + 2]);
+}
+/* out: 13 floats per item -- 1/0, then l2_p1, l2_p2, l1_q1, l1_q2 (zeros when it is no potential match) */
+void l3do_devfn_pairwise_overlap(int n, const float* p1, const float* p2, const float* q1, const float* q2, const float* e1, const float* e2,
+                                 const float* e3, const float* e4, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        f3 a = ld3(p1, i), b = ld3(p2, i), c = ld3(q1, i), d = ld3(q2, i), r[4];
+        float* o = out + 13 * (size_t)i;
+        for (int k = 0; k < 13; ++k) o[k] = 0.0f;
+        if (pairwise_overlap(a, b, c, d, cross3(a, b), cross3(c, d), ld3(e1, i), ld3(e2, i), ld3(e3, i), ld3(e4, i), &r[0], &r[1], &r[2], &r[3])) {
+            o[0] = 1.0f;
+            for (int k = 0; k < 4; ++k) { o[1 + 3 * k] = r[k].x; o[2 + 3 * k] = r[k].y; o[3 + 3 * k] = r[k].z; }
+        }
     }
 }
 void l3do_devfn_normalize3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) st3(out, i, normalize3(ld3(v, i))); }

@@ -41,6 +41,27 @@ void l3dref_get_ray_src(int n, const float* p, const float* RtKinv, int stride, 
 // cudawrapper.cu:338-344
 void l3dref_unproject_point_src(int n, const float* p, const float* C, const float* depth, const float* RtKinv, int stride, float* out)
 { for (int i = 0; i < n; ++i) st3(out, i, L3D::D_unproject_point_src(ld3(p, i), ld3(C, i), depth[i], RtKinv + (size_t)i * 3 * stride, stride)); }
+// cudawrapper.cu:492-529: K_collinearity's body for one pair of segments (make_ref_devfn.py wraps the reference's lines into
+// l3dref_collinearity_body; the points stand for the kernel's texture fetches)
+void l3dref_collinearity_pair(int n, const float* p1, const float* p2, const float* q1, const float* q2, const float* sigma_sqr, float* out)
+{ for (int i = 0; i < n; ++i) out[i] = L3D::l3dref_collinearity_body(ld3(p1, i), ld3(p2, i), ld3(q1, i), ld3(q2, i), sigma_sqr[i]); }
+// cudawrapper.cu:380-427 without :407: D_hypothesis_confidence with the target segment handed in instead of fetched (tgt: 4 floats per item;
+// par: sigma_p, sigma_a, spatial_k per item)
+void l3dref_hypothesis_confidence(int n, const float* p1, const float* p2, const float* P1, const float* P2, const float* Q1, const float* Q2, const float* Cc,
+                                  const float* tgt, const float* par, float* out)
+{
+    for (int i = 0; i < n; ++i)
+        out[i] = L3D::l3dref_hypothesis_confidence_body(ld3(p1, i), ld3(p2, i), ld3(P1, i), ld3(P2, i), ld3(Q1, i), ld3(Q2, i), ld3(Cc, i),
+                                                        make_float4(tgt[4 * i], tgt[4 * i + 1], tgt[4 * i + 2], tgt[4 * i + 3]), par[3 * i], par[3 * i + 1], par[3 * i + 2]);
+}
+// cudawrapper.cu:569-588 (K_pairwise_matches between the epipolar lines and the triangulation); out: 13 floats per item -- 1/0, then l2_p1, l2_p2,
+// l1_q1, l1_q2 (zeros when it is no potential match)
+void l3dref_pairwise_overlap(int n, const float* p1, const float* p2, const float* q1, const float* q2, const float* e1, const float* e2,
+                             const float* e3, const float* e4, float* out)
+{
+    for (int i = 0; i < n; ++i)
+        L3D::l3dref_pairwise_overlap_body(ld3(p1, i), ld3(p2, i), ld3(q1, i), ld3(q2, i), ld3(e1, i), ld3(e2, i), ld3(e3, i), ld3(e4, i), out + 13 * (size_t)i);
+}
 // helper_math.h (host definitions): normalize / cross / length / dot of float3 as the functions above see them
 void l3dref_normalize3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) st3(out, i, normalize(ld3(v, i))); }
 void l3dref_cross3(int n, const float* a, const float* b, float* out) { for (int i = 0; i < n; ++i) st3(out, i, cross(ld3(a, i), ld3(b, i))); }

@@ -117,6 +117,106 @@ def angle_cases(rng, n):
     return P1, P2, Q1, Q2
 
 
+def collinearity_cases(rng, n):
+    """Two segments per case (p1, p2, q1, q2) and the squared sigma, as K_collinearity meets them: near-collinear pairs at perpendicular
+    offsets around sigma (the affinity threshold 0.5 is at d = 1.18 sigma), along-the-line arrangements on both sides of the overlap
+    check (gaps, touching end points -- the dots against -EPS_G --, nested and crossing intervals), exact lattice cases, and unrelated or
+    degenerate segments."""
+    p1, p2, q1, q2 = overlap_cases(rng, n)                      # (nearly) collinear quadruples incl. lattice / shared end points / extremes
+    sig = rng.choice(np.array([1.0, 2.5, 5.0, 10.0, 0.3], F32), n)
+    k = rng.integers(0, 6, n)
+    nrm = np.stack([-(p2[:, 1] - p1[:, 1]), p2[:, 0] - p1[:, 0]], 1).astype(np.float64)
+    ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.divide(nrm, ln, out=np.zeros_like(nrm), where=ln > 0)
+    off = (rng.random(n) * 3.0 * sig)[:, None] * nrm            # second segment shifted sideways by 0 .. 3 sigma
+    tilt = (rng.normal(0, 0.5, n) * sig)[:, None] * nrm
+    m = k <= 2
+    q1[m, :2] = (q1[m, :2] + off[m]).astype(F32)
+    q2[m, :2] = (q2[m, :2] + off[m] + (tilt[m] if True else 0)).astype(F32)
+    thr = k == 3                                                 # right at the threshold: d = sqrt(2 ln 2) sigma
+    d0 = (np.sqrt(2.0 * np.log(2.0)) * sig * (1.0 + rng.normal(0, 1e-6, n)))[:, None] * nrm
+    q1[thr, :2] = (q1[thr, :2] + d0[thr]).astype(F32)
+    q2[thr, :2] = (q2[thr, :2] + d0[thr]).astype(F32)
+    return p1, p2, q1, q2, (sig * sig).astype(F32)
+
+
+def confidence_cases(rng, n):
+    """D_hypothesis_confidence as K_verify_matches calls it: a source segment p1 p2, the hypothesis P1 P2 and a witness Q1 Q2 (3-D), the camera
+    centre, the witness's target segment, (sigma_p, sigma_a, spatial_k).  Witnesses near the hypothesis (inside, at and outside the
+    gate k * depth), parallel / tilted / reversed directions (the angle term), target segments near the source line (the distance term),
+    and the gate switched off (spatial_k = 0)."""
+    p1, p2 = _pts2d(rng, n), _pts2d(rng, n)
+    C = points3d(rng, n, 2.0)
+    P1, P2 = points3d(rng, n, 4.0), points3d(rng, n, 4.0)
+    par = np.empty((n, 3), F32)
+    par[:, 0] = rng.choice(np.array([2.5, 1.0, 5.0], F32), n)
+    par[:, 1] = rng.choice(np.array([10.0, 5.0, 20.0], F32), n)
+    par[:, 2] = rng.choice(np.array([0.005, 0.02, 0.0, 0.1], F32), n)
+    k = rng.integers(0, 6, n)
+    depth1 = np.linalg.norm(C - P1, axis=1)
+    depth2 = np.linalg.norm(C - P2, axis=1)
+    u = rng.normal(0, 1, (n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(0, 1, (n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.where(k == 0, rng.random(n) * 2.0,                                         # inside .. twice the gate radius
+                 np.where(k == 1, 1.0 + rng.normal(0, 1e-6, n), rng.random(n) * 0.5))   # right at it / well inside
+    kk = np.where(par[:, 2] > 0, par[:, 2], 0.01)
+    Q1 = (P1 + (f * kk * depth1)[:, None] * u).astype(F32)
+    Q2 = (P2 + (f * kk * depth2)[:, None] * v).astype(F32)
+    far = k == 5
+    Q1[far] = points3d(rng, int(far.sum()), 4.0)
+    rev = k == 4                                                                       # reversed witness: angle folded at 90 degrees
+    Q1[rev], Q2[rev] = Q2[rev].copy(), Q1[rev].copy()
+    tgt = np.empty((n, 4), F32)
+    a = rng.normal(0, 1, n); b = a + rng.normal(0, 1, n)
+    off = rng.normal(0, 1, n) * par[:, 0] * 1.5
+    d = (p2[:, :2] - p1[:, :2]).astype(np.float64)
+    ln = np.linalg.norm(d, axis=1, keepdims=True); ln[ln == 0] = 1.0
+    nrm = np.stack([-d[:, 1], d[:, 0]], 1) / ln
+    tgt[:, 0:2] = (p1[:, :2] + a[:, None] * d + off[:, None] * nrm).astype(F32)
+    tgt[:, 2:4] = (p1[:, :2] + b[:, None] * d + (off + rng.normal(0, 0.5, n))[:, None] * nrm).astype(F32)
+    unrelated = rng.integers(0, 5, n) == 0
+    tgt[unrelated] = (rng.random((int(unrelated.sum()), 4)) * 1500).astype(F32)
+    return p1, p2, P1.astype(F32), P2.astype(F32), Q1, Q2, C.astype(F32), tgt, par
+
+
+def pairwise_cases(rng, n):
+    """The middle of K_pairwise_matches: source segment p1 p2, target segment q1 q2 and the four epipolar lines (of p1, p2 in the target image,
+    of q1, q2 in the source image).  A line through a chosen point of the other segment's line and an "epipole" somewhere: the intersection
+    parameters are drawn around [0, 1] (inside, at the ends, outside, reversed, far away), epipoles inside and far outside the image, plus
+    lines parallel to the segment (intersection at infinity: the validity test), degenerate lines and sub-pixel segments."""
+    p1, p2, q1, q2 = _pts2d(rng, n), _pts2d(rng, n), _pts2d(rng, n), _pts2d(rng, n)
+    short = rng.integers(0, 12, n) == 0
+    p2[short, :2] = p1[short, :2] + rng.normal(0, 0.6, (int(short.sum()), 2)).astype(F32)
+
+    def line_through(a1, a2, t, epi):
+        x = a1[:, :2].astype(np.float64) + t[:, None] * (a2[:, :2].astype(np.float64) - a1[:, :2])
+        X = np.concatenate([x, np.ones((n, 1))], 1)
+        E = np.concatenate([epi, np.ones((n, 1))], 1)
+        return np.cross(X, E).astype(F32)
+
+    def params():
+        k = rng.integers(0, 6, n)
+        t = rng.normal(0.5, 0.6, n)
+        t = np.where(k == 0, rng.choice([0.0, 1.0], n) + rng.normal(0, 1e-4, n), t)
+        t = np.where(k == 1, rng.normal(0.5, 30.0, n), t)
+        return t
+    far = rng.integers(0, 3, n) == 0
+    ep_t = np.where(far[:, None], rng.normal(0, 1e5, (n, 2)), rng.random((n, 2)) * 2000)    # epipole in the target / source image
+    ep_s = np.where(far[:, None], rng.normal(0, 1e5, (n, 2)), rng.random((n, 2)) * 2000)
+    ta, tb = params(), params()
+    swap = rng.integers(0, 4, n) == 0
+    tb = np.where(swap, ta - np.abs(tb - ta), ta + np.abs(tb - ta) * 0.8)
+    e1, e2 = line_through(q1, q2, ta, ep_t), line_through(q1, q2, tb, ep_t)
+    tc, td = params(), params()
+    e3, e4 = line_through(p1, p2, tc, ep_s), line_through(p1, p2, td, ep_s)
+    k = rng.integers(0, 20, n)
+    par = k == 0                                                   # parallel to the segment's line: z of the cross product ~ 0
+    e1[par] = np.cross(q1[par].astype(np.float64), q2[par].astype(np.float64)).astype(F32) * F32(0.5)
+    e1[par, 2] += F32(3.0)
+    e3[k == 1] = 0.0                                               # degenerate line
+    return p1, p2, q1, q2, e1, e2, e3, e4
+
+
 def matrices(rng, n, stride):
     M = np.zeros((n, 3, stride), F32)
     M[:, :, :3] = rng.normal(0, 1, (n, 3, 3)).astype(F32)
@@ -145,6 +245,9 @@ def make_inputs(seed, n):
         c["get_ray_src_stride%d" % stride] = ((p, M), (F32, (n, 3)), "get_ray_src", stride)
         Cc, depth = points3d(rng, n), (rng.random(n) * 10).astype(F32)
         c["unproject_point_src_stride%d" % stride] = ((p, Cc, depth, M), (F32, (n, 3)), "unproject_point_src", stride)
+    c["collinearity_pair"] = (collinearity_cases(rng, n), (F32, (n,)), "collinearity_pair", None)
+    c["hypothesis_confidence"] = (confidence_cases(rng, n), (F32, (n,)), "hypothesis_confidence", None)
+    c["pairwise_overlap"] = (pairwise_cases(rng, n), (F32, (n, 13)), "pairwise_overlap", None)
     v = points3d(rng, n)
     v[rng.integers(0, 10, n) == 0] = 0.0
     c["normalize3"] = ((v,), (F32, (n, 3)), "normalize3", None)
