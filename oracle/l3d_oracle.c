@@ -25,10 +25,16 @@
  *     for the fetched values (make_ref_devfn.py marks which lines are whose): D_hypothesis_confidence (:380-427 without the fetch :407 --
  *     the whole scoring of stage 2: gate, 2-D distances, 3-D angle, two expf), the middle of K_pairwise_matches (:569-588: intersection
  *     points, validity, overlaps against the thresholds -- the stage-1 decision), K_collinearity's body for one pair (:492-529): bit-equal
- *     on 10^6 cases each (the two with transcendentals in the libm build; contract build within a few 1e-6, no decision flips seen).
+ *     on 10^6 cases each (the two with transcendentals in the libm build; contract build within a few 1e-6, no decision flips seen);
+ *   - the two matching kernels WHOLE: K_pairwise_matches (:538-611) with D_get_triangulation_depth (:304-335), and K_verify_matches (:614-714),
+ *     compiled from the reference's text with only their texture-fetch lines replaced by table reads (:551-554, :558, :591-593; :637-641) and
+ *     run one thread at a time: l3do_pairwise_dense gives the same dense buffers bit for bit on real scene geometry (helix, narrow baseline,
+ *     forward motion, opposing cameras; > 10^6 pairs), l3do_verify the same confidences bit for bit (libm build; contract build within 5e-6 with
+ *     the same kept set) on packed candidate lists with clusters, outliers, runs of one camera (tests/golden/pairwise_ref.npz, verify_ref.npz).
+ *     Their three texture-reading callees D_epipolar_line, D_get_ray_tgt, D_project_point_tgt -- 3x3 / 3x4 matrix-vector products accumulated
+ *     from 0.0f in index order -- are RESTATED over tables in that build (oracle/make_ref_devfn.py says which lines are whose).
  * Still "parity unpinned" by the reference, pinned by restatement, analytic known-answer scenes and committed vectors
- * only: the three matrix-vector products that accumulate straight out of textures (D_epipolar_line, D_get_ray_tgt and with it
- * D_get_triangulation_depth, D_project_point_tgt), the control flow of the kernels around them (per-camera maxima of K_verify_matches),
+ * only: those three matrix-vector products, K_collinearity's loop around its pinned body,
  * the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc's index tables,
  * view.cc and line3D.cc -- they need CUDA texture references, boost, Eigen or OpenCV, which this image lacks; building
  * them would take stand-in headers, so they are treated as unbuildable.  The reference has no tests, golden vectors

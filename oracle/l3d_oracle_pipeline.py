@@ -143,6 +143,39 @@ def rdd(lib, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
     return out
 
 
+def pairwise_dense_view(lib, mv, cam, reference=None):
+    """The dense S x width float4 buffer K_pairwise_matches fills for neighbour `cam` of a marshalled view (marshal_view): the oracle's
+    l3do_pairwise_dense, or -- reference = oracle/_ref/libdevfn_ref.so -- the reference's own kernel text (l3dref_pairwise_matches)."""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    src, tgt, Rs, Cs, F, R, Cn = f(mv["src_segs"]), f(mv["tgt_segs"]), f(mv["RtKinv_src"]), f(mv["C_src"]), f(mv["F"]), f(mv["RtKinv"]), f(mv["centers"])
+    off, w, S = int(mv["offsets"][cam][0]), int(mv["offsets"][cam][1]), len(src)
+    out = np.zeros((S, w, 4), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    if reference is None:
+        lib.l3do_pairwise_dense(p(src), C.c_int(S), p(Rs), p(Cs), p(tgt), C.c_int(off), C.c_int(w), C.c_int(cam), p(F), p(R), p(Cn), p(out))
+    else:
+        reference.l3dref_pairwise_matches(p(out), C.c_int(w), C.c_int(S), p(Rs), C.c_int(3), C.c_int(off), C.c_int(cam), p(Cs), C.c_int(w), p(src), p(tgt),
+                                          p(F), p(R), p(Cn))
+    return out
+
+
+def verify_case(lib, case, reference=None):
+    """K_verify_matches on a packed candidate list (tests/verify_cases.py): the oracle's l3do_verify, or -- reference = oracle/_ref/libdevfn_ref.so --
+    the reference's own kernel text (l3dref_verify_matches).  Returns the confidences (the .w of matches_data)."""
+    md = np.ascontiguousarray(case["matches_data"], np.float32).copy()
+    R = len(md)
+    f = lambda a, dt=np.float32: np.ascontiguousarray(a, dt)
+    dep, mo, co = f(case["matches_depths"]), f(case["match_offsets"], np.int32), f(case["camera_offsets"], np.int32)
+    src, Rk, Cs, tgt, P = f(case["src_segs"]), f(case["RtKinv"]), f(case["C_src"]), f(case["tgt_segs"]), f(case["P"])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    sp, sa, sk = C.c_float(float(case["sigma_p"])), C.c_float(float(case["sigma_a"])), C.c_float(float(case["spatial_k"]))
+    if reference is None:
+        lib.l3do_verify(p(md), p(dep), p(mo), p(co), C.c_int(R), p(src), p(Rk), p(Cs), p(tgt), p(P), sp, sa, sk, C.c_int(0), C.c_int(R))
+    else:
+        reference.l3dref_verify_matches(p(md), p(dep), p(mo), p(co), C.c_int(R), p(src), p(Rk), C.c_int(3), p(Cs), p(tgt), p(P), sp, sa, sk)
+    return md[:, 3].copy()
+
+
 def rdd_hooked(lib, ref, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
     """l3do_rdd_hooked with the two kernels of `ref` (oracle/_ref/libdevfn_ref.so: the reference's own K_sparseMat_row_normalization and
     K_sparseMat_diffusion_step, cudawrapper.cu:717-829) in place of the oracle's restatements."""

@@ -38,7 +38,46 @@ RANGES = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.c
           ("cudawrapper.cu", 548, 548), ("cudawrapper.cu", 555, 555), ("cudawrapper.cu", 561, 561), ("cudawrapper.cu", 569, 589),
           ("text", "        out13[0] = 1.0f;\n        out13[1] = l2_p1.x; out13[2] = l2_p1.y; out13[3] = l2_p1.z; out13[4] = l2_p2.x; out13[5] = l2_p2.y; out13[6] = l2_p2.z;\n"
                    "        out13[7] = l1_q1.x; out13[8] = l1_q1.y; out13[9] = l1_q1.z; out13[10] = l1_q2.x; out13[11] = l1_q2.y; out13[12] = l1_q2.z;\n"
-                   "    }\n    (void)buffer;\n}")]
+                   "    }\n    (void)buffer;\n}"),
+          # K_verify_matches whole (:614-714) except the five lines that fetch the source segment from a texture (:637-641).  The kernel calls two
+          # texture-reading device functions; they are defined here, in front of it, by OUR lines: D_hypothesis_confidence forwards to the reference's
+          # own body above (the fetched target segment comes from a table), D_project_point_tgt is a RESTATEMENT of :355-377 reading the projection
+          # matrices from a table (the one piece of this kernel that stays pinned by restatement only).  The tables are set by the door.
+          ("text", "static const float* l3dref_tab_src = 0; static const float* l3dref_tab_tgt = 0; static const float* l3dref_tab_P = 0;\n"
+                   "static float3 D_project_point_tgt(const float3 X, const int camID)\n{\n"
+                   "    const float v[4] = { X.x, X.y, X.z, 1.0f };\n    float o[3] = { 0.0f, 0.0f, 0.0f };\n"
+                   "    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) o[r] += l3dref_tab_P[(camID * 3 + r) * 4 + c] * v[c];\n"
+                   "    if (fabs(o[2]) > L3D_EPS_G) return make_float3(o[0] / o[2], o[1] / o[2], 1.0f);\n    return make_float3(0, 0, 0);\n}\n"
+                   "static float D_hypothesis_confidence(const float3 p1, const float3 p2, const float3 P1, const float3 P2, const float3 Q1, const float3 Q2,\n"
+                   "                                     const float3 C, const int tgtID, const float sigma_p, const float sigma_a, const float spatial_k)\n{\n"
+                   "    const float* t = l3dref_tab_tgt + 4 * (size_t)tgtID;\n"
+                   "    return l3dref_hypothesis_confidence_body(p1, p2, P1, P2, Q1, Q2, C, make_float4(t[0], t[1], t[2], t[3]), sigma_p, sigma_a, spatial_k);\n}"),
+          ("cudawrapper.cu", 614, 636),
+          ("text", "            float3 p1 = make_float3(l3dref_tab_src[4 * srcID], l3dref_tab_src[4 * srcID + 1], 1.0f);\n"
+                   "            float3 p2 = make_float3(l3dref_tab_src[4 * srcID + 2], l3dref_tab_src[4 * srcID + 3], 1.0f);"),
+          ("cudawrapper.cu", 642, 714),
+          # K_pairwise_matches whole (:538-611) except its texture fetches (:551-554 the source segment, :558 the target segment, :591-593 the target
+          # camera's centre), and D_get_triangulation_depth (:304-335) as it stands.  Their texture-reading callees D_epipolar_line (:144-163) and
+          # D_get_ray_tgt (:288-303) are RESTATED here over tables (each a 3x3 matrix-vector product accumulated from 0.0f in the reference's index
+          # order): the depth formula, the kernel's control flow and its use of every pinned function are the reference's text.
+          ("text", "static const float* l3dref_tab_F = 0; static const float* l3dref_tab_R = 0; static const float* l3dref_tab_C = 0;\n"
+                   "static float3 D_epipolar_line(const float3 p, const int camID, const bool transpose)\n{\n"
+                   "    const float v[3] = { p.x, p.y, p.z };\n    float l[3] = { 0.0f, 0.0f, 0.0f };\n"
+                   "    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) l[r] += (transpose ? l3dref_tab_F[camID * 9 + c * 3 + r] : l3dref_tab_F[camID * 9 + r * 3 + c]) * v[c];\n"
+                   "    return make_float3(l[0], l[1], l[2]);\n}\n"
+                   "static float3 D_get_ray_tgt(const float3 p, const int cID)\n{\n"
+                   "    const float v[3] = { p.x, p.y, p.z };\n    float o[3] = { 0.0f, 0.0f, 0.0f };\n"
+                   "    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[r] += l3dref_tab_R[cID * 9 + r * 3 + c] * v[c];\n"
+                   "    return make_float3(o[0], o[1], o[2]);\n}"),
+          ("cudawrapper.cu", 304, 335), ("cudawrapper.cu", 538, 550),
+          ("text", "            float3 p1 = make_float3(l3dref_tab_src[4 * y], l3dref_tab_src[4 * y + 1], 1.0f);\n"
+                   "            float3 p2 = make_float3(l3dref_tab_src[4 * y + 2], l3dref_tab_src[4 * y + 3], 1.0f);"),
+          ("cudawrapper.cu", 555, 557),
+          ("text", "            float4 data = make_float4(l3dref_tab_tgt[4 * (offset + x)], l3dref_tab_tgt[4 * (offset + x) + 1], l3dref_tab_tgt[4 * (offset + x) + 2],\n"
+                   "                                      l3dref_tab_tgt[4 * (offset + x) + 3]);"),
+          ("cudawrapper.cu", 559, 590),
+          ("text", "                float3 C_tgt = make_float3(l3dref_tab_C[3 * cID], l3dref_tab_C[3 * cID + 1], l3dref_tab_C[3 * cID + 2]);"),
+          ("cudawrapper.cu", 594, 611)]
 
 
 def nvidia_include():

@@ -14,6 +14,7 @@
 
 extern "C" {
 
+void l3dref_set_launch(unsigned block_x, unsigned block_y, unsigned thread_x, unsigned thread_y, unsigned dim_x, unsigned dim_y);   // ref_devfn_launch.cc
 static inline float3 ld3(const float* p, int i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 static inline void st3(float* p, int i, float3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
 
@@ -62,6 +63,34 @@ void l3dref_pairwise_overlap(int n, const float* p1, const float* p2, const floa
     for (int i = 0; i < n; ++i)
         L3D::l3dref_pairwise_overlap_body(ld3(p1, i), ld3(p2, i), ld3(q1, i), ld3(q2, i), ld3(e1, i), ld3(e2, i), ld3(e3, i), ld3(e4, i), out + 13 * (size_t)i);
 }
+// cudawrapper.cu:614-714: K_verify_matches, one thread at a time over the R candidates (make_ref_devfn.py: the kernel's text except its texture
+// fetch of the source segment; its two texture-reading callees are bound to tables).  matches_data: R x (srcID, camera, tgtID, confidence) as floats
+// -- the confidences are written in place; matches_depths: R x 4; match_offsets: S x (start, count); camera_offsets: N x (start, count) into
+// tgt_segs; P: N x 3 x 4 row-major; RtKinv: 3 rows of r_stride floats.
+void l3dref_verify_matches(float* matches_data, const float* matches_depths, const int* match_offsets, const int* camera_offsets, int size,
+                           const float* src_segs, const float* RtKinv, int r_stride, const float* C_src, const float* tgt_segs, const float* P,
+                           float sigma_p, float sigma_a, float spatial_k)
+{
+    L3D::l3dref_tab_src = src_segs; L3D::l3dref_tab_tgt = tgt_segs; L3D::l3dref_tab_P = P;
+    for (int y = 0; y < size; ++y) {
+        l3dref_set_launch(0, (unsigned)(y / 256), 0, (unsigned)(y % 256), 1, 256);                 // dimBlock = (1, 16 * 16), cudawrapper.cu:1011
+        L3D::K_verify_matches(reinterpret_cast<float4*>(matches_data), reinterpret_cast<float4*>(const_cast<float*>(matches_depths)),
+                              reinterpret_cast<const int2*>(match_offsets), reinterpret_cast<const int2*>(camera_offsets), size, RtKinv,
+                              make_float3(C_src[0], C_src[1], C_src[2]), sigma_p, sigma_a, spatial_k, r_stride);
+    }
+}
+// cudawrapper.cu:538-611: K_pairwise_matches for one neighbour camera, one thread at a time over the height x width grid (make_ref_devfn.py: the
+// kernel's text except its texture fetches; D_epipolar_line / D_get_ray_tgt bound to tables).  buffer: height x stride float4.
+void l3dref_pairwise_matches(float* buffer, int width, int height, const float* RtKinv_src, int r_stride, int offset, int cID, const float* C_src, int stride,
+                             const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers)
+{
+    L3D::l3dref_tab_src = src_segs; L3D::l3dref_tab_tgt = tgt_segs; L3D::l3dref_tab_F = F; L3D::l3dref_tab_R = RtKinv_tgt; L3D::l3dref_tab_C = centers;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            l3dref_set_launch((unsigned)(x / 16), (unsigned)(y / 16), (unsigned)(x % 16), (unsigned)(y % 16), 16, 16);     // dimBlock = (16, 16), cudawrapper.cu:900
+            L3D::K_pairwise_matches(reinterpret_cast<float4*>(buffer), width, height, RtKinv_src, offset, cID, make_float3(C_src[0], C_src[1], C_src[2]), stride, r_stride);
+        }
+}
 // helper_math.h (host definitions): normalize / cross / length / dot of float3 as the functions above see them
 void l3dref_normalize3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) st3(out, i, normalize(ld3(v, i))); }
 void l3dref_cross3(int n, const float* a, const float* b, float* out) { for (int i = 0; i < n; ++i) st3(out, i, cross(ld3(a, i), ld3(b, i))); }
@@ -71,7 +100,6 @@ void l3dref_dot3(int n, const float* a, const float* b, float* out) { for (int i
 // cudawrapper.cu:717-762 and :765-829 -- the two kernels of replicator_dynamics_diffusion (texture-free; every thread is independent:
 // no shared memory, no barrier), run one "thread" at a time over the grid the reference launches (x = 0, y = row / entry; the launch
 // variables: ref_devfn_launch.cc).  data / P / W / P_prime: float4 records (row, column, value, unused) as SparseMatrix keeps them.
-void l3dref_set_launch(unsigned block_x, unsigned block_y, unsigned thread_x, unsigned thread_y, unsigned dim_x, unsigned dim_y);
 void l3dref_sparse_row_normalization(float* data, const int* start_indices, int num_rows, int num_entries)
 {
     for (int y = 0; y < num_rows; ++y) {

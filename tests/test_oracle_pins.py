@@ -385,3 +385,92 @@ def test_sparse_matrix_orders_match_reference_live(oracle_lib):
             oracle_lib.l3do_sort_edges(e.ctypes.data_as(C.c_void_p), C.c_int(E), C.c_int(by_row))
             assert np.array_equal(e["i"], a) and np.array_equal(e["j"], b) and e["w"].tobytes() == w.tobytes(), (n, by_row)
             assert len(np.unique(np.stack([ei, ej]), axis=1).T) < E          # (duplicates are present)
+
+
+# ---- K_verify_matches, pinned to the reference's own kernel text -------------------------------------------------------------------------
+# oracle/_ref/libdevfn_ref.so holds K_verify_matches compiled from cudawrapper.cu:614-714 -- all of it but the five lines that fetch the source
+# segment from a texture; of its two texture-reading callees D_hypothesis_confidence is the reference's own body (pinned above),
+# D_project_point_tgt a restatement over a table.  The loop over a segment's candidates, the skips, the per-camera maximum over contiguous runs,
+# the validity test of the projections, the 0.5 threshold and the sum are the reference's.  The libm build of the oracle must agree bit for
+# bit; the contract build (own expf / acosf) within 5e-6 and with the same kept set (confidence > 1).
+def _verify_checks(conf_ref, conf_libm, conf_contract):
+    assert conf_libm.tobytes() == conf_ref.tobytes()
+    assert np.max(np.abs(conf_contract - conf_ref), initial=0) <= 5e-6
+    assert np.array_equal(conf_contract > 1.0, conf_ref > 1.0)
+
+
+def test_verify_kernel_matches_reference_golden():
+    import hashlib
+    import verify_cases as vc
+    g = np.load(os.path.join(HERE, "golden", "verify_ref.npz"))
+    kept = 0
+    for k, kw in enumerate(vc.CASES):
+        case = vc.make_case(**kw)
+        h = hashlib.sha256()
+        for name in sorted(case):
+            h.update(np.ascontiguousarray(case[name]).tobytes())
+        assert h.digest() == g["c%d_digest" % k].tobytes(), k           # the inputs are the ones the vectors were made from
+        want = g["c%d_conf" % k]
+        _verify_checks(want, op.verify_case(op.load_lib(libm=True), case), op.verify_case(op.load_lib(libm=False), case))
+        kept += int((want > 1.0).sum())
+        assert (want > 0).sum() < len(want)                              # (some candidates get no support at all)
+    assert kept > 2000
+
+
+def test_verify_kernel_matches_reference_live():
+    import verify_cases as vc
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_verify_matches"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so predates the verification kernel")
+    for seed in range(40, 52):
+        case = vc.make_case(seed, S=30 + 5 * (seed % 7), N=3 + seed % 9, m_max=20 + 10 * (seed % 5), spatial_k=[0.02, 0.0, 0.05, 0.005][seed % 4])
+        _verify_checks(op.verify_case(None, case, ref), op.verify_case(op.load_lib(libm=True), case), op.verify_case(op.load_lib(libm=False), case))
+
+
+# ---- K_pairwise_matches, pinned to the reference's own kernel text ------------------------------------------------------------------------
+# cudawrapper.cu:538-611 and D_get_triangulation_depth (:304-335) compiled from the reference's text; the kernel's three texture fetches are table
+# reads, its callees D_epipolar_line / D_get_ray_tgt (3x3 matrix-vector products accumulated out of textures) restatements over tables.  No
+# transcendental is involved: both oracle builds must give the same dense buffer bit for bit, on real scene geometry (fundamental matrices,
+# RtKinv, centres as Line3D::performMatching marshals them).
+def _pairwise_golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_pairwise", os.path.join(HERE, "golden", "make_golden_pairwise.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_pairwise_kernel_matches_reference_golden(oracle_lib):
+    m = _pairwise_golden_module()
+    g = np.load(os.path.join(HERE, "golden", "pairwise_ref.npz"))
+    for name, scene, N in m.scenes():
+        o = op.run_scene(scene, N)
+        idx, val = m.entries(o, oracle_lib, None)
+        assert np.array_equal(idx, g[name + "_idx"]) and val.tobytes() == g[name + "_val"].tobytes(), name
+        cand = np.all(g[name + "_val"] > 0, axis=1).sum()
+        assert cand > 2000 and cand < len(val)                            # candidates (four positive depths) and overlap-passing pairs that are none
+
+
+def test_pairwise_kernel_matches_reference_live(oracle_lib):
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_pairwise_matches"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so predates the pair kernel")
+    from line3d_amd.synth import make_scene_from_poses
+    scenes = [(make_scene(6, 150, 4, seed=21, step=0.05), 4), (make_scene(5, 200, 4, seed=22, noise_px=1.5), 4),
+              (make_scene_from_poses([(4, 0, 0), (3.2, 0.1, 0.05), (2.4, 0.0, 0.1), (-4, 0, 0.2)], [(0, 0, 0)] * 4, 120, seed=23), 3)]      # forward motion + an opposing camera
+    pairs = 0
+    for scene, N in scenes:
+        o = op.run_scene(scene, N)
+        for v in sorted(o.trace):
+            mv = o.trace[v]["marshal"]
+            for cam in range(len(mv["offsets"])):
+                a = op.pairwise_dense_view(oracle_lib, mv, cam)
+                assert a.tobytes() == op.pairwise_dense_view(oracle_lib, mv, cam, ref).tobytes(), (v, cam)
+                pairs += a.shape[0] * a.shape[1]
+    assert pairs > 900000
