@@ -34,7 +34,8 @@
  *     Their three texture-reading callees D_epipolar_line, D_get_ray_tgt, D_project_point_tgt -- 3x3 / 3x4 matrix-vector products accumulated
  *     from 0.0f in index order -- are RESTATED over tables in that build (oracle/make_ref_devfn.py says which lines are whose).
  * Still "parity unpinned" by the reference, pinned by restatement, analytic known-answer scenes and committed vectors
- * only: those three matrix-vector products, K_collinearity's loop around its pinned body,
+ * only: those three matrix-vector products (K_collinearity too is compiled whole, :476-535 with its fetches as table reads, and reproduced
+ * bit for bit by l3do_collinearity in the libm build),
  * the host orchestration (cudawrapper.cu:858-1191), sparsematrix.cc's index tables,
  * view.cc and line3D.cc -- they need CUDA texture references, boost, Eigen or OpenCV, which this image lacks; building
  * them would take stand-in headers, so they are treated as unbuildable.  The reference has no tests, golden vectors

@@ -77,7 +77,15 @@ RANGES = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.c
                    "                                      l3dref_tab_tgt[4 * (offset + x) + 3]);"),
           ("cudawrapper.cu", 559, 590),
           ("text", "                float3 C_tgt = make_float3(l3dref_tab_C[3 * cID], l3dref_tab_C[3 * cID + 1], l3dref_tab_C[3 * cID + 2]);"),
-          ("cudawrapper.cu", 594, 611)]
+          ("cudawrapper.cu", 594, 611),
+          # K_collinearity whole (:476-535) except its two texture fetches (:495-498, :502-505): the segments come from the source table
+          ("cudawrapper.cu", 476, 494),
+          ("text", "                float3 p1 = make_float3(l3dref_tab_src[4 * x], l3dref_tab_src[4 * x + 1], 1.0f);\n"
+                   "                float3 p2 = make_float3(l3dref_tab_src[4 * x + 2], l3dref_tab_src[4 * x + 3], 1.0f);"),
+          ("cudawrapper.cu", 499, 501),
+          ("text", "                float3 q1 = make_float3(l3dref_tab_src[4 * y], l3dref_tab_src[4 * y + 1], 1.0f);\n"
+                   "                float3 q2 = make_float3(l3dref_tab_src[4 * y + 2], l3dref_tab_src[4 * y + 3], 1.0f);"),
+          ("cudawrapper.cu", 506, 535)]
 
 
 def nvidia_include():

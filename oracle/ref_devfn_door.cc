@@ -91,6 +91,17 @@ void l3dref_pairwise_matches(float* buffer, int width, int height, const float* 
             L3D::K_pairwise_matches(reinterpret_cast<float4*>(buffer), width, height, RtKinv_src, offset, cID, make_float3(C_src[0], C_src[1], C_src[2]), stride, r_stride);
         }
 }
+// cudawrapper.cu:476-535: K_collinearity over the size x size grid, one thread at a time (the kernel's text except its texture fetches);
+// relation: size x stride floats
+void l3dref_collinearity(float* relation, int size, float coll_sigma_sqr, int stride, const float* segs)
+{
+    L3D::l3dref_tab_src = segs;
+    for (int y = 0; y < size; ++y)
+        for (int x = 0; x < size; ++x) {
+            l3dref_set_launch((unsigned)(x / 16), (unsigned)(y / 16), (unsigned)(x % 16), (unsigned)(y % 16), 16, 16);     // dimBlock = (16, 16), cudawrapper.cu:842
+            L3D::K_collinearity(relation, size, coll_sigma_sqr, stride);
+        }
+}
 // helper_math.h (host definitions): normalize / cross / length / dot of float3 as the functions above see them
 void l3dref_normalize3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) st3(out, i, normalize(ld3(v, i))); }
 void l3dref_cross3(int n, const float* a, const float* b, float* out) { for (int i = 0; i < n; ++i) st3(out, i, cross(ld3(a, i), ld3(b, i))); }

@@ -287,3 +287,27 @@ def same_bits(a, b):
         return np.array_equal(a, b)
     ai, bi = a.view(np.uint32), b.view(np.uint32)
     return bool(np.all((ai == bi) | (np.isnan(a) & np.isnan(b))))
+
+
+def collinear_segments(seed, n_lines=60, pieces=5, sigma=2.5):
+    """An image's segments with planted collinearities for the K_collinearity pin: every line is cut into pieces -- with gaps, touching end points,
+    overlaps (the conflict check) and sideways jitter of 0 .. 2 sigma -- plus unrelated segments.  float32 (S, 4)."""
+    rng = np.random.default_rng(seed)
+    segs = []
+    for _ in range(n_lines):
+        o = rng.random(2) * [1700, 900] + [100, 90]
+        a = rng.random() * np.pi
+        u, nrm = np.array([np.cos(a), np.sin(a)]), np.array([-np.sin(a), np.cos(a)])
+        t = 0.0
+        for _ in range(pieces):
+            length = rng.uniform(15, 120)
+            kind = rng.integers(0, 4)
+            t += 0.0 if kind == 0 else (rng.uniform(1, 40) if kind <= 2 else -rng.uniform(1, 30))      # touching / gap / overlap
+            j1, j2 = rng.uniform(-2, 2, 2) * sigma * (rng.random() < 0.7)
+            segs.append(np.concatenate([o + t * u + j1 * nrm, o + (t + length) * u + j2 * nrm]))
+            t += length
+    for _ in range(n_lines):
+        p = rng.random(2) * [1700, 900] + [100, 90]
+        segs.append(np.concatenate([p, p + rng.normal(0, 50, 2)]))
+    segs = np.array(segs, F32)
+    return np.ascontiguousarray(segs[rng.permutation(len(segs))])

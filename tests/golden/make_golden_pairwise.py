@@ -3,7 +3,8 @@
 Data only: for two small seeded scenes (a helix, cameras that face each other) every non-zero entry of the dense buffers the REFERENCE's own
 K_pairwise_matches writes (cudawrapper.cu:538-611 + D_get_triangulation_depth :304-335 compiled from its text by oracle/make_ref_devfn.py; texture
 fetches replaced by table reads, D_epipolar_line / D_get_ray_tgt restated over tables) for every view and every neighbour camera: (view, camera, source
-segment, target segment, four depths)."""
+segment, target segment, four depths); and the non-zero entries of the collinearity relation K_collinearity (:476-535, same build) gives for the
+planted segments of tests/devfn_cases.py::collinear_segments."""
 import ctypes as C
 import os
 import sys
@@ -43,6 +44,15 @@ if __name__ == "__main__":
     for name, scene, N in scenes():
         o = op.run_scene(scene, N)
         out[name + "_idx"], out[name + "_val"] = entries(o, lib, ref)
+    # K_collinearity (cudawrapper.cu:476-535, the kernel's text with its texture fetches replaced by table reads): the non-zero entries of the relation
+    import devfn_cases as dc
+    segs = dc.collinear_segments(31)
+    S = len(segs)
+    rel = np.zeros((S, S), np.float32)
+    ref.l3dref_collinearity(rel.ctypes.data_as(C.c_void_p), C.c_int(S), C.c_float(2.5 * 2.5), C.c_int(S), segs.ctypes.data_as(C.c_void_p))
+    ys, xs = np.nonzero(rel)
+    out["coll_idx"] = np.stack([ys, xs], 1).astype(np.int32)
+    out["coll_val"] = rel[ys, xs]
     path = os.path.join(HERE, "pairwise_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes", {k: v.shape for k, v in out.items()})

@@ -474,3 +474,34 @@ def test_pairwise_kernel_matches_reference_live(oracle_lib):
                 assert a.tobytes() == op.pairwise_dense_view(oracle_lib, mv, cam, ref).tobytes(), (v, cam)
                 pairs += a.shape[0] * a.shape[1]
     assert pairs > 900000
+
+
+def test_collinearity_kernel_matches_reference(oracle_lib):
+    """K_collinearity whole (cudawrapper.cu:476-535: the kernel's text, texture fetches -> table reads) on an image with planted collinear pieces
+    (gaps, touching end points, overlaps, sideways jitter): the committed non-zero entries and, when oracle/_ref is built, the live kernel -- the
+    libm build of the oracle bit for bit, the contract build (own expf) within 1.2e-7 and with the same non-zero pattern."""
+    import devfn_cases as dc
+    g = np.load(os.path.join(HERE, "golden", "pairwise_ref.npz"))
+    segs = dc.collinear_segments(31)
+    S = len(segs)
+    assert len(g["coll_idx"]) > 100                                       # (pairs of pieces of one line, both orders)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    want = np.zeros((S, S), np.float32)
+    want[g["coll_idx"][:, 0], g["coll_idx"][:, 1]] = g["coll_val"]
+    for libm in (True, False):
+        got = np.zeros((S, S), np.float32)
+        op.load_lib(libm=libm).l3do_collinearity(p(segs), C.c_int(S), C.c_float(2.5), p(got))
+        if libm:
+            assert got.tobytes() == want.tobytes()
+        else:
+            assert np.array_equal(got > 0, want > 0) and np.max(np.abs(got - want)) <= 1.2e-7
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if os.path.exists(path) and hasattr(C.CDLL(path), "l3dref_collinearity"):
+        ref = C.CDLL(path)
+        for seed in (32, 33, 34):
+            sg = dc.collinear_segments(seed, n_lines=40 + seed, pieces=4)
+            n = len(sg)
+            a, b = np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
+            op.load_lib(libm=True).l3do_collinearity(p(sg), C.c_int(n), C.c_float(2.5), p(a))
+            ref.l3dref_collinearity(p(b), C.c_int(n), C.c_float(2.5 * 2.5), C.c_int(n), p(sg))
+            assert a.tobytes() == b.tobytes() and (b > 0).sum() > 40, seed
