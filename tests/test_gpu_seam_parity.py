@@ -821,3 +821,20 @@ def test_diffusion_equals_the_reference_kernels(gpu_ctx):
         assert A.tobytes() == g["c%d_in" % k].tobytes()
         for iters in (1, 10):
             assert gpu_ctx.replicator_dynamics_diffusion(A, case["n"], iters).tobytes() == g["c%d_it%d" % (k, iters)].tobytes(), (k, iters)
+
+
+def test_collinearity_equals_the_reference_kernel(gpu_ctx):
+    """l3d_compute_collinearity against tests/golden/pairwise_ref.npz: the relation the REFERENCE's own K_collinearity (cudawrapper.cu:476-535,
+    compiled from its text) gives for an image with planted collinear pieces -- the same non-zero pattern, weights within 1.2e-7 (one float ulp
+    below 1: the product's expf is the numeric contract's, the reference build's glibc's)."""
+    import devfn_cases as dc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pairwise_ref.npz"))
+    segs = dc.collinear_segments(31)
+    gi, gj, gw = gpu_ctx.compute_collinearity(segs, 2.5)
+    S = len(segs)
+    got = np.zeros((S, S), np.float32)
+    got[gi, gj] = gw
+    got[gj, gi] = gw
+    want = np.zeros((S, S), np.float32)
+    want[g["coll_idx"][:, 0], g["coll_idx"][:, 1]] = g["coll_val"]
+    assert (want > 0).sum() > 100 and np.array_equal(got > 0, want > 0) and np.max(np.abs(got - want)) <= 1.2e-7
