@@ -439,6 +439,10 @@ typedef struct {
     float confidence;
 } l3do_match;
 
+static void stable_sort_matches(l3do_match* m, size_t n);
+/* (door for tests/test_oracle_pins.py: the order against the reference's own comparator on a std::list) */
+void l3do_sort_matches(l3do_match* m, int n) { stable_sort_matches(m, (size_t)(n > 0 ? n : 0)); }
+
 /* sortMatchingPairs, sparsematrix.h:67-78 */
 static int cmp_match(const void* a_, const void* b_)
 {

@@ -85,7 +85,10 @@ RANGES = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.c
           ("cudawrapper.cu", 499, 501),
           ("text", "                float3 q1 = make_float3(l3dref_tab_src[4 * y], l3dref_tab_src[4 * y + 1], 1.0f);\n"
                    "                float3 q2 = make_float3(l3dref_tab_src[4 * y + 2], l3dref_tab_src[4 * y + 3], 1.0f);"),
-          ("cudawrapper.cu", 506, 535)]
+          ("cudawrapper.cu", 506, 535),
+          # L3DMatchingPair and its two comparators (sparsematrix.h:36-49 the fields, :68-85 sortMatchingPairs / sortMatchingPairsByConf) without the
+          # boost serialisation members in between (:51-65)
+          ("sparsematrix.h", 36, 49), ("text", "};"), ("sparsematrix.h", 67, 85)]
 
 
 def nvidia_include():

@@ -12,6 +12,8 @@
 // Every function takes n items; points are xyz triples.
 #include <type_traits>
 
+#include <list>
+
 extern "C" {
 
 void l3dref_set_launch(unsigned block_x, unsigned block_y, unsigned thread_x, unsigned thread_y, unsigned dim_x, unsigned dim_y);   // ref_devfn_launch.cc
@@ -101,6 +103,22 @@ void l3dref_collinearity(float* relation, int size, float coll_sigma_sqr, int st
             l3dref_set_launch((unsigned)(x / 16), (unsigned)(y / 16), (unsigned)(x % 16), (unsigned)(y % 16), 16, 16);     // dimBlock = (16, 16), cudawrapper.cu:842
             L3D::K_collinearity(relation, size, coll_sigma_sqr, stride);
         }
+}
+// sparsematrix.h:68-85 on a std::list, as compute_pairwise_matches (cudawrapper.cu:951: matches.sort(sortMatchingPairs)) and
+// L3DView::addMatches (view.cc:170: sortMatchingPairsByConf) use them.  perm[k] = input index of the k-th element after the sort.
+void l3dref_sort_matching_pairs(int n, const unsigned* seg1, const unsigned* cam2, const unsigned* seg2, const float* conf, int by_conf, int* perm)
+{
+    std::list<L3D::L3DMatchingPair> lst;
+    for (int i = 0; i < n; ++i) {
+        L3D::L3DMatchingPair mp;
+        mp.segID1_ = seg1[i]; mp.camID2_ = cam2[i]; mp.segID2_ = seg2[i]; mp.confidence_ = conf[i]; mp.active_ = true;
+        mp.depths_ = make_float4((float)i, 0.0f, 0.0f, 0.0f);                      // (the input index rides along)
+        lst.push_back(mp);
+    }
+    if (by_conf) lst.sort(L3D::sortMatchingPairsByConf);
+    else lst.sort(L3D::sortMatchingPairs);
+    int k = 0;
+    for (std::list<L3D::L3DMatchingPair>::const_iterator it = lst.begin(); it != lst.end(); ++it) perm[k++] = (int)it->depths_.x;
 }
 // helper_math.h (host definitions): normalize / cross / length / dot of float3 as the functions above see them
 void l3dref_normalize3(int n, const float* v, float* out) { for (int i = 0; i < n; ++i) st3(out, i, normalize(ld3(v, i))); }

@@ -505,3 +505,33 @@ def test_collinearity_kernel_matches_reference(oracle_lib):
             op.load_lib(libm=True).l3do_collinearity(p(sg), C.c_int(n), C.c_float(2.5), p(a))
             ref.l3dref_collinearity(p(b), C.c_int(n), C.c_float(2.5 * 2.5), C.c_int(n), p(sg))
             assert a.tobytes() == b.tobytes() and (b > 0).sum() > 40, seed
+
+
+def test_matching_pair_orders_match_reference_live(oracle_lib):
+    """The candidate order of compute_pairwise_matches (cudawrapper.cu:951: std::list::sort with sortMatchingPairs, sparsematrix.h:68-79) and the
+    only-best order of L3DView::addMatches (view.cc:170: sortMatchingPairsByConf, :81-85) by the reference's own comparators -- compiled from
+    sparsematrix.h's text without the boost members of the struct -- against the oracle's stable merge sort and the stable descending sort of
+    oracle/l3d_oracle_pipeline.py::add_matches; duplicate keys and equal confidences included (only stable sorts agree)."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_sort_matching_pairs"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so predates the comparator door")
+    rng = np.random.default_rng(8)
+    mdt = np.dtype([("segID1", np.uint32), ("camID2", np.uint32), ("segID2", np.uint32), ("depths", np.float32, 4), ("confidence", np.float32)])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for n, ns, nc, nt in ((50, 4, 3, 5), (5000, 40, 6, 30), (40000, 300, 12, 2000)):
+        m = np.zeros(n, mdt)
+        m["segID1"], m["camID2"], m["segID2"] = rng.integers(0, ns, n), rng.integers(0, nc, n), rng.integers(0, nt, n)
+        m["confidence"] = rng.choice(np.array([0.0, 0.5, 1.25, 2.0], np.float32), n) if n < 100 else rng.random(n).astype(np.float32).round(2)
+        m["depths"][:, 0] = np.arange(n)                                           # (tells equal keys apart)
+        perm = np.zeros(n, np.int32)
+        s1, c2, s2, cf = (np.ascontiguousarray(m[k]) for k in ("segID1", "camID2", "segID2", "confidence"))
+        ref.l3dref_sort_matching_pairs(C.c_int(n), p(s1), p(c2), p(s2), p(cf), C.c_int(0), p(perm))
+        mine = m.copy()
+        oracle_lib.l3do_sort_matches(p(mine), C.c_int(n))
+        assert mine.tobytes() == m[perm].tobytes(), n
+        ref.l3dref_sort_matching_pairs(C.c_int(n), p(s1), p(c2), p(s2), p(cf), C.c_int(1), p(perm))
+        assert perm.tolist() == sorted(range(n), key=lambda i: -float(cf[i])), n     # (Python's sort is stable: add_matches' only-best order)
+        assert len(np.unique(np.stack([s1, c2, s2]), axis=1).T) < n
