@@ -32,7 +32,9 @@
  *     forward motion, opposing cameras; > 10^6 pairs), l3do_verify the same confidences bit for bit (libm build; contract build within 5e-6 with
  *     the same kept set) on packed candidate lists with clusters, outliers, runs of one camera (tests/golden/pairwise_ref.npz, verify_ref.npz).
  *     Their three texture-reading callees D_epipolar_line, D_get_ray_tgt, D_project_point_tgt -- 3x3 / 3x4 matrix-vector products accumulated
- *     from 0.0f in index order -- are RESTATED over tables in that build (oracle/make_ref_devfn.py says which lines are whose).
+ *     from 0.0f in index order -- are RESTATED over tables in that build (oracle/make_ref_devfn.py says which lines are whose);
+ *   - end to end: l3do_set_kernel_hooks plugs those kernels into this file's host orchestration; a whole compute3Dmodel then equals the
+ *     un-hooked run bit for bit (tests/test_oracle_pins.py::test_pipeline_with_the_reference_kernels_equals_the_oracle).
  * Still "parity unpinned" by the reference, pinned by restatement, analytic known-answer scenes and committed vectors
  * only: those three matrix-vector products (K_collinearity too is compiled whole, :476-535 with its fetches as table reads, and reproduced
  * bit for bit by l3do_collinearity in the libm build),
@@ -254,6 +256,26 @@ static float hypothesis_confidence(f3 p1, f3 p2, f3 P1, f3 P2, f3 Q1, f3 Q2, f3 
 /* ------------------------------------------------------------------------- */
 /* K_collinearity, cudawrapper.cu:476-535 (+ compute_collinearity :833-855:
  * sigma passed squared).  relation is dense S x S, row-major. */
+/* ------------------------------------------------------------------------- */
+/* Kernel hooks (tests/test_oracle_pins.py): with them set, the host orchestration below runs the REFERENCE's own kernels -- oracle/_ref/
+ * libdevfn_ref.so, compiled from cudawrapper.cu's text -- in place of this file's restatements: the whole pipeline with the reference's
+ * kernels inside the restated host code must give what it gives without them, bit for bit (libm build).  NULL = restatement. */
+typedef void (*l3do_hook_collin)(float* relation, int size, float coll_sigma_sqr, int stride, const float* segs);
+typedef void (*l3do_hook_dense)(float* buffer, int width, int height, const float* RtKinv_src, int r_stride, int offset, int cID, const float* C_src,
+                                int stride, const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers);
+typedef void (*l3do_hook_verify)(float* matches_data, const float* matches_depths, const int* match_offsets, const int* camera_offsets, int size,
+                                 const float* src_segs, const float* RtKinv, int r_stride, const float* C_src, const float* tgt_segs, const float* P,
+                                 float sigma_p, float sigma_a, float spatial_k);
+typedef void (*l3do_hook_norm)(float* data, const int* start_indices, int num_rows, int num_entries);
+typedef void (*l3do_hook_step)(const float* P, const float* W, const int* P_rows, const int* W_cols, float* P_prime, const int* P_prime_rows, int num_entries);
+static l3do_hook_collin g_hook_collin = 0;
+static l3do_hook_dense g_hook_dense = 0;
+static l3do_hook_verify g_hook_verify = 0;
+static l3do_hook_norm g_hook_norm = 0;
+static l3do_hook_step g_hook_step = 0;
+void l3do_set_kernel_hooks(l3do_hook_collin collin, l3do_hook_dense dense, l3do_hook_verify verify, l3do_hook_norm norm, l3do_hook_step step)
+{ g_hook_collin = collin; g_hook_dense = dense; g_hook_verify = verify; g_hook_norm = norm; g_hook_step = step; }
+
 /* the kernel's body for one pair of segments, cudawrapper.cu:492-529 behind the four texture fetches (pinned to the reference's own
  * lines: tests/test_oracle_pins.py, `collinearity_pair`) */
 static float collinearity_pair(f3 p1, f3 p2, f3 q1, f3 q2, float coll_sigma_sqr)
@@ -278,6 +300,7 @@ static float collinearity_pair(f3 p1, f3 p2, f3 q1, f3 q2, float coll_sigma_sqr)
 void l3do_collinearity(const float* segs, int S, float collin_s, float* relation)
 {
     float coll_sigma_sqr = collin_s * collin_s;
+    if (g_hook_collin) { g_hook_collin(relation, S, coll_sigma_sqr, S, segs); return; }
     for (int y = 0; y < S; ++y)
         for (int x = 0; x < S; ++x) {
             if (x == y) {
@@ -532,9 +555,16 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
         int localID = toBeMatched[t];
         int feature_offset = offsets[localID * 2 + 0];
         int width = offsets[localID * 2 + 1];
+        float* dense = NULL;
+        if (g_hook_dense) {                                       /* the reference's kernel fills the whole S_src x width buffer (915-923) */
+            dense = (float*)calloc((size_t)S_src * (size_t)(width > 0 ? width : 1) * 4, sizeof(float));
+            g_hook_dense(dense, width, S_src, RtKinv_src, 3, feature_offset, localID, C_src, width, src_segs, tgt_segs, F, RtKinv, centers);
+        }
         for (int i = seg_begin; i < seg_end; ++i)
             for (int j = 0; j < width; ++j) {
-                f4 d = pairwise_one(src_segs, i, RtKinv_src, C, tgt_segs, feature_offset, j, localID, F, RtKinv, centers);
+                f4 d;
+                if (dense) { const float* q = dense + ((size_t)i * width + j) * 4; d.x = q[0]; d.y = q[1]; d.z = q[2]; d.w = q[3]; }
+                else d = pairwise_one(src_segs, i, RtKinv_src, C, tgt_segs, feature_offset, j, localID, F, RtKinv, centers);
                 if (d.x > 0.0f && d.y > 0.0f && d.z > 0.0f && d.w > 0.0f) {
                     if (n == cap) { cap *= 2; M = (l3do_match*)realloc(M, cap * sizeof(l3do_match)); }
                     l3do_match mp;
@@ -544,6 +574,7 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
                     M[n++] = mp;
                 }
             }
+        free(dense);
         pairs += (double)(seg_end - seg_begin) * width;
     }
 
@@ -589,8 +620,9 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
     }
 
     /* verify, 1013 */
-    l3do_verify(data, dep, moff, offsets, (int)n, src_segs, RtKinv_src, C_src, tgt_segs, P,
-                sigma_p, sigma_a, spatial_k, 0, (int)n);
+    if (g_hook_verify) g_hook_verify(data, dep, moff, offsets, (int)n, src_segs, RtKinv_src, 3, C_src, tgt_segs, P, sigma_p, sigma_a, spatial_k);
+    else l3do_verify(data, dep, moff, offsets, (int)n, src_segs, RtKinv_src, C_src, tgt_segs, P,
+                     sigma_p, sigma_a, spatial_k, 0, (int)n);
 
     /* best / median, 1025-1076 */
     float* dlist = (float*)malloc(((size_t)S_src * 2 + 2) * sizeof(float));
@@ -776,7 +808,7 @@ static void norm_default(float* data, const int* s, int nr, int ne) { row_normal
 static void step_default(const float* P, const float* W, const int* Pr, const int* Wc, float* Pp, const int* Ppr, int ne)
 { diffusion_step((const f4*)P, (const f4*)W, Pr, Wc, (f4*)Pp, Ppr, ne); }
 void l3do_rdd_hooked(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out, l3do_norm_fn norm, l3do_step_fn step);
-void l3do_rdd(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out) { l3do_rdd_hooked(A, nnz, n, iters, out, 0, 0); }
+void l3do_rdd(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out) { l3do_rdd_hooked(A, nnz, n, iters, out, g_hook_norm, g_hook_step); }
 void l3do_rdd_hooked(const l3do_edge* A, int nnz, int n, int iters, l3do_edge* out, l3do_norm_fn norm, l3do_step_fn step)
 {
     if (!norm) norm = norm_default;

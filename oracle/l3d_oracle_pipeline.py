@@ -143,6 +143,18 @@ def rdd(lib, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
     return out
 
 
+def set_reference_kernels(lib, ref):
+    """Run the oracle's host orchestration with the REFERENCE's own kernels (ref = oracle/_ref/libdevfn_ref.so: K_collinearity, K_pairwise_matches,
+    K_verify_matches, K_sparseMat_row_normalization, K_sparseMat_diffusion_step compiled from cudawrapper.cu's text); ref = None: back to the
+    restatements.  Process-wide for that library."""
+    if ref is None:
+        lib.l3do_set_kernel_hooks(None, None, None, None, None)
+        return
+    ptr = lambda f: C.cast(f, C.c_void_p)
+    lib.l3do_set_kernel_hooks(ptr(ref.l3dref_collinearity), ptr(ref.l3dref_pairwise_matches), ptr(ref.l3dref_verify_matches),
+                              ptr(ref.l3dref_sparse_row_normalization), ptr(ref.l3dref_sparse_diffusion_step))
+
+
 def pairwise_dense_view(lib, mv, cam, reference=None):
     """The dense S x width float4 buffer K_pairwise_matches fills for neighbour `cam` of a marshalled view (marshal_view): the oracle's
     l3do_pairwise_dense, or -- reference = oracle/_ref/libdevfn_ref.so -- the reference's own kernel text (l3dref_pairwise_matches)."""

@@ -1,6 +1,7 @@
 """End-to-end parity of the HIP pipeline (L3D::Line3D mirror over the C ABI) against the oracle pipeline:
 per-view kept matches bit-exact, affinity edges bit-exact, 3-D lines set-identical on 2-D segment ids
 and within 1e-4 on endpoint coordinates (the tolerance BASELINE.json's north_star states)."""
+import os
 import numpy as np
 import pytest
 
@@ -766,3 +767,41 @@ def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, mon
         _check_against_oracle(q, small_oracle)
         assert _products_digest(q) == want, "rank %d" % r
         q.close()
+
+
+def test_product_against_the_reference_kernels_pipeline(small_scene):
+    """The product against a pipeline whose kernels are the REFERENCE's own (K_collinearity, K_pairwise_matches, K_verify_matches, the diffusion
+    kernels: oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the same
+    correspondence ids in every view, confidences within 5e-6 (the product's expf / acosf are the numeric contract's), medians equal, the same
+    3-D lines within 1e-4 -- BASELINE's acceptance rule, checked against the reference's arithmetic directly."""
+    import ctypes as C
+    from line3d_amd.pipeline import Line3D, load_scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path) or not hasattr(C.CDLL(path), "l3dref_pairwise_matches"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so with the reference's kernels is not built")
+    ref = C.CDLL(path)
+    lib = op.load_lib(libm=True)
+    try:
+        op.set_reference_kernels(lib, ref)
+        o = op.run_scene(small_scene, 6, libm=True)
+    finally:
+        op.set_reference_kernels(lib, None)
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.compute3Dmodel(False)
+    n = 0
+    for v in sorted(o.trace):
+        got, med = l.view_matches(v)
+        want = o.trace[v]["matches"]
+        assert len(got) == len(want), v
+        for k in ("segID1", "camID2", "segID2"):
+            assert np.array_equal(got[k], want[k]), (v, k)
+        assert np.max(np.abs(got["confidence"] - want["confidence"]), initial=0) <= 5e-6
+        assert got["depths"].tobytes() == want["depths"].tobytes()
+        assert np.float32(med) == np.float32(o.trace[v]["median"])
+        n += len(got)
+    assert n > 1000
+    assert_lines_equal(l.getResult(), o.result, 1e-4)
+    l.close()

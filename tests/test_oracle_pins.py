@@ -535,3 +535,37 @@ def test_matching_pair_orders_match_reference_live(oracle_lib):
         ref.l3dref_sort_matching_pairs(C.c_int(n), p(s1), p(c2), p(s2), p(cf), C.c_int(1), p(perm))
         assert perm.tolist() == sorted(range(n), key=lambda i: -float(cf[i])), n     # (Python's sort is stable: add_matches' only-best order)
         assert len(np.unique(np.stack([s1, c2, s2]), axis=1).T) < n
+
+
+@pytest.mark.parametrize("diffusion", [False, True])
+def test_pipeline_with_the_reference_kernels_equals_the_oracle(small_scene, diffusion):
+    """The whole of compute3Dmodel with the REFERENCE's own kernels inside the oracle's host code (l3do_set_kernel_hooks: K_collinearity,
+    K_pairwise_matches, K_verify_matches and the two diffusion kernels out of oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text)
+    against the oracle's restatements, libm build: kept lists, medians, affinity list and 3-D lines bit for bit -- on the 10-view test scene and
+    on cameras that face each other / move forward."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+    ref = C.CDLL(path)
+    if not hasattr(ref, "l3dref_pairwise_matches"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so predates the kernels")
+    from line3d_amd.synth import make_scene_from_poses
+    lib = op.load_lib(libm=True)
+    scenes = [(small_scene, 6), (make_scene_from_poses([(4, 0, 0), (-4, 0.2, 0.3), (0, 0.1, 4), (3.0, 0.1, 0.05), (1.5, 0.2, 0.1)], [(0, 0, 0)] * 5, 160, seed=29), 4)]
+    kept = 0
+    for scene, N in scenes:
+        a = op.run_scene(scene, N, perform_diffusion=diffusion, libm=True)
+        try:
+            op.set_reference_kernels(lib, ref)
+            b = op.run_scene(scene, N, perform_diffusion=diffusion, libm=True)
+        finally:
+            op.set_reference_kernels(lib, None)
+        for v in sorted(a.trace):
+            assert a.trace[v]["matches"].tobytes() == b.trace[v]["matches"].tobytes(), v
+            assert np.float32(a.trace[v]["median"]).tobytes() == np.float32(b.trace[v]["median"]).tobytes(), v
+            kept += len(a.trace[v]["matches"])
+        assert a.affinity.tobytes() == b.affinity.tobytes()
+        assert len(a.result) == len(b.result)
+        for (s2a, s3a), (s2b, s3b) in zip(a.result, b.result):
+            assert s2a == s2b and np.asarray(s3a).tobytes() == np.asarray(s3b).tobytes()
+    assert kept > 3000
