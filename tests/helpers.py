@@ -92,16 +92,20 @@ def digest_lists(lists):
     return h.hexdigest()
 
 
-def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None):
+def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None, reference=None):
     """compute_pairwise_matches of the oracle for source segments [seg_lo, seg_hi) of view `vid` in the state matchViews has
     when it reaches that view (line3D.cc:620-648): matched_ after views 0..vid-1 (:875-881) and, as the existing matches
     (view.cc:200-224), the kept matches of the earlier views towards `vid` taken from `lists` (view id -> (matches, median);
     view ids are 0..V-1 in processing order).  The range is cut into one piece per host thread (the C oracle releases the
-    GIL; a source segment's verification only reads that segment's candidates, so the pieces concatenate)."""
+    GIL; a source segment's verification only reads that segment's candidates, so the pieces concatenate).
+    reference = oracle/_ref/libdevfn_ref.so: the libm build of the oracle with the REFERENCE's own kernels plugged in (one thread: their launch
+    variables are process globals)."""
     import os
     import threading
     import l3d_oracle_pipeline as op
-    o = op.OracleLine3D(matching_neighbors=N, use_collinearity=False)
+    o = op.OracleLine3D(matching_neighbors=N, use_collinearity=False, libm=reference is not None)
+    if reference is not None:
+        threads = 1
     for v in scene.views:
         o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
     o.computation = True
@@ -140,6 +144,13 @@ def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None):
             o.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
             mv["centers"], mv["P"], mv["tbm"], existing, mv["l2g"], mv["k_upper"], mv["k_lower"], 3.5, 10.0, mv["spatial_k"],
             seg_range=(cuts[i], cuts[i + 1]))[0]
+    if reference is not None:
+        try:
+            op.set_reference_kernels(o.lib, reference)
+            work(0)
+        finally:
+            op.set_reference_kernels(o.lib, None)
+        return np.concatenate(parts), mv, existing
     th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
     for t in th:
         t.start()

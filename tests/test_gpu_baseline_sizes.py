@@ -5,6 +5,8 @@ The oracle needs ~25 s for one whole 2000-segment view, so whole scenes are cove
 the conservative stage-1 filters and the depth-window search change nothing against the exact sequence / the all-pairs loop
 on EVERY pair of the scene -- and the oracle pins slices of early, mid-chain, late and early-return views bit for bit
 (reference: line3D.cc:620-648, cudawrapper.cu:858-1128)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -93,6 +95,26 @@ def test_config2_view_slices_against_the_oracle(cfg2_scene, cfg2_chain, vid, lo,
     else:
         assert len(mv["tbm"]) == min(6, 63 - vid) and (vid < 12 or len(existing) > 10000)
     assert len(exp) > 500 and got.tobytes() == exp.tobytes()
+
+
+def test_config2_mid_chain_slice_against_the_reference_kernels(cfg2_scene, cfg2_chain):
+    """The same mid-chain slice (view 33, 128 source segments) with the REFERENCE's own K_pairwise_matches and K_verify_matches
+    (oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the product keeps
+    the same correspondences with the same depths; confidences within 5e-6 (contract vs glibc expf / acosf)."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libdevfn_ref.so")
+    if not os.path.exists(path) or not hasattr(C.CDLL(path), "l3dref_pairwise_matches"):
+        pytest.skip("oracle/_ref/libdevfn_ref.so with the reference's kernels is not built")
+    _l, lists = cfg2_chain
+    vid, lo, hi = 33, 900, 1028
+    exp, mv, existing = oracle_view_slice(cfg2_scene, lists, vid, lo, hi, N2, reference=C.CDLL(path))
+    got = lists[vid][0]
+    got = got[(got["segID1"] >= lo) & (got["segID1"] < hi)]
+    assert len(exp) > 300 and len(got) == len(exp) and len(existing) > 10000
+    for k in ("segID1", "camID2", "segID2"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert got["depths"].tobytes() == exp["depths"].tobytes()
+    assert np.max(np.abs(got["confidence"] - exp["confidence"])) <= 5e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------------
