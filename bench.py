@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--neighbors", type=int, default=12)
     ap.add_argument("--seed", type=int, default=20260)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-segments", type=int, default=1500)
+    ap.add_argument("--cpu-sample-segments", type=int, default=800)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) rest of compute3Dmodel after the timed passes")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold measurement (first matchViews + first finish of the fresh object)")
@@ -124,13 +124,40 @@ def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
         dta = time.time() - t1
         all_threads = dict(value=float(sum(r for r in res if r)) / dta, cores=nthreads, seconds=dta,
                            sample="%d threads (usable CPUs of this container) x %d source segments of view %d" % (nthreads, per, vid))
-    return dict(value=stats[3] / dt, unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
-                sample="view %d of %d of the bench scene (mid-chain: %d cameras still to match, %d existing reverse matches from the %d already "
-                       "matched), first %d of %d source segments: %d pairs, %d raw candidates, %.3g verify inner iterations, %.1f s on 1 thread "
-                       "(oracle/l3d_oracle.c, reference formulation)"
-                       % (vid, V, len(mv["tbm"]), len(existing), len(mv["l2g"]) - len(mv["tbm"]), sample_segments, len(mv["src_segs"]), int(stats[3]),
-                          int(stats[0]), stats[2], dt),
-                seconds=dt, verify_iterations_per_s=stats[2] / dt)
+    port = dict(value=stats[3] / dt, cores=1, seconds=dt, verify_iterations_per_s=stats[2] / dt,
+                note="oracle/l3d_oracle.c: the scalar C restatement of the same formulation")
+    sample = ("view %d of %d of the bench scene (mid-chain: %d cameras still to match, %d existing reverse matches from the %d already "
+              "matched), first %d of %d source segments: %d pairs, %d raw candidates, %.3g verify inner iterations, %.1f s on 1 thread"
+              % (vid, V, len(mv["tbm"]), len(existing), len(mv["l2g"]) - len(mv["tbm"]), sample_segments, len(mv["src_segs"]), int(stats[3]),
+                 int(stats[0]), stats[2], dt))
+    # the same sample (half of it) with the REFERENCE's own kernels: K_pairwise_matches and K_verify_matches compiled from cudawrapper.cu's text
+    # (oracle/_ref/libdevfn_ref.so, built in the container where /root/reference exists and carried along) inside the oracle's host code
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    if os.path.exists(ref_path):
+        import ctypes as C
+        ref = C.CDLL(ref_path)
+        if hasattr(ref, "l3dref_pairwise_matches") and hasattr(ref, "l3dref_verify_matches"):
+            half = max(1, sample_segments // 2)                  # (the reference's kernels run at about a third of the port's rate: same wall time)
+            ol = op.OracleLine3D(matching_neighbors=n_neighbors, use_collinearity=False, libm=True)
+            try:
+                op.set_reference_kernels(ol.lib, ref)
+                t2 = time.time()
+                _m, _med, st2 = op.compute_pairwise_matches(
+                    ol.lib, mv["src_segs"], mv["RtKinv_src"], mv["C_src"], mv["tgt_segs"], mv["offsets"], mv["F"], mv["RtKinv"],
+                    mv["centers"], mv["P"], mv["tbm"], existing, mv["l2g"], mv["k_upper"], mv["k_lower"],
+                    3.5, 10.0, mv["spatial_k"], seg_range=(0, half), want_stats=True)
+                dt2 = time.time() - t2
+            finally:
+                op.set_reference_kernels(ol.lib, None)
+            return dict(value=st2[3] / dt2, unit="segment-pair affinities/s", cores=1, kind="reference", seconds=dt2,
+                        verify_iterations_per_s=st2[2] / dt2, all_threads=all_threads, port=port,
+                        sample="the reference's own K_pairwise_matches + K_verify_matches (compiled from cudawrapper.cu's text with g++ -O2, texture fetches "
+                               "as table reads: oracle/_ref/libdevfn_ref.so) inside the oracle's restatement of compute_pairwise_matches' host code, "
+                               "1 thread, first %d source segments of view %d of the bench scene (%d pairs, %.1f s); `port`: the oracle's own scalar "
+                               "C kernels on the first %d segments (%s); `all_threads`: the port on every usable core"
+                               % (half, vid, int(st2[3]), dt2, sample_segments, sample))
+    return dict(value=port["value"], unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
+                sample=sample + " (oracle/l3d_oracle.c, reference formulation)", seconds=dt, verify_iterations_per_s=port["verify_iterations_per_s"])
 
 
 def workload_name(n_gpus, V, S, N):

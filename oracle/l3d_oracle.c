@@ -262,7 +262,8 @@ static float hypothesis_confidence(f3 p1, f3 p2, f3 P1, f3 P2, f3 Q1, f3 Q2, f3 
  * kernels inside the restated host code must give what it gives without them, bit for bit (libm build).  NULL = restatement. */
 typedef void (*l3do_hook_collin)(float* relation, int size, float coll_sigma_sqr, int stride, const float* segs);
 typedef void (*l3do_hook_dense)(float* buffer, int width, int height, const float* RtKinv_src, int r_stride, int offset, int cID, const float* C_src,
-                                int stride, const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers);
+                                int stride, const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers,
+                                int y_begin, int y_end);
 typedef void (*l3do_hook_verify)(float* matches_data, const float* matches_depths, const int* match_offsets, const int* camera_offsets, int size,
                                  const float* src_segs, const float* RtKinv, int r_stride, const float* C_src, const float* tgt_segs, const float* P,
                                  float sigma_p, float sigma_a, float spatial_k);
@@ -556,9 +557,9 @@ int l3do_compute_pairwise_matches(const float* src_segs, int S_src, const float*
         int feature_offset = offsets[localID * 2 + 0];
         int width = offsets[localID * 2 + 1];
         float* dense = NULL;
-        if (g_hook_dense) {                                       /* the reference's kernel fills the whole S_src x width buffer (915-923) */
+        if (g_hook_dense) {                                       /* the reference's kernel fills the S_src x width buffer (915-923; here: the rows asked for) */
             dense = (float*)calloc((size_t)S_src * (size_t)(width > 0 ? width : 1) * 4, sizeof(float));
-            g_hook_dense(dense, width, S_src, RtKinv_src, 3, feature_offset, localID, C_src, width, src_segs, tgt_segs, F, RtKinv, centers);
+            g_hook_dense(dense, width, S_src, RtKinv_src, 3, feature_offset, localID, C_src, width, src_segs, tgt_segs, F, RtKinv, centers, seg_begin, seg_end);
         }
         for (int i = seg_begin; i < seg_end; ++i)
             for (int j = 0; j < width; ++j) {

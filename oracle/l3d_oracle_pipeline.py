@@ -167,7 +167,7 @@ def pairwise_dense_view(lib, mv, cam, reference=None):
         lib.l3do_pairwise_dense(p(src), C.c_int(S), p(Rs), p(Cs), p(tgt), C.c_int(off), C.c_int(w), C.c_int(cam), p(F), p(R), p(Cn), p(out))
     else:
         reference.l3dref_pairwise_matches(p(out), C.c_int(w), C.c_int(S), p(Rs), C.c_int(3), C.c_int(off), C.c_int(cam), p(Cs), C.c_int(w), p(src), p(tgt),
-                                          p(F), p(R), p(Cn))
+                                          p(F), p(R), p(Cn), C.c_int(0), C.c_int(S))
     return out
 
 

@@ -83,11 +83,12 @@ void l3dref_verify_matches(float* matches_data, const float* matches_depths, con
 }
 // cudawrapper.cu:538-611: K_pairwise_matches for one neighbour camera, one thread at a time over the height x width grid (make_ref_devfn.py: the
 // kernel's text except its texture fetches; D_epipolar_line / D_get_ray_tgt bound to tables).  buffer: height x stride float4.
+// [y_begin, y_end): the rows (source segments) to run -- the kernel's own bound is `height`
 void l3dref_pairwise_matches(float* buffer, int width, int height, const float* RtKinv_src, int r_stride, int offset, int cID, const float* C_src, int stride,
-                             const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers)
+                             const float* src_segs, const float* tgt_segs, const float* F, const float* RtKinv_tgt, const float* centers, int y_begin, int y_end)
 {
     L3D::l3dref_tab_src = src_segs; L3D::l3dref_tab_tgt = tgt_segs; L3D::l3dref_tab_F = F; L3D::l3dref_tab_R = RtKinv_tgt; L3D::l3dref_tab_C = centers;
-    for (int y = 0; y < height; ++y)
+    for (int y = y_begin < 0 ? 0 : y_begin; y < (y_end < height ? y_end : height); ++y)
         for (int x = 0; x < width; ++x) {
             l3dref_set_launch((unsigned)(x / 16), (unsigned)(y / 16), (unsigned)(x % 16), (unsigned)(y % 16), 16, 16);     // dimBlock = (16, 16), cudawrapper.cu:900
             L3D::K_pairwise_matches(reinterpret_cast<float4*>(buffer), width, height, RtKinv_src, offset, cID, make_float3(C_src[0], C_src[1], C_src[2]), stride, r_stride);
