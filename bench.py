@@ -130,14 +130,17 @@ def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
               "matched), first %d of %d source segments: %d pairs, %d raw candidates, %.3g verify inner iterations, %.1f s on 1 thread"
               % (vid, V, len(mv["tbm"]), len(existing), len(mv["l2g"]) - len(mv["tbm"]), sample_segments, len(mv["src_segs"]), int(stats[3]),
                  int(stats[0]), stats[2], dt))
-    # the same sample (half of it) with the REFERENCE's own kernels: K_pairwise_matches and K_verify_matches compiled from cudawrapper.cu's text
-    # (oracle/_ref/libdevfn_ref.so, built in the container where /root/reference exists and carried along) inside the oracle's host code
-    ref_path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    out = dict(value=port["value"], unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
+               sample=sample + " (oracle/l3d_oracle.c, reference formulation)", seconds=dt, verify_iterations_per_s=port["verify_iterations_per_s"])
+    # beside it, half of the same sample with the reference's KERNEL TEXT: K_pairwise_matches and K_verify_matches assembled from cudawrapper.cu's lines
+    # with builder-written table reads in place of the texture fetches (oracle/_spliced/libkernels_spliced.so -- corroboration, NOT "the reference
+    # compiled here", hence not the headline of this object) inside the oracle's host code
+    ref_path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if os.path.exists(ref_path):
         import ctypes as C
         ref = C.CDLL(ref_path)
         if hasattr(ref, "l3dref_pairwise_matches") and hasattr(ref, "l3dref_verify_matches"):
-            half = max(1, sample_segments // 2)                  # (the reference's kernels run at about a third of the port's rate: same wall time)
+            half = max(1, sample_segments // 2)                  # (those kernels run at about a third of the port's rate: same wall time)
             ol = op.OracleLine3D(matching_neighbors=n_neighbors, use_collinearity=False, libm=True)
             try:
                 op.set_reference_kernels(ol.lib, ref)
@@ -149,15 +152,12 @@ def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
                 dt2 = time.time() - t2
             finally:
                 op.set_reference_kernels(ol.lib, None)
-            return dict(value=st2[3] / dt2, unit="segment-pair affinities/s", cores=1, kind="reference", seconds=dt2,
-                        verify_iterations_per_s=st2[2] / dt2, all_threads=all_threads, port=port,
-                        sample="the reference's own K_pairwise_matches + K_verify_matches (compiled from cudawrapper.cu's text with g++ -O2, texture fetches "
-                               "as table reads: oracle/_ref/libdevfn_ref.so) inside the oracle's restatement of compute_pairwise_matches' host code, "
-                               "1 thread, first %d source segments of view %d of the bench scene (%d pairs, %.1f s); `port`: the oracle's own scalar "
-                               "C kernels on the first %d segments (%s); `all_threads`: the port on every usable core"
-                               % (half, vid, int(st2[3]), dt2, sample_segments, sample))
-    return dict(value=port["value"], unit="segment-pair affinities/s", cores=1, kind="port", all_threads=all_threads,
-                sample=sample + " (oracle/l3d_oracle.c, reference formulation)", seconds=dt, verify_iterations_per_s=port["verify_iterations_per_s"])
+            out["reference_kernel_text_spliced"] = dict(
+                value=st2[3] / dt2, cores=1, seconds=dt2, verify_iterations_per_s=st2[2] / dt2,
+                sample="K_pairwise_matches + K_verify_matches from cudawrapper.cu's lines (g++ -O2; texture fetches replaced by builder-written table reads, "
+                       "launch variables supplied by the builder: oracle/_spliced/libkernels_spliced.so) inside the oracle's restatement of "
+                       "compute_pairwise_matches' host code, 1 thread, first %d source segments of view %d (%d pairs, %.1f s)" % (half, vid, int(st2[3]), dt2))
+    return out
 
 
 def workload_name(n_gpus, V, S, N):
@@ -327,7 +327,7 @@ def main():
         def prof_json(kind):
             """profiles/<round>_<kind>.json of the newest round that has one: per-kernel PMC figures of this same command (scripts/measure_round.sh),
             stamped with the commit they were measured on -- NOT measured in this run."""
-            for r in ("r3", "r2", "r1"):
+            for r in ("r4", "r3", "r2", "r1"):
                 q = os.path.join(ROOT, "profiles", "%s_%s.json" % (r, kind))
                 if os.path.exists(q):
                     d = json.load(open(q))
@@ -336,7 +336,11 @@ def main():
 
         traffic_json, traffic_src = prof_json("traffic")
         valu_json, valu_src = prof_json("valu")
-        PEAK_ISSUE = 256 * 4 * 2.4e9 / 4.0      # wave64 VALU instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, one instruction per SIMD every 4 cycles
+        # wave64 VALU instructions/s the chip can issue: 256 CUs x 4 SIMD-32s x 2.4 GHz, one wave64 instruction per SIMD every 2 cycles
+        # (MI355X_MICROARCH.md, constants table: `v_fma_f32` (wave64) 2 cyc; 4 is what ONE wave alone sustains).  Equivalent to the 157.3 TFLOP/s
+        # FP32 vector peak (64 lanes x 2 flop per FMA).  Transcendental / rcp / sqrt instructions cost twice that; the count below is unweighted,
+        # profiles/r4_stalls.json carries the weighted figure (`valu_pipe_frac_trans_weighted`).
+        PEAK_ISSUE = 256 * 4 * 2.4e9 / 2.0
 
         def kernel_roof(name, launches, ms):
             # algorithmic HBM bytes per launch: one launch = one view
@@ -365,7 +369,7 @@ def main():
                 ach = vi / (avg_ms * 1e-3)
                 out.update(achieved=ach / 1e9, peak=PEAK_ISSUE / 1e9, unit="G wave-instructions/s", frac=ach / PEAK_ISSUE, valu_wave_insts_per_launch=vi, source=valu_src,
                            note="issue fraction: SQ_INSTS_VALU per launch (rocprofv3 --pmc pass of this command, committed under profiles/ at the commit "
-                                "named in `source`) / launch duration by HIP events in this run / (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)")
+                                "named in `source`) / launch duration by HIP events in this run / (256 CUs x 4 SIMD-32s x 2.4 GHz / 2 cycles per wave64 instruction)")
             else:
                 out.update(achieved=hbm_achieved, peak=8000.0, unit="GB/s", frac=hbm_achieved / 8000.0, bound="hbm",
                            note="no committed VALU profile found: the HBM figure stands in (the path is VALU bound, SURVEY 8d)")

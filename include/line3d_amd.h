@@ -195,7 +195,10 @@ int l3d_fit_clusters(l3d_ctx* ctx, const int32_t* group_start, int n_groups, con
  * order (the reference's std::map), members in key order, those with >= 4 members seen from >= 4 cameras are fitted as above.
  * labels / node_hyp (n_nodes each): cluster label and hypothesis index of every node of the affinity list; NULL: the arrays
  * l3d_perform_clustering_device / l3d_affinity_fill* left on the device.  Out (callee-allocated, l3d_free): the fitted
- * clusters -- group_start (n_groups + 1) into member_hyp -- and seg_count / segs as l3d_fit_clusters. */
+ * clusters -- group_start (n_groups + 1) into member_hyp -- and seg_count / segs as l3d_fit_clusters.
+ * PRECONDITION: hyp_cam is non-decreasing in the hypothesis index (hypotheses numbered view by view, as greedySelection numbers
+ * them, line3D.cc:899-965): the distinct cameras of a cluster are counted as camera changes between members in hypothesis
+ * order.  Checked; L3D_ERR_INVALID otherwise. */
 int l3d_fit_labelled_clusters(l3d_ctx* ctx, const int32_t* labels, const int32_t* node_hyp, int n_nodes, const l3d_hypothesis* hyp,
                               const uint32_t* hyp_cam, int n_hyp, const double* Rinv, double scale_inv, const double* tneg,
                               int32_t** group_start, int32_t** member_hyp, int* n_groups, int32_t** seg_count, double** segs, int* n_segs);
@@ -361,6 +364,11 @@ int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
  * bit 1 = overlap-bound test; 3 = both (default), 0 = none (A/B testing: results are bit-identical, a filter only rejects
  * pairs the exact sequence rejects) */
 int l3d_set_pair_pretest(l3d_ctx* ctx, int mask);
+/* Diagnostic / A-B switches (line3d_amd/csrc/l3d_options.hpp lists them with their meaning).  The environment (L3D_<NAME>) is
+ * read ONCE, when the context is created; afterwards a switch changes only through this call.  name: "L3D_TIMING", "TIMING" or
+ * "timing".  No switch selects a CPU path for the arithmetic.  L3D_ERR_INVALID for an unknown name. */
+int l3d_set_option(l3d_ctx* ctx, const char* name, int value);
+int l3d_get_option(l3d_ctx* ctx, const char* name, int* value);
 /* testing: cap the LDS image of the depth-window kernel (bytes; 0 = device limit) so that segments take the
  * global-scratch variant; process-wide */
 int l3d_set_verify_lds_budget(size_t bytes);

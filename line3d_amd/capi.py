@@ -126,6 +126,15 @@ class Context:
     def set_verify_mode(self, mode: int):
         self._chk(self.lib.l3d_set_verify_mode(self.h, C.c_int(mode)))
 
+    def set_option(self, name: str, value: int):
+        """A diagnostic / A-B switch of the context (l3d_options.hpp); the environment is read once, at context creation."""
+        self._chk(self.lib.l3d_set_option(self.h, name.encode(), C.c_int(int(value))))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._chk(self.lib.l3d_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def last_stats(self):
         s = (C.c_double * 4)()
         self._chk(self.lib.l3d_last_stats(self.h, s))

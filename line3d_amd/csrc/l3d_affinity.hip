@@ -446,7 +446,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
 {
     const int V = a.n_views, nh = a.n_hyp, nd = a.n_dense;
     hipStream_t st = c->stream;
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = c->opt.timing != 0;
     double tl = now_s();
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = now_s(); fprintf(stderr, "[l3d affinity] %-34s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -458,7 +458,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
         HIPCHK(c, hipMemsetAsync(a.flags, 0, (size_t)n_pot + 4, st));
     }
     a.chunk = 64;
-    if (const char* e = getenv("L3D_AFF_CHUNK")) a.chunk = std::max(1, std::min(64, atoi(e)));       // tests: forces multi-pass groups on small scenes
+    if (c->opt.aff_chunk > 0) a.chunk = std::min(64, c->opt.aff_chunk);       // tests: forces multi-pass groups on small scenes
     char* const base = nullptr; (void)base;
     int maxS = 1;
     for (int v = 0; v < V; ++v) maxS = std::max(maxS, seg_base_h[v + 1] - seg_base_h[v]);
@@ -488,7 +488,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     std::vector<int> cut((size_t)V, 0);
     HIPCHK(c, hipMemcpyAsync(cut.data(), needs_prev, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    const bool per_view = getenv("L3D_AFF_PER_VIEW") && atoi(getenv("L3D_AFF_PER_VIEW")) != 0;   // tests: the general schedule everywhere
+    const bool per_view = c->opt.aff_per_view != 0;   // tests: the general schedule everywhere
     int n_launches = 0;
     for (int v0 = 0; v0 < V;) {
         int v1 = v0 + 1;
@@ -673,7 +673,14 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
     if (coll_start[0] != 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_coll > 0 && (!coll_other || !coll_w))) return fail(c, L3D_ERR_INVALID, "affinity fill: bad collinearity table");
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_cs = 0, o_co = al((size_t)(nd + 1) * 8), o_cw = o_co + al((size_t)n_coll * 4 + 4), o_sb = o_cw + al((size_t)n_coll * 4 + 4);
-    if (coll_changed || P.coll_n != n_coll || P.coll.cap < o_sb + al((size_t)(V + 1) * 4)) {
+    // the resident copy is reused only for the table it was uploaded from: the caller's flag, and -- because that flag is kept by host code
+    // that also feeds the non-resident fill -- sizes and a checksum of the row starts and of the dense map
+    unsigned long long sig = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix((unsigned long long)nd); mix((unsigned long long)V); mix((unsigned long long)n_coll);
+    for (int k = 0; k <= nd; ++k) mix((unsigned long long)coll_start[k]);
+    for (int v = 0; v <= V; ++v) mix((unsigned long long)P.seg_base[(size_t)v]);
+    if (coll_changed || P.coll_n != n_coll || P.coll_sig != sig || P.coll.cap < o_sb + al((size_t)(V + 1) * 4)) {
         HIPCHK(c, P.coll.reserve(o_sb + al((size_t)(V + 1) * 4)));
         char* cb = P.coll.as<char>();
         HIPCHK(c, hipMemcpyAsync(cb + o_cs, coll_start, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, st));
@@ -682,7 +689,7 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
             HIPCHK(c, hipMemcpyAsync(cb + o_cw, coll_w, (size_t)n_coll * 4, hipMemcpyHostToDevice, st));
         }
         HIPCHK(c, hipMemcpyAsync(cb + o_sb, P.seg_base.data(), (size_t)(V + 1) * 4, hipMemcpyHostToDevice, st));
-        P.coll_n = n_coll;
+        P.coll_n = n_coll; P.coll_sig = sig;
     }
     char* cb = P.coll.as<char>();
     AffIn a;

@@ -29,6 +29,19 @@ namespace {
 const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity;tgt_rays;prod_keys;prod_sort;hypotheses;uf_components";
 }  // namespace
 
+namespace l3d {
+// The ONE place the library reads the environment (called by l3d_ctx_create).
+Options options_from_env()
+{
+    Options o;
+#define X(field, env, def, doc) if (const char* e = getenv(env)) o.field = (*e == 0) ? 1 : atoi(e);
+    L3D_OPTION_TABLE(X)
+#undef X
+    return o;
+}
+const Options& ctx_options(const l3d_ctx* c) { return c->opt; }
+}  // namespace l3d
+
 extern "C" {
 
 int l3d_ctx_create(int device, l3d_ctx** out)
@@ -41,13 +54,15 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipSetDevice(device) != hipSuccess) return L3D_ERR_HIP;
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
-    if (const char* e = getenv("L3D_CHAIN_RING")) c->chain_ring = atoi(e) != 0;
-    if (const char* e = getenv("L3D_PRETEST")) c->wedge_pretest = atoi(e) & 3;      // diagnostic: stage-1 filter mask
+    c->opt = options_from_env();                  // the one place the environment is read
+    publish_tunables(c->opt);
+    c->chain_ring = c->opt.chain_ring != 0;
+    c->wedge_pretest = c->opt.pretest & 3;         // diagnostic: stage-1 filter mask
     {   // L3D_STREAM_PRIO=1: the chain's stream (per-view critical path) at the highest priority.  Measured on config 2: no
         // difference to plain streams (21.5 ms either way), so plain streams are the default.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const bool prio = getenv("L3D_STREAM_PRIO") && atoi(getenv("L3D_STREAM_PRIO")) == 1;
+        const bool prio = c->opt.stream_prio == 1;
         if (!prio || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) {
             (void)hipGetLastError();
             if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return L3D_ERR_HIP; }
@@ -57,8 +72,29 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
     }
-    if (getenv("L3D_PAIR_STATS") && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 64) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 64);
+    if (c->opt.pair_stats && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 64) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 64);
     *out = c;
+    return L3D_OK;
+}
+
+int l3d_set_option(l3d_ctx* c, const char* name, int value)
+{
+    if (!c) return L3D_ERR_INVALID;
+    int* f = option_field(c->opt, name);
+    if (!f) return fail(c, L3D_ERR_INVALID, std::string("l3d_set_option: unknown option ") + (name ? name : "(null)"));
+    *f = value;
+    publish_tunables(c->opt);
+    c->chain_ring = c->opt.chain_ring != 0;
+    c->wedge_pretest = c->opt.pretest & 3;
+    return L3D_OK;
+}
+
+int l3d_get_option(l3d_ctx* c, const char* name, int* value)
+{
+    if (!c || !value) return L3D_ERR_INVALID;
+    int* f = option_field(c->opt, name);
+    if (!f) return fail(c, L3D_ERR_INVALID, std::string("l3d_get_option: unknown option ") + (name ? name : "(null)"));
+    *value = *f;
     return L3D_OK;
 }
 
@@ -81,7 +117,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
                 100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0]);
         (void)hipFree(c->pair_dbg);
     }
-    if (getenv("L3D_TIMING"))
+    if (c->opt.timing)
         fprintf(stderr, "[l3d timing] tables+stage1-launch %.1f  exist-sort %.1f  launch1b %.1f  sync1 %.1f  launch2 %.1f  sync2 %.1f  d2h-kept %.1f  median %.1f ms  (max candidates per segment %d)\n",
                 c->tacc[0] * 1e3, c->tacc[1] * 1e3, c->tacc[2] * 1e3, c->tacc[3] * 1e3, c->tacc[4] * 1e3, c->tacc[5] * 1e3, c->tacc[6] * 1e3, c->tacc[7] * 1e3, c->mmax_seen);
     (void)hipSetDevice(c->device);
@@ -203,9 +239,10 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
     (void)hipSetDevice(c->device);
     const size_t nd = (size_t)n_dense, N = (size_t)std::max(1, n_neighbors);
     const size_t n_pot = 3 * N * nd + 1024, n_items = (3 * N * nd) / 2 + 1024, n_edges = N * nd + 1024, slots = 2 * n_pot;
+    const size_t bslots = std::min(slots, (size_t)(c->opt.prod_block_keys > 0 ? c->opt.prod_block_keys : (1 << 28)) + 64);   // the products are built in blocks of key slots
     Products& P = c->products;
     struct R { DevBuf* b; size_t bytes; } rs[] = {
-        { &P.keys, slots * 8 }, { &P.keys2, slots * 8 }, { &P.flag, slots * 4 }, { &P.pos, slots * 4 }, { &P.tmp, slots * 4 + (64u << 10) }, { &P.pot_start, (nd + 2) * 8 },
+        { &P.keys, bslots * 8 }, { &P.keys2, bslots * 8 }, { &P.flag, bslots * 4 }, { &P.pos, bslots * 4 }, { &P.tmp, bslots * 4 + (64u << 10) }, { &P.pot_start, (nd + 2) * 8 },
         { &P.pot_tgt, slots * 4 }, { &P.best_ref, nd * 8 }, { &P.hyp_of, (nd + 2) * 8 }, { &P.score, nd * 4 }, { &P.hyp_dense, nd * 4 }, { &P.best_hyp, nd * 4 },
         { &P.aux, nd * 4 + n_pot + 1024 }, { &c->aff_hyp, nd * sizeof(Hypothesis) },
         { &c->g1, (nd + 2) * 16 + (size_t)n_views * 4 + 1024 }, { &c->g2, n_items * 8 }, { &c->g3, n_items * 8 }, { &c->g4, n_items * 4 },
@@ -449,9 +486,9 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
     va.big = 0; va.scratch = nullptr; va.scratch_stride = 0; va.kept_cnt = nullptr; va.best_depths = nullptr; va.seg_order = nullptr;
-    { static const int dbg = getenv("L3D_VW_DEBUG") ? atoi(getenv("L3D_VW_DEBUG")) : 0; va.debug = dbg; }
+    va.debug = c->opt.vw_debug;
     va.stamps = nullptr;
-    if (getenv("L3D_VW_STAMPS")) {
+    if (c->opt.vw_stamps) {
         if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
         va.stamps = c->stamps.as<unsigned long long>();
     }

@@ -234,7 +234,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     c->pin_arena.reset();
     hipStream_t st = c->stream;         // phase 2 (the chain proper)
     hipStream_t s1 = c->stage1_stream;  // stage 1 runs ahead here, concurrently with the latency-bound kernels of phase 2
-    static const bool serial = getenv("L3D_CHAIN_SERIAL") && atoi(getenv("L3D_CHAIN_SERIAL")) != 0;   // diagnostic: one stream, kernels one at a time (isolated durations)
+    const bool serial = c->opt.chain_serial != 0;   // diagnostic: one stream, kernels one at a time (isolated durations)
     if (serial) s1 = st;
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
 
@@ -242,7 +242,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     std::vector<ViewDev> vd;
     ChainLayout L;
     if (int rc = chain_plan_views(c, views, n_views, 0, 1, vd, L, "l3d_match_chain")) return rc;
-    static const bool rays_env = !(getenv("L3D_TGT_RAYS") && atoi(getenv("L3D_TGT_RAYS")) == 0);      // (0: k_pair_fill normalises per candidate, A/B)
+    const bool rays_env = c->opt.tgt_rays != 0;      // (0: k_pair_fill normalises per candidate, A/B)
     if (int rc = chain_upload_tables(c, views, n_views, vd, L, rays_env, st)) return rc;
     if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, st)) return rc;
     const unsigned char* dtab = L.dtab;
@@ -266,7 +266,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
     // the four depths of a stage-1 pair are triangulated once, by k_pair_fill (ring scheme only: the fill runs ahead, its true row counts
     // are in place before the chain counts the view's reverse matches on top); L3D_DEPTH_IN_FILL=0: A/B, k_pair_mask triangulates too
-    static const bool depth_in_fill_env = !(getenv("L3D_DEPTH_IN_FILL") && atoi(getenv("L3D_DEPTH_IN_FILL")) == 0);
+    const bool depth_in_fill_env = c->opt.depth_in_fill != 0;
     const bool depth_in_fill = depth_in_fill_env && c->chain_ring != 0;
     auto pair_args = [&](int k) {
         PairArgs pa = chain_pair_args(c, views[k], vd[(size_t)k], dtab);
@@ -322,7 +322,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     const bool use_ring = c->chain_ring != 0;
     // the row starts of the stage-1 candidates are formed inside k_pair_fill from k_pair_mask's counters and their block sums: no
     // scan launch on the stage-1 stream (the longer of the two), no statistics for the host to wait for.  L3D_FUSED_ROWS=0: A/B.
-    static const bool fused_rows_env = !(getenv("L3D_FUSED_ROWS") && atoi(getenv("L3D_FUSED_ROWS")) == 0);
+    const bool fused_rows_env = c->opt.fused_rows != 0;
     const bool fused_rows = fused_rows_env && use_ring && depth_in_fill && maxN <= 96;      // (k_pair_mask's LDS block sums: 64 rows N apart span <= 32 blocks)
     auto enqueue_fillA = [&](int k, hipStream_t s) {
         if (!use_ring) return;
@@ -555,10 +555,10 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0 };
         rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot);
     }
-    if (getenv("L3D_TIMING"))
+    if (c->opt.timing)
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
                 (t_loop0 - t_setup0) * 1e3, (t_prod0 - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
-    if (getenv("L3D_TIMING") && map) fprintf(stderr, "[l3d match_chain] products on the device %.2f ms\n", (now_s() - t_prod0) * 1e3);
+    if (c->opt.timing && map) fprintf(stderr, "[l3d match_chain] products on the device %.2f ms\n", (now_s() - t_prod0) * 1e3);
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);

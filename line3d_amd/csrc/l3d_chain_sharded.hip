@@ -36,7 +36,7 @@ static inline void wait_until(Pred pred, int spins_before_sleep)
     int spins = 0;
     while (!pred()) {
         if (++spins < spins_before_sleep) std::this_thread::yield();
-        else { static const int us = getenv("L3D_WAIT_SLEEP_US") ? atoi(getenv("L3D_WAIT_SLEEP_US")) : 20; if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us)); else std::this_thread::yield(); }
+        else { const int us = tunables().wait_sleep_us.load(std::memory_order_relaxed); if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us)); else std::this_thread::yield(); }
     }
 }
 
@@ -654,7 +654,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     (void)hipStreamSynchronize(c->stream);
     const double t_run2 = now_s();
     if (fetcher.joinable()) fetcher.join();
-    if (getenv("L3D_TIMING"))
+    if (c->opt.timing)
         fprintf(stderr, "[l3d shard chain run] enqueue loop %.2f ms, stream drained after %.2f ms, bookkeeping thread done after %.2f ms\n",
                 (t_run1 - t_run0) * 1e3, (t_run2 - t_run0) * 1e3, (now_s() - t_run0) * 1e3);
     if (rc == L3D_OK && fetch_rc) { rc = fetch_rc; rc_msg = fetch_err; }
@@ -786,7 +786,7 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
     for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);
     if (h->ev3) c->event_pool.push_back(h->ev3);
     c->stats[1] = h->raw_sum; c->stats[3] = h->kept_total;
-    if (getenv("L3D_TIMING"))
+    if (c->opt.timing)
         fprintf(stderr, "[l3d shard chain rank %d/%d] enqueue %.2f  exchange-call %.2f | fetch: wait %.2f  d2h %.2f  callback %.2f ms\n",
                 h->rank, h->world, h->t_enq * 1e3, h->t_ex * 1e3, h->t_wait * 1e3, h->t_copy * 1e3, h->t_cb * 1e3);
     delete h;

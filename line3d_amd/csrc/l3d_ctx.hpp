@@ -15,6 +15,7 @@
 
 #include "../../include/line3d_amd.h"
 #include "l3d_kernels.hpp"
+#include "l3d_options.hpp"
 
 namespace l3d {
 
@@ -83,6 +84,7 @@ struct Products {
     DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables;
     DevBuf geo, hyp_of, score, hyp_dense, best_hyp, coll, aux;       // greedy selection / affinity fill on the resident tables
     long long coll_n = 0;           // entries of the collinearity CSR resident in `coll` (with n_dense + 1 starts in front)
+    unsigned long long coll_sig = 0; // checksum of what that copy was uploaded from (sizes, row starts, dense map)
     std::vector<int> seg_base;      // host copies: the dense map, the chain's result records, what the early-return views need
     std::vector<unsigned> view_ids;
     std::vector<l3d::ChainResult> res;
@@ -95,7 +97,7 @@ struct Products {
     {
         DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
         for (DevBuf* x : b) x->release();
-        valid = hyp_valid = false; coll_n = 0;
+        valid = hyp_valid = false; coll_n = 0; coll_sig = 0;
     }
 };
 
@@ -109,6 +111,7 @@ struct ProfEntry {
 
 struct l3d_ctx {
     int device = 0;
+    l3d::Options opt;                        // every L3D_* switch: the environment read once by l3d_ctx_create, then l3d_set_option
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // bulk D2H of the resident chain, concurrent with kernels
     hipStream_t stage1_stream = nullptr;     // stage 1 of the resident chain (independent of the chain state) runs ahead here

@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include "l3d_options.hpp"
+
 namespace l3d {
 
 // CPUs this process may actually use: affinity mask and cgroup CPU quota (a container can see 256 CPUs and own 16; more busy
@@ -43,7 +45,7 @@ inline unsigned usable_cpus()
 
 inline unsigned host_threads()         // worker threads of the host-side stages that run alone (finish of compute3Dmodel)
 {
-    if (const char* e = getenv("L3D_HOST_THREADS")) return (unsigned)std::max(1, std::min(64, atoi(e)));
+    { const int e = tunables().host_threads.load(std::memory_order_relaxed); if (e > 0) return (unsigned)std::min(64, e); }     // L3D_HOST_THREADS
     return std::max(1u, std::min(16u, usable_cpus()));
 }
 

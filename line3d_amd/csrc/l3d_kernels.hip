@@ -19,6 +19,7 @@
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
+#include "l3d_options.hpp"
 #include "l3d_scan.hpp"
 #include "l3d_kept.hpp"
 #include "l3d_similarity.hpp"
@@ -861,7 +862,7 @@ __global__ void k_test_math(const float* __restrict__ x, int n, float* __restric
 // the latency of one workgroup).
 int pair_mask_src_per_block(int n_src, int maxW, int n_tbm)
 {
-    static const int forced = getenv("L3D_PAIR_SPB") ? atoi(getenv("L3D_PAIR_SPB")) : 0;
+    const int forced = tunables().pair_spb.load(std::memory_order_relaxed);
     if (forced > 0) return std::min(forced, kSrcPerBlock);
     const int tiles = (maxW + 255) / 256;
     int spb = kSrcPerBlock;

@@ -281,6 +281,10 @@ extern "C" int l3d_fit_labelled_clusters(l3d_ctx* c, const int32_t* labels, cons
     if (!node_hyp && c->resident_nodes != n_nodes) return fail(c, L3D_ERR_INVALID, "line fit: no resident node table of that size (l3d_affinity_fill)");
     if (labels) for (int v = 0; v < n_nodes; ++v) if (labels[v] < 0 || labels[v] >= n_nodes) return fail(c, L3D_ERR_INVALID, "line fit: label out of range");
     if (node_hyp) for (int v = 0; v < n_nodes; ++v) if (node_hyp[v] < 0 || node_hyp[v] >= n_hyp) return fail(c, L3D_ERR_INVALID, "line fit: node hypothesis out of range");
+    // k_lab_valid counts a cluster's cameras as camera CHANGES between neighbouring members in hypothesis order (line3D.cc:1320,1334:
+    // cluster2cameras.size() >= 4): that is the number of distinct cameras only if the hypotheses are numbered camera by camera
+    for (int k = 1; k < n_hyp; ++k)
+        if (hyp_cam[k] < hyp_cam[k - 1]) return fail(c, L3D_ERR_INVALID, "line fit: hyp_cam must be non-decreasing in hypothesis index (hypotheses numbered view by view)");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };

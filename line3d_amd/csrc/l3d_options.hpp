@@ -1,0 +1,75 @@
+// l3d_options.hpp -- every diagnostic / A-B switch of the library in one place.  The environment is read ONCE, by
+// l3d_ctx_create (l3d::options_from_env, l3d_capi.hip: the only getenv of the library); afterwards a switch changes only through
+// l3d_set_option (tests, scripts).  Nothing here selects a CPU path for the arithmetic: the switches choose between device
+// variants, turn on self-checks and timing prints, or force the small-capacity / many-pass code paths tests want to reach.
+#pragma once
+
+#include <atomic>
+#include <cstring>
+
+namespace l3d {
+
+// X(field, environment variable, default, meaning)
+#define L3D_OPTION_TABLE(X)                                                                                                          \
+    X(timing, "L3D_TIMING", 0, "1: per-stage timing lines on stderr, 2: + per-view trace of the chain")                              \
+    X(check_pot, "L3D_CHECK_POT", 0, "tests: compare the device products of matchViews with the plain host construction")            \
+    X(chain_ring, "L3D_CHAIN_RING", 1, "0: triangulation on the chain's stream instead of the stage-1 ring (A/B)")                   \
+    X(pretest, "L3D_PRETEST", 3, "stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (A/B)")                   \
+    X(stream_prio, "L3D_STREAM_PRIO", 0, "1: the chain's stream at the highest priority (measured: no difference)")                  \
+    X(pair_stats, "L3D_PAIR_STATS", 0, "device counters of k_pair_mask's levels, printed at destroy")                                \
+    X(vw_debug, "L3D_VW_DEBUG", 0, "k_verify_window debug mode")                                                                     \
+    X(vw_stamps, "L3D_VW_STAMPS", 0, "in-kernel clock stamps of k_verify_window's phases, printed at destroy")                       \
+    X(vw_lds, "L3D_VW_LDS", 0, "dynamic LDS budget of k_verify_window in bytes (0: the measured default)")                           \
+    X(vw_wide_max, "L3D_VW_WIDE_MAX", 640, "launches of up to this many segments use the 8-wave k_verify_window")                    \
+    X(chain_serial, "L3D_CHAIN_SERIAL", 0, "1: the chain on one stream, kernels one at a time (isolated durations)")                 \
+    X(tgt_rays, "L3D_TGT_RAYS", 1, "0: k_pair_fill normalises the target rays per candidate (A/B)")                                  \
+    X(src_rays, "L3D_SRC_RAYS", 1, "0: k_pair_fill normalises the source rays per row (A/B)")                                        \
+    X(depth_in_fill, "L3D_DEPTH_IN_FILL", 1, "0: depths triangulated in k_pair_mask (A/B)")                                          \
+    X(fused_rows, "L3D_FUSED_ROWS", 1, "0: separate row-scan launch on the stage-1 stream (A/B)")                                    \
+    X(pair_spb, "L3D_PAIR_SPB", 0, "source segments per k_pair_mask workgroup (0: by the size of the launch)")                       \
+    X(wait_sleep_us, "L3D_WAIT_SLEEP_US", 20, "sleep of the sharded run's waiting host threads")                                     \
+    X(aff_chunk, "L3D_AFF_CHUNK", 0, "tests: targets per pass of k_aff_groups (0: 64)")                                              \
+    X(aff_per_view, "L3D_AFF_PER_VIEW", 0, "tests: one k_aff_groups launch per view (the schedule of one-way records)")              \
+    X(cc_max_rounds, "L3D_CC_MAX_ROUNDS", 0, "tests: rounds of the connected-components loop before it gives up (0: 64)")            \
+    X(host_threads, "L3D_HOST_THREADS", 0, "worker threads of the host-side stages (0: min(16, usable CPUs))")                       \
+    X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
+    X(graph, "L3D_GRAPH", 1, "sharded chain: 0 = one API call per launch instead of the captured per-view graphs (A/B)")             \
+    X(host_bookkeeping, "L3D_HOST_BOOKKEEPING", 0, "cross-check build only: matchViews with the rounds-1-2 host bookkeeping")       \
+    X(host_clustering, "L3D_HOST_CLUSTERING", 0, "cross-check build only: merge loop and grouping on the host threads")             \
+    X(match_sync, "L3D_MATCH_SYNC", 0, "cross-check build only: matchViews through the per-view seam call")
+
+struct Options {
+#define X(field, env, def, doc) int field = def;
+    L3D_OPTION_TABLE(X)
+#undef X
+};
+
+// name = the environment variable with or without its L3D_ prefix, any case of the prefix-less part as in the table
+inline int* option_field(Options& o, const char* name)
+{
+    if (!name) return nullptr;
+#define X(field, env, def, doc) if (strcmp(name, env) == 0 || strcmp(name, &env[4]) == 0 || strcmp(name, #field) == 0) return &o.field;
+    L3D_OPTION_TABLE(X)
+#undef X
+    return nullptr;
+}
+
+Options options_from_env();             // l3d_capi.hip
+}  // namespace l3d
+struct l3d_ctx;
+namespace l3d {
+const Options& ctx_options(const l3d_ctx* c);   // l3d_capi.hip: the switches of a context, for code that sees the context as an opaque handle (line3d_host.cpp)
+
+// switches read by code that has no context at hand (launch helpers, the host worker pool): process-wide, set from the
+// options of the last context created / the last l3d_set_option
+struct ProcessTunables {
+    std::atomic<int> vw_lds{0}, vw_wide_max{640}, pair_spb{0}, host_threads{0}, wait_sleep_us{20};
+};
+inline ProcessTunables& tunables() { static ProcessTunables t; return t; }
+inline void publish_tunables(const Options& o)
+{
+    ProcessTunables& t = tunables();
+    t.vw_lds = o.vw_lds; t.vw_wide_max = o.vw_wide_max; t.pair_spb = o.pair_spb; t.host_threads = o.host_threads; t.wait_sleep_us = o.wait_sleep_us;
+}
+
+}  // namespace l3d

@@ -36,6 +36,17 @@ struct ProdView {                   // per chain index
     const int* bestpos;
     const float2* best;
 };
+// The keys are formed, sorted and reduced to CSR rows in BLOCKS of consecutive dense views (ascending: the blocks' row ranges
+// concatenate to the table), so that the transient memory -- two 64-bit key arrays, flags, positions: 24 bytes per key slot -- is
+// bounded by the block size and not by the scene (the reference spills every view's matches to disk, view.cc:150-224).
+// A block holds the keys whose SOURCE segment lies in its dense range [d0, d1): the forward key of a record of one of its views, the
+// backward key of a record that points into it.  Every chain view / early-return pair that can contribute gets a region of
+// 2 x (its records) slots in the block's key array (out_off; -1: it cannot contribute); a key outside the range is written invalid.
+struct ProdBlock {
+    int d0, d1;                     // dense range
+    long long slots;                // key slots of the block (without the sentinel)
+    size_t off_view, off_src;       // this block's out_off tables inside the uploaded table buffer (long long per chain view / per ProdSrc)
+};
 struct ProdSrc {                    // one (early-return view, source) pair
     int view, src;                  // chain indices
     int alias_base, alias_S;        // dense range of the view the source's LOCAL camera number names (-1: no such view)
@@ -53,11 +64,13 @@ __device__ __forceinline__ int find_view(const unsigned* __restrict__ ids, int n
 }
 
 // two keys per kept record of the verified views: (dense source << nb | dense target) and the reverse (line3D.cc:864-865)
-__global__ __launch_bounds__(256) void k_prod_keys(const Match* __restrict__ arena, const ProdView* __restrict__ pv, const unsigned* __restrict__ ids,
-                                                   const int* __restrict__ seg_base, int n_all, int nb, unsigned long long* __restrict__ keys)
+__global__ __launch_bounds__(256) void k_prod_keys(const Match* __restrict__ arena, const ProdView* __restrict__ pv, const long long* __restrict__ out_off,
+                                                   const unsigned* __restrict__ ids, const int* __restrict__ seg_base, int n_all, int nb, int d0, int d1,
+                                                   unsigned long long* __restrict__ keys)
 {
     const ProdView v = pv[blockIdx.y];
-    if (v.early) return;
+    const long long off = out_off[blockIdx.y];
+    if (v.early || off < 0) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < v.n_kept; i += gridDim.x * 256) {
         const Match r = arena[v.kept_base + i];
         const int t = find_view(ids, n_all, r.camID2);
@@ -65,41 +78,47 @@ __global__ __launch_bounds__(256) void k_prod_keys(const Match* __restrict__ are
         if (t >= 0 && (int)r.segID1 < v.S) {
             const int tb = seg_base[t], tS = seg_base[t + 1] - tb;
             if ((int)r.segID2 < tS) {
-                const unsigned long long a = (unsigned long long)(v.dense_base + (int)r.segID1), d = (unsigned long long)(tb + (int)r.segID2);
-                f = (a << nb) | d; b = (d << nb) | a;
+                const int ai = v.dense_base + (int)r.segID1, di = tb + (int)r.segID2;
+                const unsigned long long a = (unsigned long long)ai, d = (unsigned long long)di;
+                if (ai >= d0 && ai < d1) f = (a << nb) | d;
+                if (di >= d0 && di < d1) b = (d << nb) | a;
             }
         }
-        keys[2 * (v.kept_base + i)] = f;
-        keys[2 * (v.kept_base + i) + 1] = b;
+        keys[off + 2 * (long long)i] = f;
+        keys[off + 2 * (long long)i + 1] = b;
     }
 }
 
 // early-return views: the records of source `src` that point at the view, read reversed; the camera of such an entry is the
 // source's LOCAL number in the view's neighbour list (alias = the view that number happens to name).  Also the view's best
 // match per segment: the first entry of the list in push order (all confidences are 0): atomicMin of (source rank, record).
+// out_off == nullptr: the pass that only finds the best matches and the list lengths (once per build); otherwise the keys of one block.
 __global__ __launch_bounds__(256) void k_prod_keys_early(const Match* __restrict__ arena, const ProdView* __restrict__ pv, const ProdSrc* __restrict__ ps,
-                                                         const unsigned* __restrict__ chain_view_id, int nb, unsigned long long* __restrict__ keys,
-                                                         unsigned long long* __restrict__ best_ref, int* __restrict__ list_len)
+                                                         const long long* __restrict__ out_off, const unsigned* __restrict__ chain_view_id, int nb, int d0, int d1,
+                                                         unsigned long long* __restrict__ keys, unsigned long long* __restrict__ best_ref, int* __restrict__ list_len)
 {
     const ProdSrc e = ps[blockIdx.y];
+    const long long off = out_off ? out_off[blockIdx.y] : 0;
+    if (off < 0) return;
     const ProdView v = pv[e.view], s = pv[e.src];
     const unsigned vid = chain_view_id[e.view];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < s.n_kept; i += gridDim.x * 256) {
         const Match r = arena[s.kept_base + i];
         unsigned long long f = kInvalidKey, b = kInvalidKey;
         if (r.camID2 == vid) {
-            atomicAdd(&list_len[e.view], 1);                      // (length of the view's list: statistics)
+            if (!out_off) atomicAdd(&list_len[e.view], 1);                      // (length of the view's list: statistics)
             // the list entry: segID1 = r.segID2 (the view's segment), camID2 = local number, segID2 = r.segID1
             if ((int)r.segID2 < v.S) {
-                atomicMin(&best_ref[v.dense_base + (int)r.segID2], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i));
-                if (e.alias_base >= 0 && (int)r.segID1 < e.alias_S) {
-                    const unsigned long long a = (unsigned long long)(v.dense_base + (int)r.segID2), d = (unsigned long long)(e.alias_base + (int)r.segID1);
-                    f = (a << nb) | d; b = (d << nb) | a;
+                if (!out_off) atomicMin(&best_ref[v.dense_base + (int)r.segID2], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i));
+                else if (e.alias_base >= 0 && (int)r.segID1 < e.alias_S) {
+                    const int ai = v.dense_base + (int)r.segID2, di = e.alias_base + (int)r.segID1;
+                    const unsigned long long a = (unsigned long long)ai, d = (unsigned long long)di;
+                    if (ai >= d0 && ai < d1) f = (a << nb) | d;
+                    if (di >= d0 && di < d1) b = (d << nb) | a;
                 }
             }
         }
-        keys[e.out_off + 2 * (long long)i] = f;
-        keys[e.out_off + 2 * (long long)i + 1] = b;
+        if (out_off) { keys[off + 2 * (long long)i] = f; keys[off + 2 * (long long)i + 1] = b; }
     }
 }
 
@@ -173,8 +192,10 @@ __global__ __launch_bounds__(256) void k_prod_flags(const unsigned long long* __
 
 // unique keys -> CSR.  The thread of a first occurrence writes its target; where the source changes it also writes the row starts
 // of every source in between (segments without entries), and the first invalid key closes the table.
+// One block of sources [d0, d1): its rows start at `base` (the entries of the blocks in front of it); the closing (first invalid) key
+// writes the start of row d1 = the end of this block's rows = the base of the next block (or of the table when d1 = n_dense).
 __global__ __launch_bounds__(256) void k_prod_csr(const unsigned long long* __restrict__ keys, const int* __restrict__ flag, const int* __restrict__ pos,
-                                                  long long n, int nb, int n_dense, long long* __restrict__ pot_start, int* __restrict__ pot_tgt)
+                                                  long long n, int nb, int d0, int d1, long long base, long long* __restrict__ pot_start, int* __restrict__ pot_tgt)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -182,9 +203,9 @@ __global__ __launch_bounds__(256) void k_prod_csr(const unsigned long long* __re
     const unsigned long long mask = (1ull << nb) - 1ull;
     const bool invalid = k == kInvalidKey;
     if (invalid && i > 0 && keys[i - 1] == kInvalidKey) return;
-    const int p = pos[i];
-    const long long src = invalid ? (long long)n_dense : (long long)(k >> nb);
-    const long long prev = i == 0 ? -1 : (long long)(keys[i - 1] >> nb);
+    const long long p = base + pos[i];
+    const long long src = invalid ? (long long)d1 : (long long)(k >> nb);
+    const long long prev = i == 0 ? (long long)d0 - 1 : (long long)(keys[i - 1] >> nb);
     if (!invalid && flag[i]) pot_tgt[p] = (int)(k & mask);
     if (i == 0 || prev != src) for (long long d = prev + 1; d <= src; ++d) pot_start[d] = p;
 }
@@ -225,9 +246,9 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     // ---- host tables: one ProdView per chain view, one ProdSrc per (early-return view, source)
     std::vector<ProdView> pv((size_t)n_views);
     std::vector<ProdSrc> ps;
-    long long total_kept = 0;
+    std::vector<int> ps_alias_view;                         // dense view a ProdSrc's alias names (-1: none)
+    long long total_kept = 0, early_slots = 0;
     for (int k = 0; k < n_views; ++k) if (pvh[k].verified) total_kept = std::max(total_kept, (long long)hres[k].kept_base + hres[k].n_kept);
-    long long slots = 2 * total_kept;
     int max_kept = 0, maxS = 1;
     for (int k = 0; k < n_views; ++k) {
         const l3d_chain_view& v = views[k];
@@ -249,21 +270,71 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                 e.view = k; e.src = si; e.rank = q; e.pad = 0;
                 const int av = view_of((unsigned)v.source_cam[q]);           // the LOCAL camera number read as a view id (line3D.cc:861-865)
                 e.alias_base = av >= 0 ? P.seg_base[(size_t)av] : -1; e.alias_S = av >= 0 ? P.seg_base[(size_t)av + 1] - P.seg_base[(size_t)av] : 0;
-                e.out_off = slots;
-                slots += 2 * (long long)hres[si].n_kept;
+                e.out_off = 0;
+                early_slots += 2 * (long long)hres[si].n_kept;
                 ps.push_back(e);
+                ps_alias_view.push_back(av);
             }
         }
     }
-    if (slots > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "products: more than 2^30 kept matches (the host bookkeeping handles those)");
-    const long long n_keys = slots + 1;                    // (+ the sentinel)
+    const long long slots_all = 2 * total_kept + early_slots;      // every key there can be: the bound of the table's entries
     const int nb = bits_for(nd);
     P.total_kept = total_kept;
 
-    // ---- upload tables: [ProdView n_views][ProdSrc][ids nv][seg_base nv+1][chain view ids]
+    // ---- blocks of consecutive dense views.  touching[x] = the chain views / early pairs that can have a key with a source in dense
+    // view x: a verified chain view touches its own view (forward keys) and its neighbours' (backward keys); an early pair its view and
+    // the view its alias names.  A block is grown view by view while its key slots stay within the budget.
+    std::vector<std::vector<int>> touch_view((size_t)nv), touch_src((size_t)nv);
+    for (int k = 0; k < n_views; ++k) {
+        if (!pvh[k].verified || hres[k].n_kept == 0) continue;
+        touch_view[(size_t)P.chain_view[(size_t)k]].push_back(k);
+        for (int q = 0; q < views[k].N; ++q) {
+            const int t = view_of(views[k].local2global[q]);
+            if (t >= 0 && t != P.chain_view[(size_t)k]) touch_view[(size_t)t].push_back(k);
+        }
+    }
+    for (size_t q = 0; q < ps.size(); ++q) {
+        if (hres[ps[q].src].n_kept == 0) continue;
+        const int a = P.chain_view[(size_t)ps[q].view], b = ps_alias_view[q];
+        touch_src[(size_t)a].push_back((int)q);
+        if (b >= 0 && b != a) touch_src[(size_t)b].push_back((int)q);
+    }
+    const long long budget = c->opt.prod_block_keys > 0 ? (long long)c->opt.prod_block_keys : (1ll << 28);   // 268 M key slots = 6.4 GB of transients
+    std::vector<ProdBlock> blocks;
+    std::vector<long long> off_tab;                         // per block: out_off of every chain view, then of every early pair
+    {
+        std::vector<int> mark_v((size_t)n_views, -1), mark_s(ps.size(), -1);
+        int x = 0;
+        while (x < nv) {
+            const int bi = (int)blocks.size();
+            ProdBlock B;
+            B.d0 = P.seg_base[(size_t)x]; B.slots = 0;
+            B.off_view = off_tab.size();
+            off_tab.resize(off_tab.size() + (size_t)n_views + ps.size(), -1);
+            B.off_src = B.off_view + (size_t)n_views;
+            int x1 = x;
+            for (; x1 < nv; ++x1) {
+                long long add = 0;
+                for (int k : touch_view[(size_t)x1]) if (mark_v[(size_t)k] != bi) add += 2 * (long long)hres[k].n_kept;
+                for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) add += 2 * (long long)hres[ps[(size_t)q].src].n_kept;
+                if (x1 > x && B.slots + add > budget) break;
+                for (int k : touch_view[(size_t)x1]) if (mark_v[(size_t)k] != bi) { mark_v[(size_t)k] = bi; off_tab[B.off_view + (size_t)k] = B.slots; B.slots += 2 * (long long)hres[k].n_kept; }
+                for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) { mark_s[(size_t)q] = bi; off_tab[B.off_src + (size_t)q] = B.slots; B.slots += 2 * (long long)hres[ps[(size_t)q].src].n_kept; }
+            }
+            B.d1 = P.seg_base[(size_t)x1];
+            if (B.slots > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "products: one view and its neighbours hold more than 2^30 kept matches");
+            blocks.push_back(B);
+            x = x1;
+        }
+    }
+    long long max_slots = 0;
+    for (const ProdBlock& B : blocks) max_slots = std::max(max_slots, B.slots);
+    const long long n_keys_max = max_slots + 1;            // (+ the sentinel)
+
+    // ---- upload tables: [ProdView n_views][ProdSrc][ids nv][seg_base nv+1][chain view ids][out_off tables of all blocks]
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_pv = 0, o_ps = o_pv + al(pv.size() * sizeof(ProdView)), o_ids = o_ps + al(ps.size() * sizeof(ProdSrc) + 16),
-                 o_sb = o_ids + al((size_t)nv * 4), o_cv = o_sb + al((size_t)(nv + 1) * 4), tab_total = o_cv + al((size_t)n_views * 4);
+                 o_sb = o_ids + al((size_t)nv * 4), o_cv = o_sb + al((size_t)(nv + 1) * 4), o_off = o_cv + al((size_t)n_views * 4), tab_total = o_off + al(off_tab.size() * 8 + 16);
     HIPCHK(c, P.tables.reserve(tab_total));
     char* tb = P.tables.as<char>();
     HIPCHK(c, hipMemcpyAsync(tb + o_pv, pv.data(), pv.size() * sizeof(ProdView), hipMemcpyHostToDevice, st));
@@ -271,19 +342,21 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     HIPCHK(c, hipMemcpyAsync(tb + o_ids, P.view_ids.data(), (size_t)nv * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(tb + o_sb, P.seg_base.data(), (size_t)(nv + 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(tb + o_cv, P.chain_view_id.data(), (size_t)n_views * 4, hipMemcpyHostToDevice, st));
+    if (!off_tab.empty()) HIPCHK(c, hipMemcpyAsync(tb + o_off, off_tab.data(), off_tab.size() * 8, hipMemcpyHostToDevice, st));
     const ProdView* dpv = reinterpret_cast<const ProdView*>(tb + o_pv);
     const ProdSrc* dps = reinterpret_cast<const ProdSrc*>(tb + o_ps);
     const unsigned* dids = reinterpret_cast<const unsigned*>(tb + o_ids);
     const int* dsb = reinterpret_cast<const int*>(tb + o_sb);
     const unsigned* dcv = reinterpret_cast<const unsigned*>(tb + o_cv);
+    const long long* doff = reinterpret_cast<const long long*>(tb + o_off);
 
-    // ---- keys, best references, medians
-    HIPCHK(c, P.keys.reserve((size_t)n_keys * 8 + 64));
-    HIPCHK(c, P.keys2.reserve((size_t)n_keys * 8 + 64));
-    HIPCHK(c, P.flag.reserve(((size_t)n_keys + 2) * 4));
-    HIPCHK(c, P.pos.reserve(((size_t)n_keys + 2) * 4));
+    // ---- best references, medians (once); per block: keys, sort, unique, CSR rows
+    HIPCHK(c, P.keys.reserve((size_t)n_keys_max * 8 + 64));
+    HIPCHK(c, P.keys2.reserve((size_t)n_keys_max * 8 + 64));
+    HIPCHK(c, P.flag.reserve(((size_t)n_keys_max + 2) * 4));
+    HIPCHK(c, P.pos.reserve(((size_t)n_keys_max + 2) * 4));
     HIPCHK(c, P.pot_start.reserve(((size_t)nd + 2) * 8));
-    HIPCHK(c, P.pot_tgt.reserve(((size_t)slots + 2) * 4));
+    HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));
     HIPCHK(c, P.best_ref.reserve((size_t)nd * 8 + 64));
     HIPCHK(c, P.median.reserve((size_t)n_views * 8 + 64));          // medians | list lengths of the early-return views
     int* d_list_len = reinterpret_cast<int*>(P.median.as<float>() + n_views);
@@ -292,36 +365,55 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     unsigned long long* keys2 = P.keys2.as<unsigned long long>();
     const Match* arena = c->ch_kept.as<Match>();
     HIPCHK(c, hipMemsetAsync(P.best_ref.p, 0xff, (size_t)nd * 8, st));
-    HIPCHK(c, hipMemsetAsync(keys + slots, 0xff, 8, st));          // the sentinel
+    const unsigned gx = (unsigned)std::max(1, std::min(512, (max_kept + 1023) / 1024));
     {
         ProfScope p(c, "prod_keys", st);
-        if (max_kept > 0) hipLaunchKernelGGL(k_prod_keys, dim3(std::max(1, std::min(512, (max_kept + 1023) / 1024)), n_views), dim3(256), 0, st, arena, dpv, dids, dsb, nv, nb, keys);
-        if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(std::max(1, std::min(512, (max_kept + 1023) / 1024)), (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, dcv, nb, keys,
-                                            P.best_ref.as<unsigned long long>(), d_list_len);
+        if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, (const long long*)nullptr, dcv, nb, 0, 0,
+                                            keys, P.best_ref.as<unsigned long long>(), d_list_len);
         hipLaunchKernelGGL(k_prod_best, dim3((maxS + 255) / 256, n_views), dim3(256), 0, st, dpv, P.best_ref.as<long long>());
         hipLaunchKernelGGL(k_prod_median, dim3(n_views), dim3(256), 0, st, dpv, P.median.as<float>());
     }
-    // ---- sort, unique, CSR
-    {
-        ProfScope p(c, "prod_sort", st);
-        size_t tb1 = 0, tb2 = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
-        HIPCHK(c, P.tmp.reserve(std::max(tb1, tb2) + 256));
-        HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(P.tmp.p, tb1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
-        const unsigned blocks = (unsigned)((n_keys + 255) / 256);
-        HIPCHK(c, hipMemsetAsync(P.flag.as<int>() + n_keys, 0, 4, st));
-        hipLaunchKernelGGL(k_prod_flags, dim3(blocks), dim3(256), 0, st, keys2, n_keys, P.flag.as<int>());
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(P.tmp.p, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
-        hipLaunchKernelGGL(k_prod_csr, dim3(blocks), dim3(256), 0, st, keys2, P.flag.as<int>(), P.pos.as<int>(), n_keys, nb, nd, P.pot_start.as<long long>(), P.pot_tgt.as<int>());
+    size_t tb1 = 0, tb2 = 0;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, keys, keys2, (int)n_keys_max, 0, std::min(64, 2 * nb), st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys_max + 1, st));
+    HIPCHK(c, P.tmp.reserve(std::max(tb1, tb2) + 256));
+    long long base = 0;
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const ProdBlock& B = blocks[bi];
+        const long long n_keys = B.slots + 1;
+        {
+            ProfScope p(c, "prod_keys", st);
+            HIPCHK(c, hipMemsetAsync(keys + B.slots, 0xff, 8, st));          // the sentinel
+            if (max_kept > 0) hipLaunchKernelGGL(k_prod_keys, dim3(gx, n_views), dim3(256), 0, st, arena, dpv, doff + B.off_view, dids, dsb, nv, nb, B.d0, B.d1, keys);
+            if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, doff + B.off_src, dcv, nb, B.d0, B.d1,
+                                                keys, P.best_ref.as<unsigned long long>(), d_list_len);
+        }
+        {
+            ProfScope p(c, "prod_sort", st);
+            size_t t1 = tb1, t2 = tb2;
+            HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(P.tmp.p, t1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
+            const unsigned nblk = (unsigned)((n_keys + 255) / 256);
+            HIPCHK(c, hipMemsetAsync(P.flag.as<int>() + n_keys, 0, 4, st));
+            hipLaunchKernelGGL(k_prod_flags, dim3(nblk), dim3(256), 0, st, keys2, n_keys, P.flag.as<int>());
+            HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(P.tmp.p, t2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
+            hipLaunchKernelGGL(k_prod_csr, dim3(nblk), dim3(256), 0, st, keys2, P.flag.as<int>(), P.pos.as<int>(), n_keys, nb, B.d0, B.d1, base, P.pot_start.as<long long>(), P.pot_tgt.as<int>());
+        }
+        if (bi + 1 < blocks.size()) {                      // the next block's rows start behind this block's entries
+            int n_unique = 0;
+            HIPCHK(c, hipMemcpyAsync(&n_unique, P.pos.as<int>() + n_keys, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            base += n_unique;
+        }
     }
+    const long long last_keys = blocks.empty() ? 0 : blocks.back().slots + 1;
     // ---- the scalars the host needs
-    int n_pot = 0;
+    int n_last = 0;
     std::vector<float> med((size_t)2 * n_views, 1.0f);
-    HIPCHK(c, hipMemcpyAsync(&n_pot, P.pos.as<int>() + n_keys, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&n_last, P.pos.as<int>() + last_keys, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(med.data(), P.median.p, (size_t)n_views * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("products: ") + hipGetErrorString(e_)); }
+    const long long n_pot = base + n_last;
     P.n_pot = n_pot;
     for (int k = 0; k < n_views; ++k) {
         l3d_chain_summary& s = summary[k];

@@ -306,7 +306,7 @@ extern "C" int l3d_replicator_dynamics_diffusion(l3d_ctx* c, const l3d_edge* A, 
         if (A[k].i < 0 || A[k].i >= n || A[k].j < 0 || A[k].j >= n) return fail(c, L3D_ERR_INVALID, "edge index out of range");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = c->opt.timing != 0;
     const size_t ab = (size_t)nnz * sizeof(l3d_edge);
     HIPCHK(c, c->g6.reserve(ab + 64));
     c->resident_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;   // (whatever list was resident there is gone; g4 is scratch)
@@ -405,7 +405,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         if (A[k].i < 0 || A[k].i >= n || A[k].j < 0 || A[k].j >= n) return fail(c, L3D_ERR_INVALID, "edge index out of range");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = c->opt.timing != 0;
     double t_last = now_s();
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); const double t = now_s(); fprintf(stderr, "[l3d edges] %-24s %8.2f ms\n", what, (t - t_last) * 1e3); t_last = t; } };
     const size_t ab = (size_t)nnz * sizeof(l3d_edge);
@@ -446,8 +446,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int* changed = comp + n;                                           // (n * 4 + 256 reserved)
         const dim3 ngrid((n + 255) / 256);
         hipLaunchKernelGGL(k_cc_init, ngrid, block, 0, st, comp, n);
-        const char* mr = getenv("L3D_CC_MAX_ROUNDS");                      // (test hook: forces the not-converged path)
-        const int max_rounds = mr && atoi(mr) > 0 ? atoi(mr) : 64;
+        const int max_rounds = c->opt.cc_max_rounds > 0 ? c->opt.cc_max_rounds : 64;      // (test hook: 1 forces the not-converged path)
         for (int round = 0; round < max_rounds; ++round) {
             HIPCHK(c, hipMemsetAsync(changed, 0, 4, st));
             for (int r = 0; r < 3; ++r) {                                  // a few hooking rounds per look at the flag

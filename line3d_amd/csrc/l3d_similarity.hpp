@@ -10,13 +10,18 @@ namespace l3d {
 // =================================================================================================
 // similarity_coll3D (line3D.cc:1600-1681): double geometry, float Gaussians.
 // =================================================================================================
-__device__ __forceinline__ float p2l_3D(const double* P1, const double* dir, const double* X)   // :1684-1691
+// :1684-1691.  `P1 + (dir * ((X - P1).transpose()) * dir)` (:1689) is, by C++ precedence, the outer product dir * v^T times dir: row i of
+// the 3x3 product is dir[i] * v[j], the matrix-vector product adds its three terms in index order (an ulp of a double away from
+// dir * (v . dir) -- the association the expression has, not the one it suggests)
+__device__ __forceinline__ float p2l_3D(const double* P1, const double* dir, const double* X)
 {
     const double v0 = X[0] - P1[0], v1 = X[1] - P1[1], v2 = X[2] - P1[2];
-    const double s = v0 * dir[0] + v1 * dir[1] + v2 * dir[2];
-    const double d0 = (P1[0] + dir[0] * s) - X[0];
-    const double d1 = (P1[1] + dir[1] * s) - X[1];
-    const double d2 = (P1[2] + dir[2] * s) - X[2];
+    const double r0 = ((dir[0] * v0) * dir[0] + (dir[0] * v1) * dir[1]) + (dir[0] * v2) * dir[2];
+    const double r1 = ((dir[1] * v0) * dir[0] + (dir[1] * v1) * dir[1]) + (dir[1] * v2) * dir[2];
+    const double r2 = ((dir[2] * v0) * dir[0] + (dir[2] * v1) * dir[1]) + (dir[2] * v2) * dir[2];
+    const double d0 = (P1[0] + r0) - X[0];
+    const double d1 = (P1[1] + r1) - X[1];
+    const double d2 = (P1[2] + r2) - X[2];
     return (float)__builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
 }
 __device__ __forceinline__ float lower_unc(const Hypothesis& h, float depth)   // view.cc:353-359

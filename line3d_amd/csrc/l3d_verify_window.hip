@@ -19,6 +19,7 @@
 
 #include "l3d_geometry.hpp"
 #include "l3d_kernels.hpp"
+#include "l3d_options.hpp"
 #include "l3d_kept.hpp"
 #include "l3d_verify_eval.hpp"
 
@@ -385,7 +386,7 @@ size_t verify_window_max_lds()
 {
     static size_t limit = 0;
     if (g_lds_budget_override) return g_lds_budget_override;
-    { static const char* e = getenv("L3D_VW_LDS"); if (e && atoi(e) > 0) return (size_t)atoi(e); }     // diagnostic: dynamic LDS budget in bytes
+    { const int e = tunables().vw_lds.load(std::memory_order_relaxed); if (e > 0) return (size_t)e; }     // diagnostic (L3D_VW_LDS): dynamic LDS budget in bytes
     if (limit) return limit;
     // Measured on MI355X (config 2): the kernel is latency bound and gains more from resident workgroups than from a
     // large LDS image -- 24 KB of dynamic LDS (+8 KB static -> 5 workgroups per CU, the VGPR limit) beats 48 KB by 8 %,
@@ -421,7 +422,7 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
     // few segments (up to about two workgroups per CU): 8 waves per segment, if the wider per-lane maxima still fit
     // (replayed ranks, 2000 segments per view: 250 segments 90 -> 74 us per view, 500 segments 98 -> 94, 1000 segments 135 -> 196)
     const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
-    static const int wide_max = getenv("L3D_VW_WIDE_MAX") ? atoi(getenv("L3D_VW_WIDE_MAX")) : 640;
+    const int wide_max = tunables().vw_wide_max.load(std::memory_order_relaxed);
     if (nseg <= wide_max && lds512 <= 60 * 1024) {
         if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<512>), 1)) return;
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);

@@ -28,6 +28,7 @@
 #include "l3d_linefit.hpp"
 #include "l3d_unproject.hpp"
 #include "l3d_hostsort.hpp"
+#include "l3d_options.hpp"
 
 using namespace l3d::la;
 
@@ -236,6 +237,9 @@ struct l3d_line3d {
         return it != visual_neighbors.end() && std::binary_search(it->second.begin(), it->second.end(), b);
     }
 };
+
+// the switches of the handle's context (read once at l3d_ctx_create; l3d_set_option changes them)
+static inline const l3d::Options& hopt(const l3d_line3d* h) { return l3d::ctx_options(h->ctx); }
 
 namespace {
 
@@ -741,7 +745,7 @@ int prepare(L* h)
 {
     drop_plan(h);
     if (h->views.size() < 4) return h->fail(L3D_ERR_INVALID, "not enough images! can't compute 3D model...");   // line3D.cc:347-351
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = hopt(h).timing != 0;
     double tl = now_s();
     auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d prepare] %-28s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
     h->computation = true;
@@ -918,8 +922,7 @@ struct ChainFinalizer {
     std::vector<std::pair<int, size_t>> queue;      // (0 / 1 = the two halves of a split, order index) or (2 = merge part, view index * kParts + part)
     bool done = false;
     std::vector<std::thread> workers;
-    bool timing = getenv("L3D_TIMING") != nullptr;
-    bool trace = getenv("L3D_TIMING") && atoi(getenv("L3D_TIMING")) >= 2;
+    bool timing = false, trace = false;             // (set with h)
     struct LogRec { int kind, id; double t0, t1; };
     std::vector<LogRec> log;
     double t_split = 0, t_merge = 0, t_last_done = 0;
@@ -1172,6 +1175,7 @@ void start_finalizer(L* h, ChainPlan& P)
     P.fin = static_cast<ChainFinalizer*>(h->finalizer);
     ChainFinalizer& fin = *P.fin;
     fin.h = h;
+    fin.timing = hopt(h).timing != 0; fin.trace = hopt(h).timing >= 2;
     if (!P.fin_tables) {                                // who sends reverse entries to whom: part of the (static) schedule
         P.own_index.assign(nvl, -1); P.pending0.assign(nvl, 0); P.contributors.assign(nvl, {}); P.targets.assign(n, {});
         for (size_t k = 0; k < n; ++k) {
@@ -1227,7 +1231,7 @@ void finish_chain_host(L* h, ChainPlan& P, bool ok)
     h->pot_foreign.erase(std::unique(h->pot_foreign.begin(), h->pot_foreign.end()), h->pot_foreign.end());
     if (h->keep_view_matches) for (size_t k = 0; k < n; ++k) h->view_matches[h->order[k]].assign(h->saved[k].begin(), h->saved[k].end());
     h->t_finalize += now_s() - t2;
-    if (getenv("L3D_CHECK_POT")) {
+    if (hopt(h).check_pot) {
         // self-check (tests): every per-view list must be the plain normal form (sort + unique) of all its entries,
         // rebuilt here from the kept lists the slow way
         std::vector<std::vector<std::pair<uint32_t, Key>>> ref(h->pot.size());
@@ -1345,7 +1349,7 @@ int adopt_resident_products(L* h, ChainPlan& P)
             l3d_free(m);
         }
     }
-    if (getenv("L3D_CHECK_POT")) { int rc = check_resident_products(h, P); if (rc) return rc; }
+    if (hopt(h).check_pot) { int rc = check_resident_products(h, P); if (rc) return rc; }
     return L3D_OK;
 }
 
@@ -1369,7 +1373,7 @@ int match_views_resident(L* h, ChainPlan& P, double t0)
     h->stat_pairs += st[0];
     h->stat_raw += st[1];
     h->t_match = now_s() - t0;
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d match_views] resident chain + device products %.2f ms\n", (now_s() - t1) * 1e3);
+    if (hopt(h).timing) fprintf(stderr, "[l3d match_views] resident chain + device products %.2f ms\n", (now_s() - t1) * 1e3);
     return L3D_OK;
 }
 
@@ -1383,7 +1387,7 @@ int match_views(L* h)
     if (!Pp) return match_views_sync(h);
     ChainPlan& P = *Pp;
     const double tb = now_s();
-    if (!(h->host_bookkeeping || getenv("L3D_HOST_BOOKKEEPING"))) {
+    if (!(h->host_bookkeeping || hopt(h).host_bookkeeping)) {
         const int rr = match_views_resident(h, P, t0);
         if (rr != L3D_ERR_UNSUPPORTED) return rr;           // (more kept matches than the device builder takes: host lists)
     }
@@ -1394,7 +1398,7 @@ int match_views(L* h)
     const double t2 = now_s();
     finish_chain_host(h, P, rc == L3D_OK);
     if (h->pot_check_failed) return h->fail(L3D_ERR_INVALID, "L3D_CHECK_POT: a potential-correspondence list is not in normal form");
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d match_views] begin %.2f  schedule %.2f  finaliser start %.2f  chain %.2f  finish %.2f ms\n",
+    if (hopt(h).timing) fprintf(stderr, "[l3d match_views] begin %.2f  schedule %.2f  finaliser start %.2f  chain %.2f  finish %.2f ms\n",
                                       (ta - t0) * 1e3, (tb - ta) * 1e3, (t1 - tb) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     if (rc) return h->fail(rc, std::string("match_chain: ") + l3d_last_error(h->ctx));
     double st[4];
@@ -1509,7 +1513,6 @@ void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, 
     const l3d_edge* sorted = edges_in;
     if (!presorted) {
         std::vector<uint32_t> order;
-        const double t_sort = now_s();
         {
             const l3d_edge* e = edges_in;
             l3d::parallel_stable_order(n_edges, (size_t)65536, (size_t)65536, [e](size_t i) { return l3d::float_order_key(e[i].w) >> 16; },
@@ -1520,7 +1523,6 @@ void perform_clustering(const l3d_edge* edges_in, size_t n_edges, int numNodes, 
         l3d_edge* g = gathered.get();
         parallel_slices(n_edges, finish_threads(), [&](size_t k0, size_t k1, unsigned) { for (size_t k = k0; k < k1; ++k) g[k] = edges_in[order[k]]; });
         sorted = g;
-        if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish]   (edge order %.2f ms)\n", (now_s() - t_sort) * 1e3);
     }
     std::vector<int> rank((size_t)numNodes, 0), cid((size_t)numNodes), size((size_t)numNodes, 1);
     std::vector<float> thr((size_t)numNodes, c);
@@ -1616,7 +1618,7 @@ int perform_diffusion(L* h, const EdgeVec& A, int n, EdgeVec& out)
             }
         });
         if (missing.load() == 0) {
-            if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d rdd] %-24s %8.2f ms\n", "symmetrise", (now_s() - t_sym) * 1e3);
+            if (hopt(h).timing) fprintf(stderr, "[l3d rdd] %-24s %8.2f ms\n", "symmetrise", (now_s() - t_sym) * 1e3);
             return L3D_OK;
         }
     }
@@ -1739,7 +1741,7 @@ int fill_affinity_resident(L* h)
     std::vector<size_t> voff(nv + 1, 0);
     for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
     L::AffTables& T = h->aff;
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = hopt(h).timing != 0;
     double tl = now_s();
     auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish]   fill: %-22s %8.2f ms\n", what, (t - tl) * 1e3); tl = t; } };
     const bool changed = !T.coll_valid || T.coll_start.size() != voff.back() + 1;
@@ -1770,7 +1772,7 @@ int fill_affinity_resident(L* h)
 int cluster_segments_2D(L* h, bool perform_diff)
 {
     const double t0 = now_s();
-    const bool timing = getenv("L3D_TIMING") != nullptr;
+    const bool timing = hopt(h).timing != 0;
     double tm_last = t0;
     auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", what, (t - tm_last) * 1e3); tm_last = t; } };
     h->A.clear(); h->n_edges = 0; h->A_on_host = true; h->local2global.clear(); h->result.clear();
@@ -1912,7 +1914,7 @@ int cluster_segments_2D(L* h, bool perform_diff)
         // (L3D_ERR_UNSUPPORTED) goes through the reference's map arithmetic on the host
         // ... and so does the merge loop itself, one wave per connected component (l3d_perform_clustering_device): only the labels
         // come back.  L3D_HOST_CLUSTERING=1 keeps the merge loop on the worker threads (the seam tests compare the two).
-        const bool host_loop = getenv("L3D_HOST_CLUSTERING") != nullptr;
+        const bool host_loop = hopt(h).host_clustering != 0;
         const int nnz = (int)h->n_edges, diff = perform_diff ? 1 : 0;
         int rc = L3D_ERR_UNSUPPORTED;
         if (resident_list && !host_loop) {
@@ -2095,9 +2097,9 @@ int l3d_line3d_create(int device, int matching_neighbors, float unc_upper, float
     if (h->unc_upper <= h->unc_lower) h->unc_upper = h->unc_lower + 1.0f;
     h->sigma_p = sigma_p; h->sigma_a = sigma_a; h->min_baseline = min_baseline;
     h->use_collinearity = use_collinearity != 0;
-    h->force_sync = getenv("L3D_MATCH_SYNC") != nullptr;
+    h->force_sync = l3d::ctx_options(ctx).match_sync != 0;
     h->warm_thread = std::thread([ctx]() { (void)l3d_warm_up(ctx); });
-    h->host_bookkeeping = getenv("L3D_HOST_BOOKKEEPING") != nullptr;
+    h->host_bookkeeping = l3d::ctx_options(ctx).host_bookkeeping != 0;
     *out = h;
     return L3D_OK;
 }
@@ -2276,9 +2278,9 @@ int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
     const double t0 = now_s();
     if (h->resident_products) { const int rg = greedy_selection_resident(h); if (rg) return rg; }
     else greedy_selection(h);                              // optimizeLocalMatches, :888-896
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
+    if (hopt(h).timing) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
     const int rc = cluster_segments_2D(h, perform_diffusion != 0);
-    if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "total", (now_s() - t0) * 1e3);
+    if (hopt(h).timing) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "total", (now_s() - t0) * 1e3);
     return rc;
 }
 // Line3D::compute3Dmodel, line3D.cc:345-374
@@ -2443,7 +2445,7 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         if (slot_bytes_out) *slot_bytes_out = slot_bytes;
         const double t2 = now_s();
         const int rc2 = l3d_line3d_shard_close(h, commit == 1 && rc == L3D_OK);
-        if (getenv("L3D_TIMING")) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
+        if (hopt(h).timing) fprintf(stderr, "[l3d shard_run] open (schedule, tables, arenas) %.2f  run %.2f  close (finalise host state) %.2f ms\n",
                                           (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
         if (rc == L3D_OK) return rc2;
         h->fail(rc, msg);

@@ -1003,12 +1003,19 @@ static float sigma_squared(float k_lower, float k_upper, float median, float dep
     return -(d2 - d1) * (d2 - d1) / (2.0f * logf(0.01f));
 }
 
-/* Line3D::distance_point2line_3D, line3D.cc:1684-1691 (Eigen: dir * ((X-P1)^T * dir)) */
+/* Line3D::distance_point2line_3D, line3D.cc:1684-1691.  The expression at :1689 is `P1 + (dir * ((X - P1).transpose()) * dir)`: by C++
+ * precedence (dir * v^T) * dir -- the 3x3 OUTER PRODUCT M(i,j) = dir[i]*v[j] first (Eigen evaluates a nested product into a temporary),
+ * then the matrix-vector product M*dir, each row accumulated over j in index order -- not dir * (v . dir).  The two differ by an ulp of a
+ * double before the cast to float.  (What stays unpinned: the order in which Eigen itself adds the three terms of a fixed-size sum differs
+ * between its versions -- 3.2 unrolls x0 + (x1 + x2), 3.3 with unaligned vectorisation (x0 + x1) + x2 -- and the reference pins no version.) */
 static float distance_point2line_3D(const double* P1, const double* dir, const double* X)
 {
     double v[3] = { X[0] - P1[0], X[1] - P1[1], X[2] - P1[2] };
-    double s = v[0] * dir[0] + v[1] * dir[1] + v[2] * dir[2];
-    double pr[3] = { P1[0] + dir[0] * s, P1[1] + dir[1] * s, P1[2] + dir[2] * s };
+    double pr[3];
+    for (int i = 0; i < 3; ++i) {
+        double m0 = dir[i] * v[0], m1 = dir[i] * v[1], m2 = dir[i] * v[2];         /* row i of dir * v^T */
+        pr[i] = P1[i] + ((m0 * dir[0] + m1 * dir[1]) + m2 * dir[2]);
+    }
     double d[3] = { pr[0] - X[0], pr[1] - X[1], pr[2] - X[2] };
     return (float)sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
 }

@@ -19,6 +19,9 @@ from collections import OrderedDict
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# the reference compiled here (unmodified text behind an extern "C" door) / the kernels with builder-written splices (corroboration only)
+REF_DEVFN = os.path.join(_HERE, "_ref", "libdevfn_ref.so")
+SPLICED_KERNELS = os.path.join(_HERE, "_spliced", "libkernels_spliced.so")
 
 
 class Match(C.Structure):
@@ -144,7 +147,7 @@ def rdd(lib, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
 
 
 def set_reference_kernels(lib, ref):
-    """Run the oracle's host orchestration with the REFERENCE's own kernels (ref = oracle/_ref/libdevfn_ref.so: K_collinearity, K_pairwise_matches,
+    """Run the oracle's host orchestration with the REFERENCE's own kernels (ref = oracle/_spliced/libkernels_spliced.so: K_collinearity, K_pairwise_matches,
     K_verify_matches, K_sparseMat_row_normalization, K_sparseMat_diffusion_step compiled from cudawrapper.cu's text); ref = None: back to the
     restatements.  Process-wide for that library."""
     if ref is None:
@@ -157,7 +160,7 @@ def set_reference_kernels(lib, ref):
 
 def pairwise_dense_view(lib, mv, cam, reference=None):
     """The dense S x width float4 buffer K_pairwise_matches fills for neighbour `cam` of a marshalled view (marshal_view): the oracle's
-    l3do_pairwise_dense, or -- reference = oracle/_ref/libdevfn_ref.so -- the reference's own kernel text (l3dref_pairwise_matches)."""
+    l3do_pairwise_dense, or -- reference = oracle/_spliced/libkernels_spliced.so -- the reference's kernel text with table reads for its texture fetches (l3dref_pairwise_matches)."""
     f = lambda a: np.ascontiguousarray(a, np.float32)
     src, tgt, Rs, Cs, F, R, Cn = f(mv["src_segs"]), f(mv["tgt_segs"]), f(mv["RtKinv_src"]), f(mv["C_src"]), f(mv["F"]), f(mv["RtKinv"]), f(mv["centers"])
     off, w, S = int(mv["offsets"][cam][0]), int(mv["offsets"][cam][1]), len(src)
@@ -172,8 +175,8 @@ def pairwise_dense_view(lib, mv, cam, reference=None):
 
 
 def verify_case(lib, case, reference=None):
-    """K_verify_matches on a packed candidate list (tests/verify_cases.py): the oracle's l3do_verify, or -- reference = oracle/_ref/libdevfn_ref.so --
-    the reference's own kernel text (l3dref_verify_matches).  Returns the confidences (the .w of matches_data)."""
+    """K_verify_matches on a packed candidate list (tests/verify_cases.py): the oracle's l3do_verify, or -- reference = oracle/_spliced/libkernels_spliced.so --
+    the reference's kernel text with table reads for its texture fetches (l3dref_verify_matches).  Returns the confidences (the .w of matches_data)."""
     md = np.ascontiguousarray(case["matches_data"], np.float32).copy()
     R = len(md)
     f = lambda a, dt=np.float32: np.ascontiguousarray(a, dt)
@@ -189,7 +192,7 @@ def verify_case(lib, case, reference=None):
 
 
 def rdd_hooked(lib, ref, edges: np.ndarray, n: int, iters: int = 10) -> np.ndarray:
-    """l3do_rdd_hooked with the two kernels of `ref` (oracle/_ref/libdevfn_ref.so: the reference's own K_sparseMat_row_normalization and
+    """l3do_rdd_hooked with the two kernels of `ref` (oracle/_spliced/libkernels_spliced.so: the reference's own K_sparseMat_row_normalization and
     K_sparseMat_diffusion_step, cudawrapper.cu:717-829) in place of the oracle's restatements."""
     edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
     out = np.zeros(len(edges), dtype=EDGE_DTYPE)

@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
-"""oracle/make_ref_devfn.py -- TEST INFRASTRUCTURE.  Builds oracle/_ref/libdevfn_ref.so: the reference's own texture-free
-device functions, compiled from the sources where they lie under /root/reference against the genuine NVIDIA runtime
-headers bundled with this image's triton wheel (cuda_runtime.h, device_launch_parameters.h, math_constants.h; helper_math.h of the reference is used
-unmodified).  The translation unit is assembled in memory from line ranges of cudawrapper.h / cudawrapper.cu and piped to
-g++ -- no reference text is written into the repository, no stand-in header is involved; only the extern "C" door
-(ref_devfn_door.cc) is ours.  Exit code 0 and a message when the reference checkout or the headers are absent (the GPU box
-uses the prebuilt file)."""
+"""oracle/make_ref_devfn.py -- TEST INFRASTRUCTURE.  Builds TWO libraries from the sources where they lie under /root/reference
+against the genuine NVIDIA runtime headers bundled with this image's triton wheel (cuda_runtime.h, device_launch_parameters.h,
+math_constants.h; helper_math.h of the reference is used unmodified).  The translation units are assembled in memory from line
+ranges of cudawrapper.h / cudawrapper.cu / sparsematrix.h and piped to g++ -- no reference text is written into the repository,
+no stand-in header is involved.
+
+  oracle/_ref/libdevfn_ref.so          RANGES_CLEAN: the reference's own texture-free device functions and the two comparators of
+                                       L3DMatchingPair, UNMODIFIED text; only the extern "C" door (ref_devfn_door.cc) is ours.
+                                       This is "the reference compiled here".
+  oracle/_spliced/libkernels_spliced.so  RANGES_CLEAN + RANGES_SPLICED: the five kernels and three kernel bodies as far as they can be
+                                       built without CUDA texture references -- every ("text", ...) entry below is a BUILDER-WRITTEN
+                                       line (texture fetches as table reads, three restated texture-reading callees, function heads
+                                       around kernel bodies), the launch variables get storage from ref_devfn_launch.cc.
+                                       CORROBORATION of the oracle's restatement, not the reference compiled here; kept out of _ref/.
+
+Exit code 0 and a message when the reference checkout or the headers are absent (the GPU box uses the prebuilt files)."""
 import os
 import subprocess
 import sys
@@ -17,8 +26,12 @@ REF = os.environ.get("REF", "/root/reference")
 # D_unproject_point_src; the two texture-free kernels of replicator_dynamics_diffusion: K_sparseMat_row_normalization,
 # K_sparseMat_diffusion_step (their launch variables -- threadIdx & co., declared by the genuine <device_launch_parameters.h> -- get
 # their storage from ref_devfn_launch.cc, a second translation unit of ours)
-RANGES = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.cu", 93, 99), ("cudawrapper.cu", 116, 141),
-          ("cudawrapper.cu", 165, 285), ("cudawrapper.cu", 337, 344), ("cudawrapper.cu", 716, 829),
+RANGES_CLEAN = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.cu", 93, 99), ("cudawrapper.cu", 116, 141),
+                ("cudawrapper.cu", 165, 285), ("cudawrapper.cu", 337, 344),
+                # L3DMatchingPair and its two comparators (sparsematrix.h:36-49 the fields, :68-85 sortMatchingPairs / sortMatchingPairsByConf) without the
+                # boost serialisation members in between (:51-65); the closing brace of the shortened struct is the one line here that is ours
+                ("sparsematrix.h", 36, 49), ("text", "};"), ("sparsematrix.h", 67, 85)]
+RANGES_SPLICED = [("cudawrapper.cu", 716, 829),
           # K_collinearity's body for one pair of segments: the reference's own lines behind the four texture fetches (:492 `result`, :499 and
           # :506 the two lines, :508-529 distances, affinity, overlap check) inside a function whose parameters stand for the fetched points --
           # the two lines of text below are ours, everything between them is the reference's
@@ -85,10 +98,7 @@ RANGES = [("cudawrapper.h", 43, 46), ("cudawrapper.cu", 56, 61), ("cudawrapper.c
           ("cudawrapper.cu", 499, 501),
           ("text", "                float3 q1 = make_float3(l3dref_tab_src[4 * y], l3dref_tab_src[4 * y + 1], 1.0f);\n"
                    "                float3 q2 = make_float3(l3dref_tab_src[4 * y + 2], l3dref_tab_src[4 * y + 3], 1.0f);"),
-          ("cudawrapper.cu", 506, 535),
-          # L3DMatchingPair and its two comparators (sparsematrix.h:36-49 the fields, :68-85 sortMatchingPairs / sortMatchingPairsByConf) without the
-          # boost serialisation members in between (:51-65)
-          ("sparsematrix.h", 36, 49), ("text", "};"), ("sparsematrix.h", 67, 85)]
+          ("cudawrapper.cu", 506, 535)]
 
 
 def nvidia_include():
@@ -100,30 +110,36 @@ def nvidia_include():
     return p if all(os.path.exists(os.path.join(p, f)) for f in ("cuda_runtime.h", "device_launch_parameters.h", "math_constants.h")) else None
 
 
-def main():
-    inc = nvidia_include()
-    if not os.path.exists(os.path.join(REF, "cudawrapper.cu")) or inc is None:
-        print("reference checkout or NVIDIA runtime headers absent: keeping prebuilt oracle/_ref/libdevfn_ref.so (if any)")
-        return 0
+def build(ranges, doors, extra_sources, out, inc):
     tu = ['#include <cuda_runtime.h>\n#include <device_launch_parameters.h>\n#include <math_constants.h>\n#include "helper_math.h"\nnamespace L3D {\n']
-    for name, a, b in [(r + (None,))[:3] for r in RANGES]:
+    for name, a, b in [(r + (None,))[:3] for r in ranges]:
         if name == "text":
             tu.append(a + "\n")
             continue
         with open(os.path.join(REF, name)) as f:
             lines = f.read().split("\n")
         tu.append("\n".join(lines[a - 1:b]) + "\n")
-    tu.append('}  // namespace L3D\n#include "ref_devfn_door.cc"\n')
-    out_dir = os.path.join(HERE, "_ref")
-    os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, "libdevfn_ref.so")
+    tu.append("}  // namespace L3D\n" + "".join('#include "%s"\n' % d for d in doors))
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-shared", "-std=c++11", "-ffp-contract=off", "-fno-fast-math", "-I" + inc, "-I" + REF,
-           "-I" + HERE, os.path.join(HERE, "ref_devfn_launch.cc"), "-x", "c++", "-", "-o", out]
+           "-I" + HERE] + extra_sources + ["-x", "c++", "-", "-o", out]
     p = subprocess.run(cmd, input="".join(tu).encode(), capture_output=True)
     sys.stderr.write(p.stderr.decode())
     if p.returncode == 0:
-        print("built oracle/_ref/libdevfn_ref.so")
+        print("built " + os.path.relpath(out, os.path.dirname(HERE)))
     return p.returncode
+
+
+def main():
+    inc = nvidia_include()
+    if not os.path.exists(os.path.join(REF, "cudawrapper.cu")) or inc is None:
+        print("reference checkout or NVIDIA runtime headers absent: keeping prebuilt oracle/_ref/libdevfn_ref.so and oracle/_spliced/libkernels_spliced.so (if any)")
+        return 0
+    rc = build(RANGES_CLEAN, ["ref_devfn_door.cc"], [], os.path.join(HERE, "_ref", "libdevfn_ref.so"), inc)
+    if rc:
+        return rc
+    return build(RANGES_CLEAN + RANGES_SPLICED, ["ref_devfn_door.cc", "ref_spliced_door.cc"], [os.path.join(HERE, "ref_devfn_launch.cc")],
+                 os.path.join(HERE, "_spliced", "libkernels_spliced.so"), inc)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 """Inputs for the device-function pins (tests/test_oracle_pins.py, tests/golden/make_golden_devfn.py): the same seeded random
 and adversarial cases are fired through the reference's own functions (oracle/_ref/libdevfn_ref.so, prefix l3dref_) and the
-oracle's restatements (oracle/libl3d_oracle.so, prefix l3do_devfn_).  Points are float32 xyz triples."""
+oracle's restatements (oracle/libl3d_oracle.so, prefix l3do_devfn_); the three kernel bodies (SPLICED) through
+oracle/_spliced/libkernels_spliced.so.  Points are float32 xyz triples."""
 import ctypes as C
 
 import numpy as np
@@ -257,10 +258,17 @@ def make_inputs(seed, n):
     return {k: (tuple(np.ascontiguousarray(a) for a in ins), o, fn, st) for k, (ins, o, fn, st) in c.items()}
 
 
-def run(lib, prefix, cases):
-    """Every pinned function of `lib` on `cases` (make_inputs).  Returns {name: (inputs tuple, output)}."""
+# the three kernel BODIES: reference lines inside builder-written function heads (oracle/_spliced/libkernels_spliced.so, corroboration);
+# everything else is unmodified reference text (oracle/_ref/libdevfn_ref.so)
+SPLICED = ("collinearity_pair", "hypothesis_confidence", "pairwise_overlap")
+
+
+def run(lib, prefix, cases, only=None, skip=()):
+    """Every pinned function of `lib` on `cases` (make_inputs); only / skip: case names.  Returns {name: (inputs tuple, output)}."""
     res = {}
     for name, (ins, (dt, shape), fname, stride) in cases.items():
+        if (only is not None and name not in only) or name in skip:
+            continue
         fn = getattr(lib, prefix + fname)
         fn.restype = None
         out = np.zeros(shape, dt)
@@ -278,6 +286,15 @@ def run(lib, prefix, cases):
 
 def run_all(lib, prefix, seed, n):
     return run(lib, prefix, make_inputs(seed, n))
+
+
+def run_reference(clean, spliced, cases):
+    """The reference side of the pins: unmodified text out of oracle/_ref/libdevfn_ref.so (`clean`), the three kernel bodies out of
+    oracle/_spliced/libkernels_spliced.so (`spliced`; None: left out)."""
+    res = run(clean, "l3dref_", cases, skip=SPLICED)
+    if spliced is not None:
+        res.update({k: v for k, v in run(spliced, "l3dref_", cases, only=SPLICED).items() if k != "constants"})
+    return res
 
 
 def same_bits(a, b):

@@ -20,8 +20,9 @@ import devfn_cases as dc  # noqa: E402
 SEED, N = 20261, 3000
 
 if __name__ == "__main__":
-    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so"))
-    res = dc.run_all(ref, "l3dref_", SEED, N)
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so"))                    # unmodified reference text
+    spliced = C.CDLL(os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so"))       # the three kernel bodies (dc.SPLICED): corroboration
+    res = dc.run_reference(ref, spliced, dc.make_inputs(SEED, N))
     out = {"seed": np.int64(SEED), "n": np.int64(N), "sizeof_angle_acos": np.int64(ref.l3dref_sizeof_angle_acos())}
     for name, (ins, o) in res.items():
         for i, a in enumerate(ins):

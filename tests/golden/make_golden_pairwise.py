@@ -1,4 +1,4 @@
-"""Generates tests/golden/pairwise_ref.npz.  Run in the build container (needs oracle/_ref/libdevfn_ref.so: `make -C oracle ref_devfn`):
+"""Generates tests/golden/pairwise_ref.npz.  Run in the build container (needs oracle/_spliced/libkernels_spliced.so: `make -C oracle ref_devfn`):
     python tests/golden/make_golden_pairwise.py
 Data only: for two small seeded scenes (a helix, cameras that face each other) every non-zero entry of the dense buffers the REFERENCE's own
 K_pairwise_matches writes (cudawrapper.cu:538-611 + D_get_triangulation_depth :304-335 compiled from its text by oracle/make_ref_devfn.py; texture
@@ -38,7 +38,7 @@ def entries(o, lib, reference):
 
 
 if __name__ == "__main__":
-    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so"))
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so"))
     lib = op.load_lib()
     out = {}
     for name, scene, N in scenes():

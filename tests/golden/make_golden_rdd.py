@@ -1,4 +1,4 @@
-"""Generates tests/golden/rdd_ref.npz.  Run in the build container (needs oracle/_ref/libdevfn_ref.so: `make -C oracle ref_devfn`):
+"""Generates tests/golden/rdd_ref.npz.  Run in the build container (needs oracle/_spliced/libkernels_spliced.so: `make -C oracle ref_devfn`):
     python tests/golden/make_golden_rdd.py
 Data only: the affinity lists of tests/rdd_cases.py and the result of replicator_dynamics_diffusion (cudawrapper.cu:1131-1191) with the
 arithmetic done by the REFERENCE's own kernels -- K_sparseMat_row_normalization and K_sparseMat_diffusion_step compiled from
@@ -19,7 +19,7 @@ import l3d_oracle_pipeline as op  # noqa: E402
 import rdd_cases as rc  # noqa: E402
 
 if __name__ == "__main__":
-    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so"))
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so"))
     lib = op.load_lib()
     out = {}
     for k, case in enumerate(rc.CASES):

@@ -1,4 +1,4 @@
-"""Generates tests/golden/verify_ref.npz.  Run in the build container (needs oracle/_ref/libdevfn_ref.so: `make -C oracle ref_devfn`):
+"""Generates tests/golden/verify_ref.npz.  Run in the build container (needs oracle/_spliced/libkernels_spliced.so: `make -C oracle ref_devfn`):
     python tests/golden/make_golden_verify.py
 Data only: the confidences the REFERENCE's own K_verify_matches (cudawrapper.cu:614-714, compiled from its text by oracle/make_ref_devfn.py:
 everything but the five lines that fetch the source segment from a texture; its callee D_hypothesis_confidence is the reference's body,
@@ -27,7 +27,7 @@ def digest(case):
 
 
 if __name__ == "__main__":
-    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so"))
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so"))
     out = {}
     for k, kw in enumerate(vc.CASES):
         case = vc.make_case(**kw)

@@ -98,7 +98,7 @@ def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None, refere
     (view.cc:200-224), the kept matches of the earlier views towards `vid` taken from `lists` (view id -> (matches, median);
     view ids are 0..V-1 in processing order).  The range is cut into one piece per host thread (the C oracle releases the
     GIL; a source segment's verification only reads that segment's candidates, so the pieces concatenate).
-    reference = oracle/_ref/libdevfn_ref.so: the libm build of the oracle with the REFERENCE's own kernels plugged in (one thread: their launch
+    reference = oracle/_spliced/libkernels_spliced.so: the libm build of the oracle with the REFERENCE's own kernels plugged in (one thread: their launch
     variables are process globals)."""
     import os
     import threading

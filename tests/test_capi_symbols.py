@@ -117,3 +117,17 @@ def test_host_clustering_large_lists_with_ties(oracle_lib):
             assert ref.l3dref_clustering(ei.ctypes.data_as(C.c_void_p), ej.ctypes.data_as(C.c_void_p), ew.ctypes.data_as(C.c_void_p),
                                          C.c_int(E), C.c_int(n), C.c_float(1.0), want.ctypes.data_as(C.c_void_p)) == 0
             assert np.array_equal(labels, want), (n, E)
+
+
+def test_the_environment_is_read_in_one_place_only():
+    """Every L3D_* switch is read once, by l3d_ctx_create (l3d::options_from_env in l3d_capi.hip); afterwards switches change only
+    through l3d_set_option.  No other getenv call anywhere in the product sources."""
+    src = os.path.join(ROOT, "line3d_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".cpp", ".hpp")):
+            for i, line in enumerate(open(os.path.join(src, f)), 1):
+                code = line.split("//")[0]
+                if re.search(r"\bgetenv\s*\(", code):
+                    hits.append("%s:%d" % (f, i))
+    assert len(hits) == 1 and hits[0].startswith("l3d_capi.hip:"), hits

@@ -99,12 +99,12 @@ def test_config2_view_slices_against_the_oracle(cfg2_scene, cfg2_chain, vid, lo,
 
 def test_config2_mid_chain_slice_against_the_reference_kernels(cfg2_scene, cfg2_chain):
     """The same mid-chain slice (view 33, 128 source segments) with the REFERENCE's own K_pairwise_matches and K_verify_matches
-    (oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the product keeps
+    (oracle/_spliced/libkernels_spliced.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the product keeps
     the same correspondences with the same depths; confidences within 5e-6 (contract vs glibc expf / acosf)."""
     import ctypes as C
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path) or not hasattr(C.CDLL(path), "l3dref_pairwise_matches"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so with the reference's kernels is not built")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so with the reference's kernels is not built")
     _l, lists = cfg2_chain
     vid, lo, hi = 33, 900, 1028
     exp, mv, existing = oracle_view_slice(cfg2_scene, lists, vid, lo, hi, N2, reference=C.CDLL(path))

@@ -187,13 +187,14 @@ def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, full
     import ctypes as C
     l, _ = chain_run
     out = {}
-    variants = {"device": {}, "device, 5-target passes": {"L3D_AFF_CHUNK": "5"}, "device, one launch per view": {"L3D_AFF_PER_VIEW": "1"},
-                "device, 5 host threads": {"L3D_HOST_THREADS": "5"}}
+    variants = {"device": {}, "device, 5-target passes": {"L3D_AFF_CHUNK": 5}, "device, one launch per view": {"L3D_AFF_PER_VIEW": 1},
+                "device, 5 host threads": {"L3D_HOST_THREADS": 5}}
+    lctx = l.context()
     for name, env in variants.items():
         for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFF_PER_VIEW"):
-            monkeypatch.delenv(k, raising=False)
+            lctx.set_option(k, 0)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            lctx.set_option(k, v)
         for diffusion in (False, True):
             l.finish(diffusion)
             A, n_nodes = l.affinity()[:2]
@@ -204,7 +205,7 @@ def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, full
                 sig.update(np.asarray([np.concatenate(p) for p in seg3], dtype=np.float64).tobytes())
             out[(name, diffusion)] = (len(A), n_nodes, len(lines), sig.hexdigest())
     for k in ("L3D_AFF_CHUNK", "L3D_HOST_THREADS", "L3D_AFF_PER_VIEW"):
-        monkeypatch.delenv(k, raising=False)
+        lctx.set_option(k, 0)
     for diffusion in (False, True):
         assert out[("device", diffusion)][0] > 100000 and out[("device", diffusion)][2] > 100
         for name in variants:

@@ -711,6 +711,26 @@ def _products_digest(l):
     return {k: np.ascontiguousarray(p[k]).tobytes() for k in ("seg_base", "pot_start", "pot_tgt", "best", "hyp", "score")}
 
 
+def test_products_built_in_blocks_of_views_equal_the_one_block_build(small_scene, small_oracle):
+    """matchViews' products are built in blocks of consecutive dense views so that the transient key arrays are bounded by the block, not by
+    the scene (l3d_products.hip; the reference spills matches to disk per view, view.cc:150-224).  Blocks of one view, of a few views and the
+    one-block build give the same CSR of potential correspondences, best matches and hypotheses byte for byte (and each is compared with the
+    plain host construction: L3D_CHECK_POT), and the same lines as the oracle."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    l = Line3D("", matchingNeighbors=6)
+    load_scene(l, small_scene)
+    l.compute3Dmodel(False)
+    ref = _products_digest(l)
+    assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+    for keys in (1, 4000, 30000):
+        l.context().set_option("L3D_PROD_BLOCK_KEYS", keys)
+        l.match_views()
+        l.finish(False)
+        assert _products_digest(l) == ref, keys
+        assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+    l.close()
+
+
 def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, monkeypatch):
     """commit="device": the sharded run hands no kept list to the host -- every rank builds matchViews' products on its device from the
     gathered slots (l3d_shard_chain_products).  World 1 (local exchange) and every rank of a recorded world-3 job (replay): kept lists,
@@ -771,15 +791,15 @@ def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, mon
 
 def test_product_against_the_reference_kernels_pipeline(small_scene):
     """The product against a pipeline whose kernels are the REFERENCE's own (K_collinearity, K_pairwise_matches, K_verify_matches, the diffusion
-    kernels: oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the same
+    kernels: oracle/_spliced/libkernels_spliced.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the same
     correspondence ids in every view, confidences within 5e-6 (the product's expf / acosf are the numeric contract's), medians equal, the same
     3-D lines within 1e-4 -- BASELINE's acceptance rule, checked against the reference's arithmetic directly."""
     import ctypes as C
     from line3d_amd.pipeline import Line3D, load_scene
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(root, "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path) or not hasattr(C.CDLL(path), "l3dref_pairwise_matches"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so with the reference's kernels is not built")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so with the reference's kernels is not built")
     ref = C.CDLL(path)
     lib = op.load_lib(libm=True)
     try:

@@ -405,8 +405,7 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     (`one_way`: the schedule then waits for earlier views) -- against the reference's loops with a literal `used` set.
     Small passes (`chunk` targets) make groups and flattened entries straddle passes."""
     from line3d_amd.capi import HYP_DTYPE
-    if chunk:
-        monkeypatch.setenv("L3D_AFF_CHUNK", chunk)
+    gpu_ctx.set_option("L3D_AFF_CHUNK", int(chunk) if chunk else 0)       # (a switch of the context; the environment is read once, at its creation)
     rng = np.random.default_rng(seed)
     V, S = 7, 40
     dense = seed == 6                    # groups of more than 64 targets and collinearity lists of more than 64 entries (64-lane passes)
@@ -464,7 +463,10 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     pot_tgt = np.array([t for p in pot for t in p], np.int32)
     coll_other = np.array([x for c in coll for x, _ in c], np.int32)
     coll_w = np.array([w for c in coll for _, w in c], np.float32)
-    A, node_hyp, n_cand = gpu_ctx.affinity_fill(seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, 10.0)
+    try:
+        A, node_hyp, n_cand = gpu_ctx.affinity_fill(seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, 10.0)
+    finally:
+        gpu_ctx.set_option("L3D_AFF_CHUNK", 0)
     eA, e_nodes, e_cand = _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, coll, 10.0)
     assert n_cand == e_cand and len(eA) > 200
     assert node_hyp.tolist() == e_nodes
@@ -761,8 +763,11 @@ def test_clustering_merge_loop_without_components(gpu_ctx, oracle_lib, monkeypat
     want = op.clustering(oracle_lib, gpu_ctx.clustering_edges(A, n), n, 1.0)
     got, n_comp = gpu_ctx.perform_clustering_device(A, n, c=1.0)
     assert n_comp == 10 and np.array_equal(got, want)
-    monkeypatch.setenv("L3D_CC_MAX_ROUNDS", "1")
-    got1, n_comp1 = gpu_ctx.perform_clustering_device(A, n, c=1.0)
+    gpu_ctx.set_option("L3D_CC_MAX_ROUNDS", 1)
+    try:
+        got1, n_comp1 = gpu_ctx.perform_clustering_device(A, n, c=1.0)
+    finally:
+        gpu_ctx.set_option("L3D_CC_MAX_ROUNDS", 0)
     assert n_comp1 == 1 and np.array_equal(got1, want)
 
 

@@ -319,9 +319,11 @@ def test_device_functions_match_reference_live():
         pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
     ref = C.CDLL(path)
     assert ref.l3dref_sizeof_angle_acos() == 4
+    assert not hasattr(ref, "l3dref_pairwise_matches") and not hasattr(ref, "l3dref_collinearity_pair"), "oracle/_ref holds unmodified reference text only"
+    spliced = C.CDLL(op.SPLICED_KERNELS) if os.path.exists(op.SPLICED_KERNELS) else None     # the three kernel bodies: corroboration
     for seed in (1, 2, 3, 4):
         cases = dc.make_inputs(seed, 250000)
-        exp = dc.run(ref, "l3dref_", cases)
+        exp = dc.run_reference(ref, spliced, cases)
         for libm in (False, True):
             got = dc.run(op.load_lib(libm=libm), "l3do_devfn_", cases)
             for name in exp:
@@ -330,7 +332,7 @@ def test_device_functions_match_reference_live():
 
 # ---- the two kernels of replicator_dynamics_diffusion, pinned to the reference's own code -----------------------------------------
 # K_sparseMat_row_normalization and K_sparseMat_diffusion_step (cudawrapper.cu:717-829) are texture-free and every thread is
-# independent: oracle/_ref/libdevfn_ref.so holds them compiled from the reference's text (their launch variables get storage from
+# independent: oracle/_spliced/libkernels_spliced.so holds them compiled from the reference's text (their launch variables get storage from
 # oracle/ref_devfn_launch.cc); l3do_rdd_hooked runs the oracle's restatement of the host orchestration (sparsematrix.cc sort orders and
 # start indices, the loop of cudawrapper.cu:1131-1191) with those kernels in place of its own.
 def test_rdd_kernels_match_reference_golden(oracle_lib):
@@ -351,12 +353,12 @@ def test_rdd_kernels_match_reference_golden(oracle_lib):
 def test_rdd_kernels_match_reference_live(oracle_lib):
     """... and live, on more lists (the reference's kernels inside the oracle's loop against the oracle's own), 1 to 10 iterations."""
     import rdd_cases as rc
-    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so not built (reference checkout absent)")
     ref = C.CDLL(path)
     if not hasattr(ref, "l3dref_sparse_diffusion_step"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so predates the sparse-matrix kernels")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so predates the sparse-matrix kernels")
     for seed in range(20, 32):
         n = 20 + 37 * (seed - 20)
         A = rc.make_list(seed, n, 6 * n, symmetric_values=seed % 3 != 0, tiny=seed % 4 == 0)
@@ -388,7 +390,7 @@ def test_sparse_matrix_orders_match_reference_live(oracle_lib):
 
 
 # ---- K_verify_matches, pinned to the reference's own kernel text -------------------------------------------------------------------------
-# oracle/_ref/libdevfn_ref.so holds K_verify_matches compiled from cudawrapper.cu:614-714 -- all of it but the five lines that fetch the source
+# oracle/_spliced/libkernels_spliced.so (corroboration: builder-written table reads in place of the texture fetches) holds K_verify_matches compiled from cudawrapper.cu:614-714 -- all of it but the five lines that fetch the source
 # segment from a texture; of its two texture-reading callees D_hypothesis_confidence is the reference's own body (pinned above),
 # D_project_point_tgt a restatement over a table.  The loop over a segment's candidates, the skips, the per-camera maximum over contiguous runs,
 # the validity test of the projections, the 0.5 threshold and the sum are the reference's.  The libm build of the oracle must agree bit for
@@ -419,12 +421,12 @@ def test_verify_kernel_matches_reference_golden():
 
 def test_verify_kernel_matches_reference_live():
     import verify_cases as vc
-    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so not built (reference checkout absent)")
     ref = C.CDLL(path)
     if not hasattr(ref, "l3dref_verify_matches"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so predates the verification kernel")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so predates the verification kernel")
     for seed in range(40, 52):
         case = vc.make_case(seed, S=30 + 5 * (seed % 7), N=3 + seed % 9, m_max=20 + 10 * (seed % 5), spatial_k=[0.02, 0.0, 0.05, 0.005][seed % 4])
         _verify_checks(op.verify_case(None, case, ref), op.verify_case(op.load_lib(libm=True), case), op.verify_case(op.load_lib(libm=False), case))
@@ -455,12 +457,12 @@ def test_pairwise_kernel_matches_reference_golden(oracle_lib):
 
 
 def test_pairwise_kernel_matches_reference_live(oracle_lib):
-    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so not built (reference checkout absent)")
     ref = C.CDLL(path)
     if not hasattr(ref, "l3dref_pairwise_matches"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so predates the pair kernel")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so predates the pair kernel")
     from line3d_amd.synth import make_scene_from_poses
     scenes = [(make_scene(6, 150, 4, seed=21, step=0.05), 4), (make_scene(5, 200, 4, seed=22, noise_px=1.5), 4),
               (make_scene_from_poses([(4, 0, 0), (3.2, 0.1, 0.05), (2.4, 0.0, 0.1), (-4, 0, 0.2)], [(0, 0, 0)] * 4, 120, seed=23), 3)]      # forward motion + an opposing camera
@@ -495,7 +497,7 @@ def test_collinearity_kernel_matches_reference(oracle_lib):
             assert got.tobytes() == want.tobytes()
         else:
             assert np.array_equal(got > 0, want > 0) and np.max(np.abs(got - want)) <= 1.2e-7
-    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if os.path.exists(path) and hasattr(C.CDLL(path), "l3dref_collinearity"):
         ref = C.CDLL(path)
         for seed in (32, 33, 34):
@@ -540,15 +542,15 @@ def test_matching_pair_orders_match_reference_live(oracle_lib):
 @pytest.mark.parametrize("diffusion", [False, True])
 def test_pipeline_with_the_reference_kernels_equals_the_oracle(small_scene, diffusion):
     """The whole of compute3Dmodel with the REFERENCE's own kernels inside the oracle's host code (l3do_set_kernel_hooks: K_collinearity,
-    K_pairwise_matches, K_verify_matches and the two diffusion kernels out of oracle/_ref/libdevfn_ref.so, compiled from cudawrapper.cu's text)
+    K_pairwise_matches, K_verify_matches and the two diffusion kernels out of oracle/_spliced/libkernels_spliced.so, compiled from cudawrapper.cu's text)
     against the oracle's restatements, libm build: kept lists, medians, affinity list and 3-D lines bit for bit -- on the 10-view test scene and
     on cameras that face each other / move forward."""
-    path = os.path.join(ROOT, "oracle", "_ref", "libdevfn_ref.so")
+    path = os.path.join(ROOT, "oracle", "_spliced", "libkernels_spliced.so")
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libdevfn_ref.so not built (reference checkout absent)")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so not built (reference checkout absent)")
     ref = C.CDLL(path)
     if not hasattr(ref, "l3dref_pairwise_matches"):
-        pytest.skip("oracle/_ref/libdevfn_ref.so predates the kernels")
+        pytest.skip("oracle/_spliced/libkernels_spliced.so predates the kernels")
     from line3d_amd.synth import make_scene_from_poses
     lib = op.load_lib(libm=True)
     scenes = [(small_scene, 6), (make_scene_from_poses([(4, 0, 0), (-4, 0.2, 0.3), (0, 0.1, 4), (3.0, 0.1, 0.05), (1.5, 0.2, 0.1)], [(0, 0, 0)] * 5, 160, seed=29), 4)]
