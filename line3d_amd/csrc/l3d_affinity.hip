@@ -31,7 +31,7 @@
 // as soon as its hypothesis is earlier -- no bit of another source is read.  Only views holding an entry WITHOUT the
 // reverse record (early-return views, cudawrapper.cu:877-878) have to wait for the bits of the views before them: the
 // launches of k_aff_groups are cut there; everywhere else consecutive views share one launch.
-#include <hipcub/hipcub.hpp>
+#include "l3d_sort.hpp"
 
 #include "l3d_ctx.hpp"
 #include "l3d_similarity.hpp"
@@ -429,9 +429,9 @@ namespace {
 int scan_excl(l3d_ctx* c, const int* in, int* out, int n, hipStream_t st)
 {
     size_t bytes = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n + 1, st));
+    HIPCHK(c, exclusive_sum_int(nullptr, bytes, in, out, n + 1, st));
     HIPCHK(c, c->g7.reserve(bytes + 256));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->g7.p, bytes, in, out, n + 1, st));
+    HIPCHK(c, exclusive_sum_int(c->g7.p, bytes, in, out, n + 1, st));
     return L3D_OK;
 }
 

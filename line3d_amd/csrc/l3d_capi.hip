@@ -263,7 +263,7 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
 int l3d_warm_up(l3d_ctx* c)
 {
     if (!c) return L3D_ERR_INVALID;
-    void (*fns[])() = { warm_kernels, warm_verify_window, warm_rdd, warm_affinity, warm_linefit, warm_chain, warm_chain_sharded, warm_products };
+    void (*fns[])() = { warm_kernels, warm_verify_window, warm_rdd, warm_affinity, warm_linefit, warm_sort, warm_chain, warm_chain_sharded, warm_products };
     std::vector<std::thread> th;
     const int dev = c->device;
     for (auto f : fns) th.emplace_back([f, dev]() { (void)hipSetDevice(dev); f(); });

@@ -107,7 +107,7 @@ struct VerifyArgs {
 };
 
 // code-object warm-up, one function per translation unit (l3d_warm_up)
-void warm_kernels(); void warm_verify_window(); void warm_rdd(); void warm_affinity(); void warm_linefit(); void warm_chain(); void warm_chain_sharded(); void warm_products();
+void warm_kernels(); void warm_verify_window(); void warm_rdd(); void warm_affinity(); void warm_linefit(); void warm_chain(); void warm_chain_sharded(); void warm_products(); void warm_sort();
 inline void touch_kernel(const void* f) { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, f); }
 
 void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);

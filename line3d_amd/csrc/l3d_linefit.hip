@@ -5,7 +5,7 @@
 // takes the members' 3-D end points back to the caller's coordinates, fits the line (every lane runs the same short sequential
 // sums: the order of the additions is part of the result), gives every point its float distance along the line, ranks the points
 // (all-to-all comparison: the rank IS the stable order), and one lane sweeps them, emitting the stretches seen by >= 3 cameras.
-#include <hipcub/hipcub.hpp>
+#include "l3d_sort.hpp"
 
 #include "l3d_ctx.hpp"
 #include "l3d_linefit.hpp"
@@ -205,9 +205,9 @@ int fit_core(l3d_ctx* c, FitStage in, int n_groups, int n_members, const double*
     HIPCHK(c, hipMemsetAsync(a.out_cnt, 0, (ng + 1) * 4, st));
     { ProfScope p(c, "fit_clusters", st); hipLaunchKernelGGL(k_fit_clusters, dim3((n_groups + 3) / 4), dim3(256), 0, st, a); }
     size_t tb = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, a.out_cnt, out_off, n_groups + 1, st));
+    HIPCHK(c, exclusive_sum_int(nullptr, tb, a.out_cnt, out_off, n_groups + 1, st));
     HIPCHK(c, c->g7.reserve(tb + 256));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(c->g7.p, tb, a.out_cnt, out_off, n_groups + 1, st));
+    HIPCHK(c, exclusive_sum_int(c->g7.p, tb, a.out_cnt, out_off, n_groups + 1, st));
     int32_t* cnt = static_cast<int32_t*>(malloc((ng + 1) * 4));
     if (!cnt) return fail(c, L3D_ERR_NOMEM, "malloc");
     int total = 0;
@@ -307,8 +307,8 @@ extern "C" int l3d_fit_labelled_clusters(l3d_ctx* c, const int32_t* labels, cons
     int bits = 1;
     while ((1ll << bits) < (long long)n_nodes) ++bits;
     size_t tb = 0, tb2 = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n_nodes, 0, 32 + bits, st));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (const int*)nullptr, (int*)nullptr, n_nodes + 1, st));
+    HIPCHK(c, sort_keys_u64(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n_nodes, 0, 32 + bits, st));
+    HIPCHK(c, exclusive_sum_int(nullptr, tb2, (const int*)nullptr, (int*)nullptr, n_nodes + 1, st));
     tb = std::max(tb, tb2);
     const size_t kb = al(nn * 8), ib4 = al((nn + 2) * 4);
     HIPCHK(c, c->g5.reserve(2 * kb + 8 * ib4 + tb + 256));
@@ -324,9 +324,9 @@ extern "C" int l3d_fit_labelled_clusters(l3d_ctx* c, const int32_t* labels, cons
     void* temp = sc + 2 * kb + 8 * ib4;
     const dim3 block(256), grid((n_nodes + 1 + 255) / 256);
     hipLaunchKernelGGL(k_lab_keys, grid, block, 0, st, d_lab, d_nh, n_nodes, key_in);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(temp, tb, key_in, key, n_nodes, 0, 32 + bits, st));
+    HIPCHK(c, sort_keys_u64(temp, tb, key_in, key, n_nodes, 0, 32 + bits, st));
     hipLaunchKernelGGL(k_lab_flags, grid, block, 0, st, key, n_nodes, flag);
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, rank, n_nodes + 1, st));
+    HIPCHK(c, exclusive_sum_int(temp, tb, flag, rank, n_nodes + 1, st));
     hipLaunchKernelGGL(k_lab_starts, grid, block, 0, st, flag, rank, n_nodes, start);
     const int* n_all = rank + n_nodes;                                       // number of clusters (device)
     hipLaunchKernelGGL(k_lab_valid, grid, block, 0, st, key, start, n_all, d_cam, vflag, vsize);
@@ -335,8 +335,8 @@ extern "C" int l3d_fit_labelled_clusters(l3d_ctx* c, const int32_t* labels, cons
     int h_all = 0;
     HIPCHK(c, hipMemcpyAsync(&h_all, n_all, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, vflag, vrank, h_all + 1, st));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, vsize, voff, h_all + 1, st));
+    HIPCHK(c, exclusive_sum_int(temp, tb, vflag, vrank, h_all + 1, st));
+    HIPCHK(c, exclusive_sum_int(temp, tb, vsize, voff, h_all + 1, st));
     hipLaunchKernelGGL(k_lab_compact, dim3((h_all + 1 + 3) / 4), block, 0, st, key, start, n_all, vflag, vrank, voff, d_gs, d_mh);
     int tot[2] = { 0, 0 };
     HIPCHK(c, hipMemcpyAsync(&tot[0], vrank + h_all, 4, hipMemcpyDeviceToHost, st));

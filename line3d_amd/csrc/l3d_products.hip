@@ -15,7 +15,7 @@
 // Views with nothing left to match return early (cudawrapper.cu:877-878): their list is the localized existing list -- what the
 // earlier views pushed, in push order, LOCAL camera ids, confidence 0 -- and the reference then files its entries under those
 // local numbers read as view ids (line3D.cc:838-866).  Reproduced: such a view's entries are formed from its sources' records.
-#include <hipcub/hipcub.hpp>
+#include "l3d_sort.hpp"
 
 #include <algorithm>
 #include <vector>
@@ -374,8 +374,8 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         hipLaunchKernelGGL(k_prod_median, dim3(n_views), dim3(256), 0, st, dpv, P.median.as<float>());
     }
     size_t tb1 = 0, tb2 = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, keys, keys2, (int)n_keys_max, 0, std::min(64, 2 * nb), st));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys_max + 1, st));
+    HIPCHK(c, sort_keys_u64(nullptr, tb1, keys, keys2, (int)n_keys_max, 0, std::min(64, 2 * nb), st));
+    HIPCHK(c, exclusive_sum_int(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys_max + 1, st));
     HIPCHK(c, P.tmp.reserve(std::max(tb1, tb2) + 256));
     long long base = 0;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
@@ -391,11 +391,11 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         {
             ProfScope p(c, "prod_sort", st);
             size_t t1 = tb1, t2 = tb2;
-            HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(P.tmp.p, t1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
+            HIPCHK(c, sort_keys_u64(P.tmp.p, t1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
             const unsigned nblk = (unsigned)((n_keys + 255) / 256);
             HIPCHK(c, hipMemsetAsync(P.flag.as<int>() + n_keys, 0, 4, st));
             hipLaunchKernelGGL(k_prod_flags, dim3(nblk), dim3(256), 0, st, keys2, n_keys, P.flag.as<int>());
-            HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(P.tmp.p, t2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
+            HIPCHK(c, exclusive_sum_int(P.tmp.p, t2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
             hipLaunchKernelGGL(k_prod_csr, dim3(nblk), dim3(256), 0, st, keys2, P.flag.as<int>(), P.pos.as<int>(), n_keys, nb, B.d0, B.d1, base, P.pot_start.as<long long>(), P.pot_tgt.as<int>());
         }
         if (bi + 1 < blocks.size()) {                      // the next block's rows start behind this block's entries
@@ -535,9 +535,9 @@ int l3d_products_hypotheses(l3d_ctx* c, const l3d_view_geometry* geometry, int n
     ProfScope p(c, "hypotheses", st);
     hipLaunchKernelGGL(k_hyp_flag, dim3((nd + 255) / 256), dim3(256), 0, st, P.best_ref.as<long long>(), nd, flag);
     size_t tb = 0;
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flag, hyp_of, nd + 1, st));
+    HIPCHK(c, exclusive_sum_int(nullptr, tb, flag, hyp_of, nd + 1, st));
     HIPCHK(c, P.tmp.reserve(tb + 256));
-    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(P.tmp.p, tb, flag, hyp_of, nd + 1, st));
+    HIPCHK(c, exclusive_sum_int(P.tmp.p, tb, flag, hyp_of, nd + 1, st));
     // (the number of hypotheses is at most the number of segments: the tables are sized for that, no round trip before the build)
     HIPCHK(c, c->aff_hyp.reserve((size_t)nd * sizeof(Hypothesis) + 64));
     HIPCHK(c, P.score.reserve((size_t)nd * 4 + 64));

@@ -7,7 +7,7 @@
 // list sorts produce), the float4 entries and the first-entry tables (sparsematrix.cc:99-131) are built by kernels, and the result
 // comes back as (i, j, w) records.  Round 1 sorted on 16 host threads: 13.6 ms of the 35 ms a diffusion of the config-2 affinity
 // list (978 k entries) took; the device sorts take well under a millisecond.
-#include <hipcub/hipcub.hpp>
+#include "l3d_sort.hpp"
 
 #include "l3d_ctx.hpp"
 #include "l3d_geometry.hpp"
@@ -332,7 +332,7 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
     HIPCHK(c, c->g3.reserve(2 * sb)); HIPCHK(c, c->g4.reserve(2 * sb));
     // sort scratch: two key arrays, four index arrays, hipCUB's temporary storage
     size_t temp_bytes = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+    HIPCHK(c, sort_pairs_u64_u32(nullptr, temp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                                  (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 2 * shift, st));
     const size_t kb = ((size_t)nnz * 8 + 255) & ~(size_t)255, vb = ((size_t)nnz * 4 + 255) & ~(size_t)255;
     HIPCHK(c, c->g7.reserve(2 * kb + 4 * vb + temp_bytes + 256));
@@ -358,9 +358,9 @@ int rdd_resident(l3d_ctx* c, int nnz, int n, int iters, hipStream_t st, bool tim
     // W: column-sorted (line3D.cc:1258 -> sparsematrix.cc:81-86, stable list sort by (j,i)); P: the column-sorted entries
     // re-sorted by row (cudawrapper.cu:1145 -> sparsematrix.cc:157-167)
     hipLaunchKernelGGL(k_rdd_keys_w, grid, block, 0, st, dA, nnz, shift, key_in, val_in);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, val_in, ordW, nnz, 0, 2 * shift, st));
+    HIPCHK(c, sort_pairs_u64_u32(temp, temp_bytes, key_in, key_out, val_in, ordW, nnz, 0, 2 * shift, st));
     hipLaunchKernelGGL(k_rdd_keys_p, grid, block, 0, st, dA, ordW, nnz, shift, key_in, val_in2);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, key_in, key_out, val_in2, ordP, nnz, 0, 2 * shift, st));
+    HIPCHK(c, sort_pairs_u64_u32(temp, temp_bytes, key_in, key_out, val_in2, ordP, nnz, 0, 2 * shift, st));
     HIPCHK(c, hipMemsetAsync(startW, 0xff, (size_t)n * 4, st));           // -1: no entry in that column / row
     HIPCHK(c, hipMemsetAsync(startP, 0xff, (size_t)n * 4, st));
     HIPCHK(c, hipMemsetAsync(lenW, 0, (size_t)n * 4, st));
@@ -469,9 +469,9 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int shift = 1;
         while ((1ll << shift) < (long long)n) ++shift;
         size_t tb = 0;
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32 + shift, st));
+        HIPCHK(c, sort_pairs_u64_u32(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32 + shift, st));
         size_t tb2 = 0;
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, (const int*)nullptr, (int*)nullptr, nnz + 1, st));
+        HIPCHK(c, exclusive_sum_int(nullptr, tb2, (const int*)nullptr, (int*)nullptr, nnz + 1, st));
         tb = std::max(tb, tb2);
         const size_t kb = ((size_t)nnz * 8 + 255) & ~(size_t)255, vb4 = ((size_t)nnz * 4 + 255 + 4) & ~(size_t)255;
         HIPCHK(c, c->g7.reserve(2 * kb + 5 * vb4 + tb + 256));
@@ -485,13 +485,13 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         int* gstart = reinterpret_cast<int*>(sc + 2 * kb + 4 * vb4);
         void* temp = sc + 2 * kb + 5 * vb4;
         hipLaunchKernelGGL(k_edge_group_keys, grid, block, 0, st, E, comp, nnz, key_in, val_in);
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(temp, tb, key_in, key_out, val_in, order, nnz, 0, 32 + shift, st));
+        HIPCHK(c, sort_pairs_u64_u32(temp, tb, key_in, key_out, val_in, order, nnz, 0, 32 + shift, st));
         HIPCHK(c, c->g1.reserve(ab + 64));
         hipLaunchKernelGGL(k_edge_gather, grid, block, 0, st, E, order, nnz, c->g1.as<l3d_edge>());
         if (sorted_out) HIPCHK(c, hipMemcpyAsync(sorted_out, c->g1.p, ab, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemsetAsync(flag + nnz, 0, 4, st));
         hipLaunchKernelGGL(k_group_flags, grid, block, 0, st, key_out, nnz, flag);
-        HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(temp, tb, flag, frank, nnz + 1, st));
+        HIPCHK(c, exclusive_sum_int(temp, tb, flag, frank, nnz + 1, st));
         hipLaunchKernelGGL(k_group_starts, grid, block, 0, st, flag, frank, nnz, gstart);
         int n_groups = 0;
         HIPCHK(c, hipMemcpyAsync(&n_groups, frank + nnz, 4, hipMemcpyDeviceToHost, st));
@@ -499,7 +499,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
         if (merge_loop) {
             // nodes in (component, id) order -> local numbers; then one wave per component
             size_t tbn = 0;
-            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tbn, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0, shift, st));
+            HIPCHK(c, sort_pairs_u32_u32(nullptr, tbn, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, n, 0, shift, st));
             const size_t sb = ((size_t)n * 4 + 255) & ~(size_t)255;
             HIPCHK(c, c->g4.reserve(11 * sb + tbn + 256));
             unsigned char* ns = c->g4.as<unsigned char>();
@@ -509,7 +509,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
             int* g_state = reinterpret_cast<int*>(ns + 7 * sb);
             const dim3 ngrid((n + 255) / 256);
             hipLaunchKernelGGL(k_uf_node_keys, ngrid, block, 0, st, comp, n, nkey_in, nval_in, labels);
-            HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(ns + 11 * sb, tbn, nkey_in, nkey, nval_in, node_sorted, n, 0, shift, st));
+            HIPCHK(c, sort_pairs_u32_u32(ns + 11 * sb, tbn, nkey_in, nkey, nval_in, node_sorted, n, 0, shift, st));
             HIPCHK(c, hipMemsetAsync(ncnt, 0, (size_t)n * 4, st));
             hipLaunchKernelGGL(k_uf_pos, ngrid, block, 0, st, nkey, node_sorted, n, pos, ncnt);
             { ProfScope p(c, "uf_components");
@@ -535,7 +535,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
     }
     // stable radix sort by the weight key, then gather
     size_t temp_bytes = 0;
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32, st));
+    HIPCHK(c, sort_pairs_u32_u32(nullptr, temp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, nnz, 0, 32, st));
     const size_t vb = ((size_t)nnz * 4 + 255) & ~(size_t)255;
     HIPCHK(c, c->g7.reserve(4 * vb + temp_bytes + 256));
     unsigned char* sc = c->g7.as<unsigned char>();
@@ -544,7 +544,7 @@ static int clustering_edges_impl(l3d_ctx* c, const l3d_edge* A, int nnz, int n, 
     unsigned* val_in = reinterpret_cast<unsigned*>(sc + 2 * vb);
     unsigned* order = reinterpret_cast<unsigned*>(sc + 3 * vb);
     hipLaunchKernelGGL(k_edge_weight_keys, grid, block, 0, st, E, nnz, key_in, val_in);
-    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(sc + 4 * vb, temp_bytes, key_in, key_out, val_in, order, nnz, 0, 32, st));
+    HIPCHK(c, sort_pairs_u32_u32(sc + 4 * vb, temp_bytes, key_in, key_out, val_in, order, nnz, 0, 32, st));
     HIPCHK(c, c->g1.reserve(ab + 64));
     hipLaunchKernelGGL(k_edge_gather, grid, block, 0, st, E, order, nnz, c->g1.as<l3d_edge>());
     HIPCHK(c, hipMemcpyAsync(sorted_out, c->g1.p, ab, hipMemcpyDeviceToHost, st));
