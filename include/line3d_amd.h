@@ -333,7 +333,7 @@ const void* l3d_shard_chain_gathered(l3d_shard_chain* chain);   /* device addres
  * remaining view with a slot that says "gave up": no rank is left waiting in a collective.  Afterwards every rank reads the
  * same verdict out of the gathered slot headers: L3D_ERR_NOMEM on ALL ranks when any slot overflowed.  l3d_shard_chain_info
  * (any out pointer may be NULL): this chain's candidate capacity and slot_records, and after a run the OR of the ranks'
- * overflow bits (1 candidate capacity, 2 slot_records, 4 a rank gave up) and the largest candidate / kept count one rank
+ * overflow bits (1 candidate capacity, 2 slot_records, 4 a rank gave up, 8 the compact arena of the ring mode) and the largest candidate / kept count one rank
  * reported for one view -- what a caller needs to reopen with more room (l3d_set_chain_capacities sets the candidate capacity
  * of the next chain); l3d_line3d_shard_run does exactly that, up to three times. */
 /* matchViews' products (as l3d_match_chain_resident leaves them: potential correspondences, best matches, medians; line3D.cc:834-884)
@@ -342,6 +342,14 @@ const void* l3d_shard_chain_gathered(l3d_shard_chain* chain);   /* device addres
  * l3d_chain_products_get, l3d_products_hypotheses, l3d_affinity_fill_resident as after the single-GPU chain. */
 int l3d_shard_chain_products(l3d_shard_chain* chain, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot);
 int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept);
+/* Ring mode of l3d_shard_chain_run (cb == NULL; automatic when the gathered blocks of all views would exceed 8 GB -- 2048 views x 8 ranks
+ * x 3.8 MB = 63 GB per rank at 4000 segments x 24 neighbours --, L3D_SLOT_RING=1 / l3d_set_option forces it, 0 forbids it): the gathered
+ * buffer holds only the views later views still read (the neighbour window of the schedule + a batch); older blocks are retired into the
+ * compact kept arena, in the order of the unsharded run, before they are overwritten -- what the reference does with its per-view match files
+ * (view.cc:150-224).  l3d_shard_chain_gathered then returns NULL.  Overflow bit 8 = the compact arena's first guess was too small;
+ * l3d_shard_chain_arena_needed: the kept matches of the whole run (records of 32 bytes), for the retry (l3d_set_chain_capacities' second
+ * argument; l3d_line3d_shard_run does it). */
+long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
 
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A

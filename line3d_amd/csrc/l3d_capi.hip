@@ -128,7 +128,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
                        &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
                        &c->ch_rays, &c->aff_hyp, &c->edges_keep, &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
-    c->ch_bestpos.release();
+    c->ch_bestpos.release(); c->ch_hdr.release();
     c->products.release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
@@ -263,27 +263,40 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
 int l3d_warm_up(l3d_ctx* c)
 {
     if (!c) return L3D_ERR_INVALID;
-    void (*fns[])() = { warm_kernels, warm_verify_window, warm_rdd, warm_affinity, warm_linefit, warm_sort, warm_chain, warm_chain_sharded, warm_products };
-    std::vector<std::thread> th;
     const int dev = c->device;
-    for (auto f : fns) th.emplace_back([f, dev]() { (void)hipSetDevice(dev); f(); });
+    (void)hipSetDevice(dev);
+    const double t0 = now_s();
+    // in the order the first compute3Dmodel needs them: collinearity and stage 1, the chain, verification, the products, then the finishing
+    // stages; the big one (l3d_sort.hip: hipCUB, 7 MB) behind everything matchViews launches first -- a caller that does not wait for this
+    // function (the facade does not) finds each module loaded by the time it gets there, or waits for that one module only
+    void (*first[])() = { warm_kernels, warm_chain, warm_verify_window };
+    void (*rest[])() = { warm_products, warm_sort, warm_affinity, warm_rdd, warm_linefit, warm_chain_sharded };
+    for (auto f : first) f();
+    const double t1 = now_s();
+    std::vector<std::thread> th;
+    for (auto f : rest) th.emplace_back([f, dev]() { (void)hipSetDevice(dev); f(); });
     // the runtime builds its staging for copies between device and pageable host memory at the first such copy of a size class
-    // (20 ms at the first 12 MB read-back of an edge list): here instead
+    // (20 ms at the first 12 MB read-back of an edge list): here instead -- on a stream of its own: the context's streams belong to the caller
     {
-        (void)hipSetDevice(dev);
         const size_t bytes = 16u << 20;
         void* d = nullptr;
+        hipStream_t ws = nullptr;
         std::vector<char> host(bytes);
-        if (hipMalloc(&d, bytes) == hipSuccess) {
-            (void)hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, c->stream);
-            (void)hipMemcpyAsync(host.data(), d, bytes, hipMemcpyDeviceToHost, c->stream);
-            (void)hipMemcpyAsync(host.data(), d, 4, hipMemcpyDeviceToHost, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-            (void)hipFree(d);
+        if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess) {
+            if (hipMalloc(&d, bytes) == hipSuccess) {
+                (void)hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ws);
+                (void)hipMemcpyAsync(host.data(), d, bytes, hipMemcpyDeviceToHost, ws);
+                (void)hipMemcpyAsync(host.data(), d, 4, hipMemcpyDeviceToHost, ws);
+                (void)hipStreamSynchronize(ws);
+                (void)hipFree(d);
+            }
+            (void)hipStreamDestroy(ws);
         }
     }
+    const double t2 = now_s();
     for (auto& t : th) t.join();
     (void)hipGetLastError();
+    if (c->opt.timing) fprintf(stderr, "[l3d warm_up] stage-1 / chain / verification modules %.2f ms, copy staging %.2f ms, all modules after %.2f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t0) * 1e3);
     return L3D_OK;
 }
 int l3d_last_stats(l3d_ctx* c, double stats[4])

@@ -28,6 +28,11 @@
 #include "l3d_products.hpp"
 #include "l3d_chain_common.hpp"
 
+#ifndef L3D_AHEAD
+#define L3D_AHEAD 4
+#define L3D_S1AHEAD 8
+#endif
+
 using namespace l3d;
 
 namespace l3d {
@@ -244,7 +249,9 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (int rc = chain_plan_views(c, views, n_views, 0, 1, vd, L, "l3d_match_chain")) return rc;
     const bool rays_env = c->opt.tgt_rays != 0;      // (0: k_pair_fill normalises per candidate, A/B)
     if (int rc = chain_upload_tables(c, views, n_views, vd, L, rays_env, st)) return rc;
-    if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, st)) return rc;
+    // bit rows: a ring that covers every view between the one being collected and the newest stage 1 (kRing below: after a capacity
+    // overflow the candidates of all of them are re-formed from their bit rows)
+    if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, c->chain_ring != 0 ? L3D_AHEAD + L3D_S1AHEAD + 3 : 0, st)) return rc;
     const unsigned char* dtab = L.dtab;
     const int maxN = L.maxN;
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
@@ -291,10 +298,6 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     int k_enq = 0;                      // next view whose phase 2 is enqueued
     // run-ahead depths, A/B measured on one box (ms per config-2 pass): (12, 24) 19.1, (6, 12) 18.7, (4, 8) 18.4, (2, 4) 18.3,
     // (24, 40) 20.0 -- a shallow queue keeps the stage-1 candidates of a view cache-warm until its chain consumes them
-#ifndef L3D_AHEAD
-#define L3D_AHEAD 4
-#define L3D_S1AHEAD 8
-#endif
     // the ring covers every view that can be in flight between the one being collected and the newest stage 1: after an
     // overflow ALL of them are refilled before any of their chains runs again
     const int kAhead = L3D_AHEAD, kStage1Ahead = L3D_S1AHEAD, kRing = kAhead + kStage1Ahead + 3;

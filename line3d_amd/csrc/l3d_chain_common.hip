@@ -54,6 +54,7 @@ int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int r
         d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
         L.tab_bytes = chain_align16(o);
         L.mask_bytes += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        L.max_mask_bytes = std::max(L.max_mask_bytes, chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8));
         L.rowcnt_ints += (size_t)v.S_src * v.N;
         L.best_elems += (size_t)v.S_src;
     }
@@ -109,10 +110,10 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
     return L3D_OK;
 }
 
-int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, hipStream_t st)
+int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st)
 {
     const size_t nv = (size_t)n_views;
-    HIPCHK(c, c->ch_mask.reserve(L.mask_bytes + 16));
+    HIPCHK(c, c->ch_mask.reserve((mask_ring > 0 ? std::min(L.mask_bytes, (size_t)mask_ring * L.max_mask_bytes) : L.mask_bytes) + 16));
     HIPCHK(c, c->ch_rowcnt.reserve((L.rowcnt_ints + 2 * nv) * 4 + 16));
     // (row starts | upper-bound counts | their block sums: the last two zeroed, k_pair_mask adds into them)
     L.rowA_ints = L.rowcnt_ints + 4 * nv;
@@ -130,8 +131,13 @@ int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
         d.stats = stats_base + 2 * k;
         if (!d.verified) continue;
         const l3d_chain_view& v = views[k];
-        d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
-        mo += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        if (mask_ring > 0 && (size_t)mask_ring * L.max_mask_bytes < L.mask_bytes) {
+            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + (mo % (size_t)mask_ring) * L.max_mask_bytes);
+            mo += 1;
+        } else {
+            d.mask = reinterpret_cast<unsigned long long*>(c->ch_mask.as<unsigned char>() + mo);
+            mo += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
+        }
         d.rowcnt = c->ch_rowcnt.as<int>() + ro; ro += (size_t)v.S_src * v.N;
         d.rowA = c->ch_rowA.as<int>() + ao;
         if (fused_rows) {

@@ -29,7 +29,7 @@ struct ChainViewDev {               // device addresses of one view's static tab
 };
 
 struct ChainLayout {
-    size_t tab_bytes = 0, mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
+    size_t tab_bytes = 0, mask_bytes = 0, max_mask_bytes = 0, rowcnt_ints = 0, best_elems = 0;
     size_t rowA_ints = 0, rowub_ints = 0, rowblk_ints = 0;
     int maxS = 0, maxN = 0;
     double pairs = 0, max_pairs = 0;        // stage-1 pairs of this rank's ranges: all views / the largest view
@@ -42,7 +42,10 @@ int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int r
 int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool with_rays, hipStream_t st);
 // Reserves the whole-run arenas (bit rows, row counts, row starts [+ upper-bound counts and block sums], best depths [+ positions]) and
 // hands every view its slices; zeroes what the kernels add into.
-int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, hipStream_t st);
+// mask_ring: slots of the bit-row arena (a view's bit rows live from its k_pair_mask to its k_pair_fill, both on the stage-1 stream in order:
+// two slots instead of one slice per view -- 24.6 MB x 2048 views = 50 GB at 4000 segments x 24 neighbours); 0: one slice per view
+// (the A/B mode that triangulates on the chain's stream, views later).
+int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st);
 // Per-launch scratch that depends on the candidate capacity (candidate store, window scratch, stage-1 ring of `ring` slots).
 int chain_reserve_candidates(l3d_ctx* c, const ChainLayout& L, size_t cand_cap, int ring);
 

@@ -45,7 +45,8 @@ namespace l3d {
 struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
 static_assert(sizeof(SlotHeader) == 32, "slot header");
 
-struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off; int seg_cap, slot_records, world; };
+// ring: view blocks the gathered buffer holds (view k lives in block k % ring); n_views when every block is kept
+struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off; int seg_cap, slot_records, world, ring; };
 
 // reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
 // (blockIdx.y = source * world + rank)
@@ -53,7 +54,7 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
                                     const int* __restrict__ src_cam, unsigned view_id, int N, int s0, int s1, int* __restrict__ rowcnt)
 {
     const int src = blockIdx.y / g.world, r = blockIdx.y % g.world;
-    const unsigned char* slot = G + ((size_t)src_index[src] * g.world + r) * g.slot_bytes;
+    const unsigned char* slot = G + ((size_t)(src_index[src] % g.ring) * g.world + r) * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int*
     }
     const int e = (int)blockIdx.x - blocks_move, list = e / 16, bx = e % 16;
     const int src = list / g.world, r = list % g.world;
-    const unsigned char* slot = G + ((size_t)src_index[src] * g.world + r) * g.slot_bytes;
+    const unsigned char* slot = G + ((size_t)(src_index[src] % g.ring) * g.world + r) * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
@@ -180,14 +181,16 @@ __global__ __launch_bounds__(256) void k_pack_view(const unsigned char* __restri
 // ---- matchViews' products from the gathered slots (l3d_shard_chain_products): every rank holds every view's kept records, so every
 // rank can build what the single-GPU chain builds from its kept arena -- no rank hands lists to the host.
 // per view: kept matches and candidates summed over the ranks' slots
-__global__ void k_shard_totals(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int2* __restrict__ out)
+// (hdr, hdr_stride: the slot headers where they are -- in front of every slot of the gathered blocks, or the compact header table the ring
+// mode keeps)
+__global__ void k_shard_totals(const unsigned char* __restrict__ hdr, size_t hdr_stride, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int2* __restrict__ out)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_views) return;
     int n = 0; long long R = 0;
     if (verified[k])
         for (int r = 0; r < g.world; ++r) {
-            const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(G + ((size_t)k * g.world + r) * g.slot_bytes);
+            const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(hdr + ((size_t)k * g.world + r) * hdr_stride);
             n += hd->overflow ? 0 : hd->n_kept; R += hd->R;
         }
     out[k] = make_int2(n, (int)min(R, 0x7fffffffll));
@@ -220,16 +223,66 @@ __global__ __launch_bounds__(256) void k_shard_pack_all(const unsigned char* __r
     }
 }
 
+// Ring mode (l3d_shard_chain_run when the gathered blocks of all views would not fit a budget: 2048 views x 8 ranks x 3.8 MB slots = 63 GB at
+// 4000 segments x 24 neighbours): the gathered buffer holds only the views later views still read (the neighbour window of the schedule);
+// older blocks are RETIRED a batch at a time -- their used records into the compact kept arena in the order of the unsharded run (what
+// k_shard_pack_all does for all views at the end), their headers into a small table for the shared verdict -- before their ring block is
+// overwritten.  grid (x, rank, view of the batch).  base_dev[k]: the arena offset of view k (running sum kept on the device: the host never
+// learns a count on the way); the block of the batch's last view publishes the offset of the next batch.
+__global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int k0, int n_batch,
+                                                      long long* __restrict__ base_dev, long long arena_cap, const long long* __restrict__ best_off, Match* __restrict__ arena,
+                                                      float2* __restrict__ best_all, int* __restrict__ bestpos_all, SlotHeader* __restrict__ hdr_all, int* __restrict__ overflow)
+{
+    const int k = k0 + blockIdx.z, r = blockIdx.y;
+    long long base = base_dev[k0];
+    for (int q = k0; q < k; ++q) {
+        if (!verified[q]) continue;
+        const unsigned char* bq = G + (size_t)(q % g.ring) * g.world * g.slot_bytes;
+        for (int w = 0; w < g.world; ++w) { const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(bq + (size_t)w * g.slot_bytes); base += hq->overflow ? 0 : hq->n_kept; }
+    }
+    const unsigned char* block = G + (size_t)(k % g.ring) * g.world * g.slot_bytes;
+    int in_front = 0, all = 0;
+    if (verified[k])
+        for (int w = 0; w < g.world; ++w) {
+            const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(block + (size_t)w * g.slot_bytes);
+            const int n = hq->overflow ? 0 : hq->n_kept;
+            if (w < r) in_front += n;
+            all += n;
+        }
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (first && r == 0) base_dev[k] = base;                                          // (k0 itself: rewritten with the same value)
+    if (first && r == 0 && (int)blockIdx.z == n_batch - 1) base_dev[k + 1] = base + all;
+    SlotHeader* ho = hdr_all + (size_t)k * g.world + r;
+    if (!verified[k]) { if (first) { SlotHeader z; z.n_kept = z.R = z.overflow = z.s0 = z.s1 = 0; z.pad[0] = z.pad[1] = z.pad[2] = 0; *ho = z; } return; }
+    const unsigned char* slot = block + (size_t)r * g.slot_bytes;
+    const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
+    if (first) *ho = *hd;
+    const int n = hd->overflow ? 0 : hd->n_kept;
+    if (base + all > arena_cap) { if (first) atomicMax(overflow, 1); return; }      // the arena's first guess was too small: the run ends with a capacity verdict
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const float4* src = reinterpret_cast<const float4*>(slot + g.rec_off);
+    float4* dst = reinterpret_cast<float4*>(arena + base + in_front);
+    for (int i = tid; i < 2 * n; i += nt) dst[i] = src[i];
+    const float2* sb = reinterpret_cast<const float2*>(slot + g.best_off);
+    const int* sp = reinterpret_cast<const int*>(slot + g.bpos_off);
+    for (int i = tid; i < hd->s1 - hd->s0; i += nt) {
+        const long long o = best_off[k] + hd->s0 + i;
+        best_all[o] = sb[i];
+        const int p = sp[i];
+        bestpos_all[o] = p < 0 || n == 0 ? -1 : in_front + p;
+    }
+}
+
 // After the last exchange: the OR of the overflow bits of every gathered slot header (1 candidate capacity, 2 slot records,
 // 4 a rank gave up) and, for sizing a retry, the largest candidate / kept count any rank reported.  Every rank holds the same
 // gathered blocks, so every rank computes the same answer: the ranks agree on the outcome without another collective.
-__global__ void k_check_slots(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int* __restrict__ out3)
+__global__ void k_check_slots(const unsigned char* __restrict__ hdr, size_t hdr_stride, SlotGeom g, const unsigned char* __restrict__ verified, int n_views, int* __restrict__ out3)
 {
     int bits = 0, maxR = 0, maxK = 0;
     const int n = n_views * g.world;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!verified[i / g.world]) continue;
-        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(G + (size_t)i * g.slot_bytes);
+        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(hdr + (size_t)i * hdr_stride);
         bits |= hd->overflow & 7;
         maxR = max(maxR, hd->R);
         maxK = max(maxK, hd->pad[0]);
@@ -280,7 +333,15 @@ struct l3d_shard_chain {
     int copy_issued = -1;                    // view whose D2H copy the previous fetch has already issued (fetch thread only)
     l3d_match* copy_dst = nullptr;           // ... and where its records go (pinned arena)
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
-    int outcome[3] = { 0, 0, 0 };            // after l3d_shard_chain_run: OR of the ranks' overflow bits, largest candidate / kept count of a slot
+    int outcome[3] = { 0, 0, 0 };            // after l3d_shard_chain_run: OR of the ranks' overflow bits (8: the compact arena of the ring mode), largest candidate / kept count of a slot
+    // ring mode of l3d_shard_chain_run (commit on the device only): the gathered buffer holds `ring` view blocks, older ones are retired
+    bool ring_mode = false;
+    int window = 0;                          // max over views of (index - smallest source index): how far back a view reads
+    long long arena_cap = 0, arena_needed = 0;
+    long long* base_dev = nullptr;           // arena offset of every view (+ the total behind the last), kept on the device
+    SlotHeader* hdr_all = nullptr;           // the headers of all slots of all views (32 B each)
+    const long long* best_off_dev = nullptr;
+    const unsigned char* ver_dev = nullptr;
 };
 
 extern "C" {
@@ -304,6 +365,9 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     h->maxS = L.maxS; h->maxN = L.maxN; h->pairs = L.pairs;
     const double max_pairs = L.max_pairs;
     h->geom.world = world;
+    h->geom.ring = std::max(1, n_views);
+    for (int k = 0; k < n_views; ++k)
+        for (int q = 0; q < views[k].n_sources; ++q) h->window = std::max(h->window, k - views[k].source_index[q]);
     h->geom.seg_cap = (h->maxS + world - 1) / world + 1;
     h->geom.slot_records = slot_records;
     h->geom.best_off = sizeof(SlotHeader);
@@ -316,7 +380,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
 #define OCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return bail(L3D_ERR_HIP); } } while (0)
     // tables, target rays, per-view slices of the whole-run arenas (l3d_chain_common.hip: shared with the single-GPU chain)
     { int rc = chain_upload_tables(c, views, n_views, h->vd, L, true, st); if (rc) return bail(rc); }
-    { int rc = chain_assign_arenas(c, views, n_views, h->vd, L, false, true, st); if (rc) return bail(rc); }   // (+ best positions: l3d_shard_chain_products)
+    { int rc = chain_assign_arenas(c, views, n_views, h->vd, L, false, true, l3d_shard_chain::kRingA, st); if (rc) return bail(rc); }   // (+ best positions: l3d_shard_chain_products)
     h->dtab = L.dtab;
     OCHK(c->ch_pin_res.reserve((size_t)n_views * 8 + 64));
     h->hstats = c->ch_pin_res.as<int>();
@@ -541,15 +605,62 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     l3d_ctx* c = h->c;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t slot = h->geom.slot_bytes, block = slot * (size_t)h->world;
-    HIPCHK(c, c->ch_send.reserve((size_t)h->n_views * slot + 256));
-    HIPCHK(c, c->ch_gathered.reserve((size_t)h->n_views * block + 256));
+    // Ring mode: when the gathered blocks of all views exceed the budget (or L3D_SLOT_RING=1) and nobody commits on the host, the buffer
+    // holds window + batch + 2 view blocks; a batch of older views is retired into the compact kept arena (k_shard_retire) before its
+    // blocks are reused.  L3D_SLOT_RING=0 keeps every block (what the recording tests read back through l3d_shard_chain_gathered).
+    constexpr int kRetireBatch = 16;
+    const int ring_views = h->window + kRetireBatch + 2;
+    const size_t gathered_budget = (size_t)8 << 30;
+    h->ring_mode = !cb && c->opt.slot_ring != 0 && ring_views < h->n_views && (c->opt.slot_ring > 0 || (size_t)h->n_views * block > gathered_budget);
+    h->geom.ring = h->ring_mode ? ring_views : std::max(1, h->n_views);
+    const int send_ring = h->ring_mode ? ring_views : h->n_views;            // (a slot is read by its exchange only)
+    HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
+    HIPCHK(c, c->ch_gathered.reserve((size_t)h->geom.ring * block + 256));
     h->eager_pack = cb != nullptr;
     unsigned char* send = c->ch_send.as<unsigned char>();
     unsigned char* gathered = c->ch_gathered.as<unsigned char>();
     // every verified view's block is fully written by its exchange before anything reads it; only the blocks of views
     // that are never verified (nothing to match) must read as "no kept records"
-    for (int k = 0; k < h->n_views; ++k)
-        if (!h->vd[(size_t)k].verified) HIPCHK(c, hipMemsetAsync(gathered + (size_t)k * block, 0, block, c->stream));
+    if (!h->ring_mode)
+        for (int k = 0; k < h->n_views; ++k)
+            if (!h->vd[(size_t)k].verified) HIPCHK(c, hipMemsetAsync(gathered + (size_t)k * block, 0, block, c->stream));
+    std::vector<unsigned char> ver_h((size_t)h->n_views);
+    std::vector<long long> best_off_h((size_t)h->n_views, 0);
+    int* ring_overflow = nullptr;
+    if (h->ring_mode) {
+        // compact arena (first guess like the single-GPU chain's, or what an earlier pass / a capacity verdict taught), the per-view offsets,
+        // the header table, the flags the retire kernel reads
+        h->arena_cap = c->test_arena_cap ? (long long)c->test_arena_cap : std::max((long long)(h->pairs * h->world * 0.004) + 1048576, (long long)c->chain_seen_arena_cap);
+        HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t nvs = (size_t)h->n_views;
+        const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), tot = o_ovf + 256;
+        HIPCHK(c, c->ch_hdr.reserve(tot));
+        unsigned char* hb = c->ch_hdr.as<unsigned char>();
+        h->base_dev = reinterpret_cast<long long*>(hb + o_base);
+        h->hdr_all = reinterpret_cast<SlotHeader*>(hb + o_hdr);
+        for (int k = 0; k < h->n_views; ++k) {
+            ver_h[(size_t)k] = h->vd[(size_t)k].verified ? 1 : 0;
+            best_off_h[(size_t)k] = h->vd[(size_t)k].verified ? (long long)(h->vd[(size_t)k].best - c->ch_best.as<float2>()) : 0;
+        }
+        HIPCHK(c, hipMemsetAsync(hb, 0, o_bo, c->stream));
+        HIPCHK(c, hipMemsetAsync(hb + o_ovf, 0, 256, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hb + o_bo, best_off_h.data(), nvs * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hb + o_ver, ver_h.data(), nvs, hipMemcpyHostToDevice, c->stream));
+        h->best_off_dev = reinterpret_cast<const long long*>(hb + o_bo);
+        h->ver_dev = hb + o_ver;
+        ring_overflow = reinterpret_cast<int*>(hb + o_ovf);
+    }
+    int retired = 0;                        // views [0, retired) are in the compact arena (ring mode)
+    auto retire_to = [&](int upto) {        // enqueue the retirement of views [retired, upto) on the chain's stream (behind their exchanges)
+        while (retired < upto) {
+            const int nb = std::min(kRetireBatch, upto - retired);
+            ProfScope p(c, "retire");
+            hipLaunchKernelGGL(k_shard_retire, dim3(8, h->world, nb), dim3(256), 0, c->stream, gathered, h->geom, h->ver_dev, retired, nb, h->base_dev, h->arena_cap,
+                               h->best_off_dev, c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>(), h->hdr_all, ring_overflow);
+            retired += nb;
+        }
+    };
 
     // the "gave up" header of the failure protocol below -- allocated BEFORE any helper thread exists: an early return with
     // joinable threads would terminate the process and leave the peers waiting in their collectives
@@ -622,16 +733,21 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         const bool verified = h->vd[(size_t)k].verified;
         if (!draining) {
             const double te0 = now_s();
-            const int r2 = l3d_shard_chain_enqueue(h, k, send + (size_t)k * slot, gathered);
+            // ring mode: block k % ring is about to be overwritten by this view's exchange -- whatever lived there (view k - ring) and every
+            // older view must be in the arena first (a batch at a time; no later view reads them: they are further back than the window)
+            // (views in front of k - window are read by nobody from view k on; with ring = window + batch + 2 the block this view's exchange
+            // overwrites, k - ring, is always among the retired)
+            if (h->ring_mode && (k - h->window) - retired >= kRetireBatch) retire_to(k - h->window);
+            const int r2 = l3d_shard_chain_enqueue(h, k, send + (size_t)(k % send_ring) * slot, gathered);
             h->t_enq += now_s() - te0;
             if (r2) { rc = r2; rc_msg = c->err; draining = true; }
         }
         if (draining && verified) {
-            if (hipMemcpyAsync(send + (size_t)k * slot, abort_hdr, sizeof(SlotHeader), hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); }
+            if (hipMemcpyAsync(send + (size_t)(k % send_ring) * slot, abort_hdr, sizeof(SlotHeader), hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); }
         }
         if (verified) {
             const double te1 = now_s();
-            if (const int exr = exchange(exchange_user, k, send + (size_t)k * slot, gathered + (size_t)k * block, slot, h->world, (void*)c->stream)) {
+            if (const int exr = exchange(exchange_user, k, send + (size_t)(k % send_ring) * slot, gathered + (size_t)(k % h->geom.ring) * block, slot, h->world, (void*)c->stream)) {
                 if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = "l3d_shard_chain_run: the exchange of view " + std::to_string(k) + " failed (code " + std::to_string(exr) + ", last HIP error: " + hipGetErrorString(hipGetLastError()) + ")"; }
                 exchange_broken = true;
                 break;
@@ -664,20 +780,37 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         for (int k = 0; k < h->n_views; ++k) ver[(size_t)k] = h->vd[(size_t)k].verified ? 1 : 0;
         hipError_t e = c->ch_flags.reserve((size_t)h->n_views + 64);
         int host3[3] = { 0, 0, 0 };
+        int ring_ovf_h = 0;
+        long long arena_total_h = 0;
         if (e == hipSuccess) e = hipMemsetAsync(c->ch_flags.p, 0, 16, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->ch_flags.as<unsigned char>() + 16, ver.data(), (size_t)h->n_views, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_check_slots, dim3(8), dim3(256), 0, c->stream, gathered, h->geom, c->ch_flags.as<unsigned char>() + 16, h->n_views, c->ch_flags.as<int>());
-            e = hipMemcpyAsync(host3, c->ch_flags.p, 12, hipMemcpyDeviceToHost, c->stream);
+            if (h->ring_mode) {
+                if (!draining) retire_to(h->n_views);                  // the views still in the ring
+                if (retired == h->n_views) {
+                    hipLaunchKernelGGL(k_check_slots, dim3(8), dim3(256), 0, c->stream, reinterpret_cast<const unsigned char*>(h->hdr_all), sizeof(SlotHeader), h->geom,
+                                       c->ch_flags.as<unsigned char>() + 16, h->n_views, c->ch_flags.as<int>());
+                    e = hipMemcpyAsync(&ring_ovf_h, ring_overflow, 4, hipMemcpyDeviceToHost, c->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(&arena_total_h, h->base_dev + h->n_views, 8, hipMemcpyDeviceToHost, c->stream);
+                } else {
+                    host3[0] = 4;                                      // this rank gave up before every view was exchanged: so did the verdict
+                }
+            } else {
+                hipLaunchKernelGGL(k_check_slots, dim3(8), dim3(256), 0, c->stream, gathered, slot, h->geom, c->ch_flags.as<unsigned char>() + 16, h->n_views, c->ch_flags.as<int>());
+            }
+            if (e == hipSuccess && !(h->ring_mode && retired != h->n_views)) e = hipMemcpyAsync(host3, c->ch_flags.p, 12, hipMemcpyDeviceToHost, c->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = std::string("l3d_shard_chain_run: reading the slot headers: ") + hipGetErrorString(e); } }
         else {
+            if (ring_ovf_h) host3[0] |= 8;                          // the compact arena's first guess was too small (same data, same verdict on every rank)
+            h->arena_needed = arena_total_h;
             h->outcome[0] = host3[0]; h->outcome[1] = host3[1]; h->outcome[2] = host3[2];
             if (host3[0] && (rc == L3D_OK || rc == L3D_ERR_NOMEM)) {
                 rc = L3D_ERR_NOMEM;
                 rc_msg = std::string("l3d_shard_chain_run:") + ((host3[0] & 1) ? " candidate capacity exceeded on a rank (" + std::to_string(host3[1]) + " candidates in one view's range; l3d_set_chain_capacities);" : "") +
                          ((host3[0] & 2) ? " slot_records too small (" + std::to_string(host3[2]) + " kept matches in one view's range);" : "") +
+                         ((host3[0] & 8) ? " the compact kept arena of the slot ring is too small (" + std::to_string(arena_total_h) + " kept matches);" : "") +
                          ((host3[0] & 4) ? " a rank gave up;" : "");
             }
         }
@@ -708,7 +841,8 @@ int l3d_exchange_replay(void* user, int view, const void*, void* recv_block, siz
     if (e != hipSuccess) fprintf(stderr, "[l3d exchange_replay] view %d: hipMemcpyAsync(dst %p, src %p + %zu, %zu bytes): %s\n", view, recv_block, user, (size_t)view * block, block, hipGetErrorString(e));
     return (int)e;
 }
-const void* l3d_shard_chain_gathered(l3d_shard_chain* h) { return h ? h->c->ch_gathered.p : nullptr; }
+const void* l3d_shard_chain_gathered(l3d_shard_chain* h) { return h && !h->ring_mode ? h->c->ch_gathered.p : nullptr; }     // (ring mode: most blocks are gone)
+long long l3d_shard_chain_arena_needed(l3d_shard_chain* h) { return h ? h->arena_needed : 0; }
 int l3d_shard_chain_info(l3d_shard_chain* h, size_t* cand_cap, int* slot_records, int* overflow_bits, int* max_candidates, int* max_kept)
 {
     if (!h) return L3D_ERR_INVALID;
@@ -742,7 +876,8 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
     std::vector<unsigned char> ver(nvs);
     for (int k = 0; k < nv; ++k) ver[(size_t)k] = h->vd[(size_t)k].verified ? 1 : 0;
     HIPCHK(c, hipMemcpyAsync(sc + o_ver, ver.data(), nvs, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_shard_totals, dim3((nv + 255) / 256), dim3(256), 0, st, h->gathered, h->geom, sc + o_ver, nv, reinterpret_cast<int2*>(sc + o_tot));
+    if (h->ring_mode) hipLaunchKernelGGL(k_shard_totals, dim3((nv + 255) / 256), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(h->hdr_all), sizeof(SlotHeader), h->geom, sc + o_ver, nv, reinterpret_cast<int2*>(sc + o_tot));
+    else hipLaunchKernelGGL(k_shard_totals, dim3((nv + 255) / 256), dim3(256), 0, st, h->gathered, h->geom.slot_bytes, h->geom, sc + o_ver, nv, reinterpret_cast<int2*>(sc + o_tot));
     std::vector<int2> tot(nvs);
     HIPCHK(c, hipMemcpyAsync(tot.data(), sc + o_tot, nvs * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -762,6 +897,13 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
         pvh[(size_t)k].verified = d.verified ? 1 : 0;
         pvh[(size_t)k].best = d.verified ? d.best : nullptr;
         pvh[(size_t)k].bestpos = d.verified ? d.bestpos : nullptr;
+    }
+    if (h->ring_mode) {
+        // the records are in the arena already (k_shard_retire, view by view in this very order)
+        if (total != h->arena_needed) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: the retired records do not add up to the slot headers");
+        c->chain_seen_arena_cap = std::max(c->chain_seen_arena_cap, (size_t)total + (size_t)total / 8 + 65536);
+        h->kept_total = (double)total;
+        return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot);
     }
     HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
     HIPCHK(c, hipMemcpyAsync(sc + o_kb, kept_base.data(), nvs * 4, hipMemcpyHostToDevice, st));

@@ -124,6 +124,7 @@ struct l3d_ctx {
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    l3d::DevBuf ch_hdr;                      // sharded run, ring mode: per-view arena offsets, header table, flags
     l3d::DevBuf ch_bestpos;                  // per segment of every view: position of its best kept match in the view's slice (resident runs)
     l3d::Products products;
     std::vector<l3d::RayJob> ray_jobs;       // job list of k_tgt_rays of the running chain

@@ -33,6 +33,7 @@ namespace l3d {
     X(cc_max_rounds, "L3D_CC_MAX_ROUNDS", 0, "tests: rounds of the connected-components loop before it gives up (0: 64)")            \
     X(host_threads, "L3D_HOST_THREADS", 0, "worker threads of the host-side stages (0: min(16, usable CPUs))")                       \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
+    X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
     X(graph, "L3D_GRAPH", 1, "sharded chain: 0 = one API call per launch instead of the captured per-view graphs (A/B)")             \
     X(host_bookkeeping, "L3D_HOST_BOOKKEEPING", 0, "cross-check build only: matchViews with the rounds-1-2 host bookkeeping")       \
     X(host_clustering, "L3D_HOST_CLUSTERING", 0, "cross-check build only: merge loop and grouping on the host threads")             \

@@ -762,10 +762,11 @@ int prepare(L* h)
         int nd_all = 0;
         for (View* v : h->vlist) nd_all += v->S();
         const int nv_all = (int)h->vlist.size(), nn = h->matching_neighbors;
-        std::thread warm([h, nd_all, nv_all, nn]() {                // the finishing stages' arenas are reserved while the tiles are built and copied
-            if (h->warm_thread.joinable()) h->warm_thread.join();   // (the code objects: loading since the object was created)
-            (void)l3d_reserve_hint(h->ctx, nd_all, nv_all, nn);
-        });
+        // the finishing stages' arenas are reserved while the tiles are built and copied (a hint: a stage that needs more still gets it).
+        // Nobody waits for the code objects here: they load in the background since the object was created (l3d_warm_up), the modules this
+        // function and matchViews launch from first
+        int reserve_rc = L3D_OK;
+        std::thread warm([h, nd_all, nv_all, nn, &reserve_rc]() { reserve_rc = l3d_reserve_hint(h->ctx, nd_all, nv_all, nn); });
         std::atomic<size_t> next{ 0 };
         l3d::on_threads((unsigned)std::max<size_t>(1, std::min<size_t>(l3d::host_threads(), h->vlist.size())), [&](unsigned) {
             for (;;) {
@@ -784,6 +785,7 @@ int prepare(L* h)
         for (View* v : h->vlist) { arrs.push_back(v->segs.data()); cnts.push_back(v->S()); arrs.push_back(v->nb_segs.data()); cnts.push_back((int)(v->nb_segs.size() / 4)); }
         rc = l3d_register_segments_batch(h->ctx, arrs.data(), cnts.data(), (int)arrs.size());
         warm.join();
+        if (reserve_rc && (h->verbose || timing)) fprintf(stderr, "[l3d prepare] reserving the finishing stages' arenas ahead failed (%d): they are allocated when first needed\n", reserve_rc);
         if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
     }
     lap("neighbour tiles + residency");
@@ -2410,7 +2412,7 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
     if (!h) return L3D_ERR_INVALID;
     // A capacity failure is a verdict all ranks share (l3d_shard_chain_info): every rank reopens with the same, larger
     // capacities and runs again -- the bookkeeping of the failed attempt is dropped by the reopen (match_begin).
-    size_t cand_cap_next = 0;
+    size_t cand_cap_next = 0, arena_cap_next = 0;
     int rc = L3D_OK;
     // sizes a capacity verdict of an earlier pass of this job taught us (identical on every rank: the verdict is shared)
     if (h->shard_world_seen == world) { slot_records = std::max(slot_records, h->shard_slot_records_seen); cand_cap_next = h->shard_cand_cap_seen; }
@@ -2426,7 +2428,9 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         const double t1 = now_s();
         ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
         const bool host_commit = commit == 1;
+        if (arena_cap_next) l3d_set_chain_capacities(h->ctx, 0, arena_cap_next);          // (the compact arena of the slot ring: read by the run)
         rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, host_commit ? chain_callback : nullptr, host_commit ? &P->user : nullptr);
+        if (arena_cap_next) l3d_set_chain_capacities(h->ctx, 0, 0);
         std::string msg = rc ? std::string("shard_chain_run: ") + l3d_last_error(h->ctx) : std::string();
         if (rc == L3D_OK && commit == 2) {
             // commit on the device: this rank builds matchViews' products from the gathered slots (every rank may), no list goes to the host
@@ -2441,6 +2445,7 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         }
         size_t cand_cap = 0; int bits = 0, max_cand = 0, max_kept = 0, recs = slot_records;
         l3d_shard_chain_info(P->shard, &cand_cap, &recs, &bits, &max_cand, &max_kept);
+        const long long P_shard_arena = l3d_shard_chain_arena_needed(P->shard);
         if (gathered_out) *gathered_out = l3d_shard_chain_gathered(P->shard);
         if (slot_bytes_out) *slot_bytes_out = slot_bytes;
         const double t2 = now_s();
@@ -2449,7 +2454,8 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
                                           (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
         if (rc == L3D_OK) return rc2;
         h->fail(rc, msg);
-        if (rc != L3D_ERR_NOMEM || (bits & 4 && !(bits & 3)) || !(bits & 3)) return rc;      // not a capacity verdict: nothing a retry would change
+        if (rc != L3D_ERR_NOMEM || (bits & 4 && !(bits & 11)) || !(bits & 11)) return rc;    // not a capacity verdict: nothing a retry would change
+        if (bits & 8) { const long long need = P_shard_arena; arena_cap_next = (size_t)need + (size_t)need / 4 + 65536; }
         if ((bits & 2) && exchange == l3d_exchange_replay) return rc;                        // recorded blocks have the recorded slot size: the caller records again with more room
         if (bits & 1) cand_cap_next = h->shard_cand_cap_seen = std::max(cand_cap * 2, (size_t)max_cand + (size_t)max_cand / 4 + 65536);
         if (bits & 2) slot_records = h->shard_slot_records_seen = std::max(slot_records * 2, max_kept + max_kept / 4 + 1024);

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import l3d_oracle_pipeline as op
-from helpers import assert_lines_equal
+from helpers import digest_lists, assert_lines_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -786,6 +786,79 @@ def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, mon
         torch.cuda.synchronize()
         _check_against_oracle(q, small_oracle)
         assert _products_digest(q) == want, "rank %d" % r
+        q.close()
+
+
+def test_native_sharded_run_with_a_ring_of_gathered_slots():
+    """Ring mode of l3d_shard_chain_run (L3D_SLOT_RING=1; automatic when the gathered blocks of all views exceed 8 GB -- 63 GB per rank at
+    2048 x 4000 x 24 on 8 ranks): the gathered buffer holds only window + 18 views, older blocks are retired a batch at a time into the compact
+    kept arena before they are overwritten (k_shard_retire), the shared verdict comes from a compact header table.  48 views, 6 neighbours
+    (ring of 21 blocks: it wraps twice): world 1, and both ranks of a recorded world-2 job replayed -- kept lists, products and lines byte-equal
+    to the unsharded resident chain's; a compact arena that is too small ends in a capacity verdict and the retry grows it."""
+    import torch
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from line3d_amd import distributed as l3dist
+    V, S, N = 48, 120, 6
+    scene = make_scene(V, S, N, seed=11)
+
+    def lists_of(l):
+        return {v["id"]: l.view_matches(v["id"]) for v in scene.views}
+
+    ref = Line3D("", matchingNeighbors=N)
+    ref.keep_view_matches(True)
+    load_scene(ref, scene)
+    ref.compute3Dmodel(False)
+    want, want_lists, want_lines = _products_digest(ref), digest_lists(lists_of(ref)), ref.getResult()
+    assert len(want_lines) > 20
+    ref.close()
+    # world 1, ring forced; then with a far too small compact arena (the retry grows it)
+    for arena in (0, 300):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        l.context().set_option("L3D_SLOT_RING", 1)
+        if arena:
+            l.context().set_chain_capacities(0, arena)
+        l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=S, n_neighbors=N)
+        assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, arena
+        l.finish(False)
+        assert_lines_equal(l.getResult(), want_lines, 0.0)
+        l.close()
+    # world 2: record every block with the ring off (virtual ranks), then each rank replays its part with the ring on
+    W, SLOT = 2, 4096
+    dev = torch.device("cuda", 0)
+    ls = []
+    for r in range(W):
+        q = Line3D("", matchingNeighbors=N)
+        q.keep_view_matches(True)
+        load_scene(q, scene)
+        q.prepare()
+        ls.append(q)
+    n_views, slot_bytes = [q.shard_open(r, W, SLOT) for r, q in enumerate(ls)][0]
+    gathered = torch.zeros(n_views * W * slot_bytes, dtype=torch.uint8, device=dev)
+    send = [torch.zeros(n_views * slot_bytes, dtype=torch.uint8, device=dev) for _ in range(W)]
+    torch.cuda.synchronize()
+    for k in range(n_views):
+        for r, q in enumerate(ls):
+            q.shard_enqueue(k, send[r].data_ptr() + k * slot_bytes, gathered.data_ptr())
+        torch.cuda.synchronize()
+        if ls[0].shard_view_verified(k):
+            for r in range(W):
+                gathered[(k * W + r) * slot_bytes:(k * W + r + 1) * slot_bytes].copy_(send[r][k * slot_bytes:(k + 1) * slot_bytes])
+        torch.cuda.synchronize()
+        for q in ls:
+            q.shard_mark(k)
+    for q in ls:
+        q.shard_close(False)
+    recorded = gathered.clone()
+    for r, q in enumerate(ls):
+        q.context().set_option("L3D_SLOT_RING", 1)
+        g, _sb = q.shard_run(r, W, SLOT, "replay", recorded.data_ptr(), commit="device")
+        torch.cuda.synchronize()
+        assert not g, "ring mode hands out no gathered buffer"
+        assert digest_lists(lists_of(q)) == want_lists and _products_digest(q) == want, "rank %d" % r
         q.close()
 
 
