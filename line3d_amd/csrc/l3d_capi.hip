@@ -92,6 +92,7 @@ int l3d_set_option(l3d_ctx* c, const char* name, int value)
 int l3d_get_option(l3d_ctx* c, const char* name, int* value)
 {
     if (!c || !value) return L3D_ERR_INVALID;
+    if (name && strcmp(name, "shard_graph_launches") == 0) { *value = (int)std::min<long long>(c->shard_graph_launches, 0x7fffffff); return L3D_OK; }   // (a counter, not a switch)
     int* f = option_field(c->opt, name);
     if (!f) return fail(c, L3D_ERR_INVALID, std::string("l3d_get_option: unknown option ") + (name ? name : "(null)"));
     *value = *f;
@@ -129,6 +130,8 @@ void l3d_ctx_destroy(l3d_ctx* c)
                        &c->ch_rays, &c->aff_hyp, &c->edges_keep, &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->ch_bestpos.release(); c->ch_hdr.release();
+    for (auto& g : c->shard_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->shard_graphs.clear();
     c->products.release();
     c->pin_tab.release(); c->pin_ex.release(); c->pin_scal.release(); c->pin_best.release(); c->pin_kept.release();
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
@@ -274,7 +277,18 @@ int l3d_warm_up(l3d_ctx* c)
     for (auto f : first) f();
     const double t1 = now_s();
     std::vector<std::thread> th;
-    for (auto f : rest) th.emplace_back([f, dev]() { (void)hipSetDevice(dev); f(); });
+    const bool timing = c->opt.timing != 0;
+    static const char* rest_names[] = { "products", "sort (hipCUB)", "affinity", "rdd", "linefit", "chain_sharded" };
+    int ri = 0;
+    for (auto f : rest) {
+        const char* nm = rest_names[ri++];
+        th.emplace_back([f, dev, timing, nm, t0]() {
+            (void)hipSetDevice(dev);
+            const double a0 = now_s();
+            f();
+            if (timing) fprintf(stderr, "[l3d warm_up]   module %-16s loaded in %6.2f ms (at %6.2f ms)\n", nm, (now_s() - a0) * 1e3, (now_s() - t0) * 1e3);
+        });
+    }
     // the runtime builds its staging for copies between device and pageable host memory at the first such copy of a size class
     // (20 ms at the first 12 MB read-back of an edge list): here instead -- on a stream of its own: the context's streams belong to the caller
     {

@@ -522,7 +522,16 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 size_t new_cap = arena_cap * 2;
                 if (k >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / k * n_views * 1.3) + 1048576);
                 void* np = nullptr;
-                if (!hip_ok(hipMalloc(&np, new_cap * sizeof(Match)), "hipMalloc")) break;
+                {
+                    const hipError_t me = hipMalloc(&np, new_cap * sizeof(Match));
+                    if (me != hipSuccess) {
+                        size_t fr = 0, tot = 0;
+                        (void)hipMemGetInfo(&fr, &tot);
+                        rc_final = fail(c, L3D_ERR_NOMEM, "match_chain: growing the kept arena to " + std::to_string(new_cap * sizeof(Match) >> 20) + " MB at view " + std::to_string(k) + " of " + std::to_string(n_views) +
+                                                          " (" + std::to_string((size_t)r.kept_base * sizeof(Match) >> 20) + " MB in use, " + std::to_string(fr >> 20) + " of " + std::to_string(tot >> 20) + " MB free): " + hipGetErrorString(me));
+                        break;
+                    }
+                }
                 if (!hip_ok(hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice), "hipMemcpy")) break;
                 (void)hipFree(c->ch_kept.p);
                 c->ch_kept.p = np; c->ch_kept.cap = new_cap * sizeof(Match);

@@ -295,6 +295,7 @@ __global__ void k_check_slots(const unsigned char* __restrict__ hdr, size_t hdr_
 
 namespace {
 
+inline unsigned __float_as_uint_host(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 typedef l3d::ChainViewDev SViewDev;           // (s0, s1: this rank's source-segment range)
 
 size_t salign(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -335,6 +336,7 @@ struct l3d_shard_chain {
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
     int outcome[3] = { 0, 0, 0 };            // after l3d_shard_chain_run: OR of the ranks' overflow bits (8: the compact arena of the ring mode), largest candidate / kept count of a slot
     // ring mode of l3d_shard_chain_run (commit on the device only): the gathered buffer holds `ring` view blocks, older ones are retired
+    bool defer_stats = false, use_graphs = false;   // l3d_shard_chain_run: no host wait for a view's stage-1 statistics; graph replay of repeated passes
     bool ring_mode = false;
     int window = 0;                          // max over views of (index - smallest source index): how far back a view reads
     long long arena_cap = 0, arena_needed = 0;
@@ -461,9 +463,15 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     h->gathered = reinterpret_cast<const unsigned char*>(gathered_base);
     if (!d.verified) return L3D_OK;
     if (!send_slot) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_enqueue: null slot");
-    HIPCHK(c, hipEventSynchronize(h->ev1[(size_t)k]));
+    // The native run (l3d_shard_chain_run) never waits for a view's stage-1 statistics on the host: they only size the LDS image of the
+    // verification, which the budget caps anyway (-1: the largest image the budget allows), and the candidate total is summed when the run
+    // is over.  The step-wise protocol keeps the wait (its callers read the statistics between the steps).
+    const bool deferred = h->defer_stats;
+    if (!deferred) {
+        HIPCHK(c, hipEventSynchronize(h->ev1[(size_t)k]));
+        h->raw_sum += h->hstats[2 * k];
+    }
     HIPCHK(c, hipStreamWaitEvent(st, h->ev1[(size_t)k], 0));
-    h->raw_sum += h->hstats[2 * k];
     PairArgs pa = shard_pair_args(h, k);
     pa.cand_cap = (int)h->cand_cap;
     const int S = v.S_src, N = v.N;
@@ -472,35 +480,82 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
     const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
     unsigned char* slot = reinterpret_cast<unsigned char*>(send_slot);
-    if (v.n_sources) {
-        ProfScope p(c, "exist");
-        hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
+    int mmax = 0;
+    // this rank's kernels of view k: the same sequence whether it is launched call by call or replayed as a graph
+    auto issue = [&]() {
+        if (v.n_sources) {
+            ProfScope p(c, "exist");
+            hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
+        }
+        // row starts of this rank's rows only (+ zeroed scatter cursors, segment order); row_start[nrow] = their total
+        { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
+        {
+            ProfScope p(c, "cand_move");
+            const int blocks_move = ((d.s1 - d.s0) * v.n_tbm + 3) / 4;
+            const int blocks = blocks_move + 16 * v.n_sources * h->world;
+            if (blocks > 0)
+                hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, pa.tbm, v.n_tbm, d.rowA,
+                                   c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                                   c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
+                                   h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
+                                   c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
+        }
+        if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {          // (the window kernel orders the runs itself)
+            ProfScope p(c, "exist");
+            launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
+        }
+        VerifyArgs va = chain_verify_args(c, v, d, dtab, h->cand_cap);
+        chain_launch_verify(c, va, d, d_sc, v.n_sources, deferred ? -1 : h->hstats[2 * k + 1], h->cand_cap, st);
+        mmax = va.mmax;
+        {
+            ProfScope p(c, "kept_write");
+            hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, d.s1 - d.s0)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
+                               h->geom.slot_records, reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
+        }
+    };
+    // Passes over the same scene (bench.py's timed steps, a caller that re-runs matchViews) repeat the very same launches: the third pass on
+    // replays the five launches of a view as ONE graph launch (captured during the second pass, when the arguments proved stable; keyed by a
+    // checksum of everything the launches depend on).  A single compute3Dmodel never captures anything.  L3D_GRAPH=0: A/B.
+    ShardGraph* G = nullptr;
+    bool capture = false;
+    if (h->use_graphs && !c->prof_on && c->opt.graph != 0) {
+        if ((int)c->shard_graphs.size() < h->n_views) c->shard_graphs.resize((size_t)h->n_views);
+        G = &c->shard_graphs[(size_t)k];
+        unsigned long long sig = 1469598103934665603ull;
+        auto mix = [&](unsigned long long x) { sig = (sig ^ x) * 1099511628211ull; };
+        auto mixp = [&](const void* p) { mix((unsigned long long)(uintptr_t)p); };
+        mix((unsigned long long)k); mixp(send_slot); mixp(gathered_base); mix(h->geom.slot_bytes); mix((unsigned long long)h->geom.ring); mix((unsigned long long)h->geom.slot_records);
+        mix((unsigned long long)h->world); mix((unsigned long long)h->rank); mix(h->cand_cap); mix((unsigned long long)h->n_views);
+        mixp(c->row_start.p); mixp(c->ch_cursor.p); mixp(c->ch_segorder.p); mixp(c->cand_meta.p); mixp(c->cand_depths.p); mixp(c->cand_conf.p); mixp(c->vw_scratch.p);
+        mixp(c->kept_cnt.p); mixp(c->ch_ringA_meta.p); mixp(c->ch_ringA_depths.p); mixp(d.rowcnt); mixp(d.rowA); mixp(d.best); mixp(d.bestpos); mixp(dtab); mixp(d.src); mixp(d.tgt);
+        mix((unsigned long long)S); mix((unsigned long long)N); mix((unsigned long long)v.n_tbm); mix((unsigned long long)v.n_sources); mix((unsigned long long)v.view_id);
+        mix((unsigned long long)d.s0); mix((unsigned long long)d.s1); mix((unsigned long long)d.o_sc); mix((unsigned long long)d.o_si); mix((unsigned long long)d.o_l2g);
+        mix((unsigned long long)__float_as_uint_host(v.sigma_p)); mix((unsigned long long)__float_as_uint_host(v.sigma_a)); mix((unsigned long long)__float_as_uint_host(v.spatial_k));
+        mix((unsigned long long)c->verify_mode); mix((unsigned long long)verify_window_max_lds()); mix((unsigned long long)tunables().vw_wide_max.load()); mix((unsigned long long)c->opt.vw_debug);
+        if (G->exec && G->sig == sig) {
+            if (hipGraphLaunch(G->exec, st) == hipSuccess) { ++c->shard_graph_launches; return L3D_OK; }
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(G->exec); G->exec = nullptr; G->seen = -1000000;          // (never again on this context: launch call by call)
+        }
+        if (G->sig != sig) { if (G->exec) { (void)hipGraphExecDestroy(G->exec); G->exec = nullptr; } G->sig = sig; G->seen = 1; }
+        else if (++G->seen == 2 && !G->exec) capture = true;
     }
-    // row starts of this rank's rows only (+ zeroed scatter cursors, segment order); row_start[nrow] = their total
-    { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
-    {
-        ProfScope p(c, "cand_move");
-        const int blocks_move = ((d.s1 - d.s0) * v.n_tbm + 3) / 4;
-        const int blocks = blocks_move + 16 * v.n_sources * h->world;
-        if (blocks > 0)
-            hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, pa.tbm, v.n_tbm, d.rowA,
-                               c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
-                               c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
-                               h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
-                               c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
+    if (capture && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        issue();
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (ce == hipSuccess && graph) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ce == hipSuccess && exec && hipGraphLaunch(exec, st) == hipSuccess) { G->exec = exec; ++c->shard_graph_launches; return L3D_OK; }
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        G->seen = -1000000;                                                                     // capture is not available here: call by call from now on
+    } else if (capture) {
+        (void)hipGetLastError();
+        G->seen = -1000000;
     }
-    if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {          // (the window kernel orders the runs itself)
-        ProfScope p(c, "exist");
-        launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
-    }
-    VerifyArgs va = chain_verify_args(c, v, d, dtab, h->cand_cap);
-    chain_launch_verify(c, va, d, d_sc, v.n_sources, h->hstats[2 * k + 1], h->cand_cap, st);
-    const int mmax = va.mmax;
-    {
-        ProfScope p(c, "kept_write");
-        hipLaunchKernelGGL(k_slot_write, dim3(std::max(1, d.s1 - d.s0)), dim3(256), 0, st, va, c->kept_cnt.as<int>() + d.s0, (int)nrow,
-                           h->geom.slot_records, reinterpret_cast<const unsigned*>(dtab + d.o_l2g), d.best, h->geom, slot);
-    }
+    issue();
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("shard enqueue view ") + std::to_string(k) + " (mmax " + std::to_string(mmax) + ", lds " + std::to_string(verify_window_lds_bytes(mmax, N)) + ", range " + std::to_string(d.s0) + "-" + std::to_string(d.s1) + "): " + hipGetErrorString(e_)); }
     return L3D_OK;
 }
@@ -617,6 +672,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
     HIPCHK(c, c->ch_gathered.reserve((size_t)h->geom.ring * block + 256));
     h->eager_pack = cb != nullptr;
+    h->defer_stats = true;
+    h->use_graphs = cb == nullptr;                  // (a committing rank's pack kernel belongs to the mark, not to the view's sequence)
     unsigned char* send = c->ch_send.as<unsigned char>();
     unsigned char* gathered = c->ch_gathered.as<unsigned char>();
     // every verified view's block is fully written by its exchange before anything reads it; only the blocks of views
@@ -769,6 +826,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     const double t_run1 = now_s();
     (void)hipStreamSynchronize(c->stream);
     const double t_run2 = now_s();
+    for (int k = 0; k < h->n_views; ++k) if (h->vd[(size_t)k].verified) h->raw_sum += h->hstats[2 * k];     // (deferred: the statistics are final now)
+    h->defer_stats = false; h->use_graphs = false;
     if (fetcher.joinable()) fetcher.join();
     if (c->opt.timing)
         fprintf(stderr, "[l3d shard chain run] enqueue loop %.2f ms, stream drained after %.2f ms, bookkeeping thread done after %.2f ms\n",

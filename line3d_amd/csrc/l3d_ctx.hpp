@@ -101,6 +101,10 @@ struct Products {
     }
 };
 
+// one view's launch sequence of the sharded chain as an instantiated graph (l3d_chain_sharded.hip): sig = checksum of everything the
+// launches depend on, seen = passes in a row with that checksum
+struct ShardGraph { unsigned long long sig = 0; int seen = 0; hipGraphExec_t exec = nullptr; };
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -124,6 +128,8 @@ struct l3d_ctx {
     // arenas of the resident chain (l3d_chain.hip)
     l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
+    long long shard_graph_launches = 0;          // views enqueued as one graph launch so far (l3d_get_option "shard_graph_launches")
+    std::vector<l3d::ShardGraph> shard_graphs;   // per view of the sharded chain (repeated passes replay them)
     l3d::DevBuf ch_hdr;                      // sharded run, ring mode: per-view arena offsets, header table, flags
     l3d::DevBuf ch_bestpos;                  // per segment of every view: position of its best kept match in the view's slice (resident runs)
     l3d::Products products;

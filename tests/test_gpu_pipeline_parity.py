@@ -789,6 +789,34 @@ def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, mon
         q.close()
 
 
+def test_native_sharded_run_replays_repeated_passes_as_graphs(small_scene, small_oracle):
+    """Passes over the same scene repeat the very same launches: from the third pass on l3d_shard_chain_run replays a view's five launches as one
+    graph launch (captured in the second pass, keyed by a checksum of everything the launches depend on).  Every pass -- call by call, the
+    capturing one, the replayed ones, and again with L3D_GRAPH off -- gives the oracle's kept lists and lines and the same products."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd import distributed as l3dist
+    l = Line3D("", matchingNeighbors=6)
+    l.keep_view_matches(True)
+    load_scene(l, small_scene)
+    l.prepare()
+    ctx = l.context()
+    want = None
+    launches = []
+    for p in range(6):
+        if p == 5:
+            ctx.set_option("L3D_GRAPH", 0)
+        l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=300, n_neighbors=6)
+        _check_against_oracle(l, small_oracle)
+        d = _products_digest(l)
+        want = want or d
+        assert d == want, p
+        launches.append(ctx.get_option("shard_graph_launches"))
+    assert launches[0] == 0 and launches[1] > 0, launches                      # pass 2 captures (and launches what it captured)
+    assert launches[4] - launches[3] == launches[3] - launches[2] > 0, launches  # passes 3.. replay
+    assert launches[5] == launches[4], launches                                # switched off
+    l.close()
+
+
 def test_native_sharded_run_with_a_ring_of_gathered_slots():
     """Ring mode of l3d_shard_chain_run (L3D_SLOT_RING=1; automatic when the gathered blocks of all views exceed 8 GB -- 63 GB per rank at
     2048 x 4000 x 24 on 8 ranks): the gathered buffer holds only window + 18 views, older blocks are retired a batch at a time into the compact
@@ -822,8 +850,8 @@ def test_native_sharded_run_with_a_ring_of_gathered_slots():
         if arena:
             l.context().set_chain_capacities(0, arena)
         l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=S, n_neighbors=N)
-        assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, arena
         l.finish(False)
+        assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, arena
         assert_lines_equal(l.getResult(), want_lines, 0.0)
         l.close()
     # world 2: record every block with the ring off (virtual ranks), then each rank replays its part with the ring on
@@ -858,6 +886,7 @@ def test_native_sharded_run_with_a_ring_of_gathered_slots():
         g, _sb = q.shard_run(r, W, SLOT, "replay", recorded.data_ptr(), commit="device")
         torch.cuda.synchronize()
         assert not g, "ring mode hands out no gathered buffer"
+        q.finish(False)
         assert digest_lists(lists_of(q)) == want_lists and _products_digest(q) == want, "rank %d" % r
         q.close()
 
