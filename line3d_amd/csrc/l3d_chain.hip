@@ -521,6 +521,13 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 // (projected from the views done so far when there are enough of them: dense scenes keep 10x the first guess)
                 size_t new_cap = arena_cap * 2;
                 if (k >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / k * n_views * 1.3) + 1048576);
+                // (records are indexed with 31 bits: the arena ends at 2^31 records = 68.7 GB; doubling must not run past it while the projection still fits)
+                const size_t kMaxRecords = 0x7ffffff0u;
+                if (new_cap > kMaxRecords) {
+                    const size_t proj = k >= 4 ? (size_t)((double)r.kept_base / k * n_views * 1.15) + 1048576 : kMaxRecords;
+                    if (arena_cap >= kMaxRecords || proj > kMaxRecords) { rc_final = fail(c, L3D_ERR_UNSUPPORTED, "match_chain: more than 2^31 kept matches in one chain (view " + std::to_string(k) + " of " + std::to_string(n_views) + ")"); break; }
+                    new_cap = kMaxRecords;
+                }
                 void* np = nullptr;
                 {
                     const hipError_t me = hipMalloc(&np, new_cap * sizeof(Match));

@@ -336,6 +336,7 @@ struct l3d_shard_chain {
     double t_wait = 0, t_copy = 0, t_cb = 0, t_enq = 0, t_ex = 0;   // host-side phase timers (L3D_TIMING=1)
     int outcome[3] = { 0, 0, 0 };            // after l3d_shard_chain_run: OR of the ranks' overflow bits (8: the compact arena of the ring mode), largest candidate / kept count of a slot
     // ring mode of l3d_shard_chain_run (commit on the device only): the gathered buffer holds `ring` view blocks, older ones are retired
+    std::mutex cap_mu;                       // held while the chain's stream is capturing: HIP refuses another thread's wait on an event of a capturing stream
     bool defer_stats = false, use_graphs = false;   // l3d_shard_chain_run: no host wait for a view's stage-1 statistics; graph replay of repeated passes
     bool ring_mode = false;
     int window = 0;                          // max over views of (index - smallest source index): how far back a view reads
@@ -434,7 +435,10 @@ static int shard_stage1(l3d_shard_chain* h, int k)
         { ProfScope p(c, "scan", s1); launch_scan_range(d.rowcnt, d.rowA, h->views[k].N, d.s0, d.s1, h->views[k].S_src * h->views[k].N, nullptr, nullptr, s1, h->hstats_dev + 2 * k); }
         // depth records of the stage-1 candidates, in their own row order, into the ring slot last used by view k - kRingA
         // (its completion event is recorded by l3d_shard_chain_mark before this view's stage 1 is enqueued)
-        if (k - l3d_shard_chain::kRingA >= 0) HIPCHK(c, hipStreamWaitEvent(s1, h->ev2[(size_t)(k - l3d_shard_chain::kRingA)], 0));
+        if (k - l3d_shard_chain::kRingA >= 0) {
+            std::lock_guard<std::mutex> lk(h->cap_mu);          // (the event belongs to the chain's stream: not while that stream captures a view's launches)
+            HIPCHK(c, hipStreamWaitEvent(s1, h->ev2[(size_t)(k - l3d_shard_chain::kRingA)], 0));
+        }
         PairArgs pf = pa;
         pf.cand_cap = (int)h->cand_cap;
         pf.rowcnt = d.rowcnt;           // (the row's true count replaces k_pair_mask's upper bound)
@@ -540,11 +544,14 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         if (G->sig != sig) { if (G->exec) { (void)hipGraphExecDestroy(G->exec); G->exec = nullptr; } G->sig = sig; G->seen = 1; }
         else if (++G->seen == 2 && !G->exec) capture = true;
     }
+    std::unique_lock<std::mutex> cap_lk(h->cap_mu, std::defer_lock);
+    if (capture) cap_lk.lock();
     if (capture && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         issue();
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t ce = hipStreamEndCapture(st, &graph);
+        cap_lk.unlock();
         if (ce == hipSuccess && graph) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (ce == hipSuccess && exec && hipGraphLaunch(exec, st) == hipSuccess) { G->exec = exec; ++c->shard_graph_launches; return L3D_OK; }
@@ -555,6 +562,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         (void)hipGetLastError();
         G->seen = -1000000;
     }
+    if (cap_lk.owns_lock()) cap_lk.unlock();
     issue();
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("shard enqueue view ") + std::to_string(k) + " (mmax " + std::to_string(mmax) + ", lds " + std::to_string(verify_window_lds_bytes(mmax, N)) + ", range " + std::to_string(d.s0) + "-" + std::to_string(d.s1) + "): " + hipGetErrorString(e_)); }
     return L3D_OK;
