@@ -21,11 +21,28 @@ HYP_DTYPE = np.dtype([("P1", "<f8", (3,)), ("P2", "<f8", (3,)), ("dir", "<f8", (
 assert MATCH_DTYPE.itemsize == 32 and EDGE_DTYPE.itemsize == 12 and HYP_DTYPE.itemsize == 96
 
 _lib = None
+_lib_check = None
+CHECK_LIB_PATH = os.path.join(_HERE, "libline3d_amd_check.so")
 
 
-def load_library():
-    """dlopen libline3d_amd.so (built in-tree by __graft_entry__.build() / make -C line3d_amd/csrc)."""
-    global _lib
+def load_library(crosschecks: bool = False):
+    """dlopen libline3d_amd.so (built in-tree by __graft_entry__.build() / make -C line3d_amd/csrc).
+    crosschecks=True (tests only): libline3d_amd_check.so, the same sources built with -DL3D_CROSSCHECKS -- the only build in which
+    L3D_HOST_BOOKKEEPING / L3D_HOST_CLUSTERING / L3D_MATCH_SYNC force a host-side stage where the device stage would run."""
+    global _lib, _lib_check
+    if crosschecks:
+        if _lib_check is None:
+            load_library()
+            if not os.path.exists(CHECK_LIB_PATH):
+                raise RuntimeError("cross-check library not built: %s (make -C line3d_amd/csrc check)" % CHECK_LIB_PATH)
+            lib = C.CDLL(CHECK_LIB_PATH)
+            lib.l3d_last_error.restype = C.c_char_p
+            lib.l3d_last_error.argtypes = [C.c_void_p]
+            lib.l3d_profile_names.restype = C.c_char_p
+            lib.l3d_free.argtypes = [C.c_void_p]
+            lib.l3d_ctx_destroy.argtypes = [C.c_void_p]
+            _lib_check = lib
+        return _lib_check
     if _lib is None:
         try:
             # PyTorch-ROCm ships its own HIP runtime; when both live in one process (multi-GPU driver, tests) the

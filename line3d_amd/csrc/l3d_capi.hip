@@ -34,7 +34,7 @@ namespace l3d {
 Options options_from_env()
 {
     Options o;
-#define X(field, env, def, doc) if (const char* e = getenv(env)) o.field = (*e == 0) ? 1 : atoi(e);
+#define X(field, env, def, doc) if (kCrossChecks || !option_is_crosscheck(env)) if (const char* e = getenv(env)) o.field = (*e == 0) ? 1 : atoi(e);
     L3D_OPTION_TABLE(X)
 #undef X
     return o;
@@ -92,6 +92,7 @@ int l3d_set_option(l3d_ctx* c, const char* name, int value)
 int l3d_get_option(l3d_ctx* c, const char* name, int* value)
 {
     if (!c || !value) return L3D_ERR_INVALID;
+    if (name && strcmp(name, "crosschecks") == 0) { *value = kCrossChecks ? 1 : 0; return L3D_OK; }     // (which build this is)
     if (name && strcmp(name, "shard_graph_launches") == 0) { *value = (int)std::min<long long>(c->shard_graph_launches, 0x7fffffff); return L3D_OK; }   // (a counter, not a switch)
     int* f = option_field(c->opt, name);
     if (!f) return fail(c, L3D_ERR_INVALID, std::string("l3d_get_option: unknown option ") + (name ? name : "(null)"));
@@ -266,51 +267,24 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
 int l3d_warm_up(l3d_ctx* c)
 {
     if (!c) return L3D_ERR_INVALID;
-    const int dev = c->device;
-    (void)hipSetDevice(dev);
+    (void)hipSetDevice(c->device);
     const double t0 = now_s();
-    // in the order the first compute3Dmodel needs them: collinearity and stage 1, the chain, verification, the products, then the finishing
-    // stages; the big one (l3d_sort.hip: hipCUB, 7 MB) behind everything matchViews launches first -- a caller that does not wait for this
-    // function (the facade does not) finds each module loaded by the time it gets there, or waits for that one module only
-    void (*first[])() = { warm_kernels, warm_chain, warm_verify_window };
-    void (*rest[])() = { warm_products, warm_sort, warm_affinity, warm_rdd, warm_linefit, warm_chain_sharded };
-    for (auto f : first) f();
-    const double t1 = now_s();
-    std::vector<std::thread> th;
-    const bool timing = c->opt.timing != 0;
-    static const char* rest_names[] = { "products", "sort (hipCUB)", "affinity", "rdd", "linefit", "chain_sharded" };
-    int ri = 0;
-    for (auto f : rest) {
-        const char* nm = rest_names[ri++];
-        th.emplace_back([f, dev, timing, nm, t0]() {
-            (void)hipSetDevice(dev);
-            const double a0 = now_s();
-            f();
-            if (timing) fprintf(stderr, "[l3d warm_up]   module %-16s loaded in %6.2f ms (at %6.2f ms)\n", nm, (now_s() - a0) * 1e3, (now_s() - t0) * 1e3);
-        });
+    // One after the other, in the order the first compute3Dmodel needs them: collinearity and stage 1, the chain, verification, the
+    // products and their sort, then the finishing stages.  The runtime loads modules under one lock: eight threads loading at once took
+    // 21 ms where this loop takes 11 (measured: profiles/README.md, r4), and a kernel launch of the caller waits for that lock too -- a
+    // caller that does not wait for this function (the facade does not) finds each module loaded by the time it gets there, or waits for
+    // that one only.  (Rounds 2-3 also pushed a 16 MB copy through the runtime here to build its pageable-copy staging ahead of the first
+    // read-back of an edge list: 17 ms that nothing needs since the edge list stays on the device.)
+    struct M { void (*f)(); const char* name; } mods[] = {
+        { warm_kernels, "kernels" }, { warm_chain, "chain" }, { warm_verify_window, "verify_window" }, { warm_products, "products" }, { warm_sort, "sort" },
+        { warm_affinity, "affinity" }, { warm_rdd, "rdd" }, { warm_linefit, "linefit" }, { warm_chain_sharded, "chain_sharded" } };
+    for (const M& m : mods) {
+        const double a0 = now_s();
+        m.f();
+        if (c->opt.timing >= 2) fprintf(stderr, "[l3d warm_up]   module %-16s %6.2f ms\n", m.name, (now_s() - a0) * 1e3);
     }
-    // the runtime builds its staging for copies between device and pageable host memory at the first such copy of a size class
-    // (20 ms at the first 12 MB read-back of an edge list): here instead -- on a stream of its own: the context's streams belong to the caller
-    {
-        const size_t bytes = 16u << 20;
-        void* d = nullptr;
-        hipStream_t ws = nullptr;
-        std::vector<char> host(bytes);
-        if (hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess) {
-            if (hipMalloc(&d, bytes) == hipSuccess) {
-                (void)hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ws);
-                (void)hipMemcpyAsync(host.data(), d, bytes, hipMemcpyDeviceToHost, ws);
-                (void)hipMemcpyAsync(host.data(), d, 4, hipMemcpyDeviceToHost, ws);
-                (void)hipStreamSynchronize(ws);
-                (void)hipFree(d);
-            }
-            (void)hipStreamDestroy(ws);
-        }
-    }
-    const double t2 = now_s();
-    for (auto& t : th) t.join();
     (void)hipGetLastError();
-    if (c->opt.timing) fprintf(stderr, "[l3d warm_up] stage-1 / chain / verification modules %.2f ms, copy staging %.2f ms, all modules after %.2f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t0) * 1e3);
+    if (c->opt.timing) fprintf(stderr, "[l3d warm_up] all modules loaded after %.2f ms\n", (now_s() - t0) * 1e3);
     return L3D_OK;
 }
 int l3d_last_stats(l3d_ctx* c, double stats[4])

@@ -524,8 +524,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 // (records are indexed with 31 bits: the arena ends at 2^31 records = 68.7 GB; doubling must not run past it while the projection still fits)
                 const size_t kMaxRecords = 0x7ffffff0u;
                 if (new_cap > kMaxRecords) {
-                    const size_t proj = k >= 4 ? (size_t)((double)r.kept_base / k * n_views * 1.15) + 1048576 : kMaxRecords;
-                    if (arena_cap >= kMaxRecords || proj > kMaxRecords) { rc_final = fail(c, L3D_ERR_UNSUPPORTED, "match_chain: more than 2^31 kept matches in one chain (view " + std::to_string(k) + " of " + std::to_string(n_views) + ")"); break; }
+                    if (arena_cap >= kMaxRecords) { rc_final = fail(c, L3D_ERR_UNSUPPORTED, "match_chain: more than 2^31 kept matches in one chain (view " + std::to_string(k) + " of " + std::to_string(n_views) + ")"); break; }
                     new_cap = kMaxRecords;
                 }
                 void* np = nullptr;

@@ -680,8 +680,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
     HIPCHK(c, c->ch_gathered.reserve((size_t)h->geom.ring * block + 256));
     h->eager_pack = cb != nullptr;
-    h->defer_stats = true;
-    h->use_graphs = cb == nullptr;                  // (a committing rank's pack kernel belongs to the mark, not to the view's sequence)
+    h->defer_stats = c->opt.defer_stats != 0;
+    h->use_graphs = cb == nullptr && h->defer_stats;                  // (a committing rank's pack kernel belongs to the mark, not to the view's sequence)
     unsigned char* send = c->ch_send.as<unsigned char>();
     unsigned char* gathered = c->ch_gathered.as<unsigned char>();
     // every verified view's block is fully written by its exchange before anything reads it; only the blocks of views

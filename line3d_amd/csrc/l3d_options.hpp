@@ -34,10 +34,11 @@ namespace l3d {
     X(host_threads, "L3D_HOST_THREADS", 0, "worker threads of the host-side stages (0: min(16, usable CPUs))")                       \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
-    X(graph, "L3D_GRAPH", 1, "sharded chain: 0 = one API call per launch instead of the captured per-view graphs (A/B)")             \
-    X(host_bookkeeping, "L3D_HOST_BOOKKEEPING", 0, "cross-check build only: matchViews with the rounds-1-2 host bookkeeping")       \
-    X(host_clustering, "L3D_HOST_CLUSTERING", 0, "cross-check build only: merge loop and grouping on the host threads")             \
-    X(match_sync, "L3D_MATCH_SYNC", 0, "cross-check build only: matchViews through the per-view seam call")
+    X(defer_stats, "L3D_DEFER_STATS", 0, "sharded native run: 1 = no host wait for a view's stage-1 statistics (measured slower: 93 vs 84 us per view at 8 ranks, DESIGN 6)") \
+    X(graph, "L3D_GRAPH", 0, "sharded native run with L3D_DEFER_STATS=1: 1 = passes 3.. replay a view's five launches as one captured graph (measured slower: 99 vs 93 us per view, DESIGN 6)")             \
+    X(host_bookkeeping, "L3D_HOST_BOOKKEEPING", 0, "CROSS-CHECK BUILD ONLY (-DL3D_CROSSCHECKS, libline3d_amd_check.so): matchViews with the rounds-1-2 host bookkeeping") \
+    X(host_clustering, "L3D_HOST_CLUSTERING", 0, "CROSS-CHECK BUILD ONLY: merge loop and grouping on the host threads")             \
+    X(match_sync, "L3D_MATCH_SYNC", 0, "CROSS-CHECK BUILD ONLY: matchViews through the per-view seam call by default")
 
 struct Options {
 #define X(field, env, def, doc) int field = def;
@@ -45,11 +46,25 @@ struct Options {
 #undef X
 };
 
+// The three switches that force a host-side stage where the device stage would run exist for A/B tests only: the shipped library
+// (built without -DL3D_CROSSCHECKS) neither reads them from the environment nor lets l3d_set_option set them -- the host stages stay
+// in it only as what they are in the product: the per-view seam path (the reference's control flow), the sharded run's host commit,
+// and the fallbacks for inputs the device stages refuse.
+inline bool option_is_crosscheck(const char* env)
+{
+    return strcmp(env, "L3D_HOST_BOOKKEEPING") == 0 || strcmp(env, "L3D_HOST_CLUSTERING") == 0 || strcmp(env, "L3D_MATCH_SYNC") == 0;
+}
+#ifdef L3D_CROSSCHECKS
+constexpr bool kCrossChecks = true;
+#else
+constexpr bool kCrossChecks = false;
+#endif
+
 // name = the environment variable with or without its L3D_ prefix, any case of the prefix-less part as in the table
 inline int* option_field(Options& o, const char* name)
 {
     if (!name) return nullptr;
-#define X(field, env, def, doc) if (strcmp(name, env) == 0 || strcmp(name, &env[4]) == 0 || strcmp(name, #field) == 0) return &o.field;
+#define X(field, env, def, doc) if (strcmp(name, env) == 0 || strcmp(name, &env[4]) == 0 || strcmp(name, #field) == 0) return (kCrossChecks || !option_is_crosscheck(env)) ? &o.field : nullptr;
     L3D_OPTION_TABLE(X)
 #undef X
     return nullptr;

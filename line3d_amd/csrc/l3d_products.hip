@@ -299,7 +299,14 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         touch_src[(size_t)a].push_back((int)q);
         if (b >= 0 && b != a) touch_src[(size_t)b].push_back((int)q);
     }
-    const long long budget = c->opt.prod_block_keys > 0 ? (long long)c->opt.prod_block_keys : (1ll << 28);   // 268 M key slots = 6.4 GB of transients
+    // key slots per block: 2^28 (6.4 GB of transients at 24 B per slot) -- up to 2^30 when a quarter of the free HBM allows it: every block
+    // re-reads the records of all views that touch it (its views and their neighbours), so a dense scene wants few, big blocks
+    long long budget = 1ll << 28;
+    if (c->opt.prod_block_keys > 0) budget = c->opt.prod_block_keys;
+    else if (slots_all > budget) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::max(budget, std::min<long long>((long long)(fr / 4 / 24), (1ll << 30) - 64));
+    }
     std::vector<ProdBlock> blocks;
     std::vector<long long> off_tab;                         // per block: out_off of every chain view, then of every early pair
     {

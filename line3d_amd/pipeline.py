@@ -14,8 +14,8 @@ from .capi import MATCH_DTYPE, EDGE_DTYPE, L3DError, _p
 class Line3D:
     def __init__(self, data_directory: str = "", matchingNeighbors: int = 10, uncertainty_t_upper_2D: float = 5.0,
                  uncertainty_t_lower_2D: float = 1.0, sigma_p: float = 3.5, sigma_a: float = 10.0,
-                 min_baseline: float = 0.25, useCollinearity: bool = True, verbose: bool = False, device: int = 0):
-        self.lib = capi.load_library()
+                 min_baseline: float = 0.25, useCollinearity: bool = True, verbose: bool = False, device: int = 0, crosschecks: bool = False):
+        self.lib = capi.load_library(crosschecks)        # (crosschecks: the test-only build in which the L3D_HOST_* switches exist)
         self.lib.l3d_line3d_last_error.restype = C.c_char_p
         self.lib.l3d_line3d_last_error.argtypes = [C.c_void_p]
         self.lib.l3d_line3d_context.restype = C.c_void_p

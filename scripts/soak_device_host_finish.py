@@ -28,18 +28,18 @@ def main():
     for s in range(scenes):
         V, S, N = [(12, 600, 6), (20, 1500, 10), (16, 2500, 12), (10, 300, 4)][s % 4]
         sc = make_scene(V, S, N, seed=9000 + s)
-        l = Line3D("", matchingNeighbors=N)
+        l = Line3D("", matchingNeighbors=N, crosschecks=True)       # (the cross-check build: the only one with the L3D_HOST_CLUSTERING switch)
         load_scene(l, sc)
         l.prepare()
         l.match_views()
         for diff in (False, True):
-            os.environ.pop("L3D_HOST_CLUSTERING", None)
+            l.context().set_option("L3D_HOST_CLUSTERING", 0)
             l.finish(diff)
             a = digest(l)
-            os.environ["L3D_HOST_CLUSTERING"] = "1"
+            l.context().set_option("L3D_HOST_CLUSTERING", 1)
             l.finish(diff)
             b = digest(l)
-            os.environ.pop("L3D_HOST_CLUSTERING", None)
+            l.context().set_option("L3D_HOST_CLUSTERING", 0)
             if a != b:
                 bad += 1
             print("scene %d (%d x %d x %d) diffusion=%d: %d lines %s" % (s, V, S, N, diff, a[1], "ok" if a == b else "DIFFERENT"))

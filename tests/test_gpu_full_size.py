@@ -213,7 +213,8 @@ def test_full_size_affinity_fill_device_equals_literal_host_rule(chain_run, full
     # host bookkeeping (per-view delivery, host lists, host-packed tables): the same list
     from line3d_amd.pipeline import Line3D, load_scene
     monkeypatch.setenv("L3D_HOST_BOOKKEEPING", "1")
-    l2 = Line3D("", matchingNeighbors=N)
+    l2 = Line3D("", matchingNeighbors=N, crosschecks=True)          # (the switch only exists in the cross-check build)
+    assert l2.context().get_option("crosschecks") == 1 and l.context().get_option("crosschecks") == 0
     load_scene(l2, full_scene)
     l2.compute3Dmodel(False)
     assert l2.resident_products() is None

@@ -693,7 +693,7 @@ def test_finish_on_the_device_and_on_the_host_agree(small_scene, small_oracle, m
     for host in (False, True):
         if host:
             monkeypatch.setenv("L3D_HOST_CLUSTERING", "1")
-        l = Line3D("", matchingNeighbors=6)
+        l = Line3D("", matchingNeighbors=6, crosschecks=host)      # (the switch only exists in the cross-check build, libline3d_amd_check.so)
         load_scene(l, small_scene)
         l.compute3Dmodel(diffusion)
         res = l.getResult()
@@ -800,6 +800,8 @@ def test_native_sharded_run_replays_repeated_passes_as_graphs(small_scene, small
     load_scene(l, small_scene)
     l.prepare()
     ctx = l.context()
+    ctx.set_option("L3D_DEFER_STATS", 1)       # (both are off by default: measured slower than call-by-call launches at 8 ranks)
+    ctx.set_option("L3D_GRAPH", 1)
     want = None
     launches = []
     for p in range(6):
