@@ -152,7 +152,7 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
 // launch, and the slice starts where the previous verified view's ended (its result record) -- no cursor, no atomics.
 // Workgroup 0 also writes the view's result record (device copy for later views, host-mapped copy for the host).
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, const ChainResult* __restrict__ prev,
-                                                          int arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
+                                                          unsigned long long arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
                                                           const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos)
 {
     __shared__ int s_red[8];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
     r.overflow = r.R > a.cand_cap ? 1 : 0;
     r.n_kept = r.overflow ? 0 : total;
     r.kept_base = prev ? prev->kept_base + prev->n_kept : 0;
-    if (r.kept_base + r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
+    if ((unsigned long long)r.kept_base + (unsigned long long)r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
     if (blockIdx.x == 0 && tid == 0) { *res = r; *res_host = r; }
     if (yl >= nseg || r.overflow) return;
     write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best);
@@ -209,7 +209,7 @@ void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int*
 {
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
-void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
                              ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos)
 {
     hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos);
@@ -409,7 +409,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             ProfScope p(c, "kept_write");
             int pv = k - 1;
             while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
-            launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (int)arena_cap, dres + k, hres_dev + k,
+            launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (unsigned long long)arena_cap, dres + k, hres_dev + k,
                                     reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, map ? d.bestpos : nullptr);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
@@ -521,10 +521,10 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 // (projected from the views done so far when there are enough of them: dense scenes keep 10x the first guess)
                 size_t new_cap = arena_cap * 2;
                 if (k >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / k * n_views * 1.3) + 1048576);
-                // (records are indexed with 31 bits: the arena ends at 2^31 records = 68.7 GB; doubling must not run past it while the projection still fits)
-                const size_t kMaxRecords = 0x7ffffff0u;
+                // (records are indexed with 32 bits: the arena ends at 2^32 records = 137 GB; doubling must not run past it)
+                const size_t kMaxRecords = 0xfffffff0u;
                 if (new_cap > kMaxRecords) {
-                    if (arena_cap >= kMaxRecords) { rc_final = fail(c, L3D_ERR_UNSUPPORTED, "match_chain: more than 2^31 kept matches in one chain (view " + std::to_string(k) + " of " + std::to_string(n_views) + ")"); break; }
+                    if (arena_cap >= kMaxRecords) { rc_final = fail(c, L3D_ERR_UNSUPPORTED, "match_chain: more than 2^32 kept matches in one chain (view " + std::to_string(k) + " of " + std::to_string(n_views) + ")"); break; }
                     new_cap = kMaxRecords;
                 }
                 void* np = nullptr;

@@ -198,7 +198,7 @@ __global__ void k_shard_totals(const unsigned char* __restrict__ hdr, size_t hdr
 // all views' slots -> ONE kept arena (views back to back, ranks in segment order: the sorted list of the unsharded run) + the whole
 // view's best depth pairs and best positions (relative to the view's slice).  grid (x, rank, view).
 __global__ __launch_bounds__(256) void k_shard_pack_all(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified,
-                                                        const int* __restrict__ kept_base, const long long* __restrict__ best_off, Match* __restrict__ arena,
+                                                        const unsigned* __restrict__ kept_base, const long long* __restrict__ best_off, Match* __restrict__ arena,
                                                         float2* __restrict__ best_all, int* __restrict__ bestpos_all)
 {
     const int k = blockIdx.z, r = blockIdx.y;
@@ -950,16 +950,16 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
     HIPCHK(c, hipStreamSynchronize(st));
     std::vector<ChainResult> hres(nvs);
     std::vector<ProdChainView> pvh(nvs);
-    std::vector<int> kept_base(nvs, 0);
+    std::vector<unsigned> kept_base(nvs, 0);
     std::vector<long long> best_off(nvs, 0);
     long long total = 0;
     for (int k = 0; k < nv; ++k) {
         const SViewDev& d = h->vd[(size_t)k];
         ChainResult& r = hres[(size_t)k];
-        r.kept_base = (int)total; r.n_kept = d.verified ? tot[(size_t)k].x : 0; r.R = d.verified ? tot[(size_t)k].y : 0; r.overflow = 0;
-        kept_base[(size_t)k] = (int)total;
+        r.kept_base = (unsigned)total; r.n_kept = d.verified ? tot[(size_t)k].x : 0; r.R = d.verified ? tot[(size_t)k].y : 0; r.overflow = 0;
+        kept_base[(size_t)k] = (unsigned)total;
         total += r.n_kept;
-        if (total > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_products: more than 2^31 kept matches");
+        if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_products: more than 2^32 kept matches");
         best_off[(size_t)k] = d.verified ? (long long)(d.best - c->ch_best.as<float2>()) : 0;
         pvh[(size_t)k].verified = d.verified ? 1 : 0;
         pvh[(size_t)k].best = d.verified ? d.best : nullptr;
@@ -976,7 +976,7 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
     HIPCHK(c, hipMemcpyAsync(sc + o_kb, kept_base.data(), nvs * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(sc + o_bo, best_off.data(), nvs * 8, hipMemcpyHostToDevice, st));
     if (nv > 0)
-        hipLaunchKernelGGL(k_shard_pack_all, dim3(8, h->world, nv), dim3(256), 0, st, h->gathered, h->geom, sc + o_ver, reinterpret_cast<const int*>(sc + o_kb),
+        hipLaunchKernelGGL(k_shard_pack_all, dim3(8, h->world, nv), dim3(256), 0, st, h->gathered, h->geom, sc + o_ver, reinterpret_cast<const unsigned*>(sc + o_kb),
                            reinterpret_cast<const long long*>(sc + o_bo), c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>());
     HIPCHK(c, hipStreamSynchronize(st));                                 // (the upload sources above are locals)
     HIPCHK(c, hipGetLastError());

@@ -36,7 +36,8 @@ struct Hypothesis {                 // == l3d_hypothesis
 };
 
 struct ChainResult {                // per view of the resident chain (device -> pinned host)
-    int kept_base, n_kept, R, overflow;
+    unsigned kept_base;             // first record of the view's slice of the kept arena (records of 32 bytes: 32 bits reach 137 GB)
+    int n_kept, R, overflow;
 };
 
 struct PairArgs {
@@ -143,7 +144,7 @@ void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, cons
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
-void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, int arena_cap, ChainResult* res,
+void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
                              ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
