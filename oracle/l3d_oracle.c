@@ -7,7 +7,13 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and only as the checker.
  *
- * PARITY PIN STATUS.  Pinned to the reference's own code, compiled from its sources where they lie (oracle/_ref):
+ * PARITY PIN STATUS.  Two kinds of evidence, kept apart since round 4:
+ *   (A) oracle/_ref/ -- the reference COMPILED HERE: unmodified text behind an extern "C" door (clustering.cc, the texture-free device
+ *       functions, the comparators of sparsematrix.h).  These are the pins.
+ *   (B) oracle/_spliced/libkernels_spliced.so -- the reference's kernel text with BUILDER-WRITTEN lines where it touches CUDA textures or
+ *       launch variables (the diffusion kernels, the three bodies, the two matching kernels, K_collinearity below).  Corroboration only.
+ *   And, at the size bench.py times: tests/golden/config2_full.npz, this oracle alone over the whole 64 x 2000 x 12 scene.
+ * (A):
  *   - graph segmentation: clustering.cc + universe.h (oracle/Makefile target `ref`);
  *   - the texture-free device functions of cudawrapper.cu (:56-61, 93-99, 116-141, 165-285, 337-344: D_distance_p2l_2D_f3,
  *     D_segment_length_2D_f3, D_angle_between_lines_deg_3D_f3, D_point_on_segment_2D_f3, D_segment_overlap_2D,
@@ -16,6 +22,7 @@
  *     oracle/make_ref_devfn.py): bit-equal on 10^6 random and adversarial inputs per function, live and as committed
  *     golden vectors (tests/test_oracle_pins.py, tests/golden/devfn_ref.npz); the angle function bit-equal in the libm
  *     build, within 3e-5 degrees in the contract build (acosf is the one transcendental in it);
+ * (B):
  *   - the two kernels of replicator_dynamics_diffusion, K_sparseMat_row_normalization and K_sparseMat_diffusion_step
  *     (cudawrapper.cu:717-829; texture-free, every thread independent), compiled the same way (their launch variables, declared by
  *     the genuine <device_launch_parameters.h>, get their storage from oracle/ref_devfn_launch.cc): l3do_rdd_hooked runs them
@@ -257,8 +264,8 @@ static float hypothesis_confidence(f3 p1, f3 p2, f3 P1, f3 P2, f3 Q1, f3 Q2, f3 
 /* K_collinearity, cudawrapper.cu:476-535 (+ compute_collinearity :833-855:
  * sigma passed squared).  relation is dense S x S, row-major. */
 /* ------------------------------------------------------------------------- */
-/* Kernel hooks (tests/test_oracle_pins.py): with them set, the host orchestration below runs the REFERENCE's own kernels -- oracle/_ref/
- * libdevfn_ref.so, compiled from cudawrapper.cu's text -- in place of this file's restatements: the whole pipeline with the reference's
+/* Kernel hooks (tests/test_oracle_pins.py): with them set, the host orchestration below runs the reference's kernel text -- oracle/_spliced/
+ * libkernels_spliced.so, assembled from cudawrapper.cu's lines with table reads for its texture fetches -- in place of this file's restatements: the whole pipeline with the reference's
  * kernels inside the restated host code must give what it gives without them, bit for bit (libm build).  NULL = restatement. */
 typedef void (*l3do_hook_collin)(float* relation, int size, float coll_sigma_sqr, int stride, const float* segs);
 typedef void (*l3do_hook_dense)(float* buffer, int width, int height, const float* RtKinv_src, int r_stride, int offset, int cID, const float* C_src,
@@ -801,7 +808,7 @@ static void diffusion_step(const f4* P, const f4* W, const int* P_rows, const in
  * order of the list A; out: entries of the returned W (= P after the last swap, row-sorted),
  * as (i,j,w), nnz of them.  iters = L3D_RDD_MAX_ITER in the reference. */
 /* The same with the two kernels handed in: tests/test_oracle_pins.py passes the reference's OWN K_sparseMat_row_normalization /
- * K_sparseMat_diffusion_step (oracle/_ref/libdevfn_ref.so: compiled from cudawrapper.cu:717-829) and requires the result of
+ * K_sparseMat_diffusion_step (oracle/_spliced/libkernels_spliced.so: compiled from cudawrapper.cu:717-829) and requires the result of
  * l3do_rdd bit for bit.  NULL = the restatements above.  float4 records as plain floats. */
 typedef void (*l3do_norm_fn)(float* data, const int* start_indices, int num_rows, int num_entries);
 typedef void (*l3do_step_fn)(const float* P, const float* W, const int* P_rows, const int* W_cols, float* P_prime, const int* P_prime_rows, int num_entries);
