@@ -229,7 +229,10 @@ def main():
 
     # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
     # nobody is left waiting in a collective)
-    MODES = ["native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream, "
+    MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 8 neighbour windows in front of it, started cold; "
+             "the speculation verified with digests of the kept lists (one all-gather), the blocks all-gathered (one more), matchViews' products built on every rank "
+             "-- no per-view collective; a scene on which the verification fails falls through to the next mode",
+             "native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream, "
              "matchViews' products built on every rank's device from the gathered slots (no host bookkeeping)",
              "resident chain, source segments sharded, all-gather of per-view kept slots through torch.distributed on the library's stream",
              "per-view seam call, source segments sharded, all-gather of kept lists through the host"]
@@ -243,11 +246,21 @@ def main():
         flag = torch.tensor([0 if sharded_mode["link"] is not None else 1], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
-            sharded_mode["i"] = 1
-        if os.environ.get("L3D_BENCH_MODE"):            # testing: start at a given multi-GPU mode (0 native, 1 torch-driven, 2 per-view)
-            sharded_mode["i"] = max(sharded_mode["i"], int(os.environ["L3D_BENCH_MODE"]))
+            sharded_mode["i"] = 2                       # (no RCCL link: neither of the native modes)
+        elif world < 4:
+            sharded_mode["i"] = 1                       # (blocks of views pay a warm-up per rank: worth it from 4 ranks on)
+        if os.environ.get("L3D_BENCH_MODE"):            # testing: start at a given multi-GPU mode (0 blocks, 1 native, 2 torch-driven, 3 per-view)
+            sharded_mode["i"] = max(sharded_mode["i"] if int(flag.item()) else 0, int(os.environ["L3D_BENCH_MODE"]))
+
+    class SpeculationFailed(RuntimeError):
+        pass
 
     def step_once(mode):
+        if mode == 0:       # views sharded in blocks; False = the verification failed (the same on every rank): next mode, for good
+            if not l3dist.match_views_blocks(l3d, rank, world, sharded_mode["link"]):
+                raise SpeculationFailed("the cold-started blocks did not reproduce the chain on this scene")
+            return
+        mode -= 1
         if mode == 0:       # no rank hands lists to the host: every rank builds matchViews' products on its device from the gathered slots
             l3dist.match_views_chain_native(l3d, rank, world, sharded_mode["link"], commit="device",
                                             n_segments=args.segments, n_neighbors=args.neighbors)

@@ -351,6 +351,21 @@ int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_rec
  * argument; l3d_line3d_shard_run does it). */
 long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
 
+/* ---- Line3D::matchViews sharded by BLOCKS OF VIEWS over the ranks, speculatively, with exact verification ----------------------
+ * (line3D.cc:620-648 is a chain over views: the kept matches of a view become candidates of its later neighbours, :806,838-872.)
+ * Rank r runs the ordinary single-GPU resident chain on views [B_r - warmup_views, B_{r+1}) only (B_r = n_views * r / world), started
+ * cold: nothing is known about the views in front.  The chain's memory is short -- about three neighbour windows on the synthetic
+ * scenes (scripts/speculate_blocks.py) -- so by view B_r the kept lists normally ARE the one chain's.  That is checked, not assumed:
+ * every rank publishes a 64-bit digest of every kept list it computed (`exchange`, an all-gather: view = -1); rank r's block is exact iff
+ * rank r-1's is and the `window` views in front of B_r came out of r's warm-up exactly as r-1 computed them (from B_r on every view then
+ * has the one chain's inputs).  Every rank reads the same table and reaches the same verdict.  *verdict = 0: the ranks all-gathered
+ * their blocks (view = -2) and THIS context now holds matchViews' products exactly as after l3d_match_chain_resident over all views
+ * (arena, potential correspondences, best matches, medians; summary / n_pot as there).  *verdict = 1: the speculation did not hold (or
+ * warmup_views < window, or a block is shorter than the window): nothing was committed, run l3d_shard_chain_run instead.
+ * No per-view collective: two exchanges per pass.  window = the largest distance between a view and one of its sources. */
+int l3d_match_chain_blocks(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                           int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
+
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
  * caller may instead register segment arrays once; l3d_compute_pairwise_matches recognises
@@ -462,6 +477,11 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
  * gathered_out (optional) receives the device address of the gathered blocks (valid until the next chain) */
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);
+/* matchViews with the VIEWS sharded over the ranks in blocks, each block started cold a few neighbour windows early, the speculation verified
+ * (l3d_match_chain_blocks above; warmup_views < 0: eight windows).  *verdict = 0: this rank holds matchViews' products as after the
+ * single-GPU resident chain -- compute3Dmodel goes on from there (l3d_line3d_finish); *verdict = 1 (identical on every rank): the speculation
+ * did not hold, nothing was committed, run l3d_line3d_shard_run. */
+int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
 /* performClustering (clustering.h:125, clustering.cc:6-47) on the host (fallback and cross-check of l3d_perform_clustering_device): labels[k] = CLUniverse::find(k) */
 int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */

@@ -227,11 +227,17 @@ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // cb: per-view delivery of the kept lists to the host (l3d_match_chain); map: products built on the device at the end of the chain
 // (l3d_match_chain_resident) -- either or both
+// [k_begin, k_end): the views this call computes (k_end < 0: all).  Views outside the range are treated as if they had never run: they
+// launch nothing and their result records stay zero, so a view inside the range finds no kept matches of a source in front of it
+// (l3d_match_chain_blocks: a block of views started cold).  With a range and neither cb nor map the call only fills the kept arena and
+// the per-view result records (c->ch_pin_res).
 static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user, const l3d_dense_map* map,
-                     l3d_chain_summary* summary, int64_t* n_pot)
+                     l3d_chain_summary* summary, int64_t* n_pot, int k_begin = 0, int k_end = -1)
 {
     if (!c) return L3D_ERR_INVALID;
-    if (n_views < 0 || (n_views > 0 && (!views || (!cb && !map)))) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
+    const bool ranged = k_end >= 0;
+    if (!ranged) { k_begin = 0; k_end = n_views; }
+    if (n_views < 0 || (n_views > 0 && (!views || (!cb && !map && !ranged))) || k_begin < 0 || k_end > n_views || k_begin > k_end) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
     c->products.valid = false;
     if (n_views == 0) return L3D_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -254,6 +260,18 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, c->chain_ring != 0 ? L3D_AHEAD + L3D_S1AHEAD + 3 : 0, st)) return rc;
     const unsigned char* dtab = L.dtab;
     const int maxN = L.maxN;
+    if (ranged) {
+        // (after the arenas are laid out for all views: a view keeps its slices whatever the range is)
+        double p_range = 0, p_max = 0;
+        for (int k = 0; k < n_views; ++k) {
+            if (k < k_begin || k >= k_end) { vd[(size_t)k].verified = false; continue; }
+            if (!vd[(size_t)k].verified) continue;
+            double p = 0;
+            for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
+            p_range += p; p_max = std::max(p_max, p);
+        }
+        L.pairs = p_range; L.max_pairs = p_max;
+    }
     HIPCHK(c, c->ch_res.reserve((size_t)n_views * sizeof(ChainResult) + 16));
     HIPCHK(c, c->ch_flags.reserve(64));
     HIPCHK(c, c->ch_pin_res.reserve((size_t)n_views * (sizeof(ChainResult) + 8) + 64));
@@ -268,6 +286,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     // per-view results are written by the kernels straight into host-mapped pinned memory (no copy operations on the streams)
     ChainResult* hres = c->ch_pin_res.as<ChainResult>();
     int* hstats = reinterpret_cast<int*>(c->ch_pin_res.as<unsigned char>() + (size_t)n_views * sizeof(ChainResult));
+    if (ranged) memset(hres, 0, (size_t)n_views * sizeof(ChainResult));          // (views outside the range: no records, whatever an earlier chain left here)
     ChainResult* hres_dev = nullptr;
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&hres_dev), hres, 0));
     int* hstats_dev = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(hres_dev) + (size_t)n_views * sizeof(ChainResult));
@@ -410,7 +429,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             int pv = k - 1;
             while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
             launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (unsigned long long)arena_cap, dres + k, hres_dev + k,
-                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, map ? d.bestpos : nullptr);
+                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
@@ -601,6 +620,168 @@ extern "C" int l3d_match_chain_resident(l3d_ctx* c, const l3d_chain_view* views,
     if (!map || !map->view_ids || !map->seg_base || map->n_views < 0 || (n_views > 0 && !summary)) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_resident: bad argument");
     if (n_pot) *n_pot = 0;
     return run_chain(c, views, n_views, nullptr, nullptr, map, summary, n_pot);
+}
+
+// =================================================================================================================================
+// matchViews sharded by BLOCKS OF VIEWS, speculatively, with exact verification (round 4).
+//
+// The chain over views has a short memory: started cold at view B - L (nothing known about earlier views), its kept lists become
+// bit-identical to the true chain's after about three neighbour windows (measured: scripts/speculate_blocks.py).  So rank r of `world`
+// runs the ordinary single-GPU chain -- full-width kernels, no per-view collective -- on views [B_r - warmup, B_{r+1}) only, and the ranks
+// then CHECK the speculation: every rank publishes a 64-bit digest of every kept list it computed; rank r's block is exact if rank r-1's is
+// and the `window` views in front of B_r came out of rank r's warm-up exactly as rank r-1 (whose block they belong to) computed them --
+// from B_r on every view then has the same inputs as in the one chain, and the same arithmetic.  All ranks read the same gathered table,
+// so all reach the same verdict without another collective.  When it holds, the ranks all-gather their blocks' kept records (+ best depth
+// pairs / positions), lay them out as the one chain's arena and build matchViews' products from it (l3d_products.hip, unchanged).  When it
+// does not, nothing is committed and the caller takes the segment-sharded run (l3d_shard_chain_run), whose result needs no speculation.
+namespace l3d {
+
+struct BlockDigest { unsigned long long hash; int n_kept, R; };      // per view of the chain; zero = not computed by this rank
+static_assert(sizeof(BlockDigest) == 16, "digest entry");
+
+// order-sensitive 64-bit digest of a view's kept records: sum over records of a mix of (index, the record's eight words)
+__global__ __launch_bounds__(256) void k_block_digest(const Match* __restrict__ arena, const ChainResult* __restrict__ res, int k_begin, BlockDigest* __restrict__ out)
+{
+    const int k = k_begin + blockIdx.y;
+    const ChainResult r = res[k];
+    unsigned long long h = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < r.n_kept; i += gridDim.x * 256) {
+        const uint4* w = reinterpret_cast<const uint4*>(arena + r.kept_base + i);
+        const uint4 a = w[0], b = w[1];
+        unsigned long long x = 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        const unsigned v[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x ^= v[q]; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29; }
+        h += x;
+    }
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(&out[k].hash, h);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[k].n_kept = r.n_kept; out[k].R = r.R; }
+}
+
+}  // namespace l3d
+
+extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                                      int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!views || n_views <= 0 || !map || !summary || !exchange || !verdict || world < 1 || rank < 0 || rank >= world || warmup_views < 0 || window < 0)
+        return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: bad argument");
+    *verdict = 1;
+    if (n_pot) *n_pot = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto block_begin = [&](int r) { return (int)(((long long)n_views * r) / world); };
+    const int own0 = block_begin(rank), own1 = block_begin(rank + 1);
+    const int first = rank == 0 ? 0 : std::max(0, own0 - warmup_views);
+    const double t0 = now_s();
+    // ---- this rank's chain: its block and the warm-up views in front of it, started cold
+    { int rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, own1); if (rc) return rc; }
+    const ChainResult* hres = c->ch_pin_res.as<ChainResult>();
+    const double t1 = now_s();
+    // useful work of this rank = its own block (the warm-up is the price of the speculation)
+    {
+        double p = 0;
+        for (int k = own0; k < own1; ++k)
+            for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
+        c->stats[0] = p;
+    }
+    // ---- digests of every list this rank computed, all-gathered
+    const size_t tab_bytes = (((size_t)n_views * sizeof(BlockDigest)) + 255) & ~(size_t)255;
+    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 256));
+    BlockDigest* dtab_own = c->ch_hdr.as<BlockDigest>();
+    BlockDigest* dtab_all = reinterpret_cast<BlockDigest*>(c->ch_hdr.as<unsigned char>() + tab_bytes);
+    HIPCHK(c, hipMemsetAsync(dtab_own, 0, tab_bytes, st));
+    if (own1 > first) {
+        HIPCHK(c, hipMemcpyAsync(c->ch_res.p, hres, (size_t)n_views * sizeof(ChainResult), hipMemcpyHostToDevice, st));     // (the final records: a restart rewrites them)
+        hipLaunchKernelGGL(k_block_digest, dim3(16, own1 - first), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), first, dtab_own);
+    }
+    if (exchange(exchange_user, -1, dtab_own, dtab_all, tab_bytes, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the digests failed");
+    std::vector<BlockDigest> tab((size_t)world * (size_t)n_views);
+    for (int r = 0; r < world; ++r)
+        HIPCHK(c, hipMemcpyAsync(tab.data() + (size_t)r * n_views, reinterpret_cast<const unsigned char*>(dtab_all) + (size_t)r * tab_bytes, (size_t)n_views * sizeof(BlockDigest), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const double t2 = now_s();
+    // ---- the verdict (the same on every rank: same table)
+    bool ok = true;
+    for (int r = 1; r < world && ok; ++r) {
+        const int b = block_begin(r), fr = std::max(0, b - warmup_views), lo = b - window;
+        if (lo < fr || lo < block_begin(r - 1)) { ok = false; break; }       // warm-up shorter than the window, or a block shorter than the window
+        for (int k = lo; k < b; ++k) {
+            const BlockDigest &x = tab[(size_t)r * n_views + k], &y = tab[(size_t)(r - 1) * n_views + k];
+            // (the kept LIST must be the same; the number of candidates it was chosen from may differ while the warm-up converges)
+            if (x.hash != y.hash || x.n_kept != y.n_kept) { ok = false; if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks] rank %d's warm-up view %d differs from rank %d's (%d vs %d kept)\n", r, k, r - 1, x.n_kept, y.n_kept); break; }
+        }
+    }
+    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, speculation %s\n",
+                               rank, world, first, own1 - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ok ? "exact" : "NOT exact");
+    if (!ok) return L3D_OK;                                                    // *verdict = 1: nothing committed
+    // ---- all-gather of the blocks: [records of the block's views][best depth pairs][best positions], padded to the largest block
+    auto owner = [&](int k) { int r = (int)(((long long)k * world) / n_views); while (r + 1 < world && block_begin(r + 1) <= k) ++r; while (r > 0 && block_begin(r) > k) --r; return r; };
+    std::vector<long long> rec_of((size_t)world, 0), seg_of((size_t)world, 0);
+    for (int k = 0; k < n_views; ++k) {
+        const int r = owner(k);
+        rec_of[(size_t)r] += tab[(size_t)r * n_views + k].n_kept;
+        if (views[k].n_tbm > 0) seg_of[(size_t)r] += views[k].S_src;
+    }
+    long long max_rec = 0, max_seg = 0, total = 0;
+    for (int r = 0; r < world; ++r) { max_rec = std::max(max_rec, rec_of[(size_t)r]); max_seg = std::max(max_seg, seg_of[(size_t)r]); total += rec_of[(size_t)r]; }
+    if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_blocks: more than 2^32 kept matches");
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_best = al((size_t)max_rec * sizeof(Match)), o_bpos = o_best + al((size_t)max_seg * 8), slot = o_bpos + al((size_t)max_seg * 4);
+    HIPCHK(c, c->ch_send.reserve(slot + 256));
+    HIPCHK(c, c->ch_gathered.reserve(slot * (size_t)world + 256));
+    // offsets of the views' slices in the whole-run arrays of best pairs / positions (chain_assign_arenas: verified views back to back)
+    std::vector<long long> best_off((size_t)n_views + 1, 0);
+    for (int k = 0; k < n_views; ++k) best_off[(size_t)k + 1] = best_off[(size_t)k] + (views[k].n_tbm > 0 ? views[k].S_src : 0);
+    unsigned char* send = c->ch_send.as<unsigned char>();
+    long long own_start = 0;                                    // (this rank's arena: the views it computed, back to back from its cold start)
+    for (int k = first; k < own0; ++k) own_start += hres[k].n_kept;
+    if (rec_of[(size_t)rank] > 0)
+        HIPCHK(c, hipMemcpyAsync(send, c->ch_kept.as<Match>() + own_start, (size_t)rec_of[(size_t)rank] * sizeof(Match), hipMemcpyDeviceToDevice, st));
+    if (seg_of[(size_t)rank] > 0) {
+        HIPCHK(c, hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 8, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (exchange(exchange_user, -2, send, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the kept lists failed");
+    HIPCHK(c, hipStreamSynchronize(st));            // (the arena below may be reallocated: everything that reads the old one is done)
+    // ---- the one chain's arena: blocks in rank order = views in order
+    HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
+    std::vector<ChainResult> hres_all((size_t)n_views);
+    std::vector<ProdChainView> pvh((size_t)n_views);
+    {
+        long long base = 0;
+        for (int k = 0; k < n_views; ++k) {
+            const BlockDigest& e = tab[(size_t)owner(k) * n_views + k];
+            ChainResult& r = hres_all[(size_t)k];
+            r.kept_base = (unsigned)base; r.n_kept = e.n_kept; r.R = e.R; r.overflow = 0;
+            base += e.n_kept;
+            const bool ver = views[k].n_tbm > 0;
+            pvh[(size_t)k].verified = ver ? 1 : 0;
+            pvh[(size_t)k].best = ver ? c->ch_best.as<float2>() + best_off[(size_t)k] : nullptr;
+            pvh[(size_t)k].bestpos = ver ? c->ch_bestpos.as<int>() + best_off[(size_t)k] : nullptr;
+        }
+        long long at = 0;
+        const unsigned char* G = c->ch_gathered.as<unsigned char>();
+        for (int r = 0; r < world; ++r) {
+            const int b0 = block_begin(r);
+            if (rec_of[(size_t)r]) HIPCHK(c, hipMemcpyAsync(c->ch_kept.as<Match>() + at, G + (size_t)r * slot, (size_t)rec_of[(size_t)r] * sizeof(Match), hipMemcpyDeviceToDevice, st));
+            if (seg_of[(size_t)r]) {
+                HIPCHK(c, hipMemcpyAsync(c->ch_best.as<float2>() + best_off[(size_t)b0], G + (size_t)r * slot + o_best, (size_t)seg_of[(size_t)r] * 8, hipMemcpyDeviceToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(c->ch_bestpos.as<int>() + best_off[(size_t)b0], G + (size_t)r * slot + o_bpos, (size_t)seg_of[(size_t)r] * 4, hipMemcpyDeviceToDevice, st));
+            }
+            at += rec_of[(size_t)r];
+        }
+    }
+    const double t3 = now_s();
+    const int rc = build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, n_pot);
+    if (rc) return rc;
+    memcpy(c->ch_pin_res.as<ChainResult>(), hres_all.data(), (size_t)n_views * sizeof(ChainResult));       // (what l3d_chain_kept_list reads)
+    c->stats[3] = (double)total;
+    { double raw = 0; for (int k = own0; k < own1; ++k) raw += tab[(size_t)rank * n_views + k].R; c->stats[1] = raw; }      // (this rank's useful share)
+    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] gather of the blocks %.2f ms, products %.2f ms\n", rank, world, (t3 - t2) * 1e3, (now_s() - t3) * 1e3);
+    *verdict = 0;
+    return L3D_OK;
 }
 
 void l3d::warm_chain() { touch_kernel(reinterpret_cast<const void*>(&k_exist_count)); }

@@ -807,6 +807,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             h->t_enq += now_s() - te0;
             if (r2) { rc = r2; rc_msg = c->err; draining = true; }
         }
+        if (h->ring_mode && !verified && !draining)          // (a view that is never verified must read as "no kept records", whatever lived in its ring block)
+            if (hipMemsetAsync(gathered + (size_t)(k % h->geom.ring) * block, 0, block, c->stream) != hipSuccess) { (void)hipGetLastError(); }
         if (draining && verified) {
             if (hipMemcpyAsync(send + (size_t)(k % send_ring) * slot, abort_hdr, sizeof(SlotHeader), hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); }
         }

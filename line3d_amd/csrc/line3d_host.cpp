@@ -2462,6 +2462,43 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
     }
     return rc;
 }
+// matchViews with the VIEWS sharded over the ranks in blocks, each block started cold a few windows early and the speculation verified
+// (l3d_match_chain_blocks).  *verdict = 0: this rank holds matchViews' products as after the single-GPU resident chain; 1: the speculation
+// did not hold on this scene, nothing was committed -- the caller runs l3d_line3d_shard_run (every rank gets the same verdict).
+// warmup_views < 0: eight neighbour windows.
+int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    if (!h || !verdict) return L3D_ERR_INVALID;
+    *verdict = 1;
+    const double t0 = now_s();
+    match_begin(h);
+    ChainPlan* Pp = get_plan(h);
+    if (!Pp) return L3D_OK;                               // (a schedule the chain cannot express: the caller's other paths handle it)
+    ChainPlan& P = *Pp;
+    int window = 1;
+    for (size_t k = 0; k < P.n; ++k) for (int si : P.src_idx[k]) window = std::max(window, (int)k - si);
+    if (warmup_views < 0) warmup_views = 8 * window;       // (the chain forgets a cold start after 3-7 windows on the synthetic scenes, the denser the later: scripts/speculate_blocks.py)
+    std::vector<uint32_t> ids; std::vector<int32_t> base;
+    dense_map(h, ids, base);
+    l3d_dense_map map;
+    map.n_views = (int32_t)ids.size(); map.view_ids = ids.data(); map.seg_base = base.data();
+    h->chain_summary.assign(P.n, l3d_chain_summary());
+    h->resident_products = false;
+    const double t1 = now_s();
+    int rc = l3d_match_chain_blocks(h->ctx, P.cv.data(), (int)P.n, &map, h->chain_summary.data(), &h->resident_n_pot, rank, world, warmup_views, window,
+                                    exchange, exchange_user, verdict);
+    h->t_gpu_call += now_s() - t1;
+    if (rc) return h->fail(rc, std::string("match_chain_blocks: ") + l3d_last_error(h->ctx));
+    if (*verdict != 0) return L3D_OK;
+    rc = adopt_resident_products(h, P);
+    if (rc) return rc;
+    double st[4];
+    l3d_last_stats(h->ctx, st);
+    h->stat_pairs += st[0];
+    h->stat_raw += st[1];
+    h->t_match = now_s() - t0;
+    return L3D_OK;
+}
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 
 // performClustering (clustering.h:125, clustering.cc:6-47) as a host entry point: labels[k] = find(k)

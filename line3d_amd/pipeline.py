@@ -236,6 +236,19 @@ class Line3D:
                                                 C.c_int(int(commit)), C.byref(g), C.byref(sb)))
         return g.value, sb.value
 
+    def block_run(self, rank: int, world: int, exchange="local", exchange_user=None, warmup_views: int = -1) -> bool:
+        """matchViews with the views sharded over the ranks in blocks (l3d_line3d_block_run): True = the speculation was exact and this object
+        holds matchViews' products; False = it was not (same answer on every rank): run shard_run instead.  exchange as for shard_run."""
+        if callable(exchange):
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+            fn = self._exchange_keepalive = proto(exchange)
+        else:
+            fn = {"rccl": self.lib.l3d_exchange_rccl, "local": self.lib.l3d_exchange_local}[exchange]
+        user = C.c_void_p(exchange_user) if isinstance(exchange_user, int) else (C.c_void_p(C.addressof(exchange_user)) if exchange_user is not None else None)
+        verdict = C.c_int(1)
+        self._chk(self.lib.l3d_line3d_block_run(self.h, C.c_int(rank), C.c_int(world), C.c_int(warmup_views), C.cast(fn, C.c_void_p), user, C.byref(verdict)))
+        return verdict.value == 0
+
     def shard_close(self, committed: bool):
         self._chk(self.lib.l3d_line3d_shard_close(self.h, C.c_int(int(committed))))
 

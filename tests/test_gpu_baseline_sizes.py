@@ -252,3 +252,45 @@ def test_config5_shape_mid_chain_slice_against_the_oracle(cfg5_scene, cfg5_chain
     assert len(mv["tbm"]) == 12 and len(mv["l2g"]) == 24 and len(existing) > 100000
     got = own[(own["segID1"] >= lo) & (own["segID1"] < hi)]
     assert len(exp) > 500 and got.tobytes() == exp.tobytes()
+
+
+def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
+    """configs[2]'s 512 views x 2000 segments x 12 neighbours with the VIEWS sharded over 8 ranks in blocks of 64 (l3d_match_chain_blocks: every rank
+    the full-width single-GPU chain on its block + 36 warm-up views started cold, the speculation verified with digests of the kept lists, the blocks
+    all-gathered): eight virtual ranks as threads on the one GPU, an all-gather through the host.  Every rank must report an exact speculation and hold
+    the ONE chain's kept lists (rank 0 and rank 5 are compared view by view with the unsharded run) -- two collectives for the whole pass."""
+    import threading
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from test_gpu_pipeline_parity import _thread_exchange
+    V, S, N, W = 512, 2000, 12, 8
+    scene = make_scene(V, S, N, seed=20260)
+    ref, ref_lists = _run(scene, N)
+    want = digest_lists(ref_lists)
+    ref.close()
+    make, calls = _thread_exchange(W)
+    ls, verdicts, errors = [], [None] * W, []
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(r in (0, 5))
+        load_scene(l, scene)
+        l.prepare()
+        ls.append(l)
+
+    def run(r):
+        try:
+            verdicts[r] = ls[r].block_run(r, W, make(r), None, -1)
+        except Exception as e:      # noqa: BLE001
+            errors.append((r, e))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    assert verdicts == [True] * W, verdicts
+    assert [c[0] for c in calls] == [-1, -2]
+    for r in (0, 5):
+        assert digest_lists({v["id"]: ls[r].view_matches(v["id"]) for v in scene.views}) == want, "rank %d" % r
+    for l in ls:
+        l.close()

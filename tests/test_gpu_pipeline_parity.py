@@ -893,6 +893,97 @@ def test_native_sharded_run_with_a_ring_of_gathered_slots():
         q.close()
 
 
+def _thread_exchange(world):
+    """An all-gather for `world` virtual ranks that run as threads of this process on one GPU (the l3d_exchange_fn contract: rank r's
+    `slot_bytes` land at recv_block + r * slot_bytes on every rank): through host buffers, two barriers per call."""
+    import ctypes as C
+    import threading
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    barrier = threading.Barrier(world)
+    bufs = [None] * world
+    calls = []
+
+    def make(rank):
+        def exchange(user, view, send, recv, slot_bytes, w, stream):
+            try:
+                assert w == world
+                if hip.hipStreamSynchronize(stream):
+                    return 1
+                b = C.create_string_buffer(slot_bytes)
+                if hip.hipMemcpy(b, send, slot_bytes, 2):                    # device -> host
+                    return 2
+                bufs[rank] = b
+                barrier.wait()
+                for q in range(world):
+                    if hip.hipMemcpy(recv + q * slot_bytes, bufs[q], slot_bytes, 1):   # host -> device
+                        return 3
+                barrier.wait()
+                if rank == 0:
+                    calls.append((view, slot_bytes))
+                return 0
+            except Exception:      # noqa: BLE001  (a broken barrier etc.: fail the exchange, never hang the other ranks)
+                barrier.abort()
+                return 9
+        return exchange
+    return make, calls
+
+
+def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
+    """l3d_match_chain_blocks: the VIEWS are sharded -- every rank runs the full-width single-GPU chain on its block + a warm-up in front of it,
+    started cold; digests of the kept lists decide whether the speculation was exact (the chain's memory is a few neighbour windows:
+    scripts/speculate_blocks.py), then the ranks all-gather their blocks and build matchViews' products.  Three virtual ranks (threads, one GPU,
+    an all-gather through the host): with a long enough warm-up every rank ends up with the kept lists, products and lines of the ONE chain,
+    byte for byte -- two exchanges per pass; with a warm-up no longer than the window the verdict is "not exact" on every rank and nothing is
+    committed (the caller then takes the segment-sharded run)."""
+    import threading
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    V, S, N, W = 48, 150, 6, 3
+    scene = make_scene(V, S, N, seed=5)
+    ref = Line3D("", matchingNeighbors=N)
+    ref.keep_view_matches(True)
+    load_scene(ref, scene)
+    ref.compute3Dmodel(False)
+    lists_of = lambda l: {v["id"]: l.view_matches(v["id"]) for v in scene.views}      # noqa: E731
+    want, want_lists, want_lines = _products_digest(ref), digest_lists(lists_of(ref)), ref.getResult()
+    assert len(want_lines) > 20
+    ref.close()
+    for warmup, expect in ((-1, True), (3, False)):
+        make, calls = _thread_exchange(W)
+        ls, verdicts, errors = [], [None] * W, []
+        for r in range(W):
+            l = Line3D("", matchingNeighbors=N)
+            l.keep_view_matches(True)
+            load_scene(l, scene)
+            l.prepare()
+            ls.append(l)
+
+        def run(r):
+            try:
+                verdicts[r] = ls[r].block_run(r, W, make(r), None, warmup)
+            except Exception as e:      # noqa: BLE001
+                errors.append((r, e))
+        th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors
+        assert verdicts == [expect] * W, (warmup, verdicts)
+        if expect:
+            assert [c[0] for c in calls] == [-1, -2]                     # the digests, then the blocks: two collectives per pass
+            for r, l in enumerate(ls):
+                l.finish(False)
+                assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, "rank %d" % r
+                assert_lines_equal(l.getResult(), want_lines, 0.0)
+        else:
+            assert [c[0] for c in calls] == [-1]
+        for l in ls:
+            l.close()
+
+
 def test_product_against_the_reference_kernels_pipeline(small_scene):
     """The product against a pipeline whose kernels are the REFERENCE's own (K_collinearity, K_pairwise_matches, K_verify_matches, the diffusion
     kernels: oracle/_spliced/libkernels_spliced.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the same
