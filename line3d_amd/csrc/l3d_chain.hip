@@ -774,12 +774,68 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
         }
     }
     const double t3 = now_s();
-    const int rc = build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, n_pot);
-    if (rc) return rc;
+    // ---- matchViews' products: every rank builds the rows of its OWN block of views (sort + unique of the keys whose source lies in the block:
+    // its views' records and their neighbours', all of them in the arena now), the pieces are all-gathered and put together -- 1/world of the
+    // sort per rank instead of all of it on every rank
+    const int nvd = map->n_views;
+    auto dense_of = [&](int k) {                                   // the dense view a chain view is (ids ascend in both)
+        if (k >= n_views) return nvd;
+        const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + nvd, views[k].view_id);
+        return (int)(it - map->view_ids);
+    };
+    std::vector<int> dvb((size_t)world + 1);
+    for (int r = 0; r <= world; ++r) dvb[(size_t)r] = r == 0 ? 0 : (r == world ? nvd : dense_of(block_begin(r)));
+    for (int r = 1; r <= world; ++r) if (dvb[(size_t)r] < dvb[(size_t)r - 1]) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: the chain's views do not ascend with the dense map");
+    int64_t n_local = 0;
+    { int rc = build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, &n_local, dvb[(size_t)rank], dvb[(size_t)rank + 1]); if (rc) return rc; }
+    Products& P = c->products;
+    // counts first (a piece is padded to the largest), then [row starts of the block, numbered from 0 | entries]
+    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 512 * (size_t)(world + 1)));
+    long long* cnt_own = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>());
+    long long* cnt_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + 256);
+    const long long my_cnt = n_local;
+    HIPCHK(c, hipMemcpyAsync(cnt_own, &my_cnt, 8, hipMemcpyHostToDevice, st));
+    if (exchange(exchange_user, -3, cnt_own, cnt_all, 256, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the table sizes failed");
+    std::vector<long long> cnts((size_t)world, 0);
+    for (int r = 0; r < world; ++r) HIPCHK(c, hipMemcpyAsync(&cnts[(size_t)r], reinterpret_cast<const unsigned char*>(cnt_all) + (size_t)r * 256, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    long long max_cnt = 0, max_rows = 0, n_pot_all = 0;
+    for (int r = 0; r < world; ++r) {
+        max_cnt = std::max(max_cnt, cnts[(size_t)r]); n_pot_all += cnts[(size_t)r];
+        max_rows = std::max(max_rows, (long long)map->seg_base[dvb[(size_t)r + 1]] - map->seg_base[dvb[(size_t)r]]);
+    }
+    const size_t o_ent = al((size_t)max_rows * 8), pslot = o_ent + al((size_t)max_cnt * 4 + 4);
+    HIPCHK(c, c->ch_send.reserve(pslot + 256));
+    HIPCHK(c, c->ch_gathered.reserve(pslot * (size_t)world + 256));
+    {
+        const long long r0 = map->seg_base[dvb[(size_t)rank]], nr = (long long)map->seg_base[dvb[(size_t)rank + 1]] - r0;
+        unsigned char* sp = c->ch_send.as<unsigned char>();
+        if (nr > 0) HIPCHK(c, hipMemcpyAsync(sp, P.pot_start.as<long long>() + r0, (size_t)nr * 8, hipMemcpyDeviceToDevice, st));
+        if (n_local > 0) HIPCHK(c, hipMemcpyAsync(sp + o_ent, P.pot_tgt.p, (size_t)n_local * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (exchange(exchange_user, -4, c->ch_send.p, c->ch_gathered.p, pslot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the table pieces failed");
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, P.pot_tgt.reserve(((size_t)n_pot_all + 2) * 4));
+    {
+        const unsigned char* G = c->ch_gathered.as<unsigned char>();
+        long long base = 0;
+        for (int r = 0; r < world; ++r) {
+            const long long r0 = map->seg_base[dvb[(size_t)r]], nr = (long long)map->seg_base[dvb[(size_t)r + 1]] - r0;
+            launch_prod_shift_rows(reinterpret_cast<const long long*>(G + (size_t)r * pslot), nr, base, P.pot_start.as<long long>() + r0, st);
+            if (cnts[(size_t)r]) HIPCHK(c, hipMemcpyAsync(P.pot_tgt.as<int>() + base, G + (size_t)r * pslot + o_ent, (size_t)cnts[(size_t)r] * 4, hipMemcpyDeviceToDevice, st));
+            base += cnts[(size_t)r];
+        }
+        HIPCHK(c, hipMemcpyAsync(P.pot_start.as<long long>() + map->seg_base[nvd], &n_pot_all, 8, hipMemcpyHostToDevice, st));     // the closing row start
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+    }
+    P.n_pot = n_pot_all;
+    P.valid = true;
+    if (n_pot) *n_pot = n_pot_all;
     memcpy(c->ch_pin_res.as<ChainResult>(), hres_all.data(), (size_t)n_views * sizeof(ChainResult));       // (what l3d_chain_kept_list reads)
     c->stats[3] = (double)total;
     { double raw = 0; for (int k = own0; k < own1; ++k) raw += tab[(size_t)rank * n_views + k].R; c->stats[1] = raw; }      // (this rank's useful share)
-    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] gather of the blocks %.2f ms, products %.2f ms\n", rank, world, (t3 - t2) * 1e3, (now_s() - t3) * 1e3);
+    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] gather of the blocks %.2f ms, products (own rows + gather of the pieces) %.2f ms\n", rank, world, (t3 - t2) * 1e3, (now_s() - t3) * 1e3);
     *verdict = 0;
     return L3D_OK;
 }

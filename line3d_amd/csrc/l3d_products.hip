@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256) void k_prod_csr(const unsigned long long* __re
     if (i == 0 || prev != src) for (long long d = prev + 1; d <= src; ++d) pot_start[d] = p;
 }
 
+// a rank's piece of the table (l3d_match_chain_blocks): its row starts, numbered from 0, shifted to where its entries sit in the whole table
+__global__ __launch_bounds__(256) void k_prod_shift_rows(const long long* __restrict__ piece, long long n_rows, long long base, long long* __restrict__ pot_start)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_rows) pot_start[i] = piece[i] + base;
+}
+
 }  // namespace l3d
 
 namespace {
@@ -218,8 +225,13 @@ int bits_for(int n) { int b = 1; while ((1ll << b) <= (long long)n) ++b; return 
 
 }  // namespace
 
+void l3d::launch_prod_shift_rows(const long long* piece, long long n_rows, long long base, long long* pot_start_at, hipStream_t st)
+{
+    if (n_rows > 0) hipLaunchKernelGGL(k_prod_shift_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, piece, n_rows, base, pot_start_at);
+}
+
 int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pvh, const ChainResult* hres,
-                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out)
+                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1)
 {
     Products& P = c->products;
     P.valid = false; P.hyp_valid = false;
@@ -232,6 +244,11 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     }
     const int nd = map->seg_base[nv];
     if (nd <= 0) return fail(c, L3D_ERR_INVALID, "products: no segments");
+    // [dv0, dv1): the dense views whose rows of the table this call builds (dv1 < 0: all) -- a rank of l3d_match_chain_blocks builds the rows of
+    // its own block only, with offsets that start at 0; the pieces are all-gathered and put together by the caller
+    const bool partial = dv1 >= 0;
+    if (!partial) { dv0 = 0; dv1 = nv; }
+    if (dv0 < 0 || dv1 > nv || dv0 > dv1) return fail(c, L3D_ERR_INVALID, "products: bad view range");
     P.seg_base.assign(map->seg_base, map->seg_base + nv + 1);
     P.view_ids.assign(map->view_ids, map->view_ids + nv);
     P.res.assign(hres, hres + n_views);
@@ -311,8 +328,8 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     std::vector<long long> off_tab;                         // per block: out_off of every chain view, then of every early pair
     {
         std::vector<int> mark_v((size_t)n_views, -1), mark_s(ps.size(), -1);
-        int x = 0;
-        while (x < nv) {
+        int x = dv0;
+        while (x < dv1) {
             const int bi = (int)blocks.size();
             ProdBlock B;
             B.d0 = P.seg_base[(size_t)x]; B.slots = 0;
@@ -320,7 +337,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
             off_tab.resize(off_tab.size() + (size_t)n_views + ps.size(), -1);
             B.off_src = B.off_view + (size_t)n_views;
             int x1 = x;
-            for (; x1 < nv; ++x1) {
+            for (; x1 < dv1; ++x1) {
                 long long add = 0;
                 for (int k : touch_view[(size_t)x1]) if (mark_v[(size_t)k] != bi) add += 2 * (long long)hres[k].n_kept;
                 for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) add += 2 * (long long)hres[ps[(size_t)q].src].n_kept;
@@ -416,7 +433,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     // ---- the scalars the host needs
     int n_last = 0;
     std::vector<float> med((size_t)2 * n_views, 1.0f);
-    HIPCHK(c, hipMemcpyAsync(&n_last, P.pos.as<int>() + last_keys, 4, hipMemcpyDeviceToHost, st));
+    if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(&n_last, P.pos.as<int>() + last_keys, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(med.data(), P.median.p, (size_t)n_views * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("products: ") + hipGetErrorString(e_)); }
@@ -429,7 +446,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         s.median_depth = med[(size_t)k]; s.pad = 0;
     }
     if (n_pot_out) *n_pot_out = n_pot;
-    P.valid = true;
+    P.valid = !partial;
     return L3D_OK;
 }
 

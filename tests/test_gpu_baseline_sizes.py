@@ -258,7 +258,7 @@ def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
     """configs[2]'s 512 views x 2000 segments x 12 neighbours with the VIEWS sharded over 8 ranks in blocks of 64 (l3d_match_chain_blocks: every rank
     the full-width single-GPU chain on its block + 36 warm-up views started cold, the speculation verified with digests of the kept lists, the blocks
     all-gathered): eight virtual ranks as threads on the one GPU, an all-gather through the host.  Every rank must report an exact speculation and hold
-    the ONE chain's kept lists (rank 0 and rank 5 are compared view by view with the unsharded run) -- two collectives for the whole pass."""
+    the ONE chain's kept lists (rank 0 and rank 5 are compared view by view with the unsharded run) -- four collectives for the whole pass."""
     import threading
     from line3d_amd.pipeline import Line3D, load_scene
     from line3d_amd.synth import make_scene
@@ -289,7 +289,7 @@ def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
         x.join()
     assert not errors, errors
     assert verdicts == [True] * W, verdicts
-    assert [c[0] for c in calls] == [-1, -2]
+    assert [c[0] for c in calls] == [-1, -2, -3, -4]
     for r in (0, 5):
         assert digest_lists({v["id"]: ls[r].view_matches(v["id"]) for v in scene.views}) == want, "rank %d" % r
     for l in ls:

@@ -935,7 +935,7 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
     started cold; digests of the kept lists decide whether the speculation was exact (the chain's memory is a few neighbour windows:
     scripts/speculate_blocks.py), then the ranks all-gather their blocks and build matchViews' products.  Three virtual ranks (threads, one GPU,
     an all-gather through the host): with a long enough warm-up every rank ends up with the kept lists, products and lines of the ONE chain,
-    byte for byte -- two exchanges per pass; with a warm-up no longer than the window the verdict is "not exact" on every rank and nothing is
+    byte for byte -- four exchanges per pass (digests, blocks, sizes and pieces of the table); with a warm-up no longer than the window the verdict is "not exact" on every rank and nothing is
     committed (the caller then takes the segment-sharded run)."""
     import threading
     from line3d_amd.pipeline import Line3D, load_scene
@@ -973,7 +973,7 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
         assert not errors, errors
         assert verdicts == [expect] * W, (warmup, verdicts)
         if expect:
-            assert [c[0] for c in calls] == [-1, -2]                     # the digests, then the blocks: two collectives per pass
+            assert [c[0] for c in calls] == [-1, -2, -3, -4]             # digests, blocks, table sizes, table pieces: four collectives per pass
             for r, l in enumerate(ls):
                 l.finish(False)
                 assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, "rank %d" % r
