@@ -230,8 +230,8 @@ def main():
     # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
     # nobody is left waiting in a collective)
     MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 8 neighbour windows in front of it, started cold; "
-             "the speculation verified with digests of the kept lists (one all-gather), the blocks all-gathered (one more), matchViews' products built on every rank "
-             "-- no per-view collective; a scene on which the verification fails falls through to the next mode",
+             "the speculation verified with digests of the kept lists (one all-gather), the blocks all-gathered (one more), every rank builds its own block's rows of "
+             "matchViews' products and the pieces are all-gathered -- no per-view collective; a scene on which the verification fails falls through to the next mode",
              "native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream, "
              "matchViews' products built on every rank's device from the gathered slots (no host bookkeeping)",
              "resident chain, source segments sharded, all-gather of per-view kept slots through torch.distributed on the library's stream",

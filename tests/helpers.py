@@ -157,3 +157,43 @@ def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None, refere
     for t in th:
         t.join()
     return np.concatenate(parts), mv, existing
+
+
+# ---- an all-gather for virtual ranks that run as threads of one process on one GPU (block mode tests, scripts/soak_blocks.py) --------------
+def thread_exchange(world):
+    """An all-gather for `world` virtual ranks that run as threads of this process on one GPU (the l3d_exchange_fn contract: rank r's
+    `slot_bytes` land at recv_block + r * slot_bytes on every rank): through host buffers, two barriers per call."""
+    import ctypes as C
+    import threading
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    barrier = threading.Barrier(world)
+    bufs = [None] * world
+    calls = []
+
+    def make(rank):
+        def exchange(user, view, send, recv, slot_bytes, w, stream):
+            try:
+                assert w == world
+                if hip.hipStreamSynchronize(stream):
+                    return 1
+                b = C.create_string_buffer(slot_bytes)
+                if hip.hipMemcpy(b, send, slot_bytes, 2):                    # device -> host
+                    return 2
+                bufs[rank] = b
+                barrier.wait()
+                for q in range(world):
+                    if hip.hipMemcpy(recv + q * slot_bytes, bufs[q], slot_bytes, 1):   # host -> device
+                        return 3
+                barrier.wait()
+                if rank == 0:
+                    calls.append((view, slot_bytes))
+                return 0
+            except Exception:      # noqa: BLE001  (a broken barrier etc.: fail the exchange, never hang the other ranks)
+                barrier.abort()
+                return 9
+        return exchange
+    return make, calls
+
+

@@ -262,7 +262,7 @@ def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
     import threading
     from line3d_amd.pipeline import Line3D, load_scene
     from line3d_amd.synth import make_scene
-    from test_gpu_pipeline_parity import _thread_exchange
+    from helpers import thread_exchange as _thread_exchange
     V, S, N, W = 512, 2000, 12, 8
     scene = make_scene(V, S, N, seed=20260)
     ref, ref_lists = _run(scene, N)
