@@ -676,7 +676,11 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     const int first = rank == 0 ? 0 : std::max(0, own0 - warmup_views);
     const double t0 = now_s();
     // ---- this rank's chain: its block and the warm-up views in front of it, started cold
-    { int rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, own1); if (rc) return rc; }
+    // (a rank whose chain fails must not leave the others waiting in the first collective: it still publishes its table, with a mark that
+    // every rank reads -- they all return an error then, without entering another collective)
+    const int chain_rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, own1);
+    std::string chain_err;
+    if (chain_rc) { std::lock_guard<std::mutex> lk(c->err_mu); chain_err = c->err; }
     const ChainResult* hres = c->ch_pin_res.as<ChainResult>();
     const double t1 = now_s();
     // useful work of this rank = its own block (the warm-up is the price of the speculation)
@@ -692,7 +696,11 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     BlockDigest* dtab_own = c->ch_hdr.as<BlockDigest>();
     BlockDigest* dtab_all = reinterpret_cast<BlockDigest*>(c->ch_hdr.as<unsigned char>() + tab_bytes);
     HIPCHK(c, hipMemsetAsync(dtab_own, 0, tab_bytes, st));
-    if (own1 > first) {
+    if (chain_rc) {
+        BlockDigest mark; mark.hash = ~0ull; mark.n_kept = -1; mark.R = chain_rc;
+        (void)hipMemcpyAsync(dtab_own, &mark, sizeof(mark), hipMemcpyHostToDevice, st);
+        (void)hipStreamSynchronize(st);
+    } else if (own1 > first) {
         HIPCHK(c, hipMemcpyAsync(c->ch_res.p, hres, (size_t)n_views * sizeof(ChainResult), hipMemcpyHostToDevice, st));     // (the final records: a restart rewrites them)
         hipLaunchKernelGGL(k_block_digest, dim3(16, own1 - first), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), first, dtab_own);
     }
@@ -702,6 +710,10 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
         HIPCHK(c, hipMemcpyAsync(tab.data() + (size_t)r * n_views, reinterpret_cast<const unsigned char*>(dtab_all) + (size_t)r * tab_bytes, (size_t)n_views * sizeof(BlockDigest), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     const double t2 = now_s();
+    if (chain_rc) return fail(c, chain_rc, "l3d_match_chain_blocks: this rank's chain failed: " + chain_err);
+    for (int r = 0; r < world; ++r)
+        if (tab[(size_t)r * n_views].n_kept == -1 && tab[(size_t)r * n_views].hash == ~0ull)
+            return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the chain of rank " + std::to_string(r) + " failed (code " + std::to_string(tab[(size_t)r * n_views].R) + ")");
     // ---- the verdict (the same on every rank: same table)
     bool ok = true;
     for (int r = 1; r < world && ok; ++r) {
