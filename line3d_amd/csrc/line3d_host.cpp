@@ -766,7 +766,8 @@ int prepare(L* h)
         // Nobody waits for the code objects here: they load in the background since the object was created (l3d_warm_up), the modules this
         // function and matchViews launch from first
         int reserve_rc = L3D_OK;
-        std::thread warm([h, nd_all, nv_all, nn, &reserve_rc]() { reserve_rc = l3d_reserve_hint(h->ctx, nd_all, nv_all, nn); });
+        double t_reserve = 0;
+        std::thread warm([h, nd_all, nv_all, nn, &reserve_rc, &t_reserve]() { const double a0 = now_s(); reserve_rc = l3d_reserve_hint(h->ctx, nd_all, nv_all, nn); t_reserve = now_s() - a0; });
         std::atomic<size_t> next{ 0 };
         l3d::on_threads((unsigned)std::max<size_t>(1, std::min<size_t>(l3d::host_threads(), h->vlist.size())), [&](unsigned) {
             for (;;) {
@@ -784,7 +785,9 @@ int prepare(L* h)
         std::vector<int> cnts;
         for (View* v : h->vlist) { arrs.push_back(v->segs.data()); cnts.push_back(v->S()); arrs.push_back(v->nb_segs.data()); cnts.push_back((int)(v->nb_segs.size() / 4)); }
         rc = l3d_register_segments_batch(h->ctx, arrs.data(), cnts.data(), (int)arrs.size());
+        const double t_join0 = now_s();
         warm.join();
+        if (timing) fprintf(stderr, "[l3d prepare]   (arenas of the finishing stages reserved in %.2f ms on their own thread; waited %.2f ms for it)\n", t_reserve * 1e3, (now_s() - t_join0) * 1e3);
         if (reserve_rc && (h->verbose || timing)) fprintf(stderr, "[l3d prepare] reserving the finishing stages' arenas ahead failed (%d): they are allocated when first needed\n", reserve_rc);
         if (rc) return h->fail(rc, std::string("register_segments: ") + l3d_last_error(h->ctx));
     }
