@@ -57,7 +57,7 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     c->opt = options_from_env();                  // the one place the environment is read
     publish_tunables(c->opt);
     c->chain_ring = c->opt.chain_ring != 0;
-    c->wedge_pretest = c->opt.pretest & 3;         // diagnostic: stage-1 filter mask
+    c->wedge_pretest = c->opt.pretest & 7;         // diagnostic: stage-1 filter mask
     {   // L3D_STREAM_PRIO=1: the chain's stream (per-view critical path) at the highest priority.  Measured on config 2: no
         // difference to plain streams (21.5 ms either way), so plain streams are the default.
         int least = 0, greatest = 0;
@@ -85,7 +85,7 @@ int l3d_set_option(l3d_ctx* c, const char* name, int value)
     *f = value;
     publish_tunables(c->opt);
     c->chain_ring = c->opt.chain_ring != 0;
-    c->wedge_pretest = c->opt.pretest & 3;
+    c->wedge_pretest = c->opt.pretest & 7;
     return L3D_OK;
 }
 
@@ -138,6 +138,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     c->ch_pin_tables.release(); c->ch_pin_res.release(); c->ch_pin_kept.release(); c->ch_pin_best.release(); c->pin_arena.release();
     for (auto& kv : c->resident) if (!c->resident_arena_of.count(kv.first)) (void)hipFree(kv.second.first);
     for (auto& a : c->resident_arenas) if (a.first) (void)hipFree(a.first);
+    if (c->mask_stream) (void)hipStreamDestroy(c->mask_stream);
     (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
@@ -213,7 +214,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
 
 int l3d_set_chain_capacities(l3d_ctx* c, size_t cand_cap, size_t arena_cap) { if (!c) return L3D_ERR_INVALID; c->test_cand_cap = cand_cap; c->test_arena_cap = arena_cap; return L3D_OK; }
 int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes); return L3D_OK; }
-int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 3) return L3D_ERR_INVALID; c->wedge_pretest = mask; return L3D_OK; }
+int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 7) return L3D_ERR_INVALID; c->wedge_pretest = mask; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
 int l3d_profile_only(l3d_ctx* c, const char* kernel) { if (!c) return L3D_ERR_INVALID; c->prof_only = kernel ? kernel : ""; return L3D_OK; }

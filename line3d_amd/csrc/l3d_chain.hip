@@ -247,6 +247,12 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     hipStream_t s1 = c->stage1_stream;  // stage 1 runs ahead here, concurrently with the latency-bound kernels of phase 2
     const bool serial = c->opt.chain_serial != 0;   // diagnostic: one stream, kernels one at a time (isolated durations)
     if (serial) s1 = st;
+    // option mask_stream: k_pair_mask of view k+1 next to k_pair_fill of view k instead of behind it
+    hipStream_t sm = s1;
+    if (c->opt.mask_stream && !serial) {
+        if (!c->mask_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->mask_stream, hipStreamNonBlocking));
+        sm = c->mask_stream;
+    }
     (void)hipGetLastError();            // errors of earlier, already reported calls are not ours
 
     // ---- validation, table layout and upload, per-view slices of the whole-run arenas (l3d_chain_common.hip: shared with the sharded chain)
@@ -281,6 +287,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         hipEvent_t ready = get_event(c);
         HIPCHK(c, hipEventRecord(ready, st));
         HIPCHK(c, hipStreamWaitEvent(s1, ready, 0));
+        if (sm != s1) HIPCHK(c, hipStreamWaitEvent(sm, ready, 0));
         c->event_pool.push_back(ready);
     }
     // per-view results are written by the kernels straight into host-mapped pinned memory (no copy operations on the streams)
@@ -304,7 +311,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     // ---- phase 1 (stage 1 of a view: pair test -> bit rows -> row counts -> statistics) is independent of the
     // chain; it is enqueued a window ahead of phase 2 so that the GPU always has work while the host trails behind
     const double pairs = L.pairs, max_pairs = L.max_pairs;
-    std::vector<hipEvent_t> ev1((size_t)n_views, nullptr);
+    std::vector<hipEvent_t> ev1((size_t)n_views, nullptr), evm((size_t)n_views, nullptr);
     int k_p1 = 0;                       // next view whose stage 1 is enqueued
     c->stats[0] = pairs;
     double raw_sum = 0;
@@ -364,8 +371,14 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 PairArgs pm = pa;
                 pm.rowcnt = fused_rows ? vd[(size_t)k].rowub : vd[(size_t)k].rowcnt;
                 if (fused_rows) pm.rowblk = vd[(size_t)k].rowblk;
-                ProfScope p(c, "pair_mask", s1);
-                launch_pair_mask(pm, vd[(size_t)k].maxW, s1);
+                // (own stream: the bit rows' ring slot was last used by view k - kRing, whose chain may still re-form its candidates from them)
+                if (sm != s1) for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(sm, ev[(size_t)j], 0)); break; }
+                { ProfScope p(c, "pair_mask", sm); launch_pair_mask(pm, vd[(size_t)k].maxW, sm); }
+                if (sm != s1) {
+                    if (!evm[(size_t)k]) evm[(size_t)k] = get_event(c);
+                    HIPCHK(c, hipEventRecord(evm[(size_t)k], sm));
+                    HIPCHK(c, hipStreamWaitEvent(s1, evm[(size_t)k], 0));
+                }
             }
             // row starts of the stage-1 candidates + their statistics straight into host-mapped memory (one launch)
             if (fused_rows) {}
@@ -531,7 +544,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         if (r.overflow) {
             // not enough room for this view's candidates / kept matches: everything before it is valid and stays
             // in the arena; wait for the queue (and the delivery of earlier views) to drain, grow, and re-enqueue from this view
-            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(s1), "hipStreamSynchronize")) break;
+            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(sm), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(s1), "hipStreamSynchronize")) break;
             wait_delivered();
             if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
             if (r.overflow & 2) {
@@ -596,10 +609,12 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
                 (t_loop0 - t_setup0) * 1e3, (t_prod0 - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
     if (c->opt.timing && map) fprintf(stderr, "[l3d match_chain] products on the device %.2f ms\n", (now_s() - t_prod0) * 1e3);
+    if (sm != s1) (void)hipStreamSynchronize(sm);
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
+    for (hipEvent_t e : evm) if (e) c->event_pool.push_back(e);
     c->stats[1] = raw_sum;
     c->stats[3] = kept_total;
     if (rc_final == L3D_OK && !c->test_cand_cap && !c->test_arena_cap) {

@@ -118,6 +118,7 @@ struct l3d_ctx {
     l3d::Options opt;                        // every L3D_* switch: the environment read once by l3d_ctx_create, then l3d_set_option
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // bulk D2H of the resident chain, concurrent with kernels
+    hipStream_t mask_stream = nullptr;       // option mask_stream: k_pair_mask alone, ahead of the rest of stage 1 (created on first use)
     hipStream_t stage1_stream = nullptr;     // stage 1 of the resident chain (independent of the chain state) runs ahead here
     std::string err;                         // written under err_mu: the chains report from several host threads
     std::mutex err_mu;
@@ -141,7 +142,7 @@ struct l3d_ctx {
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0;   // what the last chain over this scene needed
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
-    int wedge_pretest = 3;          // stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing)
+    int wedge_pretest = 3;          // stage-1 filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing), bit 2 SET: level 2 does not accept
     int verify_mode = 0;            // 0: depth-window search (all-pairs kernel only beyond ~50 neighbours), 1: all-pairs
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
@@ -211,6 +212,7 @@ inline void prof_resolve(l3d_ctx* c)
 {
     (void)hipStreamSynchronize(c->stream);
     if (c->stage1_stream) (void)hipStreamSynchronize(c->stage1_stream);
+    if (c->mask_stream) (void)hipStreamSynchronize(c->mask_stream);
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {
             float ms = 0.f;

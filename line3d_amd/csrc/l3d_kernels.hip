@@ -111,20 +111,28 @@ __device__ __forceinline__ v2f pk_line(f3 l, v2f x, v2f y)
     return __builtin_elementwise_fma(lx, x, __builtin_elementwise_fma(ly, y, lz));
 }
 __device__ __forceinline__ float fline(f3 l, float x, float y) { return __builtin_fmaf(l.x, x, __builtin_fmaf(l.y, y, l.z)); }
-// Upper bound of D_segment_overlap_2D(segment [0,1] of length len, intersection points at parameters t1, t2) where
-// ti = ai/(ai - bi) and ri = 1/(ai - bi); ext_over_len = (largest coordinate)/len.  2.0f = "cannot tell".
-__device__ __forceinline__ float iou_upper(float t1, float r1, float t2, float r2, float len, float ext_over_len)
+// Bounds of D_segment_overlap_2D(segment [0,1] of length len, intersection points at parameters t1, t2) where
+// ti = ai/(ai - bi) and ri = 1/(ai - bi); ext_over_len = (largest coordinate)/len.  For collinear points the reference's case
+// analysis (:209-251) is the 1-D intersection over union of the two intervals; the float intersection points it works on lie within
+// e of t1, t2.  upper: 2.0f = "cannot tell"; lower: -1.0f = "cannot tell" (ill-conditioned, or the intersection pair is not SURELY
+// a pixel long, :211).
+struct IouBounds { float upper, lower; };
+__device__ __forceinline__ IouBounds iou_bounds(float t1, float r1, float t2, float r2, float len, float ext_over_len)
 {
     const float e1 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t1)), __builtin_fabsf(r1), 1.0e-6f * (ext_over_len + __builtin_fabsf(t1)));
     const float e2 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t2)), __builtin_fabsf(r2), 1.0e-6f * (ext_over_len + __builtin_fabsf(t2)));
     const float e = __builtin_fmaxf(e1, e2);
-    if (!(e < 10.0f)) return 2.0f;                                       // ill-conditioned, infinite or NaN
+    if (!(e < 10.0f)) return { 2.0f, -1.0f };                             // ill-conditioned, infinite or NaN
     const float lo = __builtin_fminf(t1, t2), hi = __builtin_fmaxf(t1, t2);
-    if ((hi - lo + 2.0f * e) * len < 1.0f - kIouSlack) return 0.0f;      // the intersection pair is shorter than a pixel (:211)
-    const float inter = __builtin_fminf(hi, 1.0f) - __builtin_fmaxf(lo, 0.0f) + 2.0f * e;
-    const float uni = __builtin_fmaxf(hi, 1.0f) - __builtin_fminf(lo, 0.0f) - 2.0f * e;
-    if (!(uni > 0.0f)) return 2.0f;
-    return inter * __builtin_amdgcn_rcpf(uni) * (1.0f + 1.0e-5f);
+    if ((hi - lo + 2.0f * e) * len < 1.0f - kIouSlack) return { 0.0f, -1.0f };   // the intersection pair is shorter than a pixel (:211)
+    const float in0 = __builtin_fminf(hi, 1.0f) - __builtin_fmaxf(lo, 0.0f), un0 = __builtin_fmaxf(hi, 1.0f) - __builtin_fminf(lo, 0.0f);
+    const float uni_lo = un0 - 2.0f * e;
+    IouBounds b;
+    b.upper = uni_lo > 0.0f ? (in0 + 2.0f * e) * __builtin_amdgcn_rcpf(uni_lo) * (1.0f + 1.0e-5f) : 2.0f;
+    // the lower bound only where the pair is well conditioned (e < 0.1) and the pair of intersection points surely at least a pixel long
+    const bool sure = e < 0.1f && (hi - lo - 2.0f * e) * len > 1.0f + kIouSlack && in0 - 2.0f * e > 0.0f;
+    b.lower = sure ? (in0 - 2.0f * e) * __builtin_amdgcn_rcpf(un0 + 2.0f * e) * (1.0f - 1.0e-5f) : -1.0f;
+    return b;
 }
 
 #ifndef L3D_PM_WAVES
@@ -265,6 +273,9 @@ void k_pair_mask(PairArgs a)
     int ha = 0, ca = 0, hb = 0, cb = 0;            // wave-uniform ring states
     int n_l1 = 0, n_l2 = 0;                        // diagnostic counters
     const bool use_wedge = (a.wedge_pretest & 1) != 0, use_iou = (a.wedge_pretest & 2) != 0;
+    // level 2 also ACCEPTS (bit set, no exact test) where the lower bounds of both ratios clear the thresholds: the exact test's only product
+    // here is the bit (the depths and their sign test are k_pair_fill's).  Off with bit 2 of the switch (A/B: identical bit rows, tests/)
+    const bool use_accept = !kDepth && use_iou && (a.wedge_pretest & 4) == 0;
 
     // One extra iteration (k == ny) flushes the rings.  Each level's body appears exactly once (a single loop drains
     // whichever ring is due), so nothing is outlined and no state lives in scratch.
@@ -339,10 +350,14 @@ void k_pair_mask(PairArgs a)
                     const float rb1 = __builtin_amdgcn_rcpf(b1 - b2), rb2 = __builtin_amdgcn_rcpf(b3 - b4);
                     const float ra1 = __builtin_amdgcn_rcpf(a1 - a2), ra2 = __builtin_amdgcn_rcpf(a3 - a4);
                     const float ls = sb.s.len, lt = tb.t.len;
-                    const float u1 = iou_upper(b1 * rb1, rb1, b3 * rb2, rb2, ls, ext * __builtin_amdgcn_rcpf(ls));
-                    const float u2 = iou_upper(a1 * ra1, ra1, a3 * ra2, ra2, lt, ext * __builtin_amdgcn_rcpf(lt));
-                    const bool rej = __builtin_fmaxf(u1, u2) < kMinOverlapUpper - kIouSlack || __builtin_fminf(u1, u2) < kMinOverlapLower - kIouSlack;
-                    pass = !rej;
+                    const IouBounds o1 = iou_bounds(b1 * rb1, rb1, b3 * rb2, rb2, ls, ext * __builtin_amdgcn_rcpf(ls));
+                    const IouBounds o2 = iou_bounds(a1 * ra1, ra1, a3 * ra2, ra2, lt, ext * __builtin_amdgcn_rcpf(lt));
+                    const bool rej = __builtin_fmaxf(o1.upper, o2.upper) < kMinOverlapUpper - kIouSlack || __builtin_fminf(o1.upper, o2.upper) < kMinOverlapLower - kIouSlack;
+                    // (segment lengths of at least a pixel: the reference's first exit, :211, on the exact invariants)
+                    const bool acc = use_accept && ls >= 1.0f && lt >= 1.0f && __builtin_fminf(o1.lower, o2.lower) > kMinOverlapLower + kIouSlack &&
+                                     __builtin_fmaxf(o1.lower, o2.lower) > kMinOverlapUpper + kIouSlack;
+                    if (acc) atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
+                    pass = !rej && !acc;
                 }
                 const unsigned long long pm = __ballot(pass);
                 if (pm) {
