@@ -104,19 +104,21 @@ void l3d_ctx_destroy(l3d_ctx* c)
 {
     if (!c) return;
     if (c->stamps.p) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, c->stamps.p, 64, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, c->stamps.p, 128, hipMemcpyDeviceToHost);
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
         fprintf(stderr, "[l3d verify_window wave-cycles] build %.1f%%  setup %.1f%%  scan %.1f%%  drain %.1f%%  final %.1f%%  (waves %llu, avg %.0f cycles)\n",
                 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, h[5], tot / (double)(h[5] ? h[5] : 1));
+        fprintf(stderr, "[l3d verify_window pairs] evaluated %llu  pass the 3-D gate %.1f%%  confidence > 0 %.1f%%  confidence > 0.5 %.1f%%\n", h[6], 100.0 * h[7] / (double)(h[6] ? h[6] : 1),
+                100.0 * h[8] / (double)(h[6] ? h[6] : 1), 100.0 * h[9] / (double)(h[6] ? h[6] : 1));
     }
     if (c->pair_dbg) {
-        unsigned long long h[4];
+        unsigned long long h[8];
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, c->pair_dbg, 32, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after overlap-bound test %.3f%%  candidates %.3f%%\n", h[0], 100.0 * h[1] / (double)h[0],
-                100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0]);
+        (void)hipMemcpy(h, c->pair_dbg, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after overlap-bound test %.3f%%  candidates %.3f%%  (sector test off: source side %.2f%%, target side %.2f%% of the pairs)\n",
+                h[0], 100.0 * h[1] / (double)h[0], 100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0], 100.0 * h[4] / (double)h[0], 100.0 * h[5] / (double)h[0]);
         (void)hipFree(c->pair_dbg);
     }
     if (c->opt.timing)
@@ -491,7 +493,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.debug = c->opt.vw_debug;
     va.stamps = nullptr;
     if (c->opt.vw_stamps) {
-        if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(64)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 64, st)); }
+        if (!c->stamps.p) { HIPCHK(c, c->stamps.reserve(128)); HIPCHK(c, hipMemsetAsync(c->stamps.p, 0, 128, st)); }
         va.stamps = c->stamps.as<unsigned long long>();
     }
     if (c->verify_mode == 0 && verify_window_supported(N)) {

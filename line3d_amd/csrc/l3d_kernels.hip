@@ -244,6 +244,7 @@ void k_pair_mask(PairArgs a)
         const float lo = ed.z + __builtin_fminf(ed.x * box[0], ed.x * box[1]) + __builtin_fminf(ed.y * box[2], ed.y * box[3]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[0], ed.x * box[1]) + __builtin_fmaxf(ed.y * box[2], ed.y * box[3]);
         const bool dsafe = lo > md || hi < -md;                // (NaN/inf: comparisons fail -> not safe)
+        if (a.dbg && !dsafe) atomicAdd(&a.dbg[4], 256ull);    // (diagnostic: pairs whose source-side sector test is off)
         const f3 e1w = dsafe ? e1s : mk3(0.0f, 0.0f, 0.0f), e2w = dsafe ? e2s : mk3(0.0f, 0.0f, 0.0f);
         SrcLevel1 l1;
         l1.e1x = e1w.x; l1.e1y = e1w.y; l1.e1z = e1w.z; l1.p1x = si.p1.x;
@@ -262,7 +263,10 @@ void k_pair_mask(PairArgs a)
         const float md = mq1 + mq2;
         const float lo = ed.z + __builtin_fminf(ed.x * box[4], ed.x * box[5]) + __builtin_fminf(ed.y * box[6], ed.y * box[7]);
         const float hi = ed.z + __builtin_fmaxf(ed.x * box[4], ed.x * box[5]) + __builtin_fmaxf(ed.y * box[6], ed.y * box[7]);
-        if (!(lo > md || hi < -md)) { eq1s = mk3(0.0f, 0.0f, 0.0f); eq2s = mk3(0.0f, 0.0f, 0.0f); }   // this target's sector test is off
+        if (!(lo > md || hi < -md)) {                                                                   // this target's sector test is off
+            eq1s = mk3(0.0f, 0.0f, 0.0f); eq2s = mk3(0.0f, 0.0f, 0.0f);
+            if (a.dbg && valid) atomicAdd(&a.dbg[5], (unsigned long long)ny);
+        }
     }
     const float ext = __builtin_fmaxf(__builtin_fmaxf(ext0, ext1), __builtin_fmaxf(ext2, ext3));
     __syncthreads();

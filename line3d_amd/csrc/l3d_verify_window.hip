@@ -57,7 +57,7 @@ struct VWLds {
 // per-camera maximum goes to LDS with an integer atomic max (confidences are positive floats).
 __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, const int* sOff, const unsigned* q, int head, int n, int lane,
                                          f3 C, f3 ray1, f3 ray2, float d1y, float d2y, bool gate,
-                                         float* smax_wave, float two_sig_d, float two_sig_a)
+                                         float* smax_wave, int* dirty, float two_sig_d, float two_sig_a)
 {
     // a ring entry carries everything the witness contributes (camera, target id, both depths): the only global access of
     // the evaluation is the gather of the target segment, issued straight after the ring read.  The hypothesis is rebuilt here
@@ -83,8 +83,18 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
         hT2 = sq_threshold(a.spatial_k * length(C - hX2));
     }
     const float conf = witness_conf(C, ray1, ray2, hX1, hX2, hv, hT1, hT2, gate, wd1, wd2, sP + cam * 12, tq, two_sig_d, two_sig_a);
-    if (conf > 0.5f)                                                     // :699-704 (max over the camera's witnesses)
+    if (a.stamps) {                                                      // diagnostic: how far the drained pairs get
+        const f3 Q1 = C + wd1 * ray1, Q2 = C + wd2 * ray2;
+        const f3 e1 = hX1 - Q1, e2 = hX2 - Q2;
+        const bool g = !gate || !(dot(e1, e1) > hT1 || dot(e2, e2) > hT2);
+        const unsigned long long m0 = __ballot(true), m1 = __ballot(g), m2 = __ballot(conf > 0.0f), m3 = __ballot(conf > 0.5f);
+        if (lane == 0) { atomicAdd(&a.stamps[6], (unsigned long long)__popcll(m0)); atomicAdd(&a.stamps[7], (unsigned long long)__popcll(m1));
+                         atomicAdd(&a.stamps[8], (unsigned long long)__popcll(m2)); atomicAdd(&a.stamps[9], (unsigned long long)__popcll(m3)); }
+    }
+    if (conf > 0.5f) {                                                   // :699-704 (max over the camera's witnesses)
         atomicMax(reinterpret_cast<int*>(&smax_wave[cam * 64 + origin]), __float_as_int(conf));
+        *dirty = 1;                                                      // (this wave's maxima are no longer all zero)
+    }
 }
 
 // NT threads per workgroup: 256 when the grid fills the chip, 512 when only a few segments are verified per launch
@@ -105,6 +115,7 @@ void k_verify_window(VerifyArgs a)
     __shared__ int s_bstart[kBuckets + 1];
     __shared__ int s_cursor[kBuckets];
     __shared__ int s_wtot[NW];
+    __shared__ int s_dirty[NW];              // per wave: a confidence was recorded in the current group of hypotheses
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // big == false: segments whose candidates fit the LDS image (m <= mmax); big == true: the rest, same algorithm with the
     // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop.
@@ -163,6 +174,11 @@ void k_verify_window(VerifyArgs a)
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
     float* smax_wave = smax + wave * 64 * a.N;
+    // the per-(camera, lane) maxima are zero whenever a group of hypotheses starts: zeroed here once, and again only after a group that recorded
+    // something (most groups record nothing: a fifth of the hypotheses has a witness at all, and those cluster on few segments)
+    for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;       // [camera][lane]: conflict-free rows
+    if (lane == 0) s_dirty[wave] = 0;
+    int* dirty = &s_dirty[wave];
 
     // ---- one coalesced pass over the segment's candidates (kept in registers), counting sort on the depth bucket
     constexpr int kMaxPerThread = 2048 / NT;                             // m <= 2048 in registers, more is re-read
@@ -271,7 +287,6 @@ void k_verify_window(VerifyArgs a)
                 w1 = w2 = __builtin_inff();
             }
         }
-        for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;        // [camera][lane]: conflict-free rows
         int head = 0, count = 0;                                       // wave-uniform ring state
         const float lo1 = d1y - w1, hi1 = d1y + w1;
         int j = 0, jend = 0;
@@ -309,7 +324,7 @@ void k_verify_window(VerifyArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                     if (count >= 64) {
                         VW_STAMP(2);
-                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, two_sig_d, two_sig_a);
+                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
                         head = (head + 64) & (kVQ - 1);
                         count -= 64;
                         VW_STAMP(3);
@@ -321,11 +336,15 @@ void k_verify_window(VerifyArgs a)
             for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; ct[g] = nt[g]; }
         }
         VW_STAMP(2);
-        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, two_sig_d, two_sig_a);
+        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         VW_STAMP(3);
         float conf_sum = 0.0f;
-        for (int c = 0; c < a.N; ++c) conf_sum += smax_wave[c * 64 + lane];   // ascending camera order; +0.0f is exact
+        if (__builtin_amdgcn_readfirstlane(*dirty)) {
+            for (int c = 0; c < a.N; ++c) { conf_sum += smax_wave[c * 64 + lane]; smax_wave[c * 64 + lane] = 0.0f; }   // ascending camera order; +0.0f is exact
+            if (lane == 0) *dirty = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
         if (hv) {
             a.cand_conf[start + idx_h] = conf_sum;
             kept_l += conf_sum > 1.0f;
