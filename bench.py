@@ -355,9 +355,10 @@ def main():
         # profiles/r4_stalls.json carries the weighted figure (`valu_pipe_frac_trans_weighted`).
         PEAK_ISSUE = 256 * 4 * 2.4e9 / 2.0
 
-        def kernel_roof(name, launches, ms):
-            # algorithmic HBM bytes per launch: one launch = one view
-            nv = max(1, len(scene.views))
+        def kernel_roof(name, launches, ms, passes):
+            # algorithmic HBM bytes per launch: one launch = one view.  The views this rank launched per pass: all of the
+            # scene on one GPU, its block + warm-up in the block mode (then `raw` counts those views, `pairs` its own block: approximate per launch)
+            nv = max(1, int(round(launches / max(1, passes)))) if launches else max(1, len(scene.views))
             R_per_launch = raw_local / nv
             pairs_per_launch = pairs_local / nv
             n_tbm = args.neighbors / 2.0
@@ -397,7 +398,7 @@ def main():
 
         if prof:
             name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1])
-            roof = kernel_roof(name, launches, ms)
+            roof = kernel_roof(name, launches, ms, args.steps)
             roof["kernels_ms"] = {k: round(v[1], 3) for k, v in prof_all.items()}
             roof["kernels_note"] = ("kernels_ms = per-kernel time of one untimed pass with every kernel bracketed (two streams: the times overlap); in the timed "
                                     "region only the dominant kernel carries HIP events")
@@ -420,7 +421,7 @@ def main():
             others = sorted(((k, v) for k, v in prof_all.items() if k != name), key=lambda kv: -kv[1][1])
             if others:
                 k2, (l2, m2) = others[0]
-                roof["runner_up"] = kernel_roof(k2, l2, m2)
+                roof["runner_up"] = kernel_roof(k2, l2, m2, 1)
                 roof["runner_up"]["note"] = "second kernel by time, from the untimed pass with every kernel bracketed"
         out = dict(metric="segment-pair affinities/s", value=value, unit="segment-pair affinities/s", n_gpus=n_gpus,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",

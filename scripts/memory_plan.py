@@ -21,7 +21,7 @@ def plan(V, S, N, W, kept_ratio, rho=0.065):
     W64 = 4 * ((S + 255) // 256)
     rows = []
     add = lambda name, b, where: rows.append((name, b, where))
-    add("segments + neighbour tiles, resident (every rank holds the scene)", V * (S + n_tgt) * 16, "line3d_host.cpp:prepare -> l3d_register_segments_batch")
+    add("segments + neighbour tiles, resident (every rank holds the scene)", V * (S + n_tgt) * 16, "line3d_host_views.cpp:prepare -> l3d_register_segments_batch")
     add("camera tables of all views", V * (N * 144 + 48 + n_tbm * 4 + window * 8), "l3d_chain_common.hip:chain_plan_views")
     add("viewing rays of every target / own end point", V * (n_tgt + S) * 32, "l3d_chain_common.hip:chain_upload_tables (k_tgt_rays)")
     add("bit rows: ring of 10 views (was one slice per view: %.1f GB)" % (V * n_tbm * S * W64 * 8 / GB), 10 * n_tbm * S * W64 * 8, "l3d_chain_common.hip:chain_assign_arenas (mask_ring)")
