@@ -362,8 +362,10 @@ long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
  * their blocks (view = -2) and THIS context now holds matchViews' products exactly as after l3d_match_chain_resident over all views
  * (arena, potential correspondences, best matches, medians; summary / n_pot as there).  *verdict = 1: the speculation did not hold (or
  * warmup_views < window, or a block is shorter than the window): nothing was committed, run l3d_shard_chain_run instead.
- * No per-view collective: four exchanges per pass (digests; blocks; view = -3 / -4 the sizes and the pieces of the products table, of which
- * every rank builds the rows of its own block).  window = the largest distance between a view and one of its sources. */
+ * No per-view collective: four data exchanges per pass (digests; blocks; view = -4 the pieces of the products table, of which every rank
+ * builds the rows of its own block) and three 256-byte ones of status words (view = -3; the second carries the sizes of the pieces): every step
+ * only one rank can fail in (an allocation, a launch) is followed by one, so either all ranks enter the big collective behind it or all
+ * return an error -- nobody is left waiting.  window = the largest distance between a view and one of its sources. */
 int l3d_match_chain_blocks(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
                            int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
 

@@ -743,6 +743,32 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, speculation %s\n",
                                rank, world, first, own1 - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ok ? "exact" : "NOT exact");
     if (!ok) return L3D_OK;                                                    // *verdict = 1: nothing committed
+    // From here on a rank that fails on its own (an allocation, a launch) must not leave the others waiting in the next collective: every
+    // step that only this rank can fail in is followed by a small all-gather of status words, and either all ranks enter the big collective
+    // behind it or none does.
+    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 512 * (size_t)(world + 2)));     // (the digest tables are on the host by now)
+    long long* st_own = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>());
+    long long* st_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + 256);
+    std::vector<long long> words((size_t)world, 0);
+    // publishes `mine` (negative = this rank failed with code -mine), reads everybody's; non-zero return: somebody failed (this rank's own message is kept)
+    auto all_gather_word = [&](long long mine, const char* what) -> int {
+        std::string own_err;
+        if (mine < 0) { std::lock_guard<std::mutex> lk(c->err_mu); own_err = c->err; }
+        hipError_t e = hipMemcpyAsync(st_own, &mine, 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                   // (`mine` is a stack word)
+        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
+        if (exchange(exchange_user, -3, st_own, st_all, 256, world, (void*)st)) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: the exchange of the status words failed (") + what + ")");
+        for (int r = 0; r < world; ++r) {
+            e = hipMemcpyAsync(&words[(size_t)r], reinterpret_cast<const unsigned char*>(st_all) + (size_t)r * 256, 8, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
+        }
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
+        if (mine < 0) return fail(c, (int)-mine, own_err);
+        for (int r = 0; r < world; ++r)
+            if (words[(size_t)r] < 0) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: rank " + std::to_string(r) + " failed (code " + std::to_string(-words[(size_t)r]) + ") while " + what);
+        return L3D_OK;
+    };
     // ---- all-gather of the blocks: [records of the block's views][best depth pairs][best positions], padded to the largest block
     auto owner = [&](int k) { int r = (int)(((long long)k * world) / n_views); while (r + 1 < world && block_begin(r + 1) <= k) ++r; while (r > 0 && block_begin(r) > k) --r; return r; };
     std::vector<long long> rec_of((size_t)world, 0), seg_of((size_t)world, 0);
@@ -753,30 +779,47 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     }
     long long max_rec = 0, max_seg = 0, total = 0;
     for (int r = 0; r < world; ++r) { max_rec = std::max(max_rec, rec_of[(size_t)r]); max_seg = std::max(max_seg, seg_of[(size_t)r]); total += rec_of[(size_t)r]; }
-    if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_blocks: more than 2^32 kept matches");
+    if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_blocks: more than 2^32 kept matches");     // (the same on every rank)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_best = al((size_t)max_rec * sizeof(Match)), o_bpos = o_best + al((size_t)max_seg * 8), slot = o_bpos + al((size_t)max_seg * 4);
-    HIPCHK(c, c->ch_send.reserve(slot + 256));
-    HIPCHK(c, c->ch_gathered.reserve(slot * (size_t)world + 256));
     // offsets of the views' slices in the whole-run arrays of best pairs / positions (chain_assign_arenas: verified views back to back)
     std::vector<long long> best_off((size_t)n_views + 1, 0);
     for (int k = 0; k < n_views; ++k) best_off[(size_t)k + 1] = best_off[(size_t)k] + (views[k].n_tbm > 0 ? views[k].S_src : 0);
-    unsigned char* send = c->ch_send.as<unsigned char>();
-    long long own_start = 0;                                    // (this rank's arena: the views it computed, back to back from its cold start)
-    for (int k = first; k < own0; ++k) own_start += hres[k].n_kept;
-    if (rec_of[(size_t)rank] > 0)
-        HIPCHK(c, hipMemcpyAsync(send, c->ch_kept.as<Match>() + own_start, (size_t)rec_of[(size_t)rank] * sizeof(Match), hipMemcpyDeviceToDevice, st));
-    if (seg_of[(size_t)rank] > 0) {
-        HIPCHK(c, hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 8, hipMemcpyDeviceToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 4, hipMemcpyDeviceToDevice, st));
-    }
-    if (exchange(exchange_user, -2, send, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the kept lists failed");
-    HIPCHK(c, hipStreamSynchronize(st));            // (the arena below may be reallocated: everything that reads the old one is done)
-    // ---- the one chain's arena: blocks in rank order = views in order
-    HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
+    const auto stage_block = [&]() -> int {
+        HIPCHK(c, c->ch_send.reserve(slot + 256));
+        HIPCHK(c, c->ch_gathered.reserve(slot * (size_t)world + 256));
+        unsigned char* send = c->ch_send.as<unsigned char>();
+        long long own_start = 0;                                    // (this rank's arena: the views it computed, back to back from its cold start)
+        for (int k = first; k < own0; ++k) own_start += hres[k].n_kept;
+        if (rec_of[(size_t)rank] > 0)
+            HIPCHK(c, hipMemcpyAsync(send, c->ch_kept.as<Match>() + own_start, (size_t)rec_of[(size_t)rank] * sizeof(Match), hipMemcpyDeviceToDevice, st));
+        if (seg_of[(size_t)rank] > 0) {
+            HIPCHK(c, hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 4, hipMemcpyDeviceToDevice, st));
+        }
+        return L3D_OK;
+    };
+    { const int rc = stage_block(); if (int a_rc = all_gather_word(rc ? -(long long)rc : 0, "staging its block")) return a_rc; }
+    if (exchange(exchange_user, -2, c->ch_send.p, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the kept lists failed");
+    // ---- the one chain's arena: blocks in rank order = views in order; then matchViews' products: every rank builds the rows of its OWN block
+    // of views (sort + unique of the keys whose source lies in the block: its views' records and their neighbours', all of them in the arena now),
+    // the pieces are all-gathered and put together -- 1/world of the sort per rank instead of all of it on every rank
     std::vector<ChainResult> hres_all((size_t)n_views);
     std::vector<ProdChainView> pvh((size_t)n_views);
-    {
+    const int nvd = map->n_views;
+    auto dense_of = [&](int k) {                                   // the dense view a chain view is (ids ascend in both)
+        if (k >= n_views) return nvd;
+        const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + nvd, views[k].view_id);
+        return (int)(it - map->view_ids);
+    };
+    std::vector<int> dvb((size_t)world + 1);
+    for (int r = 0; r <= world; ++r) dvb[(size_t)r] = r == 0 ? 0 : (r == world ? nvd : dense_of(block_begin(r)));
+    for (int r = 1; r <= world; ++r) if (dvb[(size_t)r] < dvb[(size_t)r - 1]) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: the chain's views do not ascend with the dense map");     // (the same on every rank)
+    int64_t n_local = 0;
+    double t3 = 0;
+    const auto assemble_and_build = [&]() -> int {
+        HIPCHK(c, hipStreamSynchronize(st));            // (the arena below may be reallocated: everything that reads the old one is done)
+        HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
         long long base = 0;
         for (int k = 0; k < n_views; ++k) {
             const BlockDigest& e = tab[(size_t)owner(k) * n_views + k];
@@ -799,47 +842,29 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
             }
             at += rec_of[(size_t)r];
         }
-    }
-    const double t3 = now_s();
-    // ---- matchViews' products: every rank builds the rows of its OWN block of views (sort + unique of the keys whose source lies in the block:
-    // its views' records and their neighbours', all of them in the arena now), the pieces are all-gathered and put together -- 1/world of the
-    // sort per rank instead of all of it on every rank
-    const int nvd = map->n_views;
-    auto dense_of = [&](int k) {                                   // the dense view a chain view is (ids ascend in both)
-        if (k >= n_views) return nvd;
-        const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + nvd, views[k].view_id);
-        return (int)(it - map->view_ids);
+        t3 = now_s();
+        return build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, &n_local, dvb[(size_t)rank], dvb[(size_t)rank + 1]);
     };
-    std::vector<int> dvb((size_t)world + 1);
-    for (int r = 0; r <= world; ++r) dvb[(size_t)r] = r == 0 ? 0 : (r == world ? nvd : dense_of(block_begin(r)));
-    for (int r = 1; r <= world; ++r) if (dvb[(size_t)r] < dvb[(size_t)r - 1]) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: the chain's views do not ascend with the dense map");
-    int64_t n_local = 0;
-    { int rc = build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, &n_local, dvb[(size_t)rank], dvb[(size_t)rank + 1]); if (rc) return rc; }
     Products& P = c->products;
-    // counts first (a piece is padded to the largest), then [row starts of the block, numbered from 0 | entries]
-    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 512 * (size_t)(world + 1)));
-    long long* cnt_own = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>());
-    long long* cnt_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + 256);
-    const long long my_cnt = n_local;
-    HIPCHK(c, hipMemcpyAsync(cnt_own, &my_cnt, 8, hipMemcpyHostToDevice, st));
-    if (exchange(exchange_user, -3, cnt_own, cnt_all, 256, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the table sizes failed");
-    std::vector<long long> cnts((size_t)world, 0);
-    for (int r = 0; r < world; ++r) HIPCHK(c, hipMemcpyAsync(&cnts[(size_t)r], reinterpret_cast<const unsigned char*>(cnt_all) + (size_t)r * 256, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    // counts first (a piece is padded to the largest; a negative count = this rank failed), then [row starts of the block, numbered from 0 | entries]
+    { const int rc = assemble_and_build(); if (int a_rc = all_gather_word(rc ? -(long long)rc : (long long)n_local, "building its rows of the products")) return a_rc; }
+    const std::vector<long long> cnts = words;
     long long max_cnt = 0, max_rows = 0, n_pot_all = 0;
     for (int r = 0; r < world; ++r) {
         max_cnt = std::max(max_cnt, cnts[(size_t)r]); n_pot_all += cnts[(size_t)r];
         max_rows = std::max(max_rows, (long long)map->seg_base[dvb[(size_t)r + 1]] - map->seg_base[dvb[(size_t)r]]);
     }
     const size_t o_ent = al((size_t)max_rows * 8), pslot = o_ent + al((size_t)max_cnt * 4 + 4);
-    HIPCHK(c, c->ch_send.reserve(pslot + 256));
-    HIPCHK(c, c->ch_gathered.reserve(pslot * (size_t)world + 256));
-    {
+    const auto stage_piece = [&]() -> int {
+        HIPCHK(c, c->ch_send.reserve(pslot + 256));
+        HIPCHK(c, c->ch_gathered.reserve(pslot * (size_t)world + 256));
         const long long r0 = map->seg_base[dvb[(size_t)rank]], nr = (long long)map->seg_base[dvb[(size_t)rank + 1]] - r0;
         unsigned char* sp = c->ch_send.as<unsigned char>();
         if (nr > 0) HIPCHK(c, hipMemcpyAsync(sp, P.pot_start.as<long long>() + r0, (size_t)nr * 8, hipMemcpyDeviceToDevice, st));
         if (n_local > 0) HIPCHK(c, hipMemcpyAsync(sp + o_ent, P.pot_tgt.p, (size_t)n_local * 4, hipMemcpyDeviceToDevice, st));
-    }
+        return L3D_OK;
+    };
+    { const int rc = stage_piece(); if (int a_rc = all_gather_word(rc ? -(long long)rc : 0, "staging its piece of the products")) return a_rc; }
     if (exchange(exchange_user, -4, c->ch_send.p, c->ch_gathered.p, pslot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the table pieces failed");
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, P.pot_tgt.reserve(((size_t)n_pot_all + 2) * 4));

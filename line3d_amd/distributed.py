@@ -212,7 +212,7 @@ def match_views_chain_native(l3d, rank: int, world: int, link: "RcclLink | None"
 def match_views_blocks(l3d, rank: int, world: int, link: "RcclLink | None", warmup_views: int = -1) -> bool:
     """Line3D::matchViews with the VIEWS sharded over the ranks in blocks (l3d_line3d_block_run): every rank runs the full-width single-GPU
     chain on its block of views + a warm-up in front of it, started cold; the ranks verify the speculation with digests of the kept lists and,
-    when it holds, all-gather their blocks, build their own block's rows of matchViews' products and all-gather the pieces.  Four collectives per pass instead of one per view.
+    when it holds, all-gather their blocks, build their own block's rows of matchViews' products and all-gather the pieces.  Four data collectives per pass (+ three of status words) instead of one per view.
     False: the speculation did not hold on this scene (identical on every rank): call match_views_chain_native."""
     if world == 1 and link is None:
         return l3d.block_run(rank, world, "local", None, warmup_views)
