@@ -240,6 +240,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (n_views < 0 || (n_views > 0 && (!views || (!cb && !map && !ranged))) || k_begin < 0 || k_end > n_views || k_begin > k_end) return fail(c, L3D_ERR_INVALID, "l3d_match_chain: bad argument");
     c->products.valid = false;
     if (n_views == 0) return L3D_OK;
+    const double t_enter = now_s();
     HIPCHK(c, hipSetDevice(c->device));
     const double t_setup0 = now_s();
     c->pin_arena.reset();
@@ -609,9 +610,11 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
                 (t_loop0 - t_setup0) * 1e3, (t_prod0 - t_loop0) * 1e3, t_wait * 1e3, t_ev1 * 1e3, t_d2h * 1e3, t_cb * 1e3);
     if (c->opt.timing && map) fprintf(stderr, "[l3d match_chain] products on the device %.2f ms\n", (now_s() - t_prod0) * 1e3);
+    const double t_tail0 = now_s();
     if (sm != s1) (void)hipStreamSynchronize(sm);
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
+    if (c->opt.timing) fprintf(stderr, "[l3d match_chain] hipSetDevice %.3f ms, final syncs %.3f ms\n", (t_setup0 - t_enter) * 1e3, (now_s() - t_tail0) * 1e3);
     for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
     for (hipEvent_t e : evm) if (e) c->event_pool.push_back(e);

@@ -282,6 +282,7 @@ bool plan_chain(L* h, ChainPlan& P)
         o.sigma_p = h->sigma_p; o.sigma_a = h->sigma_a; o.spatial_k = m.spatial_k;
         mark_matched(h, v);
     }
+    P.matched_final = h->matched;
     h->matched.clear();                                 // back to the state matchViews starts from
     return chain_ok;
 }
@@ -473,8 +474,8 @@ int adopt_resident_products(L* h, ChainPlan& P)
         View& v = h->views[h->order[k]];
         v.median_depth = h->chain_summary[k].median_depth;      // line3D.cc:835
         h->stat_kept += h->chain_summary[k].n_kept;
-        mark_matched(h, v);                                     // line3D.cc:875-881
     }
+    h->matched = P.matched_final;                               // line3D.cc:875-881 for every view of the schedule (plan_chain simulated exactly that)
     h->resident_products = true;
     if (h->keep_view_matches) {
         for (size_t k = 0; k < P.n; ++k) {
@@ -502,8 +503,10 @@ int match_views_resident(L* h, ChainPlan& P, double t0)
     h->t_gpu_call += now_s() - t1;
     if (rc == L3D_ERR_UNSUPPORTED) return rc;
     if (rc) return h->fail(rc, std::string("match_chain_resident: ") + l3d_last_error(h->ctx));
+    const double t2 = now_s();
     rc = adopt_resident_products(h, P);
     if (rc) return rc;
+    if (hopt(h).timing) fprintf(stderr, "[l3d match_views] the call %.3f ms, adopting its products on the host %.3f ms\n", (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     double st[4];
     l3d_last_stats(h->ctx, st);
     h->stat_pairs += st[0];

@@ -144,6 +144,15 @@ struct NoInitAlloc {
 };
 typedef std::vector<l3d_edge, NoInitAlloc<l3d_edge>> EdgeVec;
 
+// matched_ (line3D.h: map of maps of bool) as a sorted vector of (a << 32 | b): a few thousand keys, looked up far more often than inserted, and
+// copied whole once per matchViews (the state a pass ends in is the schedule's, ChainPlan::matched_final)
+struct KeySet {
+    std::vector<uint64_t> v;
+    size_t count(uint64_t k) const { return std::binary_search(v.begin(), v.end(), k) ? 1 : 0; }
+    void insert(uint64_t k) { auto it = std::lower_bound(v.begin(), v.end(), k); if (it == v.end() || *it != k) v.insert(it, k); }
+    void clear() { v.clear(); }
+};
+
 struct FinalLine {
     std::vector<Key> segs2D;
     std::vector<std::pair<V3, V3>> segs3D;
@@ -172,7 +181,7 @@ struct l3d_line3d {
     std::unordered_map<uint32_t, std::vector<uint32_t>> worldpoints2views;   // ascending by construction? no: sorted on use
     std::map<uint32_t, std::vector<uint32_t>> visual_neighbors; // ascending ids
     std::map<uint64_t, M3> fundamentals;                       // (a<<32|b)
-    std::set<uint64_t> matched;                                // (a<<32|b): matched_[a][b]
+    KeySet matched;                                            // (a<<32|b): matched_[a][b]
 
     // geometry transformation
     double transf_scale_inv = 1.0;
@@ -274,6 +283,7 @@ struct ChainPlan {
     std::vector<std::vector<int32_t>> src_cam, src_idx;
     std::vector<l3d_chain_view> cv;
     std::vector<int> n_tbm;
+    KeySet matched_final;                           // matched_ after the last view of the schedule
     ChainFinalizer* fin = nullptr;                  // the pipeline object's persistent finaliser
     // static tables of the finaliser (ChainFinalizer)
     bool fin_tables = false;
