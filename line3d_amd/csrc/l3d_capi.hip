@@ -72,7 +72,7 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     if (hipStreamCreateWithFlags(&c->stage1_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(c->copy_stream); (void)hipStreamDestroy(c->stream); delete c; return L3D_ERR_HIP;
     }
-    if (c->opt.pair_stats && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 64) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 64);
+    if (c->opt.pair_stats && hipMalloc(reinterpret_cast<void**>(&c->pair_dbg), 4096) == hipSuccess) (void)hipMemset(c->pair_dbg, 0, 4096);
     *out = c;
     return L3D_OK;
 }
@@ -119,6 +119,16 @@ void l3d_ctx_destroy(l3d_ctx* c)
         (void)hipMemcpy(h, c->pair_dbg, 64, hipMemcpyDeviceToHost);
         fprintf(stderr, "[l3d pair_mask] pairs %llu  after wedge test %.3f%%  after overlap-bound test %.3f%%  candidates %.3f%%  (sector test off: source side %.2f%%, target side %.2f%% of the pairs)\n",
                 h[0], 100.0 * h[1] / (double)h[0], 100.0 * h[2] / (double)h[0], 100.0 * h[3] / (double)h[0], 100.0 * h[4] / (double)h[0], 100.0 * h[5] / (double)h[0]);
+        if (h[6]) {           // (diagnostic build -DL3D_BOUND_CHECK: pairs level 2 decided AGAINST the exact test)
+            unsigned long long rec[8 * 48];
+            (void)hipMemcpy(rec, c->pair_dbg + 8, sizeof(rec), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[l3d pair_mask] %llu pairs were decided by level 2 AGAINST the exact test; the first ones:\n", h[6]);
+            for (unsigned long long i = 0; i < h[6] && i < 48; ++i) {
+                float f[8]; memcpy(f, &rec[i * 8 + 4], 32);
+                fprintf(stderr, "   view %llu src %llu cam %llu tgt %llu | bounds %.7g %.7g  exact overlaps %.7g %.7g | t-intervals src [%.7g, %.7g] tgt [%.7g, %.7g]\n",
+                        rec[i * 8] >> 32, rec[i * 8] & 0xffffffffull, rec[i * 8 + 1] >> 32, rec[i * 8 + 1] & 0xffffffffull, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+        }
         (void)hipFree(c->pair_dbg);
     }
     if (c->opt.timing)
@@ -400,7 +410,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     pa.tbm = reinterpret_cast<const int*>(tb + o_tbm);
     pa.mask = c->mask.as<unsigned long long>();
     pa.S_src = S_src; pa.N = N; pa.n_tbm = n_tbm; pa.W64 = W64;
-    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
+    pa.seg_begin = seg_begin; pa.seg_end = seg_end; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.dbg_view = -1; pa.rowcnt = nullptr;
     const unsigned* d_l2g = reinterpret_cast<const unsigned*>(tb + o_l2g);
 
     // stage 1 starts now; the host orders the existing matches meanwhile

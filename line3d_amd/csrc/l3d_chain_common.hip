@@ -185,7 +185,7 @@ PairArgs chain_pair_args(const l3d_ctx* c, const l3d_chain_view& v, const ChainV
     pa.tbm = reinterpret_cast<const int*>(dtab + d.o_tbm);
     pa.mask = d.mask;
     pa.S_src = v.S_src; pa.N = v.N; pa.n_tbm = v.n_tbm; pa.W64 = d.W64;
-    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.rowcnt = nullptr;
+    pa.seg_begin = d.s0; pa.seg_end = d.s1; pa.cand_cap = 0; pa.wedge_pretest = c->wedge_pretest; pa.dbg = c->pair_dbg; pa.dbg_view = (int)v.view_id; pa.rowcnt = nullptr;
     pa.depth_in_fill = 1;               // the four depths of a stage-1 pair are triangulated once, by k_pair_fill
     const bool src_rays_env = c->opt.src_rays != 0;   // (0: A/B, k_pair_fill normalises per row)
     pa.tgt_rays = d.rays; pa.src_rays = src_rays_env ? d.src_rays : nullptr;

@@ -114,17 +114,29 @@ __device__ __forceinline__ float fline(f3 l, float x, float y) { return __builti
 // Bounds of D_segment_overlap_2D(segment [0,1] of length len, intersection points at parameters t1, t2) where
 // ti = ai/(ai - bi) and ri = 1/(ai - bi); ext_over_len = (largest coordinate)/len.  For collinear points the reference's case
 // analysis (:209-251) is the 1-D intersection over union of the two intervals; the float intersection points it works on lie within
-// e of t1, t2.  upper: 2.0f = "cannot tell"; lower: -1.0f = "cannot tell" (ill-conditioned, or the intersection pair is not SURELY
-// a pixel long, :211).
+// e of t1, t2: conditioning of the intersection (kIouCond, in margin units) + coordinate rounding + the segment's own line, whose offset
+// term x1 y2 - x2 y1 cancels from products of the size ext^2 (2^-24 ext^2 / len pixels beside the true line, kLineCond (ext/len)^2 in t: a 3-pixel
+// segment at x = 1000 has a line that is only good to 0.05 px).  upper: 2.0f = "cannot tell"; lower: -1.0f = "cannot tell" -- ill-conditioned,
+// or the intersection pair not SURELY a pixel long (:211).  BOTH are "cannot tell" when one of the intersection points lies within 4 e of an END
+// POINT of the segment: there the reference's point-on-segment tests (:135-141, a dot product against 1e-12) flip on float noise and
+// D_segment_overlap_2D returns 0 -- or thousands -- whatever the intervals are (measured with the diagnostic build -DL3D_BOUND_CHECK: accepts AND
+// round 1's rejects decided a dozen pairs in 1e11 against the exact test before this guard; tests/golden/endpoint_quirk_pairs.npz).
+constexpr float kLineCond = 5.0e-7f;
 struct IouBounds { float upper, lower; };
 __device__ __forceinline__ IouBounds iou_bounds(float t1, float r1, float t2, float r2, float len, float ext_over_len)
 {
-    const float e1 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t1)), __builtin_fabsf(r1), 1.0e-6f * (ext_over_len + __builtin_fabsf(t1)));
-    const float e2 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t2)), __builtin_fabsf(r2), 1.0e-6f * (ext_over_len + __builtin_fabsf(t2)));
+    const float e0 = __builtin_fmaf(kLineCond * ext_over_len, ext_over_len, 1.0e-6f * ext_over_len);
+    const float e1 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t1)), __builtin_fabsf(r1), __builtin_fmaf(1.0e-6f, __builtin_fabsf(t1), e0));
+    const float e2 = __builtin_fmaf(kIouCond * (1.0f + __builtin_fabsf(t2)), __builtin_fabsf(r2), __builtin_fmaf(1.0e-6f, __builtin_fabsf(t2), e0));
     const float e = __builtin_fmaxf(e1, e2);
     if (!(e < 10.0f)) return { 2.0f, -1.0f };                             // ill-conditioned, infinite or NaN
     const float lo = __builtin_fminf(t1, t2), hi = __builtin_fmaxf(t1, t2);
     if ((hi - lo + 2.0f * e) * len < 1.0f - kIouSlack) return { 0.0f, -1.0f };   // the intersection pair is shorter than a pixel (:211)
+    // an intersection point within 4 e of an end point of the segment: the reference's case analysis may land anywhere (0, or a ratio of thousands
+    // when the "rest" it divides by is the distance of two nearly coincident points) -- neither bound means anything, the exact test decides.
+    // (Both points beyond the same end by more than that stay decidable: no point lies on the other segment, the overlap is 0.)
+    const float edge = __builtin_fminf(__builtin_fminf(__builtin_fabsf(lo), __builtin_fabsf(lo - 1.0f)), __builtin_fminf(__builtin_fabsf(hi), __builtin_fabsf(hi - 1.0f)));
+    if (!(edge > 4.0f * e)) return { 2.0f, -1.0f };
     const float in0 = __builtin_fminf(hi, 1.0f) - __builtin_fmaxf(lo, 0.0f), un0 = __builtin_fmaxf(hi, 1.0f) - __builtin_fminf(lo, 0.0f);
     const float uni_lo = un0 - 2.0f * e;
     IouBounds b;
@@ -361,6 +373,26 @@ void k_pair_mask(PairArgs a)
                     const bool acc = use_accept && ls >= 1.0f && lt >= 1.0f && __builtin_fminf(o1.lower, o2.lower) > kMinOverlapLower + kIouSlack &&
                                      __builtin_fmaxf(o1.lower, o2.lower) > kMinOverlapUpper + kIouSlack;
                     if (acc) atomicOr(&s_bits[kk * 4 + wave], 1ull << origin);
+#ifdef L3D_BOUND_CHECK
+                    if ((acc || rej) && a.dbg) {
+                        f3 c1, c2, c3, c4; bool v1, v2, v3, v4;
+                        c1 = hom_normalize(cross(tb.t.line2, sb.s.epi_p1), v1); c2 = hom_normalize(cross(tb.t.line2, sb.s.epi_p2), v2);
+                        c3 = hom_normalize(cross(sb.s.line1, tb.t.epi_q1), v3); c4 = hom_normalize(cross(sb.s.line1, tb.t.epi_q2), v4);
+                        const float ov1 = segment_overlap(sb.s.p1, sb.s.p2, sb.s.len, c3, c4, seglen2d(c3, c4));
+                        const float ov2 = segment_overlap(tb.t.q1, tb.t.q2, tb.t.len, c1, c2, seglen2d(c1, c2));
+                        const bool ex = v1 && v2 && v3 && v4 && __builtin_fminf(ov1, ov2) > kMinOverlapLower && __builtin_fmaxf(ov1, ov2) > kMinOverlapUpper;
+                        if (acc ? !ex : ex) {                      // (an accept the exact test rejects / a reject it keeps)
+                            const unsigned long long idx = atomicAdd(&a.dbg[6], 1ull);
+                            if (idx < 48) {
+                                unsigned long long* r = a.dbg + 8 + idx * 8;
+                                r[0] = ((unsigned long long)a.dbg_view << 32) | (unsigned)(y0 + kk);
+                                r[1] = ((unsigned long long)cam << 32) | (unsigned)(blockIdx.x * 256 + wave * 64 + origin);
+                                float* f = reinterpret_cast<float*>(r + 4);
+                                f[0] = acc ? o1.lower : o1.upper; f[1] = acc ? o2.lower : o2.upper; f[2] = ov1; f[3] = ov2; f[4] = b1 * rb1; f[5] = b3 * rb2; f[6] = a1 * ra1; f[7] = a3 * ra2;
+                            }
+                        }
+                    }
+#endif
                     pass = !rej && !acc;
                 }
                 const unsigned long long pm = __ballot(pass);

@@ -58,6 +58,7 @@ struct PairArgs {
     int src_per_block;              // set by launch_pair_mask (<= kSrcPerBlock)
     int* rowcnt;                    // chains: the per-(segment, camera) candidate counts are added here by k_pair_mask itself (rows zeroed at
                                     // chain start); null: a separate k_row_count launch (per-view seam call, chain restarts)
+    int dbg_view;                   // (diagnostics: the view id of this launch)
     int wedge_pretest;              // conservative filters in front of the exact test: bit 0 wedge test, bit 1 overlap-bound test, bit 2 set = no accepts at level 2 (default 3)
     // resident chain, row starts without a scan launch: k_pair_mask also adds its counts to rowblk[(row) >> 8] (sums of 256 rows; row =
     // segment * N + camera).  k_pair_fill then reads the (upper-bound) counts from rowub -- the array k_pair_mask filled, never

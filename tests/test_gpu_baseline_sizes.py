@@ -117,6 +117,26 @@ def test_config2_mid_chain_slice_against_the_reference_kernels(cfg2_scene, cfg2_
     assert np.max(np.abs(got["confidence"] - exp["confidence"])) <= 5e-6
 
 
+def test_config3_512_views_stage1_filters_decide_nothing_against_the_exact_test():
+    """1.22e10 segment pairs of configs[2]'s scene with all levels of k_pair_mask (sector test, interval bounds that reject AND accept) against the exact
+    sequence alone: the same NUMBER OF CANDIDATES (kept lists can agree while candidates differ) and the same kept lists.  This is the size at which round 4
+    found pairs the bounds decided against the exact test (an intersection point on an end point of a segment: D_segment_overlap_2D returns 0 or thousands
+    there, whatever the intervals are; tests/golden/endpoint_quirk_pairs.npz) -- nine candidates in 7.9e8, invisible at 64 views."""
+    from line3d_amd.synth import make_scene
+    V, S, N = 512, 2000, 12
+    scene = make_scene(V, S, N, seed=20260)
+    out = {}
+    for name, pretest in (("all levels", None), ("exact test alone", 0), ("no accepts", 7)):
+        l, lists = _run(scene, N, pretest=pretest)
+        st = l.stats()
+        out[name] = (digest_lists(lists), int(st["raw"]), int(st["kept"]))
+        l.close()
+        del lists
+    assert out["exact test alone"][1] > 700_000_000
+    assert out["all levels"] == out["exact test alone"], out
+    assert out["no accepts"] == out["exact test alone"], out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # configs[2]: 512 views x 2000 x 12, sharded over 8 ranks -- on one GPU: the unsharded chain against rank 0's committed lists
 # of a recorded 8-virtual-rank run replayed through the native loop
