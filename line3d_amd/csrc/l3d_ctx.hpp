@@ -162,6 +162,8 @@ struct l3d_ctx {
     std::string prof_only;          // bracket only this kernel (keeps the timed region of bench.py nearly undisturbed)
     std::map<std::string, l3d::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
+    std::vector<hipEvent_t> prof_event_pool;   // the brackets of ProfScope: events WITHOUT the system-scope fences (a default event flushes the caches at every record)
+    int prof_tick = 0;                         // (option prof_stride: with prof_only set, every n-th launch of that kernel is bracketed)
     std::mutex event_mu;
     double stats[4] = { 0, 0, 0, 0 };
     double tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // host-side phase timers of l3d_compute_pairwise_matches (L3D_TIMING=1)
@@ -193,6 +195,15 @@ inline hipEvent_t get_event(l3d_ctx* c)
     return e;
 }
 
+inline hipEvent_t get_prof_event(l3d_ctx* c)
+{
+    std::lock_guard<std::mutex> lk(c->event_mu);
+    if (!c->prof_event_pool.empty()) { hipEvent_t e = c->prof_event_pool.back(); c->prof_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); (void)hipEventCreate(&e); }
+    return e;
+}
+
 struct ProfScope {
     l3d_ctx* c; const char* name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     bool on;
@@ -200,7 +211,8 @@ struct ProfScope {
     ProfScope(l3d_ctx* c_, const char* n, hipStream_t s = nullptr) : c(c_), name(n), st(s ? s : c_->stream)
     {
         on = c->prof_on && (c->prof_only.empty() || c->prof_only == n);
-        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, st); }
+        if (on && !c->prof_only.empty() && c->opt.prof_stride > 1) on = (c->prof_tick++ % c->opt.prof_stride) == 0;
+        if (on) { a = get_prof_event(c); b = get_prof_event(c); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
@@ -217,8 +229,8 @@ inline void prof_resolve(l3d_ctx* c)
         for (auto& pr : kv.second.pending) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches += 1; }
-            c->event_pool.push_back(pr.first);
-            c->event_pool.push_back(pr.second);
+            c->prof_event_pool.push_back(pr.first);
+            c->prof_event_pool.push_back(pr.second);
         }
         kv.second.pending.clear();
     }
