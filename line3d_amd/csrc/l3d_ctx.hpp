@@ -186,11 +186,17 @@ inline int fail(l3d_ctx* c, int code, const std::string& msg)
             return l3d::fail(ctx, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Synchronisation events of the chains (view done, stage 1 done, ring slot free): created WITHOUT the system-scope acquire / release fences a default HIP
+// event carries -- 126 records per config-2 pass, each a cache write-back and invalidate the next kernels pay for (12.27 -> 12.0 ms per pass).  What they
+// order is (a) kernels on two streams of the SAME device (agent scope: the end-of-kernel release and the next kernel's acquire do that) and (b) the host
+// reading result records that the kernels write straight into pinned, coherent HOST memory (uncached on the device: nothing for a fence to write back;
+// the event's own signal is a later posted write on the same path).  Nothing the host reads after these events lives in device memory.
 inline hipEvent_t get_event(l3d_ctx* c)
 {
     std::lock_guard<std::mutex> lk(c->event_mu);         // (the sharded run enqueues from two threads)
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e;
+    if (c->opt.event_fence == 0) { if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess) return e; (void)hipGetLastError(); }
     (void)hipEventCreate(&e);
     return e;
 }

@@ -17,6 +17,7 @@ namespace l3d {
     X(pretest, "L3D_PRETEST", 3, "stage-1 conservative filters: bit 0 wedge test, bit 1 overlap-bound test (A/B)")                   \
     X(mask_stream, "L3D_MASK_STREAM", 0, "1: k_pair_mask on a stream of its own, a view ahead of k_pair_fill (A/B, DESIGN.md section 6)")                       \
     X(prof_stride, "L3D_PROF_STRIDE", 1, "with one kernel bracketed (l3d_profile_only): HIP events around every n-th launch of it only -- a uniform sample of a timed region")   \
+    X(event_fence, "L3D_EVENT_FENCE", 0, "1: the library's synchronisation events WITH system-scope fences (HIP's default; A/B: +0.27 ms per config-2 pass)")     \
     X(stream_prio, "L3D_STREAM_PRIO", 0, "1: the chain's stream at the highest priority (measured: no difference)")                  \
     X(pair_stats, "L3D_PAIR_STATS", 0, "device counters of k_pair_mask's levels, printed at destroy")                                \
     X(vw_debug, "L3D_VW_DEBUG", 0, "k_verify_window debug mode")                                                                     \
