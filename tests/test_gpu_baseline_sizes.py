@@ -131,6 +131,15 @@ def test_config3_512_views_stage1_filters_decide_nothing_against_the_exact_test(
         st = l.stats()
         out[name] = (digest_lists(lists), int(st["raw"]), int(st["kept"]))
         l.close()
+        if pretest is None:
+            # the ORACLE on the source segments around the three pairs the first accepts let through (view, source segment): mid-chain views, the
+            # kept lists of the earlier views towards them taken from this run
+            for vid, src in ((440, 182), (450, 466), (509, 1896)):
+                lo = (src // 64) * 64
+                exp, mv, _existing = oracle_view_slice(scene, lists, vid, lo, lo + 64, N)
+                got = lists[vid][0]
+                got = got[(got["segID1"] >= lo) & (got["segID1"] < lo + 64)]
+                assert len(exp) > 10 and got.tobytes() == exp.tobytes(), (vid, lo)
         del lists
     assert out["exact test alone"][1] > 700_000_000
     assert out["all levels"] == out["exact test alone"], out
