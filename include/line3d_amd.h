@@ -386,9 +386,10 @@ int l3d_register_segments_batch(l3d_ctx* ctx, const float* const* arrays, const 
  * variant; views with more than ~50 neighbours take the all-pairs kernel), 1 = all-pairs loop in the reference's formulation.
  * Results are bit-identical. */
 int l3d_set_verify_mode(l3d_ctx* ctx, int mode);
-/* stage-1 conservative filters in front of the exact epipolar/overlap/triangulation sequence: bit 0 = wedge test,
- * bit 1 = overlap-bound test; 3 = both (default), 0 = none (A/B testing: results are bit-identical, a filter only rejects
- * pairs the exact sequence rejects) */
+/* stage-1 filters in front of the exact epipolar/overlap/triangulation sequence: bit 0 = wedge test, bit 1 = interval bounds of the two
+ * overlap ratios (they reject -- and, in the chains, accept -- what they can decide; a pair with an intersection point on a segment end
+ * point is always left to the exact test), bit 2 SET = the bounds do not accept; 3 = everything (default), 0 = the exact sequence
+ * alone (A/B testing: results are bit-identical, candidate counts included) */
 int l3d_set_pair_pretest(l3d_ctx* ctx, int mask);
 /* Diagnostic / A-B switches (line3d_amd/csrc/l3d_options.hpp lists them with their meaning).  The environment (L3D_<NAME>) is
  * read ONCE, when the context is created; afterwards a switch changes only through this call.  name: "L3D_TIMING", "TIMING" or
