@@ -285,11 +285,11 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     HIPCHK(c, hipMemsetAsync(c->ch_res.p, 0, (size_t)n_views * sizeof(ChainResult), st));
     HIPCHK(c, hipMemsetAsync(c->ch_flags.p, 0, 64, st));
     {   // stage 1 starts after the tables and the zeroed row counts are in place
-        hipEvent_t ready = get_event(c);
+        hipEvent_t ready = get_local_event(c);
         HIPCHK(c, hipEventRecord(ready, st));
         HIPCHK(c, hipStreamWaitEvent(s1, ready, 0));
         if (sm != s1) HIPCHK(c, hipStreamWaitEvent(sm, ready, 0));
-        c->event_pool.push_back(ready);
+        put_local_event(c, ready);
     }
     // per-view results are written by the kernels straight into host-mapped pinned memory (no copy operations on the streams)
     ChainResult* hres = c->ch_pin_res.as<ChainResult>();
@@ -376,7 +376,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 if (sm != s1) for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(sm, ev[(size_t)j], 0)); break; }
                 { ProfScope p(c, "pair_mask", sm); launch_pair_mask(pm, vd[(size_t)k].maxW, sm); }
                 if (sm != s1) {
-                    if (!evm[(size_t)k]) evm[(size_t)k] = get_event(c);
+                    if (!evm[(size_t)k]) evm[(size_t)k] = get_local_event(c);
                     HIPCHK(c, hipEventRecord(evm[(size_t)k], sm));
                     HIPCHK(c, hipStreamWaitEvent(s1, evm[(size_t)k], 0));
                 }
@@ -389,7 +389,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(s1, ev[(size_t)j], 0)); break; }
             enqueue_fillA(k, s1);
         }
-        ev1[(size_t)k] = get_event(c);
+        ev1[(size_t)k] = get_local_event(c);
         HIPCHK(c, hipEventRecord(ev1[(size_t)k], s1));
         return L3D_OK;
     };
@@ -446,7 +446,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                                     reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-        if (!ev[(size_t)k]) ev[(size_t)k] = get_event(c);
+        if (!ev[(size_t)k]) ev[(size_t)k] = get_local_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
         return L3D_OK;
     };
@@ -615,9 +615,9 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     if (c->opt.timing) fprintf(stderr, "[l3d match_chain] hipSetDevice %.3f ms, final syncs %.3f ms\n", (t_setup0 - t_enter) * 1e3, (now_s() - t_tail0) * 1e3);
-    for (hipEvent_t e : ev) if (e) c->event_pool.push_back(e);
-    for (hipEvent_t e : ev1) if (e) c->event_pool.push_back(e);
-    for (hipEvent_t e : evm) if (e) c->event_pool.push_back(e);
+    for (hipEvent_t e : ev) put_local_event(c, e);
+    for (hipEvent_t e : ev1) put_local_event(c, e);
+    for (hipEvent_t e : evm) put_local_event(c, e);
     c->stats[1] = raw_sum;
     c->stats[3] = kept_total;
     if (rc_final == L3D_OK && !c->test_cand_cap && !c->test_arena_cap) {

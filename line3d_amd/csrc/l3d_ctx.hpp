@@ -162,6 +162,7 @@ struct l3d_ctx {
     std::string prof_only;          // bracket only this kernel (keeps the timed region of bench.py nearly undisturbed)
     std::map<std::string, l3d::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
+    std::vector<hipEvent_t> local_event_pool;  // events without system-scope fences (get_local_event: the single-GPU chain)
     std::vector<hipEvent_t> prof_event_pool;   // the brackets of ProfScope: events WITHOUT the system-scope fences (a default event flushes the caches at every record)
     int prof_tick = 0;                         // (option prof_stride: with prof_only set, every n-th launch of that kernel is bracketed)
     std::mutex event_mu;
@@ -186,20 +187,32 @@ inline int fail(l3d_ctx* c, int code, const std::string& msg)
             return l3d::fail(ctx, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// Synchronisation events of the chains (view done, stage 1 done, ring slot free): created WITHOUT the system-scope acquire / release fences a default HIP
-// event carries -- 126 records per config-2 pass, each a cache write-back and invalidate the next kernels pay for (12.27 -> 12.0 ms per pass).  What they
-// order is (a) kernels on two streams of the SAME device (agent scope: the end-of-kernel release and the next kernel's acquire do that) and (b) the host
-// reading result records that the kernels write straight into pinned, coherent HOST memory (uncached on the device: nothing for a fence to write back;
-// the event's own signal is a later posted write on the same path).  Nothing the host reads after these events lives in device memory.
+// Synchronisation events with HIP's default system-scope fences: what the SHARDED chain orders includes slots that other GPUs wrote into this
+// one's memory (the RCCL all-gather), which a consumer kernel must not read through stale cache lines.
 inline hipEvent_t get_event(l3d_ctx* c)
 {
     std::lock_guard<std::mutex> lk(c->event_mu);         // (the sharded run enqueues from two threads)
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e;
-    if (c->opt.event_fence == 0) { if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess) return e; (void)hipGetLastError(); }
     (void)hipEventCreate(&e);
     return e;
 }
+// The single-GPU chain's events (view done, stage 1 done, ring slot free): created WITHOUT the system-scope acquire / release fences a default HIP
+// event carries -- 126 records per config-2 pass, each a cache write-back and invalidate the next kernels pay for (12.27 -> 12.0 ms per pass).  What they
+// order is (a) kernels on two streams of the SAME device (agent scope: the end-of-kernel release and the next kernel's acquire do that) and (b) the host
+// reading result records that the kernels write straight into pinned, coherent HOST memory (uncached on the device: nothing for a fence to write back;
+// the event's own signal is a later posted write on the same path).  Nothing the host reads after these events lives in device memory, and nothing
+// another device wrote is read behind them.  (Option event_fence = 1: default events here too, A/B.)
+inline hipEvent_t get_local_event(l3d_ctx* c)
+{
+    if (c->opt.event_fence != 0) return get_event(c);
+    std::lock_guard<std::mutex> lk(c->event_mu);
+    if (!c->local_event_pool.empty()) { hipEvent_t e = c->local_event_pool.back(); c->local_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); (void)hipEventCreate(&e); }
+    return e;
+}
+inline void put_local_event(l3d_ctx* c, hipEvent_t e) { if (e) (c->opt.event_fence != 0 ? c->event_pool : c->local_event_pool).push_back(e); }
 
 inline hipEvent_t get_prof_event(l3d_ctx* c)
 {
