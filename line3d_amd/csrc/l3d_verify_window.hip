@@ -291,6 +291,19 @@ void k_verify_window(VerifyArgs a)
         const float lo1 = d1y - w1, hi1 = d1y + w1;
         int j = 0, jend = 0;
         if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
+        if (a.stamps) {                                                  // diagnostic: entries walked, of them inside the d1 window / inside both windows
+            int n_in = 0, n_in1 = 0, n_in2 = 0, n_oth = 0;
+            for (int e = j; e < jend; ++e) {
+                ++n_in;
+                const bool i1 = L.sd1[e] >= lo1 && L.sd1[e] <= hi1;
+                const bool i2 = __builtin_fabsf(L.sd2[e] - d2y) <= w2;
+                n_in1 += i1; n_in2 += i1 && i2; n_oth += i1 && i2 && (L.sci[e] >> 24) != cam_h;
+            }
+            for (int o = 32; o > 0; o >>= 1) { n_in += __shfl_down(n_in, o); n_in1 += __shfl_down(n_in1, o); n_in2 += __shfl_down(n_in2, o); n_oth += __shfl_down(n_oth, o); }
+            const unsigned long long nh = __popcll(__ballot(hv));
+            if (lane == 0) { atomicAdd(&a.stamps[10], (unsigned long long)n_in); atomicAdd(&a.stamps[11], (unsigned long long)n_in1); atomicAdd(&a.stamps[12], (unsigned long long)n_in2);
+                             atomicAdd(&a.stamps[13], (unsigned long long)n_oth); atomicAdd(&a.stamps[14], nh); }
+        }
         // the window is walked in groups of kG entries: the next group's loads (3 per entry, LDS or L2) are in flight while
         // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
 #ifndef L3D_KG
