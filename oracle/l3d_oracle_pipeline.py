@@ -550,10 +550,11 @@ class OracleLine3D:
                 r["confidence"] = 0.0
                 r["depths"] = (m["depths"][2], m["depths"][3], m["depths"][0], m["depths"][1])
                 other.setdefault(cam, []).append(r)
-            ref = (v, int(m["segID1"]))
-            tgt = (cam, int(m["segID2"]))
-            self.potential.setdefault(ref, {})[tgt] = True
-            self.potential.setdefault(tgt, {})[ref] = True
+            if getattr(self, "track_potential", True):           # (False: matchViews' kept lists only -- the 512-view golden, whose 7e7 map entries would not fit)
+                ref = (v, int(m["segID1"]))
+                tgt = (cam, int(m["segID2"]))
+                self.potential.setdefault(ref, {})[tgt] = True
+                self.potential.setdefault(tgt, {})[ref] = True
         for cam in sorted(other):                               # 868-872
             self.views[cam].add_matches(other[cam])
         for nb in self.visual_neighbors[v]:                     # 875-881

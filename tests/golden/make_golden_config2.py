@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(HERE, "config2_full.npz"))
     ap.add_argument("--cache", default="", help="scratch .npz of the oracle's own kept lists: written after matchViews, read instead of recomputing the "
                                                 "seam calls when it exists (the commits are always replayed); not a fixture, not committed")
+    ap.add_argument("--matching-only", action="store_true", help="matchViews only (kept lists and medians per view): what tests/golden/config3_matching.npz holds for the "
+                                                                  "512-view scene -- python tests/golden/make_golden_config2.py --views 512 --matching-only --out tests/golden/config3_matching.npz "
+                                                                  "(about 6 core-hours)")
     a = ap.parse_args()
     t0 = time.time()
     scene = make_scene(a.views, a.segments, N, seed=SEED)
@@ -100,6 +103,7 @@ def main():
         o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
     print("scene + collinearity %.1f s" % (time.time() - t0), flush=True)
     o.computation = True
+    o.track_potential = not a.matching_only
     o.matched, o.potential, o.result = {}, {}, []
     o.find_visual_neighbors()
     o.transform_geometry()
@@ -131,6 +135,10 @@ def main():
     g["kept_sha256"] = np.array(kept_sha)
     g["kept_n"] = np.array(kept_n, np.int64)
     g["median"] = np.array(medians, np.float32)
+    if a.matching_only:
+        np.savez_compressed(a.out, **g)
+        print("written %s (%d bytes) in %.0f s" % (a.out, os.path.getsize(a.out), time.time() - t0))
+        return
     t1 = time.time()
     o.greedy_selection()
     print("greedy selection %.1f s: %d hypotheses" % (time.time() - t1, len(o.best_match)), flush=True)
