@@ -88,6 +88,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=V)
     ap.add_argument("--segments", type=int, default=S)
+    ap.add_argument("--neighbors", type=int, default=N)
+    ap.add_argument("--seed", type=int, default=SEED)
     ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
     ap.add_argument("--out", default=os.path.join(HERE, "config2_full.npz"))
     ap.add_argument("--cache", default="", help="scratch .npz of the oracle's own kept lists: written after matchViews, read instead of recomputing the "
@@ -97,8 +99,8 @@ def main():
                                                                   "(about 6 core-hours)")
     a = ap.parse_args()
     t0 = time.time()
-    scene = make_scene(a.views, a.segments, N, seed=SEED)
-    o = op.OracleLine3D(matching_neighbors=N)
+    scene = make_scene(a.views, a.segments, a.neighbors, seed=a.seed)
+    o = op.OracleLine3D(matching_neighbors=a.neighbors)
     for v in scene.views:
         o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
     print("scene + collinearity %.1f s" % (time.time() - t0), flush=True)
@@ -107,11 +109,11 @@ def main():
     o.matched, o.potential, o.result = {}, {}, []
     o.find_visual_neighbors()
     o.transform_geometry()
-    g = {"shape": np.array([a.views, a.segments, N, SEED], np.int64)}
+    g = {"shape": np.array([a.views, a.segments, a.neighbors, a.seed], np.int64)}
     kept_sha, kept_n, medians = [], [], []
     cache = dict(np.load(a.cache)) if a.cache and os.path.exists(a.cache) else None
     if cache is not None:
-        assert [int(x) for x in cache["shape"]] == [a.views, a.segments, N, SEED]
+        assert [int(x) for x in cache["shape"]] == [a.views, a.segments, a.neighbors, a.seed]
     store = {"shape": g["shape"]}
     for v in sorted(o.visual_neighbors):                      # match_views, line3D.cc:620-648
         if len(o.visual_neighbors[v]) == 0:

@@ -1,7 +1,8 @@
-"""matchViews at BASELINE configs[2]'s size -- 512 views x 2000 segments x 12 neighbours, seed 20260 (the scene bench.py grows to at 8 GPUs,
-and the one on which round 4 found pairs the stage-1 bounds decided against the exact test) -- against tests/golden/config3_matching.npz, which the
-ORACLE ALONE produced (tests/golden/make_golden_config2.py --views 512 --matching-only: no GPU input; about 6 core-hours, so it is a committed
-fixture): every view's kept list bit for bit (sha256 of the 32-byte records, cudawrapper.cu:1089-1110) and its median depth (:1058-1076)."""
+"""matchViews of whole scenes against the ORACLE ALONE (tests/golden/make_golden_config2.py --matching-only: no GPU input anywhere; committed fixtures):
+every view's kept list bit for bit (sha256 of the 32-byte records, cudawrapper.cu:1089-1110) and its median depth (:1058-1076).
+* config3_matching.npz: BASELINE configs[2]'s size, 512 views x 2000 segments x 12 neighbours, seed 20260 -- the scene bench.py grows to at 8 GPUs, and the
+  one on which round 4 found pairs the stage-1 bounds decided against the exact test (6 core-hours of the oracle; 35 898 004 kept matches);
+* shape_200x1000x8_matching.npz, shape_120x2500x14_matching.npz: other proportions (8 and 14 neighbours, 1000 and 2500 segments per view)."""
 import hashlib
 import os
 
@@ -10,21 +11,23 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_matching.npz")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def test_config3_512_views_every_kept_list_and_median_equals_the_oracles():
-    if not os.path.exists(GOLDEN):
-        pytest.fail("tests/golden/config3_matching.npz is missing: run tests/golden/make_golden_config2.py --views 512 --matching-only --out tests/golden/config3_matching.npz")
-    golden = np.load(GOLDEN)
+# (file, kept matches of the whole run): configs[2]'s scene, and two shapes of other proportions (neighbour counts 8 and 14, 1000 and 2500 segments)
+@pytest.mark.parametrize("name,kept_total", [("config3_matching.npz", 35898004), ("shape_200x1000x8_matching.npz", None), ("shape_120x2500x14_matching.npz", None)])
+def test_every_kept_list_and_median_equals_the_oracles(name, kept_total):
+    path = os.path.join(GOLDEN_DIR, name)
+    if not os.path.exists(path):
+        pytest.fail("tests/golden/%s is missing: run tests/golden/make_golden_config2.py --matching-only with the shape in its name" % name)
+    golden = np.load(path)
     from line3d_amd.pipeline import Line3D, load_scene
     from line3d_amd.synth import make_scene
     V, S, N, seed = (int(x) for x in golden["shape"])
-    assert (V, S, N) == (512, 2000, 12)
     scene = make_scene(V, S, N, seed=seed)
     l = Line3D("", matchingNeighbors=N)
     l.keep_view_matches(True)
@@ -41,6 +44,8 @@ def test_config3_512_views_every_kept_list_and_median_equals_the_oracles():
             if int(golden["kept_n"][k]) and k + 1 < len(scene.views):      # the early-return view leaves the median untouched (cudawrapper.cu:877-878)
                 assert np.float32(med) == golden["median"][k], "view %d: median" % v["id"]
             total += len(m)
-        assert total == int(golden["kept_n"].sum()) == 35898004
+        assert total == int(golden["kept_n"].sum()) > 500000
+        if kept_total is not None:
+            assert total == kept_total
     finally:
         l.close()
