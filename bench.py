@@ -160,6 +160,32 @@ def cpu_baseline(scene, n_neighbors, sample_segments, lists=None):
     return out
 
 
+def profile_for_shape(kind, segments, neighbors):
+    """profiles/<round>_<kind>.json of the newest round that has one: per-kernel PMC figures of this same command (scripts/measure_round.sh),
+    stamped with the commit they were measured on -- NOT measured in this run."""
+    # A per-launch instruction count / byte count is a property of the per-view SHAPE (segments, neighbours): only a summary collected on
+    # this run's shape is used (`_shape` = [views, segments, neighbours] stamped by scripts/make_*.py; absent = the default 64 x 2000 x 12);
+    # with none, roofline.frac is null and says why -- never a fraction from another shape's counters.
+    import glob
+    import re
+    found = []
+    for q in glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % kind)):
+        m = re.match(r"r(\d+)_(?:[A-Za-z0-9]+_)?%s\.json$" % kind, os.path.basename(q))
+        if not m:
+            continue
+        try:
+            d = json.load(open(q))
+        except (OSError, ValueError):
+            continue
+        shp = d.get("_shape", [64, 2000, 12])
+        if (int(shp[1]), int(shp[2])) == (segments, neighbors):
+            found.append((int(m.group(1)), q, d))
+    if not found:
+        return {}, None
+    _r, q, d = max(found, key=lambda t: (t[0], t[1]))
+    return d, "profiles/%s @%s shape %s" % (os.path.basename(q), d.get("_commit", "unstamped"), "x".join(str(x) for x in d.get("_shape", [64, 2000, 12])))
+
+
 def workload_name(n_gpus, V, S, N):
     """which BASELINE.json config the shape is"""
     if (S, N) == (2000, 12):
@@ -337,18 +363,8 @@ def main():
         value = pairs_total * args.steps / dt
         # dominant kernel = the one with the largest summed duration on this rank
         roof = None
-        def prof_json(kind):
-            """profiles/<round>_<kind>.json of the newest round that has one: per-kernel PMC figures of this same command (scripts/measure_round.sh),
-            stamped with the commit they were measured on -- NOT measured in this run."""
-            for r in ("r4", "r3", "r2", "r1"):
-                q = os.path.join(ROOT, "profiles", "%s_%s.json" % (r, kind))
-                if os.path.exists(q):
-                    d = json.load(open(q))
-                    return d, "profiles/%s_%s.json @%s" % (r, kind, d.get("_commit", "unstamped"))
-            return {}, None
-
-        traffic_json, traffic_src = prof_json("traffic")
-        valu_json, valu_src = prof_json("valu")
+        traffic_json, traffic_src = profile_for_shape("traffic", args.segments, args.neighbors)
+        valu_json, valu_src = profile_for_shape("valu", args.segments, args.neighbors)
         # wave64 VALU instructions/s the chip can issue: 256 CUs x 4 SIMD-32s x 2.4 GHz, one wave64 instruction per SIMD every 2 cycles
         # (MI355X_MICROARCH.md, constants table: `v_fma_f32` (wave64) 2 cyc; 4 is what ONE wave alone sustains).  Equivalent to the 157.3 TFLOP/s
         # FP32 vector peak (64 lanes x 2 flop per FMA).  Transcendental / rcp / sqrt instructions cost twice that; the count below is unweighted,
@@ -385,8 +401,10 @@ def main():
                            note="issue fraction: SQ_INSTS_VALU per launch (rocprofv3 --pmc pass of this command, committed under profiles/ at the commit "
                                 "named in `source`) / launch duration by HIP events in this run / (256 CUs x 4 SIMD-32s x 2.4 GHz / 2 cycles per wave64 instruction)")
             else:
-                out.update(achieved=hbm_achieved, peak=8000.0, unit="GB/s", frac=hbm_achieved / 8000.0, bound="hbm",
-                           note="no committed VALU profile found: the HBM figure stands in (the path is VALU bound, SURVEY 8d)")
+                out.update(achieved=None, peak=PEAK_ISSUE / 1e9, unit="G wave-instructions/s", frac=None,
+                           note="no committed PMC profile of this shape (%d segments, %d neighbours) under profiles/: the issue fraction is not computed from "
+                                "another shape's counters (scripts/measure_round.sh with L3D_SHAPE / L3D_BENCH_ARGS collects one); roofline.hbm below is live"
+                                % (args.segments, args.neighbors))
             # reference-formulation flops over the measured duration against the 157.3 TFLOP/s vector peak: an EQUIVALENT rate (the kernels run the
             # reference's arithmetic only on the pairs their conservative filters / depth windows cannot exclude)
             ref_flops = {"pair_mask": 370.0 * pairs_per_launch, "pair_fill": 360.0 * R_per_launch}.get(name)

@@ -55,6 +55,7 @@ int l3d_ctx_create(int device, l3d_ctx** out)
     l3d_ctx* c = new l3d_ctx();
     c->device = device;
     c->opt = options_from_env();                  // the one place the environment is read
+    c->ch_pin_res.flags = hipHostMallocCoherent;  // result records: written by kernels, read by the host behind unfenced events (l3d_ctx.hpp: get_local_event)
     publish_tunables(c->opt);
     c->chain_ring = c->opt.chain_ring != 0;
     c->wedge_pretest = c->opt.pretest & 7;         // diagnostic: stage-1 filter mask
@@ -85,7 +86,7 @@ int l3d_set_option(l3d_ctx* c, const char* name, int value)
     *f = value;
     publish_tunables(c->opt);
     c->chain_ring = c->opt.chain_ring != 0;
-    c->wedge_pretest = c->opt.pretest & 7;
+    c->wedge_pretest = c->opt.pretest & 7;        // (l3d_set_pair_pretest writes opt.pretest too: setting another option does not reset its mask)
     return L3D_OK;
 }
 
@@ -230,7 +231,7 @@ int l3d_unregister_segments(l3d_ctx* c, const float* segments)
 
 int l3d_set_chain_capacities(l3d_ctx* c, size_t cand_cap, size_t arena_cap) { if (!c) return L3D_ERR_INVALID; c->test_cand_cap = cand_cap; c->test_arena_cap = arena_cap; return L3D_OK; }
 int l3d_set_verify_lds_budget(size_t bytes) { verify_window_set_lds_budget(bytes); return L3D_OK; }
-int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 7) return L3D_ERR_INVALID; c->wedge_pretest = mask; return L3D_OK; }
+int l3d_set_pair_pretest(l3d_ctx* c, int mask) { if (!c || mask < 0 || mask > 7) return L3D_ERR_INVALID; c->wedge_pretest = mask; c->opt.pretest = mask; return L3D_OK; }
 int l3d_set_verify_mode(l3d_ctx* c, int mode) { if (!c || mode < 0 || mode > 1) return L3D_ERR_INVALID; c->verify_mode = mode; return L3D_OK; }
 int l3d_profile_enable(l3d_ctx* c, int on) { if (!c) return L3D_ERR_INVALID; c->prof_on = on != 0; return L3D_OK; }
 int l3d_profile_only(l3d_ctx* c, const char* kernel) { if (!c) return L3D_ERR_INVALID; c->prof_only = kernel ? kernel : ""; return L3D_OK; }
@@ -419,7 +420,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
 
     // stage 1 starts now; the host orders the existing matches meanwhile
     if (seg_end > seg_begin) {
-        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, maxW, st); }
+        { ProfScope p(c, "pair_mask"); launch_pair_mask(pa, maxW, st, c->opt.pair_spb); }
         { ProfScope p(c, "row_count"); launch_row_count(pa, c->rowcnt.as<int>(), st); }
     }
     TPHASE(0);
@@ -513,13 +514,13 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     if (c->verify_mode == 0 && verify_window_supported(N)) {
         // segments that fit the LDS image in one launch, the (few) bigger ones in a second launch on a global scratch
         int mfit = mmax;
-        while (mfit > 64 && verify_window_lds_bytes(mfit, N) > verify_window_max_lds()) mfit = mfit * 3 / 4;
+        while (mfit > 64 && verify_window_lds_bytes(mfit, N) > verify_window_max_lds(c->opt.vw_lds)) mfit = mfit * 3 / 4;
         va.mmax = mfit; va.skip_above = 1;
-        { ProfScope p(c, "verify_window"); launch_verify_window(va, st); }
+        { ProfScope p(c, "verify_window"); launch_verify_window(va, st, c->opt.vw_wide_max); }
         if (mfit < mmax) {
             HIPCHK(c, c->vw_scratch.reserve(((size_t)R + kVWSlack) * 16));
             va.big = 1; va.scratch = c->vw_scratch.as<float>(); va.scratch_stride = (long long)R + kVWSlack;
-            ProfScope p(c, "verify_window"); launch_verify_window(va, st);
+            ProfScope p(c, "verify_window"); launch_verify_window(va, st, c->opt.vw_wide_max);
         }
     } else { ProfScope p(c, "verify"); launch_verify(va, st); }
     { ProfScope p(c, "seg_post"); launch_seg_post(va, c->kept_cnt.as<int>(), c->best.as<float2>(), st); }

@@ -374,7 +374,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 if (fused_rows) pm.rowblk = vd[(size_t)k].rowblk;
                 // (own stream: the bit rows' ring slot was last used by view k - kRing, whose chain may still re-form its candidates from them)
                 if (sm != s1) for (int j = k - kRing; j >= 0; j -= kRing) if (ev[(size_t)j]) { HIPCHK(c, hipStreamWaitEvent(sm, ev[(size_t)j], 0)); break; }
-                { ProfScope p(c, "pair_mask", sm); launch_pair_mask(pm, vd[(size_t)k].maxW, sm); }
+                { ProfScope p(c, "pair_mask", sm); launch_pair_mask(pm, vd[(size_t)k].maxW, sm, c->opt.pair_spb); }
                 if (sm != s1) {
                     if (!evm[(size_t)k]) evm[(size_t)k] = get_local_event(c);
                     HIPCHK(c, hipEventRecord(evm[(size_t)k], sm));
@@ -446,7 +446,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                                     reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
-        if (!ev[(size_t)k]) ev[(size_t)k] = get_local_event(c);
+        // (with a delivery callback the host starts D2H copies of device memory once it has seen this event: a default, fenced event then)
+        if (!ev[(size_t)k]) ev[(size_t)k] = cb ? get_event(c) : get_local_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
         return L3D_OK;
     };
@@ -615,7 +616,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     (void)hipStreamSynchronize(s1);
     (void)hipStreamSynchronize(st);
     if (c->opt.timing) fprintf(stderr, "[l3d match_chain] hipSetDevice %.3f ms, final syncs %.3f ms\n", (t_setup0 - t_enter) * 1e3, (now_s() - t_tail0) * 1e3);
-    for (hipEvent_t e : ev) put_local_event(c, e);
+    for (hipEvent_t e : ev) { if (cb) put_event(c, e); else put_local_event(c, e); }
     for (hipEvent_t e : ev1) put_local_event(c, e);
     for (hipEvent_t e : evm) put_local_event(c, e);
     c->stats[1] = raw_sum;

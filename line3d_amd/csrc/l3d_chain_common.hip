@@ -217,7 +217,7 @@ void chain_launch_verify(l3d_ctx* c, VerifyArgs& va, const ChainViewDev& d, cons
     // LDS budget from the raw statistics (+ room for reverse matches); bigger segments take the global-scratch blocks
     // (raw_max_per_segment < 0: no statistics -- the largest image the budget allows; the budget, not the image, sets the occupancy)
     int mmax = raw_max_per_segment < 0 ? 16384 : raw_max_per_segment + raw_max_per_segment / 4 + 64;
-    while (mmax > 64 && verify_window_lds_bytes(mmax, va.N) > verify_window_max_lds()) mmax = mmax * 3 / 4;
+    while (mmax > 64 && verify_window_lds_bytes(mmax, va.N) > verify_window_max_lds(c->opt.vw_lds)) mmax = mmax * 3 / 4;
     va.mmax = mmax;
     if (va.seg_end <= va.seg_begin) return;
     if (c->verify_mode == 0 && verify_window_supported(va.N)) {
@@ -228,7 +228,7 @@ void chain_launch_verify(l3d_ctx* c, VerifyArgs& va, const ChainViewDev& d, cons
         va.kept_cnt = c->kept_cnt.as<int>(); va.best_depths = d.best;
         va.exist_cams = exist_cams; va.n_exist_cams = n_exist_cams;            // reverse-match runs are ordered by the segment's workgroup
         ProfScope p(c, "verify_window", st);
-        launch_verify_window(va, st);
+        launch_verify_window(va, st, c->opt.vw_wide_max);
     } else {
         va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
         va.kept_cnt = nullptr; va.best_depths = nullptr;

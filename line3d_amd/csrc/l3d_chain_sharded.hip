@@ -392,7 +392,7 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
         hipEvent_t ready = get_event(c);
         OCHK(hipEventRecord(ready, st));
         OCHK(hipStreamWaitEvent(c->stage1_stream, ready, 0));
-        c->event_pool.push_back(ready);
+        put_event(c, ready);
     }
     h->cand_cap = c->test_cand_cap ? c->test_cand_cap : chain_first_cand_cap(max_pairs);     // (l3d_set_chain_capacities: tests, retries with more room)
     { int rc = chain_reserve_candidates(c, L, h->cand_cap, l3d_shard_chain::kRingA); if (rc) return bail(rc); }
@@ -429,7 +429,7 @@ static int shard_stage1(l3d_shard_chain* h, int k)
             PairArgs pm = pa;
             pm.rowcnt = d.rowcnt;
             ProfScope p(c, "pair_mask", s1);
-            launch_pair_mask(pm, d.maxW, s1);
+            launch_pair_mask(pm, d.maxW, s1, c->opt.pair_spb);
         }
         // row starts of the stage-1 candidates of the rank's rows + their statistics straight into host-mapped memory (one launch)
         { ProfScope p(c, "scan", s1); launch_scan_range(d.rowcnt, d.rowA, h->views[k].N, d.s0, d.s1, h->views[k].S_src * h->views[k].N, nullptr, nullptr, s1, h->hstats_dev + 2 * k); }
@@ -535,7 +535,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         mix((unsigned long long)S); mix((unsigned long long)N); mix((unsigned long long)v.n_tbm); mix((unsigned long long)v.n_sources); mix((unsigned long long)v.view_id);
         mix((unsigned long long)d.s0); mix((unsigned long long)d.s1); mix((unsigned long long)d.o_sc); mix((unsigned long long)d.o_si); mix((unsigned long long)d.o_l2g);
         mix((unsigned long long)__float_as_uint_host(v.sigma_p)); mix((unsigned long long)__float_as_uint_host(v.sigma_a)); mix((unsigned long long)__float_as_uint_host(v.spatial_k));
-        mix((unsigned long long)c->verify_mode); mix((unsigned long long)verify_window_max_lds()); mix((unsigned long long)tunables().vw_wide_max.load()); mix((unsigned long long)c->opt.vw_debug);
+        mix((unsigned long long)c->verify_mode); mix((unsigned long long)verify_window_max_lds(c->opt.vw_lds)); mix((unsigned long long)c->opt.vw_wide_max); mix((unsigned long long)c->opt.vw_debug);
         if (G->exec && G->sig == sig) {
             if (hipGraphLaunch(G->exec, st) == hipSuccess) { ++c->shard_graph_launches; return L3D_OK; }
             (void)hipGetLastError();
@@ -993,9 +993,9 @@ int l3d_shard_chain_close(l3d_shard_chain* h)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stage1_stream);
     (void)hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : h->ev1) if (e) c->event_pool.push_back(e);
-    for (hipEvent_t e : h->ev2) if (e) c->event_pool.push_back(e);
-    if (h->ev3) c->event_pool.push_back(h->ev3);
+    for (hipEvent_t e : h->ev1) put_event(c, e);
+    for (hipEvent_t e : h->ev2) put_event(c, e);
+    put_event(c, h->ev3);
     c->stats[1] = h->raw_sum; c->stats[3] = h->kept_total;
     if (c->opt.timing)
         fprintf(stderr, "[l3d shard chain rank %d/%d] enqueue %.2f  exchange-call %.2f | fetch: wait %.2f  d2h %.2f  callback %.2f ms\n",

@@ -38,12 +38,14 @@ struct DevBuf {
 struct PinBuf {                     // pinned host staging (async copies that really are async)
     void* p = nullptr;
     size_t cap = 0;
+    unsigned flags = hipHostMallocDefault;      // hipHostMallocCoherent for buffers KERNELS write and the host reads behind an event (result records):
+                                                // explicit, so that HIP_HOST_COHERENT=0 in the environment cannot make them non-coherent
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 2 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, flags);
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -200,9 +202,11 @@ inline hipEvent_t get_event(l3d_ctx* c)
 // The single-GPU chain's events (view done, stage 1 done, ring slot free): created WITHOUT the system-scope acquire / release fences a default HIP
 // event carries -- 126 records per config-2 pass, each a cache write-back and invalidate the next kernels pay for (12.27 -> 12.0 ms per pass).  What they
 // order is (a) kernels on two streams of the SAME device (agent scope: the end-of-kernel release and the next kernel's acquire do that) and (b) the host
-// reading result records that the kernels write straight into pinned, coherent HOST memory (uncached on the device: nothing for a fence to write back;
-// the event's own signal is a later posted write on the same path).  Nothing the host reads after these events lives in device memory, and nothing
-// another device wrote is read behind them.  (Option event_fence = 1: default events here too, A/B.)
+// reading result records that the kernels write straight into pinned HOST memory allocated hipHostMallocCoherent (ch_pin_res: uncached on the device,
+// nothing for a fence to write back; the event's own signal is a later posted write on the same path).  That holds for the RESIDENT chain only: with a
+// delivery callback (l3d_match_chain) the host, having seen a view's event, starts D2H copies of DEVICE memory (the kept slice, the best depth pairs) on
+// another stream -- nothing but the event orders those copies behind the kernels, so run_chain takes default (fenced) events for its per-view events
+// whenever a callback is given.  Nothing another device wrote is read behind these events.  (Option event_fence = 1: default events everywhere, A/B.)
 inline hipEvent_t get_local_event(l3d_ctx* c)
 {
     if (c->opt.event_fence != 0) return get_event(c);
@@ -212,7 +216,13 @@ inline hipEvent_t get_local_event(l3d_ctx* c)
     if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { (void)hipGetLastError(); (void)hipEventCreate(&e); }
     return e;
 }
-inline void put_local_event(l3d_ctx* c, hipEvent_t e) { if (e) (c->opt.event_fence != 0 ? c->event_pool : c->local_event_pool).push_back(e); }
+inline void put_local_event(l3d_ctx* c, hipEvent_t e)
+{
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(c->event_mu);
+    (c->opt.event_fence != 0 ? c->event_pool : c->local_event_pool).push_back(e);
+}
+inline void put_event(l3d_ctx* c, hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lk(c->event_mu); c->event_pool.push_back(e); } }
 
 inline hipEvent_t get_prof_event(l3d_ctx* c)
 {
@@ -244,6 +254,7 @@ inline void prof_resolve(l3d_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->stage1_stream) (void)hipStreamSynchronize(c->stage1_stream);
     if (c->mask_stream) (void)hipStreamSynchronize(c->mask_stream);
+    std::lock_guard<std::mutex> lk(c->event_mu);         // (the pools and the pending lists: ProfScope of another enqueue thread takes it too)
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {
             float ms = 0.f;

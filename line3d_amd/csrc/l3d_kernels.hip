@@ -911,19 +911,18 @@ __global__ void k_test_math(const float* __restrict__ x, int n, float* __restric
 // Source segments per workgroup: kSrcPerBlock when that still fills the GPU, fewer for short source ranges (one rank's share
 // of a view in the sharded chain: 250 segments at 8 GPUs would be 192 workgroups walking 64 sources each -- a launch bound by
 // the latency of one workgroup).
-int pair_mask_src_per_block(int n_src, int maxW, int n_tbm)
+int pair_mask_src_per_block(int n_src, int maxW, int n_tbm, int forced)
 {
-    const int forced = tunables().pair_spb.load(std::memory_order_relaxed);
     if (forced > 0) return std::min(forced, kSrcPerBlock);
     const int tiles = (maxW + 255) / 256;
     int spb = kSrcPerBlock;
     while (spb > 8 && (long long)tiles * ((n_src + spb - 1) / spb) * n_tbm < 768) spb /= 2;
     return spb;
 }
-void launch_pair_mask(const PairArgs& a0, int maxW, hipStream_t st)
+void launch_pair_mask(const PairArgs& a0, int maxW, hipStream_t st, int forced_spb)
 {
     PairArgs a = a0;
-    a.src_per_block = pair_mask_src_per_block(a.seg_end - a.seg_begin, maxW, a.n_tbm);
+    a.src_per_block = pair_mask_src_per_block(a.seg_end - a.seg_begin, maxW, a.n_tbm, forced_spb);
     dim3 grid((maxW + 255) / 256, (a.seg_end - a.seg_begin + a.src_per_block - 1) / a.src_per_block, a.n_tbm);
     if (a.depth_in_fill) hipLaunchKernelGGL(k_pair_mask<false>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pair_mask<true>, grid, dim3(256), 0, st, a);

@@ -112,7 +112,8 @@ struct VerifyArgs {
 void warm_kernels(); void warm_verify_window(); void warm_rdd(); void warm_affinity(); void warm_linefit(); void warm_chain(); void warm_chain_sharded(); void warm_products(); void warm_sort();
 inline void touch_kernel(const void* f) { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, f); }
 
-void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st);
+// forced_spb / wide_max / vw_lds_opt: the context's own switches (options pair_spb, vw_wide_max, vw_lds) -- per context, not process-wide
+void launch_pair_mask(const PairArgs& a, int maxW, hipStream_t st, int forced_spb = 0);
 void launch_row_count(const PairArgs& a, int* rowcnt, hipStream_t st);
 void launch_exist_hist(const ExistRec* ex, int n, int N, int* rowcnt, hipStream_t st);
 struct RayJob {                     // one view of k_tgt_rays
@@ -126,9 +127,9 @@ void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, 
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);
-void launch_verify_window(const VerifyArgs& a, hipStream_t st);
+void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max = 640);
 size_t verify_window_lds_bytes(int mmax, int N);
-size_t verify_window_max_lds();
+size_t verify_window_max_lds(int vw_lds_opt = 0);
 bool verify_window_supported(int N);
 void verify_window_set_lds_budget(size_t bytes);
 void launch_seg_mmax(const int* row_start, int N, int seg_begin, int seg_end, int* out, hipStream_t st);

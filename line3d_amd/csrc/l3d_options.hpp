@@ -79,16 +79,17 @@ struct l3d_ctx;
 namespace l3d {
 const Options& ctx_options(const l3d_ctx* c);   // l3d_capi.hip: the switches of a context, for code that sees the context as an opaque handle (line3d_host.cpp)
 
-// switches read by code that has no context at hand (launch helpers, the host worker pool): process-wide, set from the
-// options of the last context created / the last l3d_set_option
+// the two switches read by code that is process-wide by nature (the ONE pool of host worker threads every context shares; the sleep of waiting
+// host threads): set from the options of the last context created / the last l3d_set_option.  Everything that shapes a LAUNCH (vw_lds,
+// vw_wide_max, pair_spb) is passed down from the launching context's own options -- a second context does not change the first one's launches.
 struct ProcessTunables {
-    std::atomic<int> vw_lds{0}, vw_wide_max{640}, pair_spb{0}, host_threads{0}, wait_sleep_us{20};
+    std::atomic<int> host_threads{0}, wait_sleep_us{20};
 };
 inline ProcessTunables& tunables() { static ProcessTunables t; return t; }
 inline void publish_tunables(const Options& o)
 {
     ProcessTunables& t = tunables();
-    t.vw_lds = o.vw_lds; t.vw_wide_max = o.vw_wide_max; t.pair_spb = o.pair_spb; t.host_threads = o.host_threads; t.wait_sleep_us = o.wait_sleep_us;
+    t.host_threads = o.host_threads; t.wait_sleep_us = o.wait_sleep_us;
 }
 
 }  // namespace l3d

@@ -414,11 +414,11 @@ size_t verify_window_lds_bytes_big(int N, int nt) { return (size_t)nt * N * 4 + 
 // workgroup on gfx950 once the kernel has opted in; runtimes that refuse the opt-in stay at the 48/64 KB default.
 static size_t g_lds_budget_override = 0;
 void verify_window_set_lds_budget(size_t bytes) { g_lds_budget_override = bytes; }
-size_t verify_window_max_lds()
+size_t verify_window_max_lds(int vw_lds_opt)
 {
     static size_t limit = 0;
     if (g_lds_budget_override) return g_lds_budget_override;
-    { const int e = tunables().vw_lds.load(std::memory_order_relaxed); if (e > 0) return (size_t)e; }     // diagnostic (L3D_VW_LDS): dynamic LDS budget in bytes
+    if (vw_lds_opt > 0) return (size_t)vw_lds_opt;     // diagnostic (L3D_VW_LDS): dynamic LDS budget in bytes
     if (limit) return limit;
     // Measured on MI355X (config 2): the kernel is latency bound and gains more from resident workgroups than from a
     // large LDS image -- 24 KB of dynamic LDS (+8 KB static -> 5 workgroups per CU, the VGPR limit) beats 48 KB by 8 %,
@@ -446,7 +446,7 @@ static bool lds_opt_in(const void* fn, int which)
     done[which][dev] = 1;
     return true;
 }
-void launch_verify_window(const VerifyArgs& a, hipStream_t st)
+void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max)
 {
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
@@ -454,7 +454,6 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st)
     // few segments (up to about two workgroups per CU): 8 waves per segment, if the wider per-lane maxima still fit
     // (replayed ranks, 2000 segments per view: 250 segments 90 -> 74 us per view, 500 segments 98 -> 94, 1000 segments 135 -> 196)
     const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
-    const int wide_max = tunables().vw_wide_max.load(std::memory_order_relaxed);
     if (nseg <= wide_max && lds512 <= 60 * 1024) {
         if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<512>), 1)) return;
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);

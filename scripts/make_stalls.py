@@ -60,6 +60,7 @@ for k in sorted(tot):
         row["valu_insts_per_wave"] = round(vi / w, 1)
     out[k] = row
 out["_commit"] = os.environ.get("L3D_COMMIT", "unstamped")
+out["_shape"] = [int(x) for x in os.environ.get("L3D_SHAPE", "64,2000,12").split(",")]      # views, segments, neighbours of the profiled run
 out["_note"] = ("per-launch averages; *_CYCLES of the SQ in quad-cycles summed over waves; rocprofv3 serialises dispatches in counter mode: each kernel alone. "
                 "valu_pipe_frac = 2 cycles x SQ_INSTS_VALU / (chip cycles x 1024 SIMDs)")
 json.dump(out, sys.stdout, indent=1)

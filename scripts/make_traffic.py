@@ -40,4 +40,7 @@ if __name__ == "__main__":
         out[k] = dict(FETCH_SIZE_KB_per_launch=fk, WRITE_SIZE_KB_per_launch=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024, launches=max(n, n2),
                       note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, per-launch average")
     out["_commit"] = __import__("os").environ.get("L3D_COMMIT", "unstamped")      # (the GPU box has no .git: the caller passes the commit it sent)
+    # the shape the counters were collected on, "views,segments,neighbours" (L3D_SHAPE; absent: bench.py's default 64,2000,12): per-launch instruction
+    # counts and bytes are properties of the per-view shape (S, N) -- bench.py only prices a run against a profile of ITS shape
+    out["_shape"] = [int(x) for x in __import__("os").environ.get("L3D_SHAPE", "64,2000,12").split(",")]
     json.dump(out, sys.stdout, indent=1)

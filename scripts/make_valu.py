@@ -21,4 +21,7 @@ out = {k: dict(valu_wave_insts_per_launch=tot[k].get("SQ_INSTS_VALU", 0.0) / max
                note="SQ_INSTS_VALU / SQ_WAVES summed over all shader engines, per-launch average")
        for k in sorted(tot)}
 out["_commit"] = __import__("os").environ.get("L3D_COMMIT", "unstamped")      # (the GPU box has no .git: the caller passes the commit it sent)
+# the shape the counters were collected on, "views,segments,neighbours" (L3D_SHAPE; absent: bench.py's default 64,2000,12): per-launch instruction
+# counts and bytes are properties of the per-view shape (S, N) -- bench.py only prices a run against a profile of ITS shape
+out["_shape"] = [int(x) for x in __import__("os").environ.get("L3D_SHAPE", "64,2000,12").split(",")]
 json.dump(out, sys.stdout, indent=1)

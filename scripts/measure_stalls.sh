@@ -9,6 +9,7 @@ tag=${1:-r4}
 out=gpurun_out/${tag}_stalls
 mkdir -p $out
 export TMPDIR=/tmp
+xa=${L3D_BENCH_ARGS:-}      # (another shape: see scripts/measure_round.sh)
 rocprofv3 -L > $out/avail.txt 2>&1
 want=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
@@ -26,7 +27,7 @@ for set in "${want[@]}"; do
     if grep -qw "$c" $out/avail.txt; then have="$have $c"; else echo "counter $c not available on this box" >> $out/missing.txt; fi
   done
   if [ -n "$have" ]; then
-    rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/pass$p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/pass$p.err
+    rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/pass$p -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/pass$p.err
     f=$(find $out/pass$p -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && files="$files $f"
   fi
