@@ -157,6 +157,11 @@ typedef struct l3d_affinity_input {
 } l3d_affinity_input;
 int l3d_affinity_fill(l3d_ctx* ctx, const l3d_affinity_input* in, l3d_edge** edges, int* n_edges, int32_t** node_hyp, int* n_nodes,
                       int* n_candidates);
+/* The fill enumerates its candidates a block of source segments at a time (the reference walks them source by source, line3D.cc:996-1221), so
+ * neither the transient arrays nor any count of the whole fill is bound to 31 bits; *n_candidates above saturates at INT_MAX.  The 64-bit
+ * figures of the last fill on ctx: candidate pairs enumerated, candidates that passed their threshold (the list has two entries per passed
+ * candidate and IS bound to 2^31 entries, like the clustering stages behind it: L3D_ERR_UNSUPPORTED beyond). */
+int l3d_last_fill_counts(l3d_ctx* ctx, int64_t* n_candidates, int64_t* n_passed);
 
 /* The edge list Line3D::performClustering walks (clustering.cc:14-40; the merge loop itself: l3d_perform_clustering_device below), prepared on
  * the device: optionally performDiffusion (line3D.cc:1255-1303: replicator_dynamics_diffusion, then A(i,j) = A(j,i) =

@@ -267,6 +267,12 @@ class Context:
         self.lib.l3d_free(nodes)
         return A, node_hyp, nc.value
 
+    def last_fill_counts(self):
+        """(candidate pairs enumerated, candidates that passed their threshold) of the last affinity fill on this context, as 64-bit counts"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.l3d_last_fill_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def clustering_edges(self, edges, n_nodes, perform_diffusion=False, iters=10):
         """l3d_clustering_edges: (diffused, symmetrised) edge list in performClustering's stable ascending weight order."""
         edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)

@@ -244,11 +244,11 @@ __device__ __forceinline__ int pass_layout(const AffIn& a, long long e, bool val
     return __shfl(incl, 63);
 }
 
-__global__ __launch_bounds__(256) void k_aff_words(AffIn a, int* __restrict__ nwords)
+__global__ __launch_bounds__(256) void k_aff_words(AffIn a, int h0, int h1, int* __restrict__ nwords)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int si = blockIdx.x * 4 + wave;
-    if (si >= a.n_hyp) return;
+    const int si = h0 + blockIdx.x * 4 + wave;
+    if (si >= h1) return;
     const int d = a.hyp_dense[si];
     const long long pb = a.pot_start[d], pe = a.pot_start[d + 1];
     int words = 0;
@@ -261,11 +261,13 @@ __global__ __launch_bounds__(256) void k_aff_words(AffIn a, int* __restrict__ nw
     if (lane == 0) nwords[si] = words;
 }
 
-// kEmit = false: decide every flattened entry of every source; the ballots are stored (words), the candidates counted.
+// kEmit = false: decide every flattened entry of the sources [h0, h1); the ballots are stored (words), the candidates counted.
 // kEmit = true:  replay the words: candidate k of the source gets its pair, its weight (similarity * mean score
 //                [* collinearity weight]) or -1 when the weight does not pass the family's threshold.
+// word_off / cnt / item_off are indexed by the source; the words and the candidates of a launch are numbered from the offsets' own zero (a
+// block of sources at a time: affinity_fill_core).
 template <bool kEmit>
-__global__ __launch_bounds__(256) void k_aff_items(AffIn a, const int* __restrict__ word_off, unsigned long long* __restrict__ words,
+__global__ __launch_bounds__(256) void k_aff_items(AffIn a, int h0, int h1, const int* __restrict__ word_off, unsigned long long* __restrict__ words,
                                                    int* __restrict__ cnt, const int* __restrict__ item_off, int2* __restrict__ pairs,
                                                    float* __restrict__ wgt, float sigma_a, float two_log)
 {
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(256) void k_aff_items(AffIn a, const int* __restric
     __shared__ long long s_cs[4][64];
     __shared__ long long s_e[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int si = blockIdx.x * 4 + wave;
-    if (si >= a.n_hyp) return;
+    const int si = h0 + blockIdx.x * 4 + wave;
+    if (si >= h1) return;
     const int d = a.hyp_dense[si];
     const int vi = a.dview[d];
     const long long pb = a.pot_start[d], pe = a.pot_start[d + 1];
@@ -382,45 +384,60 @@ __global__ __launch_bounds__(256) void k_aff_items(AffIn a, const int* __restric
 }
 
 // first-touch numbering: a node is created the first time a hypothesis appears in a candidate that passed its threshold,
-// source before target (line3D.cc:1020-1048 and the two other families)
-__global__ void k_aff_first(const int2* __restrict__ pairs, const float* __restrict__ wgt, int n, int* __restrict__ first, int* __restrict__ kept)
+// source before target (line3D.cc:1020-1048 and the two other families).  Candidates are produced a block of sources at a time; the
+// position of a candidate in the whole enumeration is 64 bits wide (pos0 = the candidates in front of this block), so `first` holds
+// 2 * position + side as an unsigned 64-bit minimum and nothing here depends on the total fitting 31 bits.
+constexpr unsigned long long kFirstNone = ~0ull;
+__global__ void k_aff_first(const int2* __restrict__ pairs, const float* __restrict__ wgt, int n, unsigned long long pos0, unsigned long long* __restrict__ first, int* __restrict__ kept)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const bool on = wgt[k] > 0.0f;
     kept[k] = on ? 1 : 0;
-    if (on) { atomicMin(&first[pairs[k].x], 2 * k); atomicMin(&first[pairs[k].y], 2 * k + 1); }
+    if (on) { const unsigned long long p = 2ull * (pos0 + (unsigned long long)k); atomicMin(&first[pairs[k].x], p); atomicMin(&first[pairs[k].y], p + 1ull); }
 }
-__global__ void k_aff_posflag(const int* __restrict__ first, int n_hyp, int* __restrict__ posflag)
-{
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h < n_hyp && first[h] != 0x7fffffff) posflag[first[h]] = 1;
-}
-__global__ void k_aff_nodes(const int* __restrict__ first, const int* __restrict__ posrank, int n_hyp, int* __restrict__ node, int* __restrict__ node_hyp)
-{
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_hyp) return;
-    const int f = first[h];
-    const int nd = f != 0x7fffffff ? posrank[f] : -1;
-    node[h] = nd;
-    if (nd >= 0) node_hyp[nd] = h;
-}
-__global__ void k_aff_edges(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ erank, const int* __restrict__ node,
-                            int n, l3d_edge* __restrict__ A)
+// the candidates of a block that passed, appended to the list of all passed candidates (in enumeration order: erank = exclusive scan of kept)
+__global__ void k_aff_compact(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ erank, int n, int hyp_off,
+                              int2* __restrict__ out_pairs, float* __restrict__ out_w)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || !(wgt[k] > 0.0f)) return;
     const int r = erank[k];
-    const int na = node[pairs[k].x], nb = node[pairs[k].y];
-    A[2 * (size_t)r] = { na, nb, wgt[k] };
-    A[2 * (size_t)r + 1] = { nb, na, wgt[k] };
+    out_pairs[r] = make_int2(pairs[k].x + hyp_off, pairs[k].y + hyp_off);
+    out_w[r] = wgt[k];
 }
-__global__ void k_aff_fill(int* p, int n, int v)
+// node index = rank of a hypothesis' first position among all first positions: (first, hypothesis) sorted by first
+__global__ void k_aff_node_keys(const unsigned long long* __restrict__ first, int n_hyp, unsigned long long none_key, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hyp) return;
+    const unsigned long long f = first[h];
+    keys[h] = f == kFirstNone ? none_key : f;
+    vals[h] = (unsigned)h;
+}
+__global__ void k_aff_nodes(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals, int n_hyp, unsigned long long none_key,
+                            int* __restrict__ node, int* __restrict__ node_hyp, int* __restrict__ n_nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hyp) return;
+    const bool touched = keys[i] != none_key;
+    const int h = (int)vals[i];
+    node[h] = touched ? i : -1;
+    if (touched) { node_hyp[i] = h; if (i + 1 == n_hyp || keys[i + 1] == none_key) *n_nodes = i + 1; }
+}
+__global__ void k_aff_edges(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ node, long long n, l3d_edge* __restrict__ A)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int na = node[pairs[r].x], nb = node[pairs[r].y];
+    A[2 * (size_t)r] = { na, nb, wgt[r] };
+    A[2 * (size_t)r + 1] = { nb, na, wgt[r] };
+}
+__global__ void k_aff_fill64(unsigned long long* p, int n, unsigned long long v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-
 }  // namespace l3d
 
 namespace {
@@ -439,10 +456,83 @@ int scan_excl(l3d_ctx* c, const int* in, int* out, int n, hipStream_t st)
 
 namespace {
 
+// a device buffer grown WITHOUT losing its first `used` bytes (DevBuf::reserve drops the content)
+int grow_keep(l3d_ctx* c, DevBuf& b, size_t bytes, size_t used, hipStream_t st)
+{
+    if (bytes <= b.cap) return L3D_OK;
+    const size_t want = bytes + bytes / 2 + 4096;
+    void* np = nullptr;
+    if (hipMalloc(&np, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, L3D_ERR_NOMEM, "affinity fill: growing the list of passed candidates to " + std::to_string(want >> 20) + " MB"); }
+    if (used && b.p) { HIPCHK(c, hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, st)); HIPCHK(c, hipStreamSynchronize(st)); }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np; b.cap = want;
+    return L3D_OK;
+}
+
+// First-touch node numbering (line3D.cc:1020-1048 and the two other families) and the symmetric edge list from the candidates that passed,
+// in enumeration order, with the first-touch minima of all hypotheses: node index = rank of a hypothesis' first position among all first
+// positions (one sort of n_hyp 64-bit keys: nothing depends on the number of candidates), edges (a,b,w), (b,a,w) per passed candidate.
+int affinity_number_edges(l3d_ctx* c, const unsigned long long* first, int nh, const int2* pass_pairs, const float* pass_w, long long n_passed,
+                          l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out)
+{
+    hipStream_t st = c->stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (n_passed == 0) return L3D_OK;
+    // the edge list and everything behind it (diffusion, edge order, merge loop) count entries with 31 bits: reported, not wrapped
+    if (2 * n_passed > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "affinity fill: " + std::to_string(2 * n_passed) + " affinity entries -- the clustering stages take at most 2^31");
+    const size_t kb = al((size_t)nh * 8), vb = al((size_t)nh * 4);
+    size_t tb = 0;
+    HIPCHK(c, sort_pairs_u64_u32(nullptr, tb, nullptr, nullptr, nullptr, nullptr, nh, 0, 64, st));
+    HIPCHK(c, c->g5.reserve(2 * kb + 3 * vb + al(tb) + 1024));
+    unsigned char* sc = c->g5.as<unsigned char>();
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sc);
+    unsigned long long* keys2 = reinterpret_cast<unsigned long long*>(sc + kb);
+    unsigned* vals = reinterpret_cast<unsigned*>(sc + 2 * kb);
+    unsigned* vals2 = reinterpret_cast<unsigned*>(sc + 2 * kb + vb);
+    int* node = reinterpret_cast<int*>(sc + 2 * kb + 2 * vb);
+    void* tmp = sc + 2 * kb + 3 * vb;
+    int* d_nn = reinterpret_cast<int*>(sc + 2 * kb + 3 * vb + al(tb));
+    // (every real key is below 2^63: positions carry at most a rank in bits 44.. and twice a 43-bit count; the "never touched" key sorts last)
+    const unsigned long long none_key = 1ull << 63;
+    HIPCHK(c, hipMemsetAsync(d_nn, 0, 4, st));
+    hipLaunchKernelGGL(k_aff_node_keys, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, none_key, keys, vals);
+    HIPCHK(c, sort_pairs_u64_u32(tmp, tb, keys, keys2, vals, vals2, nh, 0, 64, st));
+    // node_hyp sits behind the edges in g6 (l3d_fit_labelled_clusters reads it there); at most nh nodes
+    HIPCHK(c, c->g6.reserve(al((size_t)n_passed * 2 * sizeof(l3d_edge)) + (size_t)nh * 4 + 512));
+    l3d_edge* dA = c->g6.as<l3d_edge>();
+    int* d_node_hyp = reinterpret_cast<int*>(c->g6.as<char>() + al((size_t)n_passed * 2 * sizeof(l3d_edge)));
+    hipLaunchKernelGGL(k_aff_nodes, dim3((nh + 255) / 256), dim3(256), 0, st, keys2, vals2, nh, none_key, node, d_node_hyp, d_nn);
+    hipLaunchKernelGGL(k_aff_edges, dim3((unsigned)((n_passed + 255) / 256)), dim3(256), 0, st, pass_pairs, pass_w, node, n_passed, dA);
+    int n_nodes = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_nodes, d_nn, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // (edges_out == nullptr: the list stays on the device only -- l3d_perform_clustering_device walks it there, l3d_resident_edges_get copies it)
+    l3d_edge* A = edges_out ? static_cast<l3d_edge*>(malloc((size_t)n_passed * 2 * sizeof(l3d_edge))) : nullptr;
+    int32_t* nh_out = static_cast<int32_t*>(malloc((size_t)n_nodes * 4 + 4));
+    if ((edges_out && !A) || !nh_out) { free(A); free(nh_out); return fail(c, L3D_ERR_NOMEM, "affinity fill: host allocation failed"); }
+    hipError_t e1 = A ? hipMemcpyAsync(A, dA, (size_t)n_passed * 2 * sizeof(l3d_edge), hipMemcpyDeviceToHost, st) : hipSuccess;
+    hipError_t e2 = hipMemcpyAsync(nh_out, d_node_hyp, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, st);
+    hipError_t e3 = hipStreamSynchronize(st);
+    hipError_t e4 = hipGetLastError();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        free(A); free(nh_out);
+        return fail(c, L3D_ERR_HIP, std::string("affinity fill: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4));
+    }
+    if (c->opt.timing) fprintf(stderr, "[l3d affinity] numbering + edges: %d nodes, %lld entries%s\n", n_nodes, 2 * n_passed, A ? " (downloaded)" : "");
+    if (edges_out) *edges_out = A;
+    *n_edges_out = (int)(2 * n_passed); *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
+    c->resident_edges = (int)(2 * n_passed);                                   // (the list stays in g6 for l3d_clustering_edges)
+    c->kept_edges = 0;
+    c->resident_nodes = n_nodes; c->resident_nodes_p = d_node_hyp;
+    c->resident_hyp = nh;
+    return L3D_OK;
+}
+
 // The fill proper, on tables that are already on the device (`a`: everything but dview / flags, which live in the context's scratch).
-// seg_base_h / vhb_h: host copies of the view tables (launch geometry).
+// seg_base_h / vhb_h: host copies of the view tables (launch geometry).  part != nullptr: a rank's part of a fill sharded by source key
+// (SURVEY 8e): candidates of the sources [h0, h1) only, left as the passed list + first-touch minima in the context (no numbering).
 int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int32_t* vhb_h, long long n_pot, long long n_coll, float sigma_a,
-                       l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
+                       l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out, const l3d::FillPart* part)
 {
     const int V = a.n_views, nh = a.n_hyp, nd = a.n_dense;
     hipStream_t st = c->stream;
@@ -500,84 +590,95 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     if (timing) fprintf(stderr, "[l3d affinity] %d launch(es) of k_aff_groups for %d views\n", n_launches, V);
     lap("reverse records + groups");
 
-    // ---- words, decisions, candidate offsets
+    // ---- words, decisions, candidates: a BLOCK OF SOURCES at a time.  The reference enumerates its candidates source by source (line3D.cc:996-1221);
+    // nothing in that order needs all of them at once, so the transient arrays -- decision words, candidate pairs and weights, their flags and
+    // ranks: 20 bytes per candidate -- are bounded by the block, and no count of the whole fill has to fit 31 bits (round 4 stopped at 2^30
+    // candidates: 256 x 4000 x 24).  Outer blocks are cut by decision WORDS (known before the decisions: 2^26 = 512 MB), inner blocks by the
+    // candidates the decisions counted (2^27 = 2.7 GB of transients; options aff_block / aff_word_block force small blocks in tests).
+    // What survives a block: the candidates that passed their threshold, appended in enumeration order (12 bytes each), and the 64-bit
+    // first-touch minimum per hypothesis.
+    const int h0 = part ? part->h0 : 0, h1 = part ? part->h1 : nh;
+    const unsigned long long pos_base = part ? part->pos_base : 0ull;
+    const int hyp_off = part ? part->hyp_off : 0;
     int* nwords = c->g1.as<int>();
     int* word_off = nwords + (nh + 2);
     int* cnt = word_off + (nh + 2);
     int* item_off = cnt + (nh + 2);
     HIPCHK(c, hipMemsetAsync(nwords, 0, ((size_t)nh + 2) * 4 * 4, st));
-    { ProfScope p(c, "aff_words", st); hipLaunchKernelGGL(k_aff_words, gsrc, dim3(256), 0, st, a, nwords); }
-    if (int rc = scan_excl(c, nwords, word_off, nh, st)) return rc;
-    int n_words = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_words, word_off + nh, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, c->g2.reserve(((size_t)n_words + 1) * 8));
+    HIPCHK(c, c->aff_first.reserve((size_t)nh * 8 + 64));
+    unsigned long long* first = c->aff_first.as<unsigned long long>();
+    hipLaunchKernelGGL(k_aff_fill64, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, kFirstNone);
+    c->fill_items = 0; c->fill_passed = 0;
     const float two_log = 2.0f * logf(0.01f);      // view.cc:376
-    { ProfScope p(c, "aff_decide", st);
-      hipLaunchKernelGGL(k_aff_items<false>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, sigma_a, two_log); }
-    if (int rc = scan_excl(c, cnt, item_off, nh, st)) return rc;
-    int n_items = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_items, item_off + nh, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    lap("words + decisions");
-    if (n_candidates_out) *n_candidates_out = n_items;
-    if (n_items == 0) return L3D_OK;
-    if (n_items > 0x3fffffff) return fail(c, L3D_ERR_NOMEM, "affinity fill: more than 2^30 candidate pairs");
-
-    // ---- candidates (similarity, thresholds), numbering, edges
-    HIPCHK(c, c->g3.reserve((size_t)n_items * 8 + 256));
-    HIPCHK(c, c->g4.reserve((size_t)n_items * 4 + 256));
-    int2* pairs = c->g3.as<int2>();
-    float* wgt = c->g4.as<float>();
-    { ProfScope p(c, "aff_emit", st);
-      hipLaunchKernelGGL(k_aff_items<true>, gsrc, dim3(256), 0, st, a, word_off, c->g2.as<unsigned long long>(), (int*)nullptr, item_off, pairs, wgt, sigma_a, two_log); }
-    // first[] n_hyp | node[] n_hyp | kept[] n_items+1 | erank[] n_items+1 | posflag[] 2 n_items+1 | posrank[] 2 n_items+1
-    const size_t ni = (size_t)n_items;
-    HIPCHK(c, c->g5.reserve(((size_t)nh * 2 + (ni + 1) * 2 + (2 * ni + 1) * 2) * 4 + 1024));
-    int* first = c->g5.as<int>();
-    int* node = first + nh;
-    int* kept = node + nh;
-    int* erank = kept + (ni + 1);
-    int* posflag = erank + (ni + 1);
-    int* posrank = posflag + (2 * ni + 1);
-    hipLaunchKernelGGL(k_aff_fill, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, 0x7fffffff);
-    HIPCHK(c, hipMemsetAsync(kept, 0, ((ni + 1) * 2 + (2 * ni + 1) * 2) * 4, st));
-    hipLaunchKernelGGL(k_aff_first, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, n_items, first, kept);
-    hipLaunchKernelGGL(k_aff_posflag, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, posflag);
-    if (int rc = scan_excl(c, kept, erank, n_items, st)) return rc;
-    if (int rc = scan_excl(c, posflag, posrank, 2 * n_items, st)) return rc;
-    int totals[2] = { 0, 0 };
-    HIPCHK(c, hipMemcpyAsync(&totals[0], erank + ni, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(&totals[1], posrank + 2 * ni, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const int n_kept = totals[0], n_nodes = totals[1];
-    lap("candidates + numbering");
-    if (n_kept == 0) return L3D_OK;
-    HIPCHK(c, c->g6.reserve((size_t)n_kept * 2 * sizeof(l3d_edge) + (size_t)n_nodes * 4 + 512));
-    l3d_edge* dA = c->g6.as<l3d_edge>();
-    int* d_node_hyp = reinterpret_cast<int*>(c->g6.as<char>() + al((size_t)n_kept * 2 * sizeof(l3d_edge)));
-    hipLaunchKernelGGL(k_aff_nodes, dim3((nh + 255) / 256), dim3(256), 0, st, first, posrank, nh, node, d_node_hyp);
-    hipLaunchKernelGGL(k_aff_edges, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, node, n_items, dA);
-    // (edges_out == nullptr: the list stays on the device only -- l3d_perform_clustering_device walks it there, l3d_resident_edges_get copies it)
-    l3d_edge* A = edges_out ? static_cast<l3d_edge*>(malloc((size_t)n_kept * 2 * sizeof(l3d_edge))) : nullptr;
-    int32_t* nh_out = static_cast<int32_t*>(malloc((size_t)n_nodes * 4 + 4));
-    if ((edges_out && !A) || !nh_out) { free(A); free(nh_out); return fail(c, L3D_ERR_NOMEM, "affinity fill: host allocation failed"); }
-    hipError_t e1 = A ? hipMemcpyAsync(A, dA, (size_t)n_kept * 2 * sizeof(l3d_edge), hipMemcpyDeviceToHost, st) : hipSuccess;
-    hipError_t e2 = hipMemcpyAsync(nh_out, d_node_hyp, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, st);
-    hipError_t e3 = hipStreamSynchronize(st);
-    hipError_t e4 = hipGetLastError();
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        free(A); free(nh_out);
-        return fail(c, L3D_ERR_HIP, std::string("affinity fill: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4));
+    long long n_items_total = 0, n_passed = 0;
+    if (h1 > h0) {
+        const dim3 gpart((h1 - h0 + 3) / 4);
+        { ProfScope p(c, "aff_words", st); hipLaunchKernelGGL(k_aff_words, gpart, dim3(256), 0, st, a, h0, h1, nwords); }
+        std::vector<int> h_nwords((size_t)(h1 - h0)), h_cnt;
+        HIPCHK(c, hipMemcpyAsync(h_nwords.data(), nwords + h0, (size_t)(h1 - h0) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        const long long word_budget = c->opt.aff_word_block > 0 ? c->opt.aff_word_block : (1ll << 26);
+        const long long cand_budget = c->opt.aff_block > 0 ? c->opt.aff_block : (1ll << 27);
+        int n_wblocks = 0, n_cblocks = 0;
+        for (int w0 = h0; w0 < h1;) {
+            long long nw = 0;
+            int w1 = w0;
+            while (w1 < h1 && (w1 == w0 || nw + h_nwords[(size_t)(w1 - h0)] <= word_budget)) { nw += h_nwords[(size_t)(w1 - h0)]; ++w1; }
+            if (nw > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "affinity fill: one source segment's candidate walk takes more than 2^31 decision words");
+            ++n_wblocks;
+            if (int rc = scan_excl(c, nwords + w0, word_off + w0, w1 - w0, st)) return rc;
+            HIPCHK(c, c->g2.reserve(((size_t)nw + 1) * 8));
+            { ProfScope p(c, "aff_decide", st);
+              hipLaunchKernelGGL(k_aff_items<false>, dim3((w1 - w0 + 3) / 4), dim3(256), 0, st, a, w0, w1, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, sigma_a, two_log); }
+            h_cnt.resize((size_t)(w1 - w0));
+            HIPCHK(c, hipMemcpyAsync(h_cnt.data(), cnt + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            for (int g0 = w0; g0 < w1;) {
+                long long ni = 0;
+                int g1 = g0;
+                while (g1 < w1 && (g1 == g0 || ni + h_cnt[(size_t)(g1 - w0)] <= cand_budget)) { ni += h_cnt[(size_t)(g1 - w0)]; ++g1; }
+                if (ni > 0x3ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "affinity fill: one source segment has more than 2^30 candidate pairs");
+                if (ni > 0) {
+                    ++n_cblocks;
+                    const int n_items = (int)ni;
+                    if (int rc = scan_excl(c, cnt + g0, item_off + g0, g1 - g0, st)) return rc;
+                    HIPCHK(c, c->g3.reserve((size_t)n_items * 8 + 256));
+                    HIPCHK(c, c->g4.reserve((size_t)n_items * 4 + 256));
+                    int2* pairs = c->g3.as<int2>();
+                    float* wgt = c->g4.as<float>();
+                    { ProfScope p(c, "aff_emit", st);
+                      hipLaunchKernelGGL(k_aff_items<true>, dim3((g1 - g0 + 3) / 4), dim3(256), 0, st, a, g0, g1, word_off, c->g2.as<unsigned long long>(), (int*)nullptr, item_off, pairs, wgt, sigma_a, two_log); }
+                    // kept[] n_items + 1 | erank[] n_items + 1
+                    HIPCHK(c, c->g5.reserve(((size_t)n_items + 1) * 2 * 4 + 1024));
+                    int* kept = c->g5.as<int>();
+                    int* erank = kept + ((size_t)n_items + 1);
+                    HIPCHK(c, hipMemsetAsync(kept + n_items, 0, 4, st));
+                    hipLaunchKernelGGL(k_aff_first, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, n_items, pos_base + (unsigned long long)n_items_total, first, kept);
+                    if (int rc = scan_excl(c, kept, erank, n_items, st)) return rc;
+                    int n_kept_blk = 0;
+                    HIPCHK(c, hipMemcpyAsync(&n_kept_blk, erank + n_items, 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    if (n_kept_blk > 0) {
+                        if (int rc = grow_keep(c, c->aff_pass_pairs, (size_t)(n_passed + n_kept_blk) * 8 + 256, (size_t)n_passed * 8, st)) return rc;
+                        if (int rc = grow_keep(c, c->aff_pass_w, (size_t)(n_passed + n_kept_blk) * 4 + 256, (size_t)n_passed * 4, st)) return rc;
+                        hipLaunchKernelGGL(k_aff_compact, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, n_items, hyp_off,
+                                           c->aff_pass_pairs.as<int2>() + n_passed, c->aff_pass_w.as<float>() + n_passed);
+                    }
+                    n_items_total += n_items; n_passed += n_kept_blk;
+                }
+                g0 = g1;
+            }
+            w0 = w1;
+        }
+        if (timing) fprintf(stderr, "[l3d affinity] sources %d..%d in %d word block(s), %d candidate block(s): %lld candidates, %lld passed\n", h0, h1, n_wblocks, n_cblocks, n_items_total, n_passed);
     }
-    lap(A ? "edges + download" : "edges");
-    if (edges_out) *edges_out = A;
-    *n_edges_out = 2 * n_kept; *node_hyp_out = nh_out; *n_nodes_out = n_nodes;
-    c->resident_edges = 2 * n_kept;                                            // (the list stays in g6 for l3d_clustering_edges)
-    c->kept_edges = 0;
-    c->resident_nodes = n_nodes; c->resident_nodes_p = d_node_hyp;
-    c->resident_hyp = nh;
-    return L3D_OK;
+    HIPCHK(c, hipStreamSynchronize(st));
+    { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("affinity fill: ") + hipGetErrorString(e_)); }
+    lap("words + decisions + candidates");
+    c->fill_items = n_items_total; c->fill_passed = n_passed;
+    if (n_candidates_out) *n_candidates_out = (int)std::min<long long>(n_items_total, 0x7fffffffll);      // (l3d_last_fill_counts has the 64-bit figures)
+    if (part) return L3D_OK;            // (a rank's part of a sharded fill: the caller puts the parts together, then affinity_number_edges)
+    return affinity_number_edges(c, first, nh, c->aff_pass_pairs.as<int2>(), c->aff_pass_w.as<float>(), n_passed, edges_out, n_edges_out, node_hyp_out, n_nodes_out);
 }
 
 }  // namespace
@@ -649,7 +750,15 @@ int l3d_affinity_fill(l3d_ctx* c, const l3d_affinity_input* in, l3d_edge** edges
     a.coll_start = reinterpret_cast<const long long*>(base + o_cs);
     a.coll_other = reinterpret_cast<const int*>(base + o_co);
     a.coll_w = reinterpret_cast<const float*>(base + o_cw);
-    return affinity_fill_core(c, a, in->seg_base, in->view_hyp_begin, n_pot, n_coll, in->sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out);
+    return affinity_fill_core(c, a, in->seg_base, in->view_hyp_begin, n_pot, n_coll, in->sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out, nullptr);
+}
+
+int l3d_last_fill_counts(l3d_ctx* c, int64_t* n_candidates, int64_t* n_passed)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (n_candidates) *n_candidates = c->fill_items;
+    if (n_passed) *n_passed = c->fill_passed;
+    return L3D_OK;
 }
 
 // The same fill on the resident tables: hypotheses (l3d_products_hypotheses), potential correspondences and best matches
@@ -706,9 +815,9 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
     a.coll_other = reinterpret_cast<const int*>(cb + o_co);
     a.coll_w = reinterpret_cast<const float*>(cb + o_cw);
     if ((int)P.view_hyp_begin.size() != V + 1) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: hypothesis ranges missing");
-    return affinity_fill_core(c, a, P.seg_base.data(), P.view_hyp_begin.data(), P.n_pot, n_coll, sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out);
+    return affinity_fill_core(c, a, P.seg_base.data(), P.view_hyp_begin.data(), P.n_pot, n_coll, sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out, nullptr);
 }
 
 }  // extern "C"
 
-void l3d::warm_affinity() { touch_kernel(reinterpret_cast<const void*>(&k_aff_fill)); }
+void l3d::warm_affinity() { touch_kernel(reinterpret_cast<const void*>(&k_aff_fill64)); }

@@ -107,6 +107,11 @@ struct Products {
 // launches depend on, seen = passes in a row with that checksum
 struct ShardGraph { unsigned long long sig = 0; int seen = 0; hipGraphExec_t exec = nullptr; };
 
+// a rank's part of an affinity fill sharded by source key (l3d_affinity.hip: affinity_fill_core): the sources it enumerates, where its
+// candidates stand in the whole enumeration (ranks own ascending source ranges: rank << 44 orders them without knowing the other ranks' counts)
+// and what turns its local hypothesis indices into global ones
+struct FillPart { int h0, h1; unsigned long long pos_base; int hyp_off; };
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -149,6 +154,8 @@ struct l3d_ctx {
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
     l3d::DevBuf aff_hyp;            // hypothesis table of the last l3d_affinity_fill (kept for l3d_fit_clusters)
+    l3d::DevBuf aff_first, aff_pass_pairs, aff_pass_w;   // affinity fill in blocks of sources: first-touch minima per hypothesis, the candidates that passed (pairs, weights)
+    long long fill_items = 0, fill_passed = 0;           // candidates enumerated / passed by the last fill (64-bit: l3d_last_fill_counts)
     int resident_hyp = 0;           // its number of hypotheses (0: none)
     int resident_edges = 0;         // entries of the edge list l3d_affinity_fill left in g6 (0: none); consumed by l3d_clustering_edges
     int resident_nodes = 0;         // nodes of that list; resident_nodes_p: their hypothesis indices (behind the edges in g6)

@@ -48,8 +48,11 @@ if want_finish:
     try:
         t0 = time.perf_counter()
         l.finish(False)
-        out.update(finish_s=round(time.perf_counter() - t0, 3), lines=int(l.stats()["lines"]), edges=int(l.stats()["edges"]), hbm_after_finish_gb=hbm_used_gb()[0])
+        cand, passed = l.context().last_fill_counts()
+        out.update(finish_s=round(time.perf_counter() - t0, 3), lines=int(l.stats()["lines"]), edges=int(l.stats()["edges"]), hbm_after_finish_gb=hbm_used_gb()[0],
+                   affinity_candidates=cand, affinity_passed=passed)
     except Exception as e:      # noqa: BLE001
-        out.update(finish_error=str(e)[:300])
+        cand, passed = l.context().last_fill_counts()
+        out.update(finish_error=str(e)[:300], affinity_candidates=cand, affinity_passed=passed, hbm_after_finish_gb=hbm_used_gb()[0])
 print(json.dumps(out))
 l.close()

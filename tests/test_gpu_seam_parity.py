@@ -398,14 +398,19 @@ def _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, co
     return A, node_hyp, n_cand
 
 
-@pytest.mark.parametrize("seed,one_way,chunk", [(1, 0.0, None), (2, 0.15, None), (3, 0.15, "3"), (4, 0.5, "1"), (5, 0.0, "2"), (6, 0.1, None)])
-def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib, monkeypatch, seed, one_way, chunk):
+@pytest.mark.parametrize("seed,one_way,chunk,blocks", [(1, 0.0, None, None), (2, 0.15, None, (300, 40)), (3, 0.15, "3", None), (4, 0.5, "1", (57, 1000000)), (5, 0.0, "2", (1000000, 7)),
+                                                       (6, 0.1, None, (1, 1))])
+def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib, monkeypatch, seed, one_way, chunk, blocks):
     """l3d_affinity_fill on random flat tables -- clustered hypotheses so that many similarities pass, long target groups,
     targets without a hypothesis, collinearity lists that are NOT symmetric, potential correspondences recorded one way only
     (`one_way`: the schedule then waits for earlier views) -- against the reference's loops with a literal `used` set.
-    Small passes (`chunk` targets) make groups and flattened entries straddle passes."""
+    Small passes (`chunk` targets) make groups and flattened entries straddle passes.  `blocks` = (candidate pairs, decision words) per block of
+    sources: the fill enumerates a block of sources at a time (round 5: no count of the whole fill is bound to 31 bits) -- tiny budgets give one
+    source per block, and the node numbering (rank of the 64-bit first-touch positions) and the edge list must not notice."""
     from line3d_amd.capi import HYP_DTYPE
     gpu_ctx.set_option("L3D_AFF_CHUNK", int(chunk) if chunk else 0)       # (a switch of the context; the environment is read once, at its creation)
+    gpu_ctx.set_option("L3D_AFF_BLOCK", blocks[0] if blocks else 0)
+    gpu_ctx.set_option("L3D_AFF_WORD_BLOCK", blocks[1] if blocks else 0)
     rng = np.random.default_rng(seed)
     V, S = 7, 40
     dense = seed == 6                    # groups of more than 64 targets and collinearity lists of more than 64 entries (64-lane passes)
@@ -467,6 +472,8 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
         A, node_hyp, n_cand = gpu_ctx.affinity_fill(seg_base, view_hyp_begin, hyp, score, hyp_dense, best, pot_start, pot_tgt, coll_start, coll_other, coll_w, 10.0)
     finally:
         gpu_ctx.set_option("L3D_AFF_CHUNK", 0)
+        gpu_ctx.set_option("L3D_AFF_BLOCK", 0)
+        gpu_ctx.set_option("L3D_AFF_WORD_BLOCK", 0)
     eA, e_nodes, e_cand = _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, coll, 10.0)
     assert n_cand == e_cand and len(eA) > 200
     assert node_hyp.tolist() == e_nodes
