@@ -111,6 +111,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
         fprintf(stderr, "[l3d verify_window wave-cycles] build %.1f%%  setup %.1f%%  scan %.1f%%  drain %.1f%%  final %.1f%%  (waves %llu, avg %.0f cycles)\n",
                 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, h[5], tot / (double)(h[5] ? h[5] : 1));
+        fprintf(stderr, "[l3d verify_window balance] the longest wave of all launches: %llu cycles = %.1f x the average wave\n", h[15], (double)h[15] / (tot / (double)(h[5] ? h[5] : 1)));
         fprintf(stderr, "[l3d verify_window walk] hypotheses %llu: entries walked per hypothesis %.2f, inside the d1 window %.2f, inside both windows %.2f, of another camera %.2f\n", h[14],
                 h[10] / (double)(h[14] ? h[14] : 1), h[11] / (double)(h[14] ? h[14] : 1), h[12] / (double)(h[14] ? h[14] : 1), h[13] / (double)(h[14] ? h[14] : 1));
         fprintf(stderr, "[l3d verify_window pairs] evaluated %llu  pass the 3-D gate %.1f%%  confidence > 0 %.1f%%  confidence > 0.5 %.1f%%\n", h[6], 100.0 * h[7] / (double)(h[6] ? h[6] : 1),

@@ -77,7 +77,7 @@ __global__ void k_exist_scatter(const Match* __restrict__ arena, const ChainResu
 // counting (keys are broadcast with shuffles, target ids inside a run are distinct) and writes them to their place.
 __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__ cams, int n_cams, int N, int S, int seg_begin, int seg_end,
                                                          const int* __restrict__ row_start, uint2* __restrict__ meta,
-                                                         float4* __restrict__ depths, int cap)
+                                                         float4* __restrict__ depths, int cap, float* stage, long long stage_stride, unsigned* stage_key)
 {
     if (row_start[(size_t)S * N] > cap) return;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
     if (t >= (seg_end - seg_begin) * n_cams) return;
     const int seg = seg_begin + t / n_cams, cam = cams[t % n_cams];
     const int b = row_start[seg * N + cam], n = row_start[seg * N + cam + 1] - b;
-    sort_exist_run(lane, b, n, cam, meta, depths);
+    sort_exist_run(lane, b, n, cam, meta, depths, stage, stage_stride, stage_key);      // (stage: the verification's scratch + confidence slots, unused until it runs)
 }
 
 // Stage-1 candidates of a view are written (k_pair_fill, stage-1 stream, well ahead of the chain) in their own
@@ -190,11 +190,11 @@ void launch_exist_scatter(const Match* arena, const ChainResult* res, const int*
     if (n_src > 0) hipLaunchKernelGGL(k_exist_scatter, dim3(32, n_src), dim3(256), 0, st, arena, res, src_index, src_cam, view_id, N, S, row_start, cursor, meta, depths, cap);
 }
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
-                            int seg_begin, int seg_end)
+                            int seg_begin, int seg_end, float* stage, long long stage_stride, unsigned* stage_key)
 {
     if (seg_end < 0) seg_end = S;
     const int runs = (seg_end - seg_begin) * n_cams;
-    if (runs > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((runs + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, seg_begin, seg_end, row_start, meta, depths, cap);
+    if (runs > 0) hipLaunchKernelGGL(k_exist_sort_runs, dim3((runs + 3) / 4), dim3(256), 0, st, cams, n_cams, N, S, seg_begin, seg_end, row_start, meta, depths, cap, stage, stage_stride, stage_key);
 }
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
@@ -424,7 +424,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             }
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");
-                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
+                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st, 0, -1,
+                                       c->vw_scratch.as<float>(), (long long)cand_cap + kVWSlack, c->cand_conf.as<unsigned>());
             }
         } else {
             if (S > 0) { ProfScope p(c, "pair_fill"); launch_pair_fill(pa, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st); }
@@ -432,7 +433,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             launch_exist_scatter(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, c->row_start.as<int>(),
                                  c->ch_cursor.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N)))
-                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st);
+                launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)cand_cap, st, 0, -1,
+                                       c->vw_scratch.as<float>(), (long long)cand_cap + kVWSlack, c->cand_conf.as<unsigned>());
         }
         VerifyArgs va = chain_verify_args(c, v, d, dtab, cand_cap);
         va.res = dres + k;

@@ -506,7 +506,8 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         }
         if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {          // (the window kernel orders the runs itself)
             ProfScope p(c, "exist");
-            launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1);
+            launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1,
+                                   c->vw_scratch.as<float>(), (long long)h->cand_cap + kVWSlack, c->cand_conf.as<unsigned>());
         }
         VerifyArgs va = chain_verify_args(c, v, d, dtab, h->cand_cap);
         chain_launch_verify(c, va, d, d_sc, v.n_sources, deferred ? -1 : h->hstats[2 * k + 1], h->cand_cap, st);

@@ -75,10 +75,42 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
 
 // One (segment, source camera) run of existing (reverse) matches, scattered in arbitrary order, into ascending target order:
 // one wave, ranks by all-to-all comparison in registers (runs are short; targets inside a run are distinct).
-__device__ __forceinline__ void sort_exist_run(int lane, int b, int n, int cam, uint2* meta, float4* depths)
+// Runs of more than 256 entries (dense scenes: 4000 segments x 24 neighbours keeps hundreds of matches per segment and camera): with a staging
+// area -- `stage`: 4 float arrays `stride` apart + `stage_key`, all indexed like the candidate arrays and unused at this point -- the wave copies the run
+// out (coalesced), ranks every element against all keys (chunks of 64 keys broadcast by shuffles, four own elements at a time) and writes it to its
+// place: O(n^2 / 64) compares per lane, no dependent chain.  Without one (the per-view seam path's separate launch) a single lane sorts in place.
+__device__ __forceinline__ void sort_exist_run(int lane, int b, int n, int cam, uint2* meta, float4* depths, float* stage = nullptr, long long stride = 0,
+                                               unsigned* stage_key = nullptr)
 {
     if (n < 2) return;
-    if (n > 256) {                                  // pathological run: one lane, in place
+    if (n > 256 && stage) {
+        float *s0 = stage + b, *s1 = stage + stride + b, *s2 = stage + 2 * stride + b, *s3 = stage + 3 * stride + b;
+        unsigned* sk = stage_key + b;
+        for (int i = lane; i < n; i += 64) { const float4 d = depths[b + i]; s0[i] = d.x; s1[i] = d.y; s2[i] = d.z; s3[i] = d.w; sk[i] = meta[b + i].x; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // (the staged copy is read back by other lanes of this wave: stores complete first)
+        for (int t0 = 0; t0 < n; t0 += 256) {
+            unsigned key[4];
+            int rank[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int i = t0 + lane + 64 * r; key[r] = i < n ? sk[i] : 0xffffffffu; }
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const unsigned mine = c0 + lane < n ? sk[c0 + lane] : 0xffffffffu;
+                const int cnt = min(64, n - c0);
+                for (int l = 0; l < cnt; ++l) {
+                    const unsigned other = __shfl(mine, l);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rank[q] += other < key[q];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = t0 + lane + 64 * r;
+                if (i < n) { meta[b + rank[r]] = make_uint2(key[r], (unsigned)cam); depths[b + rank[r]] = make_float4(s0[i], s1[i], s2[i], s3[i]); }
+            }
+        }
+        return;
+    }
+    if (n > 256) {                                  // pathological run without a staging area: one lane, in place
         if (lane == 0)
             for (int i = b + 1; i < b + n; ++i) {
                 const uint2 m = meta[i];

@@ -141,7 +141,7 @@ void launch_exist_count(const Match* arena, const ChainResult* res, const int* s
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
-                            int seg_begin = 0, int seg_end = -1);
+                            int seg_begin = 0, int seg_end = -1, float* stage = nullptr, long long stage_stride = 0, unsigned* stage_key = nullptr);
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st);

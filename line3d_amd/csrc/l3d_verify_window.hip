@@ -146,7 +146,8 @@ void k_verify_window(VerifyArgs a)
         for (int t = wave; t < a.n_exist_cams; t += NW) {
             const int cam = a.exist_cams[t];
             const int b = a.row_start[y * a.N + cam], n = a.row_start[y * a.N + cam + 1] - b;
-            sort_exist_run(lane, b, n, cam, meta_w, depths_w);
+            // (the segment's slices of the scratch and of the confidence array are not in use yet: the staging area of a long run)
+            sort_exist_run(lane, b, n, cam, meta_w, depths_w, a.scratch, a.scratch_stride, a.scratch ? reinterpret_cast<unsigned*>(a.cand_conf) : nullptr);
         }
         __threadfence_block();
         __syncthreads();
@@ -291,7 +292,7 @@ void k_verify_window(VerifyArgs a)
         const float lo1 = d1y - w1, hi1 = d1y + w1;
         int j = 0, jend = 0;
         if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
-        if (a.stamps) {                                                  // diagnostic: entries walked, of them inside the d1 window / inside both windows
+        if (a.stamps && a.debug == 9) {                                  // diagnostic (L3D_VW_DEBUG=9 on top of the stamps: this loop distorts the phase split): entries walked, of them inside the d1 window / inside both windows
             int n_in = 0, n_in1 = 0, n_in2 = 0, n_oth = 0;
             for (int e = j; e < jend; ++e) {
                 ++n_in;
@@ -393,6 +394,7 @@ void k_verify_window(VerifyArgs a)
     if (a.stamps && lane == 0) {
         for (int k = 0; k < 5; ++k) atomicAdd(&a.stamps[k], t_acc[k]);
         atomicAdd(&a.stamps[5], 1ull);
+        atomicMax(&a.stamps[15], t_acc[0] + t_acc[1] + t_acc[2] + t_acc[3] + t_acc[4]);       // the longest wave: a launch lasts as long as its longest segment
     }
 #undef VW_STAMP
 }
