@@ -365,14 +365,51 @@ long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
  * rank r-1's is and the `window` views in front of B_r came out of r's warm-up exactly as r-1 computed them (from B_r on every view then
  * has the one chain's inputs).  Every rank reads the same table and reaches the same verdict.  *verdict = 0: the ranks all-gathered
  * their blocks (view = -2) and THIS context now holds matchViews' products exactly as after l3d_match_chain_resident over all views
- * (arena, potential correspondences, best matches, medians; summary / n_pot as there).  *verdict = 1: the speculation did not hold (or
- * warmup_views < window, or a block is shorter than the window): nothing was committed, run l3d_shard_chain_run instead.
+ * (arena, potential correspondences, best matches, medians; summary / n_pot as there).  A block whose speculation did NOT hold is repaired, not
+ * abandoned (round 5): the first inexact rank takes over its predecessor's last `window` views -- true by then; records, best depth pairs and
+ * positions, one all-gather, view = -5 -- and re-runs its block warm from them; the digests are exchanged again, until every rank is exact (at most
+ * world rounds; a warm-up shorter than the window simply makes a rank take that path).  *verdict = 1 only when a block is shorter than the window
+ * (it cannot vouch for its successor's sources) or option block_recover = 0 (the round-4 behaviour): nothing was committed, run l3d_shard_chain_run.
  * No per-view collective: four data exchanges per pass (digests; blocks; view = -4 the pieces of the products table, of which every rank
  * builds the rows of its own block) and three 256-byte ones of status words (view = -3; the second carries the sizes of the pieces): every step
  * only one rank can fail in (an allocation, a launch) is followed by one, so either all ranks enter the big collective behind it or all
  * return an error -- nobody is left waiting.  window = the largest distance between a view and one of its sources. */
 int l3d_match_chain_blocks(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
                            int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
+
+/* ---- Line3D::matchViews sharded by blocks of views with NOTHING REPLICATED (the configs[4] job: 2048 views x 4000 segments x 24 neighbours keep
+ * 6.4 G matches -- beyond a 32-bit record index and, with the table built from them, beyond one GPU's HBM; the reference streams a view at a time
+ * and spills every view's matches to a file, view.cc:150-224, line3D.cc:626-648).  Same speculation and verification as l3d_match_chain_blocks;
+ * but rank r runs its chain 2 x reach views PAST its block (reach = the largest distance, in chain positions, between a view and one of its
+ * neighbours) and is checked max(window, 2 x reach) views in front of it -- so it holds, computed by itself, the exact kept records of every view
+ * within 2 x reach of its block.  From those it builds, locally: the rows of potential_correspondences_ of the views within `reach` of its block
+ * (complete: a row needs the records of the view and of its neighbours), the best matches and medians of every view it holds.  That is all the
+ * affinity fill of ITS block's sources reads (l3d_affinity_fill_sharded).  No block is gathered, no piece of the table travels; the records that
+ * point at an early-return view (cudawrapper.cu:877-878: their entries are filed under LOCAL camera numbers read as view ids and can name any view
+ * of the scene) are all-gathered, each source's by the rank that owns it (view = -6).  *verdict = 0: the context holds this rank's share --
+ * l3d_chain_kept_list serves the views it holds (empty lists for the others), l3d_chain_products_get its rows (empty rows elsewhere; *n_pot = its
+ * entries), l3d_products_hypotheses numbers the hypotheses of the views it holds from 0 (l3d_affinity_fill_sharded makes the numbers global).
+ * *verdict = 1: as l3d_match_chain_blocks (only when a block is re-run more than `world` times or the schedule holds more than 64 early returns:
+ * a failed speculation is repaired by re-running that block warm, see there). */
+int l3d_match_chain_partition(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                              int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
+/* what this rank's share covers after l3d_match_chain_partition, in views of the dense map (8 ints: rank, world, own block [0,1), rows [2,3), held [4,5)),
+ * entries of the table over all ranks, blocks re-run warm in the whole job */
+int l3d_partition_info(l3d_ctx* ctx, int info[8], int64_t* n_pot_all, int* recovery_rounds);
+/* The fill SHARDED BY SOURCE KEY over the ranks of a job whose matchViews ran partitioned (l3d_match_chain_partition below): every
+ * rank enumerates the candidates of the sources of ITS block of views -- from the rows, best matches and hypotheses it holds, nothing of another
+ * rank is read -- and five small all-gathers (`exchange`, views -7 .. -10 and status words -3) make global what has to be: hypotheses per view
+ * (global hypothesis numbers), the first-touch minima per hypothesis (64-bit positions: rank << 44 | position inside the rank's enumeration), the
+ * candidates that passed their threshold (12 bytes each; concatenated in rank order = the reference's enumeration order, line3D.cc:996-1221) and
+ * the hypothesis table (read by the line fit).  Node numbering and the edge list are then formed by every rank from the same data: afterwards the
+ * context is in the state l3d_affinity_fill_resident(edges = NULL) leaves it in, with GLOBAL hypothesis numbers -- l3d_perform_clustering_device,
+ * l3d_fit_labelled_clusters, l3d_resident_edges_get, l3d_products_hypotheses_get follow unchanged (replicas).  Outputs: n_edges / node_hyp / n_nodes
+ * as l3d_affinity_fill_resident; n_candidates_all (may be NULL): candidate pairs enumerated by all ranks; view_hyp_begin_global (caller's,
+ * n_views + 1 of the dense map), hyp_dense_global (callee-allocated, l3d_free: dense segment id per global hypothesis), n_hyp_global.
+ * A rank that fails on its own still enters every collective with a mark, so all ranks return an error together. */
+int l3d_affinity_fill_sharded(l3d_ctx* ctx, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, float sigma_a,
+                              l3d_exchange_fn exchange, void* exchange_user, int* n_edges, int32_t** node_hyp, int* n_nodes,
+                              int64_t* n_candidates_all, int32_t* view_hyp_begin_global, int32_t** hyp_dense_global, int* n_hyp_global);
 
 /* ---- residency: keep a view's segments in HBM across calls ------------------------------------
  * The reference re-uploads every neighbour's segments for every view (line3D.cc:793-800).  A
@@ -487,10 +524,17 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);
 /* matchViews with the VIEWS sharded over the ranks in blocks, each block started cold a few neighbour windows early, the speculation verified
- * (l3d_match_chain_blocks above; warmup_views < 0: eight windows).  *verdict = 0: this rank holds matchViews' products as after the
+ * (l3d_match_chain_blocks above; warmup_views < 0: four windows -- a block whose speculation fails is re-run warm, not the pass).  *verdict = 0: this rank holds matchViews' products as after the
  * single-GPU resident chain -- compute3Dmodel goes on from there (l3d_line3d_finish); *verdict = 1 (identical on every rank): the speculation
  * did not hold, nothing was committed, run l3d_line3d_shard_run. */
 int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
+/* matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition; warmup_views < 0: four windows), and the rest of
+ * compute3Dmodel as a COLLECTIVE of the job's ranks: greedy selection on the views a rank holds, the affinity fill sharded by source key
+ * (l3d_affinity_fill_sharded), then -- every rank from the same affinity list -- diffusion, clustering, line fit: every rank ends with the whole
+ * result (Line3D::getResult).  l3d_line3d_finish on such an object is the same call with the exchange of the run; l3d_line3d_view_matches serves the
+ * views this rank holds.  exchange == NULL in finish_sharded: the one the run was given. */
+int l3d_line3d_partition_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
+int l3d_line3d_finish_sharded(l3d_line3d* h, int perform_diffusion, l3d_exchange_fn exchange, void* exchange_user);
 /* performClustering (clustering.h:125, clustering.cc:6-47) on the host (fallback and cross-check of l3d_perform_clustering_device): labels[k] = CLUniverse::find(k) */
 int l3d_perform_clustering(const l3d_edge* edges, int n_edges, int num_nodes, float c, int32_t* labels);
 /* Line3D::getResult (line3D.cc:377-381), flattened; Line3D::getSegment2D (line3D.cc:2004-2013) */

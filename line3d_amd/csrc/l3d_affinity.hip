@@ -144,7 +144,7 @@ __global__ void k_aff_validate(AffIn a, long long n_pot, long long n_coll, int* 
 // bit 2 of a source's entry: the target has an earlier hypothesis and records the source among its own targets (=> m-used).
 // needs_prev[view] is raised when a target with an earlier hypothesis lacks the reverse record: its m-used test reads bits of
 // earlier views.
-__global__ __launch_bounds__(256) void k_aff_sym(AffIn a, int* __restrict__ needs_prev)
+__global__ __launch_bounds__(256) void k_aff_sym(AffIn a, int* __restrict__ needs_prev, int assume_symmetric)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int si = blockIdx.x * 4 + wave;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_aff_sym(AffIn a, int* __restrict__ need
         const int t = a.pot_tgt[e];
         const int hb = a.best[t];
         if (hb >= 0 && hb < si) {
-            if (pot_has(a, t, d)) a.flags[e] = 4; else need = true;
+            if (assume_symmetric || pot_has(a, t, d)) a.flags[e] = 4; else need = true;
         }
     }
     if (__ballot(need) && lane == 0) needs_prev[a.dview[d]] = 1;
@@ -397,14 +397,20 @@ __global__ void k_aff_first(const int2* __restrict__ pairs, const float* __restr
     if (on) { const unsigned long long p = 2ull * (pos0 + (unsigned long long)k); atomicMin(&first[pairs[k].x], p); atomicMin(&first[pairs[k].y], p + 1ull); }
 }
 // the candidates of a block that passed, appended to the list of all passed candidates (in enumeration order: erank = exclusive scan of kept)
-__global__ void k_aff_compact(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ erank, int n, int hyp_off,
+__global__ void k_aff_compact(const int2* __restrict__ pairs, const float* __restrict__ wgt, const int* __restrict__ erank, int n, const int* __restrict__ loc2glob,
                               int2* __restrict__ out_pairs, float* __restrict__ out_w)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || !(wgt[k] > 0.0f)) return;
     const int r = erank[k];
-    out_pairs[r] = make_int2(pairs[k].x + hyp_off, pairs[k].y + hyp_off);
+    out_pairs[r] = loc2glob ? make_int2(loc2glob[pairs[k].x], loc2glob[pairs[k].y]) : pairs[k];
     out_w[r] = wgt[k];
+}
+// a rank's first-touch minima (local hypothesis numbers) into the whole-scene array
+__global__ void k_aff_first_scatter(const unsigned long long* __restrict__ first, const int* __restrict__ loc2glob, int n, unsigned long long* __restrict__ out)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n) out[loc2glob[h]] = first[h];
 }
 // node index = rank of a hypothesis' first position among all first positions: (first, hypothesis) sorted by first
 __global__ void k_aff_node_keys(const unsigned long long* __restrict__ first, int n_hyp, unsigned long long none_key, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals)
@@ -574,7 +580,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
     int* needs_prev = c->g1.as<int>() + ((size_t)nh + 2) * 4;
     HIPCHK(c, hipMemsetAsync(needs_prev, 0, (size_t)V * 4, st));
-    { ProfScope p(c, "aff_sym", st); hipLaunchKernelGGL(k_aff_sym, gsrc, dim3(256), 0, st, a, needs_prev); }
+    { ProfScope p(c, "aff_sym", st); hipLaunchKernelGGL(k_aff_sym, gsrc, dim3(256), 0, st, a, needs_prev, part ? part->assume_symmetric : 0); }
     std::vector<int> cut((size_t)V, 0);
     HIPCHK(c, hipMemcpyAsync(cut.data(), needs_prev, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -599,7 +605,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     // first-touch minimum per hypothesis.
     const int h0 = part ? part->h0 : 0, h1 = part ? part->h1 : nh;
     const unsigned long long pos_base = part ? part->pos_base : 0ull;
-    const int hyp_off = part ? part->hyp_off : 0;
+    const int* loc2glob = part ? part->loc2glob : nullptr;
     int* nwords = c->g1.as<int>();
     int* word_off = nwords + (nh + 2);
     int* cnt = word_off + (nh + 2);
@@ -661,7 +667,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
                     if (n_kept_blk > 0) {
                         if (int rc = grow_keep(c, c->aff_pass_pairs, (size_t)(n_passed + n_kept_blk) * 8 + 256, (size_t)n_passed * 8, st)) return rc;
                         if (int rc = grow_keep(c, c->aff_pass_w, (size_t)(n_passed + n_kept_blk) * 4 + 256, (size_t)n_passed * 4, st)) return rc;
-                        hipLaunchKernelGGL(k_aff_compact, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, n_items, hyp_off,
+                        hipLaunchKernelGGL(k_aff_compact, dim3((n_items + 255) / 256), dim3(256), 0, st, pairs, wgt, erank, n_items, loc2glob,
                                            c->aff_pass_pairs.as<int2>() + n_passed, c->aff_pass_w.as<float>() + n_passed);
                     }
                     n_items_total += n_items; n_passed += n_kept_blk;
@@ -761,22 +767,16 @@ int l3d_last_fill_counts(l3d_ctx* c, int64_t* n_candidates, int64_t* n_passed)
     return L3D_OK;
 }
 
-// The same fill on the resident tables: hypotheses (l3d_products_hypotheses), potential correspondences and best matches
-// (l3d_match_chain_resident) never left the device; the collinearity CSR is uploaded when it changed.
-int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, float sigma_a,
-                               l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
+}  // extern "C"
+
+namespace {
+
+// the tables of a fill on the resident products (hypotheses of l3d_products_hypotheses, potential correspondences and best matches of the
+// chain): only the collinearity CSR comes from the host -- uploaded when it changed, otherwise the copy of the previous call is used
+int resident_tables(l3d_ctx* c, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, AffIn& a, long long& n_coll_out)
 {
-    if (!c) return L3D_ERR_INVALID;
-    if (!n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
-    if (edges_out) *edges_out = nullptr;
-    *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
-    c->resident_edges = 0; c->kept_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;
-    if (n_candidates_out) *n_candidates_out = 0;
     Products& P = c->products;
-    if (!P.valid || !P.hyp_valid) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: no resident products / hypotheses");
     const int nd = P.n_dense, nh = P.n_hyp, V = P.n_views_all;
-    if (nh == 0) return L3D_OK;
-    HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const long long n_coll = coll_start[nd];
     if (coll_start[0] != 0 || n_coll < 0 || n_coll > 0x7fffffffll || (n_coll > 0 && (!coll_other || !coll_w))) return fail(c, L3D_ERR_INVALID, "affinity fill: bad collinearity table");
@@ -801,7 +801,6 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
         P.coll_n = n_coll; P.coll_sig = sig;
     }
     char* cb = P.coll.as<char>();
-    AffIn a;
     a.n_views = V; a.n_hyp = nh; a.n_dense = nd; a.chunk = 64;
     a.seg_base = reinterpret_cast<const int*>(cb + o_sb);
     a.dview = nullptr; a.flags = nullptr;
@@ -814,8 +813,242 @@ int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int3
     a.coll_start = reinterpret_cast<const long long*>(cb + o_cs);
     a.coll_other = reinterpret_cast<const int*>(cb + o_co);
     a.coll_w = reinterpret_cast<const float*>(cb + o_cw);
+    n_coll_out = n_coll;
     if ((int)P.view_hyp_begin.size() != V + 1) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: hypothesis ranges missing");
+    return L3D_OK;
+}
+
+}  // namespace
+
+namespace l3d {
+
+// first-touch minima of all ranks (each a whole-scene array, "never touched" outside the rank's hypotheses) -> their minimum
+__global__ __launch_bounds__(256) void k_aff_first_min(const unsigned long long* __restrict__ all, size_t stride_words, int world, int nh, unsigned long long* __restrict__ out)
+{
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= nh) return;
+    unsigned long long m = kFirstNone;
+    for (int r = 0; r < world; ++r) { const unsigned long long v = all[(size_t)r * stride_words + h]; m = v < m ? v : m; }
+    out[h] = m;
+}
+
+}  // namespace l3d
+
+extern "C" {
+
+// The same fill on the resident tables: hypotheses (l3d_products_hypotheses), potential correspondences and best matches
+// (l3d_match_chain_resident) never left the device; the collinearity CSR is uploaded when it changed.
+int l3d_affinity_fill_resident(l3d_ctx* c, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, float sigma_a,
+                               l3d_edge** edges_out, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out, int* n_candidates_out)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start) return fail(c, L3D_ERR_INVALID, "bad argument");
+    if (edges_out) *edges_out = nullptr;
+    *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0;
+    c->resident_edges = 0; c->kept_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;
+    if (n_candidates_out) *n_candidates_out = 0;
+    Products& P = c->products;
+    if (!P.valid || !P.hyp_valid) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: no resident products / hypotheses");
+    if (P.part.active && P.part.world > 1) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_resident: the products are partitioned over the ranks (l3d_affinity_fill_sharded)");
+    if (P.n_hyp == 0) return L3D_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    AffIn a;
+    long long n_coll = 0;
+    if (int rc = resident_tables(c, coll_start, coll_other, coll_w, coll_changed, a, n_coll)) return rc;
     return affinity_fill_core(c, a, P.seg_base.data(), P.view_hyp_begin.data(), P.n_pot, n_coll, sigma_a, edges_out, n_edges_out, node_hyp_out, n_nodes_out, n_candidates_out, nullptr);
+}
+
+// The fill SHARDED BY SOURCE KEY over the ranks of a partitioned job (l3d_match_chain_partition left every rank the rows, best matches
+// and hypotheses its block's sources can reach).  Every rank enumerates the candidates of its own block's sources (in blocks of sources, as the
+// one-GPU fill does); what has to be global is small and is all-gathered: how many hypotheses every view has (-> global hypothesis numbers), the
+// first-touch minima (a hypothesis is first touched by a candidate of its own rank or of a neighbour's), the candidates that PASSED (12 bytes each,
+// concatenated in rank order = source order: the reference's enumeration order) and the hypotheses of every block (for the line fit).  Node
+// numbering and the edge list are then formed by every rank from the same data (replicas, like the clustering stages behind them).
+int l3d_affinity_fill_sharded(l3d_ctx* c, const int64_t* coll_start, const int32_t* coll_other, const float* coll_w, int coll_changed, float sigma_a,
+                              l3d_exchange_fn exchange, void* exchange_user, int* n_edges_out, int32_t** node_hyp_out, int* n_nodes_out,
+                              int64_t* n_candidates_all, int32_t* view_hyp_begin_global, int32_t** hyp_dense_global, int* n_hyp_global)
+{
+    if (!c) return L3D_ERR_INVALID;
+    if (!n_edges_out || !node_hyp_out || !n_nodes_out || !coll_start || !exchange || !view_hyp_begin_global || !hyp_dense_global || !n_hyp_global) return fail(c, L3D_ERR_INVALID, "bad argument");
+    *n_edges_out = 0; *node_hyp_out = nullptr; *n_nodes_out = 0; *hyp_dense_global = nullptr; *n_hyp_global = 0;
+    if (n_candidates_all) *n_candidates_all = 0;
+    c->resident_edges = 0; c->kept_edges = 0; c->resident_nodes = 0; c->resident_labels = 0;
+    Products& P = c->products;
+    if (!P.valid || !P.hyp_valid || !P.part.active) return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: no partitioned products / hypotheses (l3d_match_chain_partition, l3d_products_hypotheses)");
+    const ProductsPart part = P.part;
+    const int world = part.world, rank = part.rank, V = P.n_views_all, nh = P.n_hyp;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // A rank that fails on its own between two collectives still enters the next one, with a mark: nobody is left waiting (as in l3d_match_chain_blocks)
+    int local_rc = L3D_OK;
+    std::string local_err;
+    auto note = [&](int rc) { if (rc && !local_rc) { local_rc = rc; std::lock_guard<std::mutex> lk(c->err_mu); local_err = c->err; } };
+#define L3D_SOFT(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) note(fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_))); } while (0)
+    if (c->ch_hdr.reserve(512 * (size_t)(world + 2) + 256) != hipSuccess) return fail(c, L3D_ERR_NOMEM, "l3d_affinity_fill_sharded: status words");     // (before the first collective)
+    long long* st_own = c->ch_hdr.as<long long>();
+    long long* st_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + 256);
+    std::vector<long long> words((size_t)world * 4, 0);
+    // four words per rank; word 0 negative = the rank failed
+    auto all_gather_words = [&](long long w0, long long w1, long long w2, long long w3, const char* what) -> int {
+        long long mine[4] = { local_rc ? -(long long)local_rc : w0, w1, w2, w3 };
+        hipError_t e = hipMemcpyAsync(st_own, mine, 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { note(fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: status words: ") + hipGetErrorString(e))); (void)hipMemsetAsync(st_own, 0xff, 32, st); }
+        if (exchange(exchange_user, -3, st_own, st_all, 256, world, (void*)st)) return fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: the exchange of the status words failed (") + what + ")");
+        e = hipSuccess;
+        for (int r = 0; r < world && e == hipSuccess; ++r) e = hipMemcpyAsync(&words[(size_t)r * 4], reinterpret_cast<const unsigned char*>(st_all) + (size_t)r * 256, 32, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: status words: ") + hipGetErrorString(e));
+        if (local_rc) return fail(c, local_rc, local_err);
+        for (int r = 0; r < world; ++r)
+            if (words[(size_t)r * 4] < 0) return fail(c, L3D_ERR_HIP, "l3d_affinity_fill_sharded: rank " + std::to_string(r) + " failed (code " + std::to_string(-words[(size_t)r * 4]) + ") while " + what);
+        return L3D_OK;
+    };
+    auto gather = [&](int tag, size_t slot, const char* what) -> int {
+        if (exchange(exchange_user, tag, c->ch_send.p, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: the exchange of ") + what + " failed");
+        return L3D_OK;
+    };
+    auto reserve_slots = [&](size_t slot) { hipError_t e = c->ch_send.reserve(slot + 256); if (e == hipSuccess) e = c->ch_gathered.reserve(slot * (size_t)world + 256); if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_affinity_fill_sharded: exchange slots")); return e == hipSuccess; };
+
+    // ---- 1. hypotheses per view: a view's count comes from the rank that owns it; every holder of the view must agree
+    const size_t vslot = al((size_t)(V + 2) * 4);
+    // (a view this rank has hypotheses of without holding it: an early-return view -- every rank finds its best matches from the all-gathered
+    // records that point at it -- or a view an early return's local camera numbers name, whose best matches its owner sent: l3d_match_chain_partition)
+    std::vector<int> cnt_loc((size_t)V + 2, -1);           // -1: nothing is known about the view here
+    for (int v = 0; v < V; ++v) {
+        const int n = P.view_hyp_begin[(size_t)v + 1] - P.view_hyp_begin[(size_t)v];
+        if ((v >= part.held_dv0 && v < part.held_dv1) || n > 0) cnt_loc[(size_t)v] = n;
+    }
+    cnt_loc[(size_t)V] = part.own_dv0; cnt_loc[(size_t)V + 1] = part.own_dv1;
+    if (reserve_slots(vslot)) { L3D_SOFT(hipMemcpyAsync(c->ch_send.p, cnt_loc.data(), (size_t)(V + 2) * 4, hipMemcpyHostToDevice, st)); L3D_SOFT(hipStreamSynchronize(st)); }
+    if (int rc = all_gather_words(0, 0, 0, 0, "publishing its hypothesis counts")) return rc;
+    if (int rc = gather(-7, vslot, "the hypothesis counts")) return rc;
+    std::vector<int> cnt_all((size_t)world * (size_t)(V + 2), 0);
+    for (int r = 0; r < world; ++r) L3D_SOFT(hipMemcpyAsync(&cnt_all[(size_t)r * (size_t)(V + 2)], c->ch_gathered.as<unsigned char>() + (size_t)r * vslot, (size_t)(V + 2) * 4, hipMemcpyDeviceToHost, st));
+    L3D_SOFT(hipStreamSynchronize(st));
+    std::vector<int> vhb((size_t)V + 1, 0), blk0((size_t)world), blk1((size_t)world);
+    if (!local_rc) {
+        for (int r = 0; r < world; ++r) { blk0[(size_t)r] = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)V]; blk1[(size_t)r] = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)V + 1]; }
+        for (int v = 0; v < V && !local_rc; ++v) {
+            int own = -1;
+            for (int r = 0; r < world; ++r) if (v >= blk0[(size_t)r] && v < blk1[(size_t)r]) own = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)v];
+            if (own < 0) { note(fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: a view belongs to no rank's block")); break; }
+            for (int r = 0; r < world; ++r) {
+                const int x = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)v];
+                if (x >= 0 && x != own) { note(fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: rank " + std::to_string(r) + " holds " + std::to_string(x) + " hypotheses of dense view " + std::to_string(v) + ", its owner " + std::to_string(own) + " (the ranks' kept lists differ)")); break; }
+            }
+            vhb[(size_t)v + 1] = vhb[(size_t)v] + own;
+        }
+    }
+    const int nh_all = vhb[(size_t)V];
+    // local -> global hypothesis numbers (both ascend with the dense segment id: every comparison of two local numbers is the global one)
+    if (!local_rc && nh > 0) {
+        std::vector<int> l2g((size_t)nh);
+        for (int v = 0; v < V; ++v)
+            for (int h = P.view_hyp_begin[(size_t)v]; h < P.view_hyp_begin[(size_t)v + 1]; ++h) l2g[(size_t)h] = vhb[(size_t)v] + (h - P.view_hyp_begin[(size_t)v]);
+        L3D_SOFT(c->aff_l2g.reserve((size_t)nh * 4 + 64));
+        if (!local_rc) { L3D_SOFT(hipMemcpyAsync(c->aff_l2g.p, l2g.data(), (size_t)nh * 4, hipMemcpyHostToDevice, st)); L3D_SOFT(hipStreamSynchronize(st)); }
+    }
+
+    // ---- 2. this rank's candidates: the sources of its block
+    long long n_coll = 0;
+    if (!local_rc && nh > 0) {
+        AffIn a;
+        int rc = resident_tables(c, coll_start, coll_other, coll_w, coll_changed, a, n_coll);
+        if (!rc) {
+            FillPart fp;
+            fp.h0 = P.view_hyp_begin[(size_t)part.own_dv0]; fp.h1 = P.view_hyp_begin[(size_t)part.own_dv1];
+            fp.pos_base = (unsigned long long)rank << 44; fp.loc2glob = c->aff_l2g.as<int>(); fp.assume_symmetric = 1;
+            int n_e = 0, n_n = 0, n_c = 0; int32_t* nhp = nullptr;
+            rc = affinity_fill_core(c, a, P.seg_base.data(), P.view_hyp_begin.data(), P.n_pot, n_coll, sigma_a, nullptr, &n_e, &nhp, &n_n, &n_c, &fp);
+        }
+        note(rc);
+    } else { c->fill_items = 0; c->fill_passed = 0; }
+    const long long my_items = local_rc ? 0 : c->fill_items, my_passed = local_rc ? 0 : c->fill_passed;
+    const int own_h0 = nh > 0 ? P.view_hyp_begin[(size_t)part.own_dv0] : 0, own_h1 = nh > 0 ? P.view_hyp_begin[(size_t)part.own_dv1] : 0;
+    if (int rc = all_gather_words(0, my_items, my_passed, own_h1 - own_h0, "enumerating its candidates")) return rc;
+    long long items_all = 0, passed_all = 0, max_passed = 0, max_blk = 0;
+    std::vector<long long> passed_of((size_t)world), blk_of((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        items_all += words[(size_t)r * 4 + 1]; passed_of[(size_t)r] = words[(size_t)r * 4 + 2]; blk_of[(size_t)r] = words[(size_t)r * 4 + 3];
+        passed_all += passed_of[(size_t)r]; max_passed = std::max(max_passed, passed_of[(size_t)r]); max_blk = std::max(max_blk, blk_of[(size_t)r]);
+    }
+    if (n_candidates_all) *n_candidates_all = items_all;
+
+    // ---- 3. first-touch minima: every rank's, over the global hypothesis numbers -> the minimum
+    const size_t fslot = al((size_t)std::max(nh_all, 1) * 8);
+    if (reserve_slots(fslot)) {
+        hipLaunchKernelGGL(k_aff_fill64, dim3((std::max(nh_all, 1) + 255) / 256), dim3(256), 0, st, c->ch_send.as<unsigned long long>(), std::max(nh_all, 1), kFirstNone);
+        if (nh > 0 && !local_rc) hipLaunchKernelGGL(k_aff_first_scatter, dim3((nh + 255) / 256), dim3(256), 0, st, c->aff_first.as<unsigned long long>(), c->aff_l2g.as<int>(), nh, c->ch_send.as<unsigned long long>());
+    }
+    if (int rc = all_gather_words(0, 0, 0, 0, "staging its first-touch positions")) return rc;
+    if (int rc = gather(-8, fslot, "the first-touch positions")) return rc;
+    L3D_SOFT(c->aff_first.reserve((size_t)std::max(nh_all, 1) * 8 + 64));
+    if (!local_rc && nh_all > 0) hipLaunchKernelGGL(k_aff_first_min, dim3((nh_all + 255) / 256), dim3(256), 0, st, c->ch_gathered.as<unsigned long long>(), fslot / 8, world, nh_all, c->aff_first.as<unsigned long long>());
+    L3D_SOFT(hipStreamSynchronize(st));            // (the gathered buffer is reused below)
+
+    // ---- 4. the candidates that passed, concatenated in rank order
+    const size_t o_w = al((size_t)max_passed * 8), pslot = o_w + al((size_t)max_passed * 4 + 4);
+    if (reserve_slots(pslot) && my_passed > 0) {
+        L3D_SOFT(hipMemcpyAsync(c->ch_send.p, c->aff_pass_pairs.p, (size_t)my_passed * 8, hipMemcpyDeviceToDevice, st));
+        L3D_SOFT(hipMemcpyAsync(c->ch_send.as<unsigned char>() + o_w, c->aff_pass_w.p, (size_t)my_passed * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (int rc = all_gather_words(0, 0, 0, 0, "staging its passed candidates")) return rc;
+    if (int rc = gather(-9, pslot, "the passed candidates")) return rc;
+    L3D_SOFT(c->aff_pass_pairs.reserve((size_t)passed_all * 8 + 256));
+    L3D_SOFT(c->aff_pass_w.reserve((size_t)passed_all * 4 + 256));
+    if (!local_rc) {
+        long long at = 0;
+        for (int r = 0; r < world; ++r) {
+            if (passed_of[(size_t)r] > 0) {
+                L3D_SOFT(hipMemcpyAsync(c->aff_pass_pairs.as<int2>() + at, c->ch_gathered.as<unsigned char>() + (size_t)r * pslot, (size_t)passed_of[(size_t)r] * 8, hipMemcpyDeviceToDevice, st));
+                L3D_SOFT(hipMemcpyAsync(c->aff_pass_w.as<float>() + at, c->ch_gathered.as<unsigned char>() + (size_t)r * pslot + o_w, (size_t)passed_of[(size_t)r] * 4, hipMemcpyDeviceToDevice, st));
+            }
+            at += passed_of[(size_t)r];
+        }
+        L3D_SOFT(hipStreamSynchronize(st));
+    }
+
+    // ---- 5. the hypotheses of every block (the line fit reads them by global number) and the segments they belong to
+    const size_t o_hd = al((size_t)max_blk * sizeof(Hypothesis)), hslot = o_hd + al((size_t)max_blk * 4 + 4);
+    if (reserve_slots(hslot) && own_h1 > own_h0 && !local_rc) {
+        L3D_SOFT(hipMemcpyAsync(c->ch_send.p, c->aff_hyp.as<Hypothesis>() + own_h0, (size_t)(own_h1 - own_h0) * sizeof(Hypothesis), hipMemcpyDeviceToDevice, st));
+        L3D_SOFT(hipMemcpyAsync(c->ch_send.as<unsigned char>() + o_hd, P.hyp_dense.as<int>() + own_h0, (size_t)(own_h1 - own_h0) * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (int rc = all_gather_words(0, 0, 0, 0, "staging its hypotheses")) return rc;
+    if (int rc = gather(-10, hslot, "the hypotheses")) return rc;
+    // (past the last collective: a failure from here on is this rank's alone)
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, c->aff_hyp.reserve((size_t)std::max(nh_all, 1) * sizeof(Hypothesis) + 64));
+    int32_t* hd = static_cast<int32_t*>(malloc((size_t)nh_all * 4 + 4));
+    if (!hd) return fail(c, L3D_ERR_NOMEM, "malloc");
+    {
+        long long at = 0;
+        for (int r = 0; r < world; ++r) {
+            const long long n = blk_of[(size_t)r];
+            if (at != vhb[(size_t)blk0[(size_t)r]]) { free(hd); return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: the blocks' hypotheses do not line up with the global numbering"); }
+            if (n > 0) {
+                hipError_t e = hipMemcpyAsync(c->aff_hyp.as<Hypothesis>() + at, c->ch_gathered.as<unsigned char>() + (size_t)r * hslot, (size_t)n * sizeof(Hypothesis), hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess) e = hipMemcpyAsync(hd + at, c->ch_gathered.as<unsigned char>() + (size_t)r * hslot + o_hd, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess) { free(hd); return fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: ") + hipGetErrorString(e)); }
+            }
+            at += n;
+        }
+        if (at != nh_all) { free(hd); return fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: the blocks' hypotheses do not add up"); }
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { free(hd); return fail(c, L3D_ERR_HIP, std::string("l3d_affinity_fill_sharded: ") + hipGetErrorString(e)); }
+    }
+    memcpy(view_hyp_begin_global, vhb.data(), (size_t)(V + 1) * 4);
+    *hyp_dense_global = hd; *n_hyp_global = nh_all;
+    c->fill_items = items_all; c->fill_passed = passed_all;
+    P.n_hyp = nh_all;                                 // (l3d_products_hypotheses_get now returns the whole table; the local index tables of the fill are spent)
+    // ---- 6. numbering and edges: every rank from the same data
+    int rc = affinity_number_edges(c, c->aff_first.as<unsigned long long>(), nh_all, c->aff_pass_pairs.as<int2>(), c->aff_pass_w.as<float>(), passed_all, nullptr, n_edges_out, node_hyp_out, n_nodes_out);
+    if (rc) { free(hd); *hyp_dense_global = nullptr; *n_hyp_global = 0; }
+    c->resident_hyp = nh_all;
+    return rc;
+#undef L3D_SOFT
 }
 
 }  // extern "C"

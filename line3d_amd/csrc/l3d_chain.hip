@@ -231,8 +231,20 @@ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // launch nothing and their result records stay zero, so a view inside the range finds no kept matches of a source in front of it
 // (l3d_match_chain_blocks: a block of views started cold).  With a range and neither cb nor map the call only fills the kept arena and
 // the per-view result records (c->ch_pin_res).
+// pre: the views [pre->k0, pre->k1 = k_begin) taken over from another rank (their kept lists, best depth pairs and positions): they are put at
+// the head of the arena with their result records, so the range's views find their TRUE sources -- a block of views re-run warm after its
+// cold-started speculation failed.
+namespace {
+struct ChainPreload {
+    int k0 = 0, k1 = 0;
+    const Match* records = nullptr;        // device: the views' kept lists, back to back
+    const float2* best = nullptr;          // device: best depth pairs of the verified views among them, back to back (S_src each)
+    const int* bestpos = nullptr;          // device: ... and the positions of the best kept matches
+    std::vector<int> n_kept, R;            // per view
+};
+}
 static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_chain_callback cb, void* user, const l3d_dense_map* map,
-                     l3d_chain_summary* summary, int64_t* n_pot, int k_begin = 0, int k_end = -1)
+                     l3d_chain_summary* summary, int64_t* n_pot, int k_begin = 0, int k_end = -1, const ChainPreload* pre = nullptr)
 {
     if (!c) return L3D_ERR_INVALID;
     const bool ranged = k_end >= 0;
@@ -335,6 +347,15 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (same_scene) { cand_cap = std::max(cand_cap, c->chain_seen_cand_cap); arena_cap = std::max(arena_cap, c->chain_seen_arena_cap); }
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;
+    // views that own a slice of the arena: the range's verified views and the preloaded ones (a view's slice starts where the previous such view's ended)
+    std::vector<char> has_rec((size_t)n_views, 0);
+    for (int k = 0; k < n_views; ++k) has_rec[(size_t)k] = vd[(size_t)k].verified ? 1 : 0;
+    long long pre_records = 0;
+    if (pre) {
+        if (pre->k1 != k_begin || pre->k0 < 0 || pre->k0 > pre->k1 || (int)pre->n_kept.size() != pre->k1 - pre->k0 || (int)pre->R.size() != pre->k1 - pre->k0) return fail(c, L3D_ERR_INVALID, "match_chain: bad preload");
+        for (int k = pre->k0; k < pre->k1; ++k) { pre_records += pre->n_kept[(size_t)(k - pre->k0)]; has_rec[(size_t)k] = views[k].n_tbm > 0 ? 1 : 0; }
+        arena_cap += (size_t)pre_records;
+    }
 
     auto reserve_caps = [&]() -> int {
         if (int rc = chain_reserve_candidates(c, L, cand_cap, c->chain_ring ? kRing : 0)) return rc;
@@ -342,6 +363,25 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
+    if (pre && pre->k1 > pre->k0) {
+        long long base = 0;
+        size_t so = 0;
+        for (int k = pre->k0; k < pre->k1; ++k) {
+            ChainResult r;
+            r.kept_base = (unsigned)base; r.n_kept = has_rec[(size_t)k] ? pre->n_kept[(size_t)(k - pre->k0)] : 0; r.R = pre->R[(size_t)(k - pre->k0)]; r.overflow = 0;
+            hres[k] = r;
+            base += r.n_kept;
+            if (views[k].n_tbm > 0) {
+                // (chain_assign_arenas gave every verified view of the schedule its slices, whatever the range)
+                ChainViewDev& d = vd[(size_t)k];
+                if (views[k].S_src > 0 && d.best && pre->best) HIPCHK(c, hipMemcpyAsync(d.best, pre->best + so, (size_t)views[k].S_src * 8, hipMemcpyDeviceToDevice, st));
+                if (views[k].S_src > 0 && d.bestpos && pre->bestpos) HIPCHK(c, hipMemcpyAsync(d.bestpos, pre->bestpos + so, (size_t)views[k].S_src * 4, hipMemcpyDeviceToDevice, st));
+                so += (size_t)views[k].S_src;
+            }
+        }
+        if (base > 0) HIPCHK(c, hipMemcpyAsync(c->ch_kept.p, pre->records, (size_t)base * sizeof(Match), hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ch_res.as<ChainResult>() + pre->k0, hres + pre->k0, (size_t)(pre->k1 - pre->k0) * sizeof(ChainResult), hipMemcpyHostToDevice, st));
+    }
     auto ringA_meta = [&](int k) { return c->ch_ringA_meta.as<uint2>() + (size_t)(k % kRing) * cand_cap; };
     auto ringA_depths = [&](int k) { return c->ch_ringA_depths.as<float4>() + (size_t)(k % kRing) * cand_cap; };
     // row starts + depth records of a view's stage-1 candidates alone (its reverse matches are not known yet)
@@ -443,7 +483,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         {
             ProfScope p(c, "kept_write");
             int pv = k - 1;
-            while (pv >= 0 && !vd[(size_t)pv].verified) --pv;                // the arena slice starts where the previous verified view's ended
+            while (pv >= 0 && !has_rec[(size_t)pv]) --pv;                    // the arena slice starts where the previous verified (or preloaded) view's ended
             launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (unsigned long long)arena_cap, dres + k, hres_dev + k,
                                     reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr);
         }
@@ -682,28 +722,136 @@ __global__ __launch_bounds__(256) void k_block_digest(const Match* __restrict__ 
 
 }  // namespace l3d
 
-extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
-                                      int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+namespace l3d {
+
+// one source's records that point at an early-return view, in list order (stable): out == nullptr counts only
+__global__ __launch_bounds__(256) void k_early_pack(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ group_src,
+                                                    const unsigned* __restrict__ early_ids, int n_early, const long long* __restrict__ out_off, Match* __restrict__ out, int* __restrict__ counts)
+{
+    __shared__ int s_w[4];
+    const ChainResult r = res[group_src[blockIdx.x]];
+    const Match* kept = arena + r.kept_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long off = out ? out_off[blockIdx.x] : 0;
+    int total = 0;
+    for (int b = 0; b < r.n_kept; b += 256) {
+        const int i = b + tid;
+        Match m;
+        bool on = false;
+        if (i < r.n_kept) { m = kept[i]; for (int e = 0; e < n_early; ++e) on = on || m.camID2 == early_ids[e]; }
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+        if (on && out) out[off + before + __popcll(bal & ((1ull << lane) - 1ull))] = m;
+        off += all; total += all;
+        __syncthreads();
+    }
+    if (tid == 0 && !out) counts[blockIdx.x] = total;
+}
+
+// one view's best matches as a package other ranks can build its hypotheses from: [view, R, n, S | position of every segment's best match in the
+// compact list or -1 | best depth pairs | the best records, compact, in segment order (room for S)]
+__global__ __launch_bounds__(256) void k_alias_pack(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ pk_view, const int* __restrict__ pk_S,
+                                                    const long long* __restrict__ pk_best_off, const long long* __restrict__ pk_out_off, const float2* __restrict__ best_all,
+                                                    const int* __restrict__ bestpos_all, unsigned char* __restrict__ out)
+{
+    __shared__ int s_w[4];
+    const int k = pk_view[blockIdx.x], S = pk_S[blockIdx.x];
+    const ChainResult r = res[k];
+    const float2* best = best_all + pk_best_off[blockIdx.x];
+    const int* bestpos = bestpos_all + pk_best_off[blockIdx.x];
+    unsigned char* o = out + pk_out_off[blockIdx.x];
+    int* o_pos = reinterpret_cast<int*>(o + 16);
+    float2* o_best = reinterpret_cast<float2*>(o + 16 + (size_t)S * 4);
+    Match* o_rec = reinterpret_cast<Match*>(o + 16 + (size_t)S * 12);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int off = 0;
+    for (int b = 0; b < S; b += 256) {
+        const int s = b + tid;
+        const int p = s < S ? bestpos[s] : -1;
+        const bool on = p >= 0 && r.n_kept > 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+        if (s < S) {
+            const int q = on ? off + before + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+            o_pos[s] = q; o_best[s] = best[s];
+            if (on) o_rec[q] = arena[r.kept_base + p];
+        }
+        off += all;
+        __syncthreads();
+    }
+    if (tid == 0) { int* h = reinterpret_cast<int*>(o); h[0] = k; h[1] = r.R; h[2] = off; h[3] = S; }
+}
+
+}  // namespace l3d
+
+namespace {
+
+// `used` bytes of the kept arena kept across a growth (DevBuf::reserve drops the content)
+int arena_grow_keep(l3d_ctx* c, size_t records, size_t used_records)
+{
+    if (records * sizeof(Match) <= c->ch_kept.cap) return L3D_OK;
+    const size_t want = records * sizeof(Match) + records * sizeof(Match) / 8 + 4096;
+    void* np = nullptr;
+    if (hipMalloc(&np, want) != hipSuccess) { (void)hipGetLastError(); return fail(c, L3D_ERR_NOMEM, "growing the kept arena to " + std::to_string(want >> 20) + " MB"); }
+    if (used_records && c->ch_kept.p) HIPCHK(c, hipMemcpy(np, c->ch_kept.p, used_records * sizeof(Match), hipMemcpyDeviceToDevice));
+    if (c->ch_kept.p) (void)hipFree(c->ch_kept.p);
+    c->ch_kept.p = np; c->ch_kept.cap = want;
+    return L3D_OK;
+}
+
+}  // namespace
+
+// partition = 0: every rank ends up with the whole arena and the whole table (replicas for the finishing stages: l3d_match_chain_blocks).
+// partition = 1: nothing is replicated (l3d_match_chain_partition, include/line3d_amd.h).
+static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                             int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict, int partition)
 {
     if (!c) return L3D_ERR_INVALID;
     if (!views || n_views <= 0 || !map || !summary || !exchange || !verdict || world < 1 || rank < 0 || rank >= world || warmup_views < 0 || window < 0)
         return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: bad argument");
     *verdict = 1;
     if (n_pot) *n_pot = 0;
+    c->products.valid = false;
+    c->products.part = ProductsPart();
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     auto block_begin = [&](int r) { return (int)(((long long)n_views * r) / world); };
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // reach: the largest distance, in chain positions, between a view and one of its neighbours (every rank computes the same number)
+    int reach = window;
+    {
+        std::vector<std::pair<unsigned, int>> idx((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) idx[(size_t)k] = { views[k].view_id, k };
+        std::sort(idx.begin(), idx.end());
+        for (int k = 0; k < n_views; ++k)
+            for (int q = 0; q < views[k].N; ++q) {
+                if (!views[k].local2global) continue;
+                auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(views[k].local2global[q], -1));
+                if (it != idx.end() && it->first == views[k].local2global[q]) reach = std::max(reach, std::abs(it->second - k));
+            }
+    }
+    // partitioned: a rank runs its chain 2 x reach views PAST its block and must be exact 2 x reach views in front of it -- everything the rows of
+    // its block, their flags and the hypotheses they name can depend on is then computed locally (DESIGN.md section 6 iv)
+    const int tail = partition ? 2 * reach : 0;
+    const int check = partition ? std::max(window, 2 * reach) : window;
     const int own0 = block_begin(rank), own1 = block_begin(rank + 1);
-    const int first = rank == 0 ? 0 : std::max(0, own0 - warmup_views);
+    int first = rank == 0 ? 0 : std::max(0, own0 - warmup_views);
+    const int last = std::min(n_views, own1 + tail);
     const double t0 = now_s();
     // ---- this rank's chain: its block and the warm-up views in front of it, started cold
     // (a rank whose chain fails must not leave the others waiting in the first collective: it still publishes its table, with a mark that
     // every rank reads -- they all return an error then, without entering another collective)
-    const int chain_rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, own1);
+    int chain_rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, last);
     std::string chain_err;
     if (chain_rc) { std::lock_guard<std::mutex> lk(c->err_mu); chain_err = c->err; }
     const ChainResult* hres = c->ch_pin_res.as<ChainResult>();
-    const double t1 = now_s();
+    double t1 = now_s();
     // useful work of this rank = its own block (the warm-up is the price of the speculation)
     {
         double p = 0;
@@ -711,72 +859,372 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
             for (int j = 0; j < views[k].n_tbm; ++j) p += (double)views[k].S_src * views[k].offsets[2 * views[k].to_be_matched[j] + 1];
         c->stats[0] = p;
     }
-    // ---- digests of every list this rank computed, all-gathered
-    const size_t tab_bytes = (((size_t)n_views * sizeof(BlockDigest)) + 255) & ~(size_t)255;
-    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 256));
+    // Everything a rank can fail in ON ITS OWN between two collectives (an allocation, a copy, a launch) is collected in local_rc and travels
+    // with the next exchange: a failed rank still enters it, with a mark every rank reads, and then all of them return -- nobody is left waiting.
+    const size_t tab_bytes = al((size_t)n_views * sizeof(BlockDigest));
+    int local_rc = chain_rc;
+    std::string local_err = chain_err;
+    auto note = [&](int rc) { if (rc && !local_rc) { local_rc = rc; std::lock_guard<std::mutex> lk(c->err_mu); local_err = c->err; } };
+#define L3D_SOFT(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) note(fail(c, L3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_))); } while (0)
+    {   // (sized once for the digest tables AND the status words: no reallocation between collectives)
+        hipError_t e = c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 512 * (size_t)(world + 2) + 256);
+        if (e != hipSuccess) return fail(c, L3D_ERR_NOMEM, "l3d_match_chain_blocks: digest tables");     // (before the first collective of this call: every rank of the job is configured alike)
+    }
     BlockDigest* dtab_own = c->ch_hdr.as<BlockDigest>();
     BlockDigest* dtab_all = reinterpret_cast<BlockDigest*>(c->ch_hdr.as<unsigned char>() + tab_bytes);
-    HIPCHK(c, hipMemsetAsync(dtab_own, 0, tab_bytes, st));
-    if (chain_rc) {
-        BlockDigest mark; mark.hash = ~0ull; mark.n_kept = -1; mark.R = chain_rc;
-        (void)hipMemcpyAsync(dtab_own, &mark, sizeof(mark), hipMemcpyHostToDevice, st);
-        (void)hipStreamSynchronize(st);
-    } else if (own1 > first) {
-        HIPCHK(c, hipMemcpyAsync(c->ch_res.p, hres, (size_t)n_views * sizeof(ChainResult), hipMemcpyHostToDevice, st));     // (the final records: a restart rewrites them)
-        hipLaunchKernelGGL(k_block_digest, dim3(16, own1 - first), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), first, dtab_own);
-    }
-    if (exchange(exchange_user, -1, dtab_own, dtab_all, tab_bytes, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the digests failed");
+    long long* st_own = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + tab_bytes * (size_t)(world + 1));
+    long long* st_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + tab_bytes * (size_t)(world + 1) + 256);
     std::vector<BlockDigest> tab((size_t)world * (size_t)n_views);
-    for (int r = 0; r < world; ++r)
-        HIPCHK(c, hipMemcpyAsync(tab.data() + (size_t)r * n_views, reinterpret_cast<const unsigned char*>(dtab_all) + (size_t)r * tab_bytes, (size_t)n_views * sizeof(BlockDigest), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const double t2 = now_s();
-    if (chain_rc) return fail(c, chain_rc, "l3d_match_chain_blocks: this rank's chain failed: " + chain_err);
-    for (int r = 0; r < world; ++r)
-        if (tab[(size_t)r * n_views].n_kept == -1 && tab[(size_t)r * n_views].hash == ~0ull)
-            return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the chain of rank " + std::to_string(r) + " failed (code " + std::to_string(tab[(size_t)r * n_views].R) + ")");
-    // ---- the verdict (the same on every rank: same table)
-    bool ok = true;
-    for (int r = 1; r < world && ok; ++r) {
-        const int b = block_begin(r), fr = std::max(0, b - warmup_views), lo = b - window;
-        if (lo < fr || lo < block_begin(r - 1)) { ok = false; break; }       // warm-up shorter than the window, or a block shorter than the window
-        for (int k = lo; k < b; ++k) {
-            const BlockDigest &x = tab[(size_t)r * n_views + k], &y = tab[(size_t)(r - 1) * n_views + k];
-            // (the kept LIST must be the same; the number of candidates it was chosen from may differ while the warm-up converges)
-            if (x.hash != y.hash || x.n_kept != y.n_kept) { ok = false; if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks] rank %d's warm-up view %d differs from rank %d's (%d vs %d kept)\n", r, k, r - 1, x.n_kept, y.n_kept); break; }
-        }
-    }
-    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, speculation %s\n",
-                               rank, world, first, own1 - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, ok ? "exact" : "NOT exact");
-    if (!ok) return L3D_OK;                                                    // *verdict = 1: nothing committed
-    // From here on a rank that fails on its own (an allocation, a launch) must not leave the others waiting in the next collective: every
-    // step that only this rank can fail in is followed by a small all-gather of status words, and either all ranks enter the big collective
-    // behind it or none does.
-    HIPCHK(c, c->ch_hdr.reserve(tab_bytes * (size_t)(world + 1) + 512 * (size_t)(world + 2)));     // (the digest tables are on the host by now)
-    long long* st_own = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>());
-    long long* st_all = reinterpret_cast<long long*>(c->ch_hdr.as<unsigned char>() + 256);
     std::vector<long long> words((size_t)world, 0);
     // publishes `mine` (negative = this rank failed with code -mine), reads everybody's; non-zero return: somebody failed (this rank's own message is kept)
     auto all_gather_word = [&](long long mine, const char* what) -> int {
-        std::string own_err;
-        if (mine < 0) { std::lock_guard<std::mutex> lk(c->err_mu); own_err = c->err; }
+        if (local_rc && mine >= 0) mine = -(long long)local_rc;
         hipError_t e = hipMemcpyAsync(st_own, &mine, 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);                   // (`mine` is a stack word)
-        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
+        if (e != hipSuccess) { note(fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e))); (void)hipMemsetAsync(st_own, 0xff, 8, st); }   // (all ones = -1: failed)
         if (exchange(exchange_user, -3, st_own, st_all, 256, world, (void*)st)) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: the exchange of the status words failed (") + what + ")");
-        for (int r = 0; r < world; ++r) {
-            e = hipMemcpyAsync(&words[(size_t)r], reinterpret_cast<const unsigned char*>(st_all) + (size_t)r * 256, 8, hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
-        }
-        e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));
-        if (mine < 0) return fail(c, (int)-mine, own_err);
+        e = hipSuccess;
+        for (int r = 0; r < world && e == hipSuccess; ++r) e = hipMemcpyAsync(&words[(size_t)r], reinterpret_cast<const unsigned char*>(st_all) + (size_t)r * 256, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: status word: ") + hipGetErrorString(e));     // (after the collective: nobody waits for this rank any more)
+        if (local_rc) return fail(c, local_rc, local_err);
         for (int r = 0; r < world; ++r)
             if (words[(size_t)r] < 0) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: rank " + std::to_string(r) + " failed (code " + std::to_string(-words[(size_t)r]) + ") while " + what);
         return L3D_OK;
     };
-    // ---- all-gather of the blocks: [records of the block's views][best depth pairs][best positions], padded to the largest block
     auto owner = [&](int k) { int r = (int)(((long long)k * world) / n_views); while (r + 1 < world && block_begin(r + 1) <= k) ++r; while (r > 0 && block_begin(r) > k) --r; return r; };
+    // offsets of the views' slices in the whole-run arrays of best pairs / positions (chain_assign_arenas: verified views back to back)
+    std::vector<long long> best_off((size_t)n_views + 1, 0);
+    for (int k = 0; k < n_views; ++k) best_off[(size_t)k + 1] = best_off[(size_t)k] + (views[k].n_tbm > 0 ? views[k].S_src : 0);
+
+    // ---- digests of every list this rank computed, all-gathered; the verdict; a block whose speculation failed is re-run WARM from its
+    // predecessor's true lists (the first one that failed: everything in front of it is exact), then the digests are exchanged again -- a miss
+    // costs one block, not the pass
+    int arena_first = first;                // first view whose records sit in this rank's arena
+    std::vector<int> comp_from((size_t)world, 0);       // per rank: the first view it computed (or took over); every rank keeps the same table
+    for (int r = 1; r < world; ++r) comp_from[(size_t)r] = std::max(0, block_begin(r) - warmup_views);
+    double t2 = t1;
+    int rounds = 0;
+    std::vector<char> exact((size_t)world, 0);
+    for (;; ++rounds) {
+        L3D_SOFT(hipMemsetAsync(dtab_own, 0, tab_bytes, st));
+        if (local_rc) {
+            BlockDigest mark; mark.hash = ~0ull; mark.n_kept = -1; mark.R = local_rc;
+            (void)hipMemcpyAsync(dtab_own, &mark, sizeof(mark), hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);
+        } else if (last > arena_first) {
+            L3D_SOFT(hipMemcpyAsync(c->ch_res.p, hres, (size_t)n_views * sizeof(ChainResult), hipMemcpyHostToDevice, st));     // (the final records: a restart rewrites them)
+            hipLaunchKernelGGL(k_block_digest, dim3(16, last - arena_first), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), arena_first, dtab_own);
+        }
+        if (exchange(exchange_user, -1, dtab_own, dtab_all, tab_bytes, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the digests failed");
+        {
+            hipError_t e = hipSuccess;
+            for (int r = 0; r < world && e == hipSuccess; ++r)
+                e = hipMemcpyAsync(tab.data() + (size_t)r * n_views, reinterpret_cast<const unsigned char*>(dtab_all) + (size_t)r * tab_bytes, (size_t)n_views * sizeof(BlockDigest), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                // this rank cannot read the table: it cannot know the verdict the others reach.  The status-word exchange below (entered by every
+                // rank after every digest exchange) carries the failure to them.
+                note(fail(c, L3D_ERR_HIP, std::string("l3d_match_chain_blocks: reading the digest tables: ") + hipGetErrorString(e)));
+            }
+        }
+        t2 = now_s();
+        if (local_rc == L3D_OK)
+            for (int r = 0; r < world; ++r)
+                if (tab[(size_t)r * n_views].n_kept == -1 && tab[(size_t)r * n_views].hash == ~0ull) { note(fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the chain of rank " + std::to_string(r) + " failed (code " + std::to_string(tab[(size_t)r * n_views].R) + ")")); break; }
+        if (int a_rc = all_gather_word(0, "computing its block")) return a_rc;
+        // ---- the verdict (the same on every rank: same table).  exact[r]: rank r's lists are the one chain's from view B_r - check on
+        int fail_rank = -1;
+        bool hopeless = false;
+        exact[0] = 1;
+        for (int r = 1; r < world; ++r) {
+            exact[(size_t)r] = 0;
+            if (!exact[(size_t)r - 1]) continue;
+            const int b = block_begin(r), lo = std::max(0, b - check);
+            // a warm-up shorter than the check leaves views the rank never computed: not exact (the warm re-run below takes them over)
+            bool ok = lo >= comp_from[(size_t)r];
+            // (replicas: a block shorter than the window cannot vouch for its successor's sources -- the blocks are what gets gathered; partitioned: the
+            // predecessor's exact range reaches back as far as this rank's check)
+            if (!partition && b - check < block_begin(r - 1)) { ok = false; hopeless = true; }
+            for (int k = lo; k < b && ok; ++k) {
+                const BlockDigest &x = tab[(size_t)r * n_views + k], &y = tab[(size_t)(r - 1) * n_views + k];
+                // (the kept LIST must be the same; the number of candidates it was chosen from may differ while the warm-up converges)
+                if (x.hash != y.hash || x.n_kept != y.n_kept) {
+                    ok = false;
+                    if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks] rank %d's warm-up view %d differs from rank %d's (%d vs %d kept)\n", r, k, r - 1, x.n_kept, y.n_kept);
+                }
+            }
+            if (ok && partition) {          // the predecessor's tail against this rank's block: both are the one chain's, or something is wrong
+                const int e = std::min(std::min(n_views, b + tail), block_begin(r + 1));
+                for (int k = b; k < e && ok; ++k) {
+                    const BlockDigest &x = tab[(size_t)r * n_views + k], &y = tab[(size_t)(r - 1) * n_views + k];
+                    if (x.hash != y.hash || x.n_kept != y.n_kept) ok = false;
+                }
+            }
+            exact[(size_t)r] = ok ? 1 : 0;
+            if (!ok && fail_rank < 0) fail_rank = r;
+        }
+        if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] round %d: views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, first inexact rank %d\n",
+                                   rank, world, rounds, arena_first, last - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, fail_rank);
+        if (fail_rank < 0) break;
+        // option block_recover = 0 (A/B, tests of the fall-through): the round-4 behaviour -- any miss sends the pass to the caller's other mode
+        if (hopeless || c->opt.block_recover == 0 || rounds >= world) return L3D_OK;                  // *verdict = 1: nothing committed
+        // ---- recovery: rank fail_rank - 1 is exact; its last `check` views (records, best depth pairs, best positions) go to everybody (an
+        // all-gather is the one primitive of the protocol; only that rank's slot carries data), rank fail_rank re-runs views [B, last) from them
+        const int src_rank = fail_rank - 1, fb = block_begin(fail_rank), k0 = std::max(0, fb - check);
+        comp_from[(size_t)fail_rank] = k0;
+        long long t_rec = 0, t_seg = 0;
+        int k_first_rec = -1;               // (the tail's records are contiguous in the sender's arena from its first verified view on)
+        for (int k = k0; k < fb; ++k) { t_rec += tab[(size_t)src_rank * n_views + k].n_kept; if (views[k].n_tbm > 0) { t_seg += views[k].S_src; if (k_first_rec < 0) k_first_rec = k; } }
+        const size_t o_best = al((size_t)t_rec * sizeof(Match)), o_bpos = o_best + al((size_t)t_seg * 8), slot = o_bpos + al((size_t)t_seg * 4) + 256;
+        {
+            hipError_t e = c->ch_send.reserve(slot + 256);
+            if (e == hipSuccess) e = c->ch_gathered.reserve(slot * (size_t)world + 256);
+            if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_blocks: the hand-over of a block's sources"));
+            else if (rank == src_rank) {
+                unsigned char* send = c->ch_send.as<unsigned char>();
+                if (t_rec > 0) L3D_SOFT(hipMemcpyAsync(send, c->ch_kept.as<Match>() + hres[k_first_rec].kept_base, (size_t)t_rec * sizeof(Match), hipMemcpyDeviceToDevice, st));
+                if (t_seg > 0) {
+                    L3D_SOFT(hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)k0], (size_t)t_seg * 8, hipMemcpyDeviceToDevice, st));
+                    L3D_SOFT(hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)k0], (size_t)t_seg * 4, hipMemcpyDeviceToDevice, st));
+                }
+            }
+        }
+        if (int a_rc = all_gather_word(0, "staging the hand-over of a block's sources")) return a_rc;
+        if (exchange(exchange_user, -5, c->ch_send.p, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the hand-over exchange failed");
+        if (rank == fail_rank) {
+            ChainPreload pre;
+            pre.k0 = k0; pre.k1 = fb;
+            const unsigned char* G = c->ch_gathered.as<unsigned char>() + (size_t)src_rank * slot;
+            pre.records = reinterpret_cast<const Match*>(G);
+            pre.best = reinterpret_cast<const float2*>(G + o_best);
+            pre.bestpos = reinterpret_cast<const int*>(G + o_bpos);
+            for (int k = k0; k < fb; ++k) { pre.n_kept.push_back(tab[(size_t)src_rank * n_views + k].n_kept); pre.R.push_back(tab[(size_t)src_rank * n_views + k].R); }
+            const double tr0 = now_s();
+            const int rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, fb, last, &pre);
+            if (rc) note(rc);
+            hres = c->ch_pin_res.as<ChainResult>();
+            arena_first = k0;
+            t1 += now_s() - tr0;
+            if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] block re-run warm from rank %d's last %d views: %.2f ms\n", rank, world, src_rank, fb - k0, (now_s() - tr0) * 1e3);
+        }
+    }
+    c->products.part.recovery_rounds = rounds;
+    // first view from which this rank's lists are the one chain's
+    const int exact_from = rank == 0 ? 0 : std::max(arena_first, own0 - check);
+    (void)comp_from;
+
+    const int nvd = map->n_views;
+    auto dense_of = [&](int k) {                                   // the dense view a chain view is (ids ascend in both)
+        if (k >= n_views) return nvd;
+        const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + nvd, views[k].view_id);
+        return (int)(it - map->view_ids);
+    };
+    Products& P = c->products;
+
+    if (partition) {
+        // =========================================================================================================================
+        // Nothing is replicated.  This rank holds the exact records of the views [exact_from, last) and builds from them, locally: the rows
+        // of the table for the views within `reach` of its block, best matches and medians for every view it holds.  What the early-return
+        // quirk (cudawrapper.cu:877-878) files under LOCAL camera numbers read as view ids can name any view of the scene: the records that
+        // point at an early-return view -- a sliver of their sources' lists -- are all-gathered, each source's by the rank that owns it.
+        std::vector<ChainResult> hloc((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) { hloc[(size_t)k] = ChainResult(); if (k >= exact_from && k < last) hloc[(size_t)k] = hres[k]; }
+        long long used = 0;
+        for (int k = exact_from; k < last; ++k) used = std::max(used, (long long)hres[k].kept_base + hres[k].n_kept);
+        // ---- early-return views: groups = their sources; sender = the owner of the source
+        std::vector<unsigned> early_ids;
+        std::vector<int> groups_all;                               // every source of an early-return view, ascending, unique
+        for (int k = 0; k < n_views; ++k) {
+            if (views[k].n_tbm != 0 || views[k].n_sources == 0) continue;
+            early_ids.push_back(views[k].view_id);
+            for (int q = 0; q < views[k].n_sources; ++q) if (views[k].source_index[q] >= 0 && views[k].source_index[q] < k && views[views[k].source_index[q]].n_tbm > 0) groups_all.push_back(views[k].source_index[q]);
+        }
+        std::sort(groups_all.begin(), groups_all.end());
+        groups_all.erase(std::unique(groups_all.begin(), groups_all.end()), groups_all.end());
+        if (early_ids.size() > 64 || groups_all.size() > 480) return L3D_OK;    // (a schedule full of early returns: the replicated mode takes it; the same on every rank)
+        if (!groups_all.empty() && world > 1) {
+            std::vector<int> mine;
+            for (int si : groups_all) if (owner(si) == rank) mine.push_back(si);
+            const size_t o_ids = 0, o_grp = 256, o_off = o_grp + 2048, o_cnt = o_off + 4096, ctl = o_cnt + 2048;
+            std::vector<int> cnt(mine.size(), 0);
+            long long total = 0;
+            {
+                hipError_t e = c->ch_send.reserve(ctl + 256);
+                if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_partition: early-return control block"));
+                else if (!mine.empty()) {
+                    unsigned char* S0 = c->ch_send.as<unsigned char>();
+                    L3D_SOFT(hipMemcpyAsync(S0 + o_ids, early_ids.data(), early_ids.size() * 4, hipMemcpyHostToDevice, st));
+                    L3D_SOFT(hipMemcpyAsync(S0 + o_grp, mine.data(), mine.size() * 4, hipMemcpyHostToDevice, st));
+                    hipLaunchKernelGGL(k_early_pack, dim3((unsigned)mine.size()), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), reinterpret_cast<const int*>(S0 + o_grp),
+                                       reinterpret_cast<const unsigned*>(S0 + o_ids), (int)early_ids.size(), (const long long*)nullptr, (Match*)nullptr, reinterpret_cast<int*>(S0 + o_cnt));
+                    L3D_SOFT(hipMemcpyAsync(cnt.data(), S0 + o_cnt, mine.size() * 4, hipMemcpyDeviceToHost, st));
+                    L3D_SOFT(hipStreamSynchronize(st));
+                    for (int x : cnt) total += x;
+                }
+            }
+            if (int a_rc = all_gather_word(total, "counting the records that point at early-return views")) return a_rc;
+            long long max_total = 0;
+            for (int r = 0; r < world; ++r) max_total = std::max(max_total, words[(size_t)r]);
+            const size_t hdr = 4096, eslot = hdr + al((size_t)max_total * sizeof(Match)) + 256;
+            {
+                // slot: [int n_groups | (int source, int count) x n_groups] [records of the groups, back to back]; staged in ch_stage (ch_send holds the control block)
+                hipError_t e = c->ch_stage.reserve(eslot + 256);
+                if (e == hipSuccess) e = c->ch_gathered.reserve(eslot * (size_t)world + 256);
+                if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_partition: early-return slots"));
+                else {
+                    std::vector<int> h((size_t)1 + 2 * mine.size(), 0);
+                    std::vector<long long> offs(mine.size(), 0);
+                    h[0] = (int)mine.size();
+                    long long o = 0;
+                    for (size_t g = 0; g < mine.size(); ++g) { h[1 + 2 * g] = mine[g]; h[2 + 2 * g] = cnt[g]; offs[g] = o; o += cnt[g]; }
+                    unsigned char* S0 = c->ch_send.as<unsigned char>();
+                    unsigned char* E0 = c->ch_stage.as<unsigned char>();
+                    L3D_SOFT(hipMemcpyAsync(E0, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+                    if (total > 0) {
+                        L3D_SOFT(hipMemcpyAsync(S0 + o_off, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
+                        hipLaunchKernelGGL(k_early_pack, dim3((unsigned)mine.size()), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), reinterpret_cast<const int*>(S0 + o_grp),
+                                           reinterpret_cast<const unsigned*>(S0 + o_ids), (int)early_ids.size(), reinterpret_cast<const long long*>(S0 + o_off), reinterpret_cast<Match*>(E0 + hdr), (int*)nullptr);
+                    }
+                    L3D_SOFT(hipStreamSynchronize(st));        // (h / offs are stack vectors)
+                }
+            }
+            if (int a_rc = all_gather_word(0, "staging the records that point at early-return views")) return a_rc;
+            if (exchange(exchange_user, -6, c->ch_stage.p, c->ch_gathered.p, eslot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_partition: the exchange of the early-return records failed");
+            // a source this rank does not hold gets a list of its own: just those records, in list order
+            const unsigned char* G = c->ch_gathered.as<unsigned char>();
+            std::vector<int> hh(1024);
+            for (int r = 0; r < world && !local_rc; ++r) {
+                if (r == rank) continue;
+                L3D_SOFT(hipMemcpyAsync(hh.data(), G + (size_t)r * eslot, hdr, hipMemcpyDeviceToHost, st));
+                L3D_SOFT(hipStreamSynchronize(st));
+                if (local_rc) break;
+                long long o = 0;
+                for (int g = 0; g < hh[0] && g < 480; ++g) {
+                    const int si = hh[1 + 2 * g], n = hh[2 + 2 * g];
+                    if (si >= 0 && si < n_views && n > 0 && !(si >= exact_from && si < last)) {
+                        if (int rc = arena_grow_keep(c, (size_t)(used + n) + 64, (size_t)used)) { note(rc); break; }
+                        L3D_SOFT(hipMemcpyAsync(c->ch_kept.as<Match>() + used, G + (size_t)r * eslot + hdr + (size_t)o * sizeof(Match), (size_t)n * sizeof(Match), hipMemcpyDeviceToDevice, st));
+                        ChainResult& x = hloc[(size_t)si];
+                        x.kept_base = (unsigned)used; x.n_kept = n; x.R = n; x.overflow = 0;
+                        used += n;
+                    }
+                    o += n;
+                }
+            }
+            if (used > 0xfffffff0ll) note(fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_partition: more than 2^32 kept matches on one rank"));
+        }
+        // ---- the views an early return's LOCAL camera numbers name (cudawrapper.cu:877-878 hands the list back with local numbers, line3D.cc:861-865
+        // files the entries under them read as view ids): rows of an early-return view point at their segments, whoever holds them.  The affinity fill
+        // only asks whether such a segment has a hypothesis and where it stands in the order -- the views' best matches (one record per segment:
+        // a few hundred KB per view) are all-gathered, each view's by the rank that owns it
+        std::vector<char> alias_known((size_t)n_views, 0);
+        if (!early_ids.empty() && world > 1) {
+            std::vector<std::pair<unsigned, int>> idx((size_t)n_views);
+            for (int k = 0; k < n_views; ++k) idx[(size_t)k] = { views[k].view_id, k };
+            std::sort(idx.begin(), idx.end());
+            std::vector<int> alias;
+            for (int k = 0; k < n_views; ++k) {
+                if (views[k].n_tbm != 0 || views[k].n_sources == 0) continue;
+                for (int q = 0; q < views[k].n_sources; ++q) {
+                    auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair((unsigned)views[k].source_cam[q], -1));
+                    if (it != idx.end() && it->first == (unsigned)views[k].source_cam[q] && views[it->second].n_tbm > 0) alias.push_back(it->second);
+                }
+            }
+            std::sort(alias.begin(), alias.end());
+            alias.erase(std::unique(alias.begin(), alias.end()), alias.end());
+            auto pk_bytes = [&](int b) { return al(16 + (size_t)views[b].S_src * (12 + sizeof(Match))); };
+            std::vector<size_t> slot_of((size_t)world, 0);
+            for (int b : alias) slot_of[(size_t)owner(b)] += pk_bytes(b);
+            size_t aslot = 256;
+            for (int r = 0; r < world; ++r) aslot = std::max(aslot, slot_of[(size_t)r] + 256);
+            if (!alias.empty()) {
+                std::vector<int> pk_view, pk_S;
+                std::vector<long long> pk_bo, pk_oo;
+                size_t o = 0;
+                for (int b : alias) if (owner(b) == rank) { pk_view.push_back(b); pk_S.push_back(views[b].S_src); pk_bo.push_back(best_off[(size_t)b]); pk_oo.push_back((long long)o); o += pk_bytes(b); }
+                {
+                    const size_t n = pk_view.size(), ctl = al(n * 4) * 2 + al(n * 8) * 2 + 256;
+                    hipError_t e = c->ch_stage.reserve(aslot + 256);
+                    if (e == hipSuccess) e = c->ch_gathered.reserve(aslot * (size_t)world + 256);
+                    if (e == hipSuccess) e = c->ch_send.reserve(ctl);
+                    if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_partition: alias-view packages"));
+                    else if (n > 0) {
+                        unsigned char* S0 = c->ch_send.as<unsigned char>();
+                        const size_t o1 = al(n * 4), o2 = 2 * al(n * 4), o3 = o2 + al(n * 8);
+                        L3D_SOFT(hipMemcpyAsync(S0, pk_view.data(), n * 4, hipMemcpyHostToDevice, st));
+                        L3D_SOFT(hipMemcpyAsync(S0 + o1, pk_S.data(), n * 4, hipMemcpyHostToDevice, st));
+                        L3D_SOFT(hipMemcpyAsync(S0 + o2, pk_bo.data(), n * 8, hipMemcpyHostToDevice, st));
+                        L3D_SOFT(hipMemcpyAsync(S0 + o3, pk_oo.data(), n * 8, hipMemcpyHostToDevice, st));
+                        hipLaunchKernelGGL(k_alias_pack, dim3((unsigned)n), dim3(256), 0, st, c->ch_kept.as<Match>(), c->ch_res.as<ChainResult>(), reinterpret_cast<const int*>(S0), reinterpret_cast<const int*>(S0 + o1),
+                                           reinterpret_cast<const long long*>(S0 + o2), reinterpret_cast<const long long*>(S0 + o3), c->ch_best.as<float2>(), c->ch_bestpos.as<int>(), c->ch_stage.as<unsigned char>());
+                        L3D_SOFT(hipStreamSynchronize(st));        // (the control vectors are on the stack)
+                    }
+                }
+                if (int a_rc = all_gather_word(0, "packing the best matches of the views early returns name")) return a_rc;
+                if (exchange(exchange_user, -11, c->ch_stage.p, c->ch_gathered.p, aslot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_partition: the exchange of the alias views' best matches failed");
+                const unsigned char* G = c->ch_gathered.as<unsigned char>();
+                std::vector<size_t> at((size_t)world, 0);
+                for (int b : alias) {
+                    const int r = owner(b);
+                    const unsigned char* pk = G + (size_t)r * aslot + at[(size_t)r];
+                    at[(size_t)r] += pk_bytes(b);
+                    if (local_rc || (b >= exact_from && b < last)) continue;              // (held: its own records say it all)
+                    int h[4] = { 0, 0, 0, 0 };
+                    L3D_SOFT(hipMemcpyAsync(h, pk, 16, hipMemcpyDeviceToHost, st));
+                    L3D_SOFT(hipStreamSynchronize(st));
+                    const int S = views[b].S_src;
+                    if (local_rc) break;
+                    if (h[0] != b || h[3] != S || h[2] < 0 || h[2] > S) { note(fail(c, L3D_ERR_INVALID, "l3d_match_chain_partition: a package of best matches does not name the view it should")); break; }
+                    if (int rc = arena_grow_keep(c, (size_t)(used + h[2]) + 64, (size_t)used)) { note(rc); break; }
+                    if (h[2] > 0) L3D_SOFT(hipMemcpyAsync(c->ch_kept.as<Match>() + used, pk + 16 + (size_t)S * 12, (size_t)h[2] * sizeof(Match), hipMemcpyDeviceToDevice, st));
+                    L3D_SOFT(hipMemcpyAsync(c->ch_bestpos.as<int>() + best_off[(size_t)b], pk + 16, (size_t)S * 4, hipMemcpyDeviceToDevice, st));
+                    L3D_SOFT(hipMemcpyAsync(c->ch_best.as<float2>() + best_off[(size_t)b], pk + 16 + (size_t)S * 4, (size_t)S * 8, hipMemcpyDeviceToDevice, st));
+                    ChainResult& x = hloc[(size_t)b];
+                    x.kept_base = (unsigned)used; x.n_kept = h[2]; x.R = h[1]; x.overflow = 0;
+                    used += h[2];
+                    alias_known[(size_t)b] = 1;
+                }
+            }
+        }
+        // ---- the local products
+        std::vector<ProdChainView> pvh((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) {
+            const bool ver = views[k].n_tbm > 0, held = (k >= exact_from && k < last) || alias_known[(size_t)k];
+            pvh[(size_t)k].verified = ver ? 1 : 0;
+            pvh[(size_t)k].best = ver && held ? c->ch_best.as<float2>() + best_off[(size_t)k] : nullptr;
+            pvh[(size_t)k].bestpos = ver && held ? c->ch_bestpos.as<int>() + best_off[(size_t)k] : nullptr;
+        }
+        const int row0 = std::max(rank == 0 ? 0 : exact_from, own0 - reach), row1 = std::min(last, own1 + reach);
+        ProductsPart part;
+        part.active = true; part.rank = rank; part.world = world;
+        part.own_dv0 = dense_of(own0); part.own_dv1 = dense_of(own1);
+        part.row_dv0 = dense_of(row0); part.row_dv1 = dense_of(row1);
+        part.held_dv0 = dense_of(exact_from); part.held_dv1 = dense_of(last);
+        part.recovery_rounds = rounds;
+        int64_t n_local = 0;
+        const double t3 = now_s();
+        if (!local_rc) {
+            std::vector<char> held((size_t)n_views, 0);
+            for (int k = exact_from; k < last; ++k) held[(size_t)k] = 1;
+            note(build_products(c, views, n_views, pvh.data(), hloc.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, held.data()));
+        }
+        if (int a_rc = all_gather_word(n_local, "building its rows of the products")) return a_rc;
+        part.n_pot_all = 0;
+        for (int r = 0; r < world; ++r) part.n_pot_all += words[(size_t)r];
+        P.part = part;
+        P.n_pot = n_local;
+        P.valid = true;
+        if (n_pot) *n_pot = n_local;
+        memcpy(c->ch_pin_res.as<ChainResult>(), hloc.data(), (size_t)n_views * sizeof(ChainResult));       // (what l3d_chain_kept_list reads)
+        { double kept = 0, raw = 0; for (int k = own0; k < own1; ++k) { kept += hloc[(size_t)k].n_kept; raw += hloc[(size_t)k].R; } c->stats[3] = kept; c->stats[1] = raw; }      // (this rank's block)
+        if (c->opt.timing) fprintf(stderr, "[l3d chain_partition rank %d/%d] exact from view %d, chain to view %d, rows of views %d..%d, %lld potential correspondences here of %lld: products %.2f ms\n",
+                                   rank, world, exact_from, last - 1, row0, row1 - 1, (long long)n_local, part.n_pot_all, (now_s() - t3) * 1e3);
+        *verdict = 0;
+        return L3D_OK;
+    }
+
+    // ---- all-gather of the blocks: [records of the block's views][best depth pairs][best positions], padded to the largest block
     std::vector<long long> rec_of((size_t)world, 0), seg_of((size_t)world, 0);
     for (int k = 0; k < n_views; ++k) {
         const int r = owner(k);
@@ -785,39 +1233,31 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     }
     long long max_rec = 0, max_seg = 0, total = 0;
     for (int r = 0; r < world; ++r) { max_rec = std::max(max_rec, rec_of[(size_t)r]); max_seg = std::max(max_seg, seg_of[(size_t)r]); total += rec_of[(size_t)r]; }
-    if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_blocks: more than 2^32 kept matches");     // (the same on every rank)
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_blocks: more than 2^32 kept matches (l3d_match_chain_partition keeps every rank's records where they are)");     // (the same on every rank)
     const size_t o_best = al((size_t)max_rec * sizeof(Match)), o_bpos = o_best + al((size_t)max_seg * 8), slot = o_bpos + al((size_t)max_seg * 4);
-    // offsets of the views' slices in the whole-run arrays of best pairs / positions (chain_assign_arenas: verified views back to back)
-    std::vector<long long> best_off((size_t)n_views + 1, 0);
-    for (int k = 0; k < n_views; ++k) best_off[(size_t)k + 1] = best_off[(size_t)k] + (views[k].n_tbm > 0 ? views[k].S_src : 0);
-    const auto stage_block = [&]() -> int {
-        HIPCHK(c, c->ch_send.reserve(slot + 256));
-        HIPCHK(c, c->ch_gathered.reserve(slot * (size_t)world + 256));
-        unsigned char* send = c->ch_send.as<unsigned char>();
-        long long own_start = 0;                                    // (this rank's arena: the views it computed, back to back from its cold start)
-        for (int k = first; k < own0; ++k) own_start += hres[k].n_kept;
-        if (rec_of[(size_t)rank] > 0)
-            HIPCHK(c, hipMemcpyAsync(send, c->ch_kept.as<Match>() + own_start, (size_t)rec_of[(size_t)rank] * sizeof(Match), hipMemcpyDeviceToDevice, st));
-        if (seg_of[(size_t)rank] > 0) {
-            HIPCHK(c, hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 8, hipMemcpyDeviceToDevice, st));
-            HIPCHK(c, hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 4, hipMemcpyDeviceToDevice, st));
+    {
+        hipError_t e = c->ch_send.reserve(slot + 256);
+        if (e == hipSuccess) e = c->ch_gathered.reserve(slot * (size_t)world + 256);
+        if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_blocks: the blocks' slots"));
+        else {
+            unsigned char* send = c->ch_send.as<unsigned char>();
+            long long own_start = 0;                                    // (this rank's arena: the views it holds, back to back from arena_first)
+            for (int k = arena_first; k < own0; ++k) own_start += hres[k].n_kept;
+            if (rec_of[(size_t)rank] > 0)
+                L3D_SOFT(hipMemcpyAsync(send, c->ch_kept.as<Match>() + own_start, (size_t)rec_of[(size_t)rank] * sizeof(Match), hipMemcpyDeviceToDevice, st));
+            if (seg_of[(size_t)rank] > 0) {
+                L3D_SOFT(hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 8, hipMemcpyDeviceToDevice, st));
+                L3D_SOFT(hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)own0], (size_t)seg_of[(size_t)rank] * 4, hipMemcpyDeviceToDevice, st));
+            }
         }
-        return L3D_OK;
-    };
-    { const int rc = stage_block(); if (int a_rc = all_gather_word(rc ? -(long long)rc : 0, "staging its block")) return a_rc; }
+    }
+    if (int a_rc = all_gather_word(0, "staging its block")) return a_rc;
     if (exchange(exchange_user, -2, c->ch_send.p, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the kept lists failed");
     // ---- the one chain's arena: blocks in rank order = views in order; then matchViews' products: every rank builds the rows of its OWN block
     // of views (sort + unique of the keys whose source lies in the block: its views' records and their neighbours', all of them in the arena now),
     // the pieces are all-gathered and put together -- 1/world of the sort per rank instead of all of it on every rank
     std::vector<ChainResult> hres_all((size_t)n_views);
     std::vector<ProdChainView> pvh((size_t)n_views);
-    const int nvd = map->n_views;
-    auto dense_of = [&](int k) {                                   // the dense view a chain view is (ids ascend in both)
-        if (k >= n_views) return nvd;
-        const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + nvd, views[k].view_id);
-        return (int)(it - map->view_ids);
-    };
     std::vector<int> dvb((size_t)world + 1);
     for (int r = 0; r <= world; ++r) dvb[(size_t)r] = r == 0 ? 0 : (r == world ? nvd : dense_of(block_begin(r)));
     for (int r = 1; r <= world; ++r) if (dvb[(size_t)r] < dvb[(size_t)r - 1]) return fail(c, L3D_ERR_INVALID, "l3d_match_chain_blocks: the chain's views do not ascend with the dense map");     // (the same on every rank)
@@ -851,9 +1291,8 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
         t3 = now_s();
         return build_products(c, views, n_views, pvh.data(), hres_all.data(), map, summary, &n_local, dvb[(size_t)rank], dvb[(size_t)rank + 1]);
     };
-    Products& P = c->products;
     // counts first (a piece is padded to the largest; a negative count = this rank failed), then [row starts of the block, numbered from 0 | entries]
-    { const int rc = assemble_and_build(); if (int a_rc = all_gather_word(rc ? -(long long)rc : (long long)n_local, "building its rows of the products")) return a_rc; }
+    { note(assemble_and_build()); if (int a_rc = all_gather_word((long long)n_local, "building its rows of the products")) return a_rc; }
     const std::vector<long long> cnts = words;
     long long max_cnt = 0, max_rows = 0, n_pot_all = 0;
     for (int r = 0; r < world; ++r) {
@@ -861,17 +1300,20 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
         max_rows = std::max(max_rows, (long long)map->seg_base[dvb[(size_t)r + 1]] - map->seg_base[dvb[(size_t)r]]);
     }
     const size_t o_ent = al((size_t)max_rows * 8), pslot = o_ent + al((size_t)max_cnt * 4 + 4);
-    const auto stage_piece = [&]() -> int {
-        HIPCHK(c, c->ch_send.reserve(pslot + 256));
-        HIPCHK(c, c->ch_gathered.reserve(pslot * (size_t)world + 256));
-        const long long r0 = map->seg_base[dvb[(size_t)rank]], nr = (long long)map->seg_base[dvb[(size_t)rank + 1]] - r0;
-        unsigned char* sp = c->ch_send.as<unsigned char>();
-        if (nr > 0) HIPCHK(c, hipMemcpyAsync(sp, P.pot_start.as<long long>() + r0, (size_t)nr * 8, hipMemcpyDeviceToDevice, st));
-        if (n_local > 0) HIPCHK(c, hipMemcpyAsync(sp + o_ent, P.pot_tgt.p, (size_t)n_local * 4, hipMemcpyDeviceToDevice, st));
-        return L3D_OK;
-    };
-    { const int rc = stage_piece(); if (int a_rc = all_gather_word(rc ? -(long long)rc : 0, "staging its piece of the products")) return a_rc; }
+    {
+        hipError_t e = c->ch_send.reserve(pslot + 256);
+        if (e == hipSuccess) e = c->ch_gathered.reserve(pslot * (size_t)world + 256);
+        if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_blocks: the pieces' slots"));
+        else {
+            const long long r0 = map->seg_base[dvb[(size_t)rank]], nr = (long long)map->seg_base[dvb[(size_t)rank + 1]] - r0;
+            unsigned char* sp = c->ch_send.as<unsigned char>();
+            if (nr > 0) L3D_SOFT(hipMemcpyAsync(sp, P.pot_start.as<long long>() + r0, (size_t)nr * 8, hipMemcpyDeviceToDevice, st));
+            if (n_local > 0) L3D_SOFT(hipMemcpyAsync(sp + o_ent, P.pot_tgt.p, (size_t)n_local * 4, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    if (int a_rc = all_gather_word(0, "staging its piece of the products")) return a_rc;
     if (exchange(exchange_user, -4, c->ch_send.p, c->ch_gathered.p, pslot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the exchange of the table pieces failed");
+    // (past the last collective: a failure from here on is this rank's alone)
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, P.pot_tgt.reserve(((size_t)n_pot_all + 2) * 4));
     {
@@ -896,6 +1338,29 @@ extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, i
     if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] gather of the blocks %.2f ms, products (own rows + gather of the pieces) %.2f ms\n", rank, world, (t3 - t2) * 1e3, (now_s() - t3) * 1e3);
     *verdict = 0;
     return L3D_OK;
+#undef L3D_SOFT
+}
+
+extern "C" int l3d_match_chain_blocks(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                                      int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    return chain_blocks_impl(c, views, n_views, map, summary, n_pot, rank, world, warmup_views, window, exchange, exchange_user, verdict, 0);
+}
+
+extern "C" int l3d_match_chain_partition(l3d_ctx* c, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
+                                         int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    return chain_blocks_impl(c, views, n_views, map, summary, n_pot, rank, world, warmup_views, window, exchange, exchange_user, verdict, 1);
+}
+
+extern "C" int l3d_partition_info(l3d_ctx* c, int info[8], int64_t* n_pot_all, int* recovery_rounds)
+{
+    if (!c) return L3D_ERR_INVALID;
+    const ProductsPart& q = c->products.part;
+    if (info) { const int v[8] = { q.rank, q.world, q.own_dv0, q.own_dv1, q.row_dv0, q.row_dv1, q.held_dv0, q.held_dv1 }; memcpy(info, v, sizeof(v)); }
+    if (n_pot_all) *n_pot_all = q.active ? q.n_pot_all : c->products.n_pot;
+    if (recovery_rounds) *recovery_rounds = q.recovery_rounds;
+    return L3D_OK;                      // (info[1] = world of the partition; not partitioned: the defaults, world 1)
 }
 
 void l3d::warm_chain() { touch_kernel(reinterpret_cast<const void*>(&k_exist_count)); }

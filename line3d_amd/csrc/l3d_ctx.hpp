@@ -78,9 +78,21 @@ struct PinArena {
     void release() { for (auto& b : chunks) b.release(); chunks.clear(); reset(); }
 };
 
+// matchViews' products PARTITIONED over the ranks of a job (l3d_match_chain_partition): what this rank's share covers, in views of the dense map
+struct ProductsPart {
+    bool active = false;
+    int rank = 0, world = 1;
+    int own_dv0 = 0, own_dv1 = 0;       // the rank's block: its sources in the affinity fill
+    int row_dv0 = 0, row_dv1 = 0;       // views whose rows of the potential-correspondence table are complete here (the block and `reach` views either side)
+    int held_dv0 = 0, held_dv1 = 0;     // views whose kept records, best matches and medians are here (2 x reach either side): they get hypotheses
+    long long n_pot_all = 0;            // entries of the table over all ranks
+    int recovery_rounds = 0;            // blocks that were re-run warm after their speculation failed (whole job)
+};
+
 // Device-resident products of the last resident chain (l3d_products.hip) and the hypothesis table built from them
 struct Products {
     bool valid = false, hyp_valid = false;
+    ProductsPart part;
     int n_dense = 0, n_views_all = 0, n_chain = 0, n_hyp = 0;
     long long n_pot = 0, total_kept = 0;
     DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables;
@@ -110,7 +122,10 @@ struct ShardGraph { unsigned long long sig = 0; int seen = 0; hipGraphExec_t exe
 // a rank's part of an affinity fill sharded by source key (l3d_affinity.hip: affinity_fill_core): the sources it enumerates, where its
 // candidates stand in the whole enumeration (ranks own ascending source ranges: rank << 44 orders them without knowing the other ranks' counts)
 // and what turns its local hypothesis indices into global ones
-struct FillPart { int h0, h1; unsigned long long pos_base; int hyp_off; };
+// assume_symmetric: the table was built by l3d_products.hip, which files every potential correspondence under both of its segments at once (the
+// two keys of k_prod_keys): "is the source among the target's targets" is true by construction and is not looked up -- a rank holds the rows of
+// its own sources' targets only in part
+struct FillPart { int h0 = 0, h1 = 0; unsigned long long pos_base = 0; const int* loc2glob = nullptr; int assume_symmetric = 0; };     // loc2glob: device, global number of every local hypothesis
 
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -154,6 +169,7 @@ struct l3d_ctx {
     // other paths
     l3d::DevBuf g0, g1, g2, g3, g4, g5, g6, g7;
     l3d::DevBuf aff_hyp;            // hypothesis table of the last l3d_affinity_fill (kept for l3d_fit_clusters)
+    l3d::DevBuf aff_l2g;            // sharded fill: global number of every local hypothesis
     l3d::DevBuf aff_first, aff_pass_pairs, aff_pass_w;   // affinity fill in blocks of sources: first-touch minima per hypothesis, the candidates that passed (pairs, weights)
     long long fill_items = 0, fill_passed = 0;           // candidates enumerated / passed by the last fill (64-bit: l3d_last_fill_counts)
     int resident_hyp = 0;           // its number of hypotheses (0: none)

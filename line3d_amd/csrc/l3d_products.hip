@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_prod_keys_early(const Match* __restrict
             if (!out_off) atomicAdd(&list_len[e.view], 1);                      // (length of the view's list: statistics)
             // the list entry: segID1 = r.segID2 (the view's segment), camID2 = local number, segID2 = r.segID1
             if ((int)r.segID2 < v.S) {
-                if (!out_off) atomicMin(&best_ref[v.dense_base + (int)r.segID2], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i));
+                if (!out_off) { if (!e.pad) atomicMin(&best_ref[v.dense_base + (int)r.segID2], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i)); }
                 else if (e.alias_base >= 0 && (int)r.segID1 < e.alias_S) {
                     const int ai = v.dense_base + (int)r.segID2, di = e.alias_base + (int)r.segID1;
                     const unsigned long long a = (unsigned long long)ai, d = (unsigned long long)di;
@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256) void k_prod_csr(const unsigned long long* __re
     if (i == 0 || prev != src) for (long long d = prev + 1; d <= src; ++d) pot_start[d] = p;
 }
 
+// partitioned products: the rows this rank does not hold are empty -- in front of its rows they start at 0, behind them at its last entry
+__global__ __launch_bounds__(256) void k_prod_fill_rows(long long* __restrict__ pot_start, long long lo, long long hi, long long value)
+{
+    const long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < hi) pot_start[i] = value;
+}
+
 // a rank's piece of the table (l3d_match_chain_blocks): its row starts, numbered from 0, shifted to where its entries sit in the whole table
 __global__ __launch_bounds__(256) void k_prod_shift_rows(const long long* __restrict__ piece, long long n_rows, long long base, long long* __restrict__ pot_start)
 {
@@ -231,7 +238,7 @@ void l3d::launch_prod_shift_rows(const long long* piece, long long n_rows, long 
 }
 
 int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pvh, const ChainResult* hres,
-                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1)
+                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1, const char* held)
 {
     Products& P = c->products;
     P.valid = false; P.hyp_valid = false;
@@ -284,7 +291,8 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                 const int si = v.source_index[q];
                 if (si < 0 || si >= k || !pvh[si].verified) continue;       // (a source is a verified earlier view)
                 ProdSrc e;
-                e.view = k; e.src = si; e.rank = q; e.pad = 0;
+                e.view = k; e.src = si; e.rank = q; e.pad = 0;     // (partitioned: an early-return view's best matches are found on EVERY rank -- the records that point at it are
+                                                                    // all-gathered, in list order -- because what is filed under its local camera numbers makes it a target of far-away rows)
                 const int av = view_of((unsigned)v.source_cam[q]);           // the LOCAL camera number read as a view id (line3D.cc:861-865)
                 e.alias_base = av >= 0 ? P.seg_base[(size_t)av] : -1; e.alias_S = av >= 0 ? P.seg_base[(size_t)av + 1] - P.seg_base[(size_t)av] : 0;
                 e.out_off = 0;
@@ -439,6 +447,12 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("products: ") + hipGetErrorString(e_)); }
     const long long n_pot = base + n_last;
     P.n_pot = n_pot;
+    if (held) {
+        const long long r0 = blocks.empty() ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv0], r1 = blocks.empty() ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv1] + 1;
+        if (r0 > 0) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)((std::min<long long>(r0, nd + 1) + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), 0ll, std::min<long long>(r0, nd + 1), 0ll);
+        if (r1 <= nd) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)(((long long)nd + 1 - r1 + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), r1, (long long)nd + 1, n_pot);
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     for (int k = 0; k < n_views; ++k) {
         l3d_chain_summary& s = summary[k];
         s.verified = pvh[k].verified; s.n_kept = pvh[k].verified ? hres[k].n_kept : reinterpret_cast<const int*>(med.data() + n_views)[k];

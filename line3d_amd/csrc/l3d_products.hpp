@@ -17,8 +17,10 @@ struct ProdChainView {
 // CSR, medians) have arrived.  hres: the chain's per-view result records (host copies).
 // dv0, dv1 (dv1 >= 0): only the rows of the dense views [dv0, dv1), numbered from 0 -- pot_start[seg_base[dv0] .. seg_base[dv1]] and that many
 // entries of pot_tgt are valid afterwards, P.valid stays false (the caller assembles the pieces: l3d_match_chain_blocks)
+// held (partitioned products: l3d_match_chain_partition): per chain view, whether its records are on this rank; the rows outside [dv0, dv1) are
+// then left EMPTY but well-formed (the whole pot_start array is valid)
 int build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pv, const ChainResult* hres,
-                   const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, int dv0 = 0, int dv1 = -1);
+                   const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, int dv0 = 0, int dv1 = -1, const char* held = nullptr);
 
 // pot_start[first_row + i] = piece[i] + base for n_rows rows (a rank's rows of the table put in place)
 void launch_prod_shift_rows(const long long* piece, long long n_rows, long long base, long long* pot_start_at, hipStream_t st);

@@ -204,6 +204,7 @@ int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
     const double t0 = now_s();
+    if (h->partitioned && !h->part_exchange) return h->fail(L3D_ERR_INVALID, "finish: matchViews' products are partitioned over the ranks (l3d_line3d_finish_sharded)");
     if (h->resident_products) { const int rg = greedy_selection_resident(h); if (rg) return rg; }
     else greedy_selection(h);                              // optimizeLocalMatches, :888-896
     if (hopt(h).timing) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
@@ -392,18 +393,21 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
 // (l3d_match_chain_blocks).  *verdict = 0: this rank holds matchViews' products as after the single-GPU resident chain; 1: the speculation
 // did not hold on this scene, nothing was committed -- the caller runs l3d_line3d_shard_run (every rank gets the same verdict).
 // warmup_views < 0: eight neighbour windows.
-int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+static int block_run_impl(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict, bool partition)
 {
     if (!h || !verdict) return L3D_ERR_INVALID;
     *verdict = 1;
     const double t0 = now_s();
     match_begin(h);
+    h->partitioned = false;
     ChainPlan* Pp = get_plan(h);
     if (!Pp) return L3D_OK;                               // (a schedule the chain cannot express: the caller's other paths handle it)
     ChainPlan& P = *Pp;
     int window = 1;
     for (size_t k = 0; k < P.n; ++k) for (int si : P.src_idx[k]) window = std::max(window, (int)k - si);
-    if (warmup_views < 0) warmup_views = 8 * window;       // (the chain forgets a cold start after 3-7 windows on the synthetic scenes, the denser the later: scripts/speculate_blocks.py)
+    // (round 4: eight windows -- any miss cost the pass; round 5: a block whose speculation fails is re-run warm, so the default is what the
+    // chain's memory was measured at, profiles/r4_speculate_*.txt: 3-7 windows, and the check pays for the misses)
+    if (warmup_views < 0) warmup_views = 4 * window;
     std::vector<uint32_t> ids; std::vector<int32_t> base;
     dense_map(h, ids, base);
     l3d_dense_map map;
@@ -411,11 +415,15 @@ int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l
     h->chain_summary.assign(P.n, l3d_chain_summary());
     h->resident_products = false;
     const double t1 = now_s();
-    int rc = l3d_match_chain_blocks(h->ctx, P.cv.data(), (int)P.n, &map, h->chain_summary.data(), &h->resident_n_pot, rank, world, warmup_views, window,
-                                    exchange, exchange_user, verdict);
+    int rc = partition ? l3d_match_chain_partition(h->ctx, P.cv.data(), (int)P.n, &map, h->chain_summary.data(), &h->resident_n_pot, rank, world, warmup_views, window,
+                                                   exchange, exchange_user, verdict)
+                       : l3d_match_chain_blocks(h->ctx, P.cv.data(), (int)P.n, &map, h->chain_summary.data(), &h->resident_n_pot, rank, world, warmup_views, window,
+                                                exchange, exchange_user, verdict);
     h->t_gpu_call += now_s() - t1;
-    if (rc) return h->fail(rc, std::string("match_chain_blocks: ") + l3d_last_error(h->ctx));
+    if (rc) return h->fail(rc, std::string(partition ? "match_chain_partition: " : "match_chain_blocks: ") + l3d_last_error(h->ctx));
     if (*verdict != 0) return L3D_OK;
+    h->partitioned = partition;
+    h->part_exchange = exchange; h->part_user = exchange_user;
     rc = adopt_resident_products(h, P);
     if (rc) return rc;
     double st[4];
@@ -424,6 +432,27 @@ int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l
     h->stat_raw += st[1];
     h->t_match = now_s() - t0;
     return L3D_OK;
+}
+int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    return block_run_impl(h, rank, world, warmup_views, exchange, exchange_user, verdict, false);
+}
+// matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition): this rank holds its block's share of the kept records
+// and of matchViews' products; the rest of compute3Dmodel is collective -- l3d_line3d_finish_sharded on every rank
+int l3d_line3d_partition_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict)
+{
+    return block_run_impl(h, rank, world, warmup_views, exchange, exchange_user, verdict, true);
+}
+// Line3D::compute3Dmodel's tail after l3d_line3d_partition_run, on every rank of the job: greedy selection on the views this rank holds, the affinity
+// fill sharded by source key (l3d_affinity_fill_sharded: five small all-gathers), then -- replicas, every rank from the same edge list -- diffusion,
+// clustering, line fit.  Every rank ends with the whole result.
+int l3d_line3d_finish_sharded(l3d_line3d* h, int perform_diffusion, l3d_exchange_fn exchange, void* exchange_user)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    if (!h->partitioned || !h->resident_products) return h->fail(L3D_ERR_INVALID, "finish_sharded: matchViews did not run partitioned (l3d_line3d_partition_run)");
+    if (exchange) { h->part_exchange = exchange; h->part_user = exchange_user; }
+    if (!h->part_exchange) return h->fail(L3D_ERR_INVALID, "finish_sharded: no exchange");
+    return l3d_line3d_finish(h, perform_diffusion);
 }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 

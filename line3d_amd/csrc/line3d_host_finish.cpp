@@ -360,6 +360,47 @@ int fill_affinity_resident(L* h)
     return L3D_OK;
 }
 
+// the affinity fill of a job whose matchViews ran partitioned (l3d_affinity_fill_sharded): this rank's block of sources, then the global tables --
+// hypothesis numbers, which segment every hypothesis belongs to -- replace the local ones of greedy_selection_resident
+int fill_affinity_sharded(L* h)
+{
+    const size_t nv = h->vlist.size();
+    std::vector<size_t> voff(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) voff[i + 1] = voff[i] + (size_t)h->vlist[i]->S();
+    L::AffTables& T = h->aff;
+    const bool changed = !T.coll_valid || T.coll_start.size() != voff.back() + 1;
+    if (changed) pack_collinearities(h, voff);
+    std::vector<int32_t> vhb(nv + 1, 0);
+    int32_t *node_hyp = nullptr, *hyp_dense = nullptr;
+    int n_edges = 0, n_nodes = 0, nh_all = 0;
+    int64_t cand_all = 0;
+    const double t0 = now_s();
+    int rc = l3d_affinity_fill_sharded(h->ctx, T.coll_start.data(), T.coll_other.data(), T.coll_w.data(), changed ? 1 : 0, h->sigma_a, h->part_exchange, h->part_user,
+                                       &n_edges, &node_hyp, &n_nodes, &cand_all, vhb.data(), &hyp_dense, &nh_all);
+    if (rc) return h->fail(rc, std::string("affinity fill (sharded): ") + l3d_last_error(h->ctx));
+    T.coll_valid = true;
+    h->hyp_begin.assign(nv + 1, 0);
+    for (size_t i = 0; i <= nv; ++i) h->hyp_begin[i] = (size_t)vhb[i];
+    h->hyps.assign((size_t)nh_all, Hyp());
+    h->aff.hyp_cam.assign((size_t)nh_all, 0u);
+    parallel_slices(nv, finish_threads(), [&](size_t v0, size_t v1, unsigned) {
+        for (size_t vi = v0; vi < v1; ++vi)
+            for (size_t k = h->hyp_begin[vi]; k < h->hyp_begin[vi + 1]; ++k) {
+                h->hyps[k].src = mk(h->vlist[vi]->id, (uint32_t)((size_t)hyp_dense[k] - voff[vi]));
+                h->aff.hyp_cam[k] = h->vlist[vi]->id;
+            }
+    });
+    h->A.clear(); h->n_edges = (size_t)n_edges; h->A_on_host = n_edges == 0;
+    h->local2global.resize((size_t)n_nodes);
+    h->node_hyp.resize((size_t)n_nodes);
+    parallel_slices((size_t)n_nodes, finish_threads(), [&](size_t k0, size_t k1, unsigned) {
+        for (size_t k = k0; k < k1; ++k) { h->node_hyp[k] = node_hyp[k]; h->local2global[k] = h->hyps[(size_t)node_hyp[k]].src; }
+    });
+    l3d_free(node_hyp); l3d_free(hyp_dense);
+    if (hopt(h).timing) fprintf(stderr, "[l3d finish] sharded fill: %d hypotheses in the job, %lld candidate pairs, %zu edges, %.2f ms\n", nh_all, (long long)cand_all, h->n_edges, (now_s() - t0) * 1e3);
+    return L3D_OK;
+}
+
 // Line3D::clusterSegments2D, line3D.cc:968-1252: the affinity fill and the edge list of the clustering on the device
 // (l3d_affinity_fill / l3d_affinity_fill_resident, l3d_perform_clustering_device, l3d_fit_labelled_clusters); host union-find, symmetrisation and
 // edge order remain for edge lists the device path refuses.  (The literal `used` enumeration of round 1 lives on as a test helper:
@@ -371,8 +412,8 @@ int cluster_segments_2D(L* h, bool perform_diff)
     double tm_last = t0;
     auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", what, (t - tm_last) * 1e3); tm_last = t; } };
     h->A.clear(); h->n_edges = 0; h->A_on_host = true; h->local2global.clear(); h->result.clear();
-    const size_t nh = h->hyps.size();
-    if (nh == 0) return L3D_OK;
+    size_t nh = h->hyps.size();
+    if (nh == 0 && !h->partitioned) return L3D_OK;          // (partitioned: a rank without hypotheses still takes part in the collective fill)
 
     // dense index of every 2-D segment of every view (for the `used` bookkeeping)
     const size_t nv = h->vlist.size();
@@ -393,7 +434,13 @@ int cluster_segments_2D(L* h, bool perform_diff)
     if (hyp_begin.size() != nv + 1 || hyp_begin[nv] != nh) return h->fail(L3D_ERR_INVALID, "hypothesis ranges do not match the views");
 
     bool resident_list = false;                     // the affinity list is still on the device (l3d_affinity_fill ran last)
-    if (h->resident_products) {
+    if (h->partitioned) {
+        const int rc = fill_affinity_sharded(h);
+        if (rc) return rc;
+        resident_list = true;
+        nh = h->hyps.size();                        // (global from here on)
+        lap("affinity fill (sharded by source key)");
+    } else if (h->resident_products) {
         const int rc = fill_affinity_resident(h);
         if (rc) return rc;
         resident_list = true;

@@ -556,6 +556,7 @@ int prepare(L* h)
 void match_begin(L* h)
 {
     h->resident_products = false;
+    h->partitioned = false;
     h->matched.clear();
     h->pot.resize(h->vlist.size());                     // (capacities survive from an earlier pass)
     for (auto& pv : h->pot) pv.clear();

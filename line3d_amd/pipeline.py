@@ -249,6 +249,30 @@ class Line3D:
         self._chk(self.lib.l3d_line3d_block_run(self.h, C.c_int(rank), C.c_int(world), C.c_int(warmup_views), C.cast(fn, C.c_void_p), user, C.byref(verdict)))
         return verdict.value == 0
 
+    def partition_run(self, rank: int, world: int, exchange="local", exchange_user=None, warmup_views: int = -1) -> bool:
+        """matchViews sharded by blocks of views with nothing replicated (l3d_line3d_partition_run): this object then holds its block's share of the
+        kept records and of matchViews' products; finish_sharded() -- on every rank -- completes compute3Dmodel.  exchange as for block_run."""
+        if callable(exchange):
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+            fn = self._exchange_keepalive = proto(exchange)
+        else:
+            fn = {"rccl": self.lib.l3d_exchange_rccl, "local": self.lib.l3d_exchange_local}[exchange]
+        user = C.c_void_p(exchange_user) if isinstance(exchange_user, int) else (C.c_void_p(C.addressof(exchange_user)) if exchange_user is not None else None)
+        verdict = C.c_int(1)
+        self._chk(self.lib.l3d_line3d_partition_run(self.h, C.c_int(rank), C.c_int(world), C.c_int(warmup_views), C.cast(fn, C.c_void_p), user, C.byref(verdict)))
+        return verdict.value == 0
+
+    def finish_sharded(self, perform_diffusion=False):
+        """the rest of compute3Dmodel after partition_run, on every rank (collective; the exchange of the run)"""
+        self._chk(self.lib.l3d_line3d_finish_sharded(self.h, C.c_int(int(perform_diffusion)), None, None))
+
+    def partition_info(self):
+        """what this rank's share covers (views of the dense map): dict(rank, world, own, rows, held, n_pot_all, recovery_rounds)"""
+        info = (C.c_int * 8)()
+        npot, rr = C.c_int64(0), C.c_int(0)
+        self._chk(self.lib.l3d_partition_info(C.c_void_p(self.lib.l3d_line3d_context(self.h)), info, C.byref(npot), C.byref(rr)))
+        return dict(rank=info[0], world=info[1], own=(info[2], info[3]), rows=(info[4], info[5]), held=(info[6], info[7]), n_pot_all=npot.value, recovery_rounds=rr.value)
+
     def shard_close(self, committed: bool):
         self._chk(self.lib.l3d_line3d_shard_close(self.h, C.c_int(int(committed))))
 

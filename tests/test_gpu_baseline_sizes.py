@@ -318,7 +318,9 @@ def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
         x.join()
     assert not errors, errors
     assert verdicts == [True] * W, verdicts
-    assert [c[0] for c in calls] == [-1, -3, -2, -3, -3, -4]
+    tags = [c[0] for c in calls]          # (a block whose speculation failed is re-run warm: a hand-over and another round of digests each)
+    n_rep = ls[0].partition_info()["recovery_rounds"]
+    assert tags == [-1, -3] + [-3, -5, -1, -3] * n_rep + [-3, -2, -3, -3, -4], tags
     for r in (0, 5):
         assert digest_lists({v["id"]: ls[r].view_matches(v["id"]) for v in scene.views}) == want, "rank %d" % r
     for l in ls:

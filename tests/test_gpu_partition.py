@@ -1,0 +1,152 @@
+"""matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition, l3d_affinity_fill_sharded: BASELINE configs[4] as a
+job that fits -- every rank holds its block's share of the kept records and of matchViews' products, the affinity fill is sharded by source key,
+SURVEY.md 8e) against the ONE single-GPU chain: virtual ranks as threads of this process on the one GPU of the test box, the all-gather through
+the host (helpers.thread_exchange).  Reference behaviour: line3D.cc:620-648 (matchViews), :834-884 (what performMatching leaves behind),
+:968-1221 (clusterSegments2D), view.cc:150-224 (the reference's own way of not holding everything: a file per view)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import assert_lines_equal, thread_exchange
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(scene, N, diffusion):
+    from line3d_amd.pipeline import Line3D, load_scene
+    ref = Line3D("", matchingNeighbors=N)
+    ref.keep_view_matches(True)
+    load_scene(ref, scene)
+    ref.prepare()
+    ref.match_views()
+    lists = {v["id"]: ref.view_matches(v["id"]) for v in scene.views}
+    prod = ref.resident_products()
+    ref.finish(diffusion)
+    A, n_nodes = ref.affinity()
+    out = dict(lists=lists, pot_start=prod["pot_start"].copy(), pot_tgt=prod["pot_tgt"].copy(), best=prod["best"].copy(), seg_base=prod["seg_base"].copy(),
+               A=A.copy(), n_nodes=n_nodes, lines=ref.getResult(), hyp=ref.resident_products()["hyp"].copy())
+    ref.close()
+    return out
+
+
+def _run_partitioned(scene, N, W, warmup, diffusion, options=None):
+    from line3d_amd.pipeline import Line3D, load_scene
+    make, calls = thread_exchange(W)
+    ls, verdicts, errors = [], [None] * W, []
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        for k, v in (options or {}).items():
+            l.context().set_option(k, v)
+        ls.append(l)
+    shares = [None] * W
+
+    def run(r):
+        try:
+            verdicts[r] = ls[r].partition_run(r, W, make(r), None, warmup)
+            if verdicts[r]:
+                shares[r] = (ls[r].partition_info(), ls[r].resident_products())
+                ls[r].finish_sharded(diffusion)
+        except Exception as e:      # noqa: BLE001
+            errors.append((r, e))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return ls, verdicts, errors, shares, calls
+
+
+def _check_against(ref, scene, ls, shares):
+    ids = [v["id"] for v in scene.views]
+    for r, l in enumerate(ls):
+        info, prod = shares[r]
+        assert info["world"] == len(ls) and info["rank"] == r
+        o0, o1 = info["own"]
+        # the kept lists of the rank's block, byte for byte (and of every other view it holds)
+        for vi in range(info["held"][0], info["held"][1]):
+            m, med = l.view_matches(ids[vi])
+            assert m.tobytes() == ref["lists"][ids[vi]][0].tobytes(), "rank %d view %d: kept list" % (r, ids[vi])
+        # its rows of potential_correspondences_ are the one table's rows; rows it does not hold are empty
+        sb = ref["seg_base"]
+        ps, pt = prod["pot_start"], prod["pot_tgt"]
+        for vi in range(len(ids)):
+            for d in (int(sb[vi]), int(sb[vi + 1]) - 1):
+                mine = pt[ps[d]:ps[d + 1]]
+                if info["rows"][0] <= vi < info["rows"][1]:
+                    assert np.array_equal(mine, ref["pot_tgt"][ref["pot_start"][d]:ref["pot_start"][d + 1]]), "rank %d: row of dense segment %d" % (r, d)
+                else:
+                    assert len(mine) == 0
+        lo, hi = int(sb[info["rows"][0]]), int(sb[info["rows"][1]])
+        for d in range(lo, hi, 7):
+            assert np.array_equal(pt[ps[d]:ps[d + 1]], ref["pot_tgt"][ref["pot_start"][d]:ref["pot_start"][d + 1]])
+        assert info["n_pot_all"] >= len(ref["pot_tgt"])           # (rows within `reach` of a block boundary are built by both neighbours)
+        # best matches of the views it holds
+        lo, hi = int(sb[info["held"][0]]), int(sb[info["held"][1]])
+        assert prod["best"][lo:hi].tobytes() == ref["best"][lo:hi].tobytes(), "rank %d: best matches" % r
+        # after the collective finish: the ONE affinity list, the one hypothesis table, the one result -- on every rank
+        A, n_nodes = l.affinity()
+        assert n_nodes == ref["n_nodes"] and A.tobytes() == ref["A"].tobytes(), "rank %d: affinity list" % r
+        assert l.resident_products()["hyp"].tobytes() == ref["hyp"].tobytes(), "rank %d: hypothesis table" % r
+        assert_lines_equal(l.getResult(), ref["lines"], 0.0)
+
+
+@pytest.mark.parametrize("W,diffusion", [(3, False), (4, True), (1, False)])
+def test_partitioned_run_and_sharded_fill_equal_the_one_chain(W, diffusion):
+    from line3d_amd.synth import make_scene
+    V, S, N = 60, 160, 6
+    scene = make_scene(V, S, N, seed=11)
+    ref = _reference(scene, N, diffusion)
+    assert len(ref["lines"]) > 20 and len(ref["A"]) > 1000
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, diffusion)
+    try:
+        assert not errors, errors
+        assert verdicts == [True] * W
+        _check_against(ref, scene, ls, shares)
+        # nothing big travels: no block gather (-2), no table pieces (-4); the early-return records (-6) and the fill's five small gathers (-7 .. -10)
+        tags = [c[0] for c in calls]
+        assert -2 not in tags and -4 not in tags
+        if W > 1:
+            assert tags.count(-7) == 1 and tags.count(-8) == 1 and tags.count(-9) == 1 and tags.count(-10) == 1
+    finally:
+        for l in ls:
+            l.close()
+
+
+def test_partitioned_run_repairs_failed_speculations_block_by_block():
+    """A warm-up far too short for the chain's memory (one view; then none at all): every rank's speculation fails, and every block is re-run warm from
+    its predecessor's true lists, one after the other -- the result is still the one chain's, and nothing falls through to another mode."""
+    from line3d_amd.synth import make_scene
+    V, S, N, W = 60, 160, 6, 4
+    scene = make_scene(V, S, N, seed=11)
+    ref = _reference(scene, N, False)
+    for warmup in (1, 0):
+        ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, warmup, False)
+        try:
+            assert not errors, errors
+            assert verdicts == [True] * W
+            assert shares[0][0]["recovery_rounds"] == W - 1                  # (every rank but the first was re-run)
+            assert [c[0] for c in calls].count(-5) == W - 1                  # one hand-over per repaired block
+            _check_against(ref, scene, ls, shares)
+        finally:
+            for l in ls:
+                l.close()
+
+
+def test_partitioned_fill_in_small_blocks_of_sources():
+    """the sharded fill with every rank's candidates cut into many small blocks of sources (L3D_AFF_BLOCK / L3D_AFF_WORD_BLOCK): same list"""
+    from line3d_amd.synth import make_scene
+    V, S, N, W = 48, 150, 6, 3
+    scene = make_scene(V, S, N, seed=5)
+    ref = _reference(scene, N, False)
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, False, options={"L3D_AFF_BLOCK": 500, "L3D_AFF_WORD_BLOCK": 300})
+    try:
+        assert not errors, errors
+        assert verdicts == [True] * W
+        _check_against(ref, scene, ls, shares)
+    finally:
+        for l in ls:
+            l.close()

@@ -898,8 +898,9 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
     started cold; digests of the kept lists decide whether the speculation was exact (the chain's memory is a few neighbour windows:
     scripts/speculate_blocks.py), then the ranks all-gather their blocks and build matchViews' products.  Three virtual ranks (threads, one GPU,
     an all-gather through the host): with a long enough warm-up every rank ends up with the kept lists, products and lines of the ONE chain,
-    byte for byte -- four exchanges per pass (digests, blocks, sizes and pieces of the table); with a warm-up no longer than the window the verdict is "not exact" on every rank and nothing is
-    committed (the caller then takes the segment-sharded run)."""
+    byte for byte -- four exchanges per pass (digests, blocks, sizes and pieces of the table).  With a warm-up no longer than the window the speculation
+    fails -- and (round 5) the failed blocks are re-run warm from their predecessors' true lists, one hand-over (-5) each: still the one chain's
+    result; with option block_recover = 0 (the round-4 behaviour) the verdict is "not exact" on every rank and nothing is committed."""
     import threading
     from line3d_amd.pipeline import Line3D, load_scene
     from line3d_amd.synth import make_scene
@@ -913,7 +914,7 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
     want, want_lists, want_lines = _products_digest(ref), digest_lists(lists_of(ref)), ref.getResult()
     assert len(want_lines) > 20
     ref.close()
-    for warmup, expect in ((-1, True), (3, False)):
+    for warmup, recover, expect in ((24, 1, True), (3, 1, True), (3, 0, False)):
         make, calls = _thread_exchange(W)
         ls, verdicts, errors = [], [None] * W, []
         for r in range(W):
@@ -921,6 +922,7 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
             l.keep_view_matches(True)
             load_scene(l, scene)
             l.prepare()
+            l.context().set_option("L3D_BLOCK_RECOVER", recover)
             ls.append(l)
 
         def run(r):
@@ -936,15 +938,19 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
         assert not errors, errors
         assert verdicts == [expect] * W, (warmup, verdicts)
         if expect:
-            # digests, [status] blocks, [status + table sizes], [status] table pieces: four data collectives per pass, each big one behind a
-            # 256-byte all-gather of status words (a rank that fails on its own never leaves the others waiting in a collective)
-            assert [c[0] for c in calls] == [-1, -3, -2, -3, -3, -4]
+            # digests [status], [status] blocks, [status + table sizes], [status] table pieces: four data collectives per pass, every one behind a
+            # 256-byte all-gather of status words (a rank that fails on its own never leaves the others waiting in a collective); a repaired
+            # block adds a hand-over and one more round of digests
+            tags = [c[0] for c in calls]
+            n_rep = ls[0].partition_info()["recovery_rounds"]
+            assert tags == [-1, -3] + [-3, -5, -1, -3] * n_rep + [-3, -2, -3, -3, -4], tags
+            assert n_rep == (0 if warmup == 24 else W - 1)
             for r, l in enumerate(ls):
                 l.finish(False)
                 assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, "rank %d" % r
                 assert_lines_equal(l.getResult(), want_lines, 0.0)
         else:
-            assert [c[0] for c in calls] == [-1]
+            assert [c[0] for c in calls] == [-1, -3]
         for l in ls:
             l.close()
 
