@@ -366,9 +366,9 @@ long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
  * has the one chain's inputs).  Every rank reads the same table and reaches the same verdict.  *verdict = 0: the ranks all-gathered
  * their blocks (view = -2) and THIS context now holds matchViews' products exactly as after l3d_match_chain_resident over all views
  * (arena, potential correspondences, best matches, medians; summary / n_pot as there).  A block whose speculation did NOT hold is repaired, not
- * abandoned (round 5): the first inexact rank takes over its predecessor's last `window` views -- true by then; records, best depth pairs and
- * positions, one all-gather, view = -5 -- and re-runs its block warm from them; the digests are exchanged again, until every rank is exact (at most
- * world rounds; a warm-up shorter than the window simply makes a rank take that path).  *verdict = 1 only when a block is shorter than the window
+ * abandoned (round 5): every rank that missed takes over its predecessor's last `window` views -- records, best depth pairs and positions, one
+ * all-gather, view = -5 -- and re-runs its block warm from them, all of them at once; the digests are exchanged again, until nobody misses (rank j
+ * is exact after round j at the latest; a warm-up shorter than the window simply makes a rank take that path).  *verdict = 1 only when a block is shorter than the window
  * (it cannot vouch for its successor's sources) or option block_recover = 0 (the round-4 behaviour): nothing was committed, run l3d_shard_chain_run.
  * No per-view collective: four data exchanges per pass (digests; blocks; view = -4 the pieces of the products table, of which every rank
  * builds the rows of its own block) and three 256-byte ones of status words (view = -3; the second carries the sizes of the pieces): every step
@@ -393,9 +393,10 @@ int l3d_match_chain_blocks(l3d_ctx* ctx, const l3d_chain_view* views, int n_view
  * a failed speculation is repaired by re-running that block warm, see there). */
 int l3d_match_chain_partition(l3d_ctx* ctx, const l3d_chain_view* views, int n_views, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot,
                               int rank, int world, int warmup_views, int window, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
-/* what this rank's share covers after l3d_match_chain_partition, in views of the dense map (8 ints: rank, world, own block [0,1), rows [2,3), held [4,5)),
- * entries of the table over all ranks, blocks re-run warm in the whole job */
-int l3d_partition_info(l3d_ctx* ctx, int info[8], int64_t* n_pot_all, int* recovery_rounds);
+/* what this rank's share covers after l3d_match_chain_partition, in views of the dense map: info = { rank, world, own block [begin, end), rows
+ * [begin, end), held [begin, end), rounds of warm re-runs, blocks re-run in them (whole job; also set by l3d_match_chain_blocks) }; n_pot_all:
+ * entries of the table over all ranks */
+int l3d_partition_info(l3d_ctx* ctx, int info[10], int64_t* n_pot_all);
 /* The fill SHARDED BY SOURCE KEY over the ranks of a job whose matchViews ran partitioned (l3d_match_chain_partition below): every
  * rank enumerates the candidates of the sources of ITS block of views -- from the rows, best matches and hypotheses it holds, nothing of another
  * rank is read -- and five small all-gathers (`exchange`, views -7 .. -10 and status words -3) make global what has to be: hypotheses per view
@@ -524,11 +525,11 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);
 /* matchViews with the VIEWS sharded over the ranks in blocks, each block started cold a few neighbour windows early, the speculation verified
- * (l3d_match_chain_blocks above; warmup_views < 0: four windows -- a block whose speculation fails is re-run warm, not the pass).  *verdict = 0: this rank holds matchViews' products as after the
+ * (l3d_match_chain_blocks above; warmup_views < 0: six windows -- a block whose speculation fails is re-run warm, not the pass).  *verdict = 0: this rank holds matchViews' products as after the
  * single-GPU resident chain -- compute3Dmodel goes on from there (l3d_line3d_finish); *verdict = 1 (identical on every rank): the speculation
  * did not hold, nothing was committed, run l3d_line3d_shard_run. */
 int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
-/* matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition; warmup_views < 0: four windows), and the rest of
+/* matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition; warmup_views < 0: six windows), and the rest of
  * compute3Dmodel as a COLLECTIVE of the job's ranks: greedy selection on the views a rank holds, the affinity fill sharded by source key
  * (l3d_affinity_fill_sharded), then -- every rank from the same affinity list -- diffusion, clustering, line fit: every rank ends with the whole
  * result (Line3D::getResult).  l3d_line3d_finish on such an object is the same call with the exchange of the run; l3d_line3d_view_matches serves the
@@ -551,6 +552,10 @@ int l3d_line3d_save_result(const l3d_line3d* h, const char* filename, int format
  * 0 (default): the device-resident chain (l3d_match_chain).  Results are identical. */
 int l3d_line3d_set_sync_matching(l3d_line3d* h, int on);
 int l3d_line3d_keep_view_matches(l3d_line3d* h, int on);
+/* which way the last l3d_line3d_match_views took: 0 = the resident chain (products on the device), 1 = the chain with host bookkeeping, 2 = per-view
+ * seam calls on request (set_sync_matching), 3 = per-view seam calls because the schedule is not static (an early-return view's local camera
+ * numbers name a view that still accepts reverse matches, line3D.cc:844-845); -1 = matchViews has not run */
+int l3d_line3d_match_path(const l3d_line3d* h);
 int l3d_line3d_view_matches(const l3d_line3d* h, uint32_t view_id, const l3d_match** m, int* n, float* median);
 int l3d_line3d_affinity(const l3d_line3d* h, const l3d_edge** A, int* nnz, int* n_nodes);
 /* the device-resident products of the last matchViews (l3d_match_chain_resident) and, after finish, the hypothesis table of

@@ -267,6 +267,17 @@ class Context:
         self.lib.l3d_free(nodes)
         return A, node_hyp, nc.value
 
+    def chain_kept_list(self, index: int):
+        """l3d_chain_kept_list: the kept list of chain view `index` out of the resident arena (MATCH_DTYPE array); partitioned products: the
+        views this rank holds, empty for the others"""
+        p, n = C.c_void_p(), C.c_int(0)
+        self._chk(self.lib.l3d_chain_kept_list(self.h, C.c_int(index), C.byref(p), C.byref(n)))
+        out = np.zeros(n.value, dtype=MATCH_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, p, n.value * 32)
+        self.lib.l3d_free(p)
+        return out
+
     def last_fill_counts(self):
         """(candidate pairs enumerated, candidates that passed their threshold) of the last affinity fill on this context, as 64-bit counts"""
         a, b = C.c_int64(0), C.c_int64(0)

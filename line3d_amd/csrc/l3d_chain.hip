@@ -596,7 +596,9 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 // copy it over
                 // (projected from the views done so far when there are enough of them: dense scenes keep 10x the first guess)
                 size_t new_cap = arena_cap * 2;
-                if (k >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / k * n_views * 1.3) + 1048576);
+                // (views of THIS call: a ranged chain -- a block of views -- must not size its arena for the whole scene)
+                const int n_pre = pre ? pre->k1 - pre->k0 : 0, done = k - k_begin + n_pre, span = k_end - k_begin + n_pre;
+                if (done >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / done * span * 1.3) + 1048576);
                 // (records are indexed with 32 bits: the arena ends at 2^32 records = 137 GB; doubling must not run past it)
                 const size_t kMaxRecords = 0xfffffff0u;
                 if (new_cap > kMaxRecords) {
@@ -850,6 +852,15 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
     int chain_rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, first, last);
     std::string chain_err;
     if (chain_rc) { std::lock_guard<std::mutex> lk(c->err_mu); chain_err = c->err; }
+    // partitioned: the job is sized by memory, not by the time of a second pass -- what only a running chain needs (candidate store and its ring,
+    // window scratch, bit rows, viewing rays, row counters: 10-15 GB at 4000 segments x 24 neighbours) is given back before the products are built
+    auto release_chain_scratch = [&]() {
+        if (!partition || c->opt.part_release == 0) return;
+        (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(c->stage1_stream);
+        DevBuf* b[] = { &c->ch_ringA_meta, &c->ch_ringA_depths, &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->vw_scratch, &c->ch_mask, &c->ch_rays, &c->ch_rowcnt, &c->ch_rowA };
+        for (DevBuf* x : b) x->release();
+    };
+    release_chain_scratch();
     const ChainResult* hres = c->ch_pin_res.as<ChainResult>();
     double t1 = now_s();
     // useful work of this rank = its own block (the warm-up is the price of the speculation)
@@ -904,8 +915,7 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
     std::vector<int> comp_from((size_t)world, 0);       // per rank: the first view it computed (or took over); every rank keeps the same table
     for (int r = 1; r < world; ++r) comp_from[(size_t)r] = std::max(0, block_begin(r) - warmup_views);
     double t2 = t1;
-    int rounds = 0;
-    std::vector<char> exact((size_t)world, 0);
+    int rounds = 0, blocks_rerun = 0;
     for (;; ++rounds) {
         L3D_SOFT(hipMemsetAsync(dtab_own, 0, tab_bytes, st));
         if (local_rc) {
@@ -933,15 +943,15 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
             for (int r = 0; r < world; ++r)
                 if (tab[(size_t)r * n_views].n_kept == -1 && tab[(size_t)r * n_views].hash == ~0ull) { note(fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the chain of rank " + std::to_string(r) + " failed (code " + std::to_string(tab[(size_t)r * n_views].R) + ")")); break; }
         if (int a_rc = all_gather_word(0, "computing its block")) return a_rc;
-        // ---- the verdict (the same on every rank: same table).  exact[r]: rank r's lists are the one chain's from view B_r - check on
-        int fail_rank = -1;
+        // ---- the verdict (the same on every rank: same table).  miss[r]: the `check` views in front of rank r's block did not come out of its warm-up as
+        // its predecessor computed them.  No miss anywhere = every rank exact (rank 0 is; rank r's check views equal rank r-1's, which are then the
+        // one chain's, and from them on rank r's chain had the one chain's inputs).
         bool hopeless = false;
-        exact[0] = 1;
+        int n_miss = 0;
+        std::vector<char> miss((size_t)world, 0);
         for (int r = 1; r < world; ++r) {
-            exact[(size_t)r] = 0;
-            if (!exact[(size_t)r - 1]) continue;
             const int b = block_begin(r), lo = std::max(0, b - check);
-            // a warm-up shorter than the check leaves views the rank never computed: not exact (the warm re-run below takes them over)
+            // a warm-up shorter than the check leaves views the rank never computed: a miss (the warm re-run below takes them over)
             bool ok = lo >= comp_from[(size_t)r];
             // (replicas: a block shorter than the window cannot vouch for its successor's sources -- the blocks are what gets gathered; partitioned: the
             // predecessor's exact range reaches back as far as this rank's check)
@@ -961,41 +971,64 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
                     if (x.hash != y.hash || x.n_kept != y.n_kept) ok = false;
                 }
             }
-            exact[(size_t)r] = ok ? 1 : 0;
-            if (!ok && fail_rank < 0) fail_rank = r;
+            miss[(size_t)r] = ok ? 0 : 1;
+            n_miss += ok ? 0 : 1;
         }
-        if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] round %d: views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, first inexact rank %d\n",
-                                   rank, world, rounds, arena_first, last - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, fail_rank);
-        if (fail_rank < 0) break;
+        if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] round %d: views %d..%d (block from %d): chain %.2f ms, digests + exchange %.2f ms, %d rank(s) missed\n",
+                                   rank, world, rounds, arena_first, last - 1, own0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, n_miss);
+        if (n_miss == 0) break;
         // option block_recover = 0 (A/B, tests of the fall-through): the round-4 behaviour -- any miss sends the pass to the caller's other mode
         if (hopeless || c->opt.block_recover == 0 || rounds >= world) return L3D_OK;                  // *verdict = 1: nothing committed
-        // ---- recovery: rank fail_rank - 1 is exact; its last `check` views (records, best depth pairs, best positions) go to everybody (an
-        // all-gather is the one primitive of the protocol; only that rank's slot carries data), rank fail_rank re-runs views [B, last) from them
-        const int src_rank = fail_rank - 1, fb = block_begin(fail_rank), k0 = std::max(0, fb - check);
-        comp_from[(size_t)fail_rank] = k0;
-        long long t_rec = 0, t_seg = 0;
-        int k_first_rec = -1;               // (the tail's records are contiguous in the sender's arena from its first verified view on)
-        for (int k = k0; k < fb; ++k) { t_rec += tab[(size_t)src_rank * n_views + k].n_kept; if (views[k].n_tbm > 0) { t_seg += views[k].S_src; if (k_first_rec < 0) k_first_rec = k; } }
-        const size_t o_best = al((size_t)t_rec * sizeof(Match)), o_bpos = o_best + al((size_t)t_seg * 8), slot = o_bpos + al((size_t)t_seg * 4) + 256;
+        // ---- recovery, all missed blocks at once: every rank that missed takes over its predecessor's last `check` views (records, best depth
+        // pairs, best positions: one all-gather, the one primitive of the protocol) and re-runs its block WARM from them.  A predecessor that missed
+        // too hands over what its cold start produced -- usually already the one chain's by the end of a block; if not, the next round's digests
+        // show it and that rank runs again.  After round j rank j is exact whatever happened (it took over from rank j-1, exact since round j-1).
+        blocks_rerun += n_miss;
+        long long max_rec = 0, max_seg = 0;
+        std::vector<long long> t_rec((size_t)world, 0), t_seg((size_t)world, 0);
+        std::vector<int> t_first((size_t)world, -1);               // (a tail's records are contiguous in the sender's arena from its first verified view on)
+        for (int r = 1; r < world; ++r) {
+            if (!miss[(size_t)r]) continue;
+            const int s_ = r - 1, fb = block_begin(r), k0 = std::max(0, fb - check);
+            for (int k = k0; k < fb; ++k) { t_rec[(size_t)s_] += tab[(size_t)s_ * n_views + k].n_kept; if (views[k].n_tbm > 0) { t_seg[(size_t)s_] += views[k].S_src; if (t_first[(size_t)s_] < 0) t_first[(size_t)s_] = k; } }
+            max_rec = std::max(max_rec, t_rec[(size_t)s_]); max_seg = std::max(max_seg, t_seg[(size_t)s_]);
+        }
+        // a tail as one byte stream [records | best depth pairs | best positions], the same offsets on every rank; it travels in CHUNKS (option
+        // handover_chunk_kb, 256 MB): an all-gather hands every rank every slot, and a whole tail per slot would cost world x tail bytes on every
+        // rank (52 GB at 4000 x 24 x 8 ranks) for the one slot a rank reads -- a chunk per slot costs world x 256 MB
+        const size_t o_best = al((size_t)max_rec * sizeof(Match)), o_bpos = o_best + al((size_t)max_seg * 8), slot = o_bpos + al((size_t)max_seg * 4) + 256;
+        const size_t chunk = std::min(slot, al((size_t)std::max(1, c->opt.handover_chunk_kb) << 10));
+        const bool sends = rank + 1 < world && miss[(size_t)rank + 1], takes = miss[(size_t)rank] != 0;
         {
-            hipError_t e = c->ch_send.reserve(slot + 256);
-            if (e == hipSuccess) e = c->ch_gathered.reserve(slot * (size_t)world + 256);
+            hipError_t e = c->ch_send.reserve(chunk + 256);
+            if (e == hipSuccess) e = c->ch_gathered.reserve(chunk * (size_t)world + 256);
+            if (e == hipSuccess && takes) e = c->ch_stage.reserve(slot + 256);
             if (e != hipSuccess) note(fail(c, L3D_ERR_NOMEM, "l3d_match_chain_blocks: the hand-over of a block's sources"));
-            else if (rank == src_rank) {
-                unsigned char* send = c->ch_send.as<unsigned char>();
-                if (t_rec > 0) L3D_SOFT(hipMemcpyAsync(send, c->ch_kept.as<Match>() + hres[k_first_rec].kept_base, (size_t)t_rec * sizeof(Match), hipMemcpyDeviceToDevice, st));
-                if (t_seg > 0) {
-                    L3D_SOFT(hipMemcpyAsync(send + o_best, c->ch_best.as<float2>() + best_off[(size_t)k0], (size_t)t_seg * 8, hipMemcpyDeviceToDevice, st));
-                    L3D_SOFT(hipMemcpyAsync(send + o_bpos, c->ch_bestpos.as<int>() + best_off[(size_t)k0], (size_t)t_seg * 4, hipMemcpyDeviceToDevice, st));
-                }
-            }
         }
         if (int a_rc = all_gather_word(0, "staging the hand-over of a block's sources")) return a_rc;
-        if (exchange(exchange_user, -5, c->ch_send.p, c->ch_gathered.p, slot, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the hand-over exchange failed");
-        if (rank == fail_rank) {
+        for (size_t off = 0; off < slot; off += chunk) {
+            const size_t n = std::min(chunk, slot - off);
+            if (sends && !local_rc) {
+                const int k0 = std::max(0, block_begin(rank + 1) - check);
+                struct Piece { size_t at, len; const unsigned char* src; } pieces[3] = {
+                    { 0, (size_t)t_rec[(size_t)rank] * sizeof(Match), t_first[(size_t)rank] >= 0 ? reinterpret_cast<const unsigned char*>(c->ch_kept.as<Match>() + hres[t_first[(size_t)rank]].kept_base) : nullptr },
+                    { o_best, (size_t)t_seg[(size_t)rank] * 8, reinterpret_cast<const unsigned char*>(c->ch_best.as<float2>() + best_off[(size_t)k0]) },
+                    { o_bpos, (size_t)t_seg[(size_t)rank] * 4, reinterpret_cast<const unsigned char*>(c->ch_bestpos.as<int>() + best_off[(size_t)k0]) } };
+                for (const Piece& q : pieces) {
+                    const size_t lo = std::max(q.at, off), hi = std::min(q.at + q.len, off + n);
+                    if (q.src && hi > lo) L3D_SOFT(hipMemcpyAsync(c->ch_send.as<unsigned char>() + (lo - off), q.src + (lo - q.at), hi - lo, hipMemcpyDeviceToDevice, st));
+                }
+            }
+            if (exchange(exchange_user, -5, c->ch_send.p, c->ch_gathered.p, n, world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_match_chain_blocks: the hand-over exchange failed");
+            if (takes && !local_rc) L3D_SOFT(hipMemcpyAsync(c->ch_stage.as<unsigned char>() + off, c->ch_gathered.as<unsigned char>() + (size_t)(rank - 1) * n, n, hipMemcpyDeviceToDevice, st));
+            if (off + chunk < slot) L3D_SOFT(hipStreamSynchronize(st));       // (the next chunk reuses the send and gathered buffers)
+        }
+        for (int r = 1; r < world; ++r) if (miss[(size_t)r]) comp_from[(size_t)r] = std::max(0, block_begin(r) - check);
+        if (miss[(size_t)rank]) {
+            const int src_rank = rank - 1, fb = own0, k0 = std::max(0, fb - check);
             ChainPreload pre;
             pre.k0 = k0; pre.k1 = fb;
-            const unsigned char* G = c->ch_gathered.as<unsigned char>() + (size_t)src_rank * slot;
+            const unsigned char* G = c->ch_stage.as<unsigned char>();
             pre.records = reinterpret_cast<const Match*>(G);
             pre.best = reinterpret_cast<const float2*>(G + o_best);
             pre.bestpos = reinterpret_cast<const int*>(G + o_bpos);
@@ -1003,13 +1036,14 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
             const double tr0 = now_s();
             const int rc = run_chain(c, views, n_views, nullptr, nullptr, nullptr, nullptr, nullptr, fb, last, &pre);
             if (rc) note(rc);
+            release_chain_scratch();
             hres = c->ch_pin_res.as<ChainResult>();
             arena_first = k0;
             t1 += now_s() - tr0;
             if (c->opt.timing) fprintf(stderr, "[l3d chain_blocks rank %d/%d] block re-run warm from rank %d's last %d views: %.2f ms\n", rank, world, src_rank, fb - k0, (now_s() - tr0) * 1e3);
         }
     }
-    c->products.part.recovery_rounds = rounds;
+    c->products.part.recovery_rounds = rounds; c->products.part.blocks_rerun = blocks_rerun;
     // first view from which this rank's lists are the one chain's
     const int exact_from = rank == 0 ? 0 : std::max(arena_first, own0 - check);
     (void)comp_from;
@@ -1201,7 +1235,7 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
         part.own_dv0 = dense_of(own0); part.own_dv1 = dense_of(own1);
         part.row_dv0 = dense_of(row0); part.row_dv1 = dense_of(row1);
         part.held_dv0 = dense_of(exact_from); part.held_dv1 = dense_of(last);
-        part.recovery_rounds = rounds;
+        part.recovery_rounds = rounds; part.blocks_rerun = blocks_rerun;
         int64_t n_local = 0;
         const double t3 = now_s();
         if (!local_rc) {
@@ -1353,13 +1387,12 @@ extern "C" int l3d_match_chain_partition(l3d_ctx* c, const l3d_chain_view* views
     return chain_blocks_impl(c, views, n_views, map, summary, n_pot, rank, world, warmup_views, window, exchange, exchange_user, verdict, 1);
 }
 
-extern "C" int l3d_partition_info(l3d_ctx* c, int info[8], int64_t* n_pot_all, int* recovery_rounds)
+extern "C" int l3d_partition_info(l3d_ctx* c, int info[10], int64_t* n_pot_all)
 {
     if (!c) return L3D_ERR_INVALID;
     const ProductsPart& q = c->products.part;
-    if (info) { const int v[8] = { q.rank, q.world, q.own_dv0, q.own_dv1, q.row_dv0, q.row_dv1, q.held_dv0, q.held_dv1 }; memcpy(info, v, sizeof(v)); }
+    if (info) { const int v[10] = { q.rank, q.world, q.own_dv0, q.own_dv1, q.row_dv0, q.row_dv1, q.held_dv0, q.held_dv1, q.recovery_rounds, q.blocks_rerun }; memcpy(info, v, sizeof(v)); }
     if (n_pot_all) *n_pot_all = q.active ? q.n_pot_all : c->products.n_pot;
-    if (recovery_rounds) *recovery_rounds = q.recovery_rounds;
     return L3D_OK;                      // (info[1] = world of the partition; not partitioned: the defaults, world 1)
 }
 

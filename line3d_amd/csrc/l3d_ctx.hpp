@@ -86,7 +86,8 @@ struct ProductsPart {
     int row_dv0 = 0, row_dv1 = 0;       // views whose rows of the potential-correspondence table are complete here (the block and `reach` views either side)
     int held_dv0 = 0, held_dv1 = 0;     // views whose kept records, best matches and medians are here (2 x reach either side): they get hypotheses
     long long n_pot_all = 0;            // entries of the table over all ranks
-    int recovery_rounds = 0;            // blocks that were re-run warm after their speculation failed (whole job)
+    int recovery_rounds = 0;            // rounds of warm re-runs after failed speculations (all missed blocks of a round run at once)
+    int blocks_rerun = 0;               // blocks re-run in those rounds (whole job)
 };
 
 // Device-resident products of the last resident chain (l3d_products.hip) and the hypothesis table built from them

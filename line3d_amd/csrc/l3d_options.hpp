@@ -37,6 +37,9 @@ namespace l3d {
     X(aff_word_block, "L3D_AFF_WORD_BLOCK", 0, "decision words per outer block of sources of the affinity fill (0: 2^26)")          \
     X(cc_max_rounds, "L3D_CC_MAX_ROUNDS", 0, "tests: rounds of the connected-components loop before it gives up (0: 64)")            \
     X(host_threads, "L3D_HOST_THREADS", 0, "worker threads of the host-side stages (0: min(16, usable CPUs))")                       \
+    X(reserve_hint, "L3D_RESERVE_HINT", 1, "prepare(): 1 = the finishing stages' arenas are reserved ahead from the size of the scene (speed of the first finish), 0 = on demand (memory)") \
+    X(handover_chunk_kb, "L3D_HANDOVER_CHUNK_KB", 262144, "views sharded in blocks: a missed block's sources travel in chunks of this many KB per all-gather slot (tests: small values force many chunks)") \
+    X(part_release, "L3D_PART_RELEASE", 1, "partitioned run: 1 = the chain's per-launch scratch is released before the products are built (memory before the speed of a second pass)") \
     X(block_recover, "L3D_BLOCK_RECOVER", 1, "views sharded in blocks: 1 = a block whose cold-started speculation failed is re-run warm from its predecessor's true lists, 0 = any miss ends the call with verdict 1 (round 4; A/B)") \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \

@@ -452,6 +452,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         if (r0 > 0) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)((std::min<long long>(r0, nd + 1) + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), 0ll, std::min<long long>(r0, nd + 1), 0ll);
         if (r1 <= nd) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)(((long long)nd + 1 - r1 + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), r1, (long long)nd + 1, n_pot);
         HIPCHK(c, hipStreamSynchronize(st));
+        if (c->opt.part_release != 0) { P.keys.release(); P.keys2.release(); P.flag.release(); P.pos.release(); P.tmp.release(); }     // (the key blocks: transients)
     }
     for (int k = 0; k < n_views; ++k) {
         l3d_chain_summary& s = summary[k];

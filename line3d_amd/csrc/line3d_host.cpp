@@ -405,9 +405,10 @@ static int block_run_impl(l3d_line3d* h, int rank, int world, int warmup_views, 
     ChainPlan& P = *Pp;
     int window = 1;
     for (size_t k = 0; k < P.n; ++k) for (int si : P.src_idx[k]) window = std::max(window, (int)k - si);
-    // (round 4: eight windows -- any miss cost the pass; round 5: a block whose speculation fails is re-run warm, so the default is what the
-    // chain's memory was measured at, profiles/r4_speculate_*.txt: 3-7 windows, and the check pays for the misses)
-    if (warmup_views < 0) warmup_views = 4 * window;
+    // (round 4: eight windows -- any miss cost the pass.  Round 5: a block whose speculation fails is re-run warm, all missed blocks at once, so a
+    // miss costs one more block time, not the pass.  The chain's memory was measured at 3-7 windows, profiles/r4_speculate_*.txt; six windows make
+    // misses rare on those scenes -- what a shorter warm-up saves on every rank a single miss gives back with interest)
+    if (warmup_views < 0) warmup_views = 6 * window;
     std::vector<uint32_t> ids; std::vector<int32_t> base;
     dense_map(h, ids, base);
     l3d_dense_map map;
@@ -454,6 +455,9 @@ int l3d_line3d_finish_sharded(l3d_line3d* h, int perform_diffusion, l3d_exchange
     if (!h->part_exchange) return h->fail(L3D_ERR_INVALID, "finish_sharded: no exchange");
     return l3d_line3d_finish(h, perform_diffusion);
 }
+// how the last l3d_line3d_match_views ran: 0 = the resident chain with its products on the device, 1 = the chain with host bookkeeping, 2 = per-view
+// seam calls because the caller asked (l3d_line3d_set_sync_matching), 3 = per-view seam calls because the schedule is not static (-1: not yet)
+int l3d_line3d_match_path(const l3d_line3d* h) { return h ? h->last_match_path : -1; }
 int l3d_line3d_match_end(l3d_line3d* h) { if (!h) return L3D_ERR_INVALID; finalize_matching(h); return L3D_OK; }
 
 // performClustering (clustering.h:125, clustering.cc:6-47) as a host entry point: labels[k] = find(k)

@@ -519,18 +519,20 @@ int match_views_resident(L* h, ChainPlan& P, double t0)
 
 int match_views(L* h)
 {
-    if (h->force_sync) return match_views_sync(h);
+    if (h->force_sync) { h->last_match_path = 2; return match_views_sync(h); }
     const double t0 = now_s();
     match_begin(h);
     const double ta = now_s();
     ChainPlan* Pp = get_plan(h);
-    if (!Pp) return match_views_sync(h);
+    if (!Pp) { h->last_match_path = 3; return match_views_sync(h); }     // (the schedule is not static: an early return's local camera numbers name a view that still takes reverse matches)
     ChainPlan& P = *Pp;
     const double tb = now_s();
     if (!(h->host_bookkeeping || hopt(h).host_bookkeeping)) {
         const int rr = match_views_resident(h, P, t0);
+        h->last_match_path = 0;
         if (rr != L3D_ERR_UNSUPPORTED) return rr;           // (more kept matches than the device builder takes: host lists)
     }
+    h->last_match_path = 1;
     start_finalizer(h, P);
     const double t1 = now_s();
     int rc = l3d_match_chain(h->ctx, P.cv.data(), (int)P.n, chain_callback, &P.user);

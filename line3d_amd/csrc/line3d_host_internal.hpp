@@ -205,6 +205,7 @@ struct l3d_line3d {
     std::thread warm_thread;                                   // l3d_warm_up, started with the object: the code objects load while the caller adds its images
     bool host_bookkeeping = false;                             // chain with per-view delivery + host lists (L3D_HOST_BOOKKEEPING=1: A/B, cross-check of the device products)
     bool resident_products = false;                            // the last matchViews left its products on the device: no host lists exist
+    int last_match_path = -1;                                  // how the last matchViews ran (l3d_line3d_match_path)
     bool partitioned = false;                                  // ... PARTITIONED over the ranks of a job (l3d_line3d_partition_run): finish is collective (l3d_line3d_finish_sharded)
     l3d_exchange_fn part_exchange = nullptr;                   // the job's all-gather, for the collective finish
     void* part_user = nullptr;

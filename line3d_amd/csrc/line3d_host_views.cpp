@@ -519,7 +519,8 @@ int prepare(L* h)
         // function and matchViews launch from first
         int reserve_rc = L3D_OK;
         double t_reserve = 0;
-        std::thread warm([h, nd_all, nv_all, nn, &reserve_rc, &t_reserve]() { const double a0 = now_s(); reserve_rc = l3d_reserve_hint(h->ctx, nd_all, nv_all, nn); t_reserve = now_s() - a0; });
+        const bool hint = hopt(h).reserve_hint != 0;       // (0: a memory-bound job -- a rank of a partitioned run -- lets every stage take what it turns out to need)
+        std::thread warm([h, nd_all, nv_all, nn, hint, &reserve_rc, &t_reserve]() { const double a0 = now_s(); if (hint) reserve_rc = l3d_reserve_hint(h->ctx, nd_all, nv_all, nn); t_reserve = now_s() - a0; });
         std::atomic<size_t> next{ 0 };
         l3d::on_threads((unsigned)std::max<size_t>(1, std::min<size_t>(l3d::host_threads(), h->vlist.size())), [&](unsigned) {
             for (;;) {

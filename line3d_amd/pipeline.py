@@ -267,11 +267,12 @@ class Line3D:
         self._chk(self.lib.l3d_line3d_finish_sharded(self.h, C.c_int(int(perform_diffusion)), None, None))
 
     def partition_info(self):
-        """what this rank's share covers (views of the dense map): dict(rank, world, own, rows, held, n_pot_all, recovery_rounds)"""
-        info = (C.c_int * 8)()
-        npot, rr = C.c_int64(0), C.c_int(0)
-        self._chk(self.lib.l3d_partition_info(C.c_void_p(self.lib.l3d_line3d_context(self.h)), info, C.byref(npot), C.byref(rr)))
-        return dict(rank=info[0], world=info[1], own=(info[2], info[3]), rows=(info[4], info[5]), held=(info[6], info[7]), n_pot_all=npot.value, recovery_rounds=rr.value)
+        """what this rank's share covers (views of the dense map): dict(rank, world, own, rows, held, n_pot_all, recovery_rounds, blocks_rerun)"""
+        info = (C.c_int * 10)()
+        npot = C.c_int64(0)
+        self._chk(self.lib.l3d_partition_info(C.c_void_p(self.lib.l3d_line3d_context(self.h)), info, C.byref(npot)))
+        return dict(rank=info[0], world=info[1], own=(info[2], info[3]), rows=(info[4], info[5]), held=(info[6], info[7]), n_pot_all=npot.value, recovery_rounds=info[8],
+                    blocks_rerun=info[9])
 
     def shard_close(self, committed: bool):
         self._chk(self.lib.l3d_line3d_shard_close(self.h, C.c_int(int(committed))))
@@ -282,6 +283,10 @@ class Line3D:
     # -- inspection ------------------------------------------------------------------------------
     def set_sync_matching(self, on=True):
         self._chk(self.lib.l3d_line3d_set_sync_matching(self.h, C.c_int(int(on))))
+
+    def match_path(self) -> int:
+        """l3d_line3d_match_path: 0 resident chain, 1 chain + host bookkeeping, 2 per-view seam calls on request, 3 per-view because the schedule is not static"""
+        return int(self.lib.l3d_line3d_match_path(self.h))
 
     def keep_view_matches(self, on=True):
         self._chk(self.lib.l3d_line3d_keep_view_matches(self.h, C.c_int(int(on))))
@@ -334,4 +339,11 @@ class Line3D:
 def load_scene(l3d: Line3D, scene):
     for v in scene.views:
         ok = l3d.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        assert ok
+
+
+def load_scene_worldpoints(l3d: Line3D, scene):
+    """views that carry the world points they see (synth.make_scene_scattered): Line3D::addImage, neighbours chosen by the library"""
+    for v in scene.views:
+        ok = l3d.addImage(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["worldpoints"])
         assert ok

@@ -174,6 +174,58 @@ def make_scene_from_poses(centers, targets, n_segments: int, seed: int = 77, noi
     return Scene(views, np.concatenate([start, end], axis=1), params)
 
 
+def make_scene_scattered(n_views: int, n_segments: int, seed: int = 4242, n_worldpoints: int = 900, twins: float = 0.12, noise_px: float = 0.5,
+                         width: int = 1920, height: int = 1080, f: float = 1500.0) -> Scene:
+    """Cameras SCATTERED around the box, in no order (view ids do not follow the geometry), each seeing only the part of the segment pool that
+    projects into its image (ragged views: at most n_segments, often fewer); neighbours are not given -- every view carries the ids of the world
+    points it sees (`worldpoints`), so Line3D::addImage builds the view similarities (line3D.cc:95-217, 1874-1935) and findVisualNeighbors picks the
+    neighbourhoods (line3D.cc:476-549): top-N by shared points, hence NOT mutual; `twins` of the cameras stand a few centimetres beside another one
+    and fall under min_baseline (line3D.cc:504-529: rejected against the view and against every neighbour already taken).  load_scene_worldpoints()."""
+    rng = SplitMix64(seed)
+    K = np.array([[f, 0.0, width / 2.0], [0.0, f, height / 2.0], [0.0, 0.0, 1.0]])
+    u = rng.uniform(6 * n_views).reshape(n_views, 6)
+    cams, centers = [], []
+    for i in range(n_views):
+        if i > 0 and u[i, 5] < twins:
+            C = centers[int(u[i, 4] * i)] + 0.12 * (u[i, :3] - 0.5)                        # a twin: baseline <= 0.1 < min_baseline 0.25
+        else:
+            az, el, r = 2.0 * np.pi * u[i, 0], 0.9 * (u[i, 1] - 0.5), 3.9 + 1.6 * u[i, 2]
+            C = np.array([r * np.cos(az) * np.cos(el), r * np.sin(el), r * np.sin(az) * np.cos(el)])
+        centers.append(C)
+        R = _look_at(C.copy(), 0.5 * (u[i, 3:] - 0.5) * np.array([1.0, 0.6, 1.0]))
+        cams.append((R, -R @ C))
+    pool = (5 * n_segments) // 4 + 64                 # (about three quarters of the pool project into a view: some views reach n_segments, some do not)
+    q = rng.uniform(pool * 3).reshape(pool, 3)
+    start = np.stack([5.2 * q[:, 0] - 2.6, 2.8 * q[:, 1] - 1.4, 5.2 * q[:, 2] - 2.6], axis=1)
+    d = rng.normal(pool * 3).reshape(pool, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    end = start + d * (0.1 + 0.3 * np.abs(2.0 * rng.uniform(pool) - 1.0))[:, None]
+    w = rng.uniform(n_worldpoints * 3).reshape(n_worldpoints, 3)
+    wpts = np.stack([5.2 * w[:, 0] - 2.6, 2.8 * w[:, 1] - 1.4, 5.2 * w[:, 2] - 2.6], axis=1)
+
+    def project(R, t, X):
+        x = (K @ (R @ X.T + t[:, None])).T
+        return x[:, :2] / x[:, 2:3], x[:, 2]
+
+    def inside(p, z):
+        return (z > 0.1) & (p[:, 0] >= 1.0) & (p[:, 0] < width - 1.0) & (p[:, 1] >= 1.0) & (p[:, 1] < height - 1.0)
+
+    views = []
+    for i, (R, t) in enumerate(cams):
+        p1, z1 = project(R, t, start)
+        p2, z2 = project(R, t, end)
+        vis = np.nonzero(inside(p1, z1) & inside(p2, z2))[0]
+        vis = vis[rng.permutation(len(vis))][:n_segments]
+        noise = noise_px * rng.normal(4 * len(vis)).reshape(len(vis), 4)
+        segs = np.concatenate([p1[vis], p2[vis]], axis=1) + noise
+        pw, zw = project(R, t, wpts)
+        seen = np.nonzero(inside(pw, zw) & (rng.uniform(n_worldpoints) < 0.75))[0]              # (a tracker misses a quarter of what is in view)
+        views.append(dict(id=i, K=K.copy(), R=R.copy(), t=t.copy(), width=width, height=height, segments=np.ascontiguousarray(segs, dtype=np.float32),
+                          sims={}, worldpoints=seen.astype(np.uint32), gt=vis.copy()))
+    params = dict(n_views=n_views, n_segments=n_segments, seed=seed, n_worldpoints=n_worldpoints, twins=twins, noise_px=noise_px, width=width, height=height, f=f, kind="scattered")
+    return Scene(views, np.concatenate([start, end], axis=1), params)
+
+
 def pair_work(scene: Scene) -> int:
     """Stage-1 segment pairs as the reference schedules them: each mutual
     view pair is evaluated once, from the view processed first (ascending id)."""

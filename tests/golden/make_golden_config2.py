@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import l3d_oracle_pipeline as op  # noqa: E402
-from line3d_amd.synth import make_scene  # noqa: E402
+from line3d_amd.synth import make_scene, make_scene_scattered  # noqa: E402
 
 V, S, N, SEED = 64, 2000, 12, 20260
 
@@ -97,19 +97,30 @@ def main():
     ap.add_argument("--matching-only", action="store_true", help="matchViews only (kept lists and medians per view): what tests/golden/config3_matching.npz holds for the "
                                                                   "512-view scene -- python tests/golden/make_golden_config2.py --views 512 --matching-only --out tests/golden/config3_matching.npz "
                                                                   "(about 6 core-hours)")
+    ap.add_argument("--scattered", action="store_true", help="synth.make_scene_scattered instead of the helix: cameras in no order, ragged views, neighbours chosen by the library from "
+                                                             "shared world points through Line3D::addImage (line3D.cc:95-217, 476-549: not mutual, twins under min_baseline) -- "
+                                                             "python tests/golden/make_golden_config2.py --scattered --views 48 --segments 1500 --neighbors 10 --seed 4242 --out tests/golden/scattered_48x1500x10.npz")
     a = ap.parse_args()
     t0 = time.time()
-    scene = make_scene(a.views, a.segments, a.neighbors, seed=a.seed)
     o = op.OracleLine3D(matching_neighbors=a.neighbors)
-    for v in scene.views:
-        o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+    if a.scattered:
+        scene = make_scene_scattered(a.views, a.segments, seed=a.seed)
+        for v in scene.views:
+            assert o.add_image(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["worldpoints"])
+    else:
+        scene = make_scene(a.views, a.segments, a.neighbors, seed=a.seed)
+        for v in scene.views:
+            o.add_image_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
     print("scene + collinearity %.1f s" % (time.time() - t0), flush=True)
     o.computation = True
     o.track_potential = not a.matching_only
     o.matched, o.potential, o.result = {}, {}, []
     o.find_visual_neighbors()
     o.transform_geometry()
-    g = {"shape": np.array([a.views, a.segments, a.neighbors, a.seed], np.int64)}
+    g = {"shape": np.array([a.views, a.segments, a.neighbors, a.seed], np.int64), "scattered": np.int64(1 if a.scattered else 0)}
+    if a.scattered:         # what the library chose: the neighbourhoods (ragged rows: view id, then its neighbours), the views' segment counts
+        g["neighbors_flat"] = np.array([x for v in sorted(o.visual_neighbors) for x in [v, len(o.visual_neighbors[v])] + list(o.visual_neighbors[v])], np.int64)
+        g["n_segments"] = np.array([len(v["segments"]) for v in scene.views], np.int64)
     kept_sha, kept_n, medians = [], [], []
     cache = dict(np.load(a.cache)) if a.cache and os.path.exists(a.cache) else None
     if cache is not None:

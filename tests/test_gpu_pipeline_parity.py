@@ -944,7 +944,7 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
             tags = [c[0] for c in calls]
             n_rep = ls[0].partition_info()["recovery_rounds"]
             assert tags == [-1, -3] + [-3, -5, -1, -3] * n_rep + [-3, -2, -3, -3, -4], tags
-            assert n_rep == (0 if warmup == 24 else W - 1)
+            assert (n_rep == 0) if warmup == 24 else (1 <= n_rep <= W - 1 and ls[0].partition_info()["blocks_rerun"] >= W - 1)
             for r, l in enumerate(ls):
                 l.finish(False)
                 assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, "rank %d" % r
