@@ -7,9 +7,11 @@ host bookkeeping) on synthetic helix scenes.
 
 A "step" is one full matchViews pass over the scene.  Workload: BASELINE.json configs[1] per GPU --
 64*N views x 2000 segments, 12 neighbours (N=1: config 2 itself; N=8: config 3) -> weak scaling.
-For N>1 every rank holds the scene, computes a 1/N source-segment range of each view on its GPU, the per-view
-kept lists are all-gathered over RCCL, and every rank builds matchViews' products on its device from the gathered
-slots (no rank hands lists to the host).
+For N>1 every rank holds the scene (it is small).  From 4 ranks on the VIEWS are sharded in blocks: every rank runs the full-width
+single-GPU chain on its block + a warm-up started cold, the speculation is verified with digests of the kept lists and a block
+that missed is re-run warm; the blocks and the pieces of matchViews' products are all-gathered over RCCL (DESIGN.md section 6 ii).
+With 2-3 ranks every rank computes a 1/N source-segment range of each view and the per-view kept lists are all-gathered (6 i).
+No rank hands lists to the host in either mode.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -255,9 +257,10 @@ def main():
 
     # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
     # nobody is left waiting in a collective)
-    MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 8 neighbour windows in front of it, started cold; "
-             "the speculation verified with digests of the kept lists (one all-gather), the blocks all-gathered (one more), every rank builds its own block's rows of "
-             "matchViews' products and the pieces are all-gathered -- no per-view collective; a scene on which the verification fails falls through to the next mode",
+    MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 6 neighbour windows in front of it, started cold; "
+             "the speculation verified with digests of the kept lists (one all-gather); a block that missed is re-run warm from its predecessor's lists (all missed "
+             "blocks at once, then digests again); the blocks all-gathered, every rank builds its own block's rows of matchViews' products and the pieces are "
+             "all-gathered -- no per-view collective; falls through to the next mode only when a block is shorter than the neighbour window",
              "native: resident chain, source segments sharded, RCCL all-gather of per-view kept slots enqueued by the library on its own stream, "
              "matchViews' products built on every rank's device from the gathered slots (no host bookkeeping)",
              "resident chain, source segments sharded, all-gather of per-view kept slots through torch.distributed on the library's stream",

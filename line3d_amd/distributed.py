@@ -219,13 +219,15 @@ def match_views_blocks(l3d, rank: int, world: int, link: "RcclLink | None", warm
     return l3d.block_run(rank, world, "rccl", link.link, warmup_views)
 
 
-def match_views_blocks_stepwise(l3d, rank: int, world: int, dist, warmup_views: int, window: int, compute=None) -> bool:
+def match_views_blocks_stepwise(l3d, rank: int, world: int, dist, warmup_views: int, window: int, compute=None, recover: bool = True, info=None) -> bool:
     """The block protocol of l3d_match_chain_blocks spelled out over the step-wise interface (match_begin / match_view_compute /
     match_view_commit) and torch.distributed object collectives: the reference form of the protocol, what the CPU test drives under gloo with the
     oracle as `compute`.  Rank r computes views [B_r - warmup_views, B_{r+1}) of the processing order, the views in front committed EMPTY (a cold
-    start); digests of every computed kept list are all-gathered; block r is exact iff block r-1 is and the `window` views in front of B_r are
-    equal in r's warm-up and in r-1's block.  Exact on every rank: the blocks are all-gathered and every rank replays ALL commits in order from
-    the gathered lists (returns True, state = the unsharded run's).  Otherwise nothing is committed (False, the same on every rank)."""
+    start); digests of every computed kept list are all-gathered; rank r MISSES when the `window` views in front of B_r are not equal in r's warm-up
+    and in r-1's lists.  recover (round 5): every rank that missed takes over its predecessor's last `window` views and re-runs its block warm from
+    them -- all missed blocks at once --, the digests are exchanged again, until nobody misses (rank j is exact after round j at the latest);
+    recover = False: any miss returns False (nothing committed, the same on every rank).  Nobody misses: the blocks are all-gathered and every
+    rank replays ALL commits in order from the gathered lists (returns True, state = the unsharded run's).  info (a dict): rounds, blocks re-run."""
     import hashlib
     if compute is None:
         compute = l3d.match_view_compute
@@ -234,30 +236,55 @@ def match_views_blocks_stepwise(l3d, rank: int, world: int, dist, warmup_views: 
     n = len(ids)
     begin = lambda r: (n * r) // world          # noqa: E731
     own0, own1 = begin(rank), begin(rank + 1)
-    first = 0 if rank == 0 else max(0, own0 - warmup_views)
     empty = np.zeros(0, MATCH_DTYPE)
     mine = {}
-    for k in range(own1):
-        vid, S = ids[k], ns[k]
-        if k < first:
-            l3d.match_view_commit(vid, empty, None, 1.0)              # nothing is known about the views in front of the cold start
-            continue
-        m, med, best = compute(vid, 0, S)
-        early = l3d.view_num_to_be_matched(vid) == 0                  # cudawrapper.cu:877-878: the list comes back as it is, nothing was computed
-        mine[k] = (np.ascontiguousarray(m).tobytes(), None if early else np.ascontiguousarray(best, dtype=np.float32).tobytes())
-        l3d.match_view_commit(vid, m, None if early else best, 1.0 if early else med)
-    digests = {k: hashlib.sha256(v[0]).hexdigest() for k, v in mine.items()}
-    tables = [None] * world
-    dist.all_gather_object(tables, digests)
-    ok = True
-    for r in range(1, world):
-        b, fr = begin(r), max(0, begin(r) - warmup_views)
-        lo = b - window
-        if lo < fr or lo < begin(r - 1) or any(tables[r].get(k) != tables[r - 1].get(k) or k not in tables[r] for k in range(lo, b)):
-            ok = False
+
+    def run_from(first, taken):
+        """this rank's chain over [first, own1): nothing known in front of `first` but the views in `taken` (k -> (list bytes, best bytes or None))"""
+        l3d.match_begin()
+        for k in range(own1):
+            vid, S = ids[k], ns[k]
+            if k in taken:
+                mb, bb = taken[k]
+                m = np.frombuffer(mb, dtype=MATCH_DTYPE).copy()
+                l3d.match_view_commit(vid, m, None if bb is None else np.frombuffer(bb, dtype=np.float32).copy(), 1.0) if bb is None else \
+                    l3d.match_view_commit(vid, m, np.frombuffer(bb, dtype=np.float32).copy())
+                mine[k] = (mb, bb)
+                continue
+            if k < first:
+                l3d.match_view_commit(vid, empty, None, 1.0)              # nothing is known about the views in front of the cold start
+                continue
+            m, med, best = compute(vid, 0, S)
+            early = l3d.view_num_to_be_matched(vid) == 0                  # cudawrapper.cu:877-878: the list comes back as it is, nothing was computed
+            mine[k] = (np.ascontiguousarray(m).tobytes(), None if early else np.ascontiguousarray(best, dtype=np.float32).tobytes())
+            l3d.match_view_commit(vid, m, None if early else best, 1.0 if early else med)
+
+    run_from(0 if rank == 0 else max(0, own0 - warmup_views), {})
+    rounds = reruns = 0
+    while True:
+        digests = {k: hashlib.sha256(v[0]).hexdigest() for k, v in mine.items()}
+        tables = [None] * world
+        dist.all_gather_object(tables, digests)
+        miss = [False] * world
+        for r in range(1, world):
+            b = begin(r)
+            lo = max(0, b - window)
+            if b - window < begin(r - 1) and not recover:
+                miss[r] = True
+            miss[r] = miss[r] or any(k not in tables[r] or tables[r].get(k) != tables[r - 1].get(k) for k in range(lo, b))
+        if not any(miss):
             break
-    if not ok:
-        return False
+        if not recover or rounds >= world or any(begin(r) - window < begin(r - 1) for r in range(1, world)):
+            return False
+        tails = [None] * world
+        dist.all_gather_object(tails, {k: mine[k] for k in range(max(0, own1 - window), own1)} if rank + 1 < world and miss[rank + 1] else {})
+        if miss[rank]:
+            mine.clear()
+            run_from(own0, dict(tails[rank - 1]))
+        rounds += 1
+        reruns += sum(miss)
+    if info is not None:
+        info.update(rounds=rounds, blocks_rerun=reruns)
     blocks = [None] * world
     dist.all_gather_object(blocks, {k: mine[k] for k in range(own0, own1)})
     l3d.match_begin()                                                   # the one chain's state, replayed from the gathered lists

@@ -93,16 +93,23 @@ def test_world2_gloo_sharded_matching_is_bit_identical():
 
 WORKER_BLOCKS = WORKER.replace('sc = make_scene(10, 120, 6, seed=13)', 'sc = make_scene(72, 100, 6, seed=21)').replace(
     'l3dist.match_views_sharded(shim, rank, world, dist, compute=shim.compute)',
-    'ok_short = l3dist.match_views_blocks_stepwise(shim, rank, world, dist, 3, 3, compute=shim.compute)\n'
-    'ok = l3dist.match_views_blocks_stepwise(shim, rank, world, dist, 32, 3, compute=shim.compute)\n'
-    'assert ok and not ok_short, (ok, ok_short)')
+    'ok_short = l3dist.match_views_blocks_stepwise(shim, rank, world, dist, 3, 3, compute=shim.compute, recover=False)\n'
+    'inf = {}\n'
+    'ok_rep = l3dist.match_views_blocks_stepwise(shim, rank, world, dist, 3, 3, compute=shim.compute, info=inf)\n'
+    'kept_rep = {v: m.tobytes() for v, (m, med) in o.kept.items()}\n'
+    'inf2 = {}\n'
+    'ok = l3dist.match_views_blocks_stepwise(shim, rank, world, dist, 32, 3, compute=shim.compute, info=inf2)\n'
+    'assert ok and ok_rep and not ok_short, (ok, ok_rep, ok_short)\n'
+    'assert inf == dict(rounds=1, blocks_rerun=1) and inf2 == dict(rounds=0, blocks_rerun=0), (inf, inf2)\n'
+    'assert kept_rep == {v: m.tobytes() for v, (m, med) in o.kept.items()}')
 
 
 def test_world2_gloo_views_sharded_in_blocks_with_verified_speculation():
     """The block protocol (l3d_match_chain_blocks; here its step-wise form, line3d_amd/distributed.py::match_views_blocks_stepwise, with the oracle
     as the compute) in a real world of two processes under gloo: rank 1 starts its block of 36 views cold, 32 views early (the chain forgets a cold start after about 20 views on this scene); the digests agree, the
     blocks are all-gathered, and both ranks end up with the unsharded run's kept lists, affinity list and lines bit for bit.  With a warm-up of one
-    window the verdict is "not exact" on both ranks and nothing is committed."""
+    window rank 1 misses: without recovery (round 4) the verdict is "not exact" on both ranks and nothing is committed; with it (round 5) rank 1 takes over
+    rank 0's last window of views, re-runs its block warm -- one round, one block -- and the result is the same, bit for bit."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import l3d_oracle_pipeline as op
     from line3d_amd.synth import make_scene
