@@ -39,17 +39,31 @@ namespace l3d {
 
 // reverse matches for view `view_id` out of the kept lists of earlier views (blockIdx.y = source): count per
 // (segment, camera) row.  (seg, tgt) swap roles and the depth pairs swap, line3D.cc:847-856.
-__global__ void k_exist_count(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+constexpr int kCamScanMin = 262144;     // records of a source's list from which the side array is scanned first
+// cams (round 5): the target camera of every record of the arena, written beside it by the kept writer -- a later view reads 4 bytes per record
+// of its sources' lists and the 32-byte record only where it points at that view (one in N): at 4000 segments x 24 neighbours the two scans of a
+// view's sources were 2.9 GB of reads per view
+__global__ void k_exist_count(const Match* __restrict__ arena, const unsigned* __restrict__ cams, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
                               const int* __restrict__ src_cam, unsigned view_id, int N, int S, int* __restrict__ rowcnt)
 {
     const ChainResult* src = res + src_index[blockIdx.y];
     const int cam = src_cam[blockIdx.y];
     const int n = src->n_kept;
     const Match* kept = arena + src->kept_base;
+    // (short lists -- config 2 keeps 36 k matches per view, 1.2 MB -- are scanned record by record: one pass over cache-resident data beats two
+    // dependent ones; measured 12.10 vs 12.17-12.29 ms per config-2 pass, 173.2 vs 165.4 ms at 40 x 4000 x 24, profiles/r5_ab_kept_cams.txt)
+    const unsigned* kc = cams && n > kCamScanMin ? cams + src->kept_base : nullptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (kc && kc[i] != view_id) continue;
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1);
     }
+}
+// the side array of records that did not come from the kept writer (a block's sources taken over from another rank)
+__global__ void k_cams_of_records(const Match* __restrict__ arena, long long n, unsigned* __restrict__ cams)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cams[i] = arena[i].camID2;
 }
 
 __global__ void k_exist_scatter(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
 // others scatter the reverse matches (as k_exist_scatter, 32 workgroups per source view).
 __global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
-                                               const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                                               const Match* __restrict__ arena, const unsigned* __restrict__ cams, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
                                                const int* __restrict__ src_cam, unsigned view_id, int N, int S,
                                                const int* __restrict__ row_start, int* __restrict__ cursor,
                                                uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
@@ -116,7 +130,9 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __res
     const int cam = src_cam[si];
     const int n = src->n_kept;
     const Match* kept = arena + src->kept_base;
+    const unsigned* kc = cams && n > kCamScanMin ? cams + src->kept_base : nullptr;
     for (int i = bx * 256 + (int)threadIdx.x; i < n; i += 32 * 256) {
+        if (kc && kc[i] != view_id) continue;
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) {
             const int row = r.segID2 * N + cam;
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
 // Workgroup 0 also writes the view's result record (device copy for later views, host-mapped copy for the host).
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, const ChainResult* __restrict__ prev,
                                                           unsigned long long arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
-                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos)
+                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos, unsigned* __restrict__ cams)
 {
     __shared__ int s_red[8];
     __shared__ int s_cnt[32];
@@ -176,13 +192,13 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
     if ((unsigned long long)r.kept_base + (unsigned long long)r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
     if (blockIdx.x == 0 && tid == 0) { *res = r; *res_host = r; }
     if (yl >= nseg || r.overflow) return;
-    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best);
+    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best, cams ? cams + r.kept_base : nullptr);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                        int N, int S, int* rowcnt, hipStream_t st)
+                        int N, int S, int* rowcnt, hipStream_t st, const unsigned* cams)
 {
-    if (n_src > 0) hipLaunchKernelGGL(k_exist_count, dim3(32, n_src), dim3(256), 0, st, arena, res, src_index, src_cam, view_id, N, S, rowcnt);
+    if (n_src > 0) hipLaunchKernelGGL(k_exist_count, dim3(32, n_src), dim3(256), 0, st, arena, cams, res, src_index, src_cam, view_id, N, S, rowcnt);
 }
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st)
@@ -198,11 +214,11 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
 }
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st)
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams)
 {
     const int blocks_move = (S * n_tbm + 3) / 4;
     const int blocks = blocks_move + 32 * n_src;
-    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, tbm, n_tbm, rowA, metaA, depthsA, arena, res, src_index, src_cam,
+    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
                                        view_id, N, S, row_start, cursor, meta, depths, cand_cap);
 }
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
@@ -210,9 +226,9 @@ void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int*
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
-                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos)
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos, unsigned* cams)
 {
-    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos);
+    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos, cams);
 }
 
 }  // namespace l3d
@@ -357,9 +373,11 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         arena_cap += (size_t)pre_records;
     }
 
+    const bool use_cams = c->opt.kept_cams != 0;         // (0: A/B -- the sources' lists are scanned record by record)
     auto reserve_caps = [&]() -> int {
         if (int rc = chain_reserve_candidates(c, L, cand_cap, c->chain_ring ? kRing : 0)) return rc;
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
+        if (use_cams) HIPCHK(c, c->ch_keptcam.reserve(arena_cap * 4 + 64));
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
@@ -380,6 +398,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             }
         }
         if (base > 0) HIPCHK(c, hipMemcpyAsync(c->ch_kept.p, pre->records, (size_t)base * sizeof(Match), hipMemcpyDeviceToDevice, st));
+        if (base > 0 && use_cams) hipLaunchKernelGGL(k_cams_of_records, dim3((unsigned)((base + 255) / 256)), dim3(256), 0, st, c->ch_kept.as<Match>(), base, c->ch_keptcam.as<unsigned>());
         HIPCHK(c, hipMemcpyAsync(c->ch_res.as<ChainResult>() + pre->k0, hres + pre->k0, (size_t)(pre->k1 - pre->k0) * sizeof(ChainResult), hipMemcpyHostToDevice, st));
     }
     auto ringA_meta = [&](int k) { return c->ch_ringA_meta.as<uint2>() + (size_t)(k % kRing) * cand_cap; };
@@ -453,14 +472,15 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         const int* d_sc = reinterpret_cast<const int*>(dtab + d.o_sc);
         (void)hipGetLastError();
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
-        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st); }
+        unsigned* cams = use_cams ? c->ch_keptcam.as<unsigned>() : nullptr;
+        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, cams); }
         // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
         if (use_ring) {
             {
                 ProfScope p(c, "cand_move");
                 launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
-                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st);
+                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, cams);
             }
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");
@@ -485,7 +505,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             int pv = k - 1;
             while (pv >= 0 && !has_rec[(size_t)pv]) --pv;                    // the arena slice starts where the previous verified (or preloaded) view's ended
             launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (unsigned long long)arena_cap, dres + k, hres_dev + k,
-                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr);
+                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr, cams);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         // (with a delivery callback the host starts D2H copies of device memory once it has seen this event: a default, fenced event then)
@@ -619,6 +639,13 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 if (!hip_ok(hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice), "hipMemcpy")) break;
                 (void)hipFree(c->ch_kept.p);
                 c->ch_kept.p = np; c->ch_kept.cap = new_cap * sizeof(Match);
+                if (use_cams) {                             // (the side array grows with it, its used part kept)
+                    void* nc = nullptr;
+                    if (!hip_ok(hipMalloc(&nc, new_cap * 4 + 64), "hipMalloc (target cameras of the kept arena)")) break;
+                    if (!hip_ok(hipMemcpy(nc, c->ch_keptcam.p, (size_t)r.kept_base * 4, hipMemcpyDeviceToDevice), "hipMemcpy")) { (void)hipFree(nc); break; }
+                    (void)hipFree(c->ch_keptcam.p);
+                    c->ch_keptcam.p = nc; c->ch_keptcam.cap = new_cap * 4 + 64;
+                }
                 arena_cap = new_cap;
             }
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }

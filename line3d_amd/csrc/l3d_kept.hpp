@@ -17,7 +17,7 @@ namespace l3d {
 // front of every segment's group), found where the confidences already are in registers.
 __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y, int o, const unsigned* __restrict__ local2global,
                                                       Match* __restrict__ out, int* s_cnt, int* __restrict__ best_pos = nullptr,
-                                                      unsigned long long* s_best = nullptr)
+                                                      unsigned long long* s_best = nullptr, unsigned* __restrict__ cam_out = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
@@ -50,6 +50,7 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
                 rec.confidence = c[r] / 2.0f;                    // confidence_norm, cudawrapper.cu:1089,1098
                 const int pos = o + off + __popcll(b[r] & ((1ull << lane) - 1ull));
                 out[pos] = rec;
+                if (cam_out) cam_out[pos] = rec.camID2;         // (the chain's side array: later views find their reverse matches by scanning 4 bytes per record)
                 const unsigned long long key = ((unsigned long long)__float_as_uint(c[r]) << 32) | (0xffffffffu - (unsigned)pos);   // (c > 1: the bits order like the value)
                 bk = key > bk ? key : bk;
             }

@@ -39,6 +39,7 @@ namespace l3d {
     X(host_threads, "L3D_HOST_THREADS", 0, "worker threads of the host-side stages (0: min(16, usable CPUs))")                       \
     X(reserve_hint, "L3D_RESERVE_HINT", 1, "prepare(): 1 = the finishing stages' arenas are reserved ahead from the size of the scene (speed of the first finish), 0 = on demand (memory)") \
     X(handover_chunk_kb, "L3D_HANDOVER_CHUNK_KB", 262144, "views sharded in blocks: a missed block's sources travel in chunks of this many KB per all-gather slot (tests: small values force many chunks)") \
+    X(kept_cams, "L3D_KEPT_CAMS", 1, "resident chain: 1 = the kept writer leaves every record's target camera in a side array and later views scan that (4 B per record) for their reverse matches, 0 = they scan the records (A/B)") \
     X(part_release, "L3D_PART_RELEASE", 1, "partitioned run: 1 = the chain's per-launch scratch is released before the products are built (memory before the speed of a second pass)") \
     X(block_recover, "L3D_BLOCK_RECOVER", 1, "views sharded in blocks: 1 = a block whose cold-started speculation failed is re-run warm from its predecessor's true lists, 0 = any miss ends the call with verdict 1 (round 4; A/B)") \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
