@@ -439,6 +439,15 @@ __global__ void k_aff_edges(const int2* __restrict__ pairs, const float* __restr
     A[2 * (size_t)r] = { na, nb, wgt[r] };
     A[2 * (size_t)r + 1] = { nb, na, wgt[r] };
 }
+// 64-bit sum of n ints (out zeroed by the caller): whether a whole range of sources fits ONE block is a scalar question -- the per-source counts
+// are only downloaded when it does not
+__global__ __launch_bounds__(256) void k_aff_sum64(const int* __restrict__ in, int n, unsigned long long* __restrict__ out)
+{
+    unsigned long long t = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) t += (unsigned long long)(unsigned)in[i];
+    for (int o = 32; o > 0; o >>= 1) { const unsigned lo = __shfl_down((unsigned)t, o), hi = __shfl_down((unsigned)(t >> 32), o); t += ((unsigned long long)hi << 32) | lo; }
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(out, t);
+}
 __global__ void k_aff_fill64(unsigned long long* p, int n, unsigned long long v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -611,7 +620,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     int* cnt = word_off + (nh + 2);
     int* item_off = cnt + (nh + 2);
     HIPCHK(c, hipMemsetAsync(nwords, 0, ((size_t)nh + 2) * 4 * 4, st));
-    HIPCHK(c, c->aff_first.reserve((size_t)nh * 8 + 64));
+    HIPCHK(c, c->aff_first.reserve((size_t)nh * 8 + 64));              // (+ a 64-bit scratch word behind the minima)
     unsigned long long* first = c->aff_first.as<unsigned long long>();
     hipLaunchKernelGGL(k_aff_fill64, dim3((nh + 255) / 256), dim3(256), 0, st, first, nh, kFirstNone);
     c->fill_items = 0; c->fill_passed = 0;
@@ -620,29 +629,53 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     if (h1 > h0) {
         const dim3 gpart((h1 - h0 + 3) / 4);
         { ProfScope p(c, "aff_words", st); hipLaunchKernelGGL(k_aff_words, gpart, dim3(256), 0, st, a, h0, h1, nwords); }
-        std::vector<int> h_nwords((size_t)(h1 - h0)), h_cnt;
-        HIPCHK(c, hipMemcpyAsync(h_nwords.data(), nwords + h0, (size_t)(h1 - h0) * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        std::vector<int> h_nwords, h_cnt;
         const long long word_budget = c->opt.aff_word_block > 0 ? c->opt.aff_word_block : (1ll << 26);
         const long long cand_budget = c->opt.aff_block > 0 ? c->opt.aff_block : (1ll << 27);
+        // (the usual scene is ONE block: asked with a 64-bit sum on the device -- a scalar comes back, not a table)
+        unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(c->aff_first.as<unsigned char>() + (size_t)nh * 8 + 8);
+        auto device_sum = [&](const int* in, int n, unsigned long long& out) -> int {
+            HIPCHK(c, hipMemsetAsync(d_sum, 0, 8, st));
+            hipLaunchKernelGGL(k_aff_sum64, dim3(std::min(1024, (n + 255) / 256)), dim3(256), 0, st, in, n, d_sum);
+            HIPCHK(c, hipMemcpyAsync(&out, d_sum, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            return L3D_OK;
+        };
+        unsigned long long words_all = 0;
+        if (int rc = device_sum(nwords + h0, h1 - h0, words_all)) return rc;
+        lap("  words");
+        const bool one_wblock = (long long)words_all <= word_budget;
+        if (!one_wblock) {
+            h_nwords.resize((size_t)(h1 - h0));
+            HIPCHK(c, hipMemcpyAsync(h_nwords.data(), nwords + h0, (size_t)(h1 - h0) * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        }
         int n_wblocks = 0, n_cblocks = 0;
         for (int w0 = h0; w0 < h1;) {
             long long nw = 0;
             int w1 = w0;
-            while (w1 < h1 && (w1 == w0 || nw + h_nwords[(size_t)(w1 - h0)] <= word_budget)) { nw += h_nwords[(size_t)(w1 - h0)]; ++w1; }
+            if (one_wblock) { nw = (long long)words_all; w1 = h1; }
+            else while (w1 < h1 && (w1 == w0 || nw + h_nwords[(size_t)(w1 - h0)] <= word_budget)) { nw += h_nwords[(size_t)(w1 - h0)]; ++w1; }
             if (nw > 0x7ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "affinity fill: one source segment's candidate walk takes more than 2^31 decision words");
             ++n_wblocks;
             if (int rc = scan_excl(c, nwords + w0, word_off + w0, w1 - w0, st)) return rc;
             HIPCHK(c, c->g2.reserve(((size_t)nw + 1) * 8));
             { ProfScope p(c, "aff_decide", st);
               hipLaunchKernelGGL(k_aff_items<false>, dim3((w1 - w0 + 3) / 4), dim3(256), 0, st, a, w0, w1, word_off, c->g2.as<unsigned long long>(), cnt, (const int*)nullptr, (int2*)nullptr, (float*)nullptr, sigma_a, two_log); }
-            h_cnt.resize((size_t)(w1 - w0));
-            HIPCHK(c, hipMemcpyAsync(h_cnt.data(), cnt + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
+            unsigned long long cand_all = 0;
+            if (int rc = device_sum(cnt + w0, w1 - w0, cand_all)) return rc;
+            lap("  decisions");
+            const bool one_cblock = (long long)cand_all <= cand_budget;
+            if (!one_cblock) {
+                h_cnt.resize((size_t)(w1 - w0));
+                HIPCHK(c, hipMemcpyAsync(h_cnt.data(), cnt + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+            }
             for (int g0 = w0; g0 < w1;) {
                 long long ni = 0;
                 int g1 = g0;
-                while (g1 < w1 && (g1 == g0 || ni + h_cnt[(size_t)(g1 - w0)] <= cand_budget)) { ni += h_cnt[(size_t)(g1 - w0)]; ++g1; }
+                if (one_cblock) { ni = (long long)cand_all; g1 = w1; }
+                else while (g1 < w1 && (g1 == g0 || ni + h_cnt[(size_t)(g1 - w0)] <= cand_budget)) { ni += h_cnt[(size_t)(g1 - w0)]; ++g1; }
                 if (ni > 0x3ffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "affinity fill: one source segment has more than 2^30 candidate pairs");
                 if (ni > 0) {
                     ++n_cblocks;
@@ -664,6 +697,7 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
                     int n_kept_blk = 0;
                     HIPCHK(c, hipMemcpyAsync(&n_kept_blk, erank + n_items, 4, hipMemcpyDeviceToHost, st));
                     HIPCHK(c, hipStreamSynchronize(st));
+                    lap("  candidates (similarity, first touch, ranks)");
                     if (n_kept_blk > 0) {
                         if (int rc = grow_keep(c, c->aff_pass_pairs, (size_t)(n_passed + n_kept_blk) * 8 + 256, (size_t)n_passed * 8, st)) return rc;
                         if (int rc = grow_keep(c, c->aff_pass_w, (size_t)(n_passed + n_kept_blk) * 4 + 256, (size_t)n_passed * 4, st)) return rc;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_exist_sort_runs(const int* __restrict__
 // Both writers of the combined candidate arrays in one launch (independent: stage-1 candidates go to the rows of the cameras
 // to be matched, reverse matches to the rows of the source cameras): the first `blocks_move` workgroups move the stage-1 rows, the
 // others scatter the reverse matches (as k_exist_scatter, 32 workgroups per source view).
-__global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
+__global__ __launch_bounds__(256) void k_place(int blocks_move, int bps, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
                                                const Match* __restrict__ arena, const unsigned* __restrict__ cams, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
                                                const int* __restrict__ src_cam, unsigned view_id, int N, int S,
@@ -125,13 +125,13 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, const int* __res
         for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
         return;
     }
-    const int e = (int)blockIdx.x - blocks_move, si = e / 32, bx = e % 32;
+    const int e = (int)blockIdx.x - blocks_move, si = e / bps, bx = e % bps;         // bps workgroups per source view
     const ChainResult* src = res + src_index[si];
     const int cam = src_cam[si];
     const int n = src->n_kept;
     const Match* kept = arena + src->kept_base;
     const unsigned* kc = cams && n > kCamScanMin ? cams + src->kept_base : nullptr;
-    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += 32 * 256) {
+    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += bps * 256) {
         if (kc && kc[i] != view_id) continue;
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) {
@@ -196,9 +196,9 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                        int N, int S, int* rowcnt, hipStream_t st, const unsigned* cams)
+                        int N, int S, int* rowcnt, hipStream_t st, const unsigned* cams, int bps)
 {
-    if (n_src > 0) hipLaunchKernelGGL(k_exist_count, dim3(32, n_src), dim3(256), 0, st, arena, cams, res, src_index, src_cam, view_id, N, S, rowcnt);
+    if (n_src > 0) hipLaunchKernelGGL(k_exist_count, dim3(std::max(1, bps), n_src), dim3(256), 0, st, arena, cams, res, src_index, src_cam, view_id, N, S, rowcnt);
 }
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st)
@@ -214,11 +214,12 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
 }
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams)
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams, int bps)
 {
+    bps = std::max(1, bps);
     const int blocks_move = (S * n_tbm + 3) / 4;
-    const int blocks = blocks_move + 32 * n_src;
-    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
+    const int blocks = blocks_move + bps * n_src;
+    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
                                        view_id, N, S, row_start, cursor, meta, depths, cand_cap);
 }
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
@@ -454,6 +455,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     };
 
     double t_ev1 = 0;                   // host time spent waiting for stage-1 statistics
+    double kept_seen = pre ? (double)pre_records : 0.0;     // kept records / views whose result record the host has read (sizes the source scans)
+    int views_seen = pre ? pre->k1 - pre->k0 : 0;
     auto enqueue_view = [&](int k) -> int {
         const l3d_chain_view& v = views[k];
         const ViewDev& d = vd[(size_t)k];
@@ -473,14 +476,18 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         (void)hipGetLastError();
         const int* d_si = reinterpret_cast<const int*>(dtab + d.o_si);
         unsigned* cams = use_cams ? c->ch_keptcam.as<unsigned>() : nullptr;
-        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, cams); }
+        // workgroups per source view of the two scans of the sources' lists: a thread walks its stride of a list with dependent loads, so the list
+        // must be spread over enough of them -- 32 x 256 threads take config 2's 36 k records in 5 steps, but 3.5 M records (4000 x 24) in 430:
+        // sized from the lists the chain has seen so far (the host trails a few views behind)
+        const int bps = (int)std::min(512.0, std::max(32.0, (views_seen > 0 ? kept_seen / views_seen : 0.0) / 4096.0));
+        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, cams, bps); }
         // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
         if (use_ring) {
             {
                 ProfScope p(c, "cand_move");
                 launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
-                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, cams);
+                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, cams, bps);
             }
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");
@@ -665,6 +672,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             continue;
         }
         raw_sum += r.R;                     // candidates verified (stage-1 + existing), counted when the view is final (a restart enqueues views twice)
+        kept_seen += r.n_kept; views_seen += 1;
         hand_over(k, 1, r);
     }
     { std::lock_guard<std::mutex> lk(mu); done = true; }

@@ -137,14 +137,14 @@ void launch_seg_post(const VerifyArgs& a, int* kept_cnt, float2* best, hipStream
 void launch_kept_write(const VerifyArgs& a, const int* kept_start, const unsigned* l2g, Match* out, hipStream_t st);
 // resident chain (l3d_chain.hip)
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                        int N, int S, int* rowcnt, hipStream_t st, const unsigned* cams = nullptr);
+                        int N, int S, int* rowcnt, hipStream_t st, const unsigned* cams = nullptr, int bps = 32);
 void launch_exist_scatter(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                           int N, int S, const int* row_start, int* cursor, uint2* meta, float4* depths, int cap, hipStream_t st);
 void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int* row_start, uint2* meta, float4* depths, int cap, hipStream_t st,
                             int seg_begin = 0, int seg_end = -1, float* stage = nullptr, long long stage_stride = 0, unsigned* stage_key = nullptr);
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams = nullptr);
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams = nullptr, int bps = 32);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
                              ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr, unsigned* cams = nullptr);

@@ -45,6 +45,6 @@ def test_interval_bounds_never_decide_against_the_exact_pair_test():
     assert out.count("scene") == 7, out
     stats = re.findall(r"\[l3d pair_mask\] pairs (\d+)\s+after wedge test ([0-9.]+)%\s+after overlap-bound test ([0-9.]+)%", err)
     assert len(stats) == 7, err[-3000:]                          # one line per context: the diagnostic counters were live
-    assert sum(int(s[0]) for s in stats) > 5e9
+    assert sum(int(s[0]) for s in stats) > 2.5e9
     assert all(float(s[2]) < 2.0 for s in stats), stats         # the bounds decide: only a sliver reaches the exact test in the shipped build
     assert "AGAINST the exact test" not in err, err[err.index("AGAINST") - 200:][:3000]
