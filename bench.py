@@ -257,7 +257,7 @@ def main():
 
     # multi-GPU modes, best first; a failure on any rank moves ALL ranks to the next mode (agreed with an all-reduce so that
     # nobody is left waiting in a collective)
-    MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 6 neighbour windows in front of it, started cold; "
+    MODES = ["blocks of views: every rank the full-width single-GPU chain on its 1/N of the views + a warm-up of 8 neighbour windows in front of it, started cold; "
              "the speculation verified with digests of the kept lists (one all-gather); a block that missed is re-run warm from its predecessor's lists (all missed "
              "blocks at once, then digests again); the blocks all-gathered, every rank builds its own block's rows of matchViews' products and the pieces are "
              "all-gathered -- no per-view collective; falls through to the next mode only when a block is shorter than the neighbour window",

@@ -525,11 +525,11 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);
 /* matchViews with the VIEWS sharded over the ranks in blocks, each block started cold a few neighbour windows early, the speculation verified
- * (l3d_match_chain_blocks above; warmup_views < 0: six windows -- a block whose speculation fails is re-run warm, not the pass).  *verdict = 0: this rank holds matchViews' products as after the
+ * (l3d_match_chain_blocks above; warmup_views < 0: eight windows; a block whose speculation fails all the same is re-run warm, not the pass).  *verdict = 0: this rank holds matchViews' products as after the
  * single-GPU resident chain -- compute3Dmodel goes on from there (l3d_line3d_finish); *verdict = 1 (identical on every rank): the speculation
  * did not hold, nothing was committed, run l3d_line3d_shard_run. */
 int l3d_line3d_block_run(l3d_line3d* h, int rank, int world, int warmup_views, l3d_exchange_fn exchange, void* exchange_user, int* verdict);
-/* matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition; warmup_views < 0: six windows), and the rest of
+/* matchViews sharded by blocks of views with NOTHING replicated (l3d_match_chain_partition; warmup_views < 0: eight windows), and the rest of
  * compute3Dmodel as a COLLECTIVE of the job's ranks: greedy selection on the views a rank holds, the affinity fill sharded by source key
  * (l3d_affinity_fill_sharded), then -- every rank from the same affinity list -- diffusion, clustering, line fit: every rank ends with the whole
  * result (Line3D::getResult).  l3d_line3d_finish on such an object is the same call with the exchange of the run; l3d_line3d_view_matches serves the

@@ -406,9 +406,10 @@ static int block_run_impl(l3d_line3d* h, int rank, int world, int warmup_views, 
     int window = 1;
     for (size_t k = 0; k < P.n; ++k) for (int si : P.src_idx[k]) window = std::max(window, (int)k - si);
     // (round 4: eight windows -- any miss cost the pass.  Round 5: a block whose speculation fails is re-run warm, all missed blocks at once, so a
-    // miss costs one more block time, not the pass.  The chain's memory was measured at 3-7 windows, profiles/r4_speculate_*.txt; six windows make
-    // misses rare on those scenes -- what a shorter warm-up saves on every rank a single miss gives back with interest)
-    if (warmup_views < 0) warmup_views = 6 * window;
+    // miss costs one more block time, not the pass.  Still eight: the chain's memory was measured at 3-7 windows (profiles/r4_speculate_*.txt), and on
+    // the 512-view scene at 8 ranks a warm-up of 4 windows re-runs 7 blocks, of 6 windows 3, of 8 windows none (profiles/r5_warmup_needed_512.txt) -- what a
+    // shorter warm-up saves on every rank (2 windows = 12 views) a single miss gives back five times over (a block = 64 views))
+    if (warmup_views < 0) warmup_views = 8 * window;
     std::vector<uint32_t> ids; std::vector<int32_t> base;
     dense_map(h, ids, base);
     l3d_dense_map map;

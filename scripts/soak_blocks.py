@@ -50,7 +50,7 @@ def digest_result(l):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    # (views, segments, neighbours, ranks, warm-up views; -1 = the default of six windows)
+    # (views, segments, neighbours, ranks, warm-up views; -1 = the default of eight windows)
     shapes = [(48, 150, 6, 3, -1), (64, 300, 8, 4, 4), (40, 200, 6, 2, 1), (96, 120, 6, 4, 0), (72, 400, 12, 3, -1), (80, 250, 10, 5, 5)]
     bad = repaired = 0
     for s in range(n):
@@ -115,7 +115,7 @@ def main():
             bad += 0 if ok else 1
             repaired += max(0, n_rep)
             print("scene %2d (%d x %d x %d, %d ranks, warm-up %s) %-9s: verdicts %s, %d block(s) re-run warm  %s %s"
-                  % (s, V, S, N, W, warm if warm >= 0 else "6 windows", mode, verdicts, n_rep, "ok" if ok else "WRONG", errors or ""), flush=True)
+                  % (s, V, S, N, W, warm if warm >= 0 else "8 windows", mode, verdicts, n_rep, "ok" if ok else "WRONG", errors or ""), flush=True)
             for l in ls:
                 l.close()
     print("soak done: %d scenes x 2 modes, %d blocks repaired, %d violations" % (n, repaired, bad))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long a warm-up a cold-started block needs on a scene before its speculation holds -- asked of the library's own check:
-    python3 scripts/warmup_needed.py VIEWS SEGMENTS NEIGHBOURS RANKS warmup [warmup ...]
+    python3 scripts/warmup_needed.py VIEWS SEGMENTS NEIGHBOURS RANKS warmup [warmup ...]          (L3D_WARMUP_MODE=partition: l3d_line3d_partition_run)
 RANKS virtual ranks (threads, all-gather through the host) run l3d_line3d_block_run with each warm-up (in views); reported: rounds of warm
 re-runs and blocks re-run (0 = every rank's check passed at once).  No kept list goes to the host: digests on the device decide."""
 import json
@@ -31,7 +31,7 @@ for warm in warmups:
 
     def run(r):
         try:
-            verdicts[r] = ls[r].block_run(r, W, make(r), None, warm)
+            verdicts[r] = (ls[r].partition_run if os.environ.get("L3D_WARMUP_MODE") == "partition" else ls[r].block_run)(r, W, make(r), None, warm)
         except Exception as e:      # noqa: BLE001
             errors.append((r, repr(e)))
     th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
