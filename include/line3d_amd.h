@@ -355,6 +355,14 @@ int l3d_shard_chain_info(l3d_shard_chain* chain, size_t* cand_cap, int* slot_rec
  * l3d_shard_chain_arena_needed: the kept matches of the whole run (records of 32 bytes), for the retry (l3d_set_chain_capacities' second
  * argument; l3d_line3d_shard_run does it). */
 long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
+/* A PARTITIONED job on the segment-sharded run (call between l3d_shard_chain_open and l3d_shard_chain_run, cb == NULL there): every rank sees
+ * every view's gathered slots go by, so what it KEEPS is its choice -- the views its block [own_begin, own_end) of the chain needs (2 x reach
+ * either side, reach = the largest chain distance between a view and a neighbour), the sources of the early-return views and the views their
+ * local camera numbers name (cudawrapper.cu:877-878, line3D.cc:861-865).  The run retires only those into this rank's arena (ring mode, forced);
+ * l3d_shard_chain_products then builds this rank's share of matchViews' products -- the state l3d_match_chain_partition leaves, without any
+ * speculation: exact on every scene, the chain's work split 1/world per view, the kept records and the table split by view block.
+ * l3d_products_hypotheses and l3d_affinity_fill_sharded follow as there.  (l3d_line3d_shard_run: commit = 3.) */
+int l3d_shard_chain_partition(l3d_shard_chain* chain, int own_begin, int own_end);
 
 /* ---- Line3D::matchViews sharded by BLOCKS OF VIEWS over the ranks, speculatively, with exact verification ----------------------
  * (line3D.cc:620-648 is a chain over views: the kept matches of a view become candidates of its later neighbours, :806,838-872.)
@@ -520,7 +528,8 @@ int l3d_line3d_shard_close(l3d_line3d* h, int committed);
 /* open -> run -> close in one call (l3d_shard_chain_run); commit: 0 = this rank only computes and exchanges; 1 = it also does the
  * host bookkeeping (kept lists handed to the host view by view: the round-2 protocol, one rank of the job); 2 = it builds matchViews'
  * products on its device from the gathered slots (l3d_shard_chain_products) -- any number of ranks, no list leaves the device, the
- * rest of compute3Dmodel runs on the resident tables as after the single-GPU chain.
+ * rest of compute3Dmodel runs on the resident tables as after the single-GPU chain; 3 = as 2, partitioned: the rank keeps the records and
+ * builds the rows of ITS block of views only (l3d_shard_chain_partition), l3d_line3d_finish_sharded follows on every rank.
  * gathered_out (optional) receives the device address of the gathered blocks (valid until the next chain) */
 int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l3d_exchange_fn exchange, void* exchange_user, int commit,
                          const void** gathered_out, size_t* slot_bytes_out);

@@ -229,20 +229,23 @@ __global__ __launch_bounds__(256) void k_shard_pack_all(const unsigned char* __r
 // k_shard_pack_all does for all views at the end), their headers into a small table for the shared verdict -- before their ring block is
 // overwritten.  grid (x, rank, view of the batch).  base_dev[k]: the arena offset of view k (running sum kept on the device: the host never
 // learns a count on the way); the block of the batch's last view publishes the offset of the next batch.
-__global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, int k0, int n_batch,
+// keep (partitioned job, l3d_shard_chain_partition; null: every view): a view that is not flagged leaves its headers in the table (the shared
+// verdict reads them) and nothing in this rank's arena.
+__global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, const unsigned char* __restrict__ keep, int k0, int n_batch,
                                                       long long* __restrict__ base_dev, long long arena_cap, const long long* __restrict__ best_off, Match* __restrict__ arena,
                                                       float2* __restrict__ best_all, int* __restrict__ bestpos_all, SlotHeader* __restrict__ hdr_all, int* __restrict__ overflow)
 {
     const int k = k0 + blockIdx.z, r = blockIdx.y;
     long long base = base_dev[k0];
     for (int q = k0; q < k; ++q) {
-        if (!verified[q]) continue;
+        if (!verified[q] || (keep && !keep[q])) continue;
         const unsigned char* bq = G + (size_t)(q % g.ring) * g.world * g.slot_bytes;
         for (int w = 0; w < g.world; ++w) { const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(bq + (size_t)w * g.slot_bytes); base += hq->overflow ? 0 : hq->n_kept; }
     }
     const unsigned char* block = G + (size_t)(k % g.ring) * g.world * g.slot_bytes;
+    const bool kept_here = !keep || keep[k];
     int in_front = 0, all = 0;
-    if (verified[k])
+    if (verified[k] && kept_here)
         for (int w = 0; w < g.world; ++w) {
             const SlotHeader* hq = reinterpret_cast<const SlotHeader*>(block + (size_t)w * g.slot_bytes);
             const int n = hq->overflow ? 0 : hq->n_kept;
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __res
     const unsigned char* slot = block + (size_t)r * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     if (first) *ho = *hd;
+    if (!kept_here) return;
     const int n = hd->overflow ? 0 : hd->n_kept;
     if (base + all > arena_cap) { if (first) atomicMax(overflow, 1); return; }      // the arena's first guess was too small: the run ends with a capacity verdict
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
@@ -345,6 +349,14 @@ struct l3d_shard_chain {
     SlotHeader* hdr_all = nullptr;           // the headers of all slots of all views (32 B each)
     const long long* best_off_dev = nullptr;
     const unsigned char* ver_dev = nullptr;
+    // partitioned retirement (l3d_shard_chain_partition): only the views flagged in `keep` go to this rank's compact arena
+    bool partition = false;
+    int part_own0 = 0, part_own1 = 0, part_reach = 0;
+    std::vector<unsigned char> keep;
+    const unsigned char* keep_dev = nullptr;
+    l3d_exchange_fn part_exchange = nullptr;   // the run's exchange: l3d_shard_chain_products' one status exchange
+    void* part_user = nullptr;
+    unsigned char* part_status = nullptr;
 };
 
 extern "C" {
@@ -676,6 +688,10 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     const int ring_views = h->window + kRetireBatch + 2;
     const size_t gathered_budget = (size_t)8 << 30;
     h->ring_mode = !cb && c->opt.slot_ring != 0 && ring_views < h->n_views && (c->opt.slot_ring > 0 || (size_t)h->n_views * block > gathered_budget);
+    if (h->partition) {      // a partitioned job retires by definition: what a rank does not keep is gone when its ring block is reused
+        if (cb || ring_views >= h->n_views) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_run: a partitioned run needs more views than the ring of gathered blocks holds and no host callback");
+        h->ring_mode = true;
+    }
     h->geom.ring = h->ring_mode ? ring_views : std::max(1, h->n_views);
     const int send_ring = h->ring_mode ? ring_views : h->n_views;            // (a slot is read by its exchange only)
     HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
@@ -693,6 +709,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     std::vector<unsigned char> ver_h((size_t)h->n_views);
     std::vector<long long> best_off_h((size_t)h->n_views, 0);
     int* ring_overflow = nullptr;
+    unsigned char* part_status = nullptr;      // partitioned: [own word | the ranks' words], 256 B each
     if (h->ring_mode) {
         // compact arena (first guess like the single-GPU chain's, or what an earlier pass / a capacity verdict taught), the per-view offsets,
         // the header table, the flags the retire kernel reads
@@ -700,7 +717,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t nvs = (size_t)h->n_views;
-        const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), tot = o_ovf + 256;
+        const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), o_keep = o_ovf + 256, o_stat = o_keep + al(nvs), tot = o_stat + 256 * ((size_t)h->world + 1);
         HIPCHK(c, c->ch_hdr.reserve(tot));
         unsigned char* hb = c->ch_hdr.as<unsigned char>();
         h->base_dev = reinterpret_cast<long long*>(hb + o_base);
@@ -715,14 +732,23 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         HIPCHK(c, hipMemcpyAsync(hb + o_ver, ver_h.data(), nvs, hipMemcpyHostToDevice, c->stream));
         h->best_off_dev = reinterpret_cast<const long long*>(hb + o_bo);
         h->ver_dev = hb + o_ver;
+        h->keep_dev = nullptr;
+        if (h->partition) {
+            HIPCHK(c, hipMemcpyAsync(hb + o_keep, h->keep.data(), nvs, hipMemcpyHostToDevice, c->stream));
+            h->keep_dev = hb + o_keep;
+            // (the first guess of the arena: this rank's share of the scene's)
+            if (!c->test_arena_cap) { long long kv = 0; for (unsigned char x : h->keep) kv += x; h->arena_cap = std::max<long long>(1048576, h->arena_cap * kv / std::max(1, h->n_views) + 1048576); HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match))); }
+        }
         ring_overflow = reinterpret_cast<int*>(hb + o_ovf);
+        part_status = hb + o_stat;
+        h->part_status = part_status; h->part_exchange = exchange; h->part_user = exchange_user;
     }
     int retired = 0;                        // views [0, retired) are in the compact arena (ring mode)
     auto retire_to = [&](int upto) {        // enqueue the retirement of views [retired, upto) on the chain's stream (behind their exchanges)
         while (retired < upto) {
             const int nb = std::min(kRetireBatch, upto - retired);
             ProfScope p(c, "retire");
-            hipLaunchKernelGGL(k_shard_retire, dim3(8, h->world, nb), dim3(256), 0, c->stream, gathered, h->geom, h->ver_dev, retired, nb, h->base_dev, h->arena_cap,
+            hipLaunchKernelGGL(k_shard_retire, dim3(8, h->world, nb), dim3(256), 0, c->stream, gathered, h->geom, h->ver_dev, h->keep_dev, retired, nb, h->base_dev, h->arena_cap,
                                h->best_off_dev, c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>(), h->hdr_all, ring_overflow);
             retired += nb;
         }
@@ -871,6 +897,23 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             if (e == hipSuccess && !(h->ring_mode && retired != h->n_views)) e = hipMemcpyAsync(host3, c->ch_flags.p, 12, hipMemcpyDeviceToHost, c->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (h->partition && part_status) {
+            // every rank's arena is its own: "too small" is no shared verdict by itself -- one more exchange makes it one (entered by every rank,
+            // whatever happened to it: tag -3, the status words of the block modes)
+            long long w[2] = { e == hipSuccess ? (long long)ring_ovf_h : 1, 0 };
+            hipError_t e2 = hipMemcpyAsync(part_status, w, 16, hipMemcpyHostToDevice, c->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+            if (exchange(exchange_user, -3, part_status, part_status + 256, 256, h->world, (void*)c->stream)) { if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = "l3d_shard_chain_run: the exchange of the arena verdicts failed"; } }
+            else {
+                for (int r = 0; r < h->world && e2 == hipSuccess; ++r) {
+                    long long x = 0;
+                    e2 = hipMemcpyAsync(&x, part_status + 256 * ((size_t)r + 1), 8, hipMemcpyDeviceToHost, c->stream);
+                    if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+                    if (e2 == hipSuccess && x) ring_ovf_h = 1;
+                }
+            }
+            if (e == hipSuccess) e = e2;
+        }
         if (e != hipSuccess) { if (rc == L3D_OK) { rc = L3D_ERR_HIP; rc_msg = std::string("l3d_shard_chain_run: reading the slot headers: ") + hipGetErrorString(e); } }
         else {
             if (ring_ovf_h) host3[0] |= 8;                          // the compact arena's first guess was too small (same data, same verdict on every rank)
@@ -959,20 +1002,55 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
     for (int k = 0; k < nv; ++k) {
         const SViewDev& d = h->vd[(size_t)k];
         ChainResult& r = hres[(size_t)k];
-        r.kept_base = (unsigned)total; r.n_kept = d.verified ? tot[(size_t)k].x : 0; r.R = d.verified ? tot[(size_t)k].y : 0; r.overflow = 0;
+        const bool here = !h->partition || h->keep[(size_t)k];            // (partitioned: the views this rank retired)
+        r.kept_base = (unsigned)total; r.n_kept = d.verified && here ? tot[(size_t)k].x : 0; r.R = d.verified && here ? tot[(size_t)k].y : 0; r.overflow = 0;
         kept_base[(size_t)k] = (unsigned)total;
         total += r.n_kept;
-        if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_products: more than 2^32 kept matches");
+        if (total > 0xfffffff0ll) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_products: more than 2^32 kept matches on this rank (l3d_shard_chain_partition keeps a rank's share only)");
         best_off[(size_t)k] = d.verified ? (long long)(d.best - c->ch_best.as<float2>()) : 0;
         pvh[(size_t)k].verified = d.verified ? 1 : 0;
-        pvh[(size_t)k].best = d.verified ? d.best : nullptr;
-        pvh[(size_t)k].bestpos = d.verified ? d.bestpos : nullptr;
+        pvh[(size_t)k].best = d.verified && here ? d.best : nullptr;
+        pvh[(size_t)k].bestpos = d.verified && here ? d.bestpos : nullptr;
     }
     if (h->ring_mode) {
         // the records are in the arena already (k_shard_retire, view by view in this very order)
         if (total != h->arena_needed) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: the retired records do not add up to the slot headers");
-        c->chain_seen_arena_cap = std::max(c->chain_seen_arena_cap, (size_t)total + (size_t)total / 8 + 65536);
         h->kept_total = (double)total;
+        if (h->partition) {
+            // this rank's share: rows of the views within reach of its block, best matches / medians of every view it kept
+            auto dense_of = [&](int k) { if (k >= nv) return map->n_views; const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + map->n_views, h->views[k].view_id); return (int)(it - map->view_ids); };
+            ProductsPart part;
+            part.active = true; part.rank = h->rank; part.world = h->world;
+            part.own_dv0 = dense_of(h->part_own0); part.own_dv1 = dense_of(h->part_own1);
+            part.row_dv0 = dense_of(std::max(0, h->part_own0 - h->part_reach)); part.row_dv1 = dense_of(std::min(nv, h->part_own1 + h->part_reach));
+            part.held_dv0 = dense_of(std::max(0, h->part_own0 - 2 * h->part_reach)); part.held_dv1 = dense_of(std::min(nv, h->part_own1 + 2 * h->part_reach));
+            int64_t n_local = 0;
+            const int rc = build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, reinterpret_cast<const char*>(h->keep.data()));
+            // one status exchange (tag -3), entered by every rank whatever happened to it: the ranks go on to the collective finish together or not at all
+            std::string err_local;
+            if (rc) { std::lock_guard<std::mutex> lk(c->err_mu); err_local = c->err; }
+            long long w[2] = { rc ? -(long long)std::abs(rc) : (long long)n_local, 0 };
+            hipError_t e = hipMemcpyAsync(h->part_status, w, 16, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) (void)hipMemsetAsync(h->part_status, 0xff, 16, st);
+            if (!h->part_exchange || h->part_exchange(h->part_user, -3, h->part_status, h->part_status + 256, 256, h->world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: the exchange of the status words failed");
+            if (rc) return fail(c, rc, err_local);
+            part.n_pot_all = 0;
+            for (int r = 0; r < h->world; ++r) {
+                long long x = 0;
+                HIPCHK(c, hipMemcpyAsync(&x, h->part_status + 256 * ((size_t)r + 1), 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (x < 0) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: rank " + std::to_string(r) + " failed (code " + std::to_string(-x) + ") while building its rows of the products");
+                part.n_pot_all += x;
+            }
+            c->products.part = part;
+            c->products.n_pot = n_local;
+            c->products.valid = true;
+            if (n_pot) *n_pot = n_local;
+            memcpy(c->ch_pin_res.as<ChainResult>(), hres.data(), (size_t)nv * sizeof(ChainResult));      // (what l3d_chain_kept_list reads)
+            return L3D_OK;
+        }
+        c->chain_seen_arena_cap = std::max(c->chain_seen_arena_cap, (size_t)total + (size_t)total / 8 + 65536);
         return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot);
     }
     HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
@@ -985,6 +1063,42 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
     HIPCHK(c, hipGetLastError());
     h->kept_total = (double)total;
     return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot);
+}
+
+// A partitioned job on top of the segment-sharded run (round 5): every rank sees every view's gathered slots go by, so WHAT IT KEEPS is its own
+// choice -- with this call: the views its block [own_begin, own_end) of the chain needs (2 x reach either side: DESIGN.md section 6 iii), the sources
+// of the early-return views and the views their local camera numbers name (cudawrapper.cu:877-878, line3D.cc:861-865: whole lists, a few views).
+// The run then retires only those into this rank's arena; l3d_shard_chain_products builds the rows of the block and its neighbours, the best
+// matches and medians of the kept views -- the state l3d_match_chain_partition leaves, computed WITHOUT speculation (a scene whose chain never
+// forgets a cold start -- the box scene at 4000 segments x 24 neighbours keeps half of its candidates and does not within 120 views -- gets the
+// segment-sharded run's speed and the partition's memory).  l3d_affinity_fill_sharded follows as there.
+int l3d_shard_chain_partition(l3d_shard_chain* h, int own_begin, int own_end)
+{
+    if (!h) return L3D_ERR_INVALID;
+    l3d_ctx* c = h->c;
+    const int nv = h->n_views;
+    if (own_begin < 0 || own_end > nv || own_begin > own_end) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_partition: bad view range");
+    std::vector<std::pair<unsigned, int>> idx((size_t)nv);
+    for (int k = 0; k < nv; ++k) idx[(size_t)k] = { h->views[k].view_id, k };
+    std::sort(idx.begin(), idx.end());
+    auto chain_of = [&](unsigned id) { auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(id, -1)); return it != idx.end() && it->first == id ? it->second : -1; };
+    int reach = 1;
+    for (int k = 0; k < nv; ++k)
+        for (int q = 0; q < h->views[k].N; ++q) { const int j = h->views[k].local2global ? chain_of(h->views[k].local2global[q]) : -1; if (j >= 0) reach = std::max(reach, std::abs(j - k)); }
+    h->keep.assign((size_t)nv, 0);
+    for (int k = std::max(0, own_begin - 2 * reach); k < std::min(nv, own_end + 2 * reach); ++k) h->keep[(size_t)k] = 1;
+    for (int k = 0; k < nv; ++k) {
+        if (h->views[k].n_tbm != 0 || h->views[k].n_sources == 0) continue;
+        h->keep[(size_t)k] = 1;
+        for (int q = 0; q < h->views[k].n_sources; ++q) {
+            const int si = h->views[k].source_index[q];
+            if (si >= 0 && si < nv) h->keep[(size_t)si] = 1;
+            const int av = chain_of((unsigned)h->views[k].source_cam[q]);
+            if (av >= 0) h->keep[(size_t)av] = 1;
+        }
+    }
+    h->partition = true; h->part_own0 = own_begin; h->part_own1 = own_end; h->part_reach = reach;
+    return L3D_OK;
 }
 
 int l3d_shard_chain_close(l3d_shard_chain* h)

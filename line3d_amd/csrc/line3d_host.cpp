@@ -355,11 +355,15 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         const double t1 = now_s();
         ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
         const bool host_commit = commit == 1;
+        if (commit == 3) {       // partitioned: this rank keeps what its block of views needs (l3d_shard_chain_partition), nothing else
+            rc = l3d_shard_chain_partition(P->shard, (int)(((long long)n_views * rank) / world), (int)(((long long)n_views * (rank + 1)) / world));
+            if (rc) { const std::string m = std::string("shard_chain_partition: ") + l3d_last_error(h->ctx); l3d_line3d_shard_close(h, 0); return h->fail(rc, m); }
+        }
         if (arena_cap_next) l3d_set_chain_capacities(h->ctx, 0, arena_cap_next);          // (the compact arena of the slot ring: read by the run)
         rc = l3d_shard_chain_run(P->shard, exchange, exchange_user, host_commit ? chain_callback : nullptr, host_commit ? &P->user : nullptr);
         if (arena_cap_next) l3d_set_chain_capacities(h->ctx, 0, 0);
         std::string msg = rc ? std::string("shard_chain_run: ") + l3d_last_error(h->ctx) : std::string();
-        if (rc == L3D_OK && commit == 2) {
+        if (rc == L3D_OK && (commit == 2 || commit == 3)) {
             // commit on the device: this rank builds matchViews' products from the gathered slots (every rank may), no list goes to the host
             std::vector<uint32_t> ids; std::vector<int32_t> base;
             dense_map(h, ids, base);
@@ -368,7 +372,11 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
             h->chain_summary.assign(P->n, l3d_chain_summary());
             rc = l3d_shard_chain_products(P->shard, &map, h->chain_summary.data(), &h->resident_n_pot);
             if (rc) msg = std::string("shard_chain_products: ") + l3d_last_error(h->ctx);
-            else { rc = adopt_resident_products(h, *P); if (rc) msg = h->err; }
+            else {
+                if (commit == 3) { h->partitioned = true; h->part_exchange = exchange; h->part_user = exchange_user; }      // (a share: nothing to check against a host construction)
+                rc = adopt_resident_products(h, *P);
+                if (rc) { msg = h->err; h->partitioned = false; }
+            }
         }
         size_t cand_cap = 0; int bits = 0, max_cand = 0, max_kept = 0, recs = slot_records;
         l3d_shard_chain_info(P->shard, &cand_cap, &recs, &bits, &max_cand, &max_kept);

@@ -221,9 +221,13 @@ class Line3D:
         """The whole sharded chain as one native call (l3d_shard_chain_run).  exchange: "rccl" (exchange_user = a ctypes
         l3d_rccl_link), "local" (world 1) or "replay" (exchange_user = device address of recorded gathered blocks).
         commit: False / 0 = compute and exchange only, True / 1 = host bookkeeping on this rank, 2 (or "device") = matchViews' products built on
-        this rank's device from the gathered slots.  Returns (device address of the gathered blocks, slot_bytes)."""
+        this rank's device from the gathered slots, 3 (or "partition") = as 2, but this rank keeps the records and builds the rows of its block of
+        views only (l3d_shard_chain_partition: exact without speculation; finish_sharded() follows on every rank).
+        Returns (device address of the gathered blocks, slot_bytes)."""
         if commit == "device":
             commit = 2
+        if commit == "partition":
+            commit = 3
         if callable(exchange):       # tests: a Python exchange (called on this thread by the enqueue loop), e.g. to inject a failure
             proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
             fn = self._exchange_keepalive = proto(exchange)

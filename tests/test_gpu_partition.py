@@ -30,7 +30,7 @@ def _reference(scene, N, diffusion):
     return out
 
 
-def _run_partitioned(scene, N, W, warmup, diffusion, options=None):
+def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=False):
     from line3d_amd.pipeline import Line3D, load_scene
     make, calls = thread_exchange(W)
     ls, verdicts, errors = [], [None] * W, []
@@ -46,7 +46,11 @@ def _run_partitioned(scene, N, W, warmup, diffusion, options=None):
 
     def run(r):
         try:
-            verdicts[r] = ls[r].partition_run(r, W, make(r), None, warmup)
+            if segments:        # the segment-sharded run, partitioned: exact by construction, no verdict
+                ls[r].shard_run(r, W, 4096, make(r), None, commit="partition")
+                verdicts[r] = True
+            else:
+                verdicts[r] = ls[r].partition_run(r, W, make(r), None, warmup)
             if verdicts[r]:
                 shares[r] = (ls[r].partition_info(), ls[r].resident_products())
                 ls[r].finish_sharded(diffusion)
@@ -111,6 +115,26 @@ def test_partitioned_run_and_sharded_fill_equal_the_one_chain(W, diffusion):
         assert -2 not in tags and -4 not in tags
         if W > 1:
             assert tags.count(-7) == 1 and tags.count(-8) == 1 and tags.count(-9) == 1 and tags.count(-10) == 1
+    finally:
+        for l in ls:
+            l.close()
+
+
+@pytest.mark.parametrize("W,diffusion", [(3, True), (4, False)])
+def test_segment_sharded_run_partitioned_equals_the_one_chain(W, diffusion):
+    """l3d_shard_chain_partition: the source segments of every view sharded over the ranks (no speculation: l3d_shard_chain_run), every rank retiring
+    only what its block of views needs; then the very same collective finish."""
+    from line3d_amd.synth import make_scene
+    V, S, N = 60, 160, 6
+    scene = make_scene(V, S, N, seed=11)
+    ref = _reference(scene, N, diffusion)
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, diffusion, segments=True)
+    try:
+        assert not errors, errors
+        _check_against(ref, scene, ls, shares)
+        tags = [c[0] for c in calls]
+        assert -1 not in tags and -2 not in tags and -4 not in tags and -5 not in tags and -6 not in tags       # no digests, no blocks, no hand-over: nothing speculated
+        assert tags.count(-7) == 1 and tags.count(-9) == 1
     finally:
         for l in ls:
             l.close()
