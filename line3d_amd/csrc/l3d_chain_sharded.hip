@@ -411,7 +411,6 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     h->stage_bytes = salign((size_t)world * ((size_t)h->geom.seg_cap * 8 + (size_t)slot_records * sizeof(Match)), 256);
     OCHK(c->ch_pin_kept.reserve(2 * ((size_t)world * (size_t)h->geom.seg_cap * 8 + 64) + 64));
     c->pin_arena.reset();
-    OCHK(c->ch_stage.reserve((size_t)l3d_shard_chain::kRing * h->stage_bytes + 64));
     OCHK(c->ch_pin_best.reserve((size_t)n_views * sizeof(PackHeader) + 64));
     h->hdr_host = c->ch_pin_best.as<PackHeader>();
     OCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hdr_dev), h->hdr_host, 0));
@@ -586,6 +585,9 @@ static int shard_pack(l3d_shard_chain* h, int k, hipStream_t st)
 {
     l3d_ctx* c = h->c;
     const size_t block = (size_t)h->world * h->geom.slot_bytes;
+    // the staging ring of the host hand-over: 16 views x the ranks' slots -- only a rank that commits on the host ever packs (13 GB at 4000 segments x
+    // 24 neighbours: a rank that builds the products on its device never pays it)
+    HIPCHK(c, c->ch_stage.reserve((size_t)l3d_shard_chain::kRing * h->stage_bytes + 64));
     hipLaunchKernelGGL(k_pack_view, dim3(8, h->world), dim3(256), 0, st, h->gathered + (size_t)k * block, h->geom,
                        c->ch_stage.as<unsigned char>() + (size_t)(k % l3d_shard_chain::kRing) * h->stage_bytes, h->hdr_dev + k);
     h->packed[(size_t)k] = 1;
@@ -694,8 +696,13 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     }
     h->geom.ring = h->ring_mode ? ring_views : std::max(1, h->n_views);
     const int send_ring = h->ring_mode ? ring_views : h->n_views;            // (a slot is read by its exchange only)
-    HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
-    HIPCHK(c, c->ch_gathered.reserve((size_t)h->geom.ring * block + 256));
+    if (h->ring_mode) {      // (rings of whole slots: GBs whose size is exact)
+        HIPCHK(c, c->ch_send.reserve_exact((size_t)send_ring * slot + 256));
+        HIPCHK(c, c->ch_gathered.reserve_exact((size_t)h->geom.ring * block + 256));
+    } else {
+        HIPCHK(c, c->ch_send.reserve((size_t)send_ring * slot + 256));
+        HIPCHK(c, c->ch_gathered.reserve((size_t)h->geom.ring * block + 256));
+    }
     h->eager_pack = cb != nullptr;
     h->defer_stats = c->opt.defer_stats != 0;
     h->use_graphs = cb == nullptr && h->defer_stats;                  // (a committing rank's pack kernel belongs to the mark, not to the view's sequence)
@@ -714,7 +721,7 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         // compact arena (first guess like the single-GPU chain's, or what an earlier pass / a capacity verdict taught), the per-view offsets,
         // the header table, the flags the retire kernel reads
         h->arena_cap = c->test_arena_cap ? (long long)c->test_arena_cap : std::max((long long)(h->pairs * h->world * 0.004) + 1048576, (long long)c->chain_seen_arena_cap);
-        HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
+        if (!h->partition) HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t nvs = (size_t)h->n_views;
         const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), o_keep = o_ovf + 256, o_stat = o_keep + al(nvs), tot = o_stat + 256 * ((size_t)h->world + 1);
@@ -737,7 +744,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             HIPCHK(c, hipMemcpyAsync(hb + o_keep, h->keep.data(), nvs, hipMemcpyHostToDevice, c->stream));
             h->keep_dev = hb + o_keep;
             // (the first guess of the arena: this rank's share of the scene's)
-            if (!c->test_arena_cap) { long long kv = 0; for (unsigned char x : h->keep) kv += x; h->arena_cap = std::max<long long>(1048576, h->arena_cap * kv / std::max(1, h->n_views) + 1048576); HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match))); }
+            if (!c->test_arena_cap) { long long kv = 0; for (unsigned char x : h->keep) kv += x; h->arena_cap = std::max<long long>((long long)c->part_arena_seen, h->arena_cap * kv / std::max(1, h->n_views) + 1048576); }
+            HIPCHK(c, c->ch_kept.reserve_exact(((size_t)h->arena_cap + 64) * sizeof(Match)));
         }
         ring_overflow = reinterpret_cast<int*>(hb + o_ovf);
         part_status = hb + o_stat;
@@ -1025,6 +1033,14 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
             part.row_dv0 = dense_of(std::max(0, h->part_own0 - h->part_reach)); part.row_dv1 = dense_of(std::min(nv, h->part_own1 + h->part_reach));
             part.held_dv0 = dense_of(std::max(0, h->part_own0 - 2 * h->part_reach)); part.held_dv1 = dense_of(std::min(nv, h->part_own1 + 2 * h->part_reach));
             int64_t n_local = 0;
+            if (c->opt.part_release != 0) {
+                // the job is sized by memory: what only the running chain needed -- the rings of slots, the candidate store and its ring, window scratch,
+                // bit rows, viewing rays, row counters -- is given back before the products are built (as l3d_match_chain_partition does)
+                (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(c->stage1_stream);
+                DevBuf* b[] = { &c->ch_gathered, &c->ch_send, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->vw_scratch, &c->ch_mask, &c->ch_rays, &c->ch_rowcnt, &c->ch_rowA };
+                for (DevBuf* x : b) x->release();
+                h->gathered = nullptr;
+            }
             const int rc = build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, reinterpret_cast<const char*>(h->keep.data()));
             // one status exchange (tag -3), entered by every rank whatever happened to it: the ranks go on to the collective finish together or not at all
             std::string err_local;
@@ -1035,6 +1051,7 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
             if (e != hipSuccess) (void)hipMemsetAsync(h->part_status, 0xff, 16, st);
             if (!h->part_exchange || h->part_exchange(h->part_user, -3, h->part_status, h->part_status + 256, 256, h->world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: the exchange of the status words failed");
             if (rc) return fail(c, rc, err_local);
+            c->part_arena_seen = std::max(c->part_arena_seen, (size_t)total + (size_t)total / 8 + 65536);
             part.n_pot_all = 0;
             for (int r = 0; r < h->world; ++r) {
                 long long x = 0;

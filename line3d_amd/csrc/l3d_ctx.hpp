@@ -31,6 +31,15 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // a buffer whose size is a plan, not a guess (rings of slots, an arena with its own slack): no 25 % on top
+    hipError_t reserve_exact(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, bytes + 256);
+        if (e == hipSuccess) cap = bytes + 256;
+        return e;
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
@@ -162,6 +171,7 @@ struct l3d_ctx {
     std::vector<int> h_cnt;
     int mmax_seen = 0;
     int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_place (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
+    size_t part_arena_seen = 0;                     // records a partitioned segment-sharded run kept on this rank (sizes the next pass's arena)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0;   // what the last chain over this scene needed
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)

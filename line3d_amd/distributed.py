@@ -201,7 +201,9 @@ def match_views_chain_native(l3d, rank: int, world: int, link: "RcclLink | None"
     """Line3D::matchViews as the sharded resident chain in ONE native call (l3d_shard_chain_run): per view the library
     enqueues this rank's kernels, the RCCL all-gather of the ranks' kept-list slots and a completion event on its own
     stream; a host thread of the library trails behind with the bookkeeping on the ranks that commit (commit=True);
-    commit="device": no rank hands lists to the host -- this rank builds matchViews' products on its device from the gathered slots."""
+    commit="device": no rank hands lists to the host -- this rank builds matchViews' products on its device from the gathered slots;
+    commit="partition": as "device", but the rank keeps the records and builds the rows of its block of views only (l3d_shard_chain_partition:
+    the partitioned job without speculation; l3d.finish_sharded() follows on every rank)."""
     if slot_records is None:
         slot_records = default_slot_records(n_segments, n_neighbors, world)
     if world == 1 and link is None:

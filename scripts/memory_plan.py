@@ -6,6 +6,8 @@
 --mode partition (default; round 5): l3d_match_chain_partition + l3d_affinity_fill_sharded -- views sharded in blocks, NOTHING replicated: a rank holds
   the kept records of its block, of the warm-up in front of it and of 2 x reach views either side, its rows of the products, its sources' candidates.
 --mode segments: l3d_shard_chain_run (source segments of every view sharded; ring of gathered slots, compact arena REPLICATED on every rank).
+--mode segpart: l3d_shard_chain_partition + l3d_shard_chain_run + l3d_affinity_fill_sharded -- the segments of every view sharded (exact without
+  speculation), every rank RETIRES only its block of views + 2 x reach either side: the ring of gathered slots, then the partition's share of everything.
 
 `kept` = kept matches / candidates verified (config 2 measures 2.5 %; the synthetic box scene at 4000 x 24 keeps 30 % at 40 views and 48 % at 256:
 profiles/r5_256x4000x24_one_gpu_finish.json).  Stage-1 candidates per view: rho * S^2 * n_tbm, rho = 0.065 (SURVEY 8, measured on config 2);
@@ -89,6 +91,43 @@ def plan_segments(V, S, N, W, kept_ratio):
     return rows, dict(arena_records_per_rank=kept_total, kept_records_job=kept_total), dict(kept_view=kept_view, cand_view=cand_view)
 
 
+def plan_segpart(V, S, N, W, kept_ratio):
+    n_tbm, raw_view, cand_view, kept_view = model(V, S, N, kept_ratio)
+    reach = window = N // 2
+    block = -(-V // W)
+    held_views = min(V, block + 4 * reach)
+    row_views = min(V, block + 2 * reach)
+    n_tgt = N * S
+    nd = V * S
+    W64 = 4 * ((S + 255) // 256)
+    local_kept = held_views * kept_view
+    fill_cand_view, passed_view = (5.9e6, 4.2e4) if S >= 3000 else (2.8e4, 7.7e3)
+    passed_all = passed_view * V
+    n_hyp = nd * 0.98
+    rows = []
+    add = lambda phase, name, b, where: rows.append((phase, name, b, where))
+    add("all", "segments + neighbour tiles, resident (every rank holds the scene: it is small)", V * (S + n_tgt) * 16, "line3d_host_views.cpp:prepare -> l3d_register_segments_batch")
+    add("all", "camera tables, best depth pairs + positions of all views", V * (N * 144 + 48 + n_tbm * 4 + window * 8) + V * S * 12, "l3d_chain_common.hip:chain_plan_views, chain_assign_arenas")
+    add("all", "kept arena: 32 B x the records of block + 2 x reach either side (%d of %d views, + 12 %%)" % (held_views, V), 1.12 * local_kept * 32, "k_shard_retire (keep flags) -> ch_kept")
+    add("chain", "viewing rays of every target / own end point (released after the chain)", V * (n_tgt + S) * 32, "chain_upload_tables (k_tgt_rays)")
+    add("chain", "bit rows (ring of 10 views), row counters + row starts of all views (released)", 10 * n_tbm * S * W64 * 8 / W + 2 * V * S * N * 4, "chain_assign_arenas")
+    cand_cap = 1.25 * cand_view / W
+    add("chain", "candidate store + window scratch + stage-1 ring of 10 views, 1/W of every view (released)", cand_cap * 44 + 10 * cand_cap * 24, "chain_reserve_candidates")
+    slot_records = int(2.2 * kept_view / W) + 1024           # (a rank's range of segments holds up to twice its share)
+    slot_bytes = 32 + (S // W + 1) * 12 + slot_records * 32
+    ring = window + 18
+    add("chain", "send + gathered slots: ring of %d views x %d ranks, %.0f MB slots (released)" % (ring, W, slot_bytes / 2**20), ring * (W + 1) * slot_bytes, "l3d_chain_sharded.hip:l3d_shard_chain_run (ring mode)")
+    add("products", "key blocks: 2 x 8 B keys + flag + position per slot, bounded (released)", min(1 << 28, 2 * local_kept + 1) * 24, "l3d_products.hip:build_products (ProdBlock)")
+    add("after", "potential correspondences of the rows held (%d views): 4 B x 2 per local record (bound) + row starts of all segments" % row_views, 2 * local_kept * 4 + nd * 8, "build_products (pot_tgt, pot_start)")
+    add("after", "best references of all segments, hypotheses (96 B) + scores + indices of the views held (%d)" % held_views, nd * 12 + held_views * S * 112, "l3d_products_hypotheses")
+    add("fill", "flags (1 B per local table entry), decision words (2^26 x 8 B), one block of candidates (2^27 x 20 B)", 2 * row_views * kept_view + (1 << 26) * 8 + (1 << 27) * 20, "l3d_affinity.hip:affinity_fill_core")
+    add("fill", "first-touch minima of all hypotheses, own + gathered (8 B x (W + 2)), passed candidates own + gathered (12 B x 2)", n_hyp * 8 * (W + 2) + passed_all * 24, "l3d_affinity_fill_sharded")
+    add("finish", "affinity list (24 B per passed candidate) + its clustering copies (x 4), hypothesis table of the scene (96 B)", passed_all * 24 * 5 + n_hyp * 100, "affinity_number_edges, l3d_rdd.hip, l3d_linefit.hip")
+    idx = dict(arena_records_per_rank=1.12 * local_kept, table_entries_per_rank=2 * local_kept, fill_candidates_per_rank=fill_cand_view * block, fill_block_candidates=float(1 << 27),
+               affinity_entries_job=2 * passed_all, hypotheses_job=n_hyp, kept_records_job=kept_view * V)
+    return rows, idx, dict(chain_views=V, held_views=held_views, kept_view=kept_view, cand_view=cand_view)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=2048)
@@ -96,9 +135,9 @@ def main():
     ap.add_argument("--neighbors", type=int, default=24)
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--kept", type=float, nargs="+", default=[0.025, 0.25, 0.48])
-    ap.add_argument("--mode", default="partition", choices=["partition", "segments"])
+    ap.add_argument("--mode", default="partition", choices=["partition", "segments", "segpart"])
     a = ap.parse_args()
-    fn = plan_partition if a.mode == "partition" else plan_segments
+    fn = dict(partition=plan_partition, segments=plan_segments, segpart=plan_segpart)[a.mode]
     plans = [fn(a.views, a.segments, a.neighbors, a.world, k) for k in a.kept]
     print("| per rank (%s), %d views x %d segments x %d neighbours, %d ranks | " % (a.mode, a.views, a.segments, a.neighbors, a.world) + " | ".join("kept %.1f %%" % (100 * k) for k in a.kept) + " | where |")
     print("|---|" + "---|" * (len(a.kept) + 1))

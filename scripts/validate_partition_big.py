@@ -2,6 +2,7 @@
 """BASELINE configs[4]'s per-view shape as a PARTITIONED job, validated on one GPU:
     python3 scripts/validate_partition_big.py ref  VIEWS SEGMENTS NEIGHBOURS out.json       # the one chain on one GPU: per-view sha256 of every kept list, affinity list, lines
     python3 scripts/validate_partition_big.py part VIEWS SEGMENTS NEIGHBOURS ref.json [W] [warm-up views]
+    python3 scripts/validate_partition_big.py seg  VIEWS SEGMENTS NEIGHBOURS ref.json [W]                   # the segment-sharded run, partitioned (l3d_shard_chain_partition)
 `part`: W virtual ranks (threads of one process, all-gather through the host) run l3d_line3d_partition_run + finish_sharded; every rank hashes the kept
 lists of ITS block's views straight out of its arena (together: every view of the scene), and its affinity list / lines after the collective finish.
 Everything must equal the `ref` run byte for byte.  The ranks' CHAINS run one after the other (a rank starts when its predecessor reaches the first
@@ -72,7 +73,7 @@ def main():
     W = int(sys.argv[6]) if len(sys.argv) > 6 else 8
     warm = int(sys.argv[7]) if len(sys.argv) > 7 else -1
     from helpers import thread_exchange
-    make, calls = thread_exchange(W)
+    make, calls = thread_exchange(W, on_device=(mode == "seg"), timeout=900.0)
     gates = [threading.Event() for _ in range(W + 1)]
     gates[0].set()
     peak = [0.0]
@@ -89,26 +90,36 @@ def main():
             return inner(user, view, send, recv, slot_bytes, w, stream)
         return exchange
     ls = []
+    seg = mode == "seg"
+    slot_records = int(float(os.environ.get("L3D_VALIDATE_SLOT", "2.2")) * max(k[0] for k in ref["kept"]) / W) + 4096 if seg else 0      # (a rank's segment range of the densest view: ranges are not equally rich)
     for r in range(W):
         l = Line3D("", matchingNeighbors=N)
         load_scene(l, scene)
         l.prepare()
-        if os.environ.get("L3D_VALIDATE_ARENA"):          # a fixed arena per rank instead of growth by doubling (eight ranks share ONE GPU here): what the rank's
+        if seg:                                              # this rank's arena: its block and 2 x reach (= the neighbour count on these scenes) either side
+            b0, b1 = (V * r) // W, (V * (r + 1)) // W
+            l.context().set_chain_capacities(0, int(1.02 * sum(ref["kept"][k][0] for k in range(max(0, b0 - N), min(V, b1 + N)))) + 1000000)
+        elif os.environ.get("L3D_VALIDATE_ARENA"):          # a fixed arena per rank instead of growth by doubling (eight ranks share ONE GPU here): what the rank's
             # views hold in the reference run -- its block, `reach2` views taken over in front (a warm re-run) and `reach2` views behind -- + 2 %
             reach2 = N
             b0, b1 = (V * r) // W, (V * (r + 1)) // W
             lo, hi = max(0, b0 - max(reach2, warm if warm >= 0 else 3 * N)), min(V, b1 + reach2)
             l.context().set_chain_capacities(0, int(1.02 * sum(ref["kept"][k][0] for k in range(lo, hi))) + 1000000)
         ls.append(l)
-    out = dict(shape=[V, S, N], world=W, warmup_views=warm, hbm_after_prepare_gb=hbm_used_gb())
+    out = dict(shape=[V, S, N], world=W, mode=mode, warmup_views=warm, slot_records=slot_records, hbm_after_prepare_gb=hbm_used_gb())
     bad, errors, infos, res = [], [], [None] * W, [None] * W
     t_run = [0.0] * W
 
     def run(r):
         try:
-            gates[r].wait()
+            if not seg:
+                gates[r].wait()
             t0 = time.perf_counter()
-            ok = ls[r].partition_run(r, W, gated(r), None, warm)
+            if seg:         # (all ranks at once: every rank works on its 1/W of every view's source segments)
+                ls[r].shard_run(r, W, slot_records, make(r), None, commit="partition")
+                ok = True
+            else:
+                ok = ls[r].partition_run(r, W, gated(r), None, warm)
             t_run[r] = time.perf_counter() - t0
             assert ok, "verdict 1"
             infos[r] = ls[r].partition_info()
@@ -125,6 +136,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             errors.append((r, repr(e)))
             gates[min(W, r + 1)].set()
+            make.abort()                                # (the other ranks' next exchange fails instead of waiting for this one)
     th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
     t0 = time.perf_counter()
     for x in th:

@@ -160,15 +160,17 @@ def oracle_view_slice(scene, lists, vid, seg_lo, seg_hi, N, threads=None, refere
 
 
 # ---- an all-gather for virtual ranks that run as threads of one process on one GPU (block mode tests, scripts/soak_blocks.py) --------------
-def thread_exchange(world):
+def thread_exchange(world, on_device=False, timeout=600.0):
     """An all-gather for `world` virtual ranks that run as threads of this process on one GPU (the l3d_exchange_fn contract: rank r's
-    `slot_bytes` land at recv_block + r * slot_bytes on every rank): through host buffers, two barriers per call."""
+    `slot_bytes` land at recv_block + r * slot_bytes on every rank): through host buffers, two barriers per call.  on_device: the ranks share
+    the process and the device, so every rank copies the others' send slots device to device (big slots: scripts/validate_partition_big.py).
+    A rank that waits longer than `timeout` seconds for the others breaks the barrier: every exchange fails, nobody hangs."""
     import ctypes as C
     import threading
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-    barrier = threading.Barrier(world)
+    barrier = threading.Barrier(world, timeout=timeout)
     bufs = [None] * world
     calls = []
 
@@ -178,6 +180,18 @@ def thread_exchange(world):
                 assert w == world
                 if hip.hipStreamSynchronize(stream):
                     return 1
+                if on_device:
+                    bufs[rank] = send
+                    barrier.wait()
+                    for q in range(world):
+                        if hip.hipMemcpy(recv + q * slot_bytes, bufs[q], slot_bytes, 3):   # device -> device
+                            return 3
+                    if hip.hipStreamSynchronize(None):        # (a device-to-device hipMemcpy may return before it is done: the null stream's work is, after this)
+                        return 4
+                    barrier.wait()
+                    if rank == 0:
+                        calls.append((view, slot_bytes))
+                    return 0
                 b = C.create_string_buffer(slot_bytes)
                 if hip.hipMemcpy(b, send, slot_bytes, 2):                    # device -> host
                     return 2
@@ -194,6 +208,7 @@ def thread_exchange(world):
                 barrier.abort()
                 return 9
         return exchange
+    make.abort = barrier.abort
     return make, calls
 
 

@@ -30,7 +30,7 @@ def _reference(scene, N, diffusion):
     return out
 
 
-def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=False):
+def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=False, arena_of=None):
     from line3d_amd.pipeline import Line3D, load_scene
     make, calls = thread_exchange(W)
     ls, verdicts, errors = [], [None] * W, []
@@ -41,6 +41,8 @@ def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=Fals
         l.prepare()
         for k, v in (options or {}).items():
             l.context().set_option(k, v)
+        if arena_of and r in arena_of:          # (the first guess of this rank's kept arena, in records)
+            l.context().set_chain_capacities(0, arena_of[r])
         ls.append(l)
     shares = [None] * W
 
@@ -135,6 +137,24 @@ def test_segment_sharded_run_partitioned_equals_the_one_chain(W, diffusion):
         tags = [c[0] for c in calls]
         assert -1 not in tags and -2 not in tags and -4 not in tags and -5 not in tags and -6 not in tags       # no digests, no blocks, no hand-over: nothing speculated
         assert tags.count(-7) == 1 and tags.count(-9) == 1
+    finally:
+        for l in ls:
+            l.close()
+
+
+def test_segment_sharded_partitioned_run_grows_one_ranks_arena_on_every_rank():
+    """one rank's arena far too small: its verdict is no shared one by itself (every rank keeps other views) -- the ranks exchange it, all run again,
+    the rank with more room"""
+    from line3d_amd.synth import make_scene
+    V, S, N, W = 60, 160, 6, 3
+    scene = make_scene(V, S, N, seed=11)
+    ref = _reference(scene, N, False)
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, False, segments=True, arena_of={1: 1000})
+    try:
+        assert not errors, errors
+        _check_against(ref, scene, ls, shares)
+        views_exchanged = [c[0] for c in calls if c[0] >= 0]
+        assert len(views_exchanged) == 2 * len(set(views_exchanged))          # every view twice: two attempts, on every rank
     finally:
         for l in ls:
             l.close()
