@@ -18,8 +18,10 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-# (file, kept matches of the whole run): configs[2]'s scene, and two shapes of other proportions (neighbour counts 8 and 14, 1000 and 2500 segments)
-@pytest.mark.parametrize("name,kept_total", [("config3_matching.npz", 35898004), ("shape_200x1000x8_matching.npz", None), ("shape_120x2500x14_matching.npz", None)])
+# (file, kept matches of the whole run): configs[2]'s scene, two shapes of other proportions (neighbour counts 8 and 14, 1000 and 2500 segments), and
+# configs[4]'s per-view shape -- 4000 segments x 24 neighbours -- on 26 views (the first count where a view has views outside its neighbourhood)
+@pytest.mark.parametrize("name,kept_total", [("config3_matching.npz", 35898004), ("shape_200x1000x8_matching.npz", None), ("shape_120x2500x14_matching.npz", None),
+                                             ("shape_26x4000x24_matching.npz", 76695824)])
 def test_every_kept_list_and_median_equals_the_oracles(name, kept_total):
     path = os.path.join(GOLDEN_DIR, name)
     if not os.path.exists(path):
