@@ -363,6 +363,9 @@ long long l3d_shard_chain_arena_needed(l3d_shard_chain* chain);
  * speculation: exact on every scene, the chain's work split 1/world per view, the kept records and the table split by view block.
  * l3d_products_hypotheses and l3d_affinity_fill_sharded follow as there.  (l3d_line3d_shard_run: commit = 3.) */
 int l3d_shard_chain_partition(l3d_shard_chain* chain, int own_begin, int own_end);
+/* the keep set of l3d_shard_chain_partition as a function of the schedule alone (host logic, no context): keep[k] = 1 for the chain views a rank that
+ * owns [own_begin, own_end) retires; *reach (may be NULL) = the largest chain distance between a view and one of its neighbours */
+int l3d_partition_keep_views(const l3d_chain_view* views, int n_views, int own_begin, int own_end, unsigned char* keep, int* reach);
 
 /* ---- Line3D::matchViews sharded by BLOCKS OF VIEWS over the ranks, speculatively, with exact verification ----------------------
  * (line3D.cc:620-648 is a chain over views: the kept matches of a view become candidates of its later neighbours, :806,838-872.)

@@ -1089,31 +1089,42 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
 // matches and medians of the kept views -- the state l3d_match_chain_partition leaves, computed WITHOUT speculation (a scene whose chain never
 // forgets a cold start -- the box scene at 4000 segments x 24 neighbours keeps half of its candidates and does not within 120 views -- gets the
 // segment-sharded run's speed and the partition's memory).  l3d_affinity_fill_sharded follows as there.
+int l3d_partition_keep_views(const l3d_chain_view* views, int nv, int own_begin, int own_end, unsigned char* keep, int* reach_out)
+{
+    // (host logic only: no context, no device -- tests/test_partition_keep_cpu.py runs it without a GPU)
+    if (!views || !keep || nv < 0 || own_begin < 0 || own_end > nv || own_begin > own_end) return L3D_ERR_INVALID;
+    std::vector<std::pair<unsigned, int>> idx((size_t)nv);
+    for (int k = 0; k < nv; ++k) idx[(size_t)k] = { views[k].view_id, k };
+    std::sort(idx.begin(), idx.end());
+    auto chain_of = [&](unsigned id) { auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(id, -1)); return it != idx.end() && it->first == id ? it->second : -1; };
+    int reach = 1;
+    for (int k = 0; k < nv; ++k)
+        for (int q = 0; q < views[k].N; ++q) { const int j = views[k].local2global ? chain_of(views[k].local2global[q]) : -1; if (j >= 0) reach = std::max(reach, std::abs(j - k)); }
+    std::fill(keep, keep + nv, (unsigned char)0);
+    for (int k = std::max(0, own_begin - 2 * reach); k < std::min(nv, own_end + 2 * reach); ++k) keep[k] = 1;
+    for (int k = 0; k < nv; ++k) {
+        if (views[k].n_tbm != 0 || views[k].n_sources == 0) continue;          // an early-return view (cudawrapper.cu:877-878) ...
+        keep[k] = 1;
+        for (int q = 0; q < views[k].n_sources; ++q) {
+            const int si = views[k].source_index[q];                            // ... its sources, whose lists hold the records that point at it ...
+            if (si >= 0 && si < nv) keep[si] = 1;
+            const int av = chain_of((unsigned)views[k].source_cam[q]);          // ... and the view its LOCAL camera number names (line3D.cc:861-865)
+            if (av >= 0) keep[av] = 1;
+        }
+    }
+    if (reach_out) *reach_out = reach;
+    return L3D_OK;
+}
+
 int l3d_shard_chain_partition(l3d_shard_chain* h, int own_begin, int own_end)
 {
     if (!h) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
     const int nv = h->n_views;
     if (own_begin < 0 || own_end > nv || own_begin > own_end) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_partition: bad view range");
-    std::vector<std::pair<unsigned, int>> idx((size_t)nv);
-    for (int k = 0; k < nv; ++k) idx[(size_t)k] = { h->views[k].view_id, k };
-    std::sort(idx.begin(), idx.end());
-    auto chain_of = [&](unsigned id) { auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(id, -1)); return it != idx.end() && it->first == id ? it->second : -1; };
-    int reach = 1;
-    for (int k = 0; k < nv; ++k)
-        for (int q = 0; q < h->views[k].N; ++q) { const int j = h->views[k].local2global ? chain_of(h->views[k].local2global[q]) : -1; if (j >= 0) reach = std::max(reach, std::abs(j - k)); }
     h->keep.assign((size_t)nv, 0);
-    for (int k = std::max(0, own_begin - 2 * reach); k < std::min(nv, own_end + 2 * reach); ++k) h->keep[(size_t)k] = 1;
-    for (int k = 0; k < nv; ++k) {
-        if (h->views[k].n_tbm != 0 || h->views[k].n_sources == 0) continue;
-        h->keep[(size_t)k] = 1;
-        for (int q = 0; q < h->views[k].n_sources; ++q) {
-            const int si = h->views[k].source_index[q];
-            if (si >= 0 && si < nv) h->keep[(size_t)si] = 1;
-            const int av = chain_of((unsigned)h->views[k].source_cam[q]);
-            if (av >= 0) h->keep[(size_t)av] = 1;
-        }
-    }
+    int reach = 1;
+    if (int rc = l3d_partition_keep_views(h->views, nv, own_begin, own_end, h->keep.data(), &reach)) return fail(c, rc, "l3d_shard_chain_partition: bad schedule");
     h->partition = true; h->part_own0 = own_begin; h->part_own1 = own_end; h->part_reach = reach;
     return L3D_OK;
 }
