@@ -687,12 +687,12 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     // holds window + batch + 2 view blocks; a batch of older views is retired into the compact kept arena (k_shard_retire) before its
     // blocks are reused.  L3D_SLOT_RING=0 keeps every block (what the recording tests read back through l3d_shard_chain_gathered).
     constexpr int kRetireBatch = 16;
-    const int ring_views = h->window + kRetireBatch + 2;
+    const int ring_views = std::min(h->window + kRetireBatch + 2, std::max(1, h->n_views));
     const size_t gathered_budget = (size_t)8 << 30;
     h->ring_mode = !cb && c->opt.slot_ring != 0 && ring_views < h->n_views && (c->opt.slot_ring > 0 || (size_t)h->n_views * block > gathered_budget);
     if (h->partition) {      // a partitioned job retires by definition: what a rank does not keep is gone when its ring block is reused
-        if (cb || ring_views >= h->n_views) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_run: a partitioned run needs more views than the ring of gathered blocks holds and no host callback");
-        h->ring_mode = true;
+        if (cb) return fail(c, L3D_ERR_UNSUPPORTED, "l3d_shard_chain_run: a partitioned run hands nothing to the host (cb must be NULL)");
+        h->ring_mode = true;  // (a schedule that reads further back than it has views -- scattered neighbourhoods -- gets a ring that never wraps: all retired at the end)
     }
     h->geom.ring = h->ring_mode ? ring_views : std::max(1, h->n_views);
     const int send_ring = h->ring_mode ? ring_views : h->n_views;            // (a slot is read by its exchange only)

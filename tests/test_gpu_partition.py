@@ -13,11 +13,11 @@ from helpers import assert_lines_equal, thread_exchange
 pytestmark = pytest.mark.gpu
 
 
-def _reference(scene, N, diffusion):
+def _reference(scene, N, diffusion, loader=None):
     from line3d_amd.pipeline import Line3D, load_scene
     ref = Line3D("", matchingNeighbors=N)
     ref.keep_view_matches(True)
-    load_scene(ref, scene)
+    (loader or load_scene)(ref, scene)
     ref.prepare()
     ref.match_views()
     lists = {v["id"]: ref.view_matches(v["id"]) for v in scene.views}
@@ -30,14 +30,14 @@ def _reference(scene, N, diffusion):
     return out
 
 
-def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=False, arena_of=None):
+def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=False, arena_of=None, loader=None):
     from line3d_amd.pipeline import Line3D, load_scene
     make, calls = thread_exchange(W)
     ls, verdicts, errors = [], [None] * W, []
     for r in range(W):
         l = Line3D("", matchingNeighbors=N)
         l.keep_view_matches(True)
-        load_scene(l, scene)
+        (loader or load_scene)(l, scene)
         l.prepare()
         for k, v in (options or {}).items():
             l.context().set_option(k, v)
@@ -67,7 +67,7 @@ def _run_partitioned(scene, N, W, warmup, diffusion, options=None, segments=Fals
 
 
 def _check_against(ref, scene, ls, shares):
-    ids = [v["id"] for v in scene.views]
+    ids = sorted(v["id"] for v in scene.views)               # (the dense map: views in id order)
     for r, l in enumerate(ls):
         info, prod = shares[r]
         assert info["world"] == len(ls) and info["rank"] == r
@@ -137,6 +137,26 @@ def test_segment_sharded_run_partitioned_equals_the_one_chain(W, diffusion):
         tags = [c[0] for c in calls]
         assert -1 not in tags and -2 not in tags and -4 not in tags and -5 not in tags and -6 not in tags       # no digests, no blocks, no hand-over: nothing speculated
         assert tags.count(-7) == 1 and tags.count(-9) == 1
+    finally:
+        for l in ls:
+            l.close()
+
+
+@pytest.mark.parametrize("segments", [False, True], ids=["blocks of views", "segments of every view"])
+def test_partitioned_jobs_on_scattered_non_mutual_neighbourhoods(segments):
+    """Cameras in no order, ragged views, neighbours picked by the library from shared world points (line3D.cc:476-549): not mutual, up to the whole
+    scene apart in processing order -- reach is then most of the chain and every rank keeps most views; both partitioned jobs must still be the one chain."""
+    from line3d_amd.pipeline import load_scene_worldpoints
+    from line3d_amd.synth import make_scene_scattered
+    V, S, N, W = 36, 260, 8, 3
+    scene = make_scene_scattered(V, S, seed=77)
+    ref = _reference(scene, N, False, loader=load_scene_worldpoints)
+    assert len(ref["lines"]) > 5 and len(ref["A"]) > 200
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, False, segments=segments, loader=load_scene_worldpoints)
+    try:
+        assert not errors, errors
+        assert verdicts == [True] * W
+        _check_against(ref, scene, ls, shares)
     finally:
         for l in ls:
             l.close()
