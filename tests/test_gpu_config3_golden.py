@@ -51,3 +51,66 @@ def test_every_kept_list_and_median_equals_the_oracles(name, kept_total):
             assert total == kept_total
     finally:
         l.close()
+
+
+def test_config3_as_a_partitioned_job_of_8_ranks_equals_the_oracles_lists():
+    """BASELINE configs[2] (512 x 2000 x 12 on 8 ranks) as the PARTITIONED segment-sharded job (l3d_shard_chain_partition, DESIGN.md section 6 iv): eight
+    virtual ranks (threads on the one GPU of the test box, device-to-device all-gather), every rank working on 1/8 of every view's source segments and
+    keeping only its block of 64 views +- 2 x reach.  Each rank's block, straight out of its arena, against the ORACLE-ONLY golden (sha256 of every kept
+    list, every median: line3D.cc:620-648, cudawrapper.cu:1058-1110); then the collective finish: one affinity list and one set of lines on every rank,
+    equal to the single chain's."""
+    import threading
+    from helpers import assert_lines_equal, thread_exchange
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    golden = np.load(os.path.join(GOLDEN_DIR, "config3_matching.npz"))
+    V, S, N, seed = (int(x) for x in golden["shape"])
+    W = 8
+    scene = make_scene(V, S, N, seed=seed)
+    one = Line3D("", matchingNeighbors=N)
+    load_scene(one, scene)
+    one.compute3Dmodel(False)
+    want_A, want_nodes = one.affinity()
+    want_A = want_A.copy()
+    want_lines = one.getResult()
+    one.close()
+    make, calls = thread_exchange(W, on_device=True, timeout=300.0)
+    ls, errors, blocks = [], [], [None] * W
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        ls.append(l)
+
+    def run(r):
+        try:
+            ls[r].shard_run(r, W, 10 * S * N // W + 1024, make(r), None, commit="partition")
+            info = ls[r].partition_info()
+            blocks[r] = info["own"]
+            for k in range(info["own"][0], info["own"][1]):
+                m, med = ls[r].view_matches(scene.views[k]["id"])
+                assert len(m) == int(golden["kept_n"][k]) and _sha(m) == str(golden["kept_sha256"][k]), "rank %d view %d: kept list differs from the oracle's" % (r, k)
+                if int(golden["kept_n"][k]) and k + 1 < V:
+                    assert np.float32(med) == golden["median"][k], "rank %d view %d: median" % (r, k)
+            ls[r].finish_sharded(False)
+        except BaseException as e:      # noqa: BLE001
+            errors.append((r, repr(e)))
+            make.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    try:
+        assert not errors, errors
+        assert blocks == [(V * r // W, V * (r + 1) // W) for r in range(W)]
+        tags = [c[0] for c in calls]
+        assert -1 not in tags and -2 not in tags and -4 not in tags and -5 not in tags          # nothing speculated, no block and no table piece travels
+        for r in (0, 3, 7):
+            A, n_nodes = ls[r].affinity()
+            assert n_nodes == want_nodes and A.tobytes() == want_A.tobytes(), "rank %d: affinity list" % r
+            assert_lines_equal(ls[r].getResult(), want_lines, 0.0)
+    finally:
+        for l in ls:
+            l.close()
