@@ -979,12 +979,48 @@ int l3d_shard_chain_info(l3d_shard_chain* h, size_t* cand_cap, int* slot_records
 // rank's device from the gathered slots of a finished, successful l3d_shard_chain_run: all views' kept records go into one arena in the
 // order of the unsharded run, then the very builder of the single-GPU chain runs on it.  Every rank may call it (each then holds the
 // full products and can run greedy selection / affinity fill / clustering); none hands a kept list to the host.
+static int shard_products_local(l3d_shard_chain* h, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, ProductsPart* part_out);
+
 int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot)
 {
     if (!h) return L3D_ERR_INVALID;
     l3d_ctx* c = h->c;
     if (!map || !summary) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: bad argument");
-    if (!h->gathered || h->outcome[0]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: no finished run without overflow on this chain");
+    if (!h->gathered || h->outcome[0]) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: no finished run without overflow on this chain");     // (a verdict every rank shares)
+    if (!h->partition) return shard_products_local(h, map, summary, n_pot, nullptr);
+    // partitioned: whatever this rank fails in on its own travels with ONE status exchange (tag -3) that every rank enters -- the ranks go on to the
+    // collective finish together or not at all
+    ProductsPart part;
+    int64_t n_local = 0;
+    const int rc = shard_products_local(h, map, summary, &n_local, &part);
+    std::string err_local;
+    if (rc) { std::lock_guard<std::mutex> lk(c->err_mu); err_local = c->err; }
+    hipStream_t st = c->stream;
+    long long w[2] = { rc ? -(long long)std::abs(rc) : (long long)n_local, 0 };
+    hipError_t e = hipMemcpyAsync(h->part_status, w, 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) (void)hipMemsetAsync(h->part_status, 0xff, 16, st);
+    if (!h->part_exchange || h->part_exchange(h->part_user, -3, h->part_status, h->part_status + 256, 256, h->world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: the exchange of the status words failed");
+    if (rc) return fail(c, rc, err_local);
+    part.n_pot_all = 0;
+    for (int r = 0; r < h->world; ++r) {
+        long long x = 0;
+        HIPCHK(c, hipMemcpyAsync(&x, h->part_status + 256 * ((size_t)r + 1), 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (x < 0) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: rank " + std::to_string(r) + " failed (code " + std::to_string(-x) + ") while building its rows of the products");
+        part.n_pot_all += x;
+    }
+    c->products.part = part;
+    c->products.n_pot = n_local;
+    c->products.valid = true;
+    if (n_pot) *n_pot = n_local;
+    return L3D_OK;
+}
+
+// the rank-local part: totals, (partitioned: release of the chain's scratch,) the builder of the single-GPU chain on this rank's arena
+static int shard_products_local(l3d_shard_chain* h, const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, ProductsPart* part_out)
+{
+    l3d_ctx* c = h->c;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int nv = h->n_views;
@@ -1042,28 +1078,10 @@ int l3d_shard_chain_products(l3d_shard_chain* h, const l3d_dense_map* map, l3d_c
                 h->gathered = nullptr;
             }
             const int rc = build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, reinterpret_cast<const char*>(h->keep.data()));
-            // one status exchange (tag -3), entered by every rank whatever happened to it: the ranks go on to the collective finish together or not at all
-            std::string err_local;
-            if (rc) { std::lock_guard<std::mutex> lk(c->err_mu); err_local = c->err; }
-            long long w[2] = { rc ? -(long long)std::abs(rc) : (long long)n_local, 0 };
-            hipError_t e = hipMemcpyAsync(h->part_status, w, 16, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) (void)hipMemsetAsync(h->part_status, 0xff, 16, st);
-            if (!h->part_exchange || h->part_exchange(h->part_user, -3, h->part_status, h->part_status + 256, 256, h->world, (void*)st)) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: the exchange of the status words failed");
-            if (rc) return fail(c, rc, err_local);
+            if (rc) return rc;
             c->part_arena_seen = std::max(c->part_arena_seen, (size_t)total + (size_t)total / 8 + 65536);
-            part.n_pot_all = 0;
-            for (int r = 0; r < h->world; ++r) {
-                long long x = 0;
-                HIPCHK(c, hipMemcpyAsync(&x, h->part_status + 256 * ((size_t)r + 1), 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(c, hipStreamSynchronize(st));
-                if (x < 0) return fail(c, L3D_ERR_HIP, "l3d_shard_chain_products: rank " + std::to_string(r) + " failed (code " + std::to_string(-x) + ") while building its rows of the products");
-                part.n_pot_all += x;
-            }
-            c->products.part = part;
-            c->products.n_pot = n_local;
-            c->products.valid = true;
             if (n_pot) *n_pot = n_local;
+            if (part_out) *part_out = part;
             memcpy(c->ch_pin_res.as<ChainResult>(), hres.data(), (size_t)nv * sizeof(ChainResult));      // (what l3d_chain_kept_list reads)
             return L3D_OK;
         }
