@@ -162,6 +162,52 @@ def test_partitioned_jobs_on_scattered_non_mutual_neighbourhoods(segments):
             l.close()
 
 
+def test_segment_sharded_partitioned_run_with_a_broken_exchange_fails_on_every_rank():
+    """the all-gather of one rank breaks in the middle of the run (what a lost peer is to RCCL): every rank comes back with an error, nobody waits in
+    the two exchanges that follow the run (arena verdicts, status words of the products)"""
+    from line3d_amd.capi import L3DError
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    V, S, N, W = 60, 160, 6, 3
+    scene = make_scene(V, S, N, seed=11)
+    make, calls = thread_exchange(W, timeout=60.0)
+    ls, outcome = [], [None] * W
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=N)
+        load_scene(l, scene)
+        l.prepare()
+        ls.append(l)
+
+    def breaking(r):
+        inner = make(r)
+
+        def exchange(user, view, send, recv, slot_bytes, w, stream):
+            if r == 1 and view == 20:
+                make.abort()
+                return 1
+            return inner(user, view, send, recv, slot_bytes, w, stream)
+        return exchange
+
+    def run(r):
+        try:
+            ls[r].shard_run(r, W, 4096, breaking(r), None, commit="partition")
+            outcome[r] = "ok"
+        except L3DError as e:
+            outcome[r] = "error: %s" % e
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=120)
+    try:
+        assert not any(x.is_alive() for x in th), "a rank is still waiting"
+        assert all(o and o.startswith("error") for o in outcome), outcome
+        assert "exchange" in outcome[1]
+    finally:
+        for l in ls:
+            l.close()
+
+
 def test_segment_sharded_partitioned_run_grows_one_ranks_arena_on_every_rank():
     """one rank's arena far too small: its verdict is no shared one by itself (every rank keeps other views) -- the ranks exchange it, all run again,
     the rank with more room"""
