@@ -46,7 +46,7 @@ struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
 static_assert(sizeof(SlotHeader) == 32, "slot header");
 
 // ring: view blocks the gathered buffer holds (view k lives in block k % ring); n_views when every block is kept
-struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off; int seg_cap, slot_records, world, ring; };
+struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off, cam_off; int seg_cap, slot_records, world, ring; };   // cam_off: 0 = the slot carries no side array of target cameras
 
 // reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
 // (blockIdx.y = source * world + rank)
@@ -58,8 +58,10 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
+    const unsigned* cams = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;     // (dense scenes: 4 bytes per record decide, 1 record in N is read)
     const int cam = src_cam[src];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (cams && cams[i] != view_id) continue;
         const Match m = kept[i];
         if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) atomicAdd(&rowcnt[m.segID2 * N + cam], 1);
     }
@@ -68,8 +70,8 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
 // Both writers of the combined candidate arrays in one launch (they are independent: stage-1 candidates go to the rows of the
 // cameras to be matched, reverse matches to the rows of the source cameras): the first `blocks_move` workgroups copy the
 // stage-1 candidates of the rank's rows (a wave per row), the others scatter the reverse matches
-// (k_exist_scatter_slots, 16 workgroups per (source view, rank) list).
-__global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
+// (k_exist_scatter_slots, wps workgroups per (source view, rank) list).
+__global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                      const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
                                                      const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
                                                      const int* __restrict__ src_cam, unsigned view_id, int N, int S, int s0, int s1,
@@ -85,14 +87,16 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, const int*
         for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
         return;
     }
-    const int e = (int)blockIdx.x - blocks_move, list = e / 16, bx = e % 16;
+    const int e = (int)blockIdx.x - blocks_move, list = e / wps, bx = e % wps;
     const int src = list / g.world, r = list % g.world;
     const unsigned char* slot = G + ((size_t)(src_index[src] % g.ring) * g.world + r) * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
+    const unsigned* cams = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;
     const int cam = src_cam[src];
-    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += 16 * 256) {
+    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += wps * 256) {
+        if (cams && cams[i] != view_id) continue;
         const Match m = kept[i];
         if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) {
             const int row = m.segID2 * N + cam;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     if (tid == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
     int* bpos = reinterpret_cast<int*>(slot + g.bpos_off) + yl;              // (position in this slot's records; -1: the segment kept nothing)
     if (h.overflow) { if (tid == 0) *bpos = -1; return; }
-    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best);
+    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best, g.cam_off ? reinterpret_cast<unsigned*>(slot + g.cam_off) : nullptr);
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -388,7 +392,11 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     h->geom.best_off = sizeof(SlotHeader);
     h->geom.bpos_off = h->geom.best_off + (size_t)h->geom.seg_cap * 8;
     h->geom.rec_off = salign(h->geom.bpos_off + (size_t)h->geom.seg_cap * 4, 32);
-    h->geom.slot_bytes = salign(h->geom.rec_off + (size_t)slot_records * sizeof(Match), 256);
+    // dense scenes (slots of 65 536 records and more): a side array of the records' target cameras travels with the slot -- the two scans every later
+    // neighbour makes of it (k_exist_count_slots, k_place_slots) read 4 bytes per record instead of 32; + 12.5 % on the all-gather.  Measured on one
+    // emulated rank of eight at 64 x 4000 x 24 (profiles/r5_emulated_rank_64x4000x24_w8_partition.txt)
+    h->geom.cam_off = slot_records >= c->opt.slot_cams_min ? salign(h->geom.rec_off + (size_t)slot_records * sizeof(Match), 32) : 0;
+    h->geom.slot_bytes = salign((h->geom.cam_off ? h->geom.cam_off + (size_t)slot_records * 4 : h->geom.rec_off + (size_t)slot_records * sizeof(Match)), 256);
     *slot_bytes = h->geom.slot_bytes;
 
     auto bail = [&](int rc) { delete h; return rc; };
@@ -497,19 +505,23 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     unsigned char* slot = reinterpret_cast<unsigned char*>(send_slot);
     int mmax = 0;
     // this rank's kernels of view k: the same sequence whether it is launched call by call or replayed as a graph
+    // workgroups per (source view, rank) list of the two scans of the sources' slots: 16 for the lists of a sparse scene (a few thousand records: 5 steps
+    // per thread), one per 4096 records of the slot's capacity on a dense one -- 650 k records per slot at 4000 segments x 24 neighbours were 160
+    // dependent loads per thread (measured on one emulated rank of eight, 64 x 4000 x 24: exist + cand_move 47 -> see profiles/r5_emulated_rank_*)
+    const int wps = std::max(16, std::min(256, h->geom.slot_records / 4096));
     auto issue = [&]() {
         if (v.n_sources) {
             ProfScope p(c, "exist");
-            hipLaunchKernelGGL(k_exist_count_slots, dim3(16, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
+            hipLaunchKernelGGL(k_exist_count_slots, dim3(wps, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
         }
         // row starts of this rank's rows only (+ zeroed scatter cursors, segment order); row_start[nrow] = their total
         { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
         {
             ProfScope p(c, "cand_move");
             const int blocks_move = ((d.s1 - d.s0) * v.n_tbm + 3) / 4;
-            const int blocks = blocks_move + 16 * v.n_sources * h->world;
+            const int blocks = blocks_move + wps * v.n_sources * h->world;
             if (blocks > 0)
-                hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, pa.tbm, v.n_tbm, d.rowA,
+                hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, wps, pa.tbm, v.n_tbm, d.rowA,
                                    c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                    c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                    h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
@@ -955,9 +967,14 @@ int l3d_exchange_local(void*, int, const void* send_slot, void* recv_block, size
     return (int)hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 // replay of a recorded run (user = device address of its gathered blocks): one rank of a world-W job measured on one GPU
-int l3d_exchange_replay(void* user, int view, const void*, void* recv_block, size_t slot_bytes, int world, void* stream)
+int l3d_exchange_replay(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream)
 {
     const size_t block = slot_bytes * (size_t)world;
+    if (view < 0) {      // a status-word exchange of a partitioned run (tag -3): the replayed rank alone, its peers report "nothing to report"
+        hipError_t e0 = hipMemsetAsync(recv_block, 0, block, (hipStream_t)stream);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return (int)e0;
+    }
     const hipError_t e = hipMemcpyAsync(recv_block, static_cast<const unsigned char*>(user) + (size_t)view * block, block, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) fprintf(stderr, "[l3d exchange_replay] view %d: hipMemcpyAsync(dst %p, src %p + %zu, %zu bytes): %s\n", view, recv_block, user, (size_t)view * block, block, hipGetErrorString(e));
     return (int)e;

@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--ahead", type=int, default=12)
     ap.add_argument("--no-commit", action="store_true", help="rank 0 without the host hand-over (what a non-committing rank with this range would take)")
     ap.add_argument("--device-commit", action="store_true", help="the replayed rank builds matchViews' products on its device from the gathered slots (no host hand-over)")
+    ap.add_argument("--partition", action="store_true", help="the replayed rank of a PARTITIONED job (l3d_shard_chain_partition): it retires its block of views only and builds its share of the "
+                                                             "products; pass 1 records without host bookkeeping")
+    ap.add_argument("--profile", action="store_true", help="after the timed replays: one more with every kernel bracketed, per-kernel ms of the rank")
+    ap.add_argument("--cand-cap", type=int, default=0, help="candidate capacity of every rank's chain (0: the library's first guess; a recording whose guess overflows cannot be replayed)")
+    ap.add_argument("--slot-records", type=int, default=0, help="kept matches one rank may produce for one view (0: distributed.default_slot_records; dense scenes need more)")
     args = ap.parse_args()
     import torch
     from line3d_amd.pipeline import Line3D, load_scene
@@ -33,12 +38,14 @@ def main():
     W = args.world
     scene = make_scene(args.views, args.segments, args.neighbors, seed=20260)
     dev = torch.device("cuda", 0)
-    slot_records = default_slot_records(args.segments, args.neighbors, W)
+    slot_records = args.slot_records or default_slot_records(args.segments, args.neighbors, W)
 
     def mk():
         l = Line3D("", matchingNeighbors=args.neighbors)
         load_scene(l, scene)
         l.prepare()
+        if args.cand_cap:
+            l.context().set_chain_capacities(args.cand_cap, 0)
         return l
 
     # pass 1: record
@@ -58,9 +65,10 @@ def main():
         torch.cuda.synchronize()
         for l in ls:
             l.shard_mark(k)
-        ls[0].shard_fetch(k)
+        if not args.partition:
+            ls[0].shard_fetch(k)
     for r, l in enumerate(ls):
-        l.shard_close(r == 0)
+        l.shard_close(r == 0 and not args.partition)
     kept = ls[0].stats()["kept"]
     for l in ls[1:]:
         l.close()
@@ -73,11 +81,21 @@ def main():
     for rep in range(args.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(), commit=("device" if args.device_commit else (R == 0 and not args.no_commit)))
+        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(),
+                    commit=("partition" if args.partition else "device" if args.device_commit else (R == 0 and not args.no_commit)))
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rep:
             print("world %d rank %d: %d views x %d segs: %.2f ms (%.1f us/view), kept %d (recorded %d), slot %d KB"
                   % (W, R, n_views, args.segments, dt * 1e3, dt / n_views * 1e6, int(l.stats()["kept"]), int(kept), slot_bytes // 1024))
+    if args.profile:       # one more replay with every kernel bracketed by HIP events (no graphs then): where the rank's time goes
+        ctx = l.context()
+        ctx.profile_only(None); ctx.profile_enable(True); ctx.profile_reset()
+        l.shard_run(R, W, slot_records, "replay", recorded.data_ptr(),
+                    commit=("partition" if args.partition else "device" if args.device_commit else (R == 0 and not args.no_commit)))
+        torch.cuda.synchronize()
+        print("kernels_ms", {k: round(v[1], 3) for k, v in ctx.profile_all().items() if v[0]})
+        ctx.profile_enable(False)
     l.close()
 
 
