@@ -560,6 +560,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         mix((unsigned long long)d.s0); mix((unsigned long long)d.s1); mix((unsigned long long)d.o_sc); mix((unsigned long long)d.o_si); mix((unsigned long long)d.o_l2g);
         mix((unsigned long long)__float_as_uint_host(v.sigma_p)); mix((unsigned long long)__float_as_uint_host(v.sigma_a)); mix((unsigned long long)__float_as_uint_host(v.spatial_k));
         mix((unsigned long long)c->verify_mode); mix((unsigned long long)verify_window_max_lds(c->opt.vw_lds)); mix((unsigned long long)c->opt.vw_wide_max); mix((unsigned long long)c->opt.vw_debug);
+        mix((unsigned long long)c->opt.vw_split); mix((unsigned long long)c->opt.vw_unit); mix((unsigned long long)c->opt.vw_split_avg);
         if (G->exec && G->sig == sig) {
             if (hipGraphLaunch(G->exec, st) == hipSuccess) { ++c->shard_graph_launches; return L3D_OK; }
             (void)hipGetLastError();

@@ -171,6 +171,7 @@ struct l3d_ctx {
     std::vector<int> h_cnt;
     int mmax_seen = 0;
     int chain_ring = 1;             // single-GPU chain: 1 = stage-1 candidate ring + k_place (default), 0 = triangulation on the chain stream (L3D_CHAIN_RING=0, A/B)
+    l3d::DevBuf vw_bstart, vw_segstate;             // split verification (k_vw_walk): bucket starts of the built images | per-segment state + unit table
     size_t part_arena_seen = 0;                     // records a partitioned segment-sharded run kept on this rank (sizes the next pass's arena)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
     int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0;   // what the last chain over this scene needed

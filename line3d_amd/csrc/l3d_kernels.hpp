@@ -106,7 +106,17 @@ struct VerifyArgs {
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
+    // k_verify_window + k_vw_walk (big == 2 only): a segment that outgrows the LDS image is only BUILT by its scratch block (bucketed image, bucket starts,
+    // header) and its hypotheses are verified in units of split_unit by the workgroups of a second launch -- a launch of FEW segments (one rank's slice
+    // of a view on a dense scene) no longer lasts as long as its longest segment.  0: off (the scratch block does the rounds itself)
+    int split_unit, units_max;      // hypotheses per unit (a multiple of 256) | upper bound of the number of units (grid of the second launch)
+    int* unit_start;                // [segments + 1] exclusive prefix of the units per segment, in seg_order order (written by the first launch)
+    int* bstart_g;                  // [segments][kVWBuckets + 1] bucket starts of the built images
+    int4* seg_hdr;                  // [segments] (bucket base, bits of the largest |depth|, -, -)
+    unsigned long long* best64;     // [segments] (confidence bits << 32) | (0x7fffffff - candidate index): atomicMax = the first strict maximum in candidate order
+    int* done;                      // [segments] units finished: the last one writes best_depths
 };
+constexpr int kVWBuckets = 2048;
 
 // code-object warm-up, one function per translation unit (l3d_warm_up)
 void warm_kernels(); void warm_verify_window(); void warm_rdd(); void warm_affinity(); void warm_linefit(); void warm_chain(); void warm_chain_sharded(); void warm_products(); void warm_sort();

@@ -43,6 +43,9 @@ namespace l3d {
     X(part_release, "L3D_PART_RELEASE", 1, "partitioned run: 1 = the chain's per-launch scratch is released before the products are built (memory before the speed of a second pass)") \
     X(block_recover, "L3D_BLOCK_RECOVER", 1, "views sharded in blocks: 1 = a block whose cold-started speculation failed is re-run warm from its predecessor's true lists, 0 = any miss ends the call with verdict 1 (round 4; A/B)") \
     X(slot_cams_min, "L3D_SLOT_CAMS_MIN", 65536, "sharded chain: slots of at least this many records carry a 4-byte side array of target cameras (0: always; tests)") \
+    X(vw_split, "L3D_VW_SPLIT", -1, "k_verify_window: long segments built by the first launch, verified in units by a second (k_vw_walk): 1 always, 0 never, -1 launches of few segments on dense scenes") \
+    X(vw_unit, "L3D_VW_UNIT", 1024, "hypotheses per unit of the split verification (a multiple of 256)")                               \
+    X(vw_split_avg, "L3D_VW_SPLIT_AVG", 4096, "vw_split = -1: split when the candidate capacity per segment of the launch is at least this") \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
     X(defer_stats, "L3D_DEFER_STATS", 0, "sharded native run: 1 = no host wait for a view's stage-1 statistics (measured slower: 93 vs 84 us per view at 8 ranks, DESIGN 6)") \

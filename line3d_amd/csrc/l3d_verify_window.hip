@@ -35,6 +35,7 @@ namespace l3d {
 #define L3D_BUCKET_SHIFT 15
 #define L3D_BUCKETS 2048
 #endif
+static_assert(L3D_BUCKETS == kVWBuckets, "the bucket starts of built images (VerifyArgs::bstart_g) are sized by kVWBuckets");
 constexpr int kBucketShift = L3D_BUCKET_SHIFT;               // 256 buckets per octave of depth
 constexpr int kBuckets = L3D_BUCKETS;                 // 8 octaves; anything beyond is clamped into the last bucket
 #ifndef L3D_VQ
@@ -97,6 +98,234 @@ __device__ __forceinline__ void vw_drain(const VerifyArgs& a, const float* sP, c
     }
 }
 
+// The rounds of a segment's hypotheses [h_begin, h_end) of the bucketed image L (positions in bucket order): NT hypotheses per round, the window walk,
+// the evaluation of the survivors, the per-hypothesis sums.  A whole segment (k_verify_window) or one unit of a long one (k_vw_walk) -- the confidence of
+// a hypothesis does not depend on who else is processed with it.  kept_l / best_l / besti_l: this thread's share of the segment's epilogue.
+#define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
+template <int NT>
+__device__ __forceinline__ void vw_rounds(const VerifyArgs& a, const VWLds& L, const int* s_bstart, int base, float dabs_max, int start, int h_begin, int h_end,
+                                          unsigned* q, const float* sP, const int* sOff, float* smax_wave, int* dirty, f3 C, f3 ray1, f3 ray2, float c_inf,
+                                          float two_sig_d, float two_sig_a, bool gate, int& kept_l, float& best_l, int& besti_l,
+                                          unsigned long long* t_acc, unsigned long long& t_prev)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    // ---- hypotheses in bucket order: the lanes of a wave have neighbouring depths, hence nearly the same window
+    for (int h0 = h_begin; h0 < h_end; h0 += NT) {
+        const int h = h0 + tid;
+        const bool hv = h < h_end;
+        float d1y = 0.0f, d2y = 0.0f, w1 = 0.0f, w2 = 0.0f;
+        unsigned cam_h = 0xffu, idx_h = 0;
+        if (hv) {
+            d1y = L.sd1[h]; d2y = L.sd2[h];
+            cam_h = L.sci[h] >> 24; idx_h = L.sci[h] & 0xffffffu;
+            if (gate) {
+                // the gate's uncertainty spatial_k * |C - X| (cudawrapper.cu:390-394) is at most spatial_k * |d| * (1 + 1e-5): |ray| = 1 +- 3u
+                // and X = C + d*ray carries a few ulps of |C| + |d| -- far inside the margin window_margin adds.  The walk needs nothing else
+                // of the hypothesis; its 3-D endpoints and thresholds are formed in vw_drain for the pairs that get that far.
+                w1 = window_margin(a.spatial_k * __builtin_fabsf(d1y) * 1.00001f, __builtin_fabsf(d1y), dabs_max, c_inf);
+                w2 = window_margin(a.spatial_k * __builtin_fabsf(d2y) * 1.00001f, __builtin_fabsf(d2y), dabs_max, c_inf);
+            } else {
+                w1 = w2 = __builtin_inff();
+            }
+        }
+        int head = 0, count = 0;                                       // wave-uniform ring state
+        const float lo1 = d1y - w1, hi1 = d1y + w1;
+        int j = 0, jend = 0;
+        if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
+        if (a.stamps && a.debug == 9) {                                  // diagnostic (L3D_VW_DEBUG=9 on top of the stamps: this loop distorts the phase split): entries walked, of them inside the d1 window / inside both windows
+            int n_in = 0, n_in1 = 0, n_in2 = 0, n_oth = 0;
+            for (int e = j; e < jend; ++e) {
+                ++n_in;
+                const bool i1 = L.sd1[e] >= lo1 && L.sd1[e] <= hi1;
+                const bool i2 = __builtin_fabsf(L.sd2[e] - d2y) <= w2;
+                n_in1 += i1; n_in2 += i1 && i2; n_oth += i1 && i2 && (L.sci[e] >> 24) != cam_h;
+            }
+            for (int o = 32; o > 0; o >>= 1) { n_in += __shfl_down(n_in, o); n_in1 += __shfl_down(n_in1, o); n_in2 += __shfl_down(n_in2, o); n_oth += __shfl_down(n_oth, o); }
+            const unsigned long long nh = __popcll(__ballot(hv));
+            if (lane == 0) { atomicAdd(&a.stamps[10], (unsigned long long)n_in); atomicAdd(&a.stamps[11], (unsigned long long)n_in1); atomicAdd(&a.stamps[12], (unsigned long long)n_in2);
+                             atomicAdd(&a.stamps[13], (unsigned long long)n_oth); atomicAdd(&a.stamps[14], nh); }
+        }
+        // the window is walked in groups of kG entries: the next group's loads (3 per entry, LDS or L2) are in flight while
+        // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
+#ifndef L3D_KG
+#define L3D_KG 4
+#endif
+        constexpr int kG = L3D_KG;
+        float c1[kG], c2[kG];
+        unsigned cc[kG], ct[kG];
+#pragma unroll
+        for (int g = 0; g < kG; ++g) { c1[g] = L.sd1[j + g]; c2[g] = L.sd2[j + g]; cc[g] = L.sci[j + g]; ct[g] = L.stgt[j + g]; }
+        VW_STAMP(1);
+        for (;;) {
+            if (!__any(j < jend)) break;
+            float n1[kG], n2[kG];
+            unsigned nc[kG], nt[kG];
+            const int jn = j < jend ? j + kG : j;                          // (lanes that are done keep re-reading in range)
+#pragma unroll
+            for (int g = 0; g < kG; ++g) { n1[g] = L.sd1[jn + g]; n2[g] = L.sd2[jn + g]; nc[g] = L.sci[jn + g]; nt[g] = L.stgt[jn + g]; }
+#pragma unroll
+            for (int g = 0; g < kG; ++g) {
+                // :674 (other cameras only) and the 1-D tests every gate-passing witness satisfies; the exact 3-D gate
+                // and the confidence run on the compacted survivors (vw_drain)
+                const bool push = j + g < jend && (cc[g] >> 24) != cam_h && c1[g] >= lo1 && c1[g] <= hi1 && __builtin_fabsf(c2[g] - d2y) <= w2;
+                const unsigned long long pm = __ballot(push);
+                if (pm) {
+                    if (push) {
+                        const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
+                        reinterpret_cast<uint4*>(q)[pos] = make_uint4((unsigned)lane | ((cc[g] >> 24) << 8), ct[g], __float_as_uint(c1[g]), __float_as_uint(c2[g]));
+                    }
+                    count += __popcll(pm);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (count >= 64) {
+                        VW_STAMP(2);
+                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
+                        head = (head + 64) & (kVQ - 1);
+                        count -= 64;
+                        VW_STAMP(3);
+                    }
+                }
+            }
+            j = jn;
+#pragma unroll
+            for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; ct[g] = nt[g]; }
+        }
+        VW_STAMP(2);
+        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        VW_STAMP(3);
+        float conf_sum = 0.0f;
+        if (__builtin_amdgcn_readfirstlane(*dirty)) {
+            for (int c = 0; c < a.N; ++c) { conf_sum += smax_wave[c * 64 + lane]; smax_wave[c * 64 + lane] = 0.0f; }   // ascending camera order; +0.0f is exact
+            if (lane == 0) *dirty = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (hv) {
+            a.cand_conf[start + idx_h] = conf_sum;
+            kept_l += conf_sum > 1.0f;
+            if (conf_sum > best_l || (conf_sum == best_l && (int)idx_h < besti_l)) { best_l = conf_sum; besti_l = (int)idx_h; }
+        }
+        VW_STAMP(4);
+    }
+}
+
+// units of the split launch: segment seg_order[i] gets ceil(m / split_unit) units when it outgrows the LDS image (and the candidates did not overflow),
+// none otherwise; unit_start = exclusive prefix in that order (heaviest segments first).  One workgroup.
+template <int NT>
+__device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, int* s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = a.seg_end - a.seg_begin;
+    const bool overflow = a.cand_cap && a.row_start[a.nrow_total] > a.cand_cap;
+    const int per = (nseg + NT - 1) / NT, i0 = min(nseg, tid * per), i1 = min(nseg, i0 + per);
+    auto units_of = [&](int i) {
+        const int y = a.seg_order ? a.seg_order[i] : a.seg_begin + i;
+        const int m = a.row_start[(y + 1) * a.N] - a.row_start[y * a.N];
+        return (!overflow && m > a.mmax) ? (m + a.split_unit - 1) / a.split_unit : 0;
+    };
+    int tot = 0;
+    for (int i = i0; i < i1; ++i) tot += units_of(i);
+    int incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+    for (int i = i0; i < i1; ++i) { a.unit_start[i] = run; run += units_of(i); }
+    if (tid == NT - 1) a.unit_start[nseg] = run;
+}
+
+// Second launch of a split verification: workgroup b = unit (segment, part) by binary search in unit_start; the segment's image was built by its scratch
+// block of k_verify_window (bucketed arrays in the scratch, bucket starts and header in global memory).  The unit verifies its split_unit hypotheses
+// (vw_rounds: the very code of the one-launch kernel) and adds its share of the segment's epilogue with atomics -- kept count, and the first strict
+// maximum in candidate order as ONE 64-bit maximum --; the unit that finishes last writes the best hypothesis' depths (cudawrapper.cu:1037-1062).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
+{
+    constexpr int NW = NT / 64;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ int s_bstart[kBuckets + 1];
+    __shared__ int s_dirty[NW];
+    __shared__ int s_rk[NW], s_ri[NW];
+    __shared__ float s_rb[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = a.seg_end - a.seg_begin;
+    const int b = (int)blockIdx.x;
+    if (b >= a.unit_start[nseg]) return;
+    int lo = 0, hi = nseg;                                    // largest i with unit_start[i] <= b (it owns at least one unit)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.unit_start[mid] <= b) lo = mid; else hi = mid; }
+    const int part = b - a.unit_start[lo], units = a.unit_start[lo + 1] - a.unit_start[lo];
+    const int y = a.seg_order ? a.seg_order[lo] : a.seg_begin + lo;
+    const int ys = y - a.seg_begin;
+    const int start = a.row_start[y * a.N];
+    const int m = a.row_start[(y + 1) * a.N] - start;
+    const int h_begin = part * a.split_unit, h_end = min(m, h_begin + a.split_unit);
+    VWLds L;
+    {
+        float* g = a.scratch;
+        const size_t stride = (size_t)a.scratch_stride;
+        L.sd1 = g + start; L.sd2 = g + stride + start;
+        L.sci = reinterpret_cast<unsigned*>(g + 2 * stride) + start; L.stgt = reinterpret_cast<unsigned*>(g + 3 * stride) + start;
+    }
+    float* smax = reinterpret_cast<float*>(s_raw);                           // [NT][N] per-(hypothesis lane, camera) maxima
+    unsigned* qall = reinterpret_cast<unsigned*>(smax + NT * a.N);
+    unsigned* q = qall + wave * kVQ * 4;
+    float* sP = reinterpret_cast<float*>(qall + NW * kVQ * 4);
+    int* sOff = reinterpret_cast<int*>(sP + a.N * 12);
+    for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
+    for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
+    const int* bs = a.bstart_g + (size_t)ys * (kBuckets + 1);
+    for (int i = tid; i <= kBuckets; i += NT) s_bstart[i] = bs[i];
+    float* smax_wave = smax + wave * 64 * a.N;
+    for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;
+    if (lane == 0) s_dirty[wave] = 0;
+    int* dirty = &s_dirty[wave];
+    const int4 hdr = a.seg_hdr[ys];
+    const int base = hdr.x;
+    const float dabs_max = __int_as_float(hdr.y);
+    __syncthreads();
+    const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
+    const float4 sseg = a.src_segs[y];
+    const f3 ray1 = normalize(mat3_apply(a.RtKinv_src, mk3(sseg.x, sseg.y, 1.0f)));
+    const f3 ray2 = normalize(mat3_apply(a.RtKinv_src, mk3(sseg.z, sseg.w, 1.0f)));
+    const float c_inf = __builtin_fmaxf(__builtin_fabsf(C.x), __builtin_fmaxf(__builtin_fabsf(C.y), __builtin_fabsf(C.z)));
+    const float two_sig_d = 2.0f * (a.sigma_p * a.sigma_p);
+    const float two_sig_a = 2.0f * (a.sigma_a * a.sigma_a);
+    const bool gate = a.spatial_k > 0.0f;
+    int kept_l = 0, besti_l = 0x7fffffff;
+    float best_l = 0.0f;
+    unsigned long long t_prev = 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
+    vw_rounds<NT>(a, L, s_bstart, base, dabs_max, start, h_begin, h_end, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
+    for (int o = 32; o > 0; o >>= 1) {
+        kept_l += __shfl_down(kept_l, o);
+        const float ob = __shfl_down(best_l, o);
+        const int oi = __shfl_down(besti_l, o);
+        if (ob > best_l || (ob == best_l && oi < besti_l)) { best_l = ob; besti_l = oi; }
+    }
+    if (lane == 0) { s_rk[wave] = kept_l; s_rb[wave] = best_l; s_ri[wave] = besti_l; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) {
+            kept_l += s_rk[w];
+            if (s_rb[w] > best_l || (s_rb[w] == best_l && s_ri[w] < besti_l)) { best_l = s_rb[w]; besti_l = s_ri[w]; }
+        }
+        if (kept_l) atomicAdd(&a.kept_cnt[y], kept_l);
+        atomicMax(&a.best64[ys], ((unsigned long long)__float_as_uint(best_l) << 32) | (unsigned long long)(unsigned)(0x7fffffff - besti_l));     // (confidences are >= +0)
+        __threadfence();
+        if (atomicAdd(&a.done[ys], 1) == units - 1) {         // the last unit of the segment: every unit's maximum is in
+            __threadfence();
+            const unsigned long long bb = atomicMax(&a.best64[ys], 0ull);
+            const float bconf = __uint_as_float((unsigned)(bb >> 32));
+            float2 bd = make_float2(-1.0f, -1.0f);            // marker: not part of the median list
+            if (bconf > 0.5f) {                                // conf_t/2.0f
+                const float4 d = a.cand_depths[start + (0x7fffffff - (int)(unsigned)(bb & 0xffffffffull))];
+                bd = make_float2(d.x, d.y);
+            }
+            a.best_depths[y] = bd;
+        }
+    }
+}
+
 // NT threads per workgroup: 256 when the grid fills the chip, 512 when only a few segments are verified per launch
 // (one rank's slice of a view in the sharded chain): the segment's hypotheses then run 8 waves wide instead of 4.
 #ifndef L3D_VW_WAVES
@@ -121,6 +350,7 @@ void k_verify_window(VerifyArgs a)
     // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop.
     // a.big == 2 runs both kinds in one launch: blocks [0, nseg) are the LDS blocks, [nseg, 2 nseg) the scratch blocks.
     const int nseg = a.seg_end - a.seg_begin;
+    if (a.split_unit > 0 && (int)blockIdx.x == 2 * nseg) { vw_unit_table<NT>(a, s_wtot); return; }     // (one more workgroup: the units of the second launch)
     const bool big = a.big == 2 ? (int)blockIdx.x >= nseg : a.big != 0;
     const int widx = (int)blockIdx.x >= nseg ? (int)blockIdx.x - nseg : (int)blockIdx.x;
 #ifdef L3D_NO_SEG_ORDER
@@ -153,7 +383,6 @@ void k_verify_window(VerifyArgs a)
         __syncthreads();
     }
     unsigned long long t_prev = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
-#define VW_STAMP(k) do { if (a.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
     const int cap = big ? 0 : a.mmax + kVWSlack;                       // slack: the scan loads a group of entries ahead
     VWLds L;
@@ -254,6 +483,15 @@ void k_verify_window(VerifyArgs a)
     __syncthreads();
     if (a.debug == 1) return;
     VW_STAMP(0);
+    if (a.split_unit > 0 && big) {
+        // split: this block only built the image; bucket starts and header go to global memory, the segment's epilogue state is reset, and the units
+        // of k_vw_walk (the next launch on this stream) verify the hypotheses
+        const int ys = y - a.seg_begin;
+        int* bs = a.bstart_g + (size_t)ys * (kBuckets + 1);
+        for (int b = tid; b <= kBuckets; b += NT) bs[b] = s_bstart[b];
+        if (tid == 0) { a.seg_hdr[ys] = make_int4(base, s_dmax, 0, 0); a.kept_cnt[y] = 0; a.best64[ys] = 0ull; a.done[ys] = 0; }
+        return;
+    }
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
     const float4 sseg = a.src_segs[y];
@@ -268,104 +506,7 @@ void k_verify_window(VerifyArgs a)
     // fused per-segment epilogue (k_seg_post): kept count and the first strict maximum in candidate order
     int kept_l = 0, besti_l = 0x7fffffff;
     float best_l = 0.0f;
-
-    // ---- hypotheses in bucket order: the lanes of a wave have neighbouring depths, hence nearly the same window
-    for (int h0 = 0; h0 < m; h0 += NT) {
-        const int h = h0 + tid;
-        const bool hv = h < m;
-        float d1y = 0.0f, d2y = 0.0f, w1 = 0.0f, w2 = 0.0f;
-        unsigned cam_h = 0xffu, idx_h = 0;
-        if (hv) {
-            d1y = L.sd1[h]; d2y = L.sd2[h];
-            cam_h = L.sci[h] >> 24; idx_h = L.sci[h] & 0xffffffu;
-            if (gate) {
-                // the gate's uncertainty spatial_k * |C - X| (cudawrapper.cu:390-394) is at most spatial_k * |d| * (1 + 1e-5): |ray| = 1 +- 3u
-                // and X = C + d*ray carries a few ulps of |C| + |d| -- far inside the margin window_margin adds.  The walk needs nothing else
-                // of the hypothesis; its 3-D endpoints and thresholds are formed in vw_drain for the pairs that get that far.
-                w1 = window_margin(a.spatial_k * __builtin_fabsf(d1y) * 1.00001f, __builtin_fabsf(d1y), dabs_max, c_inf);
-                w2 = window_margin(a.spatial_k * __builtin_fabsf(d2y) * 1.00001f, __builtin_fabsf(d2y), dabs_max, c_inf);
-            } else {
-                w1 = w2 = __builtin_inff();
-            }
-        }
-        int head = 0, count = 0;                                       // wave-uniform ring state
-        const float lo1 = d1y - w1, hi1 = d1y + w1;
-        int j = 0, jend = 0;
-        if (hv) { j = s_bstart[bucket_of(lo1, base)]; jend = s_bstart[bucket_of(hi1, base) + 1]; }
-        if (a.stamps && a.debug == 9) {                                  // diagnostic (L3D_VW_DEBUG=9 on top of the stamps: this loop distorts the phase split): entries walked, of them inside the d1 window / inside both windows
-            int n_in = 0, n_in1 = 0, n_in2 = 0, n_oth = 0;
-            for (int e = j; e < jend; ++e) {
-                ++n_in;
-                const bool i1 = L.sd1[e] >= lo1 && L.sd1[e] <= hi1;
-                const bool i2 = __builtin_fabsf(L.sd2[e] - d2y) <= w2;
-                n_in1 += i1; n_in2 += i1 && i2; n_oth += i1 && i2 && (L.sci[e] >> 24) != cam_h;
-            }
-            for (int o = 32; o > 0; o >>= 1) { n_in += __shfl_down(n_in, o); n_in1 += __shfl_down(n_in1, o); n_in2 += __shfl_down(n_in2, o); n_oth += __shfl_down(n_oth, o); }
-            const unsigned long long nh = __popcll(__ballot(hv));
-            if (lane == 0) { atomicAdd(&a.stamps[10], (unsigned long long)n_in); atomicAdd(&a.stamps[11], (unsigned long long)n_in1); atomicAdd(&a.stamps[12], (unsigned long long)n_in2);
-                             atomicAdd(&a.stamps[13], (unsigned long long)n_oth); atomicAdd(&a.stamps[14], nh); }
-        }
-        // the window is walked in groups of kG entries: the next group's loads (3 per entry, LDS or L2) are in flight while
-        // the current one is tested, so a wave pays one memory round trip per group instead of one per entry
-#ifndef L3D_KG
-#define L3D_KG 4
-#endif
-        constexpr int kG = L3D_KG;
-        float c1[kG], c2[kG];
-        unsigned cc[kG], ct[kG];
-#pragma unroll
-        for (int g = 0; g < kG; ++g) { c1[g] = L.sd1[j + g]; c2[g] = L.sd2[j + g]; cc[g] = L.sci[j + g]; ct[g] = L.stgt[j + g]; }
-        VW_STAMP(1);
-        for (;;) {
-            if (!__any(j < jend)) break;
-            float n1[kG], n2[kG];
-            unsigned nc[kG], nt[kG];
-            const int jn = j < jend ? j + kG : j;                          // (lanes that are done keep re-reading in range)
-#pragma unroll
-            for (int g = 0; g < kG; ++g) { n1[g] = L.sd1[jn + g]; n2[g] = L.sd2[jn + g]; nc[g] = L.sci[jn + g]; nt[g] = L.stgt[jn + g]; }
-#pragma unroll
-            for (int g = 0; g < kG; ++g) {
-                // :674 (other cameras only) and the 1-D tests every gate-passing witness satisfies; the exact 3-D gate
-                // and the confidence run on the compacted survivors (vw_drain)
-                const bool push = j + g < jend && (cc[g] >> 24) != cam_h && c1[g] >= lo1 && c1[g] <= hi1 && __builtin_fabsf(c2[g] - d2y) <= w2;
-                const unsigned long long pm = __ballot(push);
-                if (pm) {
-                    if (push) {
-                        const int pos = (head + count + __popcll(pm & ((1ull << lane) - 1ull))) & (kVQ - 1);
-                        reinterpret_cast<uint4*>(q)[pos] = make_uint4((unsigned)lane | ((cc[g] >> 24) << 8), ct[g], __float_as_uint(c1[g]), __float_as_uint(c2[g]));
-                    }
-                    count += __popcll(pm);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (count >= 64) {
-                        VW_STAMP(2);
-                        vw_drain(a, sP, sOff, q, head, 64, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
-                        head = (head + 64) & (kVQ - 1);
-                        count -= 64;
-                        VW_STAMP(3);
-                    }
-                }
-            }
-            j = jn;
-#pragma unroll
-            for (int g = 0; g < kG; ++g) { c1[g] = n1[g]; c2[g] = n2[g]; cc[g] = nc[g]; ct[g] = nt[g]; }
-        }
-        VW_STAMP(2);
-        if (count > 0) vw_drain(a, sP, sOff, q, head, count, lane, C, ray1, ray2, d1y, d2y, gate, smax_wave, dirty, two_sig_d, two_sig_a);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        VW_STAMP(3);
-        float conf_sum = 0.0f;
-        if (__builtin_amdgcn_readfirstlane(*dirty)) {
-            for (int c = 0; c < a.N; ++c) { conf_sum += smax_wave[c * 64 + lane]; smax_wave[c * 64 + lane] = 0.0f; }   // ascending camera order; +0.0f is exact
-            if (lane == 0) *dirty = 0;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        if (hv) {
-            a.cand_conf[start + idx_h] = conf_sum;
-            kept_l += conf_sum > 1.0f;
-            if (conf_sum > best_l || (conf_sum == best_l && (int)idx_h < besti_l)) { best_l = conf_sum; besti_l = (int)idx_h; }
-        }
-        VW_STAMP(4);
-    }
+    vw_rounds<NT>(a, L, s_bstart, base, dabs_max, start, 0, m, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
     if (a.kept_cnt) {
         __shared__ int s_rk[NW], s_ri[NW];
         __shared__ float s_rb[NW];
@@ -436,6 +577,7 @@ bool verify_window_supported(int N) { return verify_window_lds_bytes(64, N) <= 6
 // instantiation), under a mutex (several contexts on several GPUs may launch from different threads).  A refused opt-in
 // leaves the launch error for the caller's hipGetLastError check: nothing is launched with an LDS request the device
 // would reject silently.
+constexpr int kWideLdsMax = 112 * 1024;
 static bool lds_opt_in(const void* fn, int which)
 {
     static std::mutex mu;
@@ -444,7 +586,8 @@ static bool lds_opt_in(const void* fn, int which)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lk(mu);
     if (done[which][dev]) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024) != hipSuccess) return false;   // (error stays pending)
+    // (the 8-wave instantiation runs few workgroups per launch -- one rank's slice of a view --: its per-lane maxima at 24 neighbours need 66 KB)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, which == 1 ? kWideLdsMax : 60 * 1024) != hipSuccess) return false;   // (error stays pending)
     done[which][dev] = 1;
     return true;
 }
@@ -452,11 +595,20 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max)
 {
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
+    if (a.split_unit > 0 && a.big == 2) {
+        // split (the caller's decision: few segments per launch on a dense scene -- one rank's slice of a view): the launch of whole segments lasts as
+        // long as its longest one; built by the 4-wave kernel, verified in units that keep every CU busy
+        const size_t lds = std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
+        if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<256>), 0)) return;
+        hipLaunchKernelGGL(k_verify_window<256>, dim3(2 * nseg + 1), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_vw_walk<256>, dim3((unsigned)std::max(1, a.units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a);
+        return;
+    }
     const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
     // few segments (up to about two workgroups per CU): 8 waves per segment, if the wider per-lane maxima still fit
     // (replayed ranks, 2000 segments per view: 250 segments 90 -> 74 us per view, 500 segments 98 -> 94, 1000 segments 135 -> 196)
     const size_t lds512 = a.big == 1 ? verify_window_lds_bytes_big(a.N, 512) : std::max(verify_window_lds_bytes_nt(a.mmax, a.N, 512), verify_window_lds_bytes_big(a.N, 512));
-    if (nseg <= wide_max && lds512 <= 60 * 1024) {
+    if (nseg <= wide_max && lds512 <= (size_t)kWideLdsMax) {
         if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<512>), 1)) return;
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);
     } else {
