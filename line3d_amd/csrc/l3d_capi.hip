@@ -505,7 +505,6 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end; va.nrow_total = (int)nrow;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
     va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
-    va.split_unit = 0; va.units_max = 0; va.unit_start = nullptr; va.bstart_g = nullptr; va.seg_hdr = nullptr; va.best64 = nullptr; va.done = nullptr;
     va.big = 0; va.scratch = nullptr; va.scratch_stride = 0; va.kept_cnt = nullptr; va.best_depths = nullptr; va.seg_order = nullptr;
     va.debug = c->opt.vw_debug;
     va.stamps = nullptr;

@@ -211,7 +211,6 @@ VerifyArgs chain_verify_args(l3d_ctx* c, const l3d_chain_view& v, const ChainVie
     va.N = v.N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = v.S_src * v.N;
     va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
     va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = nullptr;
-    va.split_unit = 0; va.units_max = 0; va.unit_start = nullptr; va.bstart_g = nullptr; va.seg_hdr = nullptr; va.best64 = nullptr; va.done = nullptr;
     va.seg_order = c->ch_segorder.as<int>();
     va.mmax = 0; va.only_above = -1; va.skip_above = 0; va.big = 0;
     va.kept_cnt = nullptr; va.best_depths = nullptr; va.scratch = nullptr; va.scratch_stride = 0;
@@ -239,18 +238,19 @@ void chain_launch_verify(l3d_ctx* c, VerifyArgs& va, const ChainViewDev& d, cons
         const int unit = std::max(256, (c->opt.vw_unit / 256) * 256);
         const size_t S = (size_t)(va.seg_end - va.seg_begin);
         const bool want = c->opt.vw_split > 0 || (c->opt.vw_split < 0 && (int)S <= c->opt.vw_wide_max && cand_cap / std::max<size_t>(S, 1) >= (size_t)c->opt.vw_split_avg);
+        VWSplitArgs sp;
         if (want && !va.stamps && c->vw_bstart.cap >= S * (kVWBuckets + 1) * 4 && c->vw_segstate.cap >= S * 36 + 16) {
-            va.split_unit = unit;
-            va.units_max = (int)std::min<size_t>(S + cand_cap / (size_t)unit + 1, 0x3fffffff);
+            sp.split_unit = unit;
+            sp.units_max = (int)std::min<size_t>(S + cand_cap / (size_t)unit + 1, 0x3fffffff);
             unsigned char* ss = c->vw_segstate.as<unsigned char>();
-            va.bstart_g = c->vw_bstart.as<int>();
-            va.seg_hdr = reinterpret_cast<int4*>(ss);                                  // 16 B per segment
-            va.best64 = reinterpret_cast<unsigned long long*>(ss + S * 16);            // 8 B
-            va.done = reinterpret_cast<int*>(ss + S * 24);                             // 4 B
-            va.unit_start = reinterpret_cast<int*>(ss + S * 28);                       // 4 B x (segments + 1)
+            sp.bstart_g = c->vw_bstart.as<int>();
+            sp.seg_hdr = reinterpret_cast<int4*>(ss);                                  // 16 B per segment
+            sp.best64 = reinterpret_cast<unsigned long long*>(ss + S * 16);            // 8 B
+            sp.done = reinterpret_cast<int*>(ss + S * 24);                             // 4 B
+            sp.unit_start = reinterpret_cast<int*>(ss + S * 28);                       // 4 B x (segments + 1)
         }
         ProfScope p(c, "verify_window", st);
-        launch_verify_window(va, st, c->opt.vw_wide_max);
+        launch_verify_window(va, st, c->opt.vw_wide_max, &sp);
     } else {
         va.skip_above = 0; va.only_above = -1; va.big = 0; va.scratch = nullptr; va.scratch_stride = 0;
         va.kept_cnt = nullptr; va.best_depths = nullptr;

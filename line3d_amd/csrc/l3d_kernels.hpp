@@ -106,15 +106,18 @@ struct VerifyArgs {
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
-    // k_verify_window + k_vw_walk (big == 2 only): a segment that outgrows the LDS image is only BUILT by its scratch block (bucketed image, bucket starts,
-    // header) and its hypotheses are verified in units of split_unit by the workgroups of a second launch -- a launch of FEW segments (one rank's slice
-    // of a view on a dense scene) no longer lasts as long as its longest segment.  0: off (the scratch block does the rounds itself)
-    int split_unit, units_max;      // hypotheses per unit (a multiple of 256) | upper bound of the number of units (grid of the second launch)
-    int* unit_start;                // [segments + 1] exclusive prefix of the units per segment, in seg_order order (written by the first launch)
-    int* bstart_g;                  // [segments][kVWBuckets + 1] bucket starts of the built images
-    int4* seg_hdr;                  // [segments] (bucket base, bits of the largest |depth|, -, -)
-    unsigned long long* best64;     // [segments] (confidence bits << 32) | (0x7fffffff - candidate index): atomicMax = the first strict maximum in candidate order
-    int* done;                      // [segments] units finished: the last one writes best_depths
+};
+// k_verify_window_build + k_vw_walk (big == 2 only): a segment that outgrows the LDS image is only BUILT by its scratch block (bucketed image, bucket
+// starts, header) and its hypotheses are verified in units of split_unit by the workgroups of a second launch -- a launch of FEW segments (one rank's
+// slice of a view on a dense scene) no longer lasts as long as its longest segment.  A block of its own, passed to those two kernels only: the
+// one-launch kernel keeps its argument block (and its scalar registers: 2.6 % more VALU instructions were SGPR spills when these fields sat in VerifyArgs)
+struct VWSplitArgs {
+    int split_unit = 0, units_max = 0;      // hypotheses per unit (a multiple of 256; 0: no split) | upper bound of the number of units (grid of the second launch)
+    int* unit_start = nullptr;              // [segments + 1] exclusive prefix of the units per segment, in seg_order order (written by the first launch)
+    int* bstart_g = nullptr;                // [segments][kVWBuckets + 1] bucket starts of the built images
+    int4* seg_hdr = nullptr;                // [segments] (bucket base, bits of the largest |depth|, -, -)
+    unsigned long long* best64 = nullptr;   // [segments] (confidence bits << 32) | (0x7fffffff - candidate index): atomicMax = the first strict maximum in candidate order
+    int* done = nullptr;                    // [segments] units finished: the last one writes best_depths
 };
 constexpr int kVWBuckets = 2048;
 
@@ -137,7 +140,7 @@ void launch_scan_range(const int* rowcnt, int* row_start, int N, int seg_begin, 
 void launch_pair_fill(const PairArgs& a, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_exist_place(const ExistRec* ex, int n, int N, const int* row_start, uint2* meta, float4* depths, hipStream_t st);
 void launch_verify(const VerifyArgs& a, hipStream_t st);
-void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max = 640);
+void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max = 640, const VWSplitArgs* split = nullptr);
 size_t verify_window_lds_bytes(int mmax, int N);
 size_t verify_window_max_lds(int vw_lds_opt = 0);
 bool verify_window_supported(int N);

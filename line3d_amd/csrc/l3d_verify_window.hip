@@ -212,7 +212,7 @@ __device__ __forceinline__ void vw_rounds(const VerifyArgs& a, const VWLds& L, c
 // units of the split launch: segment seg_order[i] gets ceil(m / split_unit) units when it outgrows the LDS image (and the candidates did not overflow),
 // none otherwise; unit_start = exclusive prefix in that order (heaviest segments first).  One workgroup.
 template <int NT>
-__device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, int* s_w)
+__device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, const VWSplitArgs& sp, int* s_w)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, int* s_w)
     auto units_of = [&](int i) {
         const int y = a.seg_order ? a.seg_order[i] : a.seg_begin + i;
         const int m = a.row_start[(y + 1) * a.N] - a.row_start[y * a.N];
-        return (!overflow && m > a.mmax) ? (m + a.split_unit - 1) / a.split_unit : 0;
+        return (!overflow && m > a.mmax) ? (m + sp.split_unit - 1) / sp.split_unit : 0;
     };
     int tot = 0;
     for (int i = i0; i < i1; ++i) tot += units_of(i);
@@ -231,8 +231,8 @@ __device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, int* s_w)
     __syncthreads();
     int run = incl - tot;
     for (int w = 0; w < wave; ++w) run += s_w[w];
-    for (int i = i0; i < i1; ++i) { a.unit_start[i] = run; run += units_of(i); }
-    if (tid == NT - 1) a.unit_start[nseg] = run;
+    for (int i = i0; i < i1; ++i) { sp.unit_start[i] = run; run += units_of(i); }
+    if (tid == NT - 1) sp.unit_start[nseg] = run;
 }
 
 // Second launch of a split verification: workgroup b = unit (segment, part) by binary search in unit_start; the segment's image was built by its scratch
@@ -240,7 +240,7 @@ __device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, int* s_w)
 // (vw_rounds: the very code of the one-launch kernel) and adds its share of the segment's epilogue with atomics -- kept count, and the first strict
 // maximum in candidate order as ONE 64-bit maximum --; the unit that finishes last writes the best hypothesis' depths (cudawrapper.cu:1037-1062).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
+__global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a, VWSplitArgs sp)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -251,15 +251,15 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
     const int b = (int)blockIdx.x;
-    if (b >= a.unit_start[nseg]) return;
+    if (b >= sp.unit_start[nseg]) return;
     int lo = 0, hi = nseg;                                    // largest i with unit_start[i] <= b (it owns at least one unit)
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.unit_start[mid] <= b) lo = mid; else hi = mid; }
-    const int part = b - a.unit_start[lo], units = a.unit_start[lo + 1] - a.unit_start[lo];
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sp.unit_start[mid] <= b) lo = mid; else hi = mid; }
+    const int part = b - sp.unit_start[lo], units = sp.unit_start[lo + 1] - sp.unit_start[lo];
     const int y = a.seg_order ? a.seg_order[lo] : a.seg_begin + lo;
     const int ys = y - a.seg_begin;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
-    const int h_begin = part * a.split_unit, h_end = min(m, h_begin + a.split_unit);
+    const int h_begin = part * sp.split_unit, h_end = min(m, h_begin + sp.split_unit);
     VWLds L;
     {
         float* g = a.scratch;
@@ -274,13 +274,13 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
     int* sOff = reinterpret_cast<int*>(sP + a.N * 12);
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
-    const int* bs = a.bstart_g + (size_t)ys * (kBuckets + 1);
+    const int* bs = sp.bstart_g + (size_t)ys * (kBuckets + 1);
     for (int i = tid; i <= kBuckets; i += NT) s_bstart[i] = bs[i];
     float* smax_wave = smax + wave * 64 * a.N;
     for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;
     if (lane == 0) s_dirty[wave] = 0;
     int* dirty = &s_dirty[wave];
-    const int4 hdr = a.seg_hdr[ys];
+    const int4 hdr = sp.seg_hdr[ys];
     const int base = hdr.x;
     const float dabs_max = __int_as_float(hdr.y);
     __syncthreads();
@@ -310,11 +310,11 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
             if (s_rb[w] > best_l || (s_rb[w] == best_l && s_ri[w] < besti_l)) { best_l = s_rb[w]; besti_l = s_ri[w]; }
         }
         if (kept_l) atomicAdd(&a.kept_cnt[y], kept_l);
-        atomicMax(&a.best64[ys], ((unsigned long long)__float_as_uint(best_l) << 32) | (unsigned long long)(unsigned)(0x7fffffff - besti_l));     // (confidences are >= +0)
+        atomicMax(&sp.best64[ys], ((unsigned long long)__float_as_uint(best_l) << 32) | (unsigned long long)(unsigned)(0x7fffffff - besti_l));     // (confidences are >= +0)
         __threadfence();
-        if (atomicAdd(&a.done[ys], 1) == units - 1) {         // the last unit of the segment: every unit's maximum is in
+        if (atomicAdd(&sp.done[ys], 1) == units - 1) {         // the last unit of the segment: every unit's maximum is in
             __threadfence();
-            const unsigned long long bb = atomicMax(&a.best64[ys], 0ull);
+            const unsigned long long bb = atomicMax(&sp.best64[ys], 0ull);
             const float bconf = __uint_as_float((unsigned)(bb >> 32));
             float2 bd = make_float2(-1.0f, -1.0f);            // marker: not part of the median list
             if (bconf > 0.5f) {                                // conf_t/2.0f
@@ -331,12 +331,8 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a)
 #ifndef L3D_VW_WAVES
 #define L3D_VW_WAVES 0
 #endif
-template <int NT>
-__global__ __launch_bounds__(NT)
-#if L3D_VW_WAVES
-__attribute__((amdgpu_waves_per_eu(L3D_VW_WAVES, L3D_VW_WAVES)))
-#endif
-void k_verify_window(VerifyArgs a)
+template <int NT, bool kSplit>
+__device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSplitArgs& sp)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -350,7 +346,7 @@ void k_verify_window(VerifyArgs a)
     // bucketed arrays in a global scratch (L2) instead of LDS -- still O(m*window), never the all-pairs loop.
     // a.big == 2 runs both kinds in one launch: blocks [0, nseg) are the LDS blocks, [nseg, 2 nseg) the scratch blocks.
     const int nseg = a.seg_end - a.seg_begin;
-    if (a.split_unit > 0 && (int)blockIdx.x == 2 * nseg) { vw_unit_table<NT>(a, s_wtot); return; }     // (one more workgroup: the units of the second launch)
+    if constexpr (kSplit) { if ((int)blockIdx.x == 2 * nseg) { vw_unit_table<NT>(a, sp, s_wtot); return; } }     // (one more workgroup: the units of the second launch)
     const bool big = a.big == 2 ? (int)blockIdx.x >= nseg : a.big != 0;
     const int widx = (int)blockIdx.x >= nseg ? (int)blockIdx.x - nseg : (int)blockIdx.x;
 #ifdef L3D_NO_SEG_ORDER
@@ -483,14 +479,16 @@ void k_verify_window(VerifyArgs a)
     __syncthreads();
     if (a.debug == 1) return;
     VW_STAMP(0);
-    if (a.split_unit > 0 && big) {
-        // split: this block only built the image; bucket starts and header go to global memory, the segment's epilogue state is reset, and the units
-        // of k_vw_walk (the next launch on this stream) verify the hypotheses
-        const int ys = y - a.seg_begin;
-        int* bs = a.bstart_g + (size_t)ys * (kBuckets + 1);
-        for (int b = tid; b <= kBuckets; b += NT) bs[b] = s_bstart[b];
-        if (tid == 0) { a.seg_hdr[ys] = make_int4(base, s_dmax, 0, 0); a.kept_cnt[y] = 0; a.best64[ys] = 0ull; a.done[ys] = 0; }
-        return;
+    if constexpr (kSplit) {
+        if (big) {
+            // split: this block only built the image; bucket starts and header go to global memory, the segment's epilogue state is reset, and the units
+            // of k_vw_walk (the next launch on this stream) verify the hypotheses
+            const int ys = y - a.seg_begin;
+            int* bs = sp.bstart_g + (size_t)ys * (kBuckets + 1);
+            for (int b = tid; b <= kBuckets; b += NT) bs[b] = s_bstart[b];
+            if (tid == 0) { sp.seg_hdr[ys] = make_int4(base, s_dmax, 0, 0); a.kept_cnt[y] = 0; sp.best64[ys] = 0ull; sp.done[ys] = 0; }
+            return;
+        }
     }
 
     const f3 C = mk3(a.C_src[0], a.C_src[1], a.C_src[2]);
@@ -540,6 +538,22 @@ void k_verify_window(VerifyArgs a)
 #undef VW_STAMP
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT)
+#if L3D_VW_WAVES
+__attribute__((amdgpu_waves_per_eu(L3D_VW_WAVES, L3D_VW_WAVES)))
+#endif
+void k_verify_window(VerifyArgs a)
+{
+    vw_segment_block<NT, false>(a, VWSplitArgs());
+}
+// first launch of a split verification: LDS blocks as ever, scratch blocks build only, one more workgroup writes the unit table
+template <int NT>
+__global__ __launch_bounds__(NT) void k_verify_window_build(VerifyArgs a, VWSplitArgs sp)
+{
+    vw_segment_block<NT, true>(a, sp);
+}
+
 // max candidates per segment (LDS sizing of k_verify_window)
 __global__ void k_seg_mmax(const int* __restrict__ row_start, int N, int seg_begin, int seg_end, int* __restrict__ out)
 {
@@ -581,7 +595,7 @@ constexpr int kWideLdsMax = 112 * 1024;
 static bool lds_opt_in(const void* fn, int which)
 {
     static std::mutex mu;
-    static unsigned char done[2][64] = {};
+    static unsigned char done[3][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lk(mu);
@@ -591,17 +605,17 @@ static bool lds_opt_in(const void* fn, int which)
     done[which][dev] = 1;
     return true;
 }
-void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max)
+void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max, const VWSplitArgs* sp)
 {
     const int nseg = a.seg_end - a.seg_begin;
     if (nseg <= 0) return;
-    if (a.split_unit > 0 && a.big == 2) {
+    if (sp && sp->split_unit > 0 && a.big == 2) {
         // split (the caller's decision: few segments per launch on a dense scene -- one rank's slice of a view): the launch of whole segments lasts as
         // long as its longest one; built by the 4-wave kernel, verified in units that keep every CU busy
         const size_t lds = std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
-        if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<256>), 0)) return;
-        hipLaunchKernelGGL(k_verify_window<256>, dim3(2 * nseg + 1), dim3(256), lds, st, a);
-        hipLaunchKernelGGL(k_vw_walk<256>, dim3((unsigned)std::max(1, a.units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a);
+        if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window_build<256>), 2)) return;
+        hipLaunchKernelGGL(k_verify_window_build<256>, dim3(2 * nseg + 1), dim3(256), lds, st, a, *sp);
+        hipLaunchKernelGGL(k_vw_walk<256>, dim3((unsigned)std::max(1, sp->units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a, *sp);
         return;
     }
     const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
