@@ -54,6 +54,8 @@ struct AffIn {
     const int* coll_other;                          // dense ids (same view), ascending per segment
     const float* coll_w;
     unsigned char* flags;                           // per potential correspondence: bit 0 marked as a target, bit 1 expanded
+    int coll_sym;                                   // the collinearity table holds every entry both ways (the reference's always does: segments.h:94-95) -- found by
+                                                    // k_aff_validate; then "does an earlier target list c" is asked from c's own short list
 };
 
 // d in C(t)?
@@ -132,6 +134,14 @@ __global__ void k_aff_validate(AffIn a, long long n_pot, long long n_coll, int* 
             const int x = a.coll_other[q];
             if (x < 0 || x >= a.n_dense || a.dview[x] != v || x == (int)i || (q > cb && a.coll_other[q - 1] >= x)) { *bad = 3; return; }
         }
+        // (second word: the table is NOT symmetric -- no error, the kernels then take the general path.  Ranges of x are checked by x's own thread;
+        // a bad range there is an error anyway)
+        for (long long q = cb; q < ce; ++q) {
+            const int x = a.coll_other[q];
+            const long long xb = a.coll_start[x], xe = a.coll_start[x + 1];
+            if (xb < 0 || xe < xb || xe > n_coll) break;
+            if (!coll_has(a, x, (int)i)) { bad[1] = 1; break; }
+        }
         const int hb = a.best[i];
         if (hb < -1 || hb >= a.n_hyp || (hb >= 0 && a.hyp_dense[hb] != (int)i)) *bad = 4;
     }
@@ -198,6 +208,8 @@ __global__ __launch_bounds__(256) void k_aff_groups(AffIn a, int h0, int h1)
             carry_gs = __shfl(gs, last);
         }
         s_t[wave][lane] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                 // (the other lanes' targets are read below)
+        __builtin_amdgcn_wave_barrier();
         const long long g0 = gs > c0 ? gs : c0;                                // the group's part inside this pass starts here
         // Resolution.  A target is decided once every earlier target of its group is: the first undecided target of a group
         // (its head) has by then been tested against every expanded target before it.  When a head turns out expanded, ALL
@@ -205,13 +217,50 @@ __global__ __launch_bounds__(256) void k_aff_groups(AffIn a, int h0, int h1)
         // after two iterations however long it is.
         bool marked = false, expanded = false;
         bool resolved = !valid;
+        const unsigned long long group_below = ((1ull << lane) - 1ull) & ~((1ull << (int)(g0 - c0)) - 1ull);   // earlier lanes of my group
+        if (a.coll_sym) {
+            // Symmetric table: "an expanded earlier target lists t" <=> "an element of C(t) is an expanded earlier target of the group" -- asked from
+            // t's own short list instead of every earlier target's.  The earlier targets of the group that are collinear with t: in an earlier pass of
+            // this wave (their bits are final: read back) or lanes of this pass (predmask).  A lane is decided as soon as all lanes of its predmask
+            // are: rounds = the longest chain of collinear targets, not the number of expanded targets of the group.
+            unsigned long long predmask = 0ull;
+            if (valid && !mused) {
+                const int lo_lane = (int)(g0 - c0);
+                const int t_first = s_t[wave][lo_lane];                        // first target of my group inside this pass
+                const long long qe = a.coll_start[t + 1];
+                for (long long q = a.coll_start[t]; q < qe; ++q) {
+                    const int x = a.coll_other[q];
+                    if (x >= t) break;                                         // (ascending: only earlier targets matter)
+                    if (x < t_first) {
+                        if (gs < c0 && !resolved) {                            // the group began in an earlier pass
+                            const long long p = pot_lower(a, gs, c0, x);
+                            if (p < c0 && a.pot_tgt[p] == x && (load_flag(a, p) & 2)) resolved = true;   // listed by an expanded target: not marked
+                        }
+                    } else {
+                        int l0 = lo_lane, l1 = lane;                           // x among the lanes [lo_lane, lane) of my group?
+                        while (l0 < l1) { const int mid = (l0 + l1) >> 1; if (s_t[wave][mid] < x) l0 = mid + 1; else l1 = mid; }
+                        if (l0 < lane && s_t[wave][l0] == x) predmask |= 1ull << l0;
+                    }
+                }
+            }
+            unsigned long long exp_mask = 0ull;
+            for (;;) {
+                const unsigned long long undecided = __ballot(!resolved);
+                if (!undecided) break;
+                if (!resolved && (predmask & undecided) == 0ull) {             // every collinear earlier target of the group is decided
+                    marked = !mused && (predmask & exp_mask) == 0ull;
+                    expanded = marked && hb >= 0;
+                    resolved = true;
+                }
+                exp_mask |= __ballot(expanded);
+            }
+        } else {
         if (valid) {
             bool hit = false;
             for (long long e2 = gs; e2 < c0 && !hit; ++e2)                     // the group began in an earlier pass of this wave
                 if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], t)) hit = true;
             resolved = hit;                                                    // listed by an expanded target: not marked
         }
-        const unsigned long long group_below = ((1ull << lane) - 1ull) & ~((1ull << (int)(g0 - c0)) - 1ull);   // earlier lanes of my group
         for (;;) {
             const unsigned long long undecided = __ballot(!resolved);
             if (!undecided) break;
@@ -221,6 +270,7 @@ __global__ __launch_bounds__(256) void k_aff_groups(AffIn a, int h0, int h1)
             if (!resolved && fresh) {
                 if (coll_has(a, s_t[wave][__ffsll((long long)fresh) - 1], t)) resolved = true;
             }
+        }
         }
         if (valid) __hip_atomic_store(a.flags + e, (unsigned char)((marked ? 1 : 0) | (expanded ? 2 : 0) | (mused ? 4 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                 // (the next pass of this wave may read them back)
@@ -337,6 +387,17 @@ __global__ __launch_bounds__(256) void k_aff_items(AffIn a, int h0, int h1, cons
                             const long long p = pot_lower(a, gs, ek, c);
                             skip = p < ek && a.pot_tgt[p] == c;
                         }
+                        if (a.coll_sym) {                                       // an earlier expanded target lists c?  symmetric table: ask c's own list
+                            const int t_lo = gs < ek ? a.pot_tgt[gs] : 0x7fffffff;
+                            const long long qe = a.coll_start[c + 1];
+                            for (long long q2 = a.coll_start[c]; q2 < qe && !skip; ++q2) {
+                                const int x = a.coll_other[q2];
+                                if (x < t_lo) continue;
+                                if (x >= tk) break;                             // (the group's earlier targets are smaller than tk)
+                                const long long p = pot_lower(a, gs, ek, x);
+                                if (p < ek && a.pot_tgt[p] == x && (load_flag(a, p) & 2)) skip = true;
+                            }
+                        } else
                         for (long long e2 = gs; e2 < ek && !skip; ++e2)         // an earlier expanded target lists c?
                             if ((load_flag(a, e2) & 2) && coll_has(a, a.pot_tgt[e2], c)) skip = true;
                         if (!skip) {
@@ -571,12 +632,15 @@ int affinity_fill_core(l3d_ctx* c, AffIn a, const int32_t* seg_base_h, const int
     {
         HIPCHK(c, c->g1.reserve(((size_t)nh + 2) * 4 * 4 + (size_t)V * 4 + 1024));
         int* bad = c->g1.as<int>();
-        HIPCHK(c, hipMemsetAsync(bad, 0, 4, st));
+        HIPCHK(c, hipMemsetAsync(bad, 0, 8, st));
         const int nmax = std::max(nd, nh);
+        a.coll_sym = 0;
         hipLaunchKernelGGL(k_aff_validate, dim3((nmax + 255) / 256), dim3(256), 0, st, a, n_pot, n_coll, bad);
-        int h_bad = 0;
-        HIPCHK(c, hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+        int h_bad2[2] = { 0, 0 };
+        HIPCHK(c, hipMemcpyAsync(h_bad2, bad, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        const int h_bad = h_bad2[0];
+        a.coll_sym = (h_bad2[1] == 0 && c->opt.aff_sym != 0) ? 1 : 0;
         static const char* what[] = { "", "a CSR range is out of bounds", "a potential correspondence is out of range, in the source's own view, or out of order",
                                       "a collinearity entry is out of range, in another view, a self entry, or out of order", "best[] and hyp_dense[] disagree",
                                       "hypotheses are not numbered in dense order" };

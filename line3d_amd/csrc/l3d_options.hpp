@@ -33,6 +33,7 @@ namespace l3d {
     X(wait_sleep_us, "L3D_WAIT_SLEEP_US", 20, "sleep of the sharded run's waiting host threads")                                     \
     X(aff_chunk, "L3D_AFF_CHUNK", 0, "tests: targets per pass of k_aff_groups (0: 64)")                                              \
     X(aff_per_view, "L3D_AFF_PER_VIEW", 0, "tests: one k_aff_groups launch per view (the schedule of one-way records)")              \
+    X(aff_sym, "L3D_AFF_SYM", 1, "affinity fill: 1 = a symmetric collinearity table (checked) takes the short-list path, 0 = always the general path (A/B)") \
     X(aff_block, "L3D_AFF_BLOCK", 0, "candidate pairs per block of sources of the affinity fill (0: 2^27; tests: small values force many blocks)") \
     X(aff_word_block, "L3D_AFF_WORD_BLOCK", 0, "decision words per outer block of sources of the affinity fill (0: 2^26)")          \
     X(cc_max_rounds, "L3D_CC_MAX_ROUNDS", 0, "tests: rounds of the connected-components loop before it gives up (0: 64)")            \
