@@ -383,6 +383,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     const long long* doff = reinterpret_cast<const long long*>(tb + o_off);
 
     // ---- best references, medians (once); per block: keys, sort, unique, CSR rows
+    const double t_res0 = now_s();
     HIPCHK(c, P.keys.reserve((size_t)n_keys_max * 8 + 64));
     HIPCHK(c, P.keys2.reserve((size_t)n_keys_max * 8 + 64));
     HIPCHK(c, P.flag.reserve(((size_t)n_keys_max + 2) * 4));
@@ -391,6 +392,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));
     HIPCHK(c, P.best_ref.reserve((size_t)nd * 8 + 64));
     HIPCHK(c, P.median.reserve((size_t)n_views * 8 + 64));          // medians | list lengths of the early-return views
+    if (c->opt.timing) fprintf(stderr, "[l3d products] %zu block(s) of up to %lld keys, table of up to %lld entries: buffers reserved in %.2f ms\n", blocks.size(), n_keys_max, slots_all, (now_s() - t_res0) * 1e3);
     int* d_list_len = reinterpret_cast<int*>(P.median.as<float>() + n_views);
     HIPCHK(c, hipMemsetAsync(d_list_len, 0, (size_t)n_views * 4, st));
     unsigned long long* keys = P.keys.as<unsigned long long>();
