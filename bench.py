@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) rest of compute3Dmodel after the timed passes")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold measurement (first matchViews + first finish of the fresh object)")
+    ap.add_argument("--partition", choices=["segments", "blocks"], default=None,
+                    help="matchViews as a PARTITIONED job (BASELINE configs[4]: nothing replicated; DESIGN.md section 6 iii / iv) instead of the default multi-GPU modes: "
+                         "`segments` = l3d_shard_chain_partition (source segments sharded, exact on every scene), `blocks` = l3d_match_chain_partition (views sharded, "
+                         "speculated + verified).  A step is the partitioned matchViews of every rank; the chain scratch is kept between steps (L3D_PART_RELEASE=0: "
+                         "a one-shot job releases it).  Works at --gpus 1 too (a communicator of one rank).")
     return ap.parse_args()
 
 
@@ -299,7 +304,23 @@ def main():
         else:
             l3dist.match_views_sharded(l3d, rank, world, dist)
 
+    part_link = None
+    if args.partition:
+        part_link = sharded_mode["link"] if dist is not None else l3dist.RcclLink(0, 1, None, local_rank)
+        if part_link is None:
+            raise RuntimeError("--partition needs the RCCL link")
+        ctx.set_option("L3D_PART_RELEASE", 0)
+        args.no_extras = True
+        part_slot = max(l3dist.default_slot_records(args.segments, args.neighbors, world), 65536 if args.segments * args.neighbors >= 48000 else 0)
+
     def step():
+        if args.partition == "segments":
+            l3d.shard_run(rank, world, part_slot, "rccl", part_link.link, commit="partition")
+            return
+        if args.partition == "blocks":
+            if not l3d.partition_run(rank, world, "rccl", part_link.link, -1):
+                raise RuntimeError("partitioned blocks: a block is shorter than the neighbour window (use --partition segments)")
+            return
         if dist is None:
             l3d.match_views()
             return
@@ -450,7 +471,9 @@ def main():
                    config=dict(workload="%s: %d views x %d segments, N=%d neighbours, matchViews (stage 1+2+filter+products of performMatching)"
                                         % (workload_name(n_gpus, V, args.segments, args.neighbors), V, args.segments, args.neighbors),
                                views=V, segments=args.segments, neighbors=args.neighbors, seed=args.seed,
-                               parallelism=("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU"),
+                               parallelism=(("x%d: partitioned job, %s sharded, nothing replicated (DESIGN.md section 6 %s)" % (n_gpus, "source segments" if args.partition == "segments" else "blocks of views",
+                                                                                                                               "iv" if args.partition == "segments" else "iii")) if args.partition
+                                            else ("x%d: " % n_gpus + MODES[sharded_mode["i"]]) if dist is not None else "single GPU")),
                    views_per_s=V * args.steps / dt, pairs_per_step=pairs_total, raw_candidates_per_step=raw_total,
                    kept_per_step=st["kept"], setup_s=t_setup, cold=cold,
                    host_split_s=dict(gpu_call=st["t_gpu_call"], commit=st["t_commit"], finalize=st["t_finalize"], match=st["t_match"]))
