@@ -504,7 +504,7 @@ int l3d_compute_pairwise_matches(l3d_ctx* c,
     va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
     va.N = N; va.seg_begin = seg_begin; va.seg_end = seg_end; va.nrow_total = (int)nrow;
     va.sigma_p = sigma_p; va.sigma_a = sigma_a; va.spatial_k = spatial_k;
-    va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr;
+    va.mmax = mmax; va.only_above = -1; va.skip_above = 0; va.cand_cap = 0; va.res = nullptr; va.bstart_g = nullptr;
     va.big = 0; va.scratch = nullptr; va.scratch_stride = 0; va.kept_cnt = nullptr; va.best_depths = nullptr; va.seg_order = nullptr;
     va.debug = c->opt.vw_debug;
     va.stamps = nullptr;

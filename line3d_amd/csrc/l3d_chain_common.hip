@@ -161,7 +161,7 @@ int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
 
 int chain_reserve_candidates(l3d_ctx* c, const ChainLayout& L, size_t cand_cap, int ring)
 {
-    if (c->opt.vw_split != 0) {     // split verification (k_vw_walk): per segment the bucket starts of its built image, header, 64-bit best, counters | unit table
+    if (c->opt.vw_split != 0 || L.maxN > 16) {     // bucket starts in global memory (more than 16 neighbours) | split verification (k_vw_walk): per segment the bucket starts of its built image, header, 64-bit best, counters | unit table
         const size_t S = (size_t)std::max(L.maxS, 1);
         HIPCHK(c, c->vw_bstart.reserve(S * (kVWBuckets + 1) * 4 + 64));
         HIPCHK(c, c->vw_segstate.reserve(S * 36 + 256));
@@ -210,7 +210,7 @@ VerifyArgs chain_verify_args(l3d_ctx* c, const l3d_chain_view& v, const ChainVie
     va.cand_meta = c->cand_meta.as<uint2>(); va.cand_depths = c->cand_depths.as<float4>(); va.cand_conf = c->cand_conf.as<float>();
     va.N = v.N; va.seg_begin = d.s0; va.seg_end = d.s1; va.nrow_total = v.S_src * v.N;
     va.sigma_p = v.sigma_p; va.sigma_a = v.sigma_a; va.spatial_k = v.spatial_k;
-    va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = nullptr;
+    va.debug = 0; va.stamps = nullptr; va.cand_cap = (int)cand_cap; va.res = nullptr; va.bstart_g = nullptr;
     va.seg_order = c->ch_segorder.as<int>();
     va.mmax = 0; va.only_above = -1; va.skip_above = 0; va.big = 0;
     va.kept_cnt = nullptr; va.best_depths = nullptr; va.scratch = nullptr; va.scratch_stride = 0;
@@ -238,6 +238,7 @@ void chain_launch_verify(l3d_ctx* c, VerifyArgs& va, const ChainViewDev& d, cons
         const int unit = std::max(256, (c->opt.vw_unit / 256) * 256);
         const size_t S = (size_t)(va.seg_end - va.seg_begin);
         const bool want = c->opt.vw_split > 0 || (c->opt.vw_split < 0 && (int)S <= c->opt.vw_wide_max && cand_cap / std::max<size_t>(S, 1) >= (size_t)c->opt.vw_split_avg);
+        if (va.N > 16 && c->opt.vw_gb != 0 && !va.stamps && c->vw_bstart.cap >= S * (kVWBuckets + 1) * 4) va.bstart_g = c->vw_bstart.as<int>();
         VWSplitArgs sp;
         if (want && !va.stamps && c->vw_bstart.cap >= S * (kVWBuckets + 1) * 4 && c->vw_segstate.cap >= S * 36 + 16) {
             sp.split_unit = unit;

@@ -106,6 +106,8 @@ struct VerifyArgs {
     int debug;                      // timing-only ablations (L3D_VW_DEBUG), 0 in production
     unsigned long long* stamps;     // per-phase cycle sums of k_verify_window (diagnostic build: L3D_VW_STAMPS=1), else null
     float sigma_p, sigma_a, spatial_k;
+    int* bstart_g;                  // k_verify_window_gb (more than 16 neighbours): [segments][kVWBuckets + 1] bucket starts of the built images, read by the rounds from
+                                    // global memory -- the LDS they took (with the build's cursors: 16.4 KB) is what kept a workgroup per CU out at 24 neighbours; else null
 };
 // k_verify_window_build + k_vw_walk (big == 2 only): a segment that outgrows the LDS image is only BUILT by its scratch block (bucketed image, bucket
 // starts, header) and its hypotheses are verified in units of split_unit by the workgroups of a second launch -- a launch of FEW segments (one rank's

@@ -239,12 +239,12 @@ __device__ __forceinline__ void vw_unit_table(const VerifyArgs& a, const VWSplit
 // block of k_verify_window (bucketed arrays in the scratch, bucket starts and header in global memory).  The unit verifies its split_unit hypotheses
 // (vw_rounds: the very code of the one-launch kernel) and adds its share of the segment's epilogue with atomics -- kept count, and the first strict
 // maximum in candidate order as ONE 64-bit maximum --; the unit that finishes last writes the best hypothesis' depths (cudawrapper.cu:1037-1062).
-template <int NT>
+template <int NT, bool kGB>
 __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a, VWSplitArgs sp)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
-    __shared__ int s_bstart[kBuckets + 1];
+    __shared__ int s_bstart[kGB ? 1 : kBuckets + 1];          // (kGB -- more than 16 neighbours --: the rounds read the starts where the build left them)
     __shared__ int s_dirty[NW];
     __shared__ int s_rk[NW], s_ri[NW];
     __shared__ float s_rb[NW];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a, VWSplitArgs sp)
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
     const int* bs = sp.bstart_g + (size_t)ys * (kBuckets + 1);
-    for (int i = tid; i <= kBuckets; i += NT) s_bstart[i] = bs[i];
+    if constexpr (!kGB) for (int i = tid; i <= kBuckets; i += NT) s_bstart[i] = bs[i];
     float* smax_wave = smax + wave * 64 * a.N;
     for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;
     if (lane == 0) s_dirty[wave] = 0;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a, VWSplitArgs sp)
     int kept_l = 0, besti_l = 0x7fffffff;
     float best_l = 0.0f;
     unsigned long long t_prev = 0ull, t_acc[5] = { 0, 0, 0, 0, 0 };
-    vw_rounds<NT>(a, L, s_bstart, base, dabs_max, start, h_begin, h_end, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
+    vw_rounds<NT>(a, L, kGB ? bs : s_bstart, base, dabs_max, start, h_begin, h_end, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
     for (int o = 32; o > 0; o >>= 1) {
         kept_l += __shfl_down(kept_l, o);
         const float ob = __shfl_down(best_l, o);
@@ -331,14 +331,19 @@ __global__ __launch_bounds__(NT) void k_vw_walk(VerifyArgs a, VWSplitArgs sp)
 #ifndef L3D_VW_WAVES
 #define L3D_VW_WAVES 0
 #endif
-template <int NT, bool kSplit>
+// kGB: the bucket starts live in GLOBAL memory during the rounds (VerifyArgs::bstart_g) and the build's two bucket tables (starts, cursors: 16.4 KB)
+// alias the per-lane maxima + rings, which the build does not use: 16.4 KB of static LDS less -- at 24 neighbours (24.5 KB of maxima) a workgroup
+// drops from 51.7 to 35.3 KB: four per CU instead of three.  The rounds read two bucket starts per hypothesis, once per round: L2 latency that a
+// round of tens of microseconds does not notice.  Launches of up to 16 neighbours keep the tables in LDS (four workgroups per CU either way).
+template <int NT, bool kSplit, bool kGB>
 __device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSplitArgs& sp)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ int s_dmax, s_base;
-    __shared__ int s_bstart[kBuckets + 1];
-    __shared__ int s_cursor[kBuckets];
+    __shared__ int s_tables[kGB ? 4 : 2 * kBuckets + 4];     // bucket starts [kBuckets + 1] | cursors [kBuckets]  (kGB: in the dynamic region, below)
+    int* s_bstart = s_tables;
+    int* s_cursor = s_tables + kBuckets + 2;
     __shared__ int s_wtot[NW];
     __shared__ int s_dirty[NW];              // per wave: a confidence was recorded in the current group of hypotheses
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -400,9 +405,13 @@ __device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSp
     for (int i = tid; i < a.N * 12; i += NT) sP[i] = a.P[i];
     for (int i = tid; i < a.N; i += NT) sOff[i] = a.offsets[i].x;
     float* smax_wave = smax + wave * 64 * a.N;
+    if constexpr (kGB) {                                                 // (the launcher guarantees NT * N * 4 + rings >= 2 * kBuckets + 4 ints)
+        s_bstart = reinterpret_cast<int*>(smax);
+        s_cursor = s_bstart + kBuckets + 2;
+    }
     // the per-(camera, lane) maxima are zero whenever a group of hypotheses starts: zeroed here once, and again only after a group that recorded
     // something (most groups record nothing: a fifth of the hypotheses has a witness at all, and those cluster on few segments)
-    for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;       // [camera][lane]: conflict-free rows
+    if constexpr (!kGB) for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;       // [camera][lane]: conflict-free rows   (kGB: after the build)
     if (lane == 0) s_dirty[wave] = 0;
     int* dirty = &s_dirty[wave];
 
@@ -477,6 +486,16 @@ __device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSp
     }
     if (tid < kVWSlack && !big) { L.sd1[m + tid] = 0.0f; L.sd2[m + tid] = 0.0f; L.sci[m + tid] = 0u; L.stgt[m + tid] = 0u; }   // (global slices: the prefetch reads a neighbour's entries, never uses them)
     __syncthreads();
+    const int* bst = s_bstart;                                           // what the rounds read
+    if constexpr (kGB) {
+        int* gb = a.bstart_g + (size_t)(y - a.seg_begin) * (kBuckets + 1);
+        for (int b = tid; b <= kBuckets; b += NT) gb[b] = s_bstart[b];
+        __threadfence_block();
+        __syncthreads();                                                 // the tables are copied: their LDS is the maxima's again
+        for (int c = 0; c < a.N; ++c) smax_wave[c * 64 + lane] = 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        bst = gb;
+    }
     if (a.debug == 1) return;
     VW_STAMP(0);
     if constexpr (kSplit) {
@@ -485,7 +504,7 @@ __device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSp
             // of k_vw_walk (the next launch on this stream) verify the hypotheses
             const int ys = y - a.seg_begin;
             int* bs = sp.bstart_g + (size_t)ys * (kBuckets + 1);
-            for (int b = tid; b <= kBuckets; b += NT) bs[b] = s_bstart[b];
+            for (int b = tid; b <= kBuckets; b += NT) bs[b] = bst[b];
             if (tid == 0) { sp.seg_hdr[ys] = make_int4(base, s_dmax, 0, 0); a.kept_cnt[y] = 0; sp.best64[ys] = 0ull; sp.done[ys] = 0; }
             return;
         }
@@ -504,7 +523,7 @@ __device__ __forceinline__ void vw_segment_block(const VerifyArgs& a, const VWSp
     // fused per-segment epilogue (k_seg_post): kept count and the first strict maximum in candidate order
     int kept_l = 0, besti_l = 0x7fffffff;
     float best_l = 0.0f;
-    vw_rounds<NT>(a, L, s_bstart, base, dabs_max, start, 0, m, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
+    vw_rounds<NT>(a, L, bst, base, dabs_max, start, 0, m, q, sP, sOff, smax_wave, dirty, C, ray1, ray2, c_inf, two_sig_d, two_sig_a, gate, kept_l, best_l, besti_l, t_acc, t_prev);
     if (a.kept_cnt) {
         __shared__ int s_rk[NW], s_ri[NW];
         __shared__ float s_rb[NW];
@@ -545,13 +564,19 @@ __attribute__((amdgpu_waves_per_eu(L3D_VW_WAVES, L3D_VW_WAVES)))
 #endif
 void k_verify_window(VerifyArgs a)
 {
-    vw_segment_block<NT, false>(a, VWSplitArgs());
+    vw_segment_block<NT, false, false>(a, VWSplitArgs());
+}
+// more than 16 neighbours: bucket starts in global memory during the rounds (four workgroups per CU instead of three at 24 neighbours)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_verify_window_gb(VerifyArgs a)
+{
+    vw_segment_block<NT, false, true>(a, VWSplitArgs());
 }
 // first launch of a split verification: LDS blocks as ever, scratch blocks build only, one more workgroup writes the unit table
 template <int NT>
 __global__ __launch_bounds__(NT) void k_verify_window_build(VerifyArgs a, VWSplitArgs sp)
 {
-    vw_segment_block<NT, true>(a, sp);
+    vw_segment_block<NT, true, false>(a, sp);
 }
 
 // max candidates per segment (LDS sizing of k_verify_window)
@@ -595,7 +620,7 @@ constexpr int kWideLdsMax = 112 * 1024;
 static bool lds_opt_in(const void* fn, int which)
 {
     static std::mutex mu;
-    static unsigned char done[3][64] = {};
+    static unsigned char done[4][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lk(mu);
@@ -615,7 +640,8 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max, con
         const size_t lds = std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
         if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window_build<256>), 2)) return;
         hipLaunchKernelGGL(k_verify_window_build<256>, dim3(2 * nseg + 1), dim3(256), lds, st, a, *sp);
-        hipLaunchKernelGGL(k_vw_walk<256>, dim3((unsigned)std::max(1, sp->units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a, *sp);
+        if (a.N > 16) hipLaunchKernelGGL((k_vw_walk<256, true>), dim3((unsigned)std::max(1, sp->units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a, *sp);
+        else hipLaunchKernelGGL((k_vw_walk<256, false>), dim3((unsigned)std::max(1, sp->units_max)), dim3(256), verify_window_lds_bytes_big(a.N, 256), st, a, *sp);
         return;
     }
     const dim3 grid(a.big == 2 ? 2 * nseg : nseg);
@@ -627,6 +653,11 @@ void launch_verify_window(const VerifyArgs& a, hipStream_t st, int wide_max, con
         hipLaunchKernelGGL(k_verify_window<512>, grid, dim3(512), lds512, st, a);
     } else {
         const size_t lds = a.big == 1 ? verify_window_lds_bytes_big(a.N, 256) : std::max(verify_window_lds_bytes(a.mmax, a.N), verify_window_lds_bytes_big(a.N, 256));
+        if (a.bstart_g && a.N > 16 && a.big == 2) {         // (the maxima + rings of 17+ cameras hold the build's two tables: 256 * 17 * 4 + 8192 > 16.4 KB)
+            if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window_gb<256>), 3)) return;
+            hipLaunchKernelGGL(k_verify_window_gb<256>, grid, dim3(256), lds, st, a);
+            return;
+        }
         if (!lds_opt_in(reinterpret_cast<const void*>(k_verify_window<256>), 0)) return;
         hipLaunchKernelGGL(k_verify_window<256>, grid, dim3(256), lds, st, a);
     }
