@@ -10,7 +10,7 @@ import sys
 
 NAMES = {"k_pair_mask": "pair_mask", "k_row_count": "row_count", "k_scan": "scan", "k_scan_kept_chain": "scan", "k_scan_kept_slot": "scan",
          "k_pair_fill": "pair_fill", "k_exist_count": "exist", "k_exist_scatter": "exist_scatter", "k_exist_sort_runs": "exist_sort_runs",
-         "k_verify_window": "verify_window", "k_verify": "verify", "k_seg_post": "seg_post", "k_kept_write_chain": "kept_write",
+         "k_verify_window": "verify_window", "k_verify_window_gb": "verify_window", "k_verify": "verify", "k_seg_post": "seg_post", "k_kept_write_chain": "kept_write",
          "k_kept_write": "kept_write", "k_raw_stats": "raw_stats", "k_cand_move": "cand_move", "k_place": "cand_move", "k_pack_view": "pack_view", "k_slot_write": "kept_write", "k_collinearity": "collinearity", "k_collinearity_fill": "collinearity_fill", "k_tgt_rays": "tgt_rays", "k_prod_keys": "prod_keys"}
 
 
