@@ -53,7 +53,19 @@ __global__ void k_exist_count(const Match* __restrict__ arena, const unsigned* _
     // (short lists -- config 2 keeps 36 k matches per view, 1.2 MB -- are scanned record by record: one pass over cache-resident data beats two
     // dependent ones; measured 12.10 vs 12.17-12.29 ms per config-2 pass, 173.2 vs 165.4 ms at 40 x 4000 x 24, profiles/r5_ab_kept_cams.txt)
     const unsigned* kc = cams && n > kCamScanMin ? cams + src->kept_base : nullptr;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kc) {
+        // the side array four entries at a time: one 4-byte load in flight per thread was 1.1 TB/s of a scan that has nothing else to wait for
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            const unsigned c0 = kc[i], c1 = kc[i + stride], c2 = kc[i + 2 * stride], c3 = kc[i + 3 * stride];
+            if (c0 == view_id) { const Match r = kept[i]; if ((int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1); }
+            if (c1 == view_id) { const Match r = kept[i + stride]; if ((int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1); }
+            if (c2 == view_id) { const Match r = kept[i + 2 * stride]; if ((int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1); }
+            if (c3 == view_id) { const Match r = kept[i + 3 * stride]; if ((int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1); }
+        }
+    }
+    for (; i < n; i += stride) {
         if (kc && kc[i] != view_id) continue;
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1);
@@ -131,8 +143,7 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, int bps, const i
     const int n = src->n_kept;
     const Match* kept = arena + src->kept_base;
     const unsigned* kc = cams && n > kCamScanMin ? cams + src->kept_base : nullptr;
-    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += bps * 256) {
-        if (kc && kc[i] != view_id) continue;
+    auto place = [&](int i) {
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) {
             const int row = r.segID2 * N + cam;
@@ -140,6 +151,21 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, int bps, const i
             meta[slot] = make_uint2(r.segID1, (unsigned)cam);
             depths[slot] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
         }
+    };
+    const int stride = bps * 256;
+    int i = bx * 256 + (int)threadIdx.x;
+    if (kc) {                                                    // (four entries of the side array in flight per thread: k_exist_count)
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            const unsigned c0 = kc[i], c1 = kc[i + stride], c2 = kc[i + 2 * stride], c3 = kc[i + 3 * stride];
+            if (c0 == view_id) place(i);
+            if (c1 == view_id) place(i + stride);
+            if (c2 == view_id) place(i + 2 * stride);
+            if (c3 == view_id) place(i + 3 * stride);
+        }
+    }
+    for (; i < n; i += stride) {
+        if (kc && kc[i] != view_id) continue;
+        place(i);
     }
 }
 
