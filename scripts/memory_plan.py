@@ -114,7 +114,7 @@ def plan_segpart(V, S, N, W, kept_ratio):
     cand_cap = 1.25 * cand_view / W
     add("chain", "candidate store + window scratch + stage-1 ring of 10 views, 1/W of every view (released)", cand_cap * 44 + 10 * cand_cap * 24, "chain_reserve_candidates")
     slot_records = int(2.2 * kept_view / W) + 1024           # (a rank's range of segments holds up to twice its share)
-    slot_bytes = 32 + (S // W + 1) * 12 + slot_records * 32
+    slot_bytes = 32 + (S // W + 1) * 12 + slot_records * (36 if slot_records >= 65536 else 32)      # (+ the side array of target cameras on dense scenes)
     ring = window + 18
     add("chain", "send + gathered slots: ring of %d views x %d ranks, %.0f MB slots (released)" % (ring, W, slot_bytes / 2**20), ring * (W + 1) * slot_bytes, "l3d_chain_sharded.hip:l3d_shard_chain_run (ring mode)")
     add("products", "key blocks: 2 x 8 B keys + flag + position per slot, bounded (released)", min(1 << 28, 2 * local_kept + 1) * 24, "l3d_products.hip:build_products (ProdBlock)")
