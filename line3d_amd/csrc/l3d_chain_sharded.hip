@@ -527,13 +527,17 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
                                    h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
                                    c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
         }
-        if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {          // (the window kernel orders the runs itself)
+        // (the window kernel orders the runs itself -- except on a rank's small launch of a dense scene: a segment's workgroup ranks its 12 runs three per
+        // wave, one after the other, and the launch waits for the heaviest segment; a launch of one wave per run is balanced.  Same rule as the split verification)
+        const bool sort_apart = v.n_sources && c->opt.exist_sort_apart != 0 && (c->opt.exist_sort_apart > 0 ||
+                                ((d.s1 - d.s0) <= c->opt.vw_wide_max && h->cand_cap / (size_t)std::max(1, d.s1 - d.s0) >= (size_t)c->opt.vw_split_avg));
+        if (v.n_sources && (!(c->verify_mode == 0 && verify_window_supported(N)) || sort_apart)) {
             ProfScope p(c, "exist");
             launch_exist_sort_runs(d_sc, v.n_sources, N, S, c->row_start.as<int>(), c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap, st, d.s0, d.s1,
                                    c->vw_scratch.as<float>(), (long long)h->cand_cap + kVWSlack, c->cand_conf.as<unsigned>());
         }
         VerifyArgs va = chain_verify_args(c, v, d, dtab, h->cand_cap);
-        chain_launch_verify(c, va, d, d_sc, v.n_sources, deferred ? -1 : h->hstats[2 * k + 1], h->cand_cap, st);
+        chain_launch_verify(c, va, d, d_sc, sort_apart ? 0 : v.n_sources, deferred ? -1 : h->hstats[2 * k + 1], h->cand_cap, st);
         mmax = va.mmax;
         {
             ProfScope p(c, "kept_write");
@@ -560,7 +564,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
         mix((unsigned long long)d.s0); mix((unsigned long long)d.s1); mix((unsigned long long)d.o_sc); mix((unsigned long long)d.o_si); mix((unsigned long long)d.o_l2g);
         mix((unsigned long long)__float_as_uint_host(v.sigma_p)); mix((unsigned long long)__float_as_uint_host(v.sigma_a)); mix((unsigned long long)__float_as_uint_host(v.spatial_k));
         mix((unsigned long long)c->verify_mode); mix((unsigned long long)verify_window_max_lds(c->opt.vw_lds)); mix((unsigned long long)c->opt.vw_wide_max); mix((unsigned long long)c->opt.vw_debug);
-        mix((unsigned long long)c->opt.vw_split); mix((unsigned long long)c->opt.vw_unit); mix((unsigned long long)c->opt.vw_split_avg);
+        mix((unsigned long long)c->opt.vw_split); mix((unsigned long long)c->opt.vw_unit); mix((unsigned long long)c->opt.vw_split_avg); mix((unsigned long long)c->opt.exist_sort_apart);
         if (G->exec && G->sig == sig) {
             if (hipGraphLaunch(G->exec, st) == hipSuccess) { ++c->shard_graph_launches; return L3D_OK; }
             (void)hipGetLastError();

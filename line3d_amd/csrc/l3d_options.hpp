@@ -45,6 +45,7 @@ namespace l3d {
     X(block_recover, "L3D_BLOCK_RECOVER", 1, "views sharded in blocks: 1 = a block whose cold-started speculation failed is re-run warm from its predecessor's true lists, 0 = any miss ends the call with verdict 1 (round 4; A/B)") \
     X(slot_cams_min, "L3D_SLOT_CAMS_MIN", 65536, "sharded chain: slots of at least this many records carry a 4-byte side array of target cameras (0: always; tests)") \
     X(vw_gb, "L3D_VW_GB", 1, "k_verify_window at more than 16 neighbours: 1 = bucket starts in global memory during the rounds (four workgroups per CU at 24 neighbours), 0 = in LDS (A/B)") \
+    X(exist_sort_apart, "L3D_EXIST_SORT_APART", -1, "sharded chain: reverse-match runs ranked by a launch of their own (one wave per run) instead of the segment's workgroup: 1 always, 0 never, -1 a rank's small launches on dense scenes") \
     X(vw_split, "L3D_VW_SPLIT", -1, "k_verify_window: long segments built by the first launch, verified in units by a second (k_vw_walk): 1 always, 0 never, -1 launches of few segments on dense scenes") \
     X(vw_unit, "L3D_VW_UNIT", 1024, "hypotheses per unit of the split verification (a multiple of 256)")                               \
     X(vw_split_avg, "L3D_VW_SPLIT_AVG", 4096, "vw_split = -1: split when the candidate capacity per segment of the launch is at least this") \
