@@ -47,7 +47,7 @@ namespace l3d {
     X(vw_gb, "L3D_VW_GB", 1, "k_verify_window at more than 16 neighbours: 1 = bucket starts in global memory during the rounds (four workgroups per CU at 24 neighbours), 0 = in LDS (A/B)") \
     X(exist_sort_apart, "L3D_EXIST_SORT_APART", -1, "sharded chain: reverse-match runs ranked by a launch of their own (one wave per run) instead of the segment's workgroup: 1 always, 0 never, -1 a rank's small launches on dense scenes") \
     X(vw_split, "L3D_VW_SPLIT", -1, "k_verify_window: long segments built by the first launch, verified in units by a second (k_vw_walk): 1 always, 0 never, -1 launches of few segments on dense scenes") \
-    X(vw_unit, "L3D_VW_UNIT", 1024, "hypotheses per unit of the split verification (a multiple of 256)")                               \
+    X(vw_unit, "L3D_VW_UNIT", 512, "hypotheses per unit of the split verification (a multiple of 256; emulated rank of eight at 64 x 4000 x 24: 256 -> 95.6, 512 -> 90.7, 1024 -> 92.4, 2048 -> 99.0 ms)")                               \
     X(vw_split_avg, "L3D_VW_SPLIT_AVG", 4096, "vw_split = -1: split when the candidate capacity per segment of the launch is at least this") \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
