@@ -325,3 +325,38 @@ def test_config3_512_views_sharded_by_blocks_of_views_equal_the_one_chain():
         assert digest_lists({v["id"]: ls[r].view_matches(v["id"]) for v in scene.views}) == want, "rank %d" % r
     for l in ls:
         l.close()
+
+
+def test_window_kernel_variants_agree_at_20_neighbours():
+    """The instantiations of k_verify_window that only exist above 16 neighbours or on a rank's small launches against
+    the plain one: bucket starts in global memory (k_verify_window_gb), the split verification in units (k_verify_window_build + k_vw_walk, units
+    of 256 and 512 hypotheses, with the starts in LDS and in global memory), and the all-pairs loop of K_verify_matches (cudawrapper.cu:614-714) --
+    every kept list and median of a 36-view chain with 20 neighbours."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    V, S, N = 36, 700, 20
+    scene = make_scene(V, S, N, seed=314)
+
+    def run(options=None, verify_mode=None):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        for k, v in (options or {}).items():
+            l.context().set_option(k, v)
+        if verify_mode is not None:
+            l.context().set_verify_mode(verify_mode)
+        l.match_views()
+        assert l.match_path() == 0
+        d = digest_lists({v["id"]: l.view_matches(v["id"]) for v in scene.views})
+        kept = int(l.stats()["kept"])
+        l.close()
+        return d, kept
+    ref, kept = run({"L3D_VW_GB": 0, "L3D_VW_SPLIT": 0})
+    assert kept > 300000
+    for name, opts in (("bucket starts in global memory", {"L3D_VW_GB": 1, "L3D_VW_SPLIT": 0}),
+                       ("split, units of 512, starts in LDS during the build", {"L3D_VW_GB": 0, "L3D_VW_SPLIT": 1}),
+                       ("split, units of 256", {"L3D_VW_GB": 1, "L3D_VW_SPLIT": 1, "L3D_VW_UNIT": 256}),
+                       ("defaults", {})):
+        assert run(opts) == (ref, kept), name
+    assert run(verify_mode=1) == (ref, kept), "all-pairs verification"
