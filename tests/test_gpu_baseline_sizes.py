@@ -360,3 +360,31 @@ def test_window_kernel_variants_agree_at_20_neighbours():
                        ("defaults", {})):
         assert run(opts) == (ref, kept), name
     assert run(verify_mode=1) == (ref, kept), "all-pairs verification"
+
+
+@pytest.mark.parametrize("chunk", [0, 7])
+def test_affinity_fill_short_list_path_equals_the_general_path(chunk):
+    """clusterSegments2D's fill (line3D.cc:968-1221) on a symmetric collinearity table (segments.h:94-95): "does an expanded earlier target list c"
+    asked from c's own list and k_aff_groups resolving by collinear predecessors (L3D_AFF_SYM=1, the default) against the general path that walks
+    every earlier target (L3D_AFF_SYM=0) -- the affinity list, node table and lines; also with passes of 7 targets (groups spanning passes)."""
+    from helpers import assert_lines_equal
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    V, S, N = 24, 500, 8
+    scene = make_scene(V, S, N, seed=99)
+    out = []
+    for sym in (0, 1):
+        l = Line3D("", matchingNeighbors=N)
+        load_scene(l, scene)
+        l.prepare()
+        l.context().set_option("L3D_AFF_SYM", sym)
+        if chunk:
+            l.context().set_option("L3D_AFF_CHUNK", chunk)
+        l.match_views()
+        l.finish(False)
+        A, n_nodes = l.affinity()
+        out.append((A.copy(), n_nodes, l.getResult()))
+        l.close()
+    assert len(out[0][0]) > 20000 and out[0][1] == out[1][1]
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    assert_lines_equal(out[1][2], out[0][2], 0.0)
