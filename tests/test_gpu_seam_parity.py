@@ -399,7 +399,9 @@ def _literal_affinity(oracle_lib, seg_base, hyp, score, hyp_dense, best, pot, co
 
 
 @pytest.mark.parametrize("seed,one_way,chunk,blocks", [(1, 0.0, None, None), (2, 0.15, None, (300, 40)), (3, 0.15, "3", None), (4, 0.5, "1", (57, 1000000)), (5, 0.0, "2", (1000000, 7)),
-                                                       (6, 0.1, None, (1, 1))])
+                                                       (6, 0.1, None, (1, 1)),
+                                                       # seeds 7-9: SYMMETRIC collinearity lists (what the reference always has, segments.h:94-95): the short-list path of the fill
+                                                       (7, 0.0, None, None), (8, 0.15, "3", None), (9, 0.1, None, (1, 1))])
 def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib, monkeypatch, seed, one_way, chunk, blocks):
     """l3d_affinity_fill on random flat tables -- clustered hypotheses so that many similarities pass, long target groups,
     targets without a hypothesis, collinearity lists that are NOT symmetric, potential correspondences recorded one way only
@@ -413,7 +415,8 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
     gpu_ctx.set_option("L3D_AFF_WORD_BLOCK", blocks[1] if blocks else 0)
     rng = np.random.default_rng(seed)
     V, S = 7, 40
-    dense = seed == 6                    # groups of more than 64 targets and collinearity lists of more than 64 entries (64-lane passes)
+    dense = seed in (6, 9)               # groups of more than 64 targets and collinearity lists of more than 64 entries (64-lane passes)
+    p_sym = 1.0 if seed >= 7 else 0.8
     if dense:
         V, S = 4, 260
     seg_base = np.arange(V + 1, dtype=np.int32) * S
@@ -460,7 +463,7 @@ def test_affinity_fill_tables_against_the_literal_used_rule(gpu_ctx, oracle_lib,
                 continue
             w = np.float32(rng.uniform(0.05, 1.0))
             coll[d][x] = w
-            if rng.random() < 0.8:                                       # mostly, not always, symmetric
+            if rng.random() < p_sym:                                     # (seeds 1-6: mostly, not always, symmetric: the general path)
                 coll[x][d] = w
     coll = [sorted(c.items()) for c in coll]
     pot_start = np.zeros(nd + 1, np.int64); pot_start[1:] = np.cumsum([len(p) for p in pot])
