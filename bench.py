@@ -189,7 +189,8 @@ def profile_for_shape(kind, segments, neighbors):
             found.append((int(m.group(1)), q, d))
     if not found:
         return {}, None
-    _r, q, d = max(found, key=lambda t: (t[0], t[1]))
+    # within a round the FINAL summary is the un-suffixed r<N>_<kind>.json; named ones (r<N>_v2_<kind>.json: mid-round) only when there is no final
+    _r, q, d = max(found, key=lambda t: (t[0], os.path.basename(t[1]) == "r%d_%s.json" % (t[0], kind), os.path.getmtime(t[1]), t[1]))
     return d, "profiles/%s @%s shape %s" % (os.path.basename(q), d.get("_commit", "unstamped"), "x".join(str(x) for x in d.get("_shape", [64, 2000, 12])))
 
 
@@ -389,6 +390,9 @@ def main():
         roof = None
         traffic_json, traffic_src = profile_for_shape("traffic", args.segments, args.neighbors)
         valu_json, valu_src = profile_for_shape("valu", args.segments, args.neighbors)
+        if traffic_json and valu_json and traffic_json.get("_commit") != valu_json.get("_commit"):
+            # both summaries are passes of ONE measure_round.sh run: counters of two commits are not mixed in one line
+            traffic_json, traffic_src = {}, "dropped: %s is not of the commit of %s" % (traffic_src, valu_src)
         # wave64 VALU instructions/s the chip can issue: 256 CUs x 4 SIMD-32s x 2.4 GHz, one wave64 instruction per SIMD every 2 cycles
         # (MI355X_MICROARCH.md, constants table: `v_fma_f32` (wave64) 2 cyc; 4 is what ONE wave alone sustains).  Equivalent to the 157.3 TFLOP/s
         # FP32 vector peak (64 lanes x 2 flop per FMA).  Transcendental / rcp / sqrt instructions cost twice that; the count below is unweighted,
@@ -486,6 +490,8 @@ def main():
                 out["stage_rates"] = dict(stage1_pairs_per_s=pairs_local / (s1 * 1e-3), stage1_kernel_ms=round(s1, 3),
                                           stage2_candidates_per_s=raw_local / (s2 * 1e-3), stage2_kernel_ms=round(s2, 3),
                                           note="per-pass kernel time of each stage measured with every kernel bracketed (untimed pass)")
+        if args.partition:
+            out["rest_of_compute3Dmodel"] = dict(skipped="partitioned job: the finish is the collective one (l3d_line3d_finish_sharded), not part of this line")
         if dist is None and not args.no_extras:
             # the rest of compute3Dmodel on the same scene, untimed w.r.t. `value` (affinity edges/s, diffusion):
             # greedy selection + affinity fill (device) + [diffusion +] edge order (device) + union-find + line fit (host).
@@ -523,6 +529,8 @@ def main():
                 lists = {v["id"]: l3d.view_matches(v["id"])[0] for v in scene.views[: len(scene.views) // 2]}
             out["cpu_baseline"] = cpu_baseline(scene, args.neighbors, args.cpu_sample_segments, lists)
     l3d.close()
+    if part_link is not None and part_link is not sharded_mode["link"]:
+        part_link.close()                         # (--partition at --gpus 1: a communicator of one rank of its own)
     if sharded_mode["link"] is not None:
         sharded_mode["link"].close()
     if dist is not None:

@@ -198,7 +198,13 @@ int l3d_line3d_prepare(l3d_line3d* h) { return h ? prepare(h) : L3D_ERR_INVALID;
 int l3d_line3d_match_views(l3d_line3d* h)
 {
     if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
-    return match_views(h);
+    const int rc = match_views(h);
+    // verbose: the counters compute_pairwise_matches prints per view (cudawrapper.cu:953,1114; line3D.cc:652), as totals of the pass -- the resident
+    // chain never hands a view's lists to the host
+    if (!rc && h->verbose)
+        printf("[L3D] #raw_matches:          %.0f (all views)\n[L3D] #filtered_matches (2): %.0f (all views)\n[L3D] segment pairs tested:  %.0f\n",
+               h->stat_raw, h->stat_kept, h->stat_pairs);
+    return rc;
 }
 int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
@@ -210,6 +216,9 @@ int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
     if (hopt(h).timing) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "greedy selection", (now_s() - t0) * 1e3);
     const int rc = cluster_segments_2D(h, perform_diffusion != 0);
     if (hopt(h).timing) fprintf(stderr, "[l3d finish] %-28s %8.2f ms\n", "total", (now_s() - t0) * 1e3);
+    if (!rc && h->verbose)      // line3D.cc:959-961, 1226-1229, 1251
+        printf("[L3D] #clusterable_segments:  %zu\n[L3D] A: #num_entries = %zu\n[L3D] A: #num_rows    = %zu\n[L3D] %zu 3D lines found!\n",
+               h->hyps.size(), h->n_edges, h->local2global.size(), h->result.size());
     return rc;
 }
 // Line3D::compute3Dmodel, line3D.cc:345-374
