@@ -1,9 +1,10 @@
 // line3D_amd.hpp -- C++ facade with the reference's public interface (class L3D::Line3D, line3D.h:61-101)
 // over the C ABI of include/line3d_amd.h.  Same method names, argument order and defaults (commons.h:42-61).
-// Differences forced by the scope: `cv::Mat image` is replaced by the segments the detector would have produced
-// (std::vector<float4>, the side door the reference itself has in L3DSegments(list<float4>&, bool), segments.h:60)
-// plus the image size; cameras are plain row-major double arrays or any matrix type with K(i, j) / t(i) access (Eigen's, as the
-// reference's drivers pass them) -- Eigen itself is not needed to compile this header.
+// addImage / addImage_fixed_sim come in two families: (1) the reference's own signatures -- `image` (anything with .cols / .rows: cv::Mat),
+// K, R, t matrix-typed (anything with K(i, j) / t(i): Eigen's) -- whose segments come from the segment cache of the data directory, the
+// reference's own side door for precomputed segments (line3D.cc:143-168); (2) width, height and the segments the detector would have
+// produced (std::vector<float4>, the side door of L3DSegments(list<float4>&, bool), segments.h:60), cameras as plain row-major arrays or
+// matrix types.  Neither OpenCV nor Eigen is needed to compile this header.
 #pragma once
 
 #include <array>
@@ -126,6 +127,39 @@ public:
         double k[9], r[9], tt[3];
         flatten(K, R, t, k, r, tt);
         addImage_fixed_sim(imageID, width, height, segments, k, r, tt, viewSimilarity, maxImgWidth, loadAndStoreSegments);
+    }
+    // The reference's OWN signatures (line3D.h:69-79): `image` as the second parameter -- cv::Mat in the reference, here any type with
+    // `.cols` / `.rows` (cv::Mat itself when OpenCV is there; OpenCV is not a dependency of this header), K / R / t matrix-typed as above.
+    // main_vsfm.cpp:273 / main_bundler.cpp:287 compile against these unchanged.  The image gives the view its size; its PIXELS are not read:
+    // line-segment detection is not part of this library, so the segments come from the reference's side door, the segment cache
+    // "<data_directory>/segments_<id>_<w'>x<h'>_coll<0|1>.bin" of an earlier run (w' x h' after the maxImgWidth rule, line3D.cc:130-150).
+    // No such file: the error is printed and the call returns without a view (where the reference would run LSD, line3D.cc:169-190).
+    // loadAndStoreSegments = false removes the file like the reference does (line3D.cc:153-156) -- and then there is nothing to add.
+    template <class Img, class M3, class V3, class = decltype(std::declval<const Img&>().cols), class = decltype(std::declval<const Img&>().rows),
+              class = decltype(std::declval<const M3&>()(0, 0)), class = decltype(std::declval<const V3&>()(0))>
+    void addImage(const unsigned int imageID, const Img& image, const M3& K, const M3& R, const V3& t, std::list<unsigned int>& worldpointIDs,
+                  const int maxImgWidth = 1920, const bool loadAndStoreSegments = true)
+    {
+        double k[9], r[9], tt[3];
+        flatten(K, R, t, k, r, tt);
+        const unsigned int w = image.cols > 0 ? (unsigned int)image.cols : 0u, h = image.rows > 0 ? (unsigned int)image.rows : 0u;
+        std::vector<uint32_t> wps(worldpointIDs.begin(), worldpointIDs.end());
+        report(l3d_line3d_add_image_ex(h_, imageID, w, h, nullptr, 0, k, r, tt, wps.data(), (int)wps.size(), data_directory_.c_str(), maxImgWidth,
+                                       loadAndStoreSegments ? 1 : 0));
+    }
+    template <class Img, class M3, class V3, class = decltype(std::declval<const Img&>().cols), class = decltype(std::declval<const Img&>().rows),
+              class = decltype(std::declval<const M3&>()(0, 0)), class = decltype(std::declval<const V3&>()(0))>
+    void addImage_fixed_sim(const unsigned int imageID, const Img& image, const M3& K, const M3& R, const V3& t, std::map<unsigned int, float>& viewSimilarity,
+                            const int maxImgWidth = 1920, const bool loadAndStoreSegments = true)
+    {
+        double k[9], r[9], tt[3];
+        flatten(K, R, t, k, r, tt);
+        const unsigned int w = image.cols > 0 ? (unsigned int)image.cols : 0u, h = image.rows > 0 ? (unsigned int)image.rows : 0u;
+        std::vector<uint32_t> ids;
+        std::vector<float> sims;
+        for (auto& kv : viewSimilarity) { ids.push_back(kv.first); sims.push_back(kv.second); }
+        report(l3d_line3d_add_image_fixed_sim_ex(h_, imageID, w, h, nullptr, 0, k, r, tt, ids.data(), sims.data(), (int)ids.size(), data_directory_.c_str(),
+                                                 maxImgWidth, loadAndStoreSegments ? 1 : 0));
     }
     // line3D.h:82
     void compute3Dmodel(bool perform_diffusion = false) { report(l3d_line3d_compute3Dmodel(h_, perform_diffusion ? 1 : 0)); }

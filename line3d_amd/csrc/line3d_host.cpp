@@ -117,7 +117,7 @@ int l3d_line3d_add_image_cached(l3d_line3d* h, uint32_t id, unsigned width, unsi
 // the cache decisions of addImage / addImage_fixed_sim, line3D.cc:128-199: returns 1 when the view was added from the cache file,
 // 0 when the caller's segments are to be used (cache_path set when the file is to be written), < 0: error code negated
 static int add_from_cache_or_plan_write(l3d_line3d* h, uint32_t id, unsigned width, unsigned height, const double* K, const double* R, const double* t,
-                                        const char* data_directory, int max_img_width, int load_and_store, std::string& cache_path)
+                                        const char* data_directory, int max_img_width, int load_and_store, std::string& cache_path, std::string* expected = nullptr)
 {
     unsigned new_w = width, new_h = height;
     if (max_img_width > 0 && (int)std::max(width, height) > max_img_width) {                 // :133-138
@@ -128,6 +128,7 @@ static int add_from_cache_or_plan_write(l3d_line3d* h, uint32_t id, unsigned wid
     char name[160];
     if (l3d_segment_cache_filename(id, new_w, new_h, h->use_collinearity ? 1 : 0, name, sizeof(name)) != L3D_OK) return -L3D_ERR_INVALID;
     const std::string file = std::string(data_directory ? data_directory : "") + name;
+    if (expected) *expected = file;
     FILE* f = fopen(file.c_str(), "rb");
     const bool exists = f != nullptr;
     if (f) fclose(f);
@@ -158,10 +159,14 @@ int l3d_line3d_add_image_ex(l3d_line3d* h, uint32_t id, unsigned width, unsigned
     if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
     if (n_wps == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
     if (width == 0 || height == 0 || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "image is empty!");
-    std::string cache_path;
-    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path);
+    std::string cache_path, expected;
+    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path, &expected);
     if (from_cache < 0) return -from_cache;
     if (!from_cache) {
+        // the image-typed overloads of the facade bring no segments: where the reference would detect them (line3D.cc:169-190) this library stops
+        if (n <= 0 || !segs)
+            return h->fail(L3D_ERR_INVALID, ("image [" + std::to_string(id) + "]: no segment cache " + expected + " and no segments given -- line segment "
+                                             "detection is not part of this library (run the reference once with loadAndStoreSegments, or pass the segments)").c_str());
         const int rc = add_common(h, id, width, height, segs, n, K, R, t, n_wps);
         if (rc) return rc;
         h->views[id].cache_to_write = cache_path;
@@ -179,10 +184,14 @@ int l3d_line3d_add_image_fixed_sim_ex(l3d_line3d* h, uint32_t id, unsigned width
     if (h->views.count(id)) return h->fail(L3D_ERR_INVALID, "imageID already in use!");
     if (n_sims == 0) return h->fail(L3D_ERR_INVALID, "unlinked images cannot be added!");
     if (width == 0 || height == 0 || !K || !R || !t) return h->fail(L3D_ERR_INVALID, "image is empty!");
-    std::string cache_path;
-    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path);
+    std::string cache_path, expected;
+    const int from_cache = add_from_cache_or_plan_write(h, id, width, height, K, R, t, data_directory, max_img_width, load_and_store, cache_path, &expected);
     if (from_cache < 0) return -from_cache;
     if (!from_cache) {
+        // the image-typed overloads of the facade bring no segments: where the reference would detect them (line3D.cc:169-190) this library stops
+        if (n <= 0 || !segs)
+            return h->fail(L3D_ERR_INVALID, ("image [" + std::to_string(id) + "]: no segment cache " + expected + " and no segments given -- line segment "
+                                             "detection is not part of this library (run the reference once with loadAndStoreSegments, or pass the segments)").c_str());
         const int rc = add_common(h, id, width, height, segs, n, K, R, t, n_sims);
         if (rc) return rc;
         h->views[id].cache_to_write = cache_path;

@@ -43,3 +43,61 @@ def test_facade_compiles_and_links():
                                "-Wl,-rpath," + lib, "-o", exe])
         # without a GPU the constructor reports and every call degrades to a no-op, like the reference's print-and-return
         assert subprocess.run([exe], stderr=subprocess.DEVNULL).returncode == 0
+
+
+REFERENCE = "/root/reference"
+
+
+def _build_driver(td):
+    lib = os.path.join(ROOT, "line3d_amd")
+    exe = os.path.join(td, "driver_reference_signatures")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "driver_reference_signatures.cpp"), "-L" + lib, "-lline3d_amd", "-Wl,-rpath," + lib, "-o", exe])
+    return exe
+
+
+def test_reference_signatures_compile_and_link():
+    """line3D.h:69-79 as the reference declares them -- addImage(id, image, K, R, t, worldpointIDs, maxImgWidth, loadAndStoreSegments) with a cv::Mat-
+    shaped image and Eigen-shaped cameras (tests/cpp/ref_type_doubles.hpp) -- resolve against the facade: the drivers' flow compiles and links."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_driver(td)
+        assert subprocess.run([exe], stderr=subprocess.DEVNULL).returncode == 2       # (usage: no arguments)
+
+
+def test_reference_driver_text_compiles_against_the_facade():
+    """The reference's OWN driver lines (main_vsfm.cpp: the constructor call :115-119, the image / intrinsics block :226-241, addImage :272-273 and
+    everything from compute3Dmodel to `delete line3D` :276-328; main_bundler.cpp:287) read from /root/reference at test time -- nothing of them is
+    kept here -- inside a function whose parameters are the variables those lines use, compiled and linked against include/line3D_amd.hpp with the
+    type doubles.  Skipped where the reference is absent (the GPU box)."""
+    import pytest
+    src = os.path.join(REFERENCE, "main_vsfm.cpp")
+    if not os.path.exists(src):
+        pytest.skip("no /root/reference here")
+    lines = open(src).read().split("\n")
+    bund = open(os.path.join(REFERENCE, "main_bundler.cpp")).read().split("\n")
+
+    def rng(a, b, text=lines):
+        return "\n".join(text[a - 1:b])
+    assert "new L3D::Line3D(data_directory,neighbors" in lines[115] and "line3D->addImage(i,image,K" in lines[272] and "delete line3D" in lines[327]
+    assert "line3D->addImage(i,image,K" in bund[286]
+    tu = r'''
+#include <cmath>
+#include <sstream>
+#include <vector>
+#include "ref_type_doubles.hpp"
+#include "line3D_amd.hpp"
+int reference_driver_lines(std::string inputFolder, std::string outputFolder, std::string data_directory, int max_width, int neighbors, float max_uncertainty,
+                           float min_uncertainty, bool diffusion, bool verbose, bool loadAndStore, bool collinearity, float sigma_a, float sigma_p,
+                           float min_baseline, std::string prefix, unsigned int num_cams, std::vector<std::string>& cams_imgFilenames,
+                           std::vector<float>& cams_focals, std::vector<Eigen::Matrix3d>& cams_rotation, std::vector<Eigen::Vector3d>& cams_translation,
+                           std::vector<std::list<unsigned int> >& cams_worldpointIDs)
+{
+''' + rng(115, 119) + "\n    for(unsigned int i=0; i<num_cams; ++i)\n    {\n" + rng(228, 241) + "\n" + rng(272, 273) + "\n" + rng(287, 287, bund) + "\n    }\n" \
+        + rng(276, 328) + "\n    return 0;\n}\nint main() { return 0; }\n"
+    lib = os.path.join(ROOT, "line3d_amd")
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "ref_lines.cpp")
+        open(p, "w").write(tu)
+        r = subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "cpp"), p, "-L" + lib,
+                            "-lline3d_amd", "-Wl,-rpath," + lib, "-o", os.path.join(td, "ref_lines")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]

@@ -188,6 +188,64 @@ def test_cpp_driver_over_segment_caches_matches_oracle(sfm_scene, tmp_path):
             assert np.allclose(gp, p, rtol=0, atol=1e-4) and np.allclose(gq, q, rtol=0, atol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_width", [-1, 960])
+def test_reference_signature_driver_replays_cached_scene(sfm_scene, tmp_path, max_width):
+    """tests/cpp/driver_reference_signatures.cpp: main_vsfm's flow with the reference's OWN addImage signature (line3D.h:69-73: id, image, K, R, t,
+    world points, maxImgWidth, loadAndStoreSegments) -- the image a cv::Mat-shaped size stub, cameras Eigen-shaped, segments from the segment caches
+    under the name the maxImgWidth rule gives (line3D.cc:130-150).  Its TXT result against the oracle; its three guarded calls add nothing."""
+    import subprocess
+    import l3d_oracle_pipeline as op
+    from line3d_amd import sfm
+    from line3d_amd.io import load_txt, segment_cache_filename
+    from test_facade_header import _build_driver
+    sc, pts = sfm_scene
+    nvm = str(tmp_path / "scene.nvm")
+    write_nvm(nvm, sc, pts)
+    img_dir, out_dir = str(tmp_path / "images"), str(tmp_path / "out")
+    data_dir = out_dir + "/L3D_data"
+    os.makedirs(img_dir)
+    os.makedirs(data_dir)
+    olib = op.load_lib()
+    for i, v in enumerate(sc.views):
+        w, h = v["width"], v["height"]
+        open(os.path.join(img_dir, "img_%04d.jpg" % i), "w").write("%d %d\n" % (w, h))       # (what the cv::imread double reads)
+        nw, nh = w, h
+        if max_width > 0 and max(w, h) > max_width:                                          # line3D.cc:133-138
+            scale = np.float32(max_width) / np.float32(max(w, h))
+            nw, nh = int(np.round(np.float32(w) * scale)), int(np.round(np.float32(h) * scale))
+        rel = op.collinearity(olib, v["segments"], 2.0)
+        coll = {}
+        ii, jj = np.nonzero(np.triu(rel > 0.0, 1))
+        for a, b in zip(ii.tolist(), jj.tolist()):
+            coll.setdefault(a, {})[b] = rel[b, a]
+            coll.setdefault(b, {})[a] = rel[b, a]
+        if i != len(sc.views) - 1 or max_width > 0:
+            osfm.write_segment_cache(data_dir + segment_cache_filename(i, nw, nh, True), v["segments"], coll)
+    # at the native size the LAST camera has no cache: the reference would detect its segments; here the call prints and returns, the view is missing
+    n_added = len(sc.views) - (0 if max_width > 0 else 1)
+    exe = _build_driver(str(tmp_path))
+    r = subprocess.run([exe, nvm, img_dir, out_dir, "6", "0", str(max_width)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "#images:         %d" % n_added in r.stdout
+    assert "imageID already in use!" in r.stderr and "image is empty!" in r.stderr and "no segment cache" in r.stderr
+    assert "3D lines found!" in r.stdout and "#filtered_matches (2):" in r.stdout            # verbose = true: the reference's counters
+    txt = os.path.join(out_dir, sfm.result_basename(neighbors=6).replace("W_-1", "W_%d" % max_width) + ".txt")
+    got = load_txt(txt)
+    cams, _ = osfm.read_nvm(nvm)
+    o = op.OracleLine3D(matching_neighbors=6)
+    for i, c in enumerate(cams[:n_added]):
+        w, h = sc.views[i]["width"], sc.views[i]["height"]
+        assert o.add_image(i, w, h, sc.views[i]["segments"], osfm.intrinsics(c["focal"], w, h), c["R"], c["t"], list(c["worldpoints"]))
+    o.compute3Dmodel(False)
+    assert len(got) == len(o.result) > 0
+    for (g2, g3), (o2, o3) in zip(got, o.result):
+        assert [(c, s) for c, s, _ in g2] == [tuple(k) for k in o2]
+        assert len(g3) == len(o3)
+        for (gp, gq), (p, q) in zip(g3, o3):
+            assert np.allclose(gp, p, rtol=0, atol=1e-4) and np.allclose(gq, q, rtol=0, atol=1e-4)
+
+
 def test_sfm_readers_survive_corrupted_files(sfm_scene, tmp_path):
     """Truncated and garbled NVM / bundler files: the readers return cameras or raise with a message; they never crash and never
     trust a count the file cannot back."""
