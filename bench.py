@@ -456,7 +456,7 @@ def main():
             if tot_vi > 0:
                 km = roof["kernels_ms"]
                 s1 = sum(km.get(k, 0.0) for k in ("pair_mask", "row_count", "pair_fill", "tgt_rays"))
-                s2 = sum(km.get(k, 0.0) for k in ("scan", "cand_move", "exist", "verify_window", "verify", "seg_post", "kept_write", "prod_keys", "prod_sort"))
+                s2 = sum(km.get(k, 0.0) for k in ("scan", "cand_move", "exist", "verify_window", "verify", "seg_post", "kept_write", "prod_keys", "prod_sort", "prod_rows"))
                 busy_ms = max(s1, s2)
                 roof["pass"] = dict(valu_wave_insts=tot_vi, issue_frac_of_wall=tot_vi / (ms_per_step * 1e-3) / PEAK_ISSUE,
                                     issue_frac_of_gpu_busy=(tot_vi / (busy_ms * 1e-3) / PEAK_ISSUE) if busy_ms > 0 else None, gpu_busy_ms=busy_ms,

@@ -26,7 +26,7 @@ static_assert(sizeof(l3d_match) == 32, "l3d_match is 32 bytes");
 static_assert(sizeof(l3d_hypothesis) == sizeof(Hypothesis), "l3d_hypothesis layout");
 
 namespace {
-const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity;tgt_rays;prod_keys;prod_sort;hypotheses;uf_components";
+const char* kProfNames = "pair_mask;row_count;scan;pair_fill;cand_move;exist;verify;verify_window;seg_post;kept_write;collinearity;collinearity_fill;rownorm;diffusion_step;similarity;tgt_rays;prod_keys;prod_sort;prod_rows;hypotheses;uf_components";
 }  // namespace
 
 namespace l3d {
@@ -145,7 +145,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     for (auto e : c->prof_event_pool) (void)hipEventDestroy(e);
     for (auto e : c->local_event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->vw_bstart, &c->vw_segstate, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_keptcam, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->vw_bstart, &c->vw_segstate, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_keptcam, &c->ch_rt, &c->ch_rtinfo, &c->ch_rtjobs, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
                        &c->ch_rays, &c->aff_hyp, &c->aff_first, &c->aff_pass_pairs, &c->aff_pass_w, &c->aff_l2g, &c->edges_keep, &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->ch_bestpos.release(); c->ch_hdr.release();
@@ -264,9 +264,13 @@ int l3d_reserve_hint(l3d_ctx* c, int n_dense, int n_views, int n_neighbors)
     const size_t n_pot = 3 * N * nd + 1024, n_items = (3 * N * nd) / 2 + 1024, n_edges = N * nd + 1024, slots = 2 * n_pot;
     const size_t bslots = std::min(slots, (size_t)(c->opt.prod_block_keys > 0 ? c->opt.prod_block_keys : (1 << 28)) + 64);   // the products are built in blocks of key slots
     Products& P = c->products;
+    // (transposed build of the products, round 6: 4 bytes per forward target and per backward entry, six ints per row, the table sized from its count)
+    const bool tr = c->opt.prod_transpose != 0;
+    const size_t tslots = std::min(n_pot, (size_t)(c->opt.prod_block_keys > 0 ? c->opt.prod_block_keys : (1 << 30)));
     struct R { DevBuf* b; size_t bytes; } rs[] = {
-        { &P.keys, bslots * 8 }, { &P.keys2, bslots * 8 }, { &P.flag, bslots * 4 }, { &P.pos, bslots * 4 }, { &P.tmp, bslots * 4 + (64u << 10) }, { &P.pot_start, (nd + 2) * 8 },
-        { &P.pot_tgt, slots * 4 }, { &P.best_ref, nd * 8 }, { &P.hyp_of, (nd + 2) * 8 }, { &P.score, nd * 4 }, { &P.hyp_dense, nd * 4 }, { &P.best_hyp, nd * 4 },
+        { &P.keys, tr ? tslots * 4 : bslots * 8 }, { &P.keys2, tr ? tslots * 4 : bslots * 8 }, { &P.flag, tr ? 6 * (nd + 128) * 4 : bslots * 4 }, { &P.pos, tr ? 0 : bslots * 4 },
+        { &P.tmp, tr ? (nd / 256 + 1024) * 8 + (64u << 10) : bslots * 4 + (64u << 10) }, { &P.pot_start, (nd + 2) * 8 },
+        { &P.pot_tgt, (tr ? n_pot : slots) * 4 }, { &P.best_ref, nd * 8 }, { &P.hyp_of, (nd + 2) * 8 }, { &P.score, nd * 4 }, { &P.hyp_dense, nd * 4 }, { &P.best_hyp, nd * 4 },
         { &P.aux, nd * 4 + n_pot + 1024 }, { &c->aff_hyp, nd * sizeof(Hypothesis) },
         { &c->g1, (nd + 2) * 16 + (size_t)n_views * 4 + 1024 }, { &c->g2, n_items * 8 }, { &c->g3, n_items * 8 }, { &c->g4, n_items * 4 },
         { &c->g5, (nd * 2 + n_items * 6 + 8) * 4 }, { &c->g6, n_edges * 2 * sizeof(l3d_edge) + nd * 4 }, { &c->g7, n_edges * 16 + (1u << 20) }, { &c->g0, n_edges * 2 * sizeof(l3d_edge) * 2 },

@@ -27,6 +27,7 @@
 #include "l3d_kept.hpp"
 #include "l3d_products.hpp"
 #include "l3d_chain_common.hpp"
+#include "l3d_runtable.hpp"
 
 #ifndef L3D_AHEAD
 #define L3D_AHEAD 4
@@ -69,6 +70,26 @@ __global__ void k_exist_count(const Match* __restrict__ arena, const unsigned* _
         if (kc && kc[i] != view_id) continue;
         const Match r = kept[i];
         if (r.camID2 == view_id && (int)r.segID2 < S) atomicAdd(&rowcnt[r.segID2 * N + cam], 1);
+    }
+}
+// Round 6, run tables (l3d_runtable.hpp): the records of source w that point at this view are the runs rt_w[slot][s] .. rt_w[slot + 1][s] of its list
+// (slot = this view's local camera number in w's neighbour list) -- read directly, through the packed side array (4 bytes per record: the target
+// segment is all the count needs), instead of scanning the source's whole list for them: 1/N of it is touched, twelve sources' lists are not.
+// g (a power of two) lanes share a run.
+__global__ __launch_bounds__(256) void k_exist_count_rt(const unsigned* __restrict__ qt_arena, const RtInfo* __restrict__ info, const ChainResult* __restrict__ res,
+                                                        const int* __restrict__ src_index, const int* __restrict__ src_cam, const int* __restrict__ src_slot, int g, int N, int S,
+                                                        int* __restrict__ rowcnt)
+{
+    const int si = src_index[blockIdx.y], cam = src_cam[blockIdx.y], slot = src_slot[blockIdx.y];
+    const RtInfo w = info[si];
+    if (!w.rt || slot < 0 || res[si].n_kept == 0) return;
+    const unsigned* qt = qt_arena + res[si].kept_base;
+    const int* r0 = w.rt + (size_t)slot * w.S;
+    const int* r1 = r0 + w.S;
+    const int grp = threadIdx.x / g, gl = threadIdx.x - grp * g, ngrp = 256 / g;
+    for (int s = blockIdx.x * ngrp + grp; s < w.S; s += gridDim.x * ngrp) {
+        const int a = r0[s], b = r1[s];
+        for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < S) atomicAdd(&rowcnt[u * N + cam], 1); }
     }
 }
 // the side array of records that did not come from the kept writer (a block's sources taken over from another rank)
@@ -168,6 +189,44 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, int bps, const i
         place(i);
     }
 }
+// k_place with run tables: the stage-1 rows are moved as above, the reverse matches come from the sources' runs towards this view (k_exist_count_rt)
+__global__ __launch_bounds__(256) void k_place_rt(int blocks_move, int bps, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
+                                                  const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
+                                                  const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                                                  const int* __restrict__ src_cam, int N, int S, const int* __restrict__ row_start, int* __restrict__ cursor,
+                                                  uint2* __restrict__ meta, float4* __restrict__ depths, int cap,
+                                                  const RtInfo* __restrict__ info, const int* __restrict__ src_slot, int g)
+{
+    if (row_start[(size_t)S * N] > cap) return;
+    if ((int)blockIdx.x < blocks_move) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= S * n_tbm) return;
+        const int y = row / n_tbm, cam = tbm[row % n_tbm];
+        const int a = rowA[y * N + cam], b = row_start[y * N + cam], n = row_start[y * N + cam + 1] - b;
+        for (int j = lane; j < n; j += 64) { meta[b + j] = metaA[a + j]; depths[b + j] = depthsA[a + j]; }
+        return;
+    }
+    const int e = (int)blockIdx.x - blocks_move, sj = e / bps, bx = e % bps;
+    const int si = src_index[sj], cam = src_cam[sj], slot = src_slot[sj];
+    const RtInfo w = info[si];
+    if (!w.rt || slot < 0 || res[si].n_kept == 0) return;
+    const Match* kept = arena + res[si].kept_base;
+    const int* r0 = w.rt + (size_t)slot * w.S;
+    const int* r1 = r0 + w.S;
+    const int grp = threadIdx.x / g, gl = threadIdx.x - grp * g, ngrp = 256 / g;
+    for (int sg = bx * ngrp + grp; sg < w.S; sg += bps * ngrp) {
+        const int a = r0[sg], b = r1[sg];
+        for (int i = a + gl; i < b; i += g) {
+            const Match r = kept[i];
+            if ((int)r.segID2 < S) {
+                const int row = r.segID2 * N + cam;
+                const int sl = row_start[row] + atomicAdd(&cursor[row], 1);
+                meta[sl] = make_uint2(r.segID1, (unsigned)cam);
+                depths[sl] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
+            }
+        }
+    }
+}
 
 // raw candidate total and the largest per-segment count of one view's segment range (phase 1 statistics), by one
 // workgroup; out2 = {total, max} lives in host-mapped pinned memory: no copy, the host reads it after the stage-1 event
@@ -195,10 +254,12 @@ __global__ __launch_bounds__(1024) void k_raw_stats(const int* __restrict__ rowc
 // Workgroup 0 also writes the view's result record (device copy for later views, host-mapped copy for the host).
 __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const int* __restrict__ kept_cnt, int nrow, const ChainResult* __restrict__ prev,
                                                           unsigned long long arena_cap, ChainResult* __restrict__ res, ChainResult* __restrict__ res_host,
-                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos, unsigned* __restrict__ cams)
+                                                          const unsigned* __restrict__ local2global, Match* __restrict__ arena, int* __restrict__ best_pos, unsigned* __restrict__ cams,
+                                                          int* __restrict__ rt, int rt_stride)
 {
     __shared__ int s_red[8];
     __shared__ int s_cnt[32];
+    __shared__ int s_qcnt[256];
     __shared__ unsigned long long s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
@@ -218,7 +279,8 @@ __global__ __launch_bounds__(256) void k_kept_write_chain(VerifyArgs a, const in
     if ((unsigned long long)r.kept_base + (unsigned long long)r.n_kept > arena_cap) { r.overflow |= 2; r.n_kept = 0; }
     if (blockIdx.x == 0 && tid == 0) { *res = r; *res_host = r; }
     if (yl >= nseg || r.overflow) return;
-    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best, cams ? cams + r.kept_base : nullptr);
+    write_kept_segment_wg(a, a.seg_begin + yl, before, local2global, arena + r.kept_base, s_cnt, best_pos ? best_pos + a.seg_begin + yl : nullptr, s_best, cams ? cams + r.kept_base : nullptr,
+                          rt, rt_stride, s_qcnt);
 }
 
 void launch_exist_count(const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
@@ -240,22 +302,30 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
 }
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams, int bps)
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams, int bps,
+                  const RtInfo* info, const int* src_slot, int g)
 {
     bps = std::max(1, bps);
     const int blocks_move = (S * n_tbm + 3) / 4;
     const int blocks = blocks_move + bps * n_src;
-    if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
-                                       view_id, N, S, row_start, cursor, meta, depths, cand_cap);
+    if (blocks > 0 && info) hipLaunchKernelGGL(k_place_rt, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, res, src_index, src_cam,
+                                               N, S, row_start, cursor, meta, depths, cand_cap, info, src_slot, std::max(1, g));
+    else if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
+                                            view_id, N, S, row_start, cursor, meta, depths, cand_cap);
+}
+void launch_exist_count_rt(const unsigned* qt_arena, const RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g, int bps,
+                           int N, int S, int* rowcnt, hipStream_t st)
+{
+    if (n_src > 0) hipLaunchKernelGGL(k_exist_count_rt, dim3(std::max(1, bps), n_src), dim3(256), 0, st, qt_arena, info, res, src_index, src_cam, src_slot, g, N, S, rowcnt);
 }
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
 {
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
 }
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
-                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos, unsigned* cams)
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos, unsigned* cams, int* rt, int rt_stride)
 {
-    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos, cams);
+    hipLaunchKernelGGL(k_kept_write_chain, dim3(std::max(1, a.seg_end - a.seg_begin)), dim3(256), 0, st, a, kept_cnt, nrow, prev, arena_cap, res, res_host, l2g, arena, best_pos, cams, rt, rt_stride);
 }
 
 }  // namespace l3d
@@ -319,7 +389,17 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (int rc = chain_upload_tables(c, views, n_views, vd, L, rays_env, st)) return rc;
     // bit rows: a ring that covers every view between the one being collected and the newest stage 1 (kRing below: after a capacity
     // overflow the candidates of all of them are re-formed from their bit rows)
-    if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, c->chain_ring != 0 ? L3D_AHEAD + L3D_S1AHEAD + 3 : 0, st)) return rc;
+    // run tables (round 6): the kept writer fills one per view and packs (local camera, target) into the side array; later views and the products
+    // read runs instead of scanning lists.  L3D_RUN_TABLES=0 / L3D_KEPT_CAMS=0: the A/B paths (side array of global camera ids / none)
+    const bool use_rt = c->opt.run_tables != 0 && c->opt.kept_cams != 0 && c->chain_ring != 0;
+    if (int rc = chain_assign_arenas(c, views, n_views, vd, L, true, true, c->chain_ring != 0 ? L3D_AHEAD + L3D_S1AHEAD + 3 : 0, st, use_rt)) return rc;
+    if (use_rt) {
+        std::vector<RtInfo>& info = c->rtinfo_host;     // (lives in the context: the upload is asynchronous)
+        info.resize((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) info[(size_t)k] = RtInfo{ vd[(size_t)k].rt, views[k].S_src, views[k].N };
+        HIPCHK(c, c->ch_rtinfo.reserve((size_t)n_views * sizeof(RtInfo) + 64));
+        HIPCHK(c, hipMemcpyAsync(c->ch_rtinfo.p, info.data(), info.size() * sizeof(RtInfo), hipMemcpyHostToDevice, st));
+    }
     const unsigned char* dtab = L.dtab;
     const int maxN = L.maxN;
     if (ranged) {
@@ -425,7 +505,47 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             }
         }
         if (base > 0) HIPCHK(c, hipMemcpyAsync(c->ch_kept.p, pre->records, (size_t)base * sizeof(Match), hipMemcpyDeviceToDevice, st));
-        if (base > 0 && use_cams) hipLaunchKernelGGL(k_cams_of_records, dim3((unsigned)((base + 255) / 256)), dim3(256), 0, st, c->ch_kept.as<Match>(), base, c->ch_keptcam.as<unsigned>());
+        if (base > 0 && use_cams && !use_rt) hipLaunchKernelGGL(k_cams_of_records, dim3((unsigned)((base + 255) / 256)), dim3(256), 0, st, c->ch_kept.as<Match>(), base, c->ch_keptcam.as<unsigned>());
+        if (base > 0 && use_rt) {
+            // the taken-over lists did not come out of this chain's kept writer: their side array and run tables are rebuilt from the records
+            std::vector<RtJob> jobs;
+            std::vector<unsigned> ids;
+            std::vector<int> qs;
+            std::vector<size_t> at;
+            for (int k = pre->k0; k < pre->k1; ++k) {
+                if (!has_rec[(size_t)k] || hres[k].n_kept == 0 || !vd[(size_t)k].rt) continue;
+                std::vector<std::pair<unsigned, int>> byid;
+                for (int q = 0; q < views[k].N; ++q) byid.push_back({ views[k].local2global[q], q });
+                std::sort(byid.begin(), byid.end());
+                at.push_back(ids.size());
+                for (auto& e : byid) { ids.push_back(e.first); qs.push_back(e.second); }
+                RtJob j;
+                j.recs = c->ch_kept.as<Match>() + hres[k].kept_base; j.qt = c->ch_keptcam.as<unsigned>() + hres[k].kept_base; j.rt = vd[(size_t)k].rt;
+                j.ids = nullptr; j.qs = nullptr; j.n = hres[k].n_kept; j.S = views[k].S_src; j.N = views[k].N; j.pad = 0;
+                jobs.push_back(j);
+            }
+            if (!jobs.empty()) {
+                auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+                const size_t o_ids = al(jobs.size() * sizeof(RtJob)), o_qs = o_ids + al(ids.size() * 4), o_err = o_qs + al(qs.size() * 4);
+                HIPCHK(c, c->ch_rtjobs.reserve(o_err + 256));       // (not ch_stage: the taken-over records may live there)
+                unsigned char* sb = c->ch_rtjobs.as<unsigned char>();
+                int max_n = 0, max_cells = 0;
+                for (size_t i = 0; i < jobs.size(); ++i) {
+                    jobs[i].ids = reinterpret_cast<const unsigned*>(sb + o_ids) + at[i]; jobs[i].qs = reinterpret_cast<const int*>(sb + o_qs) + at[i];
+                    max_n = std::max(max_n, jobs[i].n); max_cells = std::max(max_cells, (jobs[i].N + 1) * jobs[i].S);
+                }
+                HIPCHK(c, hipMemcpyAsync(sb, jobs.data(), jobs.size() * sizeof(RtJob), hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(sb + o_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(sb + o_qs, qs.data(), qs.size() * 4, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipMemsetAsync(sb + o_err, 0, 4, st));
+                launch_qt_from_records(reinterpret_cast<const RtJob*>(sb), (int)jobs.size(), max_n, reinterpret_cast<int*>(sb + o_err), st);
+                launch_rt_from_qt(reinterpret_cast<const RtJob*>(sb), (int)jobs.size(), max_cells, st);
+                int bad = 0;
+                HIPCHK(c, hipMemcpyAsync(&bad, sb + o_err, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (bad) return fail(c, L3D_ERR_INVALID, "match_chain: the lists taken over from another rank are not ordered (segment, camera) -- no run tables");
+            }
+        }
         HIPCHK(c, hipMemcpyAsync(c->ch_res.as<ChainResult>() + pre->k0, hres + pre->k0, (size_t)(pre->k1 - pre->k0) * sizeof(ChainResult), hipMemcpyHostToDevice, st));
     }
     auto ringA_meta = [&](int k) { return c->ch_ringA_meta.as<uint2>() + (size_t)(k % kRing) * cand_cap; };
@@ -506,14 +626,27 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         // must be spread over enough of them -- 32 x 256 threads take config 2's 36 k records in 5 steps, but 3.5 M records (4000 x 24) in 430:
         // sized from the lists the chain has seen so far (the host trails a few views behind)
         const int bps = (int)std::min(512.0, std::max(32.0, (views_seen > 0 ? kept_seen / views_seen : 0.0) / 4096.0));
-        { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, cams, bps); }
+        // run tables: g lanes per run (the average run of the lists seen so far, rounded up to a power of two), workgroups per source to cover its segments
+        const int* d_ss = reinterpret_cast<const int*>(dtab + d.o_ss);
+        const RtInfo* d_info = use_rt ? c->ch_rtinfo.as<RtInfo>() : nullptr;
+        int rt_g = 1;
+        if (use_rt) { const double avg_run = views_seen > 0 ? kept_seen / views_seen / std::max(1.0, (double)S * std::max(1, N)) : 1.0; while (rt_g < 64 && rt_g < avg_run) rt_g <<= 1; }
+        if (c->opt.rt_g > 0) rt_g = c->opt.rt_g;
+        const int rt_bps = std::max(1, std::min(512, (L.maxS * std::max(1, rt_g) + 255) / 256));
+        // short lists (config 2 keeps 36 k matches per view) are scanned record by record as before: one pass over cache-resident data beats the run
+        // tables' extra level of dependent loads (12.2 vs 12.9 ms per config-2 pass); the side array holds (camera, target) words then, not camera ids
+        const bool rt_exist = use_rt && views_seen > 0 && kept_seen / views_seen > (double)kCamScanMin;
+        const unsigned* scan_cams = use_rt ? nullptr : cams;
+        if (rt_exist) { ProfScope p(c, "exist"); launch_exist_count_rt(cams, d_info, dres, d_si, d_sc, d_ss, v.n_sources, rt_g, rt_bps, N, S, d.rowcnt, st); }
+        else { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, scan_cams, bps); }
         // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
         if (use_ring) {
             {
                 ProfScope p(c, "cand_move");
                 launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
-                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, cams, bps);
+                             c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, scan_cams, rt_exist ? rt_bps : bps,
+                             rt_exist ? d_info : nullptr, d_ss, rt_g);
             }
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");
@@ -538,7 +671,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             int pv = k - 1;
             while (pv >= 0 && !has_rec[(size_t)pv]) --pv;                    // the arena slice starts where the previous verified (or preloaded) view's ended
             launch_kept_write_chain(va, c->kept_cnt.as<int>(), (int)nrow, pv >= 0 ? dres + pv : nullptr, (unsigned long long)arena_cap, dres + k, hres_dev + k,
-                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr, cams);
+                                    reinterpret_cast<const unsigned*>(dtab + d.o_l2g), arena, st, (map || ranged) ? d.bestpos : nullptr, cams, use_rt ? d.rt : nullptr, S);
         }
         { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("chain launch, view ") + std::to_string(k) + ": " + hipGetErrorString(e_)); }
         // (with a delivery callback the host starts D2H copies of device memory once it has seen this event: a default, fenced event then)
@@ -709,8 +842,9 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     if (rc_final == L3D_OK && map) {
         // ---- the products of matchViews, on the device, from the arena (l3d_products.hip); enqueued behind the last view
         std::vector<ProdChainView> pv((size_t)n_views);
-        for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0 };
-        rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot);
+        for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0,
+                                                                         use_rt && vd[(size_t)k].verified ? vd[(size_t)k].rt : nullptr };
+        rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot, 0, -1, nullptr, use_rt ? c->ch_keptcam.as<unsigned>() : nullptr);
     }
     if (c->opt.timing)
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",

@@ -3,6 +3,7 @@
 #include <string>
 
 #include "l3d_chain_common.hpp"
+#include "l3d_runtable.hpp"
 
 namespace l3d {
 
@@ -51,7 +52,7 @@ int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int r
         size_t o = L.tab_bytes;
         d.o_off = o; o += N * 8; d.o_F = o; o += N * 36; d.o_R = o; o += N * 36; d.o_C = o; o += N * 12; d.o_P = o; o += N * 48;
         d.o_Rs = o; o += 36; d.o_Cs = o; o += 12; d.o_tbm = o; o += (size_t)v.n_tbm * 4; d.o_l2g = o; o += N * 4;
-        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4;
+        d.o_sc = o; o += (size_t)v.n_sources * 4; d.o_si = o; o += (size_t)v.n_sources * 4; d.o_ss = o; o += (size_t)v.n_sources * 4;
         L.tab_bytes = chain_align16(o);
         L.mask_bytes += chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8);
         L.max_mask_bytes = std::max(L.max_mask_bytes, chain_align16((size_t)v.n_tbm * v.S_src * d.W64 * 8));
@@ -59,6 +60,54 @@ int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int r
         L.best_elems += (size_t)v.S_src;
     }
     return L3D_OK;
+}
+
+
+// ---- run tables rebuilt from records (l3d_runtable.hpp)
+__global__ __launch_bounds__(256) void k_qt_from_records(const RtJob* __restrict__ jobs, int* __restrict__ err)
+{
+    const RtJob j = jobs[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) {
+        const Match r = j.recs[i];
+        int lo = 0, hi = j.N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (j.ids[mid] < r.camID2) lo = mid + 1; else hi = mid; }
+        const bool known = lo < j.N && j.ids[lo] == r.camID2 && (int)r.segID1 < j.S && r.segID2 < 65536u;
+        const unsigned q = known ? (unsigned)j.qs[lo] : 0xffffu;
+        j.qt[i] = (q << 16) | (r.segID2 & 0xffffu);
+        if (!known) atomicAdd(err, 1);
+        else if (i > 0) {
+            const Match p = j.recs[i - 1];
+            int l2 = 0, h2 = j.N;
+            while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (j.ids[mid] < p.camID2) l2 = mid + 1; else h2 = mid; }
+            const unsigned pq = l2 < j.N && j.ids[l2] == p.camID2 ? (unsigned)j.qs[l2] : 0u;
+            if (p.segID1 > r.segID1 || (p.segID1 == r.segID1 && pq > q)) atomicAdd(err, 1);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_rt_from_qt(const RtJob* __restrict__ jobs)
+{
+    const RtJob j = jobs[blockIdx.y];
+    const int cells = (j.N + 1) * j.S;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += gridDim.x * 256) {
+        const int q = c / j.S, s = c - q * j.S;
+        // first record whose (segment, camera) is >= (s, q); row N: (s + 1, 0)
+        const unsigned long long want = q < j.N ? ((unsigned long long)s << 16) | (unsigned)q : ((unsigned long long)(s + 1) << 16);
+        int lo = 0, hi = j.n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long key = ((unsigned long long)j.recs[mid].segID1 << 16) | (j.qt[mid] >> 16);
+            if (key < want) lo = mid + 1; else hi = mid;
+        }
+        j.rt[c] = lo;
+    }
+}
+void launch_qt_from_records(const RtJob* jobs_dev, int n_jobs, int max_n, int* err, hipStream_t st)
+{
+    if (n_jobs > 0 && max_n > 0) hipLaunchKernelGGL(k_qt_from_records, dim3((unsigned)std::max(1, std::min(512, (max_n + 1023) / 1024)), (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, err);
+}
+void launch_rt_from_qt(const RtJob* jobs_dev, int n_jobs, int max_cells, hipStream_t st)
+{
+    if (n_jobs > 0 && max_cells > 0) hipLaunchKernelGGL(k_rt_from_qt, dim3((unsigned)std::max(1, std::min(256, (max_cells + 255) / 256)), (unsigned)n_jobs), dim3(256), 0, st, jobs_dev);
 }
 
 int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool with_rays, hipStream_t st)
@@ -76,6 +125,13 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
         memcpy(tab + d.o_Cs, v.C_src, 12); memcpy(tab + d.o_tbm, v.to_be_matched, (size_t)v.n_tbm * 4);
         memcpy(tab + d.o_l2g, v.local2global, N * 4);
         if (v.n_sources) { memcpy(tab + d.o_sc, v.source_cam, (size_t)v.n_sources * 4); memcpy(tab + d.o_si, v.source_index, (size_t)v.n_sources * 4); }
+        // the LOCAL camera number this view has in each source's neighbour list (run tables: which runs of the source's list point here); -1: not listed
+        for (int q = 0; q < v.n_sources; ++q) {
+            const l3d_chain_view& w = views[v.source_index[q]];
+            int slot = -1;
+            for (int j = 0; j < w.N && w.local2global; ++j) if (w.local2global[j] == v.view_id) { slot = j; break; }
+            memcpy(tab + d.o_ss + (size_t)q * 4, &slot, 4);
+        }
     }
     if (L.tab_bytes) HIPCHK(c, hipMemcpyAsync(c->ch_tables.p, tab, L.tab_bytes, hipMemcpyHostToDevice, st));
     L.dtab = c->ch_tables.as<unsigned char>();
@@ -110,7 +166,7 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
     return L3D_OK;
 }
 
-int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st)
+int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st, bool run_tables)
 {
     const size_t nv = (size_t)n_views;
     HIPCHK(c, c->ch_mask.reserve((mask_ring > 0 ? std::min(L.mask_bytes, (size_t)mask_ring * L.max_mask_bytes) : L.mask_bytes) + 16));
@@ -124,7 +180,8 @@ int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
     HIPCHK(c, c->ch_best.reserve(L.best_elems * 8 + 16));
     if (best_positions) HIPCHK(c, c->ch_bestpos.reserve(L.best_elems * 4 + 16));
     HIPCHK(c, hipMemsetAsync(c->ch_rowcnt.p, 0, (L.rowcnt_ints + 2 * nv) * 4, st));
-    size_t mo = 0, ro = 0, bo = 0, ao = 0, ko = 0;
+    if (run_tables) HIPCHK(c, c->ch_rt.reserve((L.rowcnt_ints + L.best_elems + 4 * nv) * 4 + 64));      // (N + 1) x S ints per verified view
+    size_t mo = 0, ro = 0, bo = 0, ao = 0, ko = 0, to = 0;
     int* stats_base = c->ch_rowcnt.as<int>() + L.rowcnt_ints;
     for (int k = 0; k < n_views; ++k) {
         ChainViewDev& d = vd[(size_t)k];
@@ -149,6 +206,8 @@ int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
         d.best = c->ch_best.as<float2>() + bo;
         d.bestpos = best_positions ? c->ch_bestpos.as<int>() + bo : nullptr;
         bo += (size_t)v.S_src;
+        d.rt = run_tables ? c->ch_rt.as<int>() + to : nullptr;
+        to += (((size_t)v.N + 1) * v.S_src + 3) & ~(size_t)3;
     }
     const size_t nrow_max = (size_t)L.maxS * L.maxN;
     HIPCHK(c, c->row_start.reserve((nrow_max + 1) * 4));

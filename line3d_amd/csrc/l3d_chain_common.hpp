@@ -12,7 +12,7 @@ namespace l3d {
 
 struct ChainViewDev {               // device addresses of one view's static tables and its slices of the whole-run arenas
     const float4 *src = nullptr, *tgt = nullptr;
-    size_t o_off = 0, o_F = 0, o_R = 0, o_C = 0, o_P = 0, o_Rs = 0, o_Cs = 0, o_tbm = 0, o_l2g = 0, o_sc = 0, o_si = 0;   // offsets into the table block
+    size_t o_off = 0, o_F = 0, o_R = 0, o_C = 0, o_P = 0, o_Rs = 0, o_Cs = 0, o_tbm = 0, o_l2g = 0, o_sc = 0, o_si = 0, o_ss = 0;   // offsets into the table block
     unsigned long long* mask = nullptr;
     int* rowcnt = nullptr;
     int* rowA = nullptr;            // row starts of the stage-1 candidates alone (S*N + 1)
@@ -21,6 +21,7 @@ struct ChainViewDev {               // device addresses of one view's static tab
     int* stats = nullptr;           // {raw total, raw max per segment}
     float2* best = nullptr;
     int* bestpos = nullptr;         // per segment: position (in the view's kept slice) of its best kept match or -1 (k_kept_write_chain)
+    int* rt = nullptr;              // run table of the view's kept list, (N + 1) x S (l3d_runtable.hpp; single-GPU chain with run tables)
     float4* rays = nullptr;         // unit viewing rays of the target endpoints (2 per target entry), k_tgt_rays
     float4* src_rays = nullptr;     // ... of the view's own end points (2 per source segment)
     int W64 = 0, maxW = 0;
@@ -45,7 +46,7 @@ int chain_upload_tables(l3d_ctx* c, const l3d_chain_view* views, int n_views, st
 // mask_ring: slots of the bit-row arena (a view's bit rows live from its k_pair_mask to its k_pair_fill, both on the stage-1 stream in order:
 // two slots instead of one slice per view -- 24.6 MB x 2048 views = 50 GB at 4000 segments x 24 neighbours); 0: one slice per view
 // (the A/B mode that triangulates on the chain's stream, views later).
-int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st);
+int chain_assign_arenas(l3d_ctx* c, const l3d_chain_view* views, int n_views, std::vector<ChainViewDev>& vd, ChainLayout& L, bool fused_rows, bool best_positions, int mask_ring, hipStream_t st, bool run_tables = false);
 // Per-launch scratch that depends on the candidate capacity (candidate store, window scratch, stage-1 ring of `ring` slots).
 int chain_reserve_candidates(l3d_ctx* c, const ChainLayout& L, size_t cand_cap, int ring);
 

@@ -105,7 +105,7 @@ struct Products {
     ProductsPart part;
     int n_dense = 0, n_views_all = 0, n_chain = 0, n_hyp = 0;
     long long n_pot = 0, total_kept = 0;
-    DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables;
+    DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables, ttab, rowstage;
     DevBuf geo, hyp_of, score, hyp_dense, best_hyp, coll, aux;       // greedy selection / affinity fill on the resident tables
     long long coll_n = 0;           // entries of the collinearity CSR resident in `coll` (with n_dense + 1 starts in front)
     unsigned long long coll_sig = 0; // checksum of what that copy was uploaded from (sizes, row starts, dense map)
@@ -119,7 +119,7 @@ struct Products {
     std::vector<unsigned> chain_view_id;
     void release()
     {
-        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
+        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &ttab, &rowstage, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
         for (DevBuf* x : b) x->release();
         valid = hyp_valid = false; coll_n = 0; coll_sig = 0;
     }
@@ -159,7 +159,7 @@ struct l3d_ctx {
     l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
-    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_keptcam, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays;
+    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_keptcam, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays, ch_rt, ch_rtinfo, ch_rtjobs;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     long long shard_graph_launches = 0;          // views enqueued as one graph launch so far (l3d_get_option "shard_graph_launches")
     std::vector<l3d::ShardGraph> shard_graphs;   // per view of the sharded chain (repeated passes replay them)
@@ -200,6 +200,7 @@ struct l3d_ctx {
     std::map<std::string, l3d::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     std::vector<hipEvent_t> local_event_pool;  // events without system-scope fences (get_local_event: the single-GPU chain)
+    std::vector<l3d::RtInfo> rtinfo_host;     // host copy of the chain's per-view run-table descriptors (uploaded asynchronously)
     std::vector<hipEvent_t> prof_event_pool;   // the brackets of ProfScope: events WITHOUT the system-scope fences (a default event flushes the caches at every record)
     int prof_tick = 0;                         // (option prof_stride: with prof_only set, every n-th launch of that kernel is bracketed)
     std::mutex event_mu;

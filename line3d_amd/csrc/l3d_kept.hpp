@@ -15,13 +15,20 @@ namespace l3d {
 // best_pos (optional, with s_best = 4 x 64 bits of LDS): *best_pos = position in `out` of the segment's first kept match with the
 // highest confidence, or -1 -- what L3DView::addMatches(only_best) leaves of the list (view.cc:165-183: stable sort by confidence,
 // front of every segment's group), found where the confidences already are in registers.
+// rt (round 6, with cam_out and s_qcnt = 256 ints of LDS): the view's RUN TABLE, [camera 0 .. N][segment] with rows rt_stride apart -- rt[q * rt_stride + y] =
+// position (in `out`) of the first kept match of segment y towards LOCAL camera q, row N = the end of the segment's matches: a later view finds the
+// records that point at it (line3D.cc:838-872) and the products find every (view, camera) pair's records without scanning anything.  cam_out then
+// holds (local camera << 16 | target segment) instead of the global camera id: all a reader of a run needs of the 32-byte record except the depths.
 __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y, int o, const unsigned* __restrict__ local2global,
                                                       Match* __restrict__ out, int* s_cnt, int* __restrict__ best_pos = nullptr,
-                                                      unsigned long long* s_best = nullptr, unsigned* __restrict__ cam_out = nullptr)
+                                                      unsigned long long* s_best = nullptr, unsigned* __restrict__ cam_out = nullptr,
+                                                      int* __restrict__ rt = nullptr, int rt_stride = 0, int* s_qcnt = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
     const int m = a.row_start[(y + 1) * a.N] - start;
+    const int o_first = o;
+    if (rt) s_qcnt[tid] = 0;                 // (ordered before the first atomicAdd by the first round's barrier; m == 0: not read at all)
     unsigned long long bk = 0ull;            // (confidence bits, ~position): the maximum is the first strict maximum in list order
     for (int base = 0; base < m; base += 2048) {
         float c[8];
@@ -50,13 +57,27 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
                 rec.confidence = c[r] / 2.0f;                    // confidence_norm, cudawrapper.cu:1089,1098
                 const int pos = o + off + __popcll(b[r] & ((1ull << lane) - 1ull));
                 out[pos] = rec;
-                if (cam_out) cam_out[pos] = rec.camID2;         // (the chain's side array: later views find their reverse matches by scanning 4 bytes per record)
+                if (cam_out) cam_out[pos] = rt ? ((meta.y << 16) | meta.x) : rec.camID2;   // (the chain's side array: see rt above; without run tables the global camera id, scanned by later views)
+                if (rt) atomicAdd(&s_qcnt[meta.y], 1);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(c[r]) << 32) | (0xffffffffu - (unsigned)pos);   // (c > 1: the bits order like the value)
                 bk = key > bk ? key : bk;
             }
         }
         o += total;
         __syncthreads();                                       // s_cnt is rewritten by the next round
+    }
+    if (rt && wave == 0) {
+        // kept matches per camera -> run starts: exclusive prefix over the cameras by the first wave alone (the last round's barrier put every count in
+        // place; no barrier of its own -- the kernel's critical path is a launch per view)
+        int run = o_first;
+        for (int q0 = 0; q0 <= a.N; q0 += 64) {
+            const int q = q0 + lane;
+            const int v = (m > 0 && q < a.N) ? s_qcnt[q] : 0;
+            int incl = v;
+            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+            if (q <= a.N) rt[(size_t)q * rt_stride + y] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
     }
     if (best_pos) {
         for (int d = 32; d > 0; d >>= 1) {

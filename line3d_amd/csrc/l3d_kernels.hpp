@@ -35,6 +35,9 @@ struct Hypothesis {                 // == l3d_hypothesis
     uint32_t pad;
 };
 
+// per view of a chain on the device: its run table (null: none) and sizes -- what a later view needs to find the records that point at it (l3d_runtable.hpp)
+struct RtInfo { const int* rt; int S, N; };
+
 struct ChainResult {                // per view of the resident chain (device -> pinned host)
     unsigned kept_base;             // first record of the view's slice of the kept arena (records of 32 bytes: 32 bits reach 137 GB)
     int n_kept, R, overflow;
@@ -159,10 +162,15 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
                             int seg_begin = 0, int seg_end = -1, float* stage = nullptr, long long stage_stride = 0, unsigned* stage_key = nullptr);
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
-                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams = nullptr, int bps = 32);
+                  const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams = nullptr, int bps = 32,
+                  const struct RtInfo* info = nullptr, const int* src_slot = nullptr, int g = 1);
+// (run tables, l3d_runtable.hpp: the sources' runs towards this view instead of scans of their lists)
+void launch_exist_count_rt(const unsigned* qt_arena, const struct RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g, int bps,
+                           int N, int S, int* rowcnt, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
-                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr, unsigned* cams = nullptr);
+                             ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr, unsigned* cams = nullptr,
+                             int* rt = nullptr, int rt_stride = 0);
 void launch_collinearity(const float4* segs, int S, float sigma_sqr, unsigned long long* mask, int W64, int* rowcnt, hipStream_t st);
 void launch_collinearity_fill(const float4* segs, int S, float sigma_sqr, const unsigned long long* mask, int W64,
                               const int* row_start, int* oi, int* oj, float* ow, hipStream_t st);

@@ -49,7 +49,12 @@ namespace l3d {
     X(vw_split, "L3D_VW_SPLIT", -1, "k_verify_window: long segments built by the first launch, verified in units by a second (k_vw_walk): 1 always, 0 never, -1 launches of few segments on dense scenes") \
     X(vw_unit, "L3D_VW_UNIT", 512, "hypotheses per unit of the split verification (a multiple of 256; emulated rank of eight at 64 x 4000 x 24: 256 -> 95.6, 512 -> 90.7, 1024 -> 92.4, 2048 -> 99.0 ms)")                               \
     X(vw_split_avg, "L3D_VW_SPLIT_AVG", 4096, "vw_split = -1: split when the candidate capacity per segment of the launch is at least this") \
-    X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^28; tests: small values force many blocks)") \
+    X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^30 entries transposed, 2^28 key slots sorted; tests: small values force many blocks)") \
+    X(prod_transpose, "L3D_PROD_TRANSPOSE", 1, "matchViews' products: 1 = rows from run tables, per-pair LDS transposes and an LDS bitmap per row (round 6), 0 = radix sort of two 64-bit keys per record (A/B)") \
+    X(prod_pair_g, "L3D_PROD_PAIR_G", -1, "transposed products: lanes sharing a run in the pair transposes (-1: by the average run, 0: a run per thread)") \
+    X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \
+    X(rt_g, "L3D_RT_G", -1, "resident chain with run tables: lanes sharing a run when a view collects its reverse matches (-1: by the average run, 0: a run per thread)") \
+    X(run_tables, "L3D_RUN_TABLES", 1, "resident chain: 1 = the kept writer fills a run table per view and packs (local camera, target) into the side array; later views and the products read runs instead of scanning lists, 0 = round 5's scans of the side array of global camera ids (A/B)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
     X(defer_stats, "L3D_DEFER_STATS", 0, "sharded native run: 1 = no host wait for a view's stage-1 statistics (measured slower: 93 vs 84 us per view at 8 ranks, DESIGN 6)") \
     X(graph, "L3D_GRAPH", 0, "sharded native run with L3D_DEFER_STATS=1: 1 = passes 3.. replay a view's five launches as one captured graph (measured slower: 99 vs 93 us per view, DESIGN 6)")             \

@@ -23,6 +23,7 @@
 #include "l3d_products.hpp"
 #include "l3d_linalg.hpp"
 #include "l3d_unproject.hpp"
+#include "l3d_runtable.hpp"
 
 using namespace l3d;
 
@@ -224,6 +225,310 @@ __global__ __launch_bounds__(256) void k_prod_shift_rows(const long long* __rest
     if (i < n_rows) pot_start[i] = piece[i] + base;
 }
 
+
+// =================================================================================================================================
+// Round 6: the table as a TRANSPOSE of run tables instead of a sort of keys.  A row of the table -- the potential correspondences of one dense
+// segment (t, u) -- is the union of
+//   (F) the segment's own kept records, read forward: one contiguous run of its view's list (run table: rt[0][u] .. rt[N][u]), and
+//   (B) the records of other views that point at it, read backward.  The records of view v towards its local camera q (= view t) are the runs
+//       rt_v[q][s] .. rt_v[q + 1][s] over all s: a sparse S_v x S_t matrix in row order; B needs it in column order.  ONE workgroup per (v, q) pair
+//       transposes it in LDS (histogram over u, scan, scatter): no global atomics, nothing scanned that is not used.
+// Every list is read through its 4-byte side array qt = (local camera << 16 | target) written by the kept writer beside the records (l3d_kept.hpp;
+// rebuilt here, block by block, for lists that did not come out of the single-GPU chain): the 32-byte records are not read at all.
+//   k_prodv_pair_counts     records of every pair that targets the block (sums of run lengths)        -> where its transposed entries go
+//   k_prodv_pair_transpose  per pair: column starts boff[u] and the source segments grouped by u (E)
+//   k_prodv_rows<false>     one wave per row: F and B set bits in an LDS bitmap over the segments of the views the row's view touches --
+//   exclusive_sum_int       sorted and unique by construction -- popcount = the row's length; the scan gives the CSR's row starts;
+//   k_prodv_rows<true>      the bitmap again, expanded into the row's place.
+// A target is a BIT INDEX in the row view's bit space: the views it touches (its neighbours, the views it is a neighbour of, what the
+// early-return quirk files under it) ascending, each padded to whole 32-bit words, so that bit order = dense order and a word belongs to one view
+// (dense id of a word's bit 0: `dow`).  Transients: 4 bytes per backward entry (rounds 3-5: 48 bytes per record in key arrays); the table's entries
+// are counted before they are written, so the table is reserved at its size.  The hipCUB radix sort is off matchViews' path (kept as A/B and as
+// the way out for lists that are not ordered).
+struct ProdNbQ { int t_base, t_S; };                                  // chain view k, LOCAL camera q: the target view's dense range (-1: not in the map)
+struct ProdViewQ { const unsigned* qt; const int* rt; int nb_off, N; }; // a chain view's list through its side array and run table (null: no records here)
+struct ProdPair { int k, q, off_off, pad; };                            // a (chain view, local camera) pair that targets a view of the block; where its column starts live in boff
+struct ProdTouch { int y_base, y_S, fq, pair; };                        // a view y the rows of view x can name: its dense range; the local camera number y has in x's own chain view
+                                                                       // (F runs; -1: none); the pair (y's chain view, its camera number of x) whose columns are x's B (-1: none)
+struct ProdRowView { int dense_base, S, own_k, t0, t1, pad; };          // own_k: the chain view whose list holds the rows' F runs (-1: none); [t0, t1): its ProdTouch entries, ascending y
+
+__global__ __launch_bounds__(256) void k_prodv_pair_counts(const ProdPair* __restrict__ pairs, const ProdViewQ* __restrict__ vq, const ProdView* __restrict__ pv, int* __restrict__ pcnt)
+{
+    __shared__ int s_w[4];
+    const ProdPair pr = pairs[blockIdx.x];
+    const ProdViewQ v = vq[pr.k];
+    const int S = pv[pr.k].S;
+    int t = 0;
+    if (v.rt) for (int s = threadIdx.x; s < S; s += 256) t += v.rt[(size_t)(pr.q + 1) * S + s] - v.rt[(size_t)pr.q * S + s];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) pcnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// One workgroup of 512 threads per pair, ONE RUN PER THREAD with four of its words in flight: g lanes sharing a run left every wave with one dependent
+// load outstanding at a time (two levels, ~2 us each under load: 5 ms per build at 40 x 4000 x 24); a thread per run keeps 4 x 512 independent loads
+// in flight per workgroup, and a run's words share cache lines across the thread's iterations.  LDS: S_t + 1 counters.
+constexpr int kPairThreads = 512;
+template <class F> __device__ __forceinline__ void for_run_words(const unsigned* __restrict__ qt, int a, int b, F&& f)
+{
+    for (int i = a; i < b; i += 4) {
+        const unsigned w0 = qt[i], w1 = i + 1 < b ? qt[i + 1] : 0u, w2 = i + 2 < b ? qt[i + 2] : 0u, w3 = i + 3 < b ? qt[i + 3] : 0u;
+        f(i, w0);
+        if (i + 1 < b) f(i + 1, w1);
+        if (i + 2 < b) f(i + 2, w2);
+        if (i + 3 < b) f(i + 3, w3);
+    }
+}
+__global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const ProdPair* __restrict__ pairs, const ProdViewQ* __restrict__ vq, const ProdView* __restrict__ pv,
+                                                                       const ProdNbQ* __restrict__ nbq, const int* __restrict__ poff, int g, int* __restrict__ boff, unsigned* __restrict__ E)
+{
+    extern __shared__ int s_h[];
+    __shared__ int s_w[kPairThreads / 64];
+    const ProdPair pr = pairs[blockIdx.x];
+    const ProdViewQ v = vq[pr.k];
+    const int S = pv[pr.k].S, St = nbq[v.nb_off + pr.q].t_S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned* qt = v.qt;
+    const int* r0 = v.rt + (size_t)pr.q * S;
+    const int* r1 = v.rt + (size_t)(pr.q + 1) * S;
+    for (int u = tid; u <= St; u += kPairThreads) s_h[u] = 0;
+    __syncthreads();
+    const int grp = g ? tid / g : 0, gl = g ? tid - grp * g : 0, ngrp = g ? kPairThreads / g : 1;
+    if (g == 0) {
+        for (int s = tid; s < S; s += kPairThreads)
+            for_run_words(qt, r0[s], r1[s], [&](int, unsigned w) { const int u = (int)(w & 0xffffu); if (u < St) atomicAdd(&s_h[u], 1); });
+    } else {
+        for (int s = grp; s < S; s += ngrp) {
+            const int a = r0[s], b = r1[s];
+            for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < St) atomicAdd(&s_h[u], 1); }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the St counters: a contiguous piece per thread
+    const int per = (St + kPairThreads - 1) / kPairThreads, u0 = tid * per, u1 = min(St, u0 + per);
+    int sum = 0;
+    for (int u = u0; u < u1; ++u) sum += s_h[u];
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int run = incl - sum, all = 0;
+    for (int w = 0; w < kPairThreads / 64; ++w) { if (w < wave) run += s_w[w]; all += s_w[w]; }
+    int* bo = boff + pr.off_off;
+    for (int u = u0; u < u1; ++u) { const int c = s_h[u]; s_h[u] = run; bo[u] = run; run += c; }
+    if (tid == 0) bo[St] = all;
+    __syncthreads();
+    unsigned* e = E + poff[blockIdx.x];
+    if (g == 0) {
+        for (int s = tid; s < S; s += kPairThreads)
+            for_run_words(qt, r0[s], r1[s], [&](int, unsigned w) { const int u = (int)(w & 0xffffu); if (u < St) e[atomicAdd(&s_h[u], 1)] = (unsigned)s; });
+    } else {
+        for (int s = grp; s < S; s += ngrp) {
+            const int a = r0[s], b = r1[s];
+            for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < St) e[atomicAdd(&s_h[u], 1)] = (unsigned)s; }
+        }
+    }
+}
+
+// The early-return quirk through run tables (the chain's side arrays; with rebuilt ones the scans of k_prod_keys_early / k_prodt_early below stay):
+// the records of source `src` that point at the early-return view are the runs (s, slot) of its list.  MODE 0: the view's best match per segment
+// and its list length (k_prod_keys_early with out_off == nullptr); 1 / 2: count / scatter of the extra entries of both rows (k_prodt_early).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_prod_early_rt(const ProdView* __restrict__ pv, const ProdViewQ* __restrict__ vq, const ProdSrc* __restrict__ ps, const int* __restrict__ ps_slot,
+                                                       const int* __restrict__ src_list, int d0, int d1, int* __restrict__ cnt, const int* __restrict__ bstart,
+                                                       unsigned* __restrict__ ent, unsigned long long* __restrict__ best_ref, int* __restrict__ list_len)
+{
+    const int q = src_list ? src_list[blockIdx.y] : (int)blockIdx.y;
+    const ProdSrc e = ps[q];
+    const int slot = ps_slot[q];
+    if (slot < 0 || (MODE != 0 && e.alias_base < 0)) return;
+    const ProdView v = pv[e.view], s = pv[e.src];
+    const ProdViewQ sq = vq[e.src];
+    if (!sq.rt || s.n_kept == 0) return;
+    const int* r0 = sq.rt + (size_t)slot * s.S;
+    const int* r1 = r0 + s.S;
+    for (int sg = blockIdx.x * 256 + threadIdx.x; sg < s.S; sg += gridDim.x * 256) {
+        for_run_words(sq.qt, r0[sg], r1[sg], [&](int i, unsigned w) {
+            const int u = (int)(w & 0xffffu);                   // the view's segment (the record's segID2); sg = the record's segID1
+            if (MODE == 0) {
+                atomicAdd(&list_len[e.view], 1);
+                if (u < v.S && !e.pad) atomicMin(&best_ref[v.dense_base + u], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i));
+            } else if (u < v.S && sg < e.alias_S) {
+                const int ai = v.dense_base + u, di = e.alias_base + sg;
+                if (ai >= d0 && ai < d1) {
+                    if (MODE == 1) atomicAdd(&cnt[ai - d0], 1);
+                    else ent[bstart[ai - d0] + atomicSub(&cnt[ai - d0], 1) - 1] = (unsigned)di;
+                }
+                if (di >= d0 && di < d1) {
+                    if (MODE == 1) atomicAdd(&cnt[di - d0], 1);
+                    else ent[bstart[di - d0] + atomicSub(&cnt[di - d0], 1) - 1] = (unsigned)ai;
+                }
+            }
+        });
+    }
+}
+
+// the entries of the early-return quirk (k_prod_keys_early's keys), both directions, through a counted scatter with global atomics (a handful of
+// views): per row the DENSE ids of its extra targets
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_prodt_early(const Match* __restrict__ arena, const ProdView* __restrict__ pv, const ProdSrc* __restrict__ ps,
+                                                     const int* __restrict__ src_list, const unsigned* __restrict__ chain_view_id, int d0, int d1, int* __restrict__ cnt,
+                                                     const int* __restrict__ bstart, unsigned* __restrict__ ent)
+{
+    const int q = src_list[blockIdx.y];
+    const ProdSrc e = ps[q];
+    if (e.alias_base < 0) return;
+    const ProdView v = pv[e.view], s = pv[e.src];
+    const unsigned vid = chain_view_id[e.view];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < s.n_kept; i += gridDim.x * 256) {
+        const Match r = arena[s.kept_base + i];
+        if (r.camID2 != vid || (int)r.segID2 >= v.S || (int)r.segID1 >= e.alias_S) continue;
+        const int ai = v.dense_base + (int)r.segID2, di = e.alias_base + (int)r.segID1;
+        if (ai >= d0 && ai < d1) {
+            if (!SCATTER) atomicAdd(&cnt[ai - d0], 1);
+            else ent[bstart[ai - d0] + atomicSub(&cnt[ai - d0], 1) - 1] = (unsigned)di;
+        }
+        if (di >= d0 && di < d1) {
+            if (!SCATTER) atomicAdd(&cnt[di - d0], 1);
+            else ent[bstart[di - d0] + atomicSub(&cnt[di - d0], 1) - 1] = (unsigned)ai;
+        }
+    }
+}
+
+// One wave per row (x, u).  The row is put together from the views x touches, ascending, a GROUP of consecutive ones at a time (as many as fit 512
+// words of bitmap: 8 views of 2000 segments, 4 of 4000): for view y the run (u, camera of y) of x's own list (F) and column u of the pair (y, camera of
+// x) (B) set bits in y's words of the bitmap -- sorted and unique by construction; the lanes look all views' run and column bounds up at once, 64 views at
+// a time.  2 KB of LDS per wave: every wave slot of the CU is used (the first version's bitmap over all touched views, 12.5 KB at 25 x 4000, left 12).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_prodv_rows(const ProdRowView* __restrict__ rv, int x0, int d0, const ProdViewQ* __restrict__ vq, const ProdTouch* __restrict__ tl,
+                                                    const ProdPair* __restrict__ pairs, const int* __restrict__ poff, const int* __restrict__ boff, const unsigned* __restrict__ E,
+                                                    const int* __restrict__ bstart, const unsigned* __restrict__ ent, int* __restrict__ ucnt, const int* __restrict__ ustart,
+                                                    long long base, int* __restrict__ pot_tgt, int group_words, int* __restrict__ stage)
+{
+    constexpr int kWords = 512;
+    __shared__ unsigned s_bm[4][kWords];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ProdRowView v = rv[x0 + blockIdx.y];
+    const int u = blockIdx.x * 4 + wave;
+    if (u >= v.S) return;                                       // (whole waves leave; no workgroup barrier below)
+    unsigned* bm = s_bm[wave];
+    const int row = v.dense_base + u - d0;
+    const unsigned* fq = nullptr;
+    const int* frt = nullptr;
+    if (v.own_k >= 0) { const ProdViewQ o = vq[v.own_k]; if (o.rt) { fq = o.qt; frt = o.rt; } }
+    const int e0 = bstart ? bstart[row] : 0, ne = bstart ? bstart[row + 1] - e0 : 0;
+    int total = 0;
+    long long o = WRITE ? base + ustart[row] : 0;
+    if (!WRITE && stage && lane == 63) stage[(size_t)row * 64 + 63] = 0;         // (no staged row yet)
+    if (WRITE && stage && stage[(size_t)row * 64 + 63] == -2) {
+        // the counting pass left the row here, sorted and unique (stage[.. + 63] = -2 marks it)
+        const int n = ustart[row + 1] - ustart[row];
+        if (lane < n) pot_tgt[o + lane] = stage[(size_t)row * 64 + lane];
+        return;
+    }
+    for (int t0 = v.t0; t0 < v.t1; t0 += 64) {
+        const int j = t0 + lane;
+        ProdTouch e;
+        e.y_base = 0; e.y_S = 0; e.fq = -1; e.pair = -1;
+        int f_a = 0, f_n = 0, b_a = 0, b_n = 0;
+        if (j < v.t1) {
+            e = tl[j];
+            if (e.fq >= 0 && frt) { f_a = frt[(size_t)e.fq * v.S + u]; f_n = frt[(size_t)(e.fq + 1) * v.S + u] - f_a; }
+            if (e.pair >= 0) { const int* bo = boff + pairs[e.pair].off_off; const int a = bo[u]; b_n = bo[u + 1] - a; b_a = poff[e.pair] + a; }
+        }
+        const int cnt = min(64, v.t1 - t0);
+        const int words = j < v.t1 ? (e.y_S + 31) >> 5 : 0;
+        // SHORT ROWS (config 2: 18 + 18 entries over 12 views): at most 64 entries in all -- one per lane, as dense ids; ranked against each other by
+        // shuffles, put in order, neighbours compared: sorted and unique without a bitmap, a fence or a sweep per touched view
+        if (v.t1 - v.t0 <= 64) {
+            const int mine = f_n + b_n;
+            int incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+            const int excl = incl - mine, tot = __shfl(incl, 63);
+            if (tot + ne <= 64) {
+                int id = 0x7fffffff;
+                int l = 0;                                       // owner of entry `lane`: the last lane whose exclusive count is <= lane
+                for (int step = 32; step > 0; step >>= 1) { const int cand = l + step; const int ex = __shfl(excl, cand & 63); if (cand < 64 && ex <= lane) l = cand; }
+                const int off = lane - __shfl(excl, l), ofn = __shfl(f_n, l), ofa = __shfl(f_a, l), oba = __shfl(b_a, l), oyS = __shfl(e.y_S, l), oyb = __shfl(e.y_base, l);
+                if (lane < tot) {
+                    const unsigned t = off < ofn ? (fq[ofa + off] & 0xffffu) : E[oba + off - ofn];
+                    if ((int)t < oyS) id = oyb + (int)t;
+                } else if (lane < tot + ne) id = (int)ent[e0 + lane - tot];
+                int rank = 0;
+                for (int k = 0; k < 64; ++k) { const int other = __shfl(id, k); rank += (other < id || (other == id && k < lane)) ? 1 : 0; }
+                const int sorted = __builtin_amdgcn_ds_permute(rank << 2, id);          // lane `rank` receives this lane's id
+                const int before = __shfl_up(sorted, 1);
+                const bool keep = sorted != 0x7fffffff && (lane == 0 || before != sorted);
+                const unsigned long long km = __ballot(keep);
+                if (!WRITE) {
+                    const int n = __popcll(km);
+                    if (lane == 0) ucnt[row] = n;
+                    if (stage && n < 64) {
+                        if (keep) stage[(size_t)row * 64 + __popcll(km & ((1ull << lane) - 1ull))] = sorted;
+                        if (lane == 63) stage[(size_t)row * 64 + 63] = -2;
+                    }
+                }
+                else if (keep) pot_tgt[o + __popcll(km & ((1ull << lane) - 1ull))] = sorted;
+                return;
+            }
+        }
+        int jj = 0;
+        while (jj < cnt) {
+            // the group [jj, j1): views whose words fit the bitmap together (a single view always fits: <= 16384 segments)
+            int j1 = jj, gw = 0, any = ne;
+            while (j1 < cnt) { const int w = __shfl(words, j1); if (j1 > jj && gw + w > group_words) break; gw += w; any += __shfl(f_n, j1) + __shfl(b_n, j1); ++j1; }
+            if (any == 0) { jj = j1; continue; }
+            for (int w = lane; w < gw; w += 64) bm[w] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            int wo = 0;
+            for (int k = jj; k < j1; ++k) {
+                const int fn = __shfl(f_n, k), bn = __shfl(b_n, k), fa = __shfl(f_a, k), ba = __shfl(b_a, k), yS = __shfl(e.y_S, k), yb = __shfl(e.y_base, k);
+                unsigned* bw = bm + wo;
+                for (int i = lane; i < fn; i += 64) { const unsigned t = fq[fa + i] & 0xffffu; if ((int)t < yS) atomicOr(&bw[t >> 5], 1u << (t & 31u)); }
+                for (int i = lane; i < bn; i += 64) { const unsigned t = E[ba + i]; if ((int)t < yS) atomicOr(&bw[t >> 5], 1u << (t & 31u)); }
+                for (int i = lane; i < ne; i += 64) { const unsigned t = ent[e0 + i] - (unsigned)yb; if (t < (unsigned)yS) atomicOr(&bw[t >> 5], 1u << (t & 31u)); }
+                wo += (yS + 31) >> 5;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (!WRITE) {
+                for (int w = lane; w < gw; w += 64) total += __popc(bm[w]);
+            } else {
+                for (int wb = 0; wb < gw; wb += 64) {
+                    const int w = wb + lane;
+                    unsigned word = w < gw ? bm[w] : 0u;
+                    if (__ballot(word != 0u) == 0ull) continue;
+                    // the view a word belongs to: the last one of the group whose first word is <= w
+                    int dbase = 0, acc = 0;
+                    for (int k = jj; k < j1; ++k) { const int yb = __shfl(e.y_base, k), yw = __shfl(words, k); if (w >= acc) dbase = yb + ((w - acc) << 5); acc += yw; }
+                    const int pc = __popc(word);
+                    int incl = pc;
+                    for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+                    long long p = o + (incl - pc);
+                    while (word) { const int bit = __ffs(word) - 1; pot_tgt[p++] = dbase + bit; word &= word - 1u; }
+                    o += __shfl(incl, 63);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            jj = j1;
+        }
+    }
+    if (!WRITE) {
+        for (int d = 32; d > 0; d >>= 1) total += __shfl_down(total, d);
+        if (lane == 0) ucnt[row] = total;
+    }
+}
+
+// row starts of one block: pot_start[d0 + r] = base + ustart[r], r = 0 .. rows (the last one = where the next block's entries start)
+__global__ __launch_bounds__(256) void k_prodt_row_starts(const int* __restrict__ ustart, int rows, long long base, long long* __restrict__ pot_start_at)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r <= rows) pot_start_at[r] = base + ustart[r];
+}
+
 }  // namespace l3d
 
 namespace {
@@ -238,7 +543,7 @@ void l3d::launch_prod_shift_rows(const long long* piece, long long n_rows, long 
 }
 
 int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pvh, const ChainResult* hres,
-                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1, const char* held)
+                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1, const char* held, const unsigned* qt_arena)
 {
     Products& P = c->products;
     P.valid = false; P.hyp_valid = false;
@@ -366,91 +671,371 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     // ---- upload tables: [ProdView n_views][ProdSrc][ids nv][seg_base nv+1][chain view ids][out_off tables of all blocks]
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_pv = 0, o_ps = o_pv + al(pv.size() * sizeof(ProdView)), o_ids = o_ps + al(ps.size() * sizeof(ProdSrc) + 16),
-                 o_sb = o_ids + al((size_t)nv * 4), o_cv = o_sb + al((size_t)(nv + 1) * 4), o_off = o_cv + al((size_t)n_views * 4), tab_total = o_off + al(off_tab.size() * 8 + 16);
+                 o_sb = o_ids + al((size_t)nv * 4), o_cv = o_sb + al((size_t)(nv + 1) * 4), o_off = o_cv + al((size_t)n_views * 4), o_evq = o_off + al(off_tab.size() * 8 + 16),
+                 o_slot = o_evq + al((size_t)n_views * sizeof(ProdViewQ) + 16), tab_total = o_slot + al(ps.size() * 4 + 16);
     HIPCHK(c, P.tables.reserve(tab_total));
+    // the chain's side arrays and run tables (round 6), when every list with records has them: the early-return quirk reads runs instead of scanning lists
+    bool native_rt = qt_arena != nullptr && c->opt.prod_transpose != 0;
+    for (int k = 0; k < n_views; ++k) if (pvh[k].verified && hres[k].n_kept > 0 && !pvh[k].rt) native_rt = false;
+    std::vector<ProdViewQ> evq((size_t)n_views);
+    for (int k = 0; k < n_views; ++k) {
+        const bool has = native_rt && pvh[k].verified && hres[k].n_kept > 0;
+        evq[(size_t)k] = ProdViewQ{ has ? qt_arena + hres[k].kept_base : nullptr, has ? pvh[k].rt : nullptr, 0, views[k].N };
+    }
+    std::vector<int> ps_slot(ps.size() + 1, -1);                // the LOCAL camera number of the early-return view in its source's neighbour list
+    for (size_t q = 0; q < ps.size(); ++q) {
+        const l3d_chain_view& sv = views[ps[q].src];
+        for (int j = 0; j < sv.N; ++j) if (sv.local2global[j] == P.chain_view_id[(size_t)ps[q].view]) { ps_slot[q] = j; break; }
+    }
     char* tb = P.tables.as<char>();
-    HIPCHK(c, hipMemcpyAsync(tb + o_pv, pv.data(), pv.size() * sizeof(ProdView), hipMemcpyHostToDevice, st));
-    if (!ps.empty()) HIPCHK(c, hipMemcpyAsync(tb + o_ps, ps.data(), ps.size() * sizeof(ProdSrc), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(tb + o_ids, P.view_ids.data(), (size_t)nv * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(tb + o_sb, P.seg_base.data(), (size_t)(nv + 1) * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(tb + o_cv, P.chain_view_id.data(), (size_t)n_views * 4, hipMemcpyHostToDevice, st));
-    if (!off_tab.empty()) HIPCHK(c, hipMemcpyAsync(tb + o_off, off_tab.data(), off_tab.size() * 8, hipMemcpyHostToDevice, st));
+    std::vector<char> tblob(tab_total);
+    {
+        auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(tblob.data() + off, src, bytes); };
+        put(o_pv, pv.data(), pv.size() * sizeof(ProdView)); put(o_ps, ps.data(), ps.size() * sizeof(ProdSrc)); put(o_ids, P.view_ids.data(), (size_t)nv * 4);
+        put(o_sb, P.seg_base.data(), (size_t)(nv + 1) * 4); put(o_cv, P.chain_view_id.data(), (size_t)n_views * 4); put(o_off, off_tab.data(), off_tab.size() * 8);
+        put(o_evq, evq.data(), evq.size() * sizeof(ProdViewQ)); put(o_slot, ps_slot.data(), ps_slot.size() * 4);
+    }
+    HIPCHK(c, hipMemcpyAsync(tb, tblob.data(), tblob.size(), hipMemcpyHostToDevice, st));
     const ProdView* dpv = reinterpret_cast<const ProdView*>(tb + o_pv);
     const ProdSrc* dps = reinterpret_cast<const ProdSrc*>(tb + o_ps);
     const unsigned* dids = reinterpret_cast<const unsigned*>(tb + o_ids);
     const int* dsb = reinterpret_cast<const int*>(tb + o_sb);
     const unsigned* dcv = reinterpret_cast<const unsigned*>(tb + o_cv);
     const long long* doff = reinterpret_cast<const long long*>(tb + o_off);
+    const ProdViewQ* devq = reinterpret_cast<const ProdViewQ*>(tb + o_evq);
+    const int* dslot = reinterpret_cast<const int*>(tb + o_slot);
 
     // ---- best references, medians (once); per block: keys, sort, unique, CSR rows
     const double t_res0 = now_s();
-    HIPCHK(c, P.keys.reserve((size_t)n_keys_max * 8 + 64));
-    HIPCHK(c, P.keys2.reserve((size_t)n_keys_max * 8 + 64));
-    HIPCHK(c, P.flag.reserve(((size_t)n_keys_max + 2) * 4));
-    HIPCHK(c, P.pos.reserve(((size_t)n_keys_max + 2) * 4));
     HIPCHK(c, P.pot_start.reserve(((size_t)nd + 2) * 8));
-    HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));
     HIPCHK(c, P.best_ref.reserve((size_t)nd * 8 + 64));
     HIPCHK(c, P.median.reserve((size_t)n_views * 8 + 64));          // medians | list lengths of the early-return views
     if (c->opt.timing) fprintf(stderr, "[l3d products] %zu block(s) of up to %lld keys, table of up to %lld entries: buffers reserved in %.2f ms\n", blocks.size(), n_keys_max, slots_all, (now_s() - t_res0) * 1e3);
     int* d_list_len = reinterpret_cast<int*>(P.median.as<float>() + n_views);
     HIPCHK(c, hipMemsetAsync(d_list_len, 0, (size_t)n_views * 4, st));
-    unsigned long long* keys = P.keys.as<unsigned long long>();
-    unsigned long long* keys2 = P.keys2.as<unsigned long long>();
     const Match* arena = c->ch_kept.as<Match>();
     HIPCHK(c, hipMemsetAsync(P.best_ref.p, 0xff, (size_t)nd * 8, st));
     const unsigned gx = (unsigned)std::max(1, std::min(512, (max_kept + 1023) / 1024));
     {
         ProfScope p(c, "prod_keys", st);
-        if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, (const long long*)nullptr, dcv, nb, 0, 0,
-                                            keys, P.best_ref.as<unsigned long long>(), d_list_len);
+        if (!ps.empty() && native_rt)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<0>), dim3((unsigned)std::max(1, (maxS + 255) / 256), (unsigned)ps.size()), dim3(256), 0, st, dpv, devq, dps, dslot, (const int*)nullptr, 0, 0,
+                               (int*)nullptr, (const int*)nullptr, (unsigned*)nullptr, P.best_ref.as<unsigned long long>(), d_list_len);
+        else if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, (const long long*)nullptr, dcv, nb, 0, 0,
+                                                 (unsigned long long*)nullptr, P.best_ref.as<unsigned long long>(), d_list_len);
         hipLaunchKernelGGL(k_prod_best, dim3((maxS + 255) / 256, n_views), dim3(256), 0, st, dpv, P.best_ref.as<long long>());
         hipLaunchKernelGGL(k_prod_median, dim3(n_views), dim3(256), 0, st, dpv, P.median.as<float>());
     }
-    size_t tb1 = 0, tb2 = 0;
-    HIPCHK(c, sort_keys_u64(nullptr, tb1, keys, keys2, (int)n_keys_max, 0, std::min(64, 2 * nb), st));
-    HIPCHK(c, exclusive_sum_int(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys_max + 1, st));
-    HIPCHK(c, P.tmp.reserve(std::max(tb1, tb2) + 256));
-    long long base = 0;
-    for (size_t bi = 0; bi < blocks.size(); ++bi) {
-        const ProdBlock& B = blocks[bi];
-        const long long n_keys = B.slots + 1;
+    // ---- the transposed build (round 6; the kernels above).  kSortInstead: the records are not what it assumes -- the caller sorts.
+    constexpr int kSortInstead = -12345;
+    auto transposed = [&](long long& n_pot_out) -> int {
+        const double t_t0 = now_s();
+        auto seg_count = [&](int x) { return P.seg_base[(size_t)x + 1] - P.seg_base[(size_t)x]; };
+        for (int x = dv0; x < dv1; ++x) if (seg_count(x) > 16000) return kSortInstead;                                  // (the pair transposes keep a view's segments in 64 KB of LDS)
+        const bool rebuild = !native_rt;                        // (a list without a run table: all are rebuilt, block by block)
+        // T(x): the dense views a row of view x can name -- its chain view's neighbours, the views it is a neighbour of, the early-return aliases
+        std::vector<std::vector<int>> T((size_t)nv);
+        for (int k = 0; k < n_views; ++k) {
+            if (!pvh[k].verified) continue;
+            const int vi = P.chain_view[(size_t)k];
+            for (int q = 0; q < views[k].N; ++q) {
+                const int t = view_of(views[k].local2global[q]);
+                if (t >= 0) { T[(size_t)vi].push_back(t); T[(size_t)t].push_back(vi); }
+            }
+        }
+        for (size_t q = 0; q < ps.size(); ++q) {
+            const int a = P.chain_view[(size_t)ps[q].view], b = ps_alias_view[q];
+            if (b >= 0) { T[(size_t)a].push_back(b); T[(size_t)b].push_back(a); }
+        }
+        for (int x = 0; x < nv; ++x) { std::vector<int>& t = T[(size_t)x]; std::sort(t.begin(), t.end()); t.erase(std::unique(t.begin(), t.end()), t.end()); }
+        // per chain view and LOCAL camera: the target view (ProdNbQ); the pairs grouped by target view; the sorted ids for lists whose side arrays are rebuilt
+        std::vector<int> nb_off((size_t)n_views, 0);
+        std::vector<ProdNbQ> nbt;
+        std::vector<unsigned> ids_sorted;
+        std::vector<int> qs_sorted;
+        std::vector<std::vector<ProdPair>> pairs_of((size_t)nv);
+        std::vector<int> own_k((size_t)nv, -1);
+        for (int k = 0; k < n_views; ++k) {
+            nb_off[(size_t)k] = (int)nbt.size();
+            if (!pvh[k].verified) continue;
+            const int vi = P.chain_view[(size_t)k], N = views[k].N;
+            if (hres[k].n_kept > 0) own_k[(size_t)vi] = k;
+            std::vector<std::pair<unsigned, int>> byid;
+            for (int q = 0; q < N; ++q) {
+                const int t = view_of(views[k].local2global[q]);
+                nbt.push_back(ProdNbQ{ t >= 0 ? P.seg_base[(size_t)t] : -1, t >= 0 ? seg_count(t) : 0 });
+                byid.push_back({ views[k].local2global[q], q });
+                if (t >= 0 && hres[k].n_kept > 0) pairs_of[(size_t)t].push_back(ProdPair{ k, q, 0, 0 });
+            }
+            std::sort(byid.begin(), byid.end());
+            for (auto& e : byid) { ids_sorted.push_back(e.first); qs_sorted.push_back(e.second); }
+        }
+        std::vector<ProdRowView> rv((size_t)nv);
+        std::vector<ProdPair> pairs;
+        std::vector<ProdTouch> tl;
+        int max_touch = 0;
+        for (int x = 0; x < nv; ++x) {
+            ProdRowView& r = rv[(size_t)x];
+            r.dense_base = P.seg_base[(size_t)x]; r.S = seg_count(x); r.own_k = own_k[(size_t)x]; r.t0 = r.t1 = 0; r.pad = 0;
+            if (x < dv0 || x >= dv1) continue;
+            const int pair0 = (int)pairs.size();
+            for (const ProdPair& pr : pairs_of[(size_t)x]) pairs.push_back(pr);
+            r.t0 = (int)tl.size();
+            for (int y : T[(size_t)x]) {
+                ProdTouch e;
+                e.y_base = P.seg_base[(size_t)y]; e.y_S = seg_count(y); e.fq = -1; e.pair = -1;
+                if (r.own_k >= 0) for (int q = 0; q < views[r.own_k].N; ++q) if (view_of(views[r.own_k].local2global[q]) == y) { e.fq = q; break; }
+                for (int p = pair0; p < (int)pairs.size(); ++p) if (P.chain_view[(size_t)pairs[(size_t)p].k] == y) { e.pair = p; break; }
+                tl.push_back(e);
+            }
+            r.t1 = (int)tl.size();
+            max_touch = std::max(max_touch, r.t1 - r.t0);
+        }
+        // where the pairs of view x start in `pairs` (the blocks below cut the list at view boundaries)
+        std::vector<int> pair_begin((size_t)nv + 1, 0);
         {
-            ProfScope p(c, "prod_keys", st);
-            HIPCHK(c, hipMemsetAsync(keys + B.slots, 0xff, 8, st));          // the sentinel
-            if (max_kept > 0) hipLaunchKernelGGL(k_prod_keys, dim3(gx, n_views), dim3(256), 0, st, arena, dpv, doff + B.off_view, dids, dsb, nv, nb, B.d0, B.d1, keys);
-            if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, doff + B.off_src, dcv, nb, B.d0, B.d1,
-                                                keys, P.best_ref.as<unsigned long long>(), d_list_len);
+            int p = 0;
+            for (int x = 0; x < nv; ++x) { pair_begin[(size_t)x] = p; if (x >= dv0 && x < dv1) p += (int)pairs_of[(size_t)x].size(); }
+            pair_begin[(size_t)nv] = p;
         }
+        // blocks of consecutive dense views: the records of the chain views that touch a block (its B entries; with rebuilt side arrays also their qt) within the budget
+        struct TBlock { int x0, x1; size_t item0, n_items, src0, n_srcs; long long rec_n, rt_n, boff_n, early_n; int maxS, pair0, pair1; };
+        std::vector<TBlock> tblocks;
+        std::vector<int> items;                                 // chain views touching the block
+        std::vector<int> srcs;
+        const long long t_budget = c->opt.prod_block_keys > 0 ? c->opt.prod_block_keys : (1ll << 30) - 64;
         {
-            ProfScope p(c, "prod_sort", st);
-            size_t t1 = tb1, t2 = tb2;
-            HIPCHK(c, sort_keys_u64(P.tmp.p, t1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
-            const unsigned nblk = (unsigned)((n_keys + 255) / 256);
-            HIPCHK(c, hipMemsetAsync(P.flag.as<int>() + n_keys, 0, 4, st));
-            hipLaunchKernelGGL(k_prod_flags, dim3(nblk), dim3(256), 0, st, keys2, n_keys, P.flag.as<int>());
-            HIPCHK(c, exclusive_sum_int(P.tmp.p, t2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
-            hipLaunchKernelGGL(k_prod_csr, dim3(nblk), dim3(256), 0, st, keys2, P.flag.as<int>(), P.pos.as<int>(), n_keys, nb, B.d0, B.d1, base, P.pot_start.as<long long>(), P.pot_tgt.as<int>());
+            std::vector<int> mark_v((size_t)n_views, -1), mark_s(ps.size(), -1);
+            int x = dv0;
+            while (x < dv1) {
+                const int bi = (int)tblocks.size();
+                TBlock B;
+                B.x0 = x; B.item0 = items.size(); B.src0 = srcs.size(); B.rec_n = 0; B.rt_n = 0; B.boff_n = 0; B.early_n = 0; B.maxS = 1; B.pair0 = pair_begin[(size_t)x];
+                int x1 = x;
+                for (; x1 < dv1; ++x1) {
+                    long long add = 0;
+                    for (int k : touch_view[(size_t)x1]) if (mark_v[(size_t)k] != bi) add += hres[k].n_kept;
+                    for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) add += 2 * (long long)hres[ps[(size_t)q].src].n_kept;
+                    if (x1 > x && B.rec_n + B.early_n + add > t_budget) break;
+                    for (int k : touch_view[(size_t)x1]) if (mark_v[(size_t)k] != bi) {
+                        mark_v[(size_t)k] = bi; items.push_back(k); B.rec_n += hres[k].n_kept; B.rt_n += ((long long)views[k].N + 1) * views[k].S_src;
+                    }
+                    for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) { mark_s[(size_t)q] = bi; srcs.push_back(q); B.early_n += 2 * (long long)hres[ps[(size_t)q].src].n_kept; }
+                    B.maxS = std::max(B.maxS, seg_count(x1));
+                    for (int p = pair_begin[(size_t)x1]; p < pair_begin[(size_t)x1 + 1]; ++p) { pairs[(size_t)p].off_off = (int)B.boff_n; B.boff_n += seg_count(x1) + 1; }
+                }
+                B.x1 = x1; B.n_items = items.size() - B.item0; B.n_srcs = srcs.size() - B.src0; B.pair1 = pair_begin[(size_t)x1];
+                if (B.rec_n > 0x7ffffff0ll || B.early_n > 0x7ffffff0ll || B.boff_n > 0x7ffffff0ll || B.rt_n > 0x7ffffff0ll)
+                    return fail(c, L3D_ERR_UNSUPPORTED, "products: one view and its neighbours hold more than 2^31 kept matches");
+                tblocks.push_back(B);
+                x = x1;
+            }
         }
-        if (bi + 1 < blocks.size()) {                      // the next block's rows start behind this block's entries
-            int n_unique = 0;
-            HIPCHK(c, hipMemcpyAsync(&n_unique, P.pos.as<int>() + n_keys, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            base += n_unique;
+        long long max_rec = 0, max_rt = 0, max_boff = 0, max_early = 0;
+        int max_rows = 0, max_pairs = 0;
+        for (const TBlock& B : tblocks) {
+            max_rec = std::max(max_rec, B.rec_n); max_rt = std::max(max_rt, B.rt_n); max_boff = std::max(max_boff, B.boff_n); max_early = std::max(max_early, B.early_n);
+            max_rows = std::max(max_rows, P.seg_base[(size_t)B.x1] - P.seg_base[(size_t)B.x0]); max_pairs = std::max(max_pairs, B.pair1 - B.pair0);
         }
+        // ---- tables: [ProdViewQ x n_views (rewritten per block when rebuilt)][ProdNbQ][ids][qs][ProdRowView][ProdTouch][pairs][srcs][RtJobs]
+        std::vector<ProdViewQ> vqh((size_t)n_views);
+        for (int k = 0; k < n_views; ++k) {
+            ProdViewQ& o = vqh[(size_t)k];
+            o.nb_off = nb_off[(size_t)k]; o.N = views[k].N;
+            const bool has = pvh[k].verified && hres[k].n_kept > 0 && !rebuild;
+            o.qt = has ? qt_arena + hres[k].kept_base : nullptr; o.rt = has ? pvh[k].rt : nullptr;
+        }
+        const size_t q_vq = 0, q_nb = q_vq + al(vqh.size() * sizeof(ProdViewQ) + 16), q_ids = q_nb + al(nbt.size() * sizeof(ProdNbQ) + 16), q_qs = q_ids + al(ids_sorted.size() * 4 + 16),
+                     q_rv = q_qs + al(qs_sorted.size() * 4 + 16), q_tl = q_rv + al(rv.size() * sizeof(ProdRowView)), q_pr = q_tl + al(tl.size() * sizeof(ProdTouch) + 16),
+                     q_sr = q_pr + al(pairs.size() * sizeof(ProdPair) + 16), q_job = q_sr + al(srcs.size() * 4 + 16), q_total = q_job + al((size_t)n_views * sizeof(RtJob) + 16);
+        HIPCHK(c, P.ttab.reserve(q_total));
+        char* tt = P.ttab.as<char>();
+        std::vector<char> blob(q_job);                          // (one copy instead of eight: a config-2 pass pays ~8 us per small copy)
+        auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(blob.data() + off, src, bytes); };
+        put(q_vq, vqh.data(), vqh.size() * sizeof(ProdViewQ)); put(q_nb, nbt.data(), nbt.size() * sizeof(ProdNbQ)); put(q_ids, ids_sorted.data(), ids_sorted.size() * 4);
+        put(q_qs, qs_sorted.data(), qs_sorted.size() * 4); put(q_rv, rv.data(), rv.size() * sizeof(ProdRowView)); put(q_tl, tl.data(), tl.size() * sizeof(ProdTouch));
+        put(q_pr, pairs.data(), pairs.size() * sizeof(ProdPair)); put(q_sr, srcs.data(), srcs.size() * 4);
+        HIPCHK(c, hipMemcpyAsync(tt, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+        const ProdViewQ* dvq = reinterpret_cast<const ProdViewQ*>(tt + q_vq);
+        const ProdNbQ* dnb = reinterpret_cast<const ProdNbQ*>(tt + q_nb);
+        const unsigned* dids = reinterpret_cast<const unsigned*>(tt + q_ids);
+        const int* dqs = reinterpret_cast<const int*>(tt + q_qs);
+        const ProdRowView* drv = reinterpret_cast<const ProdRowView*>(tt + q_rv);
+        const ProdTouch* dtl = reinterpret_cast<const ProdTouch*>(tt + q_tl);
+        const ProdPair* dpr = reinterpret_cast<const ProdPair*>(tt + q_pr);
+        const int* dsr = reinterpret_cast<const int*>(tt + q_sr);
+        RtJob* djob = reinterpret_cast<RtJob*>(tt + q_job);
+        // ---- transients: E (transposed entries; early entries behind them), column starts, pair counts / offsets, four row arrays (+ the error counter);
+        // rebuilt side arrays: qt and rt of the block's chain views
+        const size_t ra = ((size_t)max_rows + 18 + 63) & ~(size_t)63;         // ints per row array (rows + 1 entries, the error counter in the last eight of the last one)
+        const size_t pa = ((size_t)max_pairs + 2 + 63) & ~(size_t)63;
+        const double t_res1 = now_s();
+        HIPCHK(c, P.keys2.reserve(((size_t)max_rec + (size_t)max_early) * 4 + 256));
+        HIPCHK(c, P.flag.reserve((5 * ra + 2 * pa + (size_t)max_boff) * 4 + 256));
+        if (rebuild) { HIPCHK(c, P.keys.reserve((size_t)max_rec * 4 + 256)); HIPCHK(c, P.pos.reserve((size_t)max_rt * 4 + 256)); }
+        size_t tbs = 0;
+        HIPCHK(c, exclusive_sum_int(nullptr, tbs, nullptr, nullptr, std::max(max_rows, max_pairs) + 1, st));
+        HIPCHK(c, P.tmp.reserve(tbs + 256));
+        if (tblocks.size() > 1) HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));        // (several blocks: the bound; one block: its count, below)
+        if (c->opt.timing) fprintf(stderr, "[l3d products] transposed (%s side arrays): %zu block(s), <= %lld records, %d pairs, %d rows, a row touches <= %d views: tables in %.2f ms, buffers in %.2f ms\n",
+                                   rebuild ? "rebuilt" : "the chain's", tblocks.size(), max_rec, max_pairs, max_rows, max_touch, (t_res1 - t_t0) * 1e3, (now_s() - t_res1) * 1e3);
+        unsigned* E = P.keys2.as<unsigned>();
+        int* cnt = P.flag.as<int>();
+        int *bstart = cnt + ra, *ucnt = cnt + 2 * ra, *ustart = cnt + 3 * ra, *spare = cnt + 4 * ra, *pcnt = cnt + 5 * ra, *poff = pcnt + pa, *boff = poff + pa;
+        int* err = spare + ra - 8;
+        HIPCHK(c, hipMemsetAsync(err, 0, 4, st));
+        long long base = 0;
+        std::vector<RtJob> jobs;
+        for (const TBlock& B : tblocks) {
+            const int d0 = P.seg_base[(size_t)B.x0], d1 = P.seg_base[(size_t)B.x1], rows = d1 - d0, n_pairs = B.pair1 - B.pair0;
+            int scal[2] = { 0, 0 };                                            // {entries of the block, error count}
+            if (rows > 0) {
+                unsigned* ent = E + B.rec_n;                                   // (early entries behind the transposed ones)
+                {
+                    ProfScope p(c, "prod_keys", st);
+                    if (rebuild) {
+                        // the side arrays of the block's chain views, from their records
+                        jobs.clear();
+                        long long qo = 0, ro = 0;
+                        int max_n = 0, max_cells = 0;
+                        for (size_t i = 0; i < B.n_items; ++i) {
+                            const int k = items[B.item0 + i];
+                            RtJob j;
+                            j.recs = arena + hres[k].kept_base; j.qt = P.keys.as<unsigned>() + qo; j.rt = P.pos.as<int>() + ro;
+                            j.ids = dids + nb_off[(size_t)k]; j.qs = dqs + nb_off[(size_t)k]; j.n = hres[k].n_kept; j.S = views[k].S_src; j.N = views[k].N; j.pad = 0;
+                            vqh[(size_t)k].qt = j.qt; vqh[(size_t)k].rt = j.rt;
+                            qo += j.n; ro += ((long long)j.N + 1) * j.S;
+                            max_n = std::max(max_n, j.n); max_cells = std::max(max_cells, (j.N + 1) * j.S);
+                            jobs.push_back(j);
+                        }
+                        HIPCHK(c, hipMemcpyAsync(djob, jobs.data(), jobs.size() * sizeof(RtJob), hipMemcpyHostToDevice, st));
+                        HIPCHK(c, hipMemcpyAsync(tt + q_vq, vqh.data(), vqh.size() * sizeof(ProdViewQ), hipMemcpyHostToDevice, st));
+                        launch_qt_from_records(djob, (int)jobs.size(), max_n, err, st);
+                        launch_rt_from_qt(djob, (int)jobs.size(), max_cells, st);
+                        HIPCHK(c, hipStreamSynchronize(st));                   // (the host vectors above are re-used by the next block)
+                    }
+                    if (n_pairs > 0) {
+                        hipLaunchKernelGGL(k_prodv_pair_counts, dim3((unsigned)n_pairs), dim3(256), 0, st, dpr + B.pair0, dvq, dpv, pcnt);
+                        HIPCHK(c, hipMemsetAsync(pcnt + n_pairs, 0, 4, st));
+                        size_t t1 = tbs;
+                        HIPCHK(c, exclusive_sum_int(P.tmp.p, t1, pcnt, poff, n_pairs + 1, st));
+                        // lanes per run (prod_pair_g: -1 = a quarter of the average run of the block's lists rounded up to a power of two, 0 = a run per thread)
+                        double recs = 0, cells = 0;
+                        for (size_t i = 0; i < B.n_items; ++i) { const int k = items[B.item0 + i]; recs += hres[k].n_kept; cells += (double)views[k].N * views[k].S_src; }
+                        int g = 1;
+                        while (g < 64 && g < recs / std::max(1.0, cells) / 4.0) g <<= 1;
+                        if (c->opt.prod_pair_g >= 0) g = c->opt.prod_pair_g;
+                        hipLaunchKernelGGL(k_prodv_pair_transpose, dim3((unsigned)n_pairs), dim3(kPairThreads), ((size_t)B.maxS + 2) * 4, st, dpr + B.pair0, dvq, dpv, dnb, (const int*)poff, g, boff, E);
+                    }
+                    if (B.n_srcs) {
+                        HIPCHK(c, hipMemsetAsync(cnt, 0, ((size_t)rows + 1) * 4, st));
+                        const dim3 eg((unsigned)std::max(1, (maxS + 255) / 256), (unsigned)B.n_srcs);
+                        if (!rebuild) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<1>), eg, dim3(256), 0, st, dpv, dvq, dps, dslot, dsr + B.src0, d0, d1, cnt, (const int*)bstart, ent,
+                                                         (unsigned long long*)nullptr, (int*)nullptr);
+                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodt_early<false>), dim3(gx, (unsigned)B.n_srcs), dim3(256), 0, st, arena, dpv, dps, dsr + B.src0, dcv, d0, d1, cnt, (const int*)bstart, ent);
+                        size_t t1 = tbs;
+                        HIPCHK(c, exclusive_sum_int(P.tmp.p, t1, cnt, bstart, rows + 1, st));
+                        if (!rebuild) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<2>), eg, dim3(256), 0, st, dpv, dvq, dps, dslot, dsr + B.src0, d0, d1, cnt, (const int*)bstart, ent,
+                                                         (unsigned long long*)nullptr, (int*)nullptr);
+                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodt_early<true>), dim3(gx, (unsigned)B.n_srcs), dim3(256), 0, st, arena, dpv, dps, dsr + B.src0, dcv, d0, d1, cnt, (const int*)bstart, ent);
+                    }
+                }
+                const dim3 rg((unsigned)((B.maxS + 3) / 4), (unsigned)(B.x1 - B.x0));
+                const int* bs = B.n_srcs ? bstart : nullptr;
+                // short rows (on average at most 48 entries before the duplicates go) are left sorted in a staging row of 64 ints by the counting pass; the writing pass copies
+                int* stage = nullptr;
+                if (2.0 * (double)B.rec_n <= 48.0 * rows && (size_t)rows * 256 <= ((size_t)1 << 30)) { HIPCHK(c, P.rowstage.reserve((size_t)rows * 256 + 256)); stage = P.rowstage.as<int>(); }
+                {
+                    ProfScope p(c, "prod_rows", st);
+                    HIPCHK(c, hipMemsetAsync(ucnt + rows, 0, 4, st));
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodv_rows<false>), rg, dim3(256), 0, st, drv, B.x0, d0, dvq, dtl, dpr, (const int*)poff - B.pair0, (const int*)boff,
+                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, (int*)nullptr, c->opt.prod_row_group, stage);
+                    size_t t1 = tbs;
+                    HIPCHK(c, exclusive_sum_int(P.tmp.p, t1, ucnt, ustart, rows + 1, st));
+                }
+                HIPCHK(c, hipMemcpyAsync(&scal[0], ustart + rows, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipMemcpyAsync(&scal[1], err, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (scal[1]) return kSortInstead;
+                if (tblocks.size() == 1) HIPCHK(c, P.pot_tgt.reserve(((size_t)scal[0] + 2) * 4));
+                {
+                    ProfScope p(c, "prod_rows", st);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodv_rows<true>), rg, dim3(256), 0, st, drv, B.x0, d0, dvq, dtl, dpr, (const int*)poff - B.pair0, (const int*)boff,
+                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, P.pot_tgt.as<int>(), c->opt.prod_row_group, stage);
+                    hipLaunchKernelGGL(k_prodt_row_starts, dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, st, (const int*)ustart, rows, base, P.pot_start.as<long long>() + d0);
+                }
+            } else {
+                hipLaunchKernelGGL(k_prod_fill_rows, dim3(1), dim3(256), 0, st, P.pot_start.as<long long>(), (long long)d0, (long long)d0 + 1, base);
+            }
+            base += scal[0];
+        }
+        if (tblocks.empty()) HIPCHK(c, P.pot_tgt.reserve(64));
+        n_pot_out = base;
+        return L3D_OK;
+    };
+    long long n_pot = 0;
+    bool rows_built = false;
+    if (c->opt.prod_transpose != 0) {
+        const int rc = transposed(n_pot);
+        if (rc == L3D_OK) rows_built = true;
+        else if (rc != kSortInstead) return rc;
+        else if (c->opt.timing) fprintf(stderr, "[l3d products] transposed build refused (a slice is not ordered by segment, or a target outside the bit space): sorting instead\n");
     }
-    const long long last_keys = blocks.empty() ? 0 : blocks.back().slots + 1;
+    if (!rows_built) {
+        // ---- the sorted build (rounds 3-5; A/B: L3D_PROD_TRANSPOSE=0, and the way out for slices the transposed build refuses)
+        HIPCHK(c, P.keys.reserve((size_t)n_keys_max * 8 + 64));
+        HIPCHK(c, P.keys2.reserve((size_t)n_keys_max * 8 + 64));
+        HIPCHK(c, P.flag.reserve(((size_t)n_keys_max + 2) * 4));
+        HIPCHK(c, P.pos.reserve(((size_t)n_keys_max + 2) * 4));
+        HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));
+        unsigned long long* keys = P.keys.as<unsigned long long>();
+        unsigned long long* keys2 = P.keys2.as<unsigned long long>();
+        size_t tb1 = 0, tb2 = 0;
+        HIPCHK(c, sort_keys_u64(nullptr, tb1, keys, keys2, (int)n_keys_max, 0, std::min(64, 2 * nb), st));
+        HIPCHK(c, exclusive_sum_int(nullptr, tb2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys_max + 1, st));
+        HIPCHK(c, P.tmp.reserve(std::max(tb1, tb2) + 256));
+        long long base = 0;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const ProdBlock& B = blocks[bi];
+            const long long n_keys = B.slots + 1;
+            {
+                ProfScope p(c, "prod_keys", st);
+                HIPCHK(c, hipMemsetAsync(keys + B.slots, 0xff, 8, st));          // the sentinel
+                if (max_kept > 0) hipLaunchKernelGGL(k_prod_keys, dim3(gx, n_views), dim3(256), 0, st, arena, dpv, doff + B.off_view, dids, dsb, nv, nb, B.d0, B.d1, keys);
+                if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, doff + B.off_src, dcv, nb, B.d0, B.d1,
+                                                    keys, P.best_ref.as<unsigned long long>(), d_list_len);
+            }
+            {
+                ProfScope p(c, "prod_sort", st);
+                size_t t1 = tb1, t2 = tb2;
+                HIPCHK(c, sort_keys_u64(P.tmp.p, t1, keys, keys2, (int)n_keys, 0, std::min(64, 2 * nb), st));
+                const unsigned nblk = (unsigned)((n_keys + 255) / 256);
+                HIPCHK(c, hipMemsetAsync(P.flag.as<int>() + n_keys, 0, 4, st));
+                hipLaunchKernelGGL(k_prod_flags, dim3(nblk), dim3(256), 0, st, keys2, n_keys, P.flag.as<int>());
+                HIPCHK(c, exclusive_sum_int(P.tmp.p, t2, P.flag.as<int>(), P.pos.as<int>(), (int)n_keys + 1, st));
+                hipLaunchKernelGGL(k_prod_csr, dim3(nblk), dim3(256), 0, st, keys2, P.flag.as<int>(), P.pos.as<int>(), n_keys, nb, B.d0, B.d1, base, P.pot_start.as<long long>(), P.pot_tgt.as<int>());
+            }
+            if (bi + 1 < blocks.size()) {                      // the next block's rows start behind this block's entries
+                int n_unique = 0;
+                HIPCHK(c, hipMemcpyAsync(&n_unique, P.pos.as<int>() + n_keys, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                base += n_unique;
+            }
+        }
+        const long long last_keys = blocks.empty() ? 0 : blocks.back().slots + 1;
+        int n_last = 0;
+        if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(&n_last, P.pos.as<int>() + last_keys, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        n_pot = base + n_last;
+    }
     // ---- the scalars the host needs
-    int n_last = 0;
     std::vector<float> med((size_t)2 * n_views, 1.0f);
-    if (!blocks.empty()) HIPCHK(c, hipMemcpyAsync(&n_last, P.pos.as<int>() + last_keys, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(med.data(), P.median.p, (size_t)n_views * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(c, L3D_ERR_HIP, std::string("products: ") + hipGetErrorString(e_)); }
-    const long long n_pot = base + n_last;
     P.n_pot = n_pot;
     if (held) {
-        const long long r0 = blocks.empty() ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv0], r1 = blocks.empty() ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv1] + 1;
+        const long long r0 = dv0 >= dv1 ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv0], r1 = dv0 >= dv1 ? (long long)nd + 1 : (long long)P.seg_base[(size_t)dv1] + 1;
         if (r0 > 0) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)((std::min<long long>(r0, nd + 1) + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), 0ll, std::min<long long>(r0, nd + 1), 0ll);
         if (r1 <= nd) hipLaunchKernelGGL(k_prod_fill_rows, dim3((unsigned)(((long long)nd + 1 - r1 + 255) / 256)), dim3(256), 0, st, P.pot_start.as<long long>(), r1, (long long)nd + 1, n_pot);
         HIPCHK(c, hipStreamSynchronize(st));

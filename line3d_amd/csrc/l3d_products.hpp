@@ -11,6 +11,7 @@ struct ProdChainView {
     const float2* best;     // depths of the best hypothesis per segment (k_verify_window epilogue), null for views that were not verified
     const int* bestpos;     // position (in the view's kept slice) of every segment's best kept match or -1
     int verified;
+    const int* rt;          // the view's run table (l3d_runtable.hpp) when the chain's kept writer filled one, else null (rebuilt by the products)
 };
 
 // Enqueued on the context's stream behind the last view of the chain; returns after the few scalars the host needs (entries of the
@@ -20,7 +21,10 @@ struct ProdChainView {
 // held (partitioned products: l3d_match_chain_partition): per chain view, whether its records are on this rank; the rows outside [dv0, dv1) are
 // then left EMPTY but well-formed (the whole pot_start array is valid)
 int build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pv, const ChainResult* hres,
-                   const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, int dv0 = 0, int dv1 = -1, const char* held = nullptr);
+                   const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, int dv0 = 0, int dv1 = -1, const char* held = nullptr,
+                   const unsigned* qt_arena = nullptr);
+// qt_arena: the side array of the kept arena, (local camera << 16 | target) per record, when the chain's kept writer filled it together with the
+// views' run tables (ProdChainView::rt); null: the products rebuild both from the records, block by block
 
 // pot_start[first_row + i] = piece[i] + base for n_rows rows (a rank's rows of the table put in place)
 void launch_prod_shift_rows(const long long* piece, long long n_rows, long long base, long long* pot_start_at, hipStream_t st);

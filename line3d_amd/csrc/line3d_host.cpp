@@ -203,17 +203,22 @@ int l3d_line3d_add_image_fixed_sim_ex(l3d_line3d* h, uint32_t id, unsigned width
 
 int l3d_line3d_num_cameras(const l3d_line3d* h) { return h ? (int)h->views.size() : 0; }
 
-int l3d_line3d_prepare(l3d_line3d* h) { return h ? prepare(h) : L3D_ERR_INVALID; }
-int l3d_line3d_match_views(l3d_line3d* h)
+// verbose: the counters compute_pairwise_matches prints per view (cudawrapper.cu:953,1114; line3D.cc:652), as totals of the pass -- the resident
+// chain never hands a view's lists to the host
+static int match_views_reported(l3d_line3d* h)
 {
-    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
     const int rc = match_views(h);
-    // verbose: the counters compute_pairwise_matches prints per view (cudawrapper.cu:953,1114; line3D.cc:652), as totals of the pass -- the resident
-    // chain never hands a view's lists to the host
     if (!rc && h->verbose)
         printf("[L3D] #raw_matches:          %.0f (all views)\n[L3D] #filtered_matches (2): %.0f (all views)\n[L3D] segment pairs tested:  %.0f\n",
                h->stat_raw, h->stat_kept, h->stat_pairs);
     return rc;
+}
+
+int l3d_line3d_prepare(l3d_line3d* h) { return h ? prepare(h) : L3D_ERR_INVALID; }
+int l3d_line3d_match_views(l3d_line3d* h)
+{
+    if (!h || !h->prepared) return h ? h->fail(L3D_ERR_INVALID, "prepare first") : L3D_ERR_INVALID;
+    return match_views_reported(h);
 }
 int l3d_line3d_finish(l3d_line3d* h, int perform_diffusion)
 {
@@ -235,7 +240,7 @@ int l3d_line3d_compute3Dmodel(l3d_line3d* h, int perform_diffusion)
 {
     if (!h) return L3D_ERR_INVALID;
     int rc = prepare(h);
-    if (!rc) rc = match_views(h);
+    if (!rc) rc = match_views_reported(h);
     if (!rc) rc = l3d_line3d_finish(h, perform_diffusion);
     return rc;
 }
