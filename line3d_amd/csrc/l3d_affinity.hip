@@ -1037,6 +1037,9 @@ int l3d_affinity_fill_sharded(l3d_ctx* c, const int64_t* coll_start, const int32
         for (int v = 0; v < V && !local_rc; ++v) {
             int own = -1;
             for (int r = 0; r < world; ++r) if (v >= blk0[(size_t)r] && v < blk1[(size_t)r]) own = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)v];
+            // (one rank's share of a larger job exercised alone -- options part_vrank / part_vworld at world 1: the other ranks' blocks are nobody's here; their
+            // views count with what this rank happens to know of them, the share's hypothesis numbers are then its own)
+            if (own < 0 && world == 1 && c->opt.part_vworld > 0) own = std::max(0, cnt_all[(size_t)v]);
             if (own < 0) { note(fail(c, L3D_ERR_INVALID, "l3d_affinity_fill_sharded: a view belongs to no rank's block")); break; }
             for (int r = 0; r < world; ++r) {
                 const int x = cnt_all[(size_t)r * (size_t)(V + 2) + (size_t)v];
@@ -1114,6 +1117,18 @@ int l3d_affinity_fill_sharded(l3d_ctx* c, const int64_t* coll_start, const int32
         L3D_SOFT(hipStreamSynchronize(st));
     }
 
+    // (one rank's share exercised alone -- part_vrank / part_vworld at world 1: the share of the fill ends here; numbering, clustering and the fits need the
+    // other ranks' blocks.  l3d_last_fill_counts has the share's candidates and passed pairs; an empty edge list goes back)
+    if (world == 1 && c->opt.part_vworld > 0) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (local_rc) return local_rc;
+        int32_t* hd0 = static_cast<int32_t*>(malloc(8));
+        int32_t* nh0 = static_cast<int32_t*>(malloc(8));
+        if (!hd0 || !nh0) { free(hd0); free(nh0); return fail(c, L3D_ERR_NOMEM, "malloc"); }
+        for (int v = 0; v <= V; ++v) view_hyp_begin_global[v] = 0;
+        *hyp_dense_global = hd0; *node_hyp_out = nh0;
+        return L3D_OK;
+    }
     // ---- 5. the hypotheses of every block (the line fit reads them by global number) and the segments they belong to
     const size_t o_hd = al((size_t)max_blk * sizeof(Hypothesis)), hslot = o_hd + al((size_t)max_blk * 4 + 4);
     if (reserve_slots(hslot) && own_h1 > own_h0 && !local_rc) {

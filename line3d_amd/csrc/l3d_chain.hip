@@ -1405,6 +1405,11 @@ static int chain_blocks_impl(l3d_ctx* c, const l3d_chain_view* views, int n_view
                     const int S = views[b].S_src;
                     if (local_rc) break;
                     if (h[0] != b || h[3] != S || h[2] < 0 || h[2] > S) { note(fail(c, L3D_ERR_INVALID, "l3d_match_chain_partition: a package of best matches does not name the view it should")); break; }
+                    //  a view this rank does not hold can be BOTH a source of an early-return view -- its list here is then the all-gathered sliver of
+                    // records that point at that view -- and a view an early return's local numbers name: one list cannot be both, and the best matches
+                    // would replace the sliver silently.  No scene of the tests does this; a job that does is refused here, on every rank alike (the
+                    // status words carry it), and takes the segment-sharded partition (l3d_shard_chain_partition), which keeps such views whole
+                    if (hloc[(size_t)b].n_kept > 0) { note(fail(c, L3D_ERR_UNSUPPORTED, "l3d_match_chain_partition: view " + std::to_string(views[b].view_id) + " is a source of an early-return view and named by an early return's local camera number: use the segment-sharded partition")); break; }
                     if (int rc = arena_grow_keep(c, (size_t)(used + h[2]) + 64, (size_t)used)) { note(rc); break; }
                     if (h[2] > 0) L3D_SOFT(hipMemcpyAsync(c->ch_kept.as<Match>() + used, pk + 16 + (size_t)S * 12, (size_t)h[2] * sizeof(Match), hipMemcpyDeviceToDevice, st));
                     L3D_SOFT(hipMemcpyAsync(c->ch_bestpos.as<int>() + best_off[(size_t)b], pk + 16, (size_t)S * 4, hipMemcpyDeviceToDevice, st));

@@ -975,6 +975,10 @@ int l3d_exchange_local(void*, int, const void* send_slot, void* recv_block, size
 int l3d_exchange_replay(void* user, int view, const void* send_slot, void* recv_block, size_t slot_bytes, int world, void* stream)
 {
     const size_t block = slot_bytes * (size_t)world;
+    //  the only negative tag a replay can answer is -3, the status words of a partitioned run, whose readers ask "did anybody report something"
+    // and "how much in all": the replayed rank's words land in slot 0, its peers' stay zero.  Any other collective of the block modes indexes the block by
+    // rank and would read the wrong slot: refused
+    if (view < 0 && view != -3) { fprintf(stderr, "[l3d exchange_replay] tag %d: a replay holds gathered slots of views and answers status exchanges (-3) only\n", view); return 1; }
     if (view < 0) {      // a status-word exchange of a partitioned run (tag -3): the replayed rank alone, its peers report "nothing to report"
         hipError_t e0 = hipMemsetAsync(recv_block, 0, block, (hipStream_t)stream);
         if (e0 == hipSuccess) e0 = hipMemcpyAsync(recv_block, send_slot, slot_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);

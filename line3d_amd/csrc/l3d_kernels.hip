@@ -288,7 +288,9 @@ void k_pair_mask(PairArgs a)
     const TgtBlockInv* tw = s_tgt + wave * 64;
     int ha = 0, ca = 0, hb = 0, cb = 0;            // wave-uniform ring states
     int n_l1 = 0, n_l2 = 0;                        // diagnostic counters
-    const bool use_wedge = (a.wedge_pretest & 1) != 0, use_iou = (a.wedge_pretest & 2) != 0;
+    // (level 2 only inside the validated range of coordinates: beyond 2^15 pixels -- no test image is a quarter of that -- every pair level 1 keeps takes the exact test;
+    // iou_bounds abstains by itself where kLineCond (ext / len)^2 >= 10, i.e. for segments shorter than ext / 4472: DESIGN.md section 4, tests/test_gpu_bound_check.py)
+    const bool use_wedge = (a.wedge_pretest & 1) != 0, use_iou = (a.wedge_pretest & 2) != 0 && ext < 32768.0f;
     // level 2 also ACCEPTS (bit set, no exact test) where the lower bounds of both ratios clear the thresholds: the exact test's only product
     // here is the bit (the depths and their sign test are k_pair_fill's).  Off with bit 2 of the switch (A/B: identical bit rows, tests/)
     const bool use_accept = !kDepth && use_iou && (a.wedge_pretest & 4) == 0;

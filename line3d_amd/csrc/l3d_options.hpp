@@ -54,6 +54,8 @@ namespace l3d {
     X(prod_pair_g, "L3D_PROD_PAIR_G", -1, "transposed products: lanes sharing a run in the pair transposes (-1: by the average run, 0: a run per thread)") \
     X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \
     X(rt_g, "L3D_RT_G", -1, "resident chain with run tables: lanes sharing a run when a view collects its reverse matches (-1: by the average run, 0: a run per thread)") \
+    X(part_vrank, "L3D_PART_VRANK", 0, "with part_vworld: the rank of the job whose block of views a world-1 partitioned run keeps") \
+    X(part_vworld, "L3D_PART_VWORLD", 0, "a world-1 shard_run with commit 3 keeps the block of views rank part_vrank of a job of this many ranks would own: ONE rank's share of a job that does not fit one GPU, exercised on one GPU (scripts/run_rank_share.py)") \
     X(run_tables, "L3D_RUN_TABLES", 1, "resident chain: 1 = the kept writer fills a run table per view and packs (local camera, target) into the side array; later views and the products read runs instead of scanning lists, 0 = round 5's scans of the side array of global camera ids (A/B)") \
     X(slot_ring, "L3D_SLOT_RING", -1, "sharded run: 1 = always retire old gathered blocks into the compact arena (ring of window + 18 views), 0 = never, -1 = when all blocks exceed 8 GB") \
     X(defer_stats, "L3D_DEFER_STATS", 0, "sharded native run: 1 = no host wait for a view's stage-1 statistics (measured slower: 93 vs 84 us per view at 8 ranks, DESIGN 6)") \

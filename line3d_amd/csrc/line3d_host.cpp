@@ -379,7 +379,9 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
         ChainPlan* P = static_cast<ChainPlan*>(h->shard_plan_);
         const bool host_commit = commit == 1;
         if (commit == 3) {       // partitioned: this rank keeps what its block of views needs (l3d_shard_chain_partition), nothing else
-            rc = l3d_shard_chain_partition(P->shard, (int)(((long long)n_views * rank) / world), (int)(((long long)n_views * (rank + 1)) / world));
+            // (options part_vrank / part_vworld at world 1: the block another job's rank would own -- one rank's share of a job too big for one GPU, on one GPU)
+            const int vw = world == 1 && hopt(h).part_vworld > 0 ? hopt(h).part_vworld : world, vr = vw != world ? std::max(0, std::min(hopt(h).part_vrank, vw - 1)) : rank;
+            rc = l3d_shard_chain_partition(P->shard, (int)(((long long)n_views * vr) / vw), (int)(((long long)n_views * (vr + 1)) / vw));
             if (rc) { const std::string m = std::string("shard_chain_partition: ") + l3d_last_error(h->ctx); l3d_line3d_shard_close(h, 0); return h->fail(rc, m); }
         }
         if (arena_cap_next) l3d_set_chain_capacities(h->ctx, 0, arena_cap_next);          // (the compact arena of the slot ring: read by the run)
@@ -412,6 +414,7 @@ int l3d_line3d_shard_run(l3d_line3d* h, int rank, int world, int slot_records, l
                                           (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
         if (rc == L3D_OK) return rc2;
         h->fail(rc, msg);
+        if (hopt(h).timing) fprintf(stderr, "[l3d shard_run] attempt %d failed (%d): %s\n", attempt, rc, msg.c_str());
         if (rc != L3D_ERR_NOMEM || (bits & 4 && !(bits & 11)) || !(bits & 11)) return rc;    // not a capacity verdict: nothing a retry would change
         if (bits & 8) { const long long need = P_shard_arena; arena_cap_next = (size_t)need + (size_t)need / 4 + 65536; }
         if ((bits & 2) && exchange == l3d_exchange_replay) return rc;                        // recorded blocks have the recorded slot size: the caller records again with more room

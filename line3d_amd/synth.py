@@ -67,9 +67,12 @@ class Scene:
 
 def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234,
                noise_px: float = 0.5, width: int = 1920, height: int = 1080, f: float = 1500.0,
-               first_id: int = 0, step: float = 0.12) -> Scene:
+               first_id: int = 0, step: float = 0.12, pp=(0.0, 0.0), seg_len=(0.1, 0.4), pool_factor: float = 1.5) -> Scene:
+    """pp: offset of the principal point from the image centre in pixels; seg_len: range of the 3-D segment lengths (the box is 2 x 1.2 x 2 units at
+    distance ~4: 0.1-0.4 projects to 40-150 pixels at f = 1500; 0.003-0.008 to 1-3 pixels; 1.5-2.5 spans the image) -- defaults reproduce every
+    committed golden scene bit for bit."""
     rng = SplitMix64(seed)
-    K = np.array([[f, 0.0, width / 2.0], [0.0, f, height / 2.0], [0.0, 0.0, 1.0]])
+    K = np.array([[f, 0.0, width / 2.0 + pp[0]], [0.0, f, height / 2.0 + pp[1]], [0.0, 0.0, 1.0]])
 
     # cameras on a helix around the origin
     cams = []
@@ -86,12 +89,12 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
 
     # pool of 3-D segments; keep those visible (both endpoints) in every view so that each view
     # has exactly n_segments observations of the same 3-D lines
-    pool = int(n_segments * 1.5) + 64
+    pool = int(n_segments * pool_factor) + 64
     u = rng.uniform(pool * 3).reshape(pool, 3)
     start = np.stack([2.0 * u[:, 0] - 1.0, 1.2 * u[:, 1] - 0.6, 2.0 * u[:, 2] - 1.0], axis=1)
     d = rng.normal(pool * 3).reshape(pool, 3)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    length = 0.1 + 0.3 * np.abs(2.0 * rng.uniform(pool) - 1.0)
+    length = seg_len[0] + (seg_len[1] - seg_len[0]) * np.abs(2.0 * rng.uniform(pool) - 1.0)
     end = start + d * length[:, None]
 
     def project(R, t, X):
@@ -123,7 +126,7 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
         views.append(dict(id=first_id + i, K=K.copy(), R=R.copy(), t=t.copy(), width=width, height=height,
                           segments=np.ascontiguousarray(segs, dtype=np.float32), sims=sims, gt=perm.copy()))
     params = dict(n_views=n_views, n_segments=n_segments, n_neighbors=n_neighbors, seed=seed,
-                  noise_px=noise_px, width=width, height=height, f=f, step=step)
+                  noise_px=noise_px, width=width, height=height, f=f, step=step, pp=tuple(pp), seg_len=tuple(seg_len))
     return Scene(views, np.concatenate([start, end], axis=1), params)
 
 

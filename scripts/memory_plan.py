@@ -51,8 +51,8 @@ def plan_partition(V, S, N, W, kept_ratio, warmup_windows=4):
     add("chain", "viewing rays of every target / own end point (released after the chain)", V * (n_tgt + S) * 32, "chain_upload_tables (k_tgt_rays)")
     add("chain", "bit rows (ring of 15 views), row counters + row starts of all views (released)", 15 * n_tbm * S * W64 * 8 + 3 * V * S * N * 4, "chain_assign_arenas")
     add("chain", "candidate store + window scratch + stage-1 ring of 15 views (released)", cand_cap * 44 + 15 * cand_cap * 24, "chain_reserve_candidates")
-    add("products", "key blocks: 2 x 8 B keys + flag + position per slot, bounded (released)", min(1 << 28, 2 * local_kept + 1) * 24, "l3d_products.hip:build_products (ProdBlock)")
-    add("after", "potential correspondences of the rows held (%d views): 4 B x 2 per local record (bound) + row starts of all segments" % row_views, 2 * local_kept * 4 + nd * 8, "build_products (pot_tgt, pot_start)")
+    add("products", "transposed build (round 6): rebuilt side words + run tables + transposed entries of a block's lists (4 + ~0.1 + 4 B per record), column starts, bounded (released)", min(1 << 30, local_kept) * 8.2 + row_views * N * (S + 1) * 4, "l3d_products.hip:build_products (transposed)")
+    add("after", "potential correspondences of the rows held (%d views): 4 B per entry, counted before they are written (~1.1 per record of those views) + row starts of all segments" % row_views, 1.1 * row_views * kept_view * 4 * 1.25 + nd * 8, "build_products (pot_tgt, pot_start)")
     add("after", "best references of all segments, hypotheses (96 B) + scores + indices of the views held (%d)" % held_views, nd * 12 + held_views * S * 112, "l3d_products_hypotheses")
     add("fill", "flags (1 B per local table entry), decision words (2^26 x 8 B), one block of candidates (2^27 x 20 B)", 2 * row_views * kept_view + (1 << 26) * 8 + (1 << 27) * 20, "l3d_affinity.hip:affinity_fill_core")
     add("fill", "first-touch minima of all hypotheses, own + gathered (8 B x (W + 2)), passed candidates own + gathered (12 B x 2)", n_hyp * 8 * (W + 2) + passed_all * 24, "l3d_affinity_fill_sharded")
@@ -91,7 +91,8 @@ def plan_segments(V, S, N, W, kept_ratio):
     return rows, dict(arena_records_per_rank=kept_total, kept_records_job=kept_total), dict(kept_view=kept_view, cand_view=cand_view)
 
 
-def plan_segpart(V, S, N, W, kept_ratio):
+def plan_segpart(V, S, N, W, kept_ratio, chain_world=0):
+    CW = chain_world or W          # (scripts/run_rank_share.py runs ONE rank's share at world 1: its chain holds whole views, not 1/W of each)
     n_tbm, raw_view, cand_view, kept_view = model(V, S, N, kept_ratio)
     reach = window = N // 2
     block = -(-V // W)
@@ -110,15 +111,15 @@ def plan_segpart(V, S, N, W, kept_ratio):
     add("all", "camera tables, best depth pairs + positions of all views", V * (N * 144 + 48 + n_tbm * 4 + window * 8) + V * S * 12, "l3d_chain_common.hip:chain_plan_views, chain_assign_arenas")
     add("all", "kept arena: 32 B x the records of block + 2 x reach either side (%d of %d views, + 12 %%)" % (held_views, V), 1.12 * local_kept * 32, "k_shard_retire (keep flags) -> ch_kept")
     add("chain", "viewing rays of every target / own end point (released after the chain)", V * (n_tgt + S) * 32, "chain_upload_tables (k_tgt_rays)")
-    add("chain", "bit rows (ring of 10 views), row counters + row starts of all views (released)", 10 * n_tbm * S * W64 * 8 / W + 2 * V * S * N * 4, "chain_assign_arenas")
-    cand_cap = 1.25 * cand_view / W
+    add("chain", "bit rows (ring of 10 views), row counters + row starts of all views (released)", 10 * n_tbm * S * W64 * 8 / CW + 2 * V * S * N * 4, "chain_assign_arenas")
+    cand_cap = 1.25 * cand_view / CW
     add("chain", "candidate store + window scratch + stage-1 ring of 10 views, 1/W of every view (released)", cand_cap * 44 + 10 * cand_cap * 24, "chain_reserve_candidates")
-    slot_records = int(2.2 * kept_view / W) + 1024           # (a rank's range of segments holds up to twice its share)
-    slot_bytes = 32 + (S // W + 1) * 12 + slot_records * (36 if slot_records >= 65536 else 32)      # (+ the side array of target cameras on dense scenes)
+    slot_records = int((2.2 if CW > 1 else 1.3) * kept_view / CW) + 1024           # (a rank's range of segments holds up to twice its share)
+    slot_bytes = 32 + (S // CW + 1) * 12 + slot_records * (36 if slot_records >= 65536 else 32)      # (+ the side array of target cameras on dense scenes)
     ring = window + 18
-    add("chain", "send + gathered slots: ring of %d views x %d ranks, %.0f MB slots (released)" % (ring, W, slot_bytes / 2**20), ring * (W + 1) * slot_bytes, "l3d_chain_sharded.hip:l3d_shard_chain_run (ring mode)")
-    add("products", "key blocks: 2 x 8 B keys + flag + position per slot, bounded (released)", min(1 << 28, 2 * local_kept + 1) * 24, "l3d_products.hip:build_products (ProdBlock)")
-    add("after", "potential correspondences of the rows held (%d views): 4 B x 2 per local record (bound) + row starts of all segments" % row_views, 2 * local_kept * 4 + nd * 8, "build_products (pot_tgt, pot_start)")
+    add("chain", "send + gathered slots: ring of %d views x %d ranks, %.0f MB slots (released)" % (ring, CW, slot_bytes / 2**20), ring * (CW + 1) * slot_bytes, "l3d_chain_sharded.hip:l3d_shard_chain_run (ring mode)")
+    add("products", "transposed build (round 6): rebuilt side words + run tables + transposed entries of a block's lists (4 + ~0.1 + 4 B per record), column starts, bounded (released)", min(1 << 30, local_kept) * 8.2 + row_views * N * (S + 1) * 4, "l3d_products.hip:build_products (transposed)")
+    add("after", "potential correspondences of the rows held (%d views): 4 B per entry, counted before they are written (~1.1 per record of those views) + row starts of all segments" % row_views, 1.1 * row_views * kept_view * 4 * 1.25 + nd * 8, "build_products (pot_tgt, pot_start)")
     add("after", "best references of all segments, hypotheses (96 B) + scores + indices of the views held (%d)" % held_views, nd * 12 + held_views * S * 112, "l3d_products_hypotheses")
     add("fill", "flags (1 B per local table entry), decision words (2^26 x 8 B), one block of candidates (2^27 x 20 B)", 2 * row_views * kept_view + (1 << 26) * 8 + (1 << 27) * 20, "l3d_affinity.hip:affinity_fill_core")
     add("fill", "first-touch minima of all hypotheses, own + gathered (8 B x (W + 2)), passed candidates own + gathered (12 B x 2)", n_hyp * 8 * (W + 2) + passed_all * 24, "l3d_affinity_fill_sharded")
@@ -136,9 +137,19 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--kept", type=float, nargs="+", default=[0.025, 0.25, 0.48])
     ap.add_argument("--mode", default="partition", choices=["partition", "segments", "segpart"])
+    ap.add_argument("--chain-world", type=int, default=0, help="segpart only: the world size the CHAIN runs at (0 = --world); 1 = one rank's share exercised on one GPU")
+    ap.add_argument("--json", action="store_true", help="the plan of the FIRST --kept value as one JSON object (scripts/run_rank_share.py compares it with a measured peak)")
     a = ap.parse_args()
     fn = dict(partition=plan_partition, segments=plan_segments, segpart=plan_segpart)[a.mode]
-    plans = [fn(a.views, a.segments, a.neighbors, a.world, k) for k in a.kept]
+    plans = [fn(a.views, a.segments, a.neighbors, a.world, k, a.chain_world) if a.mode == "segpart" else fn(a.views, a.segments, a.neighbors, a.world, k) for k in a.kept]
+    if a.json:
+        import json
+        p = plans[0]
+        g = lambda *ph: sum(r[2] for r in p[0] if r[0] in ph)
+        phases = dict(chain=g("all", "chain"), products=g("all", "products", "after"), fill=g("all", "after", "fill"), finish=g("all", "after", "finish"))
+        print(json.dumps(dict(mode=a.mode, kept=a.kept[0], peak_gb=round(max(phases.values()) / GB, 2), phases_gb={k: round(v / GB, 2) for k, v in phases.items()},
+                              rows=[dict(phase=r[0], what=r[1], gb=round(r[2] / GB, 3)) for r in p[0]], fields={k: float(v) for k, v in p[1].items()})))
+        return
     print("| per rank (%s), %d views x %d segments x %d neighbours, %d ranks | " % (a.mode, a.views, a.segments, a.neighbors, a.world) + " | ".join("kept %.1f %%" % (100 * k) for k in a.kept) + " | where |")
     print("|---|" + "---|" * (len(a.kept) + 1))
     for i, (phase, name, _b, where) in enumerate(plans[0][0]):

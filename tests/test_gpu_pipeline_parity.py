@@ -731,6 +731,38 @@ def test_products_built_in_blocks_of_views_equal_the_one_block_build(small_scene
     l.close()
 
 
+def test_products_variants_agree(small_scene, small_oracle):
+    """Round 6: matchViews' products are built as a transpose of the kept lists' run tables (kept writer: (local camera, target) words + a run table
+    per view; per-pair LDS transposes; a bitmap or, for short rows, a rank-and-dedupe per row) instead of a radix sort of 64-bit keys.  Every variant
+    -- the sort (L3D_PROD_TRANSPOSE=0), side arrays rebuilt from the records (L3D_RUN_TABLES=0: what the block and sharded modes do), the chain's own;
+    lanes per run, views per bitmap group -- gives the same table, best matches, hypotheses and kept lists byte for byte, on a sparse and a denser
+    scene (rows of more than 64 entries take the bitmap path)."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    for scene, N in ((small_scene, 6), (make_scene(10, 700, 8, seed=5, noise_px=0.05, step=0.05), 8)):
+        digests = []
+        for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1),
+                     dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=0, L3D_PROD_ROW_GROUP=512), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=64, L3D_PROD_BLOCK_KEYS=5000)):
+            l = Line3D("", matchingNeighbors=N)
+            l.keep_view_matches(False)
+            load_scene(l, scene)
+            l.prepare()
+            for k, v in opts.items():
+                l.context().set_option(k, v)
+            l.context().set_option("L3D_CHECK_POT", 1)
+            l.match_views()
+            l.finish(False)
+            d = _products_digest(l)
+            d["lines"] = repr([(list(s2), np.asarray(s3).tobytes()) for s2, s3 in l.getResult()])
+            digests.append(d)
+            if scene is small_scene:
+                assert_lines_equal(l.getResult(), small_oracle.result, 1e-4)
+            l.close()
+        assert len(digests[0]["pot_tgt"]) > 0
+        for i, d in enumerate(digests[1:], 1):
+            assert d == digests[0], i
+
+
 def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, monkeypatch):
     """commit="device": the sharded run hands no kept list to the host -- every rank builds matchViews' products on its device from the
     gathered slots (l3d_shard_chain_products).  World 1 (local exchange) and every rank of a recorded world-3 job (replay): kept lists,
