@@ -67,10 +67,12 @@ class Scene:
 
 def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234,
                noise_px: float = 0.5, width: int = 1920, height: int = 1080, f: float = 1500.0,
-               first_id: int = 0, step: float = 0.12, pp=(0.0, 0.0), seg_len=(0.1, 0.4), pool_factor: float = 1.5) -> Scene:
+               first_id: int = 0, step: float = 0.12, pp=(0.0, 0.0), seg_len=(0.1, 0.4), pool_factor: float = 1.5, turn_period: int = 0) -> Scene:
     """pp: offset of the principal point from the image centre in pixels; seg_len: range of the 3-D segment lengths (the box is 2 x 1.2 x 2 units at
-    distance ~4: 0.1-0.4 projects to 40-150 pixels at f = 1500; 0.003-0.008 to 1-3 pixels; 1.5-2.5 spans the image) -- defaults reproduce every
-    committed golden scene bit for bit."""
+    distance ~4: 0.1-0.4 projects to 40-150 pixels at f = 1500; 0.003-0.008 to 1-3 pixels; 1.5-2.5 spans the image); turn_period > 0: the helix's radius
+    and height repeat every that many turns instead of growing without bound (2048 views are 39 turns: at radius 17 the whole box projects into the
+    middle of the image and a view keeps 10-17 M matches instead of 4 M, profiles/r6_cfg5_2048_default_generator.txt) -- defaults reproduce every committed
+    golden scene bit for bit."""
     rng = SplitMix64(seed)
     K = np.array([[f, 0.0, width / 2.0 + pp[0]], [0.0, f, height / 2.0 + pp[1]], [0.0, 0.0, 1.0]])
 
@@ -80,6 +82,8 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
     for i in range(n_views):
         th = step * i
         turn = int(th // (2.0 * np.pi))
+        if turn_period > 0:
+            turn = turn % turn_period
         r = 4.0 + 0.35 * turn
         h = 0.3 * np.sin(0.7 * i) + 0.25 * turn
         C = np.array([r * np.cos(th), h, r * np.sin(th)]) + 0.02 * jit[i, :3]
@@ -126,7 +130,7 @@ def make_scene(n_views: int, n_segments: int, n_neighbors: int, seed: int = 1234
         views.append(dict(id=first_id + i, K=K.copy(), R=R.copy(), t=t.copy(), width=width, height=height,
                           segments=np.ascontiguousarray(segs, dtype=np.float32), sims=sims, gt=perm.copy()))
     params = dict(n_views=n_views, n_segments=n_segments, n_neighbors=n_neighbors, seed=seed,
-                  noise_px=noise_px, width=width, height=height, f=f, step=step, pp=tuple(pp), seg_len=tuple(seg_len))
+                  noise_px=noise_px, width=width, height=height, f=f, step=step, pp=tuple(pp), seg_len=tuple(seg_len), turn_period=turn_period)
     return Scene(views, np.concatenate([start, end], axis=1), params)
 
 

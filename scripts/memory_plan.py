@@ -18,7 +18,11 @@ import argparse
 GB = 1 << 30
 
 
-def model(V, S, N, kept_ratio, rho=0.065):
+RHO = [0.065]
+
+
+def model(V, S, N, kept_ratio, rho=None):
+    rho = RHO[0] if rho is None else rho
     n_tbm = N // 2                                     # interior views of a +-N/2 neighbourhood still match half of their neighbours
     raw_view = rho * S * S * n_tbm                     # stage-1 candidates of one view
     cand_view = raw_view / (1.0 - kept_ratio / 2.0)    # + reverse matches
@@ -138,8 +142,10 @@ def main():
     ap.add_argument("--kept", type=float, nargs="+", default=[0.025, 0.25, 0.48])
     ap.add_argument("--mode", default="partition", choices=["partition", "segments", "segpart"])
     ap.add_argument("--chain-world", type=int, default=0, help="segpart only: the world size the CHAIN runs at (0 = --world); 1 = one rank's share exercised on one GPU")
+    ap.add_argument("--rho", type=float, default=0.065, help="stage-1 candidates per segment pair (0.065: config 2; the 2048-view scene measures 0.11)")
     ap.add_argument("--json", action="store_true", help="the plan of the FIRST --kept value as one JSON object (scripts/run_rank_share.py compares it with a measured peak)")
     a = ap.parse_args()
+    RHO[0] = a.rho
     fn = dict(partition=plan_partition, segments=plan_segments, segpart=plan_segpart)[a.mode]
     plans = [fn(a.views, a.segments, a.neighbors, a.world, k, a.chain_world) if a.mode == "segpart" else fn(a.views, a.segments, a.neighbors, a.world, k) for k in a.kept]
     if a.json:

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--ranks", type=int, nargs="+", default=[3, 4])
     ap.add_argument("--window", type=int, default=64)
     ap.add_argument("--slot-records", type=int, default=0)
+    ap.add_argument("--turn-period", type=int, default=5, help="synth.make_scene(turn_period=...): the helix repeats every that many turns (0: the default generator, whose radius grows with "
+                    "every turn -- at 2048 views the scene then keeps 10-17 M matches per view and a rank's share exceeds 2^32 records)")
     ap.add_argument("--cand-cap", type=int, default=0)
     ap.add_argument("--arena-records", type=int, default=0, help="records of the rank's compact arena (0: the library's first guess, grown by capacity verdicts -- each one re-runs the chain)")
     a = ap.parse_args()
@@ -45,8 +47,8 @@ def main():
     from line3d_amd.distributed import default_slot_records
     V, S, N, W = a.views, a.segments, a.neighbors, a.world
     t0 = time.perf_counter()
-    scene = make_scene(V, S, N, seed=20260)
-    out = dict(shape=[V, S, N], world=W, scene_s=round(time.perf_counter() - t0, 2), ranks={})
+    scene = make_scene(V, S, N, seed=20260, turn_period=a.turn_period)
+    out = dict(shape=[V, S, N], world=W, turn_period=a.turn_period, scene_s=round(time.perf_counter() - t0, 2), ranks={})
     slot = a.slot_records or max(default_slot_records(S, N, 1), int(0.06 * S * S * N / 2 * 0.6) + 65536)   # world 1: a slot holds a whole view's kept list
     digests = {}
     for r in a.ranks:
@@ -60,8 +62,9 @@ def main():
         th = threading.Thread(target=sampler, daemon=True)
         l = Line3D("", matchingNeighbors=N)
         load_scene(l, scene)
-        t0 = time.perf_counter(); l.prepare(); t_prep = time.perf_counter() - t0
         ctx = l.context()
+        ctx.set_option("L3D_RESERVE_HINT", 0)          # (a partitioned job: the finishing stages' arenas are a share's, not the scene's)
+        t0 = time.perf_counter(); l.prepare(); t_prep = time.perf_counter() - t0
         ctx.set_option("L3D_PART_VRANK", r); ctx.set_option("L3D_PART_VWORLD", W)
         if a.cand_cap or a.arena_records:
             ctx.set_chain_capacities(a.cand_cap, a.arena_records)
@@ -77,9 +80,14 @@ def main():
         info = l.partition_info()
         st = l.stats()
         peak_chain = peak[0]
-        # (kept lists are hashed on the host: only the views near the block's ends, where a neighbouring rank's keep set overlaps this one's)
-        b0, b1 = (V * r) // W, (V * (r + 1)) // W
-        held = [k for k in range(info["held"][0], info["held"][1]) if min(abs(k - b0), abs(k - b1)) <= 2 * N]
+        # (kept lists are hashed on the host: only the views another rank of --ranks holds too -- a rank holds its block and 2 x reach = N views either side)
+        def held_range(q):
+            return range(max(0, (V * q) // W - N), min(V, (V * (q + 1)) // W + N))
+        others = set()
+        for q in a.ranks:
+            if q != r:
+                others |= set(held_range(q))
+        held = [k for k in range(info["held"][0], info["held"][1]) if k in others]
         t0 = time.perf_counter()
         d = {}
         n_held = 0
@@ -100,10 +108,12 @@ def main():
         lines = l.getResult()
         n_held_views = max(1, info["held"][1] - info["held"][0])
         kept_ratio = (st["kept"] / n_held_views) / max(1.0, st["raw"] / V)       # (the records this rank retired are those of the views it holds; the candidates are all views')
+        # stage-1 candidates per segment pair as measured: candidates verified = stage-1 + reverse matches (about half of the kept lists)
+        rho = (st["raw"] / V) * (1.0 - kept_ratio / 2.0) / (float(S) * S * (N // 2))
         plan = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "memory_plan.py"), "--views", str(V), "--segments", str(S), "--neighbors", str(N),
-                                                    "--world", str(W), "--mode", "segpart", "--chain-world", "1", "--kept", "%.4f" % kept_ratio, "--json"]).decode())
+                                                    "--world", str(W), "--mode", "segpart", "--chain-world", "1", "--kept", "%.4f" % kept_ratio, "--rho", "%.4f" % rho, "--json"]).decode())
         out["ranks"][r] = dict(prepare_s=round(t_prep, 2), chain_and_products_s=round(t_run, 2), finish_sharded_s=round(t_fin, 2), digests_s=round(t_dig, 2), partition=info,
-                               pairs=st["pairs"], candidates=st["raw"], kept_records_retired=st["kept"], views_held=n_held_views, kept_ratio=round(kept_ratio, 4), kept_records_hashed=n_held,
+                               pairs=st["pairs"], candidates=st["raw"], kept_records_retired=st["kept"], views_held=n_held_views, kept_ratio=round(kept_ratio, 4), rho_measured=round(rho, 4), kept_records_hashed=n_held,
                                g_pairs_per_s=round(st["pairs"] / t_run / 1e9, 2), hbm_after_prepare_gb=round(base, 2), hbm_peak_gb=round(peak[0], 2), hbm_peak_chain_gb=round(peak_chain, 2),
                                plan_peak_gb=plan["peak_gb"], plan=plan, peak_over_plan=round(peak[0] / plan["peak_gb"], 3),
                                affinity_entries_of_the_share=int(len(A)), lines_of_the_share=len(lines), match_path=l.match_path())
