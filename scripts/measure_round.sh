@@ -13,11 +13,11 @@ mkdir -p $out
 export TMPDIR=/tmp
 xa=${L3D_BENCH_ARGS:-}
 python3 bench.py $xa > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $xa --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $xa --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err
 find $out/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/write.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $out/valu -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/valu.err
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/fetch.err
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/write.err
+timeout 420 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $out/valu -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/valu.err
 f=$(find $out/fetch -name "*counter_collection.csv" | head -1); w=$(find $out/write -name "*counter_collection.csv" | head -1); v=$(find $out/valu -name "*counter_collection.csv" | head -1)
 python3 scripts/make_traffic.py $f $w > $out/traffic.json
 python3 scripts/make_valu.py $v > $out/valu.json

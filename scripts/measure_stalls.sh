@@ -27,7 +27,7 @@ for set in "${want[@]}"; do
     if grep -qw "$c" $out/avail.txt; then have="$have $c"; else echo "counter $c not available on this box" >> $out/missing.txt; fi
   done
   if [ -n "$have" ]; then
-    rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/pass$p -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/pass$p.err
+    timeout 420 rocprofv3 --kernel-trace --pmc $have --output-format csv -d $out/pass$p -- python3 bench.py $xa --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extras --no-cold > /dev/null 2> $out/pass$p.err
     f=$(find $out/pass$p -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && files="$files $f"
   fi

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 p=0
 for counters in "$@"; do
   rm -rf gpurun_out/pmc_$tag
-  rocprofv3 --kernel-trace --pmc $counters --output-format csv -d gpurun_out/pmc_$tag -- python3 scripts/bench_shape.py $V $S $N 0 > /dev/null 2> gpurun_out/pmc_$tag.err
+  timeout 300 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d gpurun_out/pmc_$tag -- python3 scripts/bench_shape.py $V $S $N 0 > /dev/null 2> gpurun_out/pmc_$tag.err
   f=$(find gpurun_out/pmc_$tag -name "*counter_collection.csv" | head -1)
   python3 scripts/pmc_summary.py $f | grep -E "$rx" >> gpurun_out/$tag.txt
   rm -rf gpurun_out/pmc_$tag
