@@ -451,7 +451,15 @@ def main():
             # the whole pass against the issue peak: summed VALU instructions of all kernels of one pass (committed PMC profile) over the wall time of a
             # pass (this run) and over the time the GPU is busy (the longer of the two streams' kernel sums of the bracketed pass: an upper bound of busy)
             tot_vi = 0.0
+            # (the products' two brackets cover several kernels each: their instructions come from the profile's own launch counts -- its PMC pass is ONE matchViews pass)
+            groups = {"prod_keys": ("k_prodv_pair_counts", "k_prodv_pair_transpose", "k_prod_early_rt", "k_prod_keys_early", "k_prod_best", "k_prod_median", "prod_keys"),
+                      "prod_rows": ("k_prodv_rows", "k_prodt_row_starts")}
             for kname, (kl, _kms) in prof_all.items():
+                if kname in groups and kname not in valu_json:
+                    for g in groups[kname]:
+                        e = valu_json.get(g, {})
+                        tot_vi += e.get("valu_wave_insts_per_launch", 0.0) * e.get("launches", 0)
+                    continue
                 tot_vi += valu_json.get(kname, {}).get("valu_wave_insts_per_launch", 0.0) * kl
             if tot_vi > 0:
                 km = roof["kernels_ms"]
