@@ -105,7 +105,7 @@ struct Products {
     ProductsPart part;
     int n_dense = 0, n_views_all = 0, n_chain = 0, n_hyp = 0;
     long long n_pot = 0, total_kept = 0;
-    DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables, ttab, rowstage;
+    DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables, ttab, rowstage, tstage;
     DevBuf geo, hyp_of, score, hyp_dense, best_hyp, coll, aux;       // greedy selection / affinity fill on the resident tables
     long long coll_n = 0;           // entries of the collinearity CSR resident in `coll` (with n_dense + 1 starts in front)
     unsigned long long coll_sig = 0; // checksum of what that copy was uploaded from (sizes, row starts, dense map)
@@ -119,7 +119,7 @@ struct Products {
     std::vector<unsigned> chain_view_id;
     void release()
     {
-        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &ttab, &rowstage, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
+        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &ttab, &rowstage, &tstage, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
         for (DevBuf* x : b) x->release();
         valid = hyp_valid = false; coll_n = 0; coll_sig = 0;
     }

@@ -51,6 +51,7 @@ namespace l3d {
     X(vw_split_avg, "L3D_VW_SPLIT_AVG", 4096, "vw_split = -1: split when the candidate capacity per segment of the launch is at least this") \
     X(prod_block_keys, "L3D_PROD_BLOCK_KEYS", 0, "key slots per block of the products' construction (0: 2^30 entries transposed, 2^28 key slots sorted; tests: small values force many blocks)") \
     X(prod_transpose, "L3D_PROD_TRANSPOSE", 1, "matchViews' products: 1 = rows from run tables, per-pair LDS transposes and an LDS bitmap per row (round 6), 0 = radix sort of two 64-bit keys per record (A/B)") \
+    X(prod_pair_stage, "L3D_PROD_PAIR_STAGE", 1, "transposed products: 1 = the pair transposes scatter in two levels (buckets of consecutive target segments in a staging region, then an LDS image written in whole lines), 0 = directly (A/B: 4 GB of partial-line write-backs per 0.6 GB of entries at 40 x 4000 x 24)") \
     X(prod_pair_g, "L3D_PROD_PAIR_G", -1, "transposed products: lanes sharing a run in the pair transposes (-1: by the average run, 0: a run per thread)") \
     X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \
     X(rt_g, "L3D_RT_G", -1, "resident chain with run tables: lanes sharing a run when a view collects its reverse matches (-1: by the average run, 0: a run per thread)") \

@@ -280,11 +280,19 @@ template <class F> __device__ __forceinline__ void for_run_words(const unsigned*
         if (i + 3 < b) f(i + 3, w3);
     }
 }
+// T (optional; round 6, late): the scatter in two levels.  The direct scatter below sends every 4-byte store of a pair's 650 KB region of E its own way:
+// 792 pairs' regions are sixteen times the L2s, every store ends as a partial-line write-back -- WRITE_SIZE 4.03 GB per launch for 0.62 GB of entries
+// (profiles/r6_cfg5_traffic.json).  With T the records first go, packed (u within its bucket << 14 | s), to one of NB buckets of consecutive u in a staging
+// region of the pair's size (NB sequential write streams per workgroup: their open lines fit the L2 and leave it full), then bucket by bucket into an LDS image of
+// the bucket's piece of E at their exact places (LDS cursors), and the image goes out in whole lines.  NB = the smallest power of two for which the largest bucket
+// fits `cap` entries of LDS (a pair whose single busiest u does not fit -- more than `cap` sources for one target segment -- scatters directly).
 __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const ProdPair* __restrict__ pairs, const ProdViewQ* __restrict__ vq, const ProdView* __restrict__ pv,
-                                                                       const ProdNbQ* __restrict__ nbq, const int* __restrict__ poff, int g, int* __restrict__ boff, unsigned* __restrict__ E)
+                                                                       const ProdNbQ* __restrict__ nbq, const int* __restrict__ poff, int g, int* __restrict__ boff, unsigned* __restrict__ E,
+                                                                       unsigned* __restrict__ T, int cap)
 {
     extern __shared__ int s_h[];
     __shared__ int s_w[kPairThreads / 64];
+    __shared__ int s_kb;
     const ProdPair pr = pairs[blockIdx.x];
     const ProdViewQ v = vq[pr.k];
     const int S = pv[pr.k].S, St = nbq[v.nb_off + pr.q].t_S;
@@ -317,9 +325,51 @@ __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const Pro
     for (int w = 0; w < kPairThreads / 64; ++w) { if (w < wave) run += s_w[w]; all += s_w[w]; }
     int* bo = boff + pr.off_off;
     for (int u = u0; u < u1; ++u) { const int c = s_h[u]; s_h[u] = run; bo[u] = run; run += c; }
-    if (tid == 0) bo[St] = all;
+    if (tid == 0) { bo[St] = all; s_h[St] = all; }
     __syncthreads();
     unsigned* e = E + poff[blockIdx.x];
+    if (T && cap > 0 && all > 32768) {                          // (a small region -- config 2: 3 k entries per pair -- is written in place: it stays in L2)
+        // bucket width: the smallest shift kb (from "32 buckets" down to one u per bucket) for which every bucket's piece of E fits the LDS image
+        if (tid == 0) s_kb = -1;
+        __syncthreads();
+        int kb0 = 0;
+        while ((St >> kb0) > 32) ++kb0;
+        for (int kb = kb0; kb >= 0; --kb) {
+            const int nbk = (St + (1 << kb) - 1) >> kb;
+            int bad = nbk > cap ? 1 : 0;                              // (level 1 keeps a cursor per bucket in the image)
+            for (int b = tid; b < nbk; b += kPairThreads) bad |= (s_h[min(St, (b + 1) << kb)] - s_h[b << kb]) > cap ? 1 : 0;
+            if (__syncthreads_or(bad) == 0) { if (tid == 0) s_kb = kb; break; }
+        }
+        __syncthreads();
+        const int kb = s_kb;
+        if (kb >= 0) {
+            unsigned* t = T + poff[blockIdx.x];
+            int* img = s_h + St + 2;                                   // the bucket's piece of E (cap ints); in front of it, level 1's write cursors of the buckets (reused)
+            const int nbk = (St + (1 << kb) - 1) >> kb;
+            int* bcur = img;                                          // (nbk <= cap: asserted by the host's choice of cap >= 512)
+            for (int b = tid; b < nbk; b += kPairThreads) bcur[b] = s_h[b << kb];
+            __syncthreads();
+            const unsigned umask = (1u << kb) - 1u;
+            auto lvl1 = [&](int s, unsigned w) { const unsigned u = w & 0xffffu; if ((int)u < St) t[atomicAdd(&bcur[u >> kb], 1)] = ((u & umask) << 14) | (unsigned)s; };
+            if (g == 0) { for (int s = tid; s < S; s += kPairThreads) for_run_words(qt, r0[s], r1[s], [&](int, unsigned w) { lvl1(s, w); }); }
+            else for (int s = grp; s < S; s += ngrp) { const int a = r0[s], b = r1[s]; for (int i = a + gl; i < b; i += g) lvl1(s, qt[i]); }
+            __threadfence_block();
+            __syncthreads();
+            for (int b = 0; b < nbk; ++b) {
+                const int ub = b << kb, p0 = s_h[ub], p1 = s_h[min(St, (b + 1) << kb)];     // (s_h[u] is still the START of column u: level 1 used its own cursors)
+                __syncthreads();                                       // (the image of the bucket before is out)
+                // the bucket's records, in any order, to their places: a cursor per u of the bucket (the counts are gone: cursors run from the column starts,
+                // kept apart in the image's tail so that s_h stays the column starts)
+                int* cur = img + cap;                                  // 1 << kb ints
+                for (int j = tid; j < (1 << kb) && ub + j <= St; j += kPairThreads) cur[j] = s_h[min(St, ub + j)] - p0;
+                __syncthreads();
+                for (int i = p0 + tid; i < p1; i += kPairThreads) { const unsigned x = t[i]; img[atomicAdd(&cur[x >> 14], 1)] = (int)(x & 0x3fffu); }
+                __syncthreads();
+                for (int i = tid; i < p1 - p0; i += kPairThreads) e[p0 + i] = (unsigned)img[i];
+            }
+            return;
+        }
+    }
     if (g == 0) {
         for (int s = tid; s < S; s += kPairThreads)
             for_run_words(qt, r0[s], r1[s], [&](int, unsigned w) { const int u = (int)(w & 0xffffu); if (u < St) e[atomicAdd(&s_h[u], 1)] = (unsigned)s; });
@@ -348,11 +398,18 @@ __global__ __launch_bounds__(256) void k_prod_early_rt(const ProdView* __restric
     if (!sq.rt || s.n_kept == 0) return;
     const int* r0 = sq.rt + (size_t)slot * s.S;
     const int* r1 = r0 + s.S;
-    for (int sg = blockIdx.x * 256 + threadIdx.x; sg < s.S; sg += gridDim.x * 256) {
-        for_run_words(sq.qt, r0[sg], r1[sg], [&](int i, unsigned w) {
+    // sixteen lanes per run (coalesced words; a run per thread touched 64 lines per wave instruction), the list length by a reduction over the wave -- one
+    // atomic per record on ONE counter was 1.5 ms per build at 40 x 4000 x 24
+    constexpr int g = 16;
+    const int grp = threadIdx.x / g, gl = threadIdx.x % g, ngrp = 256 / g;
+    int n_mine = 0;
+    for (int sg = blockIdx.x * ngrp + grp; sg < s.S; sg += gridDim.x * ngrp) {
+        const int ra = r0[sg], rb = r1[sg];
+        for (int i = ra + gl; i < rb; i += g) {
+            const unsigned w = sq.qt[i];
             const int u = (int)(w & 0xffffu);                   // the view's segment (the record's segID2); sg = the record's segID1
             if (MODE == 0) {
-                atomicAdd(&list_len[e.view], 1);
+                ++n_mine;
                 if (u < v.S && !e.pad) atomicMin(&best_ref[v.dense_base + u], ((unsigned long long)e.rank << 40) | (unsigned long long)(s.kept_base + i));
             } else if (u < v.S && sg < e.alias_S) {
                 const int ai = v.dense_base + u, di = e.alias_base + sg;
@@ -365,7 +422,11 @@ __global__ __launch_bounds__(256) void k_prod_early_rt(const ProdView* __restric
                     else ent[bstart[di - d0] + atomicSub(&cnt[di - d0], 1) - 1] = (unsigned)ai;
                 }
             }
-        });
+        }
+    }
+    if (MODE == 0) {
+        for (int d = 32; d > 0; d >>= 1) n_mine += __shfl_down(n_mine, d);
+        if ((threadIdx.x & 63) == 0 && n_mine) atomicAdd(&list_len[e.view], n_mine);
     }
 }
 
@@ -719,7 +780,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
     {
         ProfScope p(c, "prod_keys", st);
         if (!ps.empty() && native_rt)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<0>), dim3((unsigned)std::max(1, (maxS + 255) / 256), (unsigned)ps.size()), dim3(256), 0, st, dpv, devq, dps, dslot, (const int*)nullptr, 0, 0,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<0>), dim3((unsigned)std::max(1, std::min(256, (maxS + 15) / 16)), (unsigned)ps.size()), dim3(256), 0, st, dpv, devq, dps, dslot, (const int*)nullptr, 0, 0,
                                (int*)nullptr, (const int*)nullptr, (unsigned*)nullptr, P.best_ref.as<unsigned long long>(), d_list_len);
         else if (!ps.empty()) hipLaunchKernelGGL(k_prod_keys_early, dim3(gx, (unsigned)ps.size()), dim3(256), 0, st, arena, dpv, dps, (const long long*)nullptr, dcv, nb, 0, 0,
                                                  (unsigned long long*)nullptr, P.best_ref.as<unsigned long long>(), d_list_len);
@@ -925,11 +986,20 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                         int g = 1;
                         while (g < 64 && g < recs / std::max(1.0, cells) / 4.0) g <<= 1;
                         if (c->opt.prod_pair_g >= 0) g = c->opt.prod_pair_g;
-                        hipLaunchKernelGGL(k_prodv_pair_transpose, dim3((unsigned)n_pairs), dim3(kPairThreads), ((size_t)B.maxS + 2) * 4, st, dpr + B.pair0, dvq, dpv, dnb, (const int*)poff, g, boff, E);
+                        // two-level scatter (prod_pair_stage: 1 on, 0 the direct scatter): an LDS image of `cap` entries of E per workgroup + a cursor per u of a bucket
+                        int cap = 0;
+                        unsigned* T = nullptr;
+                        if (c->opt.prod_pair_stage != 0) {
+                            cap = 12288;
+                            while (cap > 1024 && ((size_t)B.maxS + 2 + 2 * (size_t)cap) * 4 > 64 * 1024) cap -= 1024;
+                            if (((size_t)B.maxS + 2 + 2 * (size_t)cap) * 4 <= 64 * 1024) { HIPCHK(c, P.tstage.reserve((size_t)max_rec * 4 + 256)); T = P.tstage.as<unsigned>(); } else cap = 0;
+                        }
+                        hipLaunchKernelGGL(k_prodv_pair_transpose, dim3((unsigned)n_pairs), dim3(kPairThreads), ((size_t)B.maxS + 2 + 2 * (size_t)cap) * 4, st, dpr + B.pair0, dvq, dpv, dnb,
+                                           (const int*)poff, g, boff, E, T, cap);
                     }
                     if (B.n_srcs) {
                         HIPCHK(c, hipMemsetAsync(cnt, 0, ((size_t)rows + 1) * 4, st));
-                        const dim3 eg((unsigned)std::max(1, (maxS + 255) / 256), (unsigned)B.n_srcs);
+                        const dim3 eg((unsigned)std::max(1, std::min(256, (maxS + 15) / 16)), (unsigned)B.n_srcs);
                         if (!rebuild) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_early_rt<1>), eg, dim3(256), 0, st, dpv, dvq, dps, dslot, dsr + B.src0, d0, d1, cnt, (const int*)bstart, ent,
                                                          (unsigned long long*)nullptr, (int*)nullptr);
                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodt_early<false>), dim3(gx, (unsigned)B.n_srcs), dim3(256), 0, st, arena, dpv, dps, dsr + B.src0, dcv, d0, d1, cnt, (const int*)bstart, ent);
