@@ -145,7 +145,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     for (auto e : c->prof_event_pool) (void)hipEventDestroy(e);
     for (auto e : c->local_event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->src_segs, &c->tgt_segs, &c->tables, &c->tbm, &c->l2g, &c->exist, &c->mask, &c->rowcnt, &c->row_start,
-                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->vw_bstart, &c->vw_segstate, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_keptcam, &c->ch_rt, &c->ch_rtinfo, &c->ch_rtjobs, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
+                       &c->cand_meta, &c->cand_depths, &c->cand_conf, &c->kept_cnt, &c->kept_start, &c->best, &c->kept, &c->scal, &c->stamps, &c->vw_scratch, &c->vw_bstart, &c->vw_segstate, &c->ch_tables, &c->ch_mask, &c->ch_rowcnt, &c->ch_cursor, &c->ch_best, &c->ch_kept, &c->ch_keptcam, &c->ch_rt, &c->ch_rtinfo, &c->ch_rtjobs, &c->ch_existpart, &c->ch_res, &c->ch_flags, &c->ch_send, &c->ch_gathered, &c->ch_stage, &c->ch_rowA, &c->ch_ringA_meta, &c->ch_ringA_depths, &c->ch_segorder,
                        &c->ch_rays, &c->aff_hyp, &c->aff_first, &c->aff_pass_pairs, &c->aff_pass_w, &c->aff_l2g, &c->edges_keep, &c->g0, &c->g1, &c->g2, &c->g3, &c->g4, &c->g5, &c->g6, &c->g7 };
     for (auto* b : bufs) b->release();
     c->ch_bestpos.release(); c->ch_hdr.release();

@@ -76,21 +76,46 @@ __global__ void k_exist_count(const Match* __restrict__ arena, const unsigned* _
 // (slot = this view's local camera number in w's neighbour list) -- read directly, through the packed side array (4 bytes per record: the target
 // segment is all the count needs), instead of scanning the source's whole list for them: 1/N of it is touched, twelve sources' lists are not.
 // g (a power of two) lanes share a run.
-__global__ __launch_bounds__(256) void k_exist_count_rt(const unsigned* __restrict__ qt_arena, const RtInfo* __restrict__ info, const ChainResult* __restrict__ res,
-                                                        const int* __restrict__ src_index, const int* __restrict__ src_cam, const int* __restrict__ src_slot, int g, int N, int S,
-                                                        int* __restrict__ rowcnt)
+// (round 6, late) NO GLOBAL ATOMICS: 2 M scattered atomicAdds per view -- every one on its own 64-byte line, the rows being N x 4 bytes apart -- ran at
+// 14 G/s whatever fed them (144 us per view at 40 x 4000 x 24, with or without the run tables).  A source's segments are cut into kExistChunks chunks; a
+// workgroup per (chunk, source) counts its runs' targets in LDS and leaves its S counters in `part`; k_exist_combine turns every (source, target segment)'s
+// chunk counts into chunk BASES (exclusive sums, in place) and stores the row count; k_place_rt's scatter workgroups -- one per (chunk, source) again -- start
+// their LDS cursors at row start + chunk base and place their records without a global cursor.
+constexpr int kExistChunks = 16;
+constexpr int kExistThreads = 1024;         // (sixteen waves per (chunk, source): a workgroup's critical path is its runs / waves dependent load pairs)
+__global__ __launch_bounds__(kExistThreads) void k_exist_count_rt(const unsigned* __restrict__ qt_arena, const RtInfo* __restrict__ info, const ChainResult* __restrict__ res,
+                                                        const int* __restrict__ src_index, const int* __restrict__ src_slot, int g, int S, int* __restrict__ part)
 {
-    const int si = src_index[blockIdx.y], cam = src_cam[blockIdx.y], slot = src_slot[blockIdx.y];
+    extern __shared__ int s_hist[];
+    const int j = blockIdx.y, ch = blockIdx.x;
+    const int si = src_index[j], slot = src_slot[j];
     const RtInfo w = info[si];
-    if (!w.rt || slot < 0 || res[si].n_kept == 0) return;
-    const unsigned* qt = qt_arena + res[si].kept_base;
-    const int* r0 = w.rt + (size_t)slot * w.S;
-    const int* r1 = r0 + w.S;
-    const int grp = threadIdx.x / g, gl = threadIdx.x - grp * g, ngrp = 256 / g;
-    for (int s = blockIdx.x * ngrp + grp; s < w.S; s += gridDim.x * ngrp) {
-        const int a = r0[s], b = r1[s];
-        for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < S) atomicAdd(&rowcnt[u * N + cam], 1); }
+    int* out = part + ((size_t)j * kExistChunks + ch) * S;
+    for (int u = threadIdx.x; u < S; u += kExistThreads) s_hist[u] = 0;
+    __syncthreads();
+    if (w.rt && slot >= 0 && res[si].n_kept > 0) {
+        const unsigned* qt = qt_arena + res[si].kept_base;
+        const int* r0 = w.rt + (size_t)slot * w.S;
+        const int* r1 = r0 + w.S;
+        const int s_lo = (int)(((long long)w.S * ch) / kExistChunks), s_hi = (int)(((long long)w.S * (ch + 1)) / kExistChunks);
+        const int grp = threadIdx.x / g, gl = threadIdx.x - grp * g, ngrp = kExistThreads / g;
+        for (int s = s_lo + grp; s < s_hi; s += ngrp) {
+            const int a = r0[s], b = r1[s];
+            for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < S) atomicAdd(&s_hist[u], 1); }
+        }
     }
+    __syncthreads();
+    for (int u = threadIdx.x; u < S; u += kExistThreads) out[u] = s_hist[u];
+}
+__global__ __launch_bounds__(256) void k_exist_combine(int* __restrict__ part, const int* __restrict__ src_cam, int N, int S, int* __restrict__ rowcnt)
+{
+    const int j = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= S) return;
+    int* p = part + (size_t)j * kExistChunks * S + u;
+    int run = 0;
+#pragma unroll
+    for (int ch = 0; ch < kExistChunks; ++ch) { const int t = p[(size_t)ch * S]; p[(size_t)ch * S] = run; run += t; }
+    if (run) atomicAdd(&rowcnt[u * N + src_cam[j]], run);           // (one thread per cell: the atomic only keeps the add whole beside stage 1's rows of other cameras)
 }
 // the side array of records that did not come from the kept writer (a block's sources taken over from another rank)
 __global__ void k_cams_of_records(const Match* __restrict__ arena, long long n, unsigned* __restrict__ cams)
@@ -189,7 +214,9 @@ __global__ __launch_bounds__(256) void k_place(int blocks_move, int bps, const i
         place(i);
     }
 }
-// k_place with run tables: the stage-1 rows are moved as above, the reverse matches come from the sources' runs towards this view (k_exist_count_rt)
+// k_place with run tables (default): the stage-1 rows are moved as in k_place, the reverse matches come from the sources' runs towards this view through the
+// global row cursors -- 6000 small workgroups in one launch with the move: faster than 192 (or 768) big ones with LDS cursors in a launch of their own
+// (cand_move 12.0 against 17.1 / 13.2 ms at 40 x 4000 x 24, NOTEBOOK 12.f)
 __global__ __launch_bounds__(256) void k_place_rt(int blocks_move, int bps, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                   const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
                                                   const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
@@ -221,6 +248,39 @@ __global__ __launch_bounds__(256) void k_place_rt(int blocks_move, int bps, cons
             if ((int)r.segID2 < S) {
                 const int row = r.segID2 * N + cam;
                 const int sl = row_start[row] + atomicAdd(&cursor[row], 1);
+                meta[sl] = make_uint2(r.segID1, (unsigned)cam);
+                depths[sl] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
+            }
+        }
+    }
+}
+// (A/B, option rt_place_lds) k_place with run tables: the stage-1 rows are moved by k_place itself (launched without sources); the reverse matches by a launch of their own -- one workgroup
+// of kExistThreads per (chunk, source), LDS cursors from the row starts and the chunk bases of k_exist_combine: no global cursor, no global atomic
+__global__ __launch_bounds__(kExistThreads) void k_place_scatter_rt(const Match* __restrict__ arena, const ChainResult* __restrict__ res, const int* __restrict__ src_index,
+                                                                    const int* __restrict__ src_cam, int N, int S, const int* __restrict__ row_start,
+                                                                    uint2* __restrict__ meta, float4* __restrict__ depths, int cap,
+                                                                    const RtInfo* __restrict__ info, const int* __restrict__ src_slot, int g, const int* __restrict__ part)
+{
+    extern __shared__ int s_cur[];
+    if (row_start[(size_t)S * N] > cap) return;
+    const int sj = blockIdx.y, bx = blockIdx.x;
+    const int si = src_index[sj], cam = src_cam[sj], slot = src_slot[sj];
+    const RtInfo w = info[si];
+    if (!w.rt || slot < 0 || res[si].n_kept == 0) return;
+    const int* base = part + ((size_t)sj * kExistChunks + bx) * S;
+    for (int u = threadIdx.x; u < S; u += kExistThreads) s_cur[u] = row_start[u * N + cam] + base[u];
+    __syncthreads();
+    const Match* kept = arena + res[si].kept_base;
+    const int* r0 = w.rt + (size_t)slot * w.S;
+    const int* r1 = r0 + w.S;
+    const int s_lo = (int)(((long long)w.S * bx) / kExistChunks), s_hi = (int)(((long long)w.S * (bx + 1)) / kExistChunks);
+    const int grp = threadIdx.x / g, gl = threadIdx.x - grp * g, ngrp = kExistThreads / g;
+    for (int sg = s_lo + grp; sg < s_hi; sg += ngrp) {
+        const int a = r0[sg], b = r1[sg];
+        for (int i = a + gl; i < b; i += g) {
+            const Match r = kept[i];
+            if ((int)r.segID2 < S) {
+                const int sl = atomicAdd(&s_cur[r.segID2], 1);
                 meta[sl] = make_uint2(r.segID1, (unsigned)cam);
                 depths[sl] = make_float4(r.depths[2], r.depths[3], r.depths[0], r.depths[1]);
             }
@@ -303,21 +363,30 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams, int bps,
-                  const RtInfo* info, const int* src_slot, int g)
+                  const RtInfo* info, const int* src_slot, int g, const int* part)
 {
     bps = std::max(1, bps);
     const int blocks_move = (S * n_tbm + 3) / 4;
     const int blocks = blocks_move + bps * n_src;
-    if (blocks > 0 && info) hipLaunchKernelGGL(k_place_rt, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, res, src_index, src_cam,
-                                               N, S, row_start, cursor, meta, depths, cand_cap, info, src_slot, std::max(1, g));
+    if (info && part) {     // (option rt_place_lds, A/B) the move by k_place without sources, the scatter by kExistChunks workgroups per source with LDS cursors of S ints
+        if (blocks_move > 0) hipLaunchKernelGGL(k_place, dim3(blocks_move), dim3(256), 0, st, blocks_move, 1, tbm, n_tbm, rowA, metaA, depthsA, arena, (const unsigned*)nullptr, res, src_index, src_cam,
+                                                view_id, N, S, row_start, cursor, meta, depths, cand_cap);
+        if (n_src > 0 && S > 0) hipLaunchKernelGGL(k_place_scatter_rt, dim3(kExistChunks, n_src), dim3(kExistThreads), (size_t)S * 4, st, arena, res, src_index, src_cam, N, S, row_start, meta, depths,
+                                                   cand_cap, info, src_slot, std::max(1, g), part);
+    }
+    else if (info) { if (blocks > 0) hipLaunchKernelGGL(k_place_rt, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, res, src_index, src_cam,
+                                                         N, S, row_start, cursor, meta, depths, cand_cap, info, src_slot, std::max(1, g)); }
     else if (blocks > 0) hipLaunchKernelGGL(k_place, dim3(blocks), dim3(256), 0, st, blocks_move, bps, tbm, n_tbm, rowA, metaA, depthsA, arena, cams, res, src_index, src_cam,
                                             view_id, N, S, row_start, cursor, meta, depths, cand_cap);
 }
-void launch_exist_count_rt(const unsigned* qt_arena, const RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g, int bps,
-                           int N, int S, int* rowcnt, hipStream_t st)
+void launch_exist_count_rt(const unsigned* qt_arena, const RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g,
+                           int N, int S, int* rowcnt, int* part, hipStream_t st)
 {
-    if (n_src > 0) hipLaunchKernelGGL(k_exist_count_rt, dim3(std::max(1, bps), n_src), dim3(256), 0, st, qt_arena, info, res, src_index, src_cam, src_slot, g, N, S, rowcnt);
+    if (n_src <= 0 || S <= 0) return;
+    hipLaunchKernelGGL(k_exist_count_rt, dim3(kExistChunks, n_src), dim3(kExistThreads), (size_t)S * 4, st, qt_arena, info, res, src_index, src_slot, std::max(1, g), S, part);
+    hipLaunchKernelGGL(k_exist_combine, dim3((S + 255) / 256, n_src), dim3(256), 0, st, part, src_cam, N, S, rowcnt);
 }
+int exist_chunks() { return kExistChunks; }
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st)
 {
     hipLaunchKernelGGL(k_raw_stats, dim3(1), dim3(1024), 0, st, rowcnt, N, seg_begin, seg_end, out2_host);
@@ -398,6 +467,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         info.resize((size_t)n_views);
         for (int k = 0; k < n_views; ++k) info[(size_t)k] = RtInfo{ vd[(size_t)k].rt, views[k].S_src, views[k].N };
         HIPCHK(c, c->ch_rtinfo.reserve((size_t)n_views * sizeof(RtInfo) + 64));
+        HIPCHK(c, c->ch_existpart.reserve((size_t)std::max(1, L.maxN) * exist_chunks() * (size_t)std::max(1, L.maxS) * 4 + 256));     // chunk counts / bases of a view's sources
         HIPCHK(c, hipMemcpyAsync(c->ch_rtinfo.p, info.data(), info.size() * sizeof(RtInfo), hipMemcpyHostToDevice, st));
     }
     const unsigned char* dtab = L.dtab;
@@ -637,7 +707,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         // tables' extra level of dependent loads (12.2 vs 12.9 ms per config-2 pass); the side array holds (camera, target) words then, not camera ids
         const bool rt_exist = use_rt && views_seen > 0 && kept_seen / views_seen > (double)kCamScanMin;
         const unsigned* scan_cams = use_rt ? nullptr : cams;
-        if (rt_exist) { ProfScope p(c, "exist"); launch_exist_count_rt(cams, d_info, dres, d_si, d_sc, d_ss, v.n_sources, rt_g, rt_bps, N, S, d.rowcnt, st); }
+        if (rt_exist) { ProfScope p(c, "exist"); launch_exist_count_rt(cams, d_info, dres, d_si, d_sc, d_ss, v.n_sources, rt_g, N, S, d.rowcnt, c->ch_existpart.as<int>(), st); }
         else { ProfScope p(c, "exist"); launch_exist_count(arena, dres, d_si, d_sc, v.n_sources, v.view_id, N, S, d.rowcnt, st, scan_cams, bps); }
         // combined row starts (+ zeroed scatter cursors, + the segments ordered longest first for the verification launch)
         { ProfScope p(c, "scan"); launch_scan(d.rowcnt, c->row_start.as<int>(), (int)nrow, c->ch_cursor.as<int>(), st, c->ch_segorder.as<int>(), N, 0, S); }
@@ -646,7 +716,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 ProfScope p(c, "cand_move");
                 launch_place(pa.tbm, v.n_tbm, N, S, d.rowA, ringA_meta(k), ringA_depths(k), arena, dres, d_si, d_sc, v.n_sources, v.view_id,
                              c->row_start.as<int>(), c->ch_cursor.as<int>(), (int)cand_cap, c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), st, scan_cams, rt_exist ? rt_bps : bps,
-                             rt_exist ? d_info : nullptr, d_ss, rt_g);
+                             rt_exist ? d_info : nullptr, d_ss, rt_g, c->opt.rt_place_lds ? c->ch_existpart.as<int>() : nullptr);
             }
             if (v.n_sources && !(c->verify_mode == 0 && verify_window_supported(N))) {     // (the window kernel orders the runs itself)
                 ProfScope p(c, "exist");

@@ -159,7 +159,7 @@ struct l3d_ctx {
     l3d::DevBuf kept_cnt, kept_start, best, kept, scal, stamps, vw_scratch;
     l3d::PinBuf pin_tab, pin_ex, pin_scal, pin_best, pin_kept;
     // arenas of the resident chain (l3d_chain.hip)
-    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_keptcam, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays, ch_rt, ch_rtinfo, ch_rtjobs;
+    l3d::DevBuf ch_tables, ch_mask, ch_rowcnt, ch_cursor, ch_best, ch_kept, ch_keptcam, ch_res, ch_flags, ch_send, ch_gathered, ch_stage, ch_rowA, ch_ringA_meta, ch_ringA_depths, ch_segorder, ch_rays, ch_rt, ch_rtinfo, ch_rtjobs, ch_existpart;
     l3d::PinBuf ch_pin_tables, ch_pin_res, ch_pin_kept, ch_pin_best;
     long long shard_graph_launches = 0;          // views enqueued as one graph launch so far (l3d_get_option "shard_graph_launches")
     std::vector<l3d::ShardGraph> shard_graphs;   // per view of the sharded chain (repeated passes replay them)

@@ -163,10 +163,11 @@ void launch_exist_sort_runs(const int* cams, int n_cams, int N, int S, const int
 void launch_place(const int* tbm, int n_tbm, int N, int S, const int* rowA, const uint2* metaA, const float4* depthsA,
                   const Match* arena, const ChainResult* res, const int* src_index, const int* src_cam, int n_src, unsigned view_id,
                   const int* row_start, int* cursor, int cand_cap, uint2* meta, float4* depths, hipStream_t st, const unsigned* cams = nullptr, int bps = 32,
-                  const struct RtInfo* info = nullptr, const int* src_slot = nullptr, int g = 1);
+                  const struct RtInfo* info = nullptr, const int* src_slot = nullptr, int g = 1, const int* part = nullptr);
+int exist_chunks();
 // (run tables, l3d_runtable.hpp: the sources' runs towards this view instead of scans of their lists)
-void launch_exist_count_rt(const unsigned* qt_arena, const struct RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g, int bps,
-                           int N, int S, int* rowcnt, hipStream_t st);
+void launch_exist_count_rt(const unsigned* qt_arena, const struct RtInfo* info, const ChainResult* res, const int* src_index, const int* src_cam, const int* src_slot, int n_src, int g,
+                           int N, int S, int* rowcnt, int* part, hipStream_t st);
 void launch_raw_stats(const int* rowcnt, int N, int seg_begin, int seg_end, int* out2_host, hipStream_t st);
 void launch_kept_write_chain(const VerifyArgs& a, const int* kept_cnt, int nrow, const ChainResult* prev, unsigned long long arena_cap, ChainResult* res,
                              ChainResult* res_host, const unsigned* l2g, Match* arena, hipStream_t st, int* best_pos = nullptr, unsigned* cams = nullptr,
