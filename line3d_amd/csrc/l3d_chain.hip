@@ -596,12 +596,16 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             }
             if (!jobs.empty()) {
                 auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-                const size_t o_ids = al(jobs.size() * sizeof(RtJob)), o_qs = o_ids + al(ids.size() * 4), o_err = o_qs + al(qs.size() * 4);
-                HIPCHK(c, c->ch_rtjobs.reserve(o_err + 256));       // (not ch_stage: the taken-over records may live there)
+                const size_t o_ids = al(jobs.size() * sizeof(RtJob)), o_qs = o_ids + al(ids.size() * 4), o_err = o_qs + al(qs.size() * 4), o_key = o_err + 256;
+                size_t n_keys = 0;
+                for (const RtJob& j : jobs) n_keys += (size_t)j.n;
+                HIPCHK(c, c->ch_rtjobs.reserve(o_key + n_keys * 4 + 256));       // (not ch_stage: the taken-over records may live there)
                 unsigned char* sb = c->ch_rtjobs.as<unsigned char>();
                 int max_n = 0, max_cells = 0;
+                size_t ko = 0;
                 for (size_t i = 0; i < jobs.size(); ++i) {
                     jobs[i].ids = reinterpret_cast<const unsigned*>(sb + o_ids) + at[i]; jobs[i].qs = reinterpret_cast<const int*>(sb + o_qs) + at[i];
+                    jobs[i].skey = reinterpret_cast<unsigned*>(sb + o_key) + ko; ko += (size_t)jobs[i].n;
                     max_n = std::max(max_n, jobs[i].n); max_cells = std::max(max_cells, (jobs[i].N + 1) * jobs[i].S);
                 }
                 HIPCHK(c, hipMemcpyAsync(sb, jobs.data(), jobs.size() * sizeof(RtJob), hipMemcpyHostToDevice, st));

@@ -67,21 +67,33 @@ int chain_plan_views(l3d_ctx* c, const l3d_chain_view* views, int n_views, int r
 __global__ __launch_bounds__(256) void k_qt_from_records(const RtJob* __restrict__ jobs, int* __restrict__ err)
 {
     const RtJob j = jobs[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) {
-        const Match r = j.recs[i];
-        int lo = 0, hi = j.N;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (j.ids[mid] < r.camID2) lo = mid + 1; else hi = mid; }
-        const bool known = lo < j.N && j.ids[lo] == r.camID2 && (int)r.segID1 < j.S && r.segID2 < 65536u;
-        const unsigned q = known ? (unsigned)j.qs[lo] : 0xffffu;
-        j.qt[i] = (q << 16) | (r.segID2 & 0xffffu);
-        if (!known) atomicAdd(err, 1);
-        else if (i > 0) {
-            const Match p = j.recs[i - 1];
-            int l2 = 0, h2 = j.N;
-            while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (j.ids[mid] < p.camID2) l2 = mid + 1; else h2 = mid; }
-            const unsigned pq = l2 < j.N && j.ids[l2] == p.camID2 ? (unsigned)j.qs[l2] : 0u;
-            if (p.segID1 > r.segID1 || (p.segID1 == r.segID1 && pq > q)) atomicAdd(err, 1);
+    const int lane = threadIdx.x & 63;
+    // (whole waves iterate together: the order check takes the previous record's key from the neighbouring lane)
+    for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < j.n; i0 += gridDim.x * 256) {
+        const int i = i0 + lane;
+        unsigned key = 0xffffffffu;
+        if (i < j.n) {
+            const Match r = j.recs[i];
+            int lo = 0, hi = j.N;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (j.ids[mid] < r.camID2) lo = mid + 1; else hi = mid; }
+            const bool known = lo < j.N && j.ids[lo] == r.camID2 && (int)r.segID1 < j.S && r.segID2 < 65536u;
+            const unsigned q = known ? (unsigned)j.qs[lo] : 0xffu;
+            j.qt[i] = ((known ? q : 0xffffu) << 16) | (r.segID2 & 0xffffu);
+            key = known ? (r.segID1 << 8) | q : 0xffffffffu;
+            j.skey[i] = key;
+            if (!known) atomicAdd(err, 1);
         }
+        const unsigned prev = __shfl_up(key, 1);                       // (lane 0 has no neighbour: k_qt_order_seams checks every 64th boundary)
+        if (lane > 0 && i < j.n && key != 0xffffffffu && prev != 0xffffffffu && prev > key) atomicAdd(err, 1);
+    }
+}
+// the wave boundaries of the order check (lane 0 of every wave of k_qt_from_records has no neighbour): one more thin pass over every 64th key
+__global__ __launch_bounds__(256) void k_qt_order_seams(const RtJob* __restrict__ jobs, int* __restrict__ err)
+{
+    const RtJob j = jobs[blockIdx.y];
+    for (int i = (blockIdx.x * 256 + threadIdx.x + 1) * 64; i < j.n; i += gridDim.x * 256 * 64) {
+        const unsigned a = j.skey[i - 1], b = j.skey[i];
+        if (a != 0xffffffffu && b != 0xffffffffu && a > b) atomicAdd(err, 1);
     }
 }
 __global__ __launch_bounds__(256) void k_rt_from_qt(const RtJob* __restrict__ jobs)
@@ -91,19 +103,18 @@ __global__ __launch_bounds__(256) void k_rt_from_qt(const RtJob* __restrict__ jo
     for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += gridDim.x * 256) {
         const int q = c / j.S, s = c - q * j.S;
         // first record whose (segment, camera) is >= (s, q); row N: (s + 1, 0)
-        const unsigned long long want = q < j.N ? ((unsigned long long)s << 16) | (unsigned)q : ((unsigned long long)(s + 1) << 16);
+        const unsigned want = q < j.N ? ((unsigned)s << 8) | (unsigned)q : ((unsigned)(s + 1) << 8);
         int lo = 0, hi = j.n;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const unsigned long long key = ((unsigned long long)j.recs[mid].segID1 << 16) | (j.qt[mid] >> 16);
-            if (key < want) lo = mid + 1; else hi = mid;
-        }
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (j.skey[mid] < want) lo = mid + 1; else hi = mid; }
         j.rt[c] = lo;
     }
 }
 void launch_qt_from_records(const RtJob* jobs_dev, int n_jobs, int max_n, int* err, hipStream_t st)
 {
-    if (n_jobs > 0 && max_n > 0) hipLaunchKernelGGL(k_qt_from_records, dim3((unsigned)std::max(1, std::min(512, (max_n + 1023) / 1024)), (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, err);
+    if (n_jobs > 0 && max_n > 0) {
+        hipLaunchKernelGGL(k_qt_from_records, dim3((unsigned)std::max(1, std::min(512, (max_n + 1023) / 1024)), (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, err);
+        hipLaunchKernelGGL(k_qt_order_seams, dim3((unsigned)std::max(1, std::min(64, (max_n / 64 + 255) / 256)), (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, err);
+    }
 }
 void launch_rt_from_qt(const RtJob* jobs_dev, int n_jobs, int max_cells, hipStream_t st)
 {

@@ -933,7 +933,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         const double t_res1 = now_s();
         HIPCHK(c, P.keys2.reserve(((size_t)max_rec + (size_t)max_early) * 4 + 256));
         HIPCHK(c, P.flag.reserve((5 * ra + 2 * pa + (size_t)max_boff) * 4 + 256));
-        if (rebuild) { HIPCHK(c, P.keys.reserve((size_t)max_rec * 4 + 256)); HIPCHK(c, P.pos.reserve((size_t)max_rt * 4 + 256)); }
+        if (rebuild) { HIPCHK(c, P.keys.reserve((size_t)max_rec * 4 + 256)); HIPCHK(c, P.pos.reserve((size_t)max_rt * 4 + 256)); HIPCHK(c, P.tstage.reserve((size_t)max_rec * 4 + 256)); }
         size_t tbs = 0;
         HIPCHK(c, exclusive_sum_int(nullptr, tbs, nullptr, nullptr, std::max(max_rows, max_pairs) + 1, st));
         HIPCHK(c, P.tmp.reserve(tbs + 256));
@@ -964,6 +964,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                             RtJob j;
                             j.recs = arena + hres[k].kept_base; j.qt = P.keys.as<unsigned>() + qo; j.rt = P.pos.as<int>() + ro;
                             j.ids = dids + nb_off[(size_t)k]; j.qs = dqs + nb_off[(size_t)k]; j.n = hres[k].n_kept; j.S = views[k].S_src; j.N = views[k].N; j.pad = 0;
+                            j.skey = P.tstage.as<unsigned>() + qo;            // (the staging region of the pair transposes, not in use yet)
                             vqh[(size_t)k].qt = j.qt; vqh[(size_t)k].rt = j.rt;
                             qo += j.n; ro += ((long long)j.N + 1) * j.S;
                             max_n = std::max(max_n, j.n); max_cells = std::max(max_cells, (j.N + 1) * j.S);

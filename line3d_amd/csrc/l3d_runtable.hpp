@@ -17,6 +17,8 @@ struct RtJob {                      // one view's list
     const unsigned* ids;            // the view's neighbours' global ids, ascending
     const int* qs;                  // ... and their local camera numbers
     int n, S, N, pad;
+    unsigned* skey;                 // scratch, n words: (segment << 8 | local camera) per record -- what the run table's lower bounds search (4 contiguous bytes per probe
+                                    // instead of a 32-byte record and a side word)
 };
 
 // qt of every job's records; *err counts records whose camera is not a neighbour or whose (segment, camera) order descends (the tables would be wrong)
