@@ -51,17 +51,30 @@ struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off, cam_off; int s
 // reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
 // (blockIdx.y = source * world + rank)
 __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
-                                    const int* __restrict__ src_cam, unsigned view_id, int N, int s0, int s1, int* __restrict__ rowcnt)
+                                    const int* __restrict__ src_cam, const int* __restrict__ src_slot, unsigned view_id, int N, int s0, int s1, int* __restrict__ rowcnt)
 {
     const int src = blockIdx.y / g.world, r = blockIdx.y % g.world;
     const unsigned char* slot = G + ((size_t)(src_index[src] % g.ring) * g.world + r) * g.slot_bytes;
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
-    const unsigned* cams = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;     // (dense scenes: 4 bytes per record decide, 1 record in N is read)
+    // side array (dense scenes): (the record's LOCAL camera << 16 | its target segment) -- camera and segment range are decided on 4 bytes, the count reads no
+    // record (round 5: the global camera id; the 1 record in N that matched was read, 7 in 8 of those for another rank's range)
+    const unsigned* side = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;
     const int cam = src_cam[src];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (cams && cams[i] != view_id) continue;
+    const unsigned want = (unsigned)src_slot[src];
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (side) {
+        auto count = [&](unsigned w) { const int u = (int)(w & 0xffffu); if ((w >> 16) == want && u >= s0 && u < s1) atomicAdd(&rowcnt[u * N + cam], 1); };
+        for (; i + 3 * stride < n; i += 4 * stride) {      // four words in flight per thread
+            const unsigned c0 = side[i], c1 = side[i + stride], c2 = side[i + 2 * stride], c3 = side[i + 3 * stride];
+            count(c0); count(c1); count(c2); count(c3);
+        }
+        for (; i < n; i += stride) count(side[i]);
+        return;
+    }
+    for (; i < n; i += stride) {
         const Match m = kept[i];
         if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) atomicAdd(&rowcnt[m.segID2 * N + cam], 1);
     }
@@ -74,7 +87,7 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
 __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, const int* __restrict__ tbm, int n_tbm, const int* __restrict__ rowA,
                                                      const uint2* __restrict__ metaA, const float4* __restrict__ depthsA,
                                                      const unsigned char* __restrict__ G, SlotGeom g, const int* __restrict__ src_index,
-                                                     const int* __restrict__ src_cam, unsigned view_id, int N, int S, int s0, int s1,
+                                                     const int* __restrict__ src_cam, const int* __restrict__ src_slot, unsigned view_id, int N, int S, int s0, int s1,
                                                      const int* __restrict__ row_start, int* __restrict__ cursor,
                                                      uint2* __restrict__ meta, float4* __restrict__ depths, int cap)
 {
@@ -93,10 +106,10 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, c
     const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(slot);
     const int n = hd->overflow ? 0 : hd->n_kept;
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
-    const unsigned* cams = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;
+    const unsigned* side = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;     // (local camera << 16 | target segment): k_exist_count_slots
     const int cam = src_cam[src];
-    for (int i = bx * 256 + (int)threadIdx.x; i < n; i += wps * 256) {
-        if (cams && cams[i] != view_id) continue;
+    const unsigned want = (unsigned)src_slot[src];
+    auto place = [&](int i) {
         const Match m = kept[i];
         if (m.camID2 == view_id && (int)m.segID2 >= s0 && (int)m.segID2 < s1) {
             const int row = m.segID2 * N + cam;
@@ -104,7 +117,22 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, c
             meta[slotpos] = make_uint2(m.segID1, (unsigned)cam);
             depths[slotpos] = make_float4(m.depths[2], m.depths[3], m.depths[0], m.depths[1]);
         }
+    };
+    auto mine = [&](unsigned w) { const int u = (int)(w & 0xffffu); return (w >> 16) == want && u >= s0 && u < s1; };
+    const int stride = wps * 256;
+    int i = bx * 256 + (int)threadIdx.x;
+    if (side) {     // (four words in flight per thread; a record is read only where the word says it is this rank's)
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            const unsigned c0 = side[i], c1 = side[i + stride], c2 = side[i + 2 * stride], c3 = side[i + 3 * stride];
+            if (mine(c0)) place(i);
+            if (mine(c1)) place(i + stride);
+            if (mine(c2)) place(i + 2 * stride);
+            if (mine(c3)) place(i + 3 * stride);
+        }
+        for (; i < n; i += stride) if (mine(side[i])) place(i);
+        return;
     }
+    for (; i < n; i += stride) place(i);
 }
 
 // Kept records of this rank's source-segment range [s0,s1) into its slot, in ONE launch behind the verification (every
@@ -140,7 +168,9 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     if (tid == 0) reinterpret_cast<float2*>(slot + g.best_off)[yl] = best[y];
     int* bpos = reinterpret_cast<int*>(slot + g.bpos_off) + yl;              // (position in this slot's records; -1: the segment kept nothing)
     if (h.overflow) { if (tid == 0) *bpos = -1; return; }
-    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best, g.cam_off ? reinterpret_cast<unsigned*>(slot + g.cam_off) : nullptr);
+    // (round 6) the side array holds (local camera << 16 | target segment): a reader decides camera AND segment range on 4 bytes -- the count reads no record at all
+    write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best, g.cam_off ? reinterpret_cast<unsigned*>(slot + g.cam_off) : nullptr,
+                          nullptr, 0, nullptr, true);
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -508,11 +538,11 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     // workgroups per (source view, rank) list of the two scans of the sources' slots: 16 for the lists of a sparse scene (a few thousand records: 5 steps
     // per thread), one per 4096 records of the slot's capacity on a dense one -- 650 k records per slot at 4000 segments x 24 neighbours were 160
     // dependent loads per thread (measured on one emulated rank of eight, 64 x 4000 x 24: exist + cand_move 47 -> see profiles/r5_emulated_rank_*)
-    const int wps = std::max(16, std::min(256, h->geom.slot_records / 4096));
+    const int wps = std::max(16, std::min(256, h->geom.slot_records / (h->c->opt.slot_scan_grain > 0 ? h->c->opt.slot_scan_grain : 4096)));
     auto issue = [&]() {
         if (v.n_sources) {
             ProfScope p(c, "exist");
-            hipLaunchKernelGGL(k_exist_count_slots, dim3(wps, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, v.view_id, N, d.s0, d.s1, d.rowcnt);
+            hipLaunchKernelGGL(k_exist_count_slots, dim3(wps, v.n_sources * h->world), dim3(256), 0, st, h->gathered, h->geom, d_si, d_sc, reinterpret_cast<const int*>(h->dtab + d.o_ss), v.view_id, N, d.s0, d.s1, d.rowcnt);
         }
         // row starts of this rank's rows only (+ zeroed scatter cursors, segment order); row_start[nrow] = their total
         { ProfScope p(c, "scan"); launch_scan_range(d.rowcnt, c->row_start.as<int>(), N, d.s0, d.s1, (int)nrow, c->ch_cursor.as<int>(), c->ch_segorder.as<int>(), st); }
@@ -524,7 +554,7 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
                 hipLaunchKernelGGL(k_place_slots, dim3(blocks), dim3(256), 0, st, blocks_move, wps, pa.tbm, v.n_tbm, d.rowA,
                                    c->ch_ringA_meta.as<uint2>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
                                    c->ch_ringA_depths.as<float4>() + (size_t)(k % l3d_shard_chain::kRingA) * h->cand_cap,
-                                   h->gathered, h->geom, d_si, d_sc, v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
+                                   h->gathered, h->geom, d_si, d_sc, reinterpret_cast<const int*>(h->dtab + d.o_ss), v.view_id, N, S, d.s0, d.s1, c->row_start.as<int>(), c->ch_cursor.as<int>(),
                                    c->cand_meta.as<uint2>(), c->cand_depths.as<float4>(), (int)h->cand_cap);
         }
         // (the window kernel orders the runs itself -- except on a rank's small launch of a dense scene: a segment's workgroup ranks its 12 runs three per

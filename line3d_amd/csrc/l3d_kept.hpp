@@ -22,7 +22,7 @@ namespace l3d {
 __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y, int o, const unsigned* __restrict__ local2global,
                                                       Match* __restrict__ out, int* s_cnt, int* __restrict__ best_pos = nullptr,
                                                       unsigned long long* s_best = nullptr, unsigned* __restrict__ cam_out = nullptr,
-                                                      int* __restrict__ rt = nullptr, int rt_stride = 0, int* s_qcnt = nullptr)
+                                                      int* __restrict__ rt = nullptr, int rt_stride = 0, int* s_qcnt = nullptr, bool pack_side = false)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int start = a.row_start[y * a.N];
@@ -57,7 +57,7 @@ __device__ __forceinline__ void write_kept_segment_wg(const VerifyArgs& a, int y
                 rec.confidence = c[r] / 2.0f;                    // confidence_norm, cudawrapper.cu:1089,1098
                 const int pos = o + off + __popcll(b[r] & ((1ull << lane) - 1ull));
                 out[pos] = rec;
-                if (cam_out) cam_out[pos] = rt ? ((meta.y << 16) | meta.x) : rec.camID2;   // (the chain's side array: see rt above; without run tables the global camera id, scanned by later views)
+                if (cam_out) cam_out[pos] = (rt || pack_side) ? ((meta.y << 16) | meta.x) : rec.camID2;   // (pack_side: the sharded chain's slots, without run tables)   // (the chain's side array: see rt above; without run tables the global camera id, scanned by later views)
                 if (rt) atomicAdd(&s_qcnt[meta.y], 1);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(c[r]) << 32) | (0xffffffffu - (unsigned)pos);   // (c > 1: the bits order like the value)
                 bk = key > bk ? key : bk;

@@ -54,6 +54,7 @@ namespace l3d {
     X(prod_pair_stage, "L3D_PROD_PAIR_STAGE", 1, "transposed products: 1 = the pair transposes scatter in two levels (buckets of consecutive target segments in a staging region, then an LDS image written in whole lines), 0 = directly (A/B: 4 GB of partial-line write-backs per 0.6 GB of entries at 40 x 4000 x 24)") \
     X(prod_pair_g, "L3D_PROD_PAIR_G", -1, "transposed products: lanes sharing a run in the pair transposes (-1: by the average run, 0: a run per thread)") \
     X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \
+    X(slot_scan_grain, "L3D_SLOT_SCAN_GRAIN", 0, "sharded chain: records of a slot per workgroup of the two scans of the sources' slots (0: 4096)") \
     X(rt_place_lds, "L3D_RT_PLACE_LDS", 0, "resident chain with run tables: 1 = reverse matches placed by big workgroups with LDS cursors from the chunk bases (no global cursor; measured slower: too few workgroups), 0 = through the global row cursors (A/B)") \
     X(rt_g, "L3D_RT_G", -1, "resident chain with run tables: lanes sharing a run when a view collects its reverse matches (-1: by the average run, 0: a run per thread)") \
     X(part_vrank, "L3D_PART_VRANK", 0, "with part_vworld: the rank of the job whose block of views a world-1 partitioned run keeps") \
