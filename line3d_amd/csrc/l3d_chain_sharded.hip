@@ -46,7 +46,7 @@ struct SlotHeader { int n_kept, R, overflow, s0, s1, pad[3]; };
 static_assert(sizeof(SlotHeader) == 32, "slot header");
 
 // ring: view blocks the gathered buffer holds (view k lives in block k % ring); n_views when every block is kept
-struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off, cam_off; int seg_cap, slot_records, world, ring; };   // cam_off: 0 = the slot carries no side array of target cameras
+struct SlotGeom { size_t slot_bytes, best_off, bpos_off, rec_off, cam_off, rt_off; int seg_cap, slot_records, world, ring, max_n; };   // rt_off: 0 = no run table in the slot   // cam_off: 0 = the slot carries no side array of target cameras
 
 // reverse matches for view `view_id`, source-segment range [s0,s1), out of the gathered slots of earlier views
 // (blockIdx.y = source * world + rank)
@@ -62,9 +62,24 @@ __global__ void k_exist_count_slots(const unsigned char* __restrict__ G, SlotGeo
     // record (round 5: the global camera id; the 1 record in N that matched was read, 7 in 8 of those for another rank's range)
     const unsigned* side = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;
     const int cam = src_cam[src];
+    if (src_slot[src] < 0) return;                              // (this view is not among the source's neighbours: no record of it points here)
     const unsigned want = (unsigned)src_slot[src];
     const int stride = gridDim.x * blockDim.x;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (side && g.rt_off && (int)want <= g.max_n) {
+        if (n <= 0) return;                                     // (an overflowed slot holds no records and no run table)
+        // run tables: the runs of this view's camera in the rank's slot, sixteen lanes per run
+        const int* rt = reinterpret_cast<const int*>(slot + g.rt_off);
+        const int* r0 = rt + (size_t)want * g.seg_cap;
+        const int* r1 = r0 + g.seg_cap;
+        const int nsl = hd->s1 - hd->s0;
+        const int grp = i >> 4, gl = i & 15, ngrp = stride >> 4;
+        for (int sl = grp; sl < nsl; sl += ngrp) {
+            const int a = r0[sl], b = r1[sl];
+            for (int k = a + gl; k < b; k += 16) { const unsigned w = side[k]; const int u = (int)(w & 0xffffu); if (u >= s0 && u < s1) atomicAdd(&rowcnt[u * N + cam], 1); }
+        }
+        return;
+    }
     if (side) {
         auto count = [&](unsigned w) { const int u = (int)(w & 0xffffu); if ((w >> 16) == want && u >= s0 && u < s1) atomicAdd(&rowcnt[u * N + cam], 1); };
         for (; i + 3 * stride < n; i += 4 * stride) {      // four words in flight per thread
@@ -108,6 +123,7 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, c
     const Match* kept = reinterpret_cast<const Match*>(slot + g.rec_off);
     const unsigned* side = g.cam_off ? reinterpret_cast<const unsigned*>(slot + g.cam_off) : nullptr;     // (local camera << 16 | target segment): k_exist_count_slots
     const int cam = src_cam[src];
+    if (src_slot[src] < 0) return;                              // (this view is not among the source's neighbours: no record of it points here)
     const unsigned want = (unsigned)src_slot[src];
     auto place = [&](int i) {
         const Match m = kept[i];
@@ -121,6 +137,19 @@ __global__ __launch_bounds__(256) void k_place_slots(int blocks_move, int wps, c
     auto mine = [&](unsigned w) { const int u = (int)(w & 0xffffu); return (w >> 16) == want && u >= s0 && u < s1; };
     const int stride = wps * 256;
     int i = bx * 256 + (int)threadIdx.x;
+    if (side && g.rt_off && (int)want <= g.max_n) {     // run tables: k_exist_count_slots
+        if (n <= 0) return;
+        const int* rt = reinterpret_cast<const int*>(slot + g.rt_off);
+        const int* r0 = rt + (size_t)want * g.seg_cap;
+        const int* r1 = r0 + g.seg_cap;
+        const int nsl = hd->s1 - hd->s0;
+        const int grp = i >> 4, gl = i & 15, ngrp = stride >> 4;
+        for (int sl = grp; sl < nsl; sl += ngrp) {
+            const int a = r0[sl], b = r1[sl];
+            for (int k = a + gl; k < b; k += 16) { const unsigned w = side[k]; const int u = (int)(w & 0xffffu); if (u >= s0 && u < s1) place(k); }
+        }
+        return;
+    }
     if (side) {     // (four words in flight per thread; a record is read only where the word says it is this rank's)
         for (; i + 3 * stride < n; i += 4 * stride) {
             const unsigned c0 = side[i], c1 = side[i + stride], c2 = side[i + 2 * stride], c3 = side[i + 3 * stride];
@@ -145,6 +174,7 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
 {
     __shared__ int s_red[8];
     __shared__ int s_cnt[32];
+    __shared__ int s_qcnt[256];
     __shared__ unsigned long long s_best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = a.seg_end - a.seg_begin;
@@ -169,8 +199,10 @@ __global__ __launch_bounds__(256) void k_slot_write(VerifyArgs a, const int* __r
     int* bpos = reinterpret_cast<int*>(slot + g.bpos_off) + yl;              // (position in this slot's records; -1: the segment kept nothing)
     if (h.overflow) { if (tid == 0) *bpos = -1; return; }
     // (round 6) the side array holds (local camera << 16 | target segment): a reader decides camera AND segment range on 4 bytes -- the count reads no record at all
+    // the run table's rows are seg_cap apart and indexed by the segment's position in the rank's range (the writer indexes by the segment: the base is shifted)
+    int* rt = g.rt_off ? reinterpret_cast<int*>(slot + g.rt_off) - a.seg_begin : nullptr;
     write_kept_segment_wg(a, y, before, local2global, reinterpret_cast<Match*>(slot + g.rec_off), s_cnt, bpos, s_best, g.cam_off ? reinterpret_cast<unsigned*>(slot + g.cam_off) : nullptr,
-                          nullptr, 0, nullptr, true);
+                          rt, g.seg_cap, s_qcnt, true);
 }
 
 // Hand-over of one finished view on a committing rank: the ranks' kept records, concatenated in rank (= segment) order
@@ -426,7 +458,12 @@ int l3d_shard_chain_open(l3d_ctx* c, const l3d_chain_view* views, int n_views, i
     // neighbour makes of it (k_exist_count_slots, k_place_slots) read 4 bytes per record instead of 32; + 12.5 % on the all-gather.  Measured on one
     // emulated rank of eight at 64 x 4000 x 24 (profiles/r5_emulated_rank_64x4000x24_w8_partition.txt)
     h->geom.cam_off = slot_records >= c->opt.slot_cams_min ? salign(h->geom.rec_off + (size_t)slot_records * sizeof(Match), 32) : 0;
-    h->geom.slot_bytes = salign((h->geom.cam_off ? h->geom.cam_off + (size_t)slot_records * 4 : h->geom.rec_off + (size_t)slot_records * sizeof(Match)), 256);
+    // ... and (round 6) the slot's RUN TABLE, (N + 1) x seg_cap ints (l3d_runtable.hpp; positions in the slot's records): a later neighbour reads the runs of its
+    // camera -- 1/N of the slot -- instead of scanning the side array (188 MB per view and rank at 64 x 4000 x 24 on eight ranks)
+    h->geom.max_n = h->maxN;
+    h->geom.rt_off = h->geom.cam_off && c->opt.run_tables != 0 ? salign(h->geom.cam_off + (size_t)slot_records * 4, 32) : 0;
+    h->geom.slot_bytes = salign(h->geom.rt_off ? h->geom.rt_off + ((size_t)h->maxN + 1) * h->geom.seg_cap * 4
+                                : (h->geom.cam_off ? h->geom.cam_off + (size_t)slot_records * 4 : h->geom.rec_off + (size_t)slot_records * sizeof(Match)), 256);
     *slot_bytes = h->geom.slot_bytes;
 
     auto bail = [&](int rc) { delete h; return rc; };
@@ -538,7 +575,9 @@ int l3d_shard_chain_enqueue(l3d_shard_chain* h, int k, void* send_slot, const vo
     // workgroups per (source view, rank) list of the two scans of the sources' slots: 16 for the lists of a sparse scene (a few thousand records: 5 steps
     // per thread), one per 4096 records of the slot's capacity on a dense one -- 650 k records per slot at 4000 segments x 24 neighbours were 160
     // dependent loads per thread (measured on one emulated rank of eight, 64 x 4000 x 24: exist + cand_move 47 -> see profiles/r5_emulated_rank_*)
-    const int wps = std::max(16, std::min(256, h->geom.slot_records / (h->c->opt.slot_scan_grain > 0 ? h->c->opt.slot_scan_grain : 4096)));
+    // workgroups per (source, rank) list: a scan wants them by the slot's records; with run tables a list is seg_cap runs of sixteen lanes
+    const int wps = h->geom.rt_off ? std::max(1, std::min(256, (h->geom.seg_cap * 16 + 255) / 256))
+                                   : std::max(16, std::min(256, h->geom.slot_records / (h->c->opt.slot_scan_grain > 0 ? h->c->opt.slot_scan_grain : 4096)));
     auto issue = [&]() {
         if (v.n_sources) {
             ProfScope p(c, "exist");
