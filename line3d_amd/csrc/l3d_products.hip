@@ -237,14 +237,12 @@ __global__ __launch_bounds__(256) void k_prod_shift_rows(const long long* __rest
 // rebuilt here, block by block, for lists that did not come out of the single-GPU chain): the 32-byte records are not read at all.
 //   k_prodv_pair_counts     records of every pair that targets the block (sums of run lengths)        -> where its transposed entries go
 //   k_prodv_pair_transpose  per pair: column starts boff[u] and the source segments grouped by u (E)
-//   k_prodv_rows<false>     one wave per row: F and B set bits in an LDS bitmap over the segments of the views the row's view touches --
-//   exclusive_sum_int       sorted and unique by construction -- popcount = the row's length; the scan gives the CSR's row starts;
-//   k_prodv_rows<true>      the bitmap again, expanded into the row's place.
-// A target is a BIT INDEX in the row view's bit space: the views it touches (its neighbours, the views it is a neighbour of, what the
-// early-return quirk files under it) ascending, each padded to whole 32-bit words, so that bit order = dense order and a word belongs to one view
-// (dense id of a word's bit 0: `dow`).  Transients: 4 bytes per backward entry (rounds 3-5: 48 bytes per record in key arrays); the table's entries
-// are counted before they are written, so the table is reserved at its size.  The hipCUB radix sort is off matchViews' path (kept as A/B and as
-// the way out for lists that are not ordered).
+//   k_prodv_rows<false>     one wave per row, view by view of the views the row's view touches (ascending: dense order): the F run of that camera and the B column
+//   exclusive_sum_int       of that pair set bits in a bitmap of the view's segments -- sorted and unique by construction; popcount = the row's length; the scan
+//   k_prodv_rows<true>      gives the CSR's row starts; the bitmaps again, expanded into the row's place.  Rows of at most 64 entries: ranked by shuffles instead.
+// Transients: 4 bytes per backward entry (+ 4 for the staging of the two-level scatter; rounds 3-5: 48 bytes per record in key arrays); the table's entries are
+// counted before they are written, so the table is reserved at its size.  The hipCUB radix sort is off matchViews' path (kept as A/B and as the way out for lists
+// that are not ordered).
 struct ProdNbQ { int t_base, t_S; };                                  // chain view k, LOCAL camera q: the target view's dense range (-1: not in the map)
 struct ProdViewQ { const unsigned* qt; const int* rt; int nb_off, N; }; // a chain view's list through its side array and run table (null: no records here)
 struct ProdPair { int k, q, off_off, pad; };                            // a (chain view, local camera) pair that targets a view of the block; where its column starts live in boff
