@@ -341,6 +341,8 @@ def main():
                 raise RuntimeError("every multi-GPU mode failed")
             sharded_mode["i"] += 1
 
+    if dist is not None and args.warmup == 0 and not args.partition:
+        step()          # (untimed: the multi-GPU mode is settled -- a mode that fails moves all ranks to the next one -- before anything is timed, warm-up or not)
     for _ in range(args.warmup):
         step()
     prof_all, dominant = {}, None

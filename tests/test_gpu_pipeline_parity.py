@@ -763,6 +763,43 @@ def test_products_variants_agree(small_scene, small_oracle):
             assert d == digests[0], i
 
 
+def test_products_of_a_hub_view_touched_by_more_than_64_views():
+    """A view that (nearly) all 79 other views list as a neighbour (and that lists two of them): its rows of the table collect entries from 79 (view, camera) pairs -- the rows
+    kernel's lanes look the touched views up 64 at a time, the short-row path does not apply.  Transposed products (the chain's side arrays and rebuilt ones)
+    against the sorted ones and against the plain host construction (L3D_CHECK_POT); kept lists against the per-view seam path."""
+    from line3d_amd.pipeline import Line3D
+    from line3d_amd.synth import make_scene
+    V = 80
+    HUB = V // 2
+    sc = make_scene(V, 150, 3, seed=31, step=0.012, noise_px=0.2)      # (80 views within 0.96 rad: every view sees much of what the hub in the middle sees)
+    for i, v in enumerate(sc.views):
+        o1, o2 = ((i + d) % V if (i + d) % V != HUB else (i + d + 1) % V for d in (6, 12))      # (three neighbours: a kept match needs two witnesses' cameras)
+        v["sims"] = {HUB + 6: 1.0, HUB - 6: 0.9, HUB + 12: 0.8} if i == HUB else {HUB: 1.0, o1: 0.5, o2: 0.4}
+    digests, paths = [], []
+    for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1)):
+        l = Line3D("", matchingNeighbors=3)
+        for v in sc.views:
+            l.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
+        l.prepare()
+        for k, val in opts.items():
+            l.context().set_option(k, val)
+        l.context().set_option("L3D_CHECK_POT", 1)
+        l.match_views()
+        paths.append(l.match_path())
+        l.finish(False)
+        p = l.resident_products()
+        if p is not None:
+            d = {k: np.ascontiguousarray(p[k]).tobytes() for k in ("seg_base", "pot_start", "pot_tgt", "best", "hyp", "score")}
+            rows0 = int(p["pot_start"][150 * (HUB + 1)]) - int(p["pot_start"][150 * HUB])        # entries of the hub's rows
+            d["lines"] = repr([(list(s2), np.asarray(s3).tobytes()) for s2, s3 in l.getResult()])
+            digests.append((d, rows0))
+        l.close()
+    assert paths == [paths[0]] * 3
+    assert paths[0] == 0                                       # the resident chain took the scene: the device products exist
+    assert len(digests) == 3 and digests[0][1] > 64            # (the hub's rows hold entries of many views)
+    assert digests[1][0] == digests[0][0] and digests[2][0] == digests[0][0]
+
+
 def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, monkeypatch):
     """commit="device": the sharded run hands no kept list to the host -- every rank builds matchViews' products on its device from the
     gathered slots (l3d_shard_chain_products).  World 1 (local exchange) and every rank of a recorded world-3 job (replay): kept lists,
