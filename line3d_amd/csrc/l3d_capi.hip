@@ -157,6 +157,7 @@ void l3d_ctx_destroy(l3d_ctx* c)
     for (auto& kv : c->resident) if (!c->resident_arena_of.count(kv.first)) (void)hipFree(kv.second.first);
     for (auto& a : c->resident_arenas) if (a.first) (void)hipFree(a.first);
     if (c->mask_stream) (void)hipStreamDestroy(c->mask_stream);
+    if (c->prod_stream) (void)hipStreamDestroy(c->prod_stream);
     (void)hipStreamDestroy(c->stage1_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);

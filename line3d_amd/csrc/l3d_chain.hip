@@ -551,10 +551,55 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     }
 
     const bool use_cams = c->opt.kept_cams != 0;         // (0: A/B -- the sources' lists are scanned record by record)
+    // early pair transposes (round 6, l3d_products.hip): a (view, camera) pair of the potential-correspondence build depends on that view's kept list alone, so
+    // it is transposed on a side stream right behind the view's kept writer -- next to the following views' chains -- and the end of matchViews finds only the rows
+    // left.  Entries live in an array aligned with the kept arena (a view's pairs hold exactly its records).  L3D_PROD_EARLY=0: all transposes at the end (A/B)
+    Products& PE = c->products;
+    // Long lists only (option value 1; 2: always): at config 2 (36 k records per view) the two launches and the event per view cost the enqueueing thread more than
+    // the 0.2 ms of transposes they take off the end (12.60 vs 12.41 ms per pass); at 4000 x 24 (3.9 M per view) the end shrinks from 8.3 to 5.6 ms.  The lists'
+    // length: what the last pass over this scene kept, or the arena's first guess
+    bool early = map && use_rt && !ranged && !pre && !cb && c->opt.prod_early != 0 && c->opt.prod_transpose != 0 && maxN > 0;
+    if (early && c->opt.prod_early == 1) {
+        const double per_view = (same_scene && c->chain_seen_kept > 0 ? c->chain_seen_kept : pairs * 0.004) / std::max(1, n_views);
+        early = per_view > (double)kCamScanMin;
+    }
+    hipStream_t sp = nullptr;
+    int early_maxSt = 1;
+    if (early) {
+        std::vector<int> tab((size_t)n_views * maxN * 2, 0);       // [St | boff_off], n_views x maxN each
+        PE.e_boff_off.assign((size_t)n_views * maxN, 0);
+        long long nb = 0;
+        for (int k = 0; k < n_views && early; ++k) {
+            if (!vd[(size_t)k].verified) continue;
+            for (int q = 0; q < views[k].N; ++q) {
+                const uint32_t* it = std::lower_bound(map->view_ids, map->view_ids + map->n_views, views[k].local2global[q]);
+                if (it == map->view_ids + map->n_views || *it != views[k].local2global[q]) continue;
+                const int t = (int)(it - map->view_ids), St = map->seg_base[t + 1] - map->seg_base[t];
+                if (St <= 0) continue;
+                tab[(size_t)k * maxN + q] = St;
+                tab[(size_t)n_views * maxN + (size_t)k * maxN + q] = (int)nb;
+                PE.e_boff_off[(size_t)k * maxN + q] = (int)nb;
+                nb += St + 1;
+                early_maxSt = std::max(early_maxSt, St);
+                if (nb > 0x7ffffff0ll) early = false;
+            }
+        }
+        if (early) {
+            if (!c->prod_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->prod_stream, hipStreamNonBlocking));
+            sp = c->prod_stream;
+            HIPCHK(c, PE.e_tab.reserve(tab.size() * 4 + 64));
+            HIPCHK(c, PE.e_cnt.reserve((size_t)n_views * maxN * 4 + 64));
+            HIPCHK(c, PE.e_poff.reserve((size_t)n_views * maxN * 4 + 64));
+            HIPCHK(c, PE.e_boff.reserve((size_t)nb * 4 + 64));
+            HIPCHK(c, hipMemcpyAsync(PE.e_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));                    // (`tab` is pageable and leaves scope)
+        }
+    }
     auto reserve_caps = [&]() -> int {
         if (int rc = chain_reserve_candidates(c, L, cand_cap, c->chain_ring ? kRing : 0)) return rc;
         HIPCHK(c, c->ch_kept.reserve(arena_cap * sizeof(Match)));
         if (use_cams) HIPCHK(c, c->ch_keptcam.reserve(arena_cap * 4 + 64));
+        if (early && arena_cap < 0x7ffffff0ull) { HIPCHK(c, PE.e_E.reserve(arena_cap * 4 + 64)); HIPCHK(c, PE.e_T.reserve(arena_cap * 4 + 64)); }
         return L3D_OK;
     };
     { int rc = reserve_caps(); if (rc) return rc; }
@@ -751,6 +796,13 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         // (with a delivery callback the host starts D2H copies of device memory once it has seen this event: a default, fenced event then)
         if (!ev[(size_t)k]) ev[(size_t)k] = cb ? get_event(c) : get_local_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
+        if (early && arena_cap < 0x7ffffff0ull) {
+            HIPCHK(c, hipStreamWaitEvent(sp, ev[(size_t)k], 0));
+            const double avg_run = views_seen > 0 ? kept_seen / views_seen / std::max(1.0, (double)S * std::max(1, N)) : 1.0;
+            const int* etab = PE.e_tab.as<int>();
+            launch_early_transposes(c, k, d.rt, etab + (size_t)k * maxN, etab + (size_t)n_views * maxN + (size_t)k * maxN, S, N, maxN, early_maxSt, dres, cams, PE.e_cnt.as<int>(),
+                                    PE.e_poff.as<unsigned>(), PE.e_boff.as<int>(), PE.e_E.as<unsigned>(), PE.e_T.as<unsigned>(), avg_run, sp);
+        }
         return L3D_OK;
     };
 
@@ -849,6 +901,8 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             // not enough room for this view's candidates / kept matches: everything before it is valid and stays
             // in the arena; wait for the queue (and the delivery of earlier views) to drain, grow, and re-enqueue from this view
             if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(sm), "hipStreamSynchronize") || !hip_ok(hipStreamSynchronize(s1), "hipStreamSynchronize")) break;
+            if (sp && !hip_ok(hipStreamSynchronize(sp), "hipStreamSynchronize")) break;
+            const double t_restart0 = now_s();
             wait_delivered();
             if (r.overflow & 1) cand_cap = (size_t)r.R + (size_t)r.R / 4 + 65536;
             if (r.overflow & 2) {
@@ -858,7 +912,13 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                 size_t new_cap = arena_cap * 2;
                 // (views of THIS call: a ranged chain -- a block of views -- must not size its arena for the whole scene)
                 const int n_pre = pre ? pre->k1 - pre->k0 : 0, done = k - k_begin + n_pre, span = k_end - k_begin + n_pre;
-                if (done >= 4) new_cap = std::max(new_cap, (size_t)((double)r.kept_base / done * span * 1.3) + 1048576);
+                // the first views of a chain have few sources yet and keep less than the later ones (40 x 4000 x 24: the projection at view 8 x 1.3 fell 2 % short,
+                // the arena overflowed again at view 38 and DOUBLED to 9.8 GB -- an allocation that took 3 to 250 ms): 1.5 early on; past the
+                // middle the projection is good and replaces the doubling
+                if (done >= 4) {
+                    const size_t proj = (size_t)((double)r.kept_base / done * span * (2 * done < span ? 1.5 : 1.15)) + 1048576;
+                    new_cap = 2 * done < span ? std::max(new_cap, proj) : std::max(proj, arena_cap + arena_cap / 8);
+                }
                 // (records are indexed with 32 bits: the arena ends at 2^32 records = 137 GB; doubling must not run past it)
                 const size_t kMaxRecords = 0xfffffff0u;
                 if (new_cap > kMaxRecords) {
@@ -886,9 +946,18 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                     (void)hipFree(c->ch_keptcam.p);
                     c->ch_keptcam.p = nc; c->ch_keptcam.cap = new_cap * 4 + 64;
                 }
+                if (early && new_cap < 0x7ffffff0ull) {     // (the earlier views' transposed entries move with their records; beyond 2^31 records the end transposes block by block)
+                    void* ne = nullptr;
+                    if (!hip_ok(hipMalloc(&ne, new_cap * 4 + 64), "hipMalloc (transposed entries of the kept arena)")) break;
+                    if (!hip_ok(hipMemcpy(ne, PE.e_E.p, (size_t)r.kept_base * 4, hipMemcpyDeviceToDevice), "hipMemcpy")) { (void)hipFree(ne); break; }
+                    (void)hipFree(PE.e_E.p);
+                    PE.e_E.p = ne; PE.e_E.cap = new_cap * 4 + 64;
+                }
                 arena_cap = new_cap;
             }
             { int rc = reserve_caps(); if (rc) { rc_final = rc; break; } }
+            if (c->opt.timing) fprintf(stderr, "[l3d match_chain] view %d of %d overflowed (%d): candidates %zu, arena %zu records; regrown in %.2f ms, %.2f ms into the loop\n", k, n_views, r.overflow, cand_cap, arena_cap,
+                                       (now_s() - t_restart0) * 1e3, (now_s() - t_loop0) * 1e3);
             // the row counts of the views enqueued after k were already incremented by their reverse matches: rebuild
             // and the stage-1 candidate buffers of every view in flight live in the (re-sized) ring: refill them
             for (int j = k; j < k_p1; ++j) {
@@ -918,7 +987,17 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         std::vector<ProdChainView> pv((size_t)n_views);
         for (int k = 0; k < n_views; ++k) pv[(size_t)k] = ProdChainView{ vd[(size_t)k].verified ? vd[(size_t)k].best : nullptr, vd[(size_t)k].verified ? vd[(size_t)k].bestpos : nullptr, vd[(size_t)k].verified ? 1 : 0,
                                                                          use_rt && vd[(size_t)k].verified ? vd[(size_t)k].rt : nullptr };
-        rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot, 0, -1, nullptr, use_rt ? c->ch_keptcam.as<unsigned>() : nullptr);
+        ProdEarly pe;
+        const bool early_done = early && arena_cap < 0x7ffffff0ull;
+        if (early_done) {
+            hipEvent_t e = get_local_event(c);
+            (void)hipEventRecord(e, sp);
+            (void)hipStreamWaitEvent(st, e, 0);
+            put_local_event(c, e);
+            pe.pcnt_kq = PE.e_cnt.as<int>(); pe.poff_kq = PE.e_poff.as<unsigned>(); pe.boff = PE.e_boff.as<int>(); pe.E = PE.e_E.as<unsigned>();
+            pe.boff_off_host = PE.e_boff_off.data(); pe.maxN = maxN;
+        }
+        rc_final = build_products(c, views, n_views, pv.data(), hres, map, summary, n_pot, 0, -1, nullptr, use_rt ? c->ch_keptcam.as<unsigned>() : nullptr, early_done ? &pe : nullptr);
     }
     if (c->opt.timing)
         fprintf(stderr, "[l3d match_chain] setup %.2f ms | enqueue + watch loop %.2f ms (waiting: view results %.2f, stage-1 statistics %.2f) | delivery thread: d2h %.2f, callback %.2f\n",
@@ -927,6 +1006,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     const double t_tail0 = now_s();
     if (sm != s1) (void)hipStreamSynchronize(sm);
     (void)hipStreamSynchronize(s1);
+    if (sp) (void)hipStreamSynchronize(sp);
     (void)hipStreamSynchronize(st);
     if (c->opt.timing) fprintf(stderr, "[l3d match_chain] hipSetDevice %.3f ms, final syncs %.3f ms\n", (t_setup0 - t_enter) * 1e3, (now_s() - t_tail0) * 1e3);
     for (hipEvent_t e : ev) { if (cb) put_event(c, e); else put_local_event(c, e); }
@@ -935,7 +1015,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     c->stats[1] = raw_sum;
     c->stats[3] = kept_total;
     if (rc_final == L3D_OK && !c->test_cand_cap && !c->test_arena_cap) {
-        c->chain_seen_views = n_views; c->chain_seen_pairs = pairs; c->chain_seen_cand_cap = cand_cap; c->chain_seen_arena_cap = arena_cap;
+        c->chain_seen_views = n_views; c->chain_seen_pairs = pairs; c->chain_seen_cand_cap = cand_cap; c->chain_seen_arena_cap = arena_cap; c->chain_seen_kept = kept_seen;
     }
     return rc_final;
 }

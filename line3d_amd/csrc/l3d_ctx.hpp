@@ -106,6 +106,8 @@ struct Products {
     int n_dense = 0, n_views_all = 0, n_chain = 0, n_hyp = 0;
     long long n_pot = 0, total_kept = 0;
     DevBuf keys, keys2, flag, pos, tmp, pot_start, pot_tgt, best_ref, median, tables, ttab, rowstage, tstage;
+    DevBuf e_cnt, e_poff, e_boff, e_E, e_T, e_tab;     // the chain's early pair transposes (l3d_chain.hip: per (view, camera) counts / entry offsets, column starts, entries, staging, per-view tables)
+    std::vector<int> e_boff_off;                        // host copy: where a (chain view, camera)'s column starts lie in e_boff
     DevBuf geo, hyp_of, score, hyp_dense, best_hyp, coll, aux;       // greedy selection / affinity fill on the resident tables
     long long coll_n = 0;           // entries of the collinearity CSR resident in `coll` (with n_dense + 1 starts in front)
     unsigned long long coll_sig = 0; // checksum of what that copy was uploaded from (sizes, row starts, dense map)
@@ -119,7 +121,7 @@ struct Products {
     std::vector<unsigned> chain_view_id;
     void release()
     {
-        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &ttab, &rowstage, &tstage, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
+        DevBuf* b[] = { &keys, &keys2, &flag, &pos, &tmp, &pot_start, &pot_tgt, &best_ref, &median, &tables, &ttab, &rowstage, &tstage, &e_cnt, &e_poff, &e_boff, &e_E, &e_T, &e_tab, &geo, &hyp_of, &score, &hyp_dense, &best_hyp, &coll, &aux };
         for (DevBuf* x : b) x->release();
         valid = hyp_valid = false; coll_n = 0; coll_sig = 0;
     }
@@ -150,6 +152,7 @@ struct l3d_ctx {
     l3d::Options opt;                        // every L3D_* switch: the environment read once by l3d_ctx_create, then l3d_set_option
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // bulk D2H of the resident chain, concurrent with kernels
+    hipStream_t prod_stream = nullptr;       // option prod_early: a view's pair transposes, behind its kept writer (created on first use)
     hipStream_t mask_stream = nullptr;       // option mask_stream: k_pair_mask alone, ahead of the rest of stage 1 (created on first use)
     hipStream_t stage1_stream = nullptr;     // stage 1 of the resident chain (independent of the chain state) runs ahead here
     std::string err;                         // written under err_mu: the chains report from several host threads
@@ -174,7 +177,7 @@ struct l3d_ctx {
     l3d::DevBuf vw_bstart, vw_segstate;             // split verification (k_vw_walk): bucket starts of the built images | per-segment state + unit table
     size_t part_arena_seen = 0;                     // records a partitioned segment-sharded run kept on this rank (sizes the next pass's arena)
     size_t test_cand_cap = 0, test_arena_cap = 0;   // tests: initial capacities of the resident chain (0 = estimate)
-    int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0;   // what the last chain over this scene needed
+    int chain_seen_views = 0; double chain_seen_pairs = 0; size_t chain_seen_cand_cap = 0, chain_seen_arena_cap = 0; double chain_seen_kept = 0;   // what the last chain over this scene needed (and kept)
     unsigned long long* pair_dbg = nullptr;   // L3D_PAIR_STATS=1: device counters of k_pair_mask's levels (printed at destroy)
     int wedge_pretest = 3;          // stage-1 filters: bit 0 wedge test, bit 1 overlap-bound test (cleared only for A/B testing), bit 2 SET: level 2 does not accept
     int verify_mode = 0;            // 0: depth-window search (all-pairs kernel only beyond ~50 neighbours), 1: all-pairs
@@ -290,6 +293,7 @@ inline void prof_resolve(l3d_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->stage1_stream) (void)hipStreamSynchronize(c->stage1_stream);
     if (c->mask_stream) (void)hipStreamSynchronize(c->mask_stream);
+    if (c->prod_stream) (void)hipStreamSynchronize(c->prod_stream);
     std::lock_guard<std::mutex> lk(c->event_mu);         // (the pools and the pending lists: ProfScope of another enqueue thread takes it too)
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {

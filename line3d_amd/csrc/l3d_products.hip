@@ -284,20 +284,13 @@ template <class F> __device__ __forceinline__ void for_run_words(const unsigned*
 // region of the pair's size (NB sequential write streams per workgroup: their open lines fit the L2 and leave it full), then bucket by bucket into an LDS image of
 // the bucket's piece of E at their exact places (LDS cursors), and the image goes out in whole lines.  NB = the smallest power of two for which the largest bucket
 // fits `cap` entries of LDS (a pair whose single busiest u does not fit -- more than `cap` sources for one target segment -- scatters directly).
-__global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const ProdPair* __restrict__ pairs, const ProdViewQ* __restrict__ vq, const ProdView* __restrict__ pv,
-                                                                       const ProdNbQ* __restrict__ nbq, const int* __restrict__ poff, int g, int* __restrict__ boff, unsigned* __restrict__ E,
-                                                                       unsigned* __restrict__ T, int cap)
+// one pair's transpose by one workgroup of kPairThreads: the runs r0[s] .. r1[s] (s < S) of the side array qt, targets below St; column starts to bo[0 .. St], the
+// source segments grouped by target to e[0 ..); t: the staging region of the two-level scatter (null: direct).  s_h: St + 2 + 2 * cap ints of LDS.
+__device__ __forceinline__ void pair_transpose_wg(const unsigned* __restrict__ qt, const int* __restrict__ r0, const int* __restrict__ r1, int S, int St, int g,
+                                                  int* __restrict__ bo, unsigned* __restrict__ e, unsigned* __restrict__ t, int cap, int* s_h, int* s_w, int* s_kbp)
 {
-    extern __shared__ int s_h[];
-    __shared__ int s_w[kPairThreads / 64];
-    __shared__ int s_kb;
-    const ProdPair pr = pairs[blockIdx.x];
-    const ProdViewQ v = vq[pr.k];
-    const int S = pv[pr.k].S, St = nbq[v.nb_off + pr.q].t_S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned* qt = v.qt;
-    const int* r0 = v.rt + (size_t)pr.q * S;
-    const int* r1 = v.rt + (size_t)(pr.q + 1) * S;
+    int& s_kb = *s_kbp;
     for (int u = tid; u <= St; u += kPairThreads) s_h[u] = 0;
     __syncthreads();
     const int grp = g ? tid / g : 0, gl = g ? tid - grp * g : 0, ngrp = g ? kPairThreads / g : 1;
@@ -321,12 +314,10 @@ __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const Pro
     __syncthreads();
     int run = incl - sum, all = 0;
     for (int w = 0; w < kPairThreads / 64; ++w) { if (w < wave) run += s_w[w]; all += s_w[w]; }
-    int* bo = boff + pr.off_off;
     for (int u = u0; u < u1; ++u) { const int c = s_h[u]; s_h[u] = run; bo[u] = run; run += c; }
     if (tid == 0) { bo[St] = all; s_h[St] = all; }
     __syncthreads();
-    unsigned* e = E + poff[blockIdx.x];
-    if (T && cap > 0 && all > 32768) {                          // (a small region -- config 2: 3 k entries per pair -- is written in place: it stays in L2)
+    if (t && cap > 0 && all > 32768) {                          // (a small region -- config 2: 3 k entries per pair -- is written in place: it stays in L2)
         // bucket width: the smallest shift kb (from "32 buckets" down to one u per bucket) for which every bucket's piece of E fits the LDS image
         if (tid == 0) s_kb = -1;
         __syncthreads();
@@ -341,7 +332,6 @@ __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const Pro
         __syncthreads();
         const int kb = s_kb;
         if (kb >= 0) {
-            unsigned* t = T + poff[blockIdx.x];
             int* img = s_h + St + 2;                                   // the bucket's piece of E (cap ints); in front of it, level 1's write cursors of the buckets (reused)
             const int nbk = (St + (1 << kb) - 1) >> kb;
             int* bcur = img;                                          // (nbk <= cap: asserted by the host's choice of cap >= 512)
@@ -377,6 +367,52 @@ __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const Pro
             for (int i = a + gl; i < b; i += g) { const int u = (int)(qt[i] & 0xffffu); if (u < St) e[atomicAdd(&s_h[u], 1)] = (unsigned)s; }
         }
     }
+}
+
+__global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const ProdPair* __restrict__ pairs, const ProdViewQ* __restrict__ vq, const ProdView* __restrict__ pv,
+                                                                       const ProdNbQ* __restrict__ nbq, const int* __restrict__ poff, int g, int* __restrict__ boff, unsigned* __restrict__ E,
+                                                                       unsigned* __restrict__ T, int cap)
+{
+    extern __shared__ int s_h[];
+    __shared__ int s_w[kPairThreads / 64];
+    __shared__ int s_kb;
+    const ProdPair pr = pairs[blockIdx.x];
+    const ProdViewQ v = vq[pr.k];
+    const int S = pv[pr.k].S, St = nbq[v.nb_off + pr.q].t_S;
+    pair_transpose_wg(v.qt, v.rt + (size_t)pr.q * S, v.rt + (size_t)(pr.q + 1) * S, S, St, g, boff + pr.off_off, E + poff[blockIdx.x], T ? T + poff[blockIdx.x] : nullptr, cap, s_h, s_w, &s_kb);
+}
+
+// ---- the transposes of ONE view's pairs, launched by the chain on a side stream right behind the view's kept writer (round 6, late): a pair depends on its view's
+// list alone, so only the rows are left for the end of matchViews.  Canonical places, independent of the tables the end builds: counts and E offsets per (chain view,
+// camera) at [k * maxN + q]; the pair's entries inside its view's piece of an arena-aligned E (the pairs of a view hold exactly its records), camera by camera.
+struct EarlyView { const int* rt; const int* St; const int* boff_off; int k, S, N, maxN; };      // St, boff_off: per local camera, the target view's segments (0: none) / its column starts' place
+__global__ __launch_bounds__(256) void k_prode_counts(EarlyView v, const ChainResult* __restrict__ res, int* __restrict__ pcnt_kq)
+{
+    __shared__ int s_w[4];
+    const int q = blockIdx.x;
+    const ChainResult r = res[v.k];
+    int t = 0;
+    if (!r.overflow && r.n_kept > 0 && v.St[q] > 0)
+        for (int s = threadIdx.x; s < v.S; s += 256) t += v.rt[(size_t)(q + 1) * v.S + s] - v.rt[(size_t)q * v.S + s];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) pcnt_kq[(size_t)v.k * v.maxN + q] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(kPairThreads) void k_prode_transpose(EarlyView v, const ChainResult* __restrict__ res, const unsigned* __restrict__ qt_arena, const int* __restrict__ pcnt_kq,
+                                                                  unsigned* __restrict__ poff_kq, int g, int* __restrict__ boff, unsigned* __restrict__ E, unsigned* __restrict__ T, int cap)
+{
+    extern __shared__ int s_h[];
+    __shared__ int s_w[kPairThreads / 64];
+    __shared__ int s_kb;
+    const int q = blockIdx.x;
+    const ChainResult r = res[v.k];
+    const int St = v.St[q];
+    unsigned off = r.kept_base;
+    for (int j = 0; j < q; ++j) off += (unsigned)pcnt_kq[(size_t)v.k * v.maxN + j];
+    if (threadIdx.x == 0) poff_kq[(size_t)v.k * v.maxN + q] = off;
+    if (r.overflow || r.n_kept == 0 || St <= 0) return;                 // (an overflowed view is run again, and transposed again behind that run)
+    pair_transpose_wg(qt_arena + r.kept_base, v.rt + (size_t)q * v.S, v.rt + (size_t)(q + 1) * v.S, v.S, St, g, boff + v.boff_off[q], E + off, T ? T + off : nullptr, cap, s_h, s_w, &s_kb);
 }
 
 // The early-return quirk through run tables (the chain's side arrays; with rebuilt ones the scans of k_prod_keys_early / k_prodt_early below stay):
@@ -463,7 +499,8 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void k_prodv_rows(const ProdRowView* __restrict__ rv, int x0, int d0, const ProdViewQ* __restrict__ vq, const ProdTouch* __restrict__ tl,
                                                     const ProdPair* __restrict__ pairs, const int* __restrict__ poff, const int* __restrict__ boff, const unsigned* __restrict__ E,
                                                     const int* __restrict__ bstart, const unsigned* __restrict__ ent, int* __restrict__ ucnt, const int* __restrict__ ustart,
-                                                    long long base, int* __restrict__ pot_tgt, int group_words, int* __restrict__ stage)
+                                                    long long base, int* __restrict__ pot_tgt, int group_words, int* __restrict__ stage,
+                                                    const unsigned* __restrict__ poff_kq, int maxN)
 {
     constexpr int kWords = 512;
     __shared__ unsigned s_bm[4][kWords];
@@ -494,7 +531,13 @@ __global__ __launch_bounds__(256) void k_prodv_rows(const ProdRowView* __restric
         if (j < v.t1) {
             e = tl[j];
             if (e.fq >= 0 && frt) { f_a = frt[(size_t)e.fq * v.S + u]; f_n = frt[(size_t)(e.fq + 1) * v.S + u] - f_a; }
-            if (e.pair >= 0) { const int* bo = boff + pairs[e.pair].off_off; const int a = bo[u]; b_n = bo[u + 1] - a; b_a = poff[e.pair] + a; }
+            if (e.pair >= 0) {
+                const ProdPair pr = pairs[e.pair];
+                const int* bo = boff + pr.off_off;
+                const int a = bo[u];
+                b_n = bo[u + 1] - a;
+                b_a = (poff_kq ? (int)poff_kq[(size_t)pr.k * maxN + pr.q] : poff[e.pair]) + a;         // (the chain's transposes: E is aligned with the arena; < 2^31 records asserted by the host)
+            }
         }
         const int cnt = min(64, v.t1 - t0);
         const int words = j < v.t1 ? (e.y_S + 31) >> 5 : 0;
@@ -601,8 +644,29 @@ void l3d::launch_prod_shift_rows(const long long* piece, long long n_rows, long 
     if (n_rows > 0) hipLaunchKernelGGL(k_prod_shift_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, piece, n_rows, base, pot_start_at);
 }
 
+void l3d::launch_early_transposes(l3d_ctx* c, int k, const int* rt, const int* St_dev, const int* boff_off_dev, int S, int N, int maxN, int maxSt, const ChainResult* res,
+                                  const unsigned* qt_arena, int* pcnt_kq, unsigned* poff_kq, int* boff, unsigned* E, unsigned* T, double avg_run, hipStream_t st)
+{
+    if (N <= 0 || S <= 0) return;
+    EarlyView v;
+    v.rt = rt; v.St = St_dev; v.boff_off = boff_off_dev; v.k = k; v.S = S; v.N = N; v.maxN = maxN;
+    int g = 1;
+    while (g < 64 && g < avg_run / 4.0) g <<= 1;
+    if (c->opt.prod_pair_g >= 0) g = c->opt.prod_pair_g;
+    int cap = 0;
+    if (c->opt.prod_pair_stage != 0 && T) {
+        cap = 12288;
+        while (cap > 1024 && ((size_t)maxSt + 2 + 2 * (size_t)cap) * 4 > 64 * 1024) cap -= 1024;
+        if (((size_t)maxSt + 2 + 2 * (size_t)cap) * 4 > 64 * 1024) cap = 0;
+    }
+    ProfScope p(c, "prod_keys", st);
+    hipLaunchKernelGGL(k_prode_counts, dim3((unsigned)N), dim3(256), 0, st, v, res, pcnt_kq);
+    hipLaunchKernelGGL(k_prode_transpose, dim3((unsigned)N), dim3(kPairThreads), ((size_t)maxSt + 2 + 2 * (size_t)cap) * 4, st, v, res, qt_arena, (const int*)pcnt_kq, poff_kq, g, boff, E,
+                       cap ? T : (unsigned*)nullptr, cap);
+}
+
 int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pvh, const ChainResult* hres,
-                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1, const char* held, const unsigned* qt_arena)
+                        const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot_out, int dv0, int dv1, const char* held, const unsigned* qt_arena, const ProdEarly* early)
 {
     Products& P = c->products;
     P.valid = false; P.hyp_valid = false;
@@ -792,6 +856,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         auto seg_count = [&](int x) { return P.seg_base[(size_t)x + 1] - P.seg_base[(size_t)x]; };
         for (int x = dv0; x < dv1; ++x) if (seg_count(x) > 16000) return kSortInstead;                                  // (the pair transposes keep a view's segments in 64 KB of LDS)
         const bool rebuild = !native_rt;                        // (a list without a run table: all are rebuilt, block by block)
+        const bool use_early = early && !rebuild && early->E && early->boff && early->poff_kq;      // the chain transposed every pair behind its view's kept writer
         // T(x): the dense views a row of view x can name -- its chain view's neighbours, the views it is a neighbour of, the early-return aliases
         // (the dense view of every (chain view, local camera), looked up ONCE: the table loops below asked three times per pair and 144 times per touched view --
         // 0.12 ms of host time per config-2 pass with the GPU idle behind it)
@@ -893,7 +958,10 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                     }
                     for (int q : touch_src[(size_t)x1]) if (mark_s[(size_t)q] != bi) { mark_s[(size_t)q] = bi; srcs.push_back(q); B.early_n += 2 * (long long)hres[ps[(size_t)q].src].n_kept; }
                     B.maxS = std::max(B.maxS, seg_count(x1));
-                    for (int p = pair_begin[(size_t)x1]; p < pair_begin[(size_t)x1 + 1]; ++p) { pairs[(size_t)p].off_off = (int)B.boff_n; B.boff_n += seg_count(x1) + 1; }
+                    for (int p = pair_begin[(size_t)x1]; p < pair_begin[(size_t)x1 + 1]; ++p) {
+                        if (use_early) { pairs[(size_t)p].off_off = early->boff_off_host[(size_t)pairs[(size_t)p].k * early->maxN + pairs[(size_t)p].q]; continue; }   // (the chain's transposes: canonical places)
+                        pairs[(size_t)p].off_off = (int)B.boff_n; B.boff_n += seg_count(x1) + 1;
+                    }
                 }
                 B.x1 = x1; B.n_items = items.size() - B.item0; B.n_srcs = srcs.size() - B.src0; B.pair1 = pair_begin[(size_t)x1];
                 if (B.rec_n > 0x7ffffff0ll || B.early_n > 0x7ffffff0ll || B.boff_n > 0x7ffffff0ll || B.rt_n > 0x7ffffff0ll)
@@ -941,7 +1009,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         const size_t ra = ((size_t)max_rows + 18 + 63) & ~(size_t)63;         // ints per row array (rows + 1 entries, the error counter in the last eight of the last one)
         const size_t pa = ((size_t)max_pairs + 2 + 63) & ~(size_t)63;
         const double t_res1 = now_s();
-        HIPCHK(c, P.keys2.reserve(((size_t)max_rec + (size_t)max_early) * 4 + 256));
+        HIPCHK(c, P.keys2.reserve(((use_early ? 0 : (size_t)max_rec) + (size_t)max_early) * 4 + 256));
         HIPCHK(c, P.flag.reserve((5 * ra + 2 * pa + (size_t)max_boff) * 4 + 256));
         if (rebuild) { HIPCHK(c, P.keys.reserve((size_t)max_rec * 4 + 256)); HIPCHK(c, P.pos.reserve((size_t)max_rt * 4 + 256)); HIPCHK(c, P.tstage.reserve((size_t)max_rec * 4 + 256)); }
         size_t tbs = 0;
@@ -950,9 +1018,11 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
         if (tblocks.size() > 1) HIPCHK(c, P.pot_tgt.reserve(((size_t)slots_all + 2) * 4));        // (several blocks: the bound; one block: its count, below)
         if (c->opt.timing) fprintf(stderr, "[l3d products] transposed (%s side arrays): %zu block(s), <= %lld records, %d pairs, %d rows, a row touches <= %d views: tables in %.2f ms, buffers in %.2f ms\n",
                                    rebuild ? "rebuilt" : "the chain's", tblocks.size(), max_rec, max_pairs, max_rows, max_touch, (t_res1 - t_t0) * 1e3, (now_s() - t_res1) * 1e3);
-        unsigned* E = P.keys2.as<unsigned>();
+        unsigned* E = use_early ? const_cast<unsigned*>(early->E) : P.keys2.as<unsigned>();
         int* cnt = P.flag.as<int>();
-        int *bstart = cnt + ra, *ucnt = cnt + 2 * ra, *ustart = cnt + 3 * ra, *spare = cnt + 4 * ra, *pcnt = cnt + 5 * ra, *poff = pcnt + pa, *boff = poff + pa;
+        int *bstart = cnt + ra, *ucnt = cnt + 2 * ra, *ustart = cnt + 3 * ra, *spare = cnt + 4 * ra, *pcnt = cnt + 5 * ra, *poff = pcnt + pa, *boff = use_early ? const_cast<int*>(early->boff) : poff + pa;
+        const unsigned* poff_kq = use_early ? early->poff_kq : nullptr;
+        const int e_maxN = use_early ? early->maxN : 0;
         int* err = spare + ra - 8;
         HIPCHK(c, hipMemsetAsync(err, 0, 4, st));
         long long base = 0;
@@ -961,7 +1031,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
             const int d0 = P.seg_base[(size_t)B.x0], d1 = P.seg_base[(size_t)B.x1], rows = d1 - d0, n_pairs = B.pair1 - B.pair0;
             int scal[2] = { 0, 0 };                                            // {entries of the block, error count}
             if (rows > 0) {
-                unsigned* ent = E + B.rec_n;                                   // (early entries behind the transposed ones)
+                unsigned* ent = use_early ? P.keys2.as<unsigned>() : E + B.rec_n;      // (early-return entries behind the transposed ones; the chain's transposes: a buffer of their own)
                 {
                     ProfScope p(c, "prod_keys", st);
                     if (rebuild) {
@@ -986,7 +1056,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                         launch_rt_from_qt(djob, (int)jobs.size(), max_cells, st);
                         HIPCHK(c, hipStreamSynchronize(st));                   // (the host vectors above are re-used by the next block)
                     }
-                    if (n_pairs > 0) {
+                    if (n_pairs > 0 && !use_early) {
                         hipLaunchKernelGGL(k_prodv_pair_counts, dim3((unsigned)n_pairs), dim3(256), 0, st, dpr + B.pair0, dvq, dpv, pcnt);
                         HIPCHK(c, hipMemsetAsync(pcnt + n_pairs, 0, 4, st));
                         size_t t1 = tbs;
@@ -1030,7 +1100,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                     ProfScope p(c, "prod_rows", st);
                     HIPCHK(c, hipMemsetAsync(ucnt + rows, 0, 4, st));
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodv_rows<false>), rg, dim3(256), 0, st, drv, B.x0, d0, dvq, dtl, dpr, (const int*)poff - B.pair0, (const int*)boff,
-                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, (int*)nullptr, c->opt.prod_row_group, stage);
+                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, (int*)nullptr, c->opt.prod_row_group, stage, poff_kq, e_maxN);
                     size_t t1 = tbs;
                     HIPCHK(c, exclusive_sum_int(P.tmp.p, t1, ucnt, ustart, rows + 1, st));
                 }
@@ -1042,7 +1112,7 @@ int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, co
                 {
                     ProfScope p(c, "prod_rows", st);
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prodv_rows<true>), rg, dim3(256), 0, st, drv, B.x0, d0, dvq, dtl, dpr, (const int*)poff - B.pair0, (const int*)boff,
-                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, P.pot_tgt.as<int>(), c->opt.prod_row_group, stage);
+                                       (const unsigned*)E, bs, (const unsigned*)ent, ucnt, (const int*)ustart, base, P.pot_tgt.as<int>(), c->opt.prod_row_group, stage, poff_kq, e_maxN);
                     hipLaunchKernelGGL(k_prodt_row_starts, dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, st, (const int*)ustart, rows, base, P.pot_start.as<long long>() + d0);
                 }
             } else {

@@ -14,6 +14,17 @@ struct ProdChainView {
     const int* rt;          // the view's run table (l3d_runtable.hpp) when the chain's kept writer filled one, else null (rebuilt by the products)
 };
 
+// The transposes of the (view, camera) pairs done by the chain itself, view by view on a side stream (l3d_chain.hip; round 6): what the end of matchViews finds ready.
+// Canonical places: pcnt / poff at [chain view * maxN + camera] (poff: the pair's first entry in E, which is aligned with the kept arena); boff_off[chain view][camera]:
+// where the pair's column starts lie in boff (host copy: the builder files it in its pairs).
+struct ProdEarly {
+    const int* pcnt_kq = nullptr;
+    const unsigned* poff_kq = nullptr;
+    const int* boff = nullptr;
+    const unsigned* E = nullptr;
+    const int* boff_off_host = nullptr;     // n_views x maxN
+    int maxN = 0;
+};
 // Enqueued on the context's stream behind the last view of the chain; returns after the few scalars the host needs (entries of the
 // CSR, medians) have arrived.  hres: the chain's per-view result records (host copies).
 // dv0, dv1 (dv1 >= 0): only the rows of the dense views [dv0, dv1), numbered from 0 -- pot_start[seg_base[dv0] .. seg_base[dv1]] and that many
@@ -22,9 +33,14 @@ struct ProdChainView {
 // then left EMPTY but well-formed (the whole pot_start array is valid)
 int build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pv, const ChainResult* hres,
                    const l3d_dense_map* map, l3d_chain_summary* summary, int64_t* n_pot, int dv0 = 0, int dv1 = -1, const char* held = nullptr,
-                   const unsigned* qt_arena = nullptr);
+                   const unsigned* qt_arena = nullptr, const ProdEarly* early = nullptr);
 // qt_arena: the side array of the kept arena, (local camera << 16 | target) per record, when the chain's kept writer filled it together with the
 // views' run tables (ProdChainView::rt); null: the products rebuild both from the records, block by block
+
+// one view's pairs: counts, then transposes, on `st` (behind the view's kept writer).  rt, St_dev, boff_off_dev: device arrays of the view (run table; per local camera
+// the target view's segment count or 0, the place of its column starts in boff)
+void launch_early_transposes(l3d_ctx* c, int k, const int* rt, const int* St_dev, const int* boff_off_dev, int S, int N, int maxN, int maxSt, const ChainResult* res,
+                             const unsigned* qt_arena, int* pcnt_kq, unsigned* poff_kq, int* boff, unsigned* E, unsigned* T, double avg_run, hipStream_t st);
 
 // pot_start[first_row + i] = piece[i] + base for n_rows rows (a rank's rows of the table put in place)
 void launch_prod_shift_rows(const long long* piece, long long n_rows, long long base, long long* pot_start_at, hipStream_t st);

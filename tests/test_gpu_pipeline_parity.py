@@ -570,6 +570,32 @@ def test_chain_overflow_restart_with_more_views_than_ring_slots():
     assert len(set(digests)) == 1, digests
 
 
+def test_early_pair_transposes_survive_arena_growth_and_restarts():
+    """The chain transposes a view's (view, camera) pairs behind its kept writer into an array aligned with the kept arena (L3D_PROD_EARLY; forced here, the default
+    takes it for long lists only).  When the arena overflows, the chain grows it, MOVES the earlier views' entries with their records and runs the overflowed view
+    and the ones behind it again -- their transposes too.  Products (CSR, best matches, hypotheses) equal the undisturbed run's with the transposes at the end."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    sc = make_scene(30, 400, 10, seed=4242)
+    digests = []
+    for early, caps in ((0, None), (2, None), (2, (6000, 1 << 22)), (2, (1 << 22, 900)), (2, (5000, 700))):
+        l = Line3D("", matchingNeighbors=10)
+        l.keep_view_matches(False)
+        load_scene(l, sc)
+        l.prepare()
+        l.context().set_option("L3D_PROD_EARLY", early)
+        l.context().set_option("L3D_CHECK_POT", 1)
+        if caps:
+            l.context().set_chain_capacities(*caps)
+        l.match_views()
+        l.finish(False)
+        digests.append(_products_digest(l))
+        assert len(digests[-1]["pot_tgt"]) > 5000
+        l.close()
+    for i, d in enumerate(digests[1:], 1):
+        assert d == digests[0], i
+
+
 @pytest.mark.parametrize("seed", [101, 202, 303, 404])
 def test_random_small_scenes_full_parity(seed):
     """Randomised end-to-end parity: number of views, segments per view (ragged), neighbours, noise, first image id,
@@ -742,7 +768,9 @@ def test_products_variants_agree(small_scene, small_oracle):
     for scene, N in ((small_scene, 6), (make_scene(10, 700, 8, seed=5, noise_px=0.05, step=0.05), 8)):
         digests = []
         for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1),
-                     dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=0, L3D_PROD_ROW_GROUP=512), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=64, L3D_PROD_BLOCK_KEYS=5000)):
+                     dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=0, L3D_PROD_ROW_GROUP=512), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=64, L3D_PROD_BLOCK_KEYS=5000),
+                     # the pairs transposed by the chain itself, behind each view's kept writer (default for long lists only: forced here), and all at the end
+                     dict(L3D_PROD_EARLY=2), dict(L3D_PROD_EARLY=2, L3D_PROD_PAIR_G=16, L3D_PROD_PAIR_STAGE=0), dict(L3D_PROD_EARLY=0)):
             l = Line3D("", matchingNeighbors=N)
             l.keep_view_matches(False)
             load_scene(l, scene)
@@ -776,7 +804,7 @@ def test_products_of_a_hub_view_touched_by_more_than_64_views():
         o1, o2 = ((i + d) % V if (i + d) % V != HUB else (i + d + 1) % V for d in (6, 12))      # (three neighbours: a kept match needs two witnesses' cameras)
         v["sims"] = {HUB + 6: 1.0, HUB - 6: 0.9, HUB + 12: 0.8} if i == HUB else {HUB: 1.0, o1: 0.5, o2: 0.4}
     digests, paths = [], []
-    for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1)):
+    for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1), dict(L3D_PROD_EARLY=2)):
         l = Line3D("", matchingNeighbors=3)
         for v in sc.views:
             l.addImage_fixed_sim(v["id"], v["width"], v["height"], v["segments"], v["K"], v["R"], v["t"], v["sims"])
@@ -794,10 +822,10 @@ def test_products_of_a_hub_view_touched_by_more_than_64_views():
             d["lines"] = repr([(list(s2), np.asarray(s3).tobytes()) for s2, s3 in l.getResult()])
             digests.append((d, rows0))
         l.close()
-    assert paths == [paths[0]] * 3
+    assert paths == [paths[0]] * 4
     assert paths[0] == 0                                       # the resident chain took the scene: the device products exist
-    assert len(digests) == 3 and digests[0][1] > 64            # (the hub's rows hold entries of many views)
-    assert digests[1][0] == digests[0][0] and digests[2][0] == digests[0][0]
+    assert len(digests) == 4 and digests[0][1] > 64            # (the hub's rows hold entries of many views)
+    assert all(d[0] == digests[0][0] for d in digests[1:])
 
 
 def test_native_sharded_run_commits_on_the_device(small_scene, small_oracle, monkeypatch):
