@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void k_shard_pack_all(const unsigned char* __r
 // verdict reads them) and nothing in this rank's arena.
 __global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __restrict__ G, SlotGeom g, const unsigned char* __restrict__ verified, const unsigned char* __restrict__ keep, int k0, int n_batch,
                                                       long long* __restrict__ base_dev, long long arena_cap, const long long* __restrict__ best_off, Match* __restrict__ arena,
-                                                      float2* __restrict__ best_all, int* __restrict__ bestpos_all, SlotHeader* __restrict__ hdr_all, int* __restrict__ overflow)
+                                                      float2* __restrict__ best_all, int* __restrict__ bestpos_all, SlotHeader* __restrict__ hdr_all, int* __restrict__ overflow,
+                                                      unsigned* __restrict__ qt_arena, int* __restrict__ rt_all, const long long* __restrict__ rt_off, const int2* __restrict__ view_sn)
 {
     const int k = k0 + blockIdx.z, r = blockIdx.y;
     long long base = base_dev[k0];
@@ -340,6 +341,20 @@ __global__ __launch_bounds__(256) void k_shard_retire(const unsigned char* __res
         best_all[o] = sb[i];
         const int p = sp[i];
         bestpos_all[o] = p < 0 || n == 0 ? -1 : in_front + p;
+    }
+    // (round 6) the slot's side words and run table travel with its records: the view's (local camera << 16 | target) array and its run table, (N + 1) x S with
+    // positions counted from the view's first record -- what the single-GPU chain's kept writer leaves, so the products transpose without rebuilding either
+    if (qt_arena) {
+        const unsigned* sq = reinterpret_cast<const unsigned*>(slot + g.cam_off);
+        unsigned* dq = qt_arena + base + in_front;
+        for (int i = tid; i < n; i += nt) dq[i] = sq[i];
+        const int S = view_sn[k].x, N = view_sn[k].y, ns = hd->s1 - hd->s0;
+        int* rt = rt_all + rt_off[k];
+        const int* srt = reinterpret_cast<const int*>(slot + g.rt_off);
+        for (int i = tid; i < (N + 1) * ns; i += nt) {
+            const int q = i / ns, j = i - q * ns;
+            rt[(size_t)q * S + hd->s0 + j] = in_front + (n > 0 ? srt[(size_t)q * g.seg_cap + j] : 0);
+        }
     }
 }
 
@@ -415,6 +430,8 @@ struct l3d_shard_chain {
     SlotHeader* hdr_all = nullptr;           // the headers of all slots of all views (32 B each)
     const long long* best_off_dev = nullptr;
     const unsigned char* ver_dev = nullptr;
+    bool retire_tables = false;              // the retire kernel also files the slots' side words and run tables (ch_keptcam, ch_rt): the products need not rebuild them
+    std::vector<long long> rt_off;           // where view k's run table starts in ch_rt (ints)
     // partitioned retirement (l3d_shard_chain_partition): only the views flagged in `keep` go to this rank's compact arena
     bool partition = false;
     int part_own0 = 0, part_own1 = 0, part_reach = 0;
@@ -803,6 +820,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
     std::vector<long long> best_off_h((size_t)h->n_views, 0);
     int* ring_overflow = nullptr;
     unsigned char* part_status = nullptr;      // partitioned: [own word | the ranks' words], 256 B each
+    size_t o_rto_ = 0, o_sn_ = 0;              // (ring mode: the run tables' offsets / the views' (S, N) in the header block)
+    h->retire_tables = false;
     if (h->ring_mode) {
         // compact arena (first guess like the single-GPU chain's, or what an earlier pass / a capacity verdict taught), the per-view offsets,
         // the header table, the flags the retire kernel reads
@@ -810,7 +829,8 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         if (!h->partition) HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t nvs = (size_t)h->n_views;
-        const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), o_keep = o_ovf + 256, o_stat = o_keep + al(nvs), tot = o_stat + 256 * ((size_t)h->world + 1);
+        const size_t o_base = 0, o_hdr = al((nvs + 2) * 8), o_bo = o_hdr + al(nvs * h->world * sizeof(SlotHeader)), o_ver = o_bo + al(nvs * 8), o_ovf = o_ver + al(nvs), o_keep = o_ovf + 256, o_stat = o_keep + al(nvs),
+                     o_rto = o_stat + 256 * ((size_t)h->world + 1), o_sn = o_rto + al(nvs * 8), tot = o_sn + al(nvs * 8);
         HIPCHK(c, c->ch_hdr.reserve(tot));
         unsigned char* hb = c->ch_hdr.as<unsigned char>();
         h->base_dev = reinterpret_cast<long long*>(hb + o_base);
@@ -833,6 +853,24 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             if (!c->test_arena_cap) { long long kv = 0; for (unsigned char x : h->keep) kv += x; h->arena_cap = std::max<long long>((long long)c->part_arena_seen, h->arena_cap * kv / std::max(1, h->n_views) + 1048576); }
             HIPCHK(c, c->ch_kept.reserve_exact(((size_t)h->arena_cap + 64) * sizeof(Match)));
         }
+        // the retired views' side words and run tables (slots that carry both: L3D_RUN_TABLES, the default)
+        h->retire_tables = h->geom.rt_off != 0 && h->geom.cam_off != 0 && c->opt.prod_transpose != 0 && c->opt.retire_tables != 0;
+        if (h->retire_tables) {
+            h->rt_off.assign(nvs, 0);
+            std::vector<int2> sn(nvs);
+            long long rt_ints = 0;
+            for (int k = 0; k < h->n_views; ++k) {
+                sn[(size_t)k] = make_int2(h->views[k].S_src, h->views[k].N);
+                h->rt_off[(size_t)k] = rt_ints;
+                if (h->vd[(size_t)k].verified && (!h->partition || h->keep[(size_t)k])) rt_ints += ((long long)h->views[k].N + 1) * h->views[k].S_src;
+            }
+            HIPCHK(c, c->ch_rt.reserve((size_t)rt_ints * 4 + 256));
+            HIPCHK(c, c->ch_keptcam.reserve(((size_t)h->arena_cap + 64) * 4));
+            HIPCHK(c, hipMemcpyAsync(hb + o_rto, h->rt_off.data(), nvs * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hb + o_sn, sn.data(), nvs * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));         // (`sn` leaves scope)
+        }
+        o_rto_ = o_rto; o_sn_ = o_sn;
         ring_overflow = reinterpret_cast<int*>(hb + o_ovf);
         part_status = hb + o_stat;
         h->part_status = part_status; h->part_exchange = exchange; h->part_user = exchange_user;
@@ -843,7 +881,9 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
             const int nb = std::min(kRetireBatch, upto - retired);
             ProfScope p(c, "retire");
             hipLaunchKernelGGL(k_shard_retire, dim3(8, h->world, nb), dim3(256), 0, c->stream, gathered, h->geom, h->ver_dev, h->keep_dev, retired, nb, h->base_dev, h->arena_cap,
-                               h->best_off_dev, c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>(), h->hdr_all, ring_overflow);
+                               h->best_off_dev, c->ch_kept.as<Match>(), c->ch_best.as<float2>(), c->ch_bestpos.as<int>(), h->hdr_all, ring_overflow,
+                               h->retire_tables ? c->ch_keptcam.as<unsigned>() : nullptr, h->retire_tables ? c->ch_rt.as<int>() : nullptr,
+                               reinterpret_cast<const long long*>(c->ch_hdr.as<unsigned char>() + o_rto_), reinterpret_cast<const int2*>(c->ch_hdr.as<unsigned char>() + o_sn_));
             retired += nb;
         }
     };
@@ -1150,7 +1190,9 @@ static int shard_products_local(l3d_shard_chain* h, const l3d_dense_map* map, l3
         pvh[(size_t)k].verified = d.verified ? 1 : 0;
         pvh[(size_t)k].best = d.verified && here ? d.best : nullptr;
         pvh[(size_t)k].bestpos = d.verified && here ? d.bestpos : nullptr;
+        pvh[(size_t)k].rt = h->ring_mode && h->retire_tables && d.verified && here ? c->ch_rt.as<int>() + h->rt_off[(size_t)k] : nullptr;
     }
+    const unsigned* qt_arena = h->ring_mode && h->retire_tables ? c->ch_keptcam.as<unsigned>() : nullptr;
     if (h->ring_mode) {
         // the records are in the arena already (k_shard_retire, view by view in this very order)
         if (total != h->arena_needed) return fail(c, L3D_ERR_INVALID, "l3d_shard_chain_products: the retired records do not add up to the slot headers");
@@ -1172,7 +1214,7 @@ static int shard_products_local(l3d_shard_chain* h, const l3d_dense_map* map, l3
                 for (DevBuf* x : b) x->release();
                 h->gathered = nullptr;
             }
-            const int rc = build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, reinterpret_cast<const char*>(h->keep.data()));
+            const int rc = build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, &n_local, part.row_dv0, part.row_dv1, reinterpret_cast<const char*>(h->keep.data()), qt_arena);
             if (rc) return rc;
             c->part_arena_seen = std::max(c->part_arena_seen, (size_t)total + (size_t)total / 8 + 65536);
             if (n_pot) *n_pot = n_local;
@@ -1181,7 +1223,7 @@ static int shard_products_local(l3d_shard_chain* h, const l3d_dense_map* map, l3
             return L3D_OK;
         }
         c->chain_seen_arena_cap = std::max(c->chain_seen_arena_cap, (size_t)total + (size_t)total / 8 + 65536);
-        return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot);
+        return build_products(c, h->views, nv, pvh.data(), hres.data(), map, summary, n_pot, 0, -1, nullptr, qt_arena);
     }
     HIPCHK(c, c->ch_kept.reserve(((size_t)total + 64) * sizeof(Match)));
     HIPCHK(c, hipMemcpyAsync(sc + o_kb, kept_base.data(), nvs * 4, hipMemcpyHostToDevice, st));

@@ -122,15 +122,19 @@ def test_partitioned_run_and_sharded_fill_equal_the_one_chain(W, diffusion):
             l.close()
 
 
-@pytest.mark.parametrize("W,diffusion", [(3, True), (4, False)])
-def test_segment_sharded_run_partitioned_equals_the_one_chain(W, diffusion):
+@pytest.mark.parametrize("W,diffusion,options", [(3, True, None), (4, False, None), (3, False, dict(L3D_SLOT_CAMS_MIN=0, L3D_CHECK_POT=1)),
+                                                 (4, True, dict(L3D_SLOT_CAMS_MIN=0, L3D_RETIRE_TABLES=0, L3D_CHECK_POT=1))],
+                         ids=["3 ranks", "4 ranks", "3 ranks, slots with side words and run tables, retired with the records", "4 ranks, the same slots, tables rebuilt from the records"])
+def test_segment_sharded_run_partitioned_equals_the_one_chain(W, diffusion, options):
     """l3d_shard_chain_partition: the source segments of every view sharded over the ranks (no speculation: l3d_shard_chain_run), every rank retiring
-    only what its block of views needs; then the very same collective finish."""
+    only what its block of views needs; then the very same collective finish.  Slots of a dense scene carry a (local camera, target) word per record and
+    a run table (forced here on a small scene: L3D_SLOT_CAMS_MIN=0); the retire kernel files both with the records, so the products transpose the lists
+    without rebuilding either (round 6; L3D_RETIRE_TABLES=0: rebuilt) -- each rank's rows are checked against the plain host construction too (L3D_CHECK_POT)."""
     from line3d_amd.synth import make_scene
     V, S, N = 60, 160, 6
     scene = make_scene(V, S, N, seed=11)
     ref = _reference(scene, N, diffusion)
-    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, diffusion, segments=True)
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, diffusion, options=options, segments=True)
     try:
         assert not errors, errors
         _check_against(ref, scene, ls, shares)

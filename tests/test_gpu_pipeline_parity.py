@@ -940,12 +940,15 @@ def test_native_sharded_run_with_a_ring_of_gathered_slots():
     assert len(want_lines) > 20
     ref.close()
     # world 1, ring forced; then with a far too small compact arena (the retry grows it)
-    for arena in (0, 300):
+    # (slots with side words and run tables -- what a dense scene's slots carry -- retired with the records / rebuilt by the products: round 6)
+    for arena, opts in ((0, {}), (300, {}), (0, dict(L3D_SLOT_CAMS_MIN=0, L3D_CHECK_POT=1)), (300, dict(L3D_SLOT_CAMS_MIN=0, L3D_CHECK_POT=1)), (0, dict(L3D_SLOT_CAMS_MIN=0, L3D_RETIRE_TABLES=0))):
         l = Line3D("", matchingNeighbors=N)
         l.keep_view_matches(True)
         load_scene(l, scene)
         l.prepare()
         l.context().set_option("L3D_SLOT_RING", 1)
+        for kk, vv in opts.items():
+            l.context().set_option(kk, vv)
         if arena:
             l.context().set_chain_capacities(0, arena)
         l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=S, n_neighbors=N)
