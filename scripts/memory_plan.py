@@ -114,15 +114,19 @@ def plan_segpart(V, S, N, W, kept_ratio, chain_world=0):
     add("all", "segments + neighbour tiles, resident (every rank holds the scene: it is small)", V * (S + n_tgt) * 16, "line3d_host_views.cpp:prepare -> l3d_register_segments_batch")
     add("all", "camera tables, best depth pairs + positions of all views", V * (N * 144 + 48 + n_tbm * 4 + window * 8) + V * S * 12, "l3d_chain_common.hip:chain_plan_views, chain_assign_arenas")
     add("all", "kept arena: 32 B x the records of block + 2 x reach either side (%d of %d views, + 12 %%)" % (held_views, V), 1.12 * local_kept * 32, "k_shard_retire (keep flags) -> ch_kept")
+    slot_records = int((2.2 if CW > 1 else 1.3) * kept_view / CW) + 1024           # (a rank's range of segments holds up to twice its share)
+    if slot_records >= 65536:      # (slots of a dense scene carry side words and run tables; the retire kernel files both with the records: no rebuild by the products)
+        add("all", "side words of the kept arena (4 B per record: local camera << 16 | target) + run tables of the views held ((N + 1) x S ints each)", 1.12 * local_kept * 4 + held_views * (N + 1) * S * 4,
+            "k_shard_retire -> ch_keptcam, ch_rt (round 6)")
     add("chain", "viewing rays of every target / own end point (released after the chain)", V * (n_tgt + S) * 32, "chain_upload_tables (k_tgt_rays)")
     add("chain", "bit rows (ring of 10 views), row counters + row starts of all views (released)", 10 * n_tbm * S * W64 * 8 / CW + 2 * V * S * N * 4, "chain_assign_arenas")
     cand_cap = 1.25 * cand_view / CW
     add("chain", "candidate store + window scratch + stage-1 ring of 10 views, 1/W of every view (released)", cand_cap * 44 + 10 * cand_cap * 24, "chain_reserve_candidates")
-    slot_records = int((2.2 if CW > 1 else 1.3) * kept_view / CW) + 1024           # (a rank's range of segments holds up to twice its share)
     slot_bytes = 32 + (S // CW + 1) * 12 + slot_records * (36 if slot_records >= 65536 else 32)      # (+ the side array of target cameras on dense scenes)
     ring = window + 18
     add("chain", "send + gathered slots: ring of %d views x %d ranks, %.0f MB slots (released)" % (ring, CW, slot_bytes / 2**20), ring * (CW + 1) * slot_bytes, "l3d_chain_sharded.hip:l3d_shard_chain_run (ring mode)")
-    add("products", "transposed build (round 6): rebuilt side words + run tables + transposed entries of a block's lists (4 + ~0.1 + 4 B per record), column starts, bounded (released)", min(1 << 30, local_kept) * 8.2 + row_views * N * (S + 1) * 4, "l3d_products.hip:build_products (transposed)")
+    add("products", "transposed build (round 6): transposed entries + their staging copy of a block's lists (4 + 4 B per record; slots without side words: + 4.1 B of rebuilt words and run tables), column starts, bounded (released)",
+        min(1 << 30, local_kept) * (8.0 if slot_records >= 65536 else 12.2) + row_views * N * (S + 1) * 4, "l3d_products.hip:build_products (transposed)")
     add("after", "potential correspondences of the rows held (%d views): 4 B per entry, counted before they are written (~1.1 per record of those views) + row starts of all segments" % row_views, 1.1 * row_views * kept_view * 4 * 1.25 + nd * 8, "build_products (pot_tgt, pot_start)")
     add("after", "best references of all segments, hypotheses (96 B) + scores + indices of the views held (%d)" % held_views, nd * 12 + held_views * S * 112, "l3d_products_hypotheses")
     add("fill", "flags (1 B per local table entry), decision words (2^26 x 8 B), one block of candidates (2^27 x 20 B)", 2 * row_views * kept_view + (1 << 26) * 8 + (1 << 27) * 20, "l3d_affinity.hip:affinity_fill_core")
