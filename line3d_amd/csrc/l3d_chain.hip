@@ -555,18 +555,20 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     // it is transposed on a side stream right behind the view's kept writer -- next to the following views' chains -- and the end of matchViews finds only the rows
     // left.  Entries live in an array aligned with the kept arena (a view's pairs hold exactly its records).  L3D_PROD_EARLY=0: all transposes at the end (A/B)
     Products& PE = c->products;
-    // Long lists only (option value 1; 2: always): at config 2 (36 k records per view) the two launches and the event per view cost the enqueueing thread more than
-    // the 0.2 ms of transposes they take off the end (12.60 vs 12.41 ms per pass); at 4000 x 24 (3.9 M per view) the end shrinks from 8.3 to 5.6 ms.  The lists'
-    // length: what the last pass over this scene kept, or the arena's first guess
+    // Long lists only (> 2^18 records per view: what the last pass over this scene kept, or the arena's first guess), view by view.  At config 2 (36 k records per view)
+    // two launches and an event per view cost more than the 0.2 ms of transposes they take off the end (12.60 vs 12.41 ms per pass); eight views per launch still lose
+    // (12.52 vs 12.41; the first pass pays 5 ms for the side stream and its buffers).  Option values 2 / 3 force a view / eight views per launch (tests)
     bool early = map && use_rt && !ranged && !pre && !cb && c->opt.prod_early != 0 && c->opt.prod_transpose != 0 && maxN > 0;
+    int early_batch = c->opt.prod_early == 3 ? 8 : 1;
     if (early && c->opt.prod_early == 1) {
         const double per_view = (same_scene && c->chain_seen_kept > 0 ? c->chain_seen_kept : pairs * 0.004) / std::max(1, n_views);
         early = per_view > (double)kCamScanMin;
     }
+    int early_next = 0;                 // views [0, early_next) have their transposes launched
     hipStream_t sp = nullptr;
     int early_maxSt = 1;
     if (early) {
-        std::vector<int> tab((size_t)n_views * maxN * 2, 0);       // [St | boff_off], n_views x maxN each
+        std::vector<int> tab((size_t)n_views * maxN * 2 + (size_t)n_views * (sizeof(EarlyView) / 4), 0);       // [St | boff_off], n_views x maxN each; the views' descriptors behind them
         PE.e_boff_off.assign((size_t)n_views * maxN, 0);
         long long nb = 0;
         for (int k = 0; k < n_views && early; ++k) {
@@ -588,6 +590,18 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             if (!c->prod_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->prod_stream, hipStreamNonBlocking));
             sp = c->prod_stream;
             HIPCHK(c, PE.e_tab.reserve(tab.size() * 4 + 64));
+            static_assert(sizeof(EarlyView) % 8 == 0, "descriptor size");
+            {
+                const int* dt = PE.e_tab.as<int>();
+                EarlyView* hv = reinterpret_cast<EarlyView*>(tab.data() + (size_t)n_views * maxN * 2);       // (n_views * maxN * 2 ints: 8-byte aligned)
+                for (int k = 0; k < n_views; ++k) {
+                    EarlyView e;
+                    e.rt = vd[(size_t)k].verified ? vd[(size_t)k].rt : nullptr;
+                    e.St = dt + (size_t)k * maxN; e.boff_off = dt + (size_t)n_views * maxN + (size_t)k * maxN;
+                    e.k = k; e.S = views[k].S_src; e.N = views[k].N; e.pad = 0;
+                    hv[k] = e;
+                }
+            }
             HIPCHK(c, PE.e_cnt.reserve((size_t)n_views * maxN * 4 + 64));
             HIPCHK(c, PE.e_poff.reserve((size_t)n_views * maxN * 4 + 64));
             HIPCHK(c, PE.e_boff.reserve((size_t)nb * 4 + 64));
@@ -796,12 +810,12 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         // (with a delivery callback the host starts D2H copies of device memory once it has seen this event: a default, fenced event then)
         if (!ev[(size_t)k]) ev[(size_t)k] = cb ? get_event(c) : get_local_event(c);
         HIPCHK(c, hipEventRecord(ev[(size_t)k], st));
-        if (early && arena_cap < 0x7ffffff0ull) {
+        if (early && arena_cap < 0x7ffffff0ull && k + 1 - early_next >= early_batch) {
             HIPCHK(c, hipStreamWaitEvent(sp, ev[(size_t)k], 0));
             const double avg_run = views_seen > 0 ? kept_seen / views_seen / std::max(1.0, (double)S * std::max(1, N)) : 1.0;
-            const int* etab = PE.e_tab.as<int>();
-            launch_early_transposes(c, k, d.rt, etab + (size_t)k * maxN, etab + (size_t)n_views * maxN + (size_t)k * maxN, S, N, maxN, early_maxSt, dres, cams, PE.e_cnt.as<int>(),
+            launch_early_transposes(c, reinterpret_cast<const EarlyView*>(PE.e_tab.as<int>() + (size_t)n_views * maxN * 2), early_next, k + 1 - early_next, maxN, early_maxSt, dres, cams, PE.e_cnt.as<int>(),
                                     PE.e_poff.as<unsigned>(), PE.e_boff.as<int>(), PE.e_E.as<unsigned>(), PE.e_T.as<unsigned>(), avg_run, sp);
+            early_next = k + 1;
         }
         return L3D_OK;
     };
@@ -970,6 +984,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
             }
             if (rc_final) break;
             k_enq = k;
+            early_next = std::min(early_next, k);           // (the views run again are transposed again)
             --k;
             continue;
         }
@@ -990,6 +1005,12 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
         ProdEarly pe;
         const bool early_done = early && arena_cap < 0x7ffffff0ull;
         if (early_done) {
+            if (early_next < n_views) {                     // the last batch's remainder: on the chain's stream, behind the last view
+                const double avg_run = views_seen > 0 ? kept_seen / views_seen / std::max(1.0, (double)L.maxS * std::max(1, maxN)) : 1.0;
+                launch_early_transposes(c, reinterpret_cast<const EarlyView*>(PE.e_tab.as<int>() + (size_t)n_views * maxN * 2), early_next, n_views - early_next, maxN, early_maxSt, c->ch_res.as<ChainResult>(),
+                                        c->ch_keptcam.as<unsigned>(), PE.e_cnt.as<int>(), PE.e_poff.as<unsigned>(), PE.e_boff.as<int>(), PE.e_E.as<unsigned>(), PE.e_T.as<unsigned>(), avg_run, st);
+                early_next = n_views;
+            }
             hipEvent_t e = get_local_event(c);
             (void)hipEventRecord(e, sp);
             (void)hipStreamWaitEvent(st, e, 0);

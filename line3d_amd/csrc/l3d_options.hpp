@@ -53,7 +53,7 @@ namespace l3d {
     X(prod_transpose, "L3D_PROD_TRANSPOSE", 1, "matchViews' products: 1 = rows from run tables, per-pair LDS transposes and an LDS bitmap per row (round 6), 0 = radix sort of two 64-bit keys per record (A/B)") \
     X(prod_pair_stage, "L3D_PROD_PAIR_STAGE", 1, "transposed products: 1 = the pair transposes scatter in two levels (buckets of consecutive target segments in a staging region, then an LDS image written in whole lines), 0 = directly (A/B: 4 GB of partial-line write-backs per 0.6 GB of entries at 40 x 4000 x 24)") \
     X(prod_pair_g, "L3D_PROD_PAIR_G", -1, "transposed products: lanes sharing a run in the pair transposes (-1: by the average run, 0: a run per thread)") \
-    X(prod_early, "L3D_PROD_EARLY", 1, "transposed products: the chain transposes a view's (view, camera) pairs on a side stream right behind its kept writer; only the rows are left for the end of matchViews (0: all at the end)") \
+    X(prod_early, "L3D_PROD_EARLY", 1, "transposed products: the chain transposes its views' (view, camera) pairs on a side stream behind their kept writers; only the rows are left for the end of matchViews (1: for lists above 2^18 records per view; 2 / 3: always, a view / eight views per launch; 0: all at the end)") \
     X(retire_tables, "L3D_RETIRE_TABLES", 1, "sharded chain, ring mode: the retire kernel files the slots' side words and run tables with their records, the products transpose without rebuilding them (0: rebuilt from the records)") \
     X(retire_apart, "L3D_RETIRE_APART", 1, "sharded chain, ring mode: batches of views are retired into the compact arena on a side stream; the chain waits only before it overwrites their ring blocks (0: on the chain's stream)") \
     X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \

@@ -385,11 +385,12 @@ __global__ __launch_bounds__(kPairThreads) void k_prodv_pair_transpose(const Pro
 // ---- the transposes of ONE view's pairs, launched by the chain on a side stream right behind the view's kept writer (round 6, late): a pair depends on its view's
 // list alone, so only the rows are left for the end of matchViews.  Canonical places, independent of the tables the end builds: counts and E offsets per (chain view,
 // camera) at [k * maxN + q]; the pair's entries inside its view's piece of an arena-aligned E (the pairs of a view hold exactly its records), camera by camera.
-struct EarlyView { const int* rt; const int* St; const int* boff_off; int k, S, N, maxN; };      // St, boff_off: per local camera, the target view's segments (0: none) / its column starts' place
-__global__ __launch_bounds__(256) void k_prode_counts(EarlyView v, const ChainResult* __restrict__ res, int* __restrict__ pcnt_kq)
+__global__ __launch_bounds__(256) void k_prode_counts(const EarlyView* __restrict__ views, int k0, int maxN, const ChainResult* __restrict__ res, int* __restrict__ pcnt_kq)
 {
     __shared__ int s_w[4];
+    const EarlyView v = views[k0 + blockIdx.y];
     const int q = blockIdx.x;
+    if (!v.rt || q >= v.N) return;
     const ChainResult r = res[v.k];
     int t = 0;
     if (!r.overflow && r.n_kept > 0 && v.St[q] > 0)
@@ -397,20 +398,23 @@ __global__ __launch_bounds__(256) void k_prode_counts(EarlyView v, const ChainRe
     for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) pcnt_kq[(size_t)v.k * v.maxN + q] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) pcnt_kq[(size_t)v.k * maxN + q] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ __launch_bounds__(kPairThreads) void k_prode_transpose(EarlyView v, const ChainResult* __restrict__ res, const unsigned* __restrict__ qt_arena, const int* __restrict__ pcnt_kq,
-                                                                  unsigned* __restrict__ poff_kq, int g, int* __restrict__ boff, unsigned* __restrict__ E, unsigned* __restrict__ T, int cap)
+__global__ __launch_bounds__(kPairThreads) void k_prode_transpose(const EarlyView* __restrict__ views, int k0, int maxN, const ChainResult* __restrict__ res, const unsigned* __restrict__ qt_arena,
+                                                                  const int* __restrict__ pcnt_kq, unsigned* __restrict__ poff_kq, int g, int* __restrict__ boff, unsigned* __restrict__ E,
+                                                                  unsigned* __restrict__ T, int cap)
 {
     extern __shared__ int s_h[];
     __shared__ int s_w[kPairThreads / 64];
     __shared__ int s_kb;
+    const EarlyView v = views[k0 + blockIdx.y];
     const int q = blockIdx.x;
+    if (!v.rt || q >= v.N) return;
     const ChainResult r = res[v.k];
     const int St = v.St[q];
     unsigned off = r.kept_base;
-    for (int j = 0; j < q; ++j) off += (unsigned)pcnt_kq[(size_t)v.k * v.maxN + j];
-    if (threadIdx.x == 0) poff_kq[(size_t)v.k * v.maxN + q] = off;
+    for (int j = 0; j < q; ++j) off += (unsigned)pcnt_kq[(size_t)v.k * maxN + j];
+    if (threadIdx.x == 0) poff_kq[(size_t)v.k * maxN + q] = off;
     if (r.overflow || r.n_kept == 0 || St <= 0) return;                 // (an overflowed view is run again, and transposed again behind that run)
     pair_transpose_wg(qt_arena + r.kept_base, v.rt + (size_t)q * v.S, v.rt + (size_t)(q + 1) * v.S, v.S, St, g, boff + v.boff_off[q], E + off, T ? T + off : nullptr, cap, s_h, s_w, &s_kb);
 }
@@ -644,12 +648,10 @@ void l3d::launch_prod_shift_rows(const long long* piece, long long n_rows, long 
     if (n_rows > 0) hipLaunchKernelGGL(k_prod_shift_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, piece, n_rows, base, pot_start_at);
 }
 
-void l3d::launch_early_transposes(l3d_ctx* c, int k, const int* rt, const int* St_dev, const int* boff_off_dev, int S, int N, int maxN, int maxSt, const ChainResult* res,
+void l3d::launch_early_transposes(l3d_ctx* c, const EarlyView* views_dev, int k0, int nb, int maxN, int maxSt, const ChainResult* res,
                                   const unsigned* qt_arena, int* pcnt_kq, unsigned* poff_kq, int* boff, unsigned* E, unsigned* T, double avg_run, hipStream_t st)
 {
-    if (N <= 0 || S <= 0) return;
-    EarlyView v;
-    v.rt = rt; v.St = St_dev; v.boff_off = boff_off_dev; v.k = k; v.S = S; v.N = N; v.maxN = maxN;
+    if (maxN <= 0 || nb <= 0) return;
     int g = 1;
     while (g < 64 && g < avg_run / 4.0) g <<= 1;
     if (c->opt.prod_pair_g >= 0) g = c->opt.prod_pair_g;
@@ -660,9 +662,9 @@ void l3d::launch_early_transposes(l3d_ctx* c, int k, const int* rt, const int* S
         if (((size_t)maxSt + 2 + 2 * (size_t)cap) * 4 > 64 * 1024) cap = 0;
     }
     ProfScope p(c, "prod_keys", st);
-    hipLaunchKernelGGL(k_prode_counts, dim3((unsigned)N), dim3(256), 0, st, v, res, pcnt_kq);
-    hipLaunchKernelGGL(k_prode_transpose, dim3((unsigned)N), dim3(kPairThreads), ((size_t)maxSt + 2 + 2 * (size_t)cap) * 4, st, v, res, qt_arena, (const int*)pcnt_kq, poff_kq, g, boff, E,
-                       cap ? T : (unsigned*)nullptr, cap);
+    hipLaunchKernelGGL(k_prode_counts, dim3((unsigned)maxN, (unsigned)nb), dim3(256), 0, st, views_dev, k0, maxN, res, pcnt_kq);
+    hipLaunchKernelGGL(k_prode_transpose, dim3((unsigned)maxN, (unsigned)nb), dim3(kPairThreads), ((size_t)maxSt + 2 + 2 * (size_t)cap) * 4, st, views_dev, k0, maxN, res, qt_arena, (const int*)pcnt_kq, poff_kq, g,
+                       boff, E, cap ? T : (unsigned*)nullptr, cap);
 }
 
 int l3d::build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const ProdChainView* pvh, const ChainResult* hres,

@@ -37,9 +37,11 @@ int build_products(l3d_ctx* c, const l3d_chain_view* views, int n_views, const P
 // qt_arena: the side array of the kept arena, (local camera << 16 | target) per record, when the chain's kept writer filled it together with the
 // views' run tables (ProdChainView::rt); null: the products rebuild both from the records, block by block
 
-// one view's pairs: counts, then transposes, on `st` (behind the view's kept writer).  rt, St_dev, boff_off_dev: device arrays of the view (run table; per local camera
-// the target view's segment count or 0, the place of its column starts in boff)
-void launch_early_transposes(l3d_ctx* c, int k, const int* rt, const int* St_dev, const int* boff_off_dev, int S, int N, int maxN, int maxSt, const ChainResult* res,
+// the chain's views as the early transposes see them (device array, one per chain view; rt == null: nothing to transpose): run table, per local camera the target
+// view's segment count (0: none) and the place of its column starts in boff
+struct EarlyView { const int* rt; const int* St; const int* boff_off; int k, S, N, pad; };
+// the pairs of the chain views [k0, k0 + nb): counts, then transposes, on `st` (behind the kept writer of the last of them)
+void launch_early_transposes(l3d_ctx* c, const EarlyView* views_dev, int k0, int nb, int maxN, int maxSt, const ChainResult* res,
                              const unsigned* qt_arena, int* pcnt_kq, unsigned* poff_kq, int* boff, unsigned* E, unsigned* T, double avg_run, hipStream_t st);
 
 // pot_start[first_row + i] = piece[i] + base for n_rows rows (a rank's rows of the table put in place)

@@ -571,14 +571,14 @@ def test_chain_overflow_restart_with_more_views_than_ring_slots():
 
 
 def test_early_pair_transposes_survive_arena_growth_and_restarts():
-    """The chain transposes a view's (view, camera) pairs behind its kept writer into an array aligned with the kept arena (L3D_PROD_EARLY; forced here, the default
-    takes it for long lists only).  When the arena overflows, the chain grows it, MOVES the earlier views' entries with their records and runs the overflowed view
+    """The chain transposes a view's (view, camera) pairs behind its kept writer into an array aligned with the kept arena (L3D_PROD_EARLY: 2 view by view -- the default for long lists --, 3 in batches of
+    eight views; short lists are transposed at the end by default).  When the arena overflows, the chain grows it, MOVES the earlier views' entries with their records and runs the overflowed view
     and the ones behind it again -- their transposes too.  Products (CSR, best matches, hypotheses) equal the undisturbed run's with the transposes at the end."""
     from line3d_amd.pipeline import Line3D, load_scene
     from line3d_amd.synth import make_scene
     sc = make_scene(30, 400, 10, seed=4242)
     digests = []
-    for early, caps in ((0, None), (2, None), (2, (6000, 1 << 22)), (2, (1 << 22, 900)), (2, (5000, 700))):
+    for early, caps in ((0, None), (2, None), (3, None), (2, (6000, 1 << 22)), (2, (1 << 22, 900)), (2, (5000, 700)), (3, (1 << 22, 900)), (3, (5000, 700))):
         l = Line3D("", matchingNeighbors=10)
         l.keep_view_matches(False)
         load_scene(l, sc)
@@ -769,8 +769,8 @@ def test_products_variants_agree(small_scene, small_oracle):
         digests = []
         for opts in (dict(L3D_PROD_TRANSPOSE=0, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=0), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1),
                      dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=0, L3D_PROD_ROW_GROUP=512), dict(L3D_PROD_TRANSPOSE=1, L3D_RUN_TABLES=1, L3D_PROD_PAIR_G=64, L3D_PROD_BLOCK_KEYS=5000),
-                     # the pairs transposed by the chain itself, behind each view's kept writer (default for long lists only: forced here), and all at the end
-                     dict(L3D_PROD_EARLY=2), dict(L3D_PROD_EARLY=2, L3D_PROD_PAIR_G=16, L3D_PROD_PAIR_STAGE=0), dict(L3D_PROD_EARLY=0)):
+                     # the pairs transposed by the chain itself, behind each view's kept writer (2: view by view, 3: eight views per launch; 1, the default: long lists only), and all at the end
+                     dict(L3D_PROD_EARLY=2), dict(L3D_PROD_EARLY=2, L3D_PROD_PAIR_G=16, L3D_PROD_PAIR_STAGE=0), dict(L3D_PROD_EARLY=3), dict(L3D_PROD_EARLY=0)):
             l = Line3D("", matchingNeighbors=N)
             l.keep_view_matches(False)
             load_scene(l, scene)
