@@ -11,11 +11,13 @@ from helpers import digest_lists, assert_lines_equal, thread_exchange as _thread
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(scene, n_neighbors, diffusion=False, collin=True):
+def _run_gpu(scene, n_neighbors, diffusion=False, collin=True, options=None):
     from line3d_amd.pipeline import Line3D, load_scene
     l = Line3D("", matchingNeighbors=n_neighbors, useCollinearity=collin)
     l.keep_view_matches(True)
     load_scene(l, scene)
+    for k, v in (options or {}).items():
+        l.context().set_option(k, v)
     l.compute3Dmodel(diffusion)
     return l
 
@@ -610,13 +612,16 @@ def test_random_small_scenes_full_parity(seed):
         v["gt"] = v["gt"][:keep]
     collin, diffusion = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     o = op.run_scene(sc, N, use_collinearity=collin, perform_diffusion=diffusion)
-    l = _run_gpu(sc, N, diffusion=diffusion, collin=collin)
-    for v in sorted(o.trace):
-        got, med = l.view_matches(v)
-        assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
-        assert np.float32(med) == np.float32(o.trace[v]["median"])
-    assert_lines_equal(l.getResult(), o.result, 1e-4)
-    l.close()
+    # (the defaults; then the chain's own pair transposes forced on these short ragged lists, a view and eight views per launch -- with the host's
+    # plain construction of the table beside the device's: L3D_CHECK_POT)
+    for options in (None, dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1)):
+        l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options)
+        for v in sorted(o.trace):
+            got, med = l.view_matches(v)
+            assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
+            assert np.float32(med) == np.float32(o.trace[v]["median"])
+        assert_lines_equal(l.getResult(), o.result, 1e-4)
+        l.close()
 
 
 def test_degenerate_segments_through_the_whole_pipeline():
