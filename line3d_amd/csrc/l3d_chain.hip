@@ -525,6 +525,10 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     // ---- capacities (guarded on the device; an overflow restarts the chain at that view with more room)
     // first guess from the pair counts (raw density ~6 %, kept ~0.2 % of the pairs on the synthetic scenes)
     size_t cand_cap = chain_first_cand_cap(max_pairs);
+    // The kept arena's first guess is GENEROUS (5 % of the pairs: the densest synthetic scene keeps 4.5 %, config 2 0.16 %) within 35 % of the free HBM: memory that is
+    // never written costs an allocation of a millisecond when it is the process's first big one, while growing later means a hipMalloc of tens of GB in a process that
+    // has freed big buffers before -- measured at 256 x 4000 x 24: 0.5 ms for the first 59 GB, 1.8-2.2 s for 75 GB at the second regrow, 25 ms per GB at 40 views in one
+    // run of three (profiles/r6_first_pass_allocations.txt).  A job sized by memory gives its capacities (l3d_set_chain_capacities) or the old guess (L3D_ARENA_GUESS=4)
     size_t arena_cap = (size_t)(pairs * 0.004) + 1048576;
     std::vector<hipEvent_t> ev((size_t)n_views, nullptr);
     int k_enq = 0;                      // next view whose phase 2 is enqueued
@@ -538,6 +542,15 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
     // overflow, no restart, no allocation after the first pass
     const bool same_scene = c->chain_seen_views == n_views && c->chain_seen_pairs == pairs;
     if (same_scene) { cand_cap = std::max(cand_cap, c->chain_seen_cand_cap); arena_cap = std::max(arena_cap, c->chain_seen_arena_cap); }
+    else if (c->opt.arena_guess > 4 && !ranged && !pre) {      // (a block of views of a partitioned job is sized by memory: it keeps the small guess and grows)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const size_t want = (size_t)(pairs * 0.001 * c->opt.arena_guess) + 1048576, fits = (size_t)((double)fr * 0.35 / 40.0);
+            arena_cap = std::max(arena_cap, std::min(want, fits));
+        }
+        (void)hipGetLastError();
+        if (arena_cap > 0xfffffff0ull) arena_cap = 0xfffffff0ull;
+    }
     if (c->test_cand_cap) cand_cap = c->test_cand_cap;      // tests: force the overflow / restart path
     if (c->test_arena_cap) arena_cap = c->test_arena_cap;
     // views that own a slice of the arena: the range's verified views and the preloaded ones (a view's slice starts where the previous such view's ended)
@@ -940,6 +953,7 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                     new_cap = kMaxRecords;
                 }
                 void* np = nullptr;
+                const double t_m0 = now_s();
                 {
                     const hipError_t me = hipMalloc(&np, new_cap * sizeof(Match));
                     if (me != hipSuccess) {
@@ -950,8 +964,12 @@ static int run_chain(l3d_ctx* c, const l3d_chain_view* views, int n_views, l3d_c
                         break;
                     }
                 }
+                const double t_m1 = now_s();
                 if (!hip_ok(hipMemcpy(np, c->ch_kept.p, (size_t)r.kept_base * sizeof(Match), hipMemcpyDeviceToDevice), "hipMemcpy")) break;
+                const double t_m2 = now_s();
                 (void)hipFree(c->ch_kept.p);
+                if (c->opt.timing) fprintf(stderr, "[l3d match_chain]   arena of %zu MB: hipMalloc %.2f ms, copy of %zu MB %.2f ms, hipFree of the old one %.2f ms\n", new_cap * sizeof(Match) >> 20, (t_m1 - t_m0) * 1e3,
+                                           (size_t)r.kept_base * sizeof(Match) >> 20, (t_m2 - t_m1) * 1e3, (now_s() - t_m2) * 1e3);
                 c->ch_kept.p = np; c->ch_kept.cap = new_cap * sizeof(Match);
                 if (use_cams) {                             // (the side array grows with it, its used part kept)
                     void* nc = nullptr;

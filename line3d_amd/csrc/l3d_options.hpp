@@ -56,6 +56,7 @@ namespace l3d {
     X(prod_early, "L3D_PROD_EARLY", 1, "transposed products: the chain transposes its views' (view, camera) pairs on a side stream behind their kept writers; only the rows are left for the end of matchViews (1: for lists above 2^18 records per view; 2 / 3: always, a view / eight views per launch; 0: all at the end)") \
     X(retire_tables, "L3D_RETIRE_TABLES", 1, "sharded chain, ring mode: the retire kernel files the slots' side words and run tables with their records, the products transpose without rebuilding them (0: rebuilt from the records)") \
     X(retire_apart, "L3D_RETIRE_APART", 1, "sharded chain, ring mode: batches of views are retired into the compact arena on a side stream; the chain waits only before it overwrites their ring blocks (0: on the chain's stream)") \
+    X(arena_guess, "L3D_ARENA_GUESS", 50, "resident chain: first guess of the kept arena in thousandths of the scene's segment pairs, within 35 % of the free HBM (4: the small guess of rounds 1-5, grown on overflow)") \
     X(prod_row_group, "L3D_PROD_ROW_GROUP", 1, "transposed products: bitmap words a group of touched views may fill together in the rows kernel (1: a view at a time, up to 512)") \
     X(slot_scan_grain, "L3D_SLOT_SCAN_GRAIN", 0, "sharded chain: records of a slot per workgroup of the two scans of the sources' slots (0: 4096)") \
     X(rt_place_lds, "L3D_RT_PLACE_LDS", 0, "resident chain with run tables: 1 = reverse matches placed by big workgroups with LDS cursors from the chunk bases (no global cursor; measured slower: too few workgroups), 0 = through the global row cursors (A/B)") \
