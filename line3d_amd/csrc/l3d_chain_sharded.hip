@@ -826,6 +826,15 @@ int l3d_shard_chain_run(l3d_shard_chain* h, l3d_exchange_fn exchange, void* exch
         // compact arena (first guess like the single-GPU chain's, or what an earlier pass / a capacity verdict taught), the per-view offsets,
         // the header table, the flags the retire kernel reads
         h->arena_cap = c->test_arena_cap ? (long long)c->test_arena_cap : std::max((long long)(h->pairs * h->world * 0.004) + 1048576, (long long)c->chain_seen_arena_cap);
+        if (!h->partition && !c->test_arena_cap && c->opt.arena_guess > 4) {
+            // (as the single-GPU chain: a generous first guess within 35 % of the free HBM -- here a guess that is too small costs a capacity verdict and the whole chain again)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                const long long want = (long long)(h->pairs * h->world * 0.001 * c->opt.arena_guess) + 1048576, fits = (long long)((double)fr * 0.35 / 40.0);
+                h->arena_cap = std::min<long long>(0xfffffff0ll, std::max(h->arena_cap, std::min(want, fits)));
+            }
+            (void)hipGetLastError();
+        }
         if (!h->partition) HIPCHK(c, c->ch_kept.reserve(((size_t)h->arena_cap + 64) * sizeof(Match)));
         auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t nvs = (size_t)h->n_views;
