@@ -166,17 +166,27 @@ def test_chain_and_per_view_matching_agree(small_scene, small_oracle):
     assert_lines_equal(outs[0][3], small_oracle.result, 1e-4)
 
 
-def test_chain_rerun_is_idempotent(small_scene):
+@pytest.mark.parametrize("early", [1, 2, 3], ids=["defaults", "pairs transposed by the chain, view by view", "pairs transposed by the chain, eight views per launch"])
+def test_chain_rerun_is_idempotent(small_scene, early):
+    """Passes over the same scene on one context reuse the capacities, side buffers and (forced here) the chain's own transposes of the first pass: kept lists and
+    products of the third pass equal the first's, and the device's table equals the host's plain construction every time (L3D_CHECK_POT)."""
     from line3d_amd.pipeline import Line3D, load_scene
     l = Line3D("", matchingNeighbors=6)
     l.keep_view_matches(True)
     load_scene(l, small_scene)
     l.prepare()
+    l.context().set_option("L3D_PROD_EARLY", early)
+    l.context().set_option("L3D_CHECK_POT", 1)
     l.match_views()
     a = {v["id"]: l.view_matches(v["id"])[0].tobytes() for v in small_scene.views}
+    pa = _products_digest(l) if l.resident_products() is not None else None
+    l.match_views()
     l.match_views()
     b = {v["id"]: l.view_matches(v["id"])[0].tobytes() for v in small_scene.views}
     assert a == b and sum(len(x) for x in a.values()) > 0
+    if pa is not None:
+        pb = _products_digest(l)
+        assert all(pa[k] == pb[k] for k in ("seg_base", "pot_start", "pot_tgt", "best"))
     l.close()
 
 
