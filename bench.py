@@ -454,7 +454,7 @@ def main():
             # pass (this run) and over the time the GPU is busy (the longer of the two streams' kernel sums of the bracketed pass: an upper bound of busy)
             tot_vi = 0.0
             # (the products' two brackets cover several kernels each: their instructions come from the profile's own launch counts -- its PMC pass is ONE matchViews pass)
-            groups = {"prod_keys": ("k_prodv_pair_counts", "k_prodv_pair_transpose", "k_prod_early_rt", "k_prod_keys_early", "k_prod_best", "k_prod_median", "prod_keys"),
+            groups = {"prod_keys": ("k_prodv_pair_counts", "k_prodv_pair_transpose", "k_prode_counts", "k_prode_transpose", "k_prod_early_rt", "k_prod_keys_early", "k_prod_best", "k_prod_median", "prod_keys"),
                       "prod_rows": ("k_prodv_rows", "k_prodt_row_starts")}
             for kname, (kl, _kms) in prof_all.items():
                 if kname in groups and kname not in valu_json:
