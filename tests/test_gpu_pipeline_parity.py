@@ -608,7 +608,8 @@ def test_early_pair_transposes_survive_arena_growth_and_restarts():
         assert d == digests[0], i
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303, 404])
+# (L3D_FUZZ_SEEDS=n: n more seeds -- a fuzzing run outside the suite's time budget; the round-6 run of 150 is recorded in profiles/README.md)
+@pytest.mark.parametrize("seed", [101, 202, 303, 404] + [5000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
 def test_random_small_scenes_full_parity(seed):
     """Randomised end-to-end parity: number of views, segments per view (ragged), neighbours, noise, first image id,
     collinearity and diffusion drawn per seed; kept lists and affinity list bit-exact, lines within 1e-4."""
