@@ -3,6 +3,7 @@ job that fits -- every rank holds its block's share of the kept records and of m
 SURVEY.md 8e) against the ONE single-GPU chain: virtual ranks as threads of this process on the one GPU of the test box, the all-gather through
 the host (helpers.thread_exchange).  Reference behaviour: line3D.cc:620-648 (matchViews), :834-884 (what performMatching leaves behind),
 :968-1221 (clusterSegments2D), view.cc:150-224 (the reference's own way of not holding everything: a file per view)."""
+import os
 import threading
 
 import numpy as np
@@ -161,6 +162,48 @@ def test_partitioned_jobs_on_scattered_non_mutual_neighbourhoods(segments):
         assert not errors, errors
         assert verdicts == [True] * W
         _check_against(ref, scene, ls, shares)
+    finally:
+        for l in ls:
+            l.close()
+
+
+# (L3D_FUZZ_SEEDS=n: n more seeds, outside the suite's time budget)
+@pytest.mark.parametrize("seed", [11, 12, 13] + [7000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
+def test_partitioned_jobs_on_randomly_drawn_scenes(seed):
+    """Both partitioned jobs on scenes drawn per seed -- 24-72 views, 60-200 segments per view (ragged prefixes), 6-10 neighbours, helix or scattered cameras,
+    2-4 virtual ranks, with or without diffusion; the segment-sharded one also with slots that carry side words and run tables (what a dense scene's do: retired with
+    the records or rebuilt by the products) -- against the ONE chain: kept lists, rows of the table, best matches, affinity list, hypotheses, lines."""
+    from line3d_amd.pipeline import load_scene_worldpoints
+    from line3d_amd.synth import make_scene, make_scene_scattered
+    rng = np.random.default_rng(seed)
+    N, W, diffusion = int(2 * rng.integers(3, 6)), int(rng.integers(2, 5)), bool(rng.integers(0, 2))      # (4 neighbours keep nothing: two witnesses' cameras are needed)
+    scattered = bool(rng.integers(0, 4) == 0)
+    V, S = int(rng.integers(max(24, 4 * N), 73)), int(rng.integers(60, 201))
+    loader = None
+    if scattered:
+        scene, loader = make_scene_scattered(min(V, 40), S + 60, seed=seed), load_scene_worldpoints
+    else:
+        scene = make_scene(V, S, N, seed=seed, noise_px=float(rng.choice([0.3, 0.5, 1.5])))
+        for v in scene.views:
+            keep = int(rng.integers(S // 2, S + 1))
+            v["segments"] = np.ascontiguousarray(v["segments"][:keep])
+            v["gt"] = v["gt"][:keep]
+    segments = bool(rng.integers(0, 3) != 0) or scattered
+    options = None
+    if segments and rng.integers(0, 3) != 0:
+        options = dict(L3D_SLOT_CAMS_MIN=0, L3D_RETIRE_TABLES=int(rng.integers(0, 2)), L3D_RETIRE_APART=int(rng.integers(0, 2)), L3D_CHECK_POT=1)
+    ref = _reference(scene, N, diffusion, loader=loader)
+    ls, verdicts, errors, shares, calls = _run_partitioned(scene, N, W, -1, diffusion, options=options, segments=segments, loader=loader)
+    try:
+        assert not errors, (seed, errors)
+        if verdicts != [True] * W:          # (blocks of views shorter than the neighbour window: refused on every rank alike -- the segment-sharded job takes such scenes)
+            assert not segments and verdicts == [False] * W, (seed, verdicts)
+            print("seed %d: %d views on %d ranks, blocks of views refused" % (seed, len(scene.views), W))
+            return
+        _check_against(ref, scene, ls, shares)
+        print("seed %d: %d views x <= %d segments, N %d, %d ranks, %s, %s, options %r: %d kept, %d affinity entries, %d lines" % (
+            seed, len(scene.views), max(len(v["segments"]) for v in scene.views), N, W, "scattered" if scattered else "helix", "segments sharded" if segments else "blocks of views", options,
+            sum(len(m[0]) for m in ref["lists"].values()), len(ref["A"]), len(ref["lines"])))
     finally:
         for l in ls:
             l.close()
