@@ -11,13 +11,15 @@ from helpers import digest_lists, assert_lines_equal, thread_exchange as _thread
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(scene, n_neighbors, diffusion=False, collin=True, options=None):
+def _run_gpu(scene, n_neighbors, diffusion=False, collin=True, options=None, caps=None):
     from line3d_amd.pipeline import Line3D, load_scene
     l = Line3D("", matchingNeighbors=n_neighbors, useCollinearity=collin)
     l.keep_view_matches(True)
     load_scene(l, scene)
     for k, v in (options or {}).items():
         l.context().set_option(k, v)
+    if caps:
+        l.context().set_chain_capacities(*caps)
     l.compute3Dmodel(diffusion)
     return l
 
@@ -625,8 +627,11 @@ def test_random_small_scenes_full_parity(seed):
     o = op.run_scene(sc, N, use_collinearity=collin, perform_diffusion=diffusion)
     # (the defaults; then the chain's own pair transposes forced on these short ragged lists, a view and eight views per launch -- with the host's
     # plain construction of the table beside the device's: L3D_CHECK_POT)
-    for options in (None, dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1)):
-        l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options)
+    # ... and with capacities far too small, drawn per seed: the chain grows its buffers and restarts at the view that overflowed, the early transposes with it
+    small = (int(rng.integers(1500, 9000)), int(rng.integers(200, 4000)))
+    for options, caps in ((None, None), (dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), None), (dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1), None),
+                          (dict(L3D_PROD_EARLY=int(rng.integers(1, 4)), L3D_CHECK_POT=1), small)):
+        l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options, caps=caps)
         for v in sorted(o.trace):
             got, med = l.view_matches(v)
             assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
