@@ -1014,6 +1014,50 @@ def test_native_sharded_run_with_a_ring_of_gathered_slots():
         q.close()
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23] + [9000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
+def test_native_sharded_run_on_randomly_drawn_scenes(seed):
+    """l3d_shard_chain_run at world 1 (every segment local; the exchange a device copy) with the commit on the device, on scenes drawn per seed: all gathered blocks kept or a
+    ring of them with retirement, slots with or without side words and run tables, those retired with the records or rebuilt, the retirement on the chain's stream or beside
+    it -- kept lists, products and lines equal the unsharded resident chain's byte for byte."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    from line3d_amd import distributed as l3dist
+    rng = np.random.default_rng(seed)
+    V, S, N = int(rng.integers(24, 64)), int(rng.integers(80, 220)), int(2 * rng.integers(3, 6))
+    scene = make_scene(V, S, N, seed=seed, noise_px=float(rng.choice([0.3, 0.5, 1.5])))
+    for v in scene.views:
+        keep = int(rng.integers(S // 2, S + 1))
+        v["segments"] = np.ascontiguousarray(v["segments"][:keep])
+        v["gt"] = v["gt"][:keep]
+    opts = dict(L3D_SLOT_RING=int(rng.integers(0, 2)), L3D_RETIRE_TABLES=int(rng.integers(0, 2)), L3D_RETIRE_APART=int(rng.integers(0, 2)), L3D_CHECK_POT=1)
+    if rng.integers(0, 3) != 0:
+        opts["L3D_SLOT_CAMS_MIN"] = 0
+    arena = int(rng.integers(200, 3000)) if opts["L3D_SLOT_RING"] and rng.integers(0, 3) == 0 else 0      # (a compact arena that is too small: capacity verdict, the retry grows it)
+
+    def lists_of(l):
+        return {v["id"]: l.view_matches(v["id"]) for v in scene.views}
+
+    ref = Line3D("", matchingNeighbors=N)
+    ref.keep_view_matches(True)
+    load_scene(ref, scene)
+    ref.compute3Dmodel(False)
+    want, want_lists, want_lines = _products_digest(ref), digest_lists(lists_of(ref)), ref.getResult()
+    ref.close()
+    l = Line3D("", matchingNeighbors=N)
+    l.keep_view_matches(True)
+    load_scene(l, scene)
+    l.prepare()
+    for k, v in opts.items():
+        l.context().set_option(k, v)
+    if arena:
+        l.context().set_chain_capacities(0, arena)
+    l3dist.match_views_chain_native(l, 0, 1, None, commit="device", n_segments=S, n_neighbors=N)
+    l.finish(False)
+    assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, (seed, opts, arena)
+    assert_lines_equal(l.getResult(), want_lines, 0.0)
+    l.close()
+
+
 def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
     """l3d_match_chain_blocks: the VIEWS are sharded -- every rank runs the full-width single-GPU chain on its block + a warm-up in front of it,
     started cold; digests of the kept lists decide whether the speculation was exact (the chain's memory is a few neighbour windows:
