@@ -1120,6 +1120,63 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
             l.close()
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33] + [11000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
+def test_blocks_of_views_on_randomly_drawn_scenes(seed):
+    """l3d_match_chain_blocks (the multi-GPU bench's first mode) on scenes, rank counts and warm-up lengths drawn per seed: whenever the ranks agree that the run was exact
+    (speculation verified or repaired), every rank holds the ONE chain's kept lists, products and lines; when they agree that it was not, nothing is committed."""
+    import threading
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    rng = np.random.default_rng(seed)
+    N, W = int(2 * rng.integers(3, 6)), int(rng.integers(2, 5))
+    V, S = int(rng.integers(max(30, 5 * N), 90)), int(rng.integers(60, 180))
+    scene = make_scene(V, S, N, seed=seed, noise_px=float(rng.choice([0.3, 0.5, 1.5])))
+    for v in scene.views:
+        keep = int(rng.integers(S // 2, S + 1))
+        v["segments"] = np.ascontiguousarray(v["segments"][:keep])
+        v["gt"] = v["gt"][:keep]
+    warmup, recover = int(rng.choice([-1, 2, N // 2, 2 * N, 4 * N])), int(rng.integers(0, 4) != 0)
+    ref = Line3D("", matchingNeighbors=N)
+    ref.keep_view_matches(True)
+    load_scene(ref, scene)
+    ref.compute3Dmodel(False)
+    lists_of = lambda l: {v["id"]: l.view_matches(v["id"]) for v in scene.views}      # noqa: E731
+    want, want_lists, want_lines = _products_digest(ref), digest_lists(lists_of(ref)), ref.getResult()
+    ref.close()
+    make, calls = _thread_exchange(W)
+    ls, verdicts, errors = [], [None] * W, []
+    for r in range(W):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        l.context().set_option("L3D_BLOCK_RECOVER", recover)
+        ls.append(l)
+
+    def run(r):
+        try:
+            verdicts[r] = ls[r].block_run(r, W, make(r), None, warmup)
+        except Exception as e:      # noqa: BLE001
+            errors.append((r, e))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    try:
+        assert not errors, (seed, errors)
+        assert verdicts in ([True] * W, [False] * W), (seed, verdicts)
+        print("seed %d: %d views, N %d, %d ranks, warm-up %d, recover %d: %s" % (seed, V, N, W, warmup, recover, "exact" if verdicts[0] else "not exact: nothing committed"))
+        if verdicts[0]:
+            for r, l in enumerate(ls):
+                l.finish(False)
+                assert digest_lists(lists_of(l)) == want_lists and _products_digest(l) == want, "seed %d rank %d" % (seed, r)
+                assert_lines_equal(l.getResult(), want_lines, 0.0)
+    finally:
+        for l in ls:
+            l.close()
+
+
 def test_product_against_the_reference_kernels_pipeline(small_scene):
     """The product against a pipeline whose kernels are the REFERENCE's own (K_collinearity, K_pairwise_matches, K_verify_matches, the diffusion
     kernels: oracle/_spliced/libkernels_spliced.so, compiled from cudawrapper.cu's text) inside the oracle's host code, glibc transcendentals: the same
