@@ -629,13 +629,19 @@ def test_random_small_scenes_full_parity(seed):
     # plain construction of the table beside the device's: L3D_CHECK_POT)
     # ... and with capacities far too small, drawn per seed: the chain grows its buffers and restarts at the view that overflowed, the early transposes with it
     small = (int(rng.integers(1500, 9000)), int(rng.integers(200, 4000)))
+    # ... and the affinity fill in small blocks of sources / decision words, its general path on a symmetric table, one launch per view, few targets per pass (drawn per seed)
+    fill = dict(L3D_AFF_BLOCK=int(rng.choice([0, 300, 5000])), L3D_AFF_WORD_BLOCK=int(rng.choice([0, 64, 2000])), L3D_AFF_SYM=int(rng.integers(0, 2)), L3D_AFF_PER_VIEW=int(rng.integers(0, 2)),
+                L3D_AFF_CHUNK=int(rng.choice([0, 1, 7])))
     for options, caps in ((None, None), (dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), None), (dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1), None),
-                          (dict(L3D_PROD_EARLY=int(rng.integers(1, 4)), L3D_CHECK_POT=1), small)):
+                          (dict(fill, L3D_PROD_EARLY=int(rng.integers(1, 4)), L3D_CHECK_POT=1), small)):
         l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options, caps=caps)
         for v in sorted(o.trace):
             got, med = l.view_matches(v)
             assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
             assert np.float32(med) == np.float32(o.trace[v]["median"])
+        if not diffusion:                                   # (with diffusion the list the facade holds is the diffused one)
+            A, n_nodes = l.affinity()
+            assert n_nodes == len(o.local2global) and A.tobytes() == o.affinity.tobytes(), "affinity list differs (options %r)" % (options,)
         assert_lines_equal(l.getResult(), o.result, 1e-4)
         l.close()
 
