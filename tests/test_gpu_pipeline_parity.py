@@ -11,15 +11,18 @@ from helpers import digest_lists, assert_lines_equal, thread_exchange as _thread
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(scene, n_neighbors, diffusion=False, collin=True, options=None, caps=None):
+def _run_gpu(scene, n_neighbors, diffusion=False, collin=True, options=None, caps=None, sync=False, verify_mode=0):
     from line3d_amd.pipeline import Line3D, load_scene
     l = Line3D("", matchingNeighbors=n_neighbors, useCollinearity=collin)
     l.keep_view_matches(True)
+    l.set_sync_matching(sync)               # (True: matchViews through the per-view seam call, l3d_compute_pairwise_matches)
     load_scene(l, scene)
     for k, v in (options or {}).items():
         l.context().set_option(k, v)
     if caps:
         l.context().set_chain_capacities(*caps)
+    if verify_mode:
+        l.context().set_verify_mode(verify_mode)    # (1: the all-pairs verification instead of the window kernel)
     l.compute3Dmodel(diffusion)
     return l
 
@@ -632,9 +635,10 @@ def test_random_small_scenes_full_parity(seed):
     # ... and the affinity fill in small blocks of sources / decision words, its general path on a symmetric table, one launch per view, few targets per pass (drawn per seed)
     fill = dict(L3D_AFF_BLOCK=int(rng.choice([0, 300, 5000])), L3D_AFF_WORD_BLOCK=int(rng.choice([0, 64, 2000])), L3D_AFF_SYM=int(rng.integers(0, 2)), L3D_AFF_PER_VIEW=int(rng.integers(0, 2)),
                 L3D_AFF_CHUNK=int(rng.choice([0, 1, 7])))
-    for options, caps in ((None, None), (dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), None), (dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1), None),
-                          (dict(fill, L3D_PROD_EARLY=int(rng.integers(1, 4)), L3D_CHECK_POT=1), small)):
-        l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options, caps=caps)
+    # ... and matchViews through the per-view seam call (the drop-in boundary itself), window or all-pairs verification drawn per seed
+    for options, caps, sync in ((None, None, False), (dict(L3D_PROD_EARLY=2, L3D_CHECK_POT=1), None, False), (dict(L3D_PROD_EARLY=3, L3D_CHECK_POT=1), None, False),
+                                (dict(fill, L3D_PROD_EARLY=int(rng.integers(1, 4)), L3D_CHECK_POT=1), small, False), (dict(fill), None, True)):
+        l = _run_gpu(sc, N, diffusion=diffusion, collin=collin, options=options, caps=caps, sync=sync, verify_mode=int(rng.integers(0, 2)) if sync else 0)
         for v in sorted(o.trace):
             got, med = l.view_matches(v)
             assert got.tobytes() == o.trace[v]["matches"].tobytes(), "view %d kept matches differ" % v
