@@ -1130,6 +1130,49 @@ def test_matchviews_sharded_by_blocks_of_views_with_verified_speculation():
             l.close()
 
 
+@pytest.mark.parametrize("seed", [41, 42] + [13000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
+def test_fast_paths_equal_the_plain_paths_on_medium_scenes(seed):
+    """Scenes too big for the oracle in a test (12-28 views of 600-2400 segments, 8-16 neighbours, narrow baselines: thousands of candidates per segment, rows of the table with
+    hundreds of entries, pairs beyond the direct scatter) through the defaults (+ the chain's own transposes) and through the PLAIN paths whose parity the small scenes and the
+    goldens pin: the exact pair test alone (no wedge test, no interval bounds), the all-pairs verification, record scans instead of run tables, the sorted products --
+    kept lists, products, affinity list and lines byte for byte."""
+    from line3d_amd.pipeline import Line3D, load_scene
+    from line3d_amd.synth import make_scene
+    rng = np.random.default_rng(seed)
+    V, S, N = int(rng.integers(12, 29)), int(rng.integers(600, 2401)), int(2 * rng.integers(4, 9))
+    scene = make_scene(V, S, N, seed=seed, noise_px=float(rng.choice([0.05, 0.2, 0.5])), step=float(rng.choice([0.03, 0.06, 0.12])))
+    for v in scene.views:
+        keep = int(rng.integers(2 * S // 3, S + 1))
+        v["segments"] = np.ascontiguousarray(v["segments"][:keep])
+        v["gt"] = v["gt"][:keep]
+    outs = []
+    for plain in (False, True):
+        l = Line3D("", matchingNeighbors=N)
+        l.keep_view_matches(True)
+        load_scene(l, scene)
+        l.prepare()
+        ctx = l.context()
+        if plain:
+            ctx.set_pair_pretest(0)
+            ctx.set_verify_mode(1)
+            for k, v in dict(L3D_RUN_TABLES=0, L3D_PROD_TRANSPOSE=0, L3D_KEPT_CAMS=int(rng.integers(0, 2)), L3D_AFF_SYM=0).items():
+                ctx.set_option(k, v)
+        else:
+            ctx.set_option("L3D_PROD_EARLY", int(rng.integers(1, 4)))
+        l.match_views()
+        lists = digest_lists({v["id"]: l.view_matches(v["id"]) for v in scene.views})
+        prod = _products_digest(l)
+        l.finish(False)
+        A, n_nodes = l.affinity()
+        outs.append((lists, prod, A.tobytes(), n_nodes, l.getResult(), int(l.stats()["kept"])))
+        l.close()
+    assert outs[0][5] > 0 or seed >= 13000, (seed, outs[0][5])       # (a drawn scene may keep little; the suite's own seeds keep thousands)
+    assert outs[0][0] == outs[1][0], "seed %d: kept lists" % seed
+    assert outs[0][1] == outs[1][1], "seed %d: products" % seed
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3], "seed %d: affinity list" % seed
+    assert_lines_equal(outs[0][4], outs[1][4], 0.0)
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33] + [11000 + i for i in range(int(os.environ.get("L3D_FUZZ_SEEDS", "0")))])
 def test_blocks_of_views_on_randomly_drawn_scenes(seed):
     """l3d_match_chain_blocks (the multi-GPU bench's first mode) on scenes, rank counts and warm-up lengths drawn per seed: whenever the ranks agree that the run was exact
