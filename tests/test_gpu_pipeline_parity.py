@@ -1159,6 +1159,8 @@ def test_fast_paths_equal_the_plain_paths_on_medium_scenes(seed):
                 ctx.set_option(k, v)
         else:
             ctx.set_option("L3D_PROD_EARLY", int(rng.integers(1, 4)))
+            if rng.integers(0, 2):          # a kept arena that is too small for the scene: it grows -- and moves, the transposed entries with it -- once or several times
+                ctx.set_chain_capacities(0, int(rng.choice([5000, 50000, 300000])))
         l.match_views()
         lists = digest_lists({v["id"]: l.view_matches(v["id"]) for v in scene.views})
         prod = _products_digest(l)
