@@ -57,14 +57,18 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--pairs", type=float, default=1e11)
     ap.add_argument("--seconds", type=float, default=1200.0)
+    ap.add_argument("--families", default="", help="comma-separated subset of the families (default: all eight in turn)")
+    ap.add_argument("--first-seed", type=int, default=1000)
     a = ap.parse_args()
     if not os.path.exists(DIAG):
         sys.exit("line3d_amd/libline3d_amd_diag.so is not built (make -C line3d_amd/csrc diag)")
     env = dict(os.environ, L3D_LIBRARY=DIAG, L3D_PAIR_STATS="1")
     families = ["hd", "vga", "uhd", "hd+short", "hd+long", "uhd+short", "vga+long", "adversarial"]
+    if a.families:
+        families = [f for f in a.families.split(",") if f in families]
     per = {f: dict(pairs=0, runs=0, against=0, to_exact_test_pct_max=0.0) for f in families}
     t0 = time.time()
-    seed, total, against = 1000, 0, 0
+    seed, total, against = a.first_seed, 0, 0
     first_offenders = []
     while total < a.pairs and time.time() - t0 < a.seconds:
         fam = families[seed % len(families)]
